@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py -- CG iterations/sec + SpMV GB/s against the HBM roofline on synthetic 3-D 7-point Poisson CSR.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+A "step" is ONE iteration of the reference's unpreconditioned CG (src/solver/cg.rs:141-285: SpMV + 2 inner
+products + 3 vector updates) on a matrix, right-hand side and iterate that are already resident in HBM.
+W warm-up iterations and exactly K timed iterations run inside one stepping session (tol = 0, so the device
+never stops early); the timed region is bracketed by barrier + device synchronize on both sides and the maximum
+over ranks is reported.  One JSON line on rank 0.
+
+N = 1: the workload of BASELINE.json configs[1] (256^3).  N > 1: the SAME global problem is row-partitioned in
+k-slabs over the ranks (strong scaling, north_star), halo planes over xGMI, inner products by RCCL all-gather.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 measured copy)
+
+
+def spmv_bytes(n, nnz):
+    """Algorithmic bytes of one CSR SpMV: 12 B per nnz (f64 value + i32 column), 4 B per row pointer,
+    x read once and y written once (16 B per row)."""
+    return 12 * nnz + 4 * (n + 1) + 16 * n
+
+
+def cpu_baseline(grid, seconds=15.0):
+    """The oracle's CG (the CPU restatement of the reference path) timed on the host cores on a bounded sample of
+    the same workload: as many CG iterations on the same grid as fit in ~`seconds`."""
+    import numpy as np
+    import kryst_amd as K
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0))
+    O.set_threads(cores)
+    T, V, F = K.reduce_spec()
+    rp, ci, va = K.host_stencil7(grid, "poisson")
+    a = O.Csr(grid ** 3, grid ** 3, rp, ci, va, check=False)
+    b = a.spmv(np.ones(a.nrows))
+    rs = O.Reduce.tiled(T, V, F)
+    t0 = time.perf_counter(); O.solve("cg", a, b, tol=0.0, max_iters=3, rs=rs); t3 = time.perf_counter() - t0
+    iters = int(max(5, min(400, seconds / max(t3 / 4.0, 1e-4))))     # 3 iterations + the initial residual pass
+    t0 = time.perf_counter()
+    res = O.solve("cg", a, b, tol=0.0, max_iters=iters, rs=rs)
+    dt = time.perf_counter() - t0
+    return {"value": res.iterations / dt, "unit": "cg_iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{res.iterations} oracle CG iterations on the same {grid}^3 Poisson system ({dt:.1f} s, "
+                      f"OpenMP rows/tiles over {cores} threads, device-order dot)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--grid", type=int, default=0, help="grid edge (default 256 on one GPU, 512 on several)")
+    ap.add_argument("--solver", default="cg", choices=["cg", "pcg"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    grid = args.grid or (256 if world == 1 else 512)
+
+    dist = None
+    if world > 1:
+        # torch.distributed (gloo) is plumbing only: ship the RCCL unique id and provide the host barrier / max
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import kryst_amd as K
+
+    if world > 1:
+        box = [K.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx = K.Context(local_rank, rank, world, box[0])
+    else:
+        ctx = K.Context(0)
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    a = K.CsrMatrix.stencil7(grid, "poisson", ctx=ctx)
+    nloc = a.nrows()
+    n = grid ** 3
+    nnz = 7 * n - 6 * grid * grid
+    ones = ctx.vec(nloc).fill(1.0)
+    b = a.spmv(ones)                      # b = A*1 (tests/preconditioner_integration.rs:25-31 convention)
+    x = ctx.vec(nloc)
+    pc = K.Jacobi().setup(a) if args.solver == "pcg" else None
+
+    sess = K.Session(args.solver, a, pc, b, x, tol=0.0, max_iters=args.warmup + args.steps)
+    sess.step(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    sess.step(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    stats = sess.end()
+    assert stats.iterations == args.warmup + args.steps, stats
+
+    # dominant kernel: the SpMV with the fused (p,Ap) partials, timed live with HIP events on its own stream
+    y = ctx.vec(nloc)
+    spmv_ms = a.bench_spmv(b, y, fused_dots=1, reps=50)
+    bytes_local = spmv_bytes(nloc, a.nnz)
+    achieved = bytes_local / (spmv_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "cg_iterations_per_sec", "value": args.steps / dt, "unit": "iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{'jacobi_pcg' if args.solver == 'pcg' else 'cg'}_poisson7_{grid}^3", "grid": grid,
+                   "rows": n, "nnz": nnz, "partition": f"{world} k-slab(s)", "rhs": "A*1", "x0": "0",
+                   "final_residual": stats.final_residual},
+        "roofline": {"bound": "hbm", "kernel": "spmv_kernel<1> (CSR SpMV + fused (p,Ap) partials)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "bytes_per_launch": bytes_local, "ms_per_launch": spmv_ms, "traffic": None},
+    }
+    tf = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    if os.path.exists(tf):
+        try:
+            tr = json.load(open(tf))
+            if tr.get("grid") == grid and world == 1:
+                out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(grid)
+        except Exception as e:                      # the oracle is only the reported baseline, never the product
+            out["cpu_baseline"] = {"value": None, "unit": "cg_iterations/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

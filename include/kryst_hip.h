@@ -1,0 +1,197 @@
+/*
+ * kryst_hip.h -- C ABI of libkryst_hip.so: the MI355X (gfx950) Krylov inner loop behind kryst's
+ * MatVec / Preconditioner / LinearSolver traits.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the kryst crate,
+ * tmathis720/kryst v0.5.3).  A Rust maintainer binds these with `extern "C"` (INTEGRATION.md shows the
+ * stub); tests and bench.py bind them with ctypes (kryst_amd/_ffi.py).
+ *
+ * Conventions
+ *   - every function returns an int32 status: 0 OK, 1..6 mirror `KError` (src/error.rs:6-19),
+ *     >= 100 are HIP / RCCL / argument errors; kryst_hip_last_error() gives the text.  Nothing unwinds
+ *     across the ABI.
+ *   - handles are opaque, created and destroyed by the library; host arrays are borrowed only for the
+ *     duration of a call; one host thread per context; contexts are independent.
+ *   - all arithmetic is IEEE fp64 with no FMA contraction; row sums run over ascending stored columns.
+ *   - inner products use ONE fixed association tree (kryst_reduce_spec): results are run-to-run and
+ *     launch-configuration independent; with nranks > 1 rank results are folded in rank order.
+ *   - there is no CPU fallback: without a GPU every compute call fails with KRYST_ERR_HIP.
+ */
+#ifndef KRYST_HIP_H
+#define KRYST_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: src/error.rs:6-19 ---- */
+enum {
+    KRYST_OK = 0,
+    KRYST_FACTOR_ERROR = 1,             /* KError::FactorError */
+    KRYST_SOLVE_ERROR = 2,              /* KError::SolveError */
+    KRYST_INDEFINITE_MATRIX = 3,        /* KError::IndefiniteMatrix            cg.rs:168-174, pcg.rs:162-172 */
+    KRYST_INDEFINITE_PRECONDITIONER = 4,/* KError::IndefinitePreconditioner    cg.rs:254-259, pcg.rs:208-213 */
+    KRYST_ZERO_PIVOT = 5,               /* KError::ZeroPivot(row) */
+    KRYST_UNSUPPORTED = 6,              /* KError::Unsupported */
+    KRYST_ERR_HIP = 100,                /* HIP runtime error / no device */
+    KRYST_ERR_RCCL = 101,               /* RCCL error / library not found */
+    KRYST_ERR_ARG = 102,                /* bad argument (length mismatch = the reference's assert_eq! panics) */
+    KRYST_ERR_CSR = 103                 /* CSR violates new_checked preconditions (sparse.rs:36-42) */
+};
+
+typedef struct kryst_ctx_s* kryst_ctx_t;
+typedef struct kryst_csr_s* kryst_csr_t;
+typedef struct kryst_vec_s* kryst_vec_t;
+typedef struct kryst_pc_s*  kryst_pc_t;
+
+const char* kryst_hip_last_error(void);
+int32_t     kryst_hip_abi_version(void);
+/* The fixed inner-product tree: tile = T*V elements; thread t folds its V elements, 64-lane xor butterfly,
+ * serial across the T/64 waves; tile partials folded by F threads (stride F), butterfly, serial across waves. */
+void        kryst_reduce_spec(int32_t* T, int32_t* V, int32_t* F);
+
+/* ---- context: one per GPU / per rank.  Replaces src/parallel (Comm trait, parallel/mod.rs:4-35) ---- */
+int32_t kryst_ctx_create(int32_t device_id, kryst_ctx_t* out);
+/* rank/nranks + 128-byte RCCL unique id (rank 0 makes it with kryst_comm_unique_id and ships it to the other
+ * ranks by any side channel).  Replaces MpiComm::new (src/parallel/mpi_comm.rs:49-55). */
+int32_t kryst_comm_unique_id(void* out128);
+int32_t kryst_ctx_create_dist(int32_t device_id, int32_t rank, int32_t nranks, const void* unique_id128,
+                              kryst_ctx_t* out);
+int32_t kryst_ctx_destroy(kryst_ctx_t ctx);
+int32_t kryst_ctx_synchronize(kryst_ctx_t ctx);                    /* hipStreamSynchronize on the ctx streams */
+int32_t kryst_ctx_rank(kryst_ctx_t ctx, int32_t* rank, int32_t* nranks);   /* Comm::rank / Comm::size */
+int32_t kryst_comm_barrier(kryst_ctx_t ctx);                       /* Comm::barrier, mpi_comm.rs:67 */
+int32_t kryst_comm_all_reduce(kryst_ctx_t ctx, double x, double* out);     /* Comm::all_reduce, mpi_comm.rs:116-121 */
+/* wall-clock of the device work enqueued between the two marks, in ms (hipEvent on the ctx compute stream) */
+int32_t kryst_ctx_timer_start(kryst_ctx_t ctx);
+int32_t kryst_ctx_timer_stop(kryst_ctx_t ctx, double* ms);
+
+/* ---- device vectors (the reference's V = Vec<f64>); in a distributed ctx n is the LOCAL length ---- */
+int32_t kryst_vec_create(kryst_ctx_t ctx, int64_t n, kryst_vec_t* out);
+int32_t kryst_vec_destroy(kryst_vec_t v);
+int32_t kryst_vec_len(kryst_vec_t v, int64_t* n);
+int32_t kryst_vec_upload(kryst_vec_t v, const double* host, int64_t n);
+int32_t kryst_vec_download(kryst_vec_t v, double* host, int64_t n);
+int32_t kryst_vec_fill(kryst_vec_t v, double value);
+int32_t kryst_vec_copy(kryst_vec_t dst, kryst_vec_t src);
+/* deterministic synthetic fill on device: v[i] = uniform[0,1) from splitmix64(seed, global index) */
+int32_t kryst_vec_fill_splitmix(kryst_vec_t v, uint64_t seed, int64_t global_offset);
+
+/* ---- CSR operator: CsrMatrix::from_csr (src/matrix/sparse.rs:28-46), usize = uint64 layout ---- */
+int32_t kryst_csr_create(kryst_ctx_t ctx, int64_t nrows, int64_t ncols, const uint64_t* row_ptr,
+                         const uint64_t* col_idx, const double* vals, kryst_csr_t* out);
+/* same with int32 column indices / int64 row pointers (what the device keeps; avoids 2x host memory) */
+int32_t kryst_csr_create_i32(kryst_ctx_t ctx, int64_t nrows, int64_t ncols, const int64_t* row_ptr,
+                             const int32_t* col_idx, const double* vals, kryst_csr_t* out);
+/* Row-partitioned operator: this rank owns global rows [row_lo,row_hi) (= row_offsets[rank..rank+1]);
+ * row_ptr is local (row_ptr[0] == 0), col_idx are GLOBAL columns.  Builds the halo exchange plan (one
+ * RCCL exchange of index lists).  The reference has no counterpart (mpi_comm.rs:133-143 is a TODO). */
+int32_t kryst_csr_create_dist(kryst_ctx_t ctx, int64_t n_global, const int64_t* row_offsets /*nranks+1*/,
+                              const int64_t* row_ptr, const int64_t* col_idx_global, const double* vals,
+                              kryst_csr_t* out);
+/* Synthetic 7-point stencil operator generated on the device: kind 0 Poisson, 1 anisotropic,
+ * 2 upwind convection-diffusion; grid N^3; in a distributed ctx each rank builds its k-slab. */
+int32_t kryst_csr_create_stencil7(kryst_ctx_t ctx, int32_t N, int32_t kind, kryst_csr_t* out);
+int32_t kryst_csr_destroy(kryst_csr_t a);
+int32_t kryst_csr_shape(kryst_csr_t a, int64_t* nrows_local, int64_t* ncols_global, int64_t* nnz_local);
+int32_t kryst_csr_download(kryst_csr_t a, int64_t* row_ptr, int32_t* col_idx_local, double* vals);
+
+/* MatVec::matvec (src/core/traits.rs:4-7) == SparseMatrix::spmv (sparse.rs:56-67): y <- A x, y overwritten */
+int32_t kryst_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y);
+/* operator-level drop-in on host slices (PCIe both ways; plumbing / Jacobi::setup-style callers only) */
+int32_t kryst_spmv_host(kryst_csr_t a, const double* x, int64_t nx, double* y, int64_t ny);
+
+/* measurement hook: `reps` back-to-back launches of the SpMV kernel (fused_dots = 0 plain, 1 = the CG kernel
+ * with the (x,Ax) partials, 2 = BiCGStab's) between two HIP events on the compute stream; average ms per launch */
+int32_t kryst_bench_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t fused_dots, int32_t reps, double* avg_ms);
+
+/* ---- BLAS-1: InnerProduct for () (src/core/wrappers.rs:90-127) and the solvers' pointwise loops ---- */
+int32_t kryst_dot(kryst_vec_t x, kryst_vec_t y, double* out);       /* wrappers.rs:90-108 */
+int32_t kryst_norm(kryst_vec_t x, double* out);                     /* wrappers.rs:110-127 */
+int32_t kryst_axpy(double alpha, kryst_vec_t x, kryst_vec_t y);     /* y[i] = y[i] + alpha*x[i]   cg.rs:207-209 */
+int32_t kryst_aypx(double beta, kryst_vec_t x, kryst_vec_t y);      /* y[i] = x[i] + beta*y[i]    cg.rs:274-276 */
+int32_t kryst_sub(kryst_vec_t a, kryst_vec_t b, kryst_vec_t out);   /* out[i] = a[i] - b[i]       cg.rs:123 */
+
+/* ---- preconditioners: Preconditioner<M,V>::{setup,apply} (src/preconditioner/mod.rs:8-13) ---- */
+enum { KRYST_ILU_KRYST_COMPAT = 0,   /* Ilu0 exactly as written, src/preconditioner/ilu.rs:59-122 */
+       KRYST_ILU_ILUP0 = 1,          /* Ilup::new(0) exactly as written, src/preconditioner/ilup.rs:77-167 */
+       KRYST_ILU_TRUE_ILU0 = 2 };    /* extension: textbook ILU(0) on A's pattern */
+int32_t kryst_pc_identity(kryst_ctx_t ctx, kryst_pc_t* out);                        /* test IdentityPC, pcg.rs:245-251 */
+int32_t kryst_pc_jacobi(kryst_csr_t a, kryst_pc_t* out);                            /* Jacobi::setup jacobi.rs:53-73 */
+int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out);                /* Ilu0::setup / Ilup::setup */
+int32_t kryst_pc_chebyshev_stub(kryst_ctx_t ctx, int32_t degree, kryst_pc_t* out);  /* Chebyshev trait object: apply -> SolveError, chebyshev.rs:68-70 */
+int32_t kryst_pc_chebyshev(kryst_csr_t a, double alpha, double beta, int32_t degree, kryst_pc_t* out); /* extension: apply == apply_chebyshev */
+int32_t kryst_pc_apply(kryst_pc_t pc, kryst_vec_t r, kryst_vec_t z);                /* Preconditioner::apply */
+int32_t kryst_pc_destroy(kryst_pc_t pc);
+/* apply_chebyshev(a, r, z, alpha, beta, m), src/preconditioner/chebyshev.rs:83-140 */
+int32_t kryst_apply_chebyshev(kryst_csr_t a, kryst_vec_t r, kryst_vec_t z, double alpha, double beta, int64_t m);
+
+/* ---- solvers: LinearSolver<M,V>::solve (src/solver/mod.rs:30-52) ---- */
+typedef struct {
+    double  tol;                 /* Convergence::tol      src/utils/convergence.rs:4-7 */
+    int64_t max_iters;           /* Convergence::max_iters */
+    int32_t restart;             /* GmresSolver::restart  gmres.rs:40 */
+    int32_t precond_side;        /* gmres.rs:28-32 Preconditioning: 0 None, 1 Left (default), 2 Right */
+    int32_t norm_type;           /* CgNormType cg.rs:35: 0 Preconditioned, 1 Unpreconditioned (default), 2 Natural, 3 None */
+    int32_t single_reduction;    /* with_single_reduction cg.rs:69 (same fold on the device; accepted, no effect) */
+    int32_t has_radius;  double radius;        /* with_radius     cg.rs:74  (-> KRYST_UNSUPPORTED when set) */
+    int32_t has_obj_target; double obj_target; /* with_obj_target cg.rs:79  (-> KRYST_UNSUPPORTED when set) */
+    int32_t check_every;         /* host polls the device convergence flag every this many iterations (0 = default);
+                                    the device stops at the exact reference iteration regardless */
+} kryst_params_t;
+
+typedef struct {                 /* SolveStats src/utils/convergence.rs:10-14 */
+    int64_t iterations;
+    double  final_residual;
+    int32_t converged;
+} kryst_stats_t;
+
+typedef void (*kryst_monitor_fn)(int64_t iteration, double residual, void* user);   /* with_monitor cg.rs:84 */
+
+/* Residual history: hist[0..min(*hist_len,hist_cap)) receives what CgSolver/PcgSolver push to
+ * residual_history (cg.rs:140,263; pcg.rs:146,199); GMRES / BiCGStab record |g[j+1]| / ||r|| per iteration
+ * (an addition: the reference keeps none).  monitor (if non-NULL) is called on the calling thread, in order,
+ * after the solve has finished on the device. */
+#define KRYST_SOLVE_ARGS kryst_csr_t a, kryst_pc_t pc /* NULL = None */, \
+        const kryst_params_t* params, kryst_stats_t* stats, \
+        double* hist, int64_t hist_cap, int64_t* hist_len, kryst_monitor_fn monitor, void* user
+
+/* b, x on the host (x in/out = initial guess / solution), exactly the reference call shape */
+int32_t kryst_cg_solve      (const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS);  /* CgSolver::solve       cg.rs:114-288 */
+int32_t kryst_pcg_solve     (const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS);  /* PcgSolver::solve      pcg.rs:114-222 */
+int32_t kryst_gmres_solve   (const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS);  /* GmresSolver::solve    gmres.rs:216-402 */
+int32_t kryst_bicgstab_solve(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS);  /* BiCgStabSolver::solve bicgstab.rs:69-293 */
+/* same with b, x resident in HBM (the performant drop-in; bench.py times these) */
+int32_t kryst_cg_solve_dev      (kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS);
+int32_t kryst_pcg_solve_dev     (kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS);
+int32_t kryst_gmres_solve_dev   (kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS);
+int32_t kryst_bicgstab_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS);
+/* extension: right-preconditioned BiCGStab (the reference ignores pc, bicgstab.rs:70) */
+int32_t kryst_bicgstab_rpc_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS);
+
+/* ---- stepping session: the same solver split into begin / step / end, so that a caller (bench.py) can
+ * enqueue and time exactly K iterations.  method: 0 CgSolver, 1 PcgSolver, 2 BiCgStabSolver.
+ * step() enqueues up to k further iterations (never past max_iters) without synchronising the host. ---- */
+typedef struct kryst_session_s* kryst_session_t;
+int32_t kryst_session_begin(int32_t method, kryst_vec_t b, kryst_vec_t x, kryst_csr_t a, kryst_pc_t pc,
+                            const kryst_params_t* params, kryst_session_t* out);
+int32_t kryst_session_step(kryst_session_t s, int64_t k);
+int32_t kryst_session_end(kryst_session_t s, kryst_stats_t* stats, double* hist, int64_t hist_cap, int64_t* hist_len);
+
+/* ---- host-only helpers (no GPU needed) ---- */
+/* 7-point stencil rows of planes [k_lo,k_hi) with global columns; returns nnz; pass NULL arrays to size */
+int64_t kryst_host_stencil7(int32_t N, int32_t kind, int32_t k_lo, int32_t k_hi,
+                            int64_t* row_ptr, int64_t* col_idx, double* vals);
+/* contiguous row blocks, boundaries aligned to `align` rows (k-slabs: align = N*N) */
+int32_t kryst_host_partition_rows(int64_t n, int32_t nranks, int64_t align, int64_t* row_offsets /*nranks+1*/);
+/* halo plan of one rank: which global columns it must receive from each owner.
+ * recv_counts[nranks]; recv_cols[sum] ascending per owner.  Returns total count (call with NULL to size). */
+int64_t kryst_host_halo_recv_plan(int32_t rank, int32_t nranks, const int64_t* row_offsets,
+                                  const int64_t* row_ptr, const int64_t* col_idx_global,
+                                  int64_t* recv_counts, int64_t* recv_cols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,604 @@
+"""kryst_amd -- host-side mirror of kryst's operator / preconditioner / solver interface for the MI355X path.
+
+The classes keep the reference's names, constructor arguments, builder methods, public fields and error
+behaviour (paths relative to the kryst crate):
+
+    CsrMatrix.from_csr(nrows, ncols, row_ptr, col_idx, values)      src/matrix/sparse.rs:28-46
+    CsrMatrix.spmv(x, y) / matvec(x, y)                             src/matrix/sparse.rs:56-67, core/traits.rs:4-7
+    dot(x, y), norm(x)                                              src/core/wrappers.rs:90-127
+    Jacobi / Ilu0 / Ilup / Chebyshev  .setup(a) .apply(r, z)        src/preconditioner/*.rs
+    apply_chebyshev(a, r, z, alpha, beta, m)                        src/preconditioner/chebyshev.rs:83-140
+    CgSolver / PcgSolver / GmresSolver / BiCgStabSolver .solve(a, pc, b, x) -> SolveStats   src/solver/*.rs
+    Convergence, SolveStats, KError, CgNormType, Preconditioning    src/utils/convergence.rs, src/error.rs
+
+Everything executes in libkryst_hip.so (hand-written HIP for gfx950) through the C ABI of include/kryst_hip.h.
+There is no CPU fallback and no torch dependency.
+"""
+import ctypes as C
+import enum
+import numpy as np
+
+from . import _ffi
+from ._ffi import KError, lib, check
+
+__all__ = ["Context", "DeviceVec", "CsrMatrix", "dot", "norm", "Jacobi", "Ilu0", "Ilup", "TrueIlu0", "Chebyshev",
+           "ChebyshevPc", "IdentityPc", "apply_chebyshev", "Convergence", "SolveStats", "CgNormType",
+           "Preconditioning", "CgSolver", "PcgSolver", "GmresSolver", "BiCgStabSolver", "BiCgStabRightPcSolver", "Session", "KError", "reduce_spec",
+           "host_stencil7", "partition_rows", "halo_recv_plan"]
+
+
+def _dp(a):
+    return a.ctypes.data_as(_ffi.c_dp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def reduce_spec():
+    """(T, V, F) of the library's fixed inner-product tree (kryst_reduce_spec)."""
+    t, v, f = C.c_int32(), C.c_int32(), C.c_int32()
+    lib().kryst_reduce_spec(C.byref(t), C.byref(v), C.byref(f))
+    return t.value, v.value, f.value
+
+
+class Context:
+    """One GPU (one rank).  Replaces the Comm objects of src/parallel (RayonComm / MpiComm)."""
+
+    _default = None
+
+    def __init__(self, device=0, rank=0, nranks=1, unique_id=None):
+        self.h = _ffi.Handle()
+        if nranks == 1 and unique_id is None:
+            check(lib().kryst_ctx_create(device, C.byref(self.h)))
+        else:
+            buf = C.create_string_buffer(bytes(unique_id), 128)
+            check(lib().kryst_ctx_create_dist(device, rank, nranks, buf, C.byref(self.h)))
+        self.rank, self.nranks, self.device = rank, nranks, device
+
+    @staticmethod
+    def default():
+        if Context._default is None:
+            Context._default = Context(0)
+        return Context._default
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().kryst_comm_unique_id(buf))
+        return buf.raw
+
+    def size(self):
+        return self.nranks
+
+    def barrier(self):
+        check(lib().kryst_comm_barrier(self.h))
+
+    def all_reduce(self, x):
+        out = C.c_double()
+        check(lib().kryst_comm_all_reduce(self.h, float(x), C.byref(out)))
+        return out.value
+
+    def synchronize(self):
+        check(lib().kryst_ctx_synchronize(self.h))
+
+    def timer_start(self):
+        check(lib().kryst_ctx_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_double()
+        check(lib().kryst_ctx_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def vec(self, n_or_array):
+        return DeviceVec(self, n_or_array)
+
+    def close(self):
+        if self.h:
+            lib().kryst_ctx_destroy(self.h)
+            self.h = None
+
+
+class DeviceVec:
+    """A Vec<f64> resident in HBM."""
+
+    def __init__(self, ctx, n_or_array):
+        self.ctx = ctx
+        self.h = _ffi.Handle()
+        if np.isscalar(n_or_array):
+            self.n = int(n_or_array)
+            check(lib().kryst_vec_create(ctx.h, self.n, C.byref(self.h)))
+        else:
+            a = _f64(n_or_array)
+            self.n = len(a)
+            check(lib().kryst_vec_create(ctx.h, self.n, C.byref(self.h)))
+            self.upload(a)
+
+    def __len__(self):
+        return self.n
+
+    def upload(self, a):
+        a = _f64(a)
+        check(lib().kryst_vec_upload(self.h, _dp(a), len(a)))
+        return self
+
+    def to_host(self):
+        out = np.empty(self.n)
+        check(lib().kryst_vec_download(self.h, _dp(out), self.n))
+        return out
+
+    def fill(self, v):
+        check(lib().kryst_vec_fill(self.h, float(v)))
+        return self
+
+    def fill_splitmix(self, seed, global_offset=0):
+        check(lib().kryst_vec_fill_splitmix(self.h, seed, global_offset))
+        return self
+
+    def copy_from(self, other):
+        check(lib().kryst_vec_copy(self.h, other.h))
+        return self
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                lib().kryst_vec_destroy(self.h)
+        except Exception:
+            pass
+
+
+def dot(x, y):
+    """InnerProduct::dot (wrappers.rs:90-108) on device vectors."""
+    out = C.c_double()
+    check(lib().kryst_dot(x.h, y.h, C.byref(out)))
+    return out.value
+
+
+def norm(x):
+    """InnerProduct::norm (wrappers.rs:110-127)."""
+    out = C.c_double()
+    check(lib().kryst_norm(x.h, C.byref(out)))
+    return out.value
+
+
+def axpy(alpha, x, y):
+    check(lib().kryst_axpy(float(alpha), x.h, y.h))
+
+
+def aypx(beta, x, y):
+    check(lib().kryst_aypx(float(beta), x.h, y.h))
+
+
+class CsrMatrix:
+    """CsrMatrix<f64> (src/matrix/sparse.rs:22-46) living on the GPU; implements SparseMatrix::spmv and MatVec."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+        nr, nc, nz = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib().kryst_csr_shape(self.h, C.byref(nr), C.byref(nc), C.byref(nz)))
+        self._nrows, self._ncols, self.nnz = nr.value, nc.value, nz.value
+
+    @staticmethod
+    def from_csr(nrows, ncols, row_ptr, col_idx, values, ctx=None):
+        """from_csr(nrows, ncols, row_ptr: Vec<usize>, col_idx: Vec<usize>, values)  sparse.rs:28-46.
+        Violating new_checked's preconditions raises KError (the reference panics)."""
+        ctx = ctx or Context.default()
+        rp = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        ci = np.ascontiguousarray(col_idx, dtype=np.uint64)
+        va = _f64(values)
+        if len(rp) != nrows + 1 or len(ci) != len(va) or (len(rp) and int(rp[-1]) != len(va)):
+            raise KError(102, "from_csr: inconsistent array lengths")
+        h = _ffi.Handle()
+        check(lib().kryst_csr_create(ctx.h, nrows, ncols, rp.ctypes.data_as(_ffi.c_u64p), ci.ctypes.data_as(_ffi.c_u64p),
+                                     _dp(va), C.byref(h)))
+        return CsrMatrix(ctx, h)
+
+    @staticmethod
+    def from_csr_i32(nrows, ncols, row_ptr, col_idx, values, ctx=None):
+        ctx = ctx or Context.default()
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        ci = np.ascontiguousarray(col_idx, dtype=np.int32)
+        va = _f64(values)
+        h = _ffi.Handle()
+        check(lib().kryst_csr_create_i32(ctx.h, nrows, ncols, rp.ctypes.data_as(_ffi.c_i64p),
+                                         ci.ctypes.data_as(_ffi.c_i32p), _dp(va), C.byref(h)))
+        return CsrMatrix(ctx, h)
+
+    @staticmethod
+    def from_csr_dist(ctx, n_global, row_offsets, row_ptr, col_idx_global, values):
+        """Row block [row_offsets[rank], row_offsets[rank+1]) of a row-partitioned operator (global columns)."""
+        ro = np.ascontiguousarray(row_offsets, dtype=np.int64)
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        ci = np.ascontiguousarray(col_idx_global, dtype=np.int64)
+        va = _f64(values)
+        h = _ffi.Handle()
+        check(lib().kryst_csr_create_dist(ctx.h, n_global, ro.ctypes.data_as(_ffi.c_i64p), rp.ctypes.data_as(_ffi.c_i64p),
+                                          ci.ctypes.data_as(_ffi.c_i64p), _dp(va), C.byref(h)))
+        return CsrMatrix(ctx, h)
+
+    @staticmethod
+    def stencil7(N, kind="poisson", ctx=None):
+        """Synthetic 7-point operator on an N^3 grid; each rank of a distributed ctx gets its k-slab."""
+        ctx = ctx or Context.default()
+        h = _ffi.Handle()
+        check(lib().kryst_csr_create_stencil7(ctx.h, N, {"poisson": 0, "aniso": 1, "convdiff": 2}[kind], C.byref(h)))
+        return CsrMatrix(ctx, h)
+
+    def nrows(self):
+        return self._nrows
+
+    def ncols(self):
+        return self._ncols
+
+    def spmv(self, x, y=None):
+        """SparseMatrix::spmv(&self, x, y): y <- A x.  Device vectors stay on the device; host arrays round-trip
+        over PCIe (operator-level drop-in, plumbing only)."""
+        if isinstance(x, DeviceVec):
+            if y is None:
+                y = DeviceVec(self.ctx, self._nrows)
+            check(lib().kryst_spmv(self.h, x.h, y.h))
+            return y
+        xa = _f64(x)
+        out = np.empty(self._nrows) if y is None else y
+        if len(out) != self._nrows:
+            raise KError(102, "spmv: y.len() != nrows")
+        tmp = out if (out.dtype == np.float64 and out.flags.c_contiguous) else np.empty(self._nrows)
+        check(lib().kryst_spmv_host(self.h, _dp(xa), len(xa), _dp(tmp), len(tmp)))
+        if tmp is not out:
+            out[:] = tmp
+        return out
+
+    def bench_spmv(self, x, y, fused_dots=1, reps=50):
+        """Average milliseconds per launch of the SpMV kernel (HIP events on the compute stream)."""
+        ms = C.c_double()
+        check(lib().kryst_bench_spmv(self.h, x.h, y.h, fused_dots, reps, C.byref(ms)))
+        return ms.value
+
+    matvec = spmv                                # MatVec::matvec (core/traits.rs:4-7)
+    spmv_parallel = spmv                         # sparse.rs:103-114 (same arithmetic)
+
+    def download(self):
+        rp = np.empty(self._nrows + 1, dtype=np.int64)
+        ci = np.empty(self.nnz, dtype=np.int32)
+        va = np.empty(self.nnz)
+        check(lib().kryst_csr_download(self.h, rp.ctypes.data_as(_ffi.c_i64p), ci.ctypes.data_as(_ffi.c_i32p), _dp(va)))
+        return rp, ci, va
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                lib().kryst_csr_destroy(self.h)
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------- preconditioners
+class _Pc:
+    """Preconditioner<M, V> (src/preconditioner/mod.rs:8-13): setup(&mut self, a), apply(&self, r, z)."""
+
+    def __init__(self):
+        self.h, self.ctx = None, None
+
+    def _set(self, ctx, handle):
+        self._free()
+        self.ctx, self.h = ctx, handle
+
+    def apply(self, r, z=None):
+        if self.h is None:
+            raise KError(2, "preconditioner used before setup")
+        if isinstance(r, DeviceVec):
+            z = z if z is not None else DeviceVec(self.ctx, len(r))
+            check(lib().kryst_pc_apply(self.h, r.h, z.h))
+            return z
+        rv = DeviceVec(self.ctx, r)
+        zv = DeviceVec(self.ctx, len(rv))
+        check(lib().kryst_pc_apply(self.h, rv.h, zv.h))
+        out = zv.to_host()
+        if z is not None:
+            z[:] = out
+            return z
+        return out
+
+    def _free(self):
+        try:
+            if self.h and self.ctx and self.ctx.h:
+                lib().kryst_pc_destroy(self.h)
+        except Exception:
+            pass
+        self.h = None
+
+    def __del__(self):
+        self._free()
+
+
+class Jacobi(_Pc):
+    """Jacobi::new(); setup extracts 1/diag (src/preconditioner/jacobi.rs:26-95)."""
+
+    def setup(self, a):
+        h = _ffi.Handle()
+        check(lib().kryst_pc_jacobi(a.h, C.byref(h)))
+        self._set(a.ctx, h)
+        self._a = a
+        return self
+
+
+class _IluBase(_Pc):
+    MODE = 0
+
+    def setup(self, a):
+        h = _ffi.Handle()
+        check(lib().kryst_pc_ilu0(a.h, self.MODE, C.byref(h)))
+        self._set(a.ctx, h)
+        self._a = a
+        return self
+
+
+class Ilu0(_IluBase):
+    """Ilu0 exactly as written in src/preconditioner/ilu.rs:59-122 (L = I + tril(A,-1)D^-1, U = I + triu(A,1))."""
+    MODE = 0
+
+
+class Ilup(_IluBase):
+    """Ilup::new(0) exactly as written in src/preconditioner/ilup.rs:77-167 (only fill = 0 is built)."""
+    MODE = 1
+
+    def __init__(self, fill=0):
+        super().__init__()
+        if fill != 0:
+            raise KError(6, "only fill level 0 is built on the device")
+        self.fill = fill
+
+
+class TrueIlu0(_IluBase):
+    """Extension: textbook ILU(0) on A's pattern (not in the reference)."""
+    MODE = 2
+
+
+class Chebyshev(_Pc):
+    """Chebyshev::new(degree, lambda_min, lambda_max); the trait apply is a stub that returns Err
+    (src/preconditioner/chebyshev.rs:35-70) -- use apply_chebyshev."""
+
+    def __init__(self, degree, lambda_min=None, lambda_max=None):
+        super().__init__()
+        self.degree, self.lambda_min, self.lambda_max = degree, lambda_min, lambda_max
+
+    def setup(self, a):
+        h = _ffi.Handle()
+        check(lib().kryst_pc_chebyshev_stub(a.ctx.h, self.degree, C.byref(h)))
+        self._set(a.ctx, h)
+        return self
+
+
+class ChebyshevPc(_Pc):
+    """Extension: a Preconditioner whose apply is apply_chebyshev(a, r, z, alpha, beta, degree)."""
+
+    def __init__(self, degree, alpha, beta):
+        super().__init__()
+        self.degree, self.alpha, self.beta = degree, alpha, beta
+
+    def setup(self, a):
+        h = _ffi.Handle()
+        check(lib().kryst_pc_chebyshev(a.h, self.alpha, self.beta, self.degree, C.byref(h)))
+        self._set(a.ctx, h)
+        self._a = a
+        return self
+
+
+class IdentityPc(_Pc):
+    """The reference tests' IdentityPC (src/solver/pcg.rs:245-251)."""
+
+    def setup(self, a):
+        h = _ffi.Handle()
+        check(lib().kryst_pc_identity(a.ctx.h, C.byref(h)))
+        self._set(a.ctx, h)
+        return self
+
+
+def apply_chebyshev(a, r, z, alpha, beta, m):
+    """apply_chebyshev(a, r, z, alpha, beta, m)  src/preconditioner/chebyshev.rs:83-140."""
+    if isinstance(r, DeviceVec):
+        check(lib().kryst_apply_chebyshev(a.h, r.h, z.h, alpha, beta, m))
+        return z
+    rv = DeviceVec(a.ctx, r)
+    zv = DeviceVec(a.ctx, len(rv))
+    check(lib().kryst_apply_chebyshev(a.h, rv.h, zv.h, alpha, beta, m))
+    z[:] = zv.to_host()
+    return z
+
+
+# ----------------------------------------------------------------------------- solvers
+class Convergence:
+    """Convergence { tol, max_iters }  src/utils/convergence.rs:4-7."""
+
+    def __init__(self, tol, max_iters):
+        self.tol, self.max_iters = tol, max_iters
+
+
+class SolveStats:
+    """SolveStats { iterations, final_residual, converged }  src/utils/convergence.rs:10-14."""
+
+    def __init__(self, iterations, final_residual, converged):
+        self.iterations, self.final_residual, self.converged = iterations, final_residual, converged
+
+    def __repr__(self):
+        return (f"SolveStats {{ iterations: {self.iterations}, final_residual: {self.final_residual:e}, "
+                f"converged: {self.converged} }}")
+
+
+class CgNormType(enum.IntEnum):                  # src/solver/cg.rs:35
+    Preconditioned = 0
+    Unpreconditioned = 1
+    Natural = 2
+    NoNorm = 3
+
+
+class Preconditioning(enum.IntEnum):             # src/solver/gmres.rs:28-32
+    NoPc = 0
+    Left = 1
+    Right = 2
+
+
+class _Solver:
+    _HOST = _DEV = None
+
+    def __init__(self, tol, max_iters):
+        self.conv = Convergence(tol, max_iters)
+        self.norm_type = CgNormType.Unpreconditioned
+        self.single_reduction = False
+        self.radius = None
+        self.obj_target = None
+        self.monitor = None
+        self.residual_history = []
+        self.restart = 0
+        self.preconditioning = Preconditioning.Left
+        self.check_every = 0
+
+    def _params(self):
+        return _ffi.Params(self.conv.tol, self.conv.max_iters, self.restart, int(self.preconditioning),
+                           int(self.norm_type), int(self.single_reduction),
+                           int(self.radius is not None), self.radius or 0.0,
+                           int(self.obj_target is not None), self.obj_target or 0.0, self.check_every)
+
+    def solve(self, a, pc, b, x):
+        """LinearSolver::solve(&mut self, a, pc: Option<&dyn Preconditioner>, b, x) -> Result<SolveStats, KError>
+        (src/solver/mod.rs:43-49).  x is in/out.  Host arrays are uploaded / downloaded around the device solve;
+        DeviceVec arguments stay in HBM."""
+        prm = self._params()
+        st = _ffi.Stats()
+        cap = self.conv.max_iters + max(self.restart, 1) + 8
+        hist = np.zeros(cap)
+        hlen = C.c_int64(0)
+        cb = _ffi.MONITOR(lambda it, res, _u: self.monitor(it, res)) if self.monitor else _ffi.MONITOR()
+        pch = pc.h if pc is not None else None
+        if pc is not None and pch is None:
+            raise KError(2, "preconditioner used before setup")
+        tail = (a.h, pch, C.byref(prm), C.byref(st), _dp(hist), cap, C.byref(hlen), cb, None)
+        if isinstance(b, DeviceVec):
+            rc = getattr(lib(), self._DEV)(b.h, x.h, *tail)
+        else:
+            bb = _f64(b)
+            if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags.c_contiguous):
+                raise KError(102, "x must be a contiguous float64 numpy array (it is written in place)")
+            if len(bb) != len(x):
+                raise KError(102, "b and x differ in length")
+            rc = getattr(lib(), self._HOST)(_dp(bb), _dp(x), len(bb), *tail)
+        self.residual_history.extend(hist[:min(hlen.value, cap)].tolist())
+        stats = SolveStats(st.iterations, st.final_residual, bool(st.converged))
+        check(rc, stats)
+        return stats
+
+    def clear_history(self):
+        self.residual_history.clear()
+
+    # builder methods (cg.rs:64-88)
+    def with_norm(self, norm_type):
+        self.norm_type = norm_type
+        return self
+
+    def with_single_reduction(self, flag):
+        self.single_reduction = flag
+        return self
+
+    def with_radius(self, radius):
+        self.radius = radius
+        return self
+
+    def with_obj_target(self, obj):
+        self.obj_target = obj
+        return self
+
+    def with_monitor(self, f):
+        self.monitor = f
+        return self
+
+
+class CgSolver(_Solver):
+    """CgSolver::new(tol, max_iters)  src/solver/cg.rs:40-93,114-288 (pc is ignored, cg.rs:115)."""
+    _HOST, _DEV = "kryst_cg_solve", "kryst_cg_solve_dev"
+
+
+class PcgSolver(_Solver):
+    """PcgSolver::new(tol, max_iters)  src/solver/pcg.rs:31-91,114-222."""
+    _HOST, _DEV = "kryst_pcg_solve", "kryst_pcg_solve_dev"
+
+
+class GmresSolver(_Solver):
+    """GmresSolver::new(restart, tol, max_iters)  src/solver/gmres.rs:38-60,216-402."""
+    _HOST, _DEV = "kryst_gmres_solve", "kryst_gmres_solve_dev"
+
+    def __init__(self, restart, tol, max_iters):
+        super().__init__(tol, max_iters)
+        self.restart = restart
+
+    def with_preconditioning(self, mode):
+        self.preconditioning = mode
+        return self
+
+
+class BiCgStabSolver(_Solver):
+    """BiCgStabSolver::new(tol, max_iters)  src/solver/bicgstab.rs:36-48,69-293 (pc ignored, absolute tolerance)."""
+    _HOST, _DEV = "kryst_bicgstab_solve", "kryst_bicgstab_solve_dev"
+
+
+class BiCgStabRightPcSolver(_Solver):
+    """Extension: right-preconditioned BiCGStab (device vectors only)."""
+    _HOST, _DEV = None, "kryst_bicgstab_rpc_solve_dev"
+
+
+class Session:
+    """Stepping form of CgSolver / PcgSolver / BiCgStabSolver on device vectors: begin, step(k) (enqueue k
+    iterations without synchronising), end() -> SolveStats.  bench.py uses it to time exactly K iterations."""
+    METHODS = {"cg": 0, "pcg": 1, "bicgstab": 2}
+
+    def __init__(self, method, a, pc, b, x, tol, max_iters, norm_type=CgNormType.Unpreconditioned):
+        self.a, self.pc, self.b, self.x = a, pc, b, x
+        self.max_iters = max_iters
+        prm = _ffi.Params(tol, max_iters, 0, 1, int(norm_type), 0, 0, 0.0, 0, 0.0, 0)
+        self.h = _ffi.Handle()
+        check(lib().kryst_session_begin(self.METHODS[method], b.h, x.h, a.h, pc.h if pc is not None else None,
+                                        C.byref(prm), C.byref(self.h)))
+
+    def step(self, k):
+        check(lib().kryst_session_step(self.h, k))
+
+    def end(self):
+        st = _ffi.Stats()
+        cap = self.max_iters + 8
+        hist = np.zeros(cap)
+        hlen = C.c_int64(0)
+        rc = lib().kryst_session_end(self.h, C.byref(st), _dp(hist), cap, C.byref(hlen))
+        self.h = None
+        self.residual_history = hist[:min(hlen.value, cap)].tolist()
+        stats = SolveStats(st.iterations, st.final_residual, bool(st.converged))
+        check(rc, stats)
+        return stats
+
+
+# ----------------------------------------------------------------------------- host-only helpers
+def host_stencil7(N, kind="poisson", k_lo=0, k_hi=None):
+    k_hi = N if k_hi is None else k_hi
+    kk = {"poisson": 0, "aniso": 1, "convdiff": 2}[kind]
+    nnz = lib().kryst_host_stencil7(N, kk, k_lo, k_hi, None, None, None)
+    if nnz < 0:
+        raise KError(102, "host_stencil7")
+    nloc = (k_hi - k_lo) * N * N
+    rp = np.empty(nloc + 1, dtype=np.int64); ci = np.empty(nnz, dtype=np.int64); va = np.empty(nnz)
+    lib().kryst_host_stencil7(N, kk, k_lo, k_hi, rp.ctypes.data_as(_ffi.c_i64p), ci.ctypes.data_as(_ffi.c_i64p), _dp(va))
+    return rp, ci, va
+
+
+def partition_rows(n, nranks, align=1):
+    out = np.empty(nranks + 1, dtype=np.int64)
+    check(lib().kryst_host_partition_rows(n, nranks, align, out.ctypes.data_as(_ffi.c_i64p)))
+    return out
+
+
+def halo_recv_plan(rank, nranks, row_offsets, row_ptr, col_idx_global):
+    ro = np.ascontiguousarray(row_offsets, dtype=np.int64)
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    ci = np.ascontiguousarray(col_idx_global, dtype=np.int64)
+    args = (rank, nranks, ro.ctypes.data_as(_ffi.c_i64p), rp.ctypes.data_as(_ffi.c_i64p), ci.ctypes.data_as(_ffi.c_i64p))
+    total = lib().kryst_host_halo_recv_plan(*args, None, None)
+    counts = np.zeros(nranks, dtype=np.int64); cols = np.zeros(max(total, 1), dtype=np.int64)
+    lib().kryst_host_halo_recv_plan(*args, counts.ctypes.data_as(_ffi.c_i64p), cols.ctypes.data_as(_ffi.c_i64p))
+    return counts, cols[:total]

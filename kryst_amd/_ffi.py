@@ -1,0 +1,127 @@
+"""ctypes binding of libkryst_hip.so (include/kryst_hip.h).  No torch, no CPU fallback: if the library is
+missing or there is no GPU, calls fail loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkryst_hip.so")
+
+OK = 0
+ERR_NAMES = {1: "FactorError", 2: "SolveError", 3: "IndefiniteMatrix", 4: "IndefinitePreconditioner",
+             5: "ZeroPivot", 6: "Unsupported", 100: "HipError", 101: "RcclError", 102: "ArgumentError",
+             103: "CsrError"}
+
+c_dp = C.POINTER(C.c_double)
+c_i64p = C.POINTER(C.c_int64)
+c_u64p = C.POINTER(C.c_uint64)
+c_i32p = C.POINTER(C.c_int32)
+Handle = C.c_void_p
+MONITOR = C.CFUNCTYPE(None, C.c_int64, C.c_double, C.c_void_p)
+
+
+class Params(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iters", C.c_int64), ("restart", C.c_int32),
+                ("precond_side", C.c_int32), ("norm_type", C.c_int32), ("single_reduction", C.c_int32),
+                ("has_radius", C.c_int32), ("radius", C.c_double),
+                ("has_obj_target", C.c_int32), ("obj_target", C.c_double), ("check_every", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iterations", C.c_int64), ("final_residual", C.c_double), ("converged", C.c_int32)]
+
+
+_SOLVE_TAIL = [Handle, Handle, C.POINTER(Params), C.POINTER(Stats), c_dp, C.c_int64, c_i64p, MONITOR, C.c_void_p]
+
+# name -> (restype, argtypes): every symbol include/kryst_hip.h declares
+SIGNATURES = {
+    "kryst_hip_last_error": (C.c_char_p, []),
+    "kryst_hip_abi_version": (C.c_int32, []),
+    "kryst_reduce_spec": (None, [c_i32p, c_i32p, c_i32p]),
+    "kryst_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(Handle)]),
+    "kryst_comm_unique_id": (C.c_int32, [C.c_void_p]),
+    "kryst_ctx_create_dist": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(Handle)]),
+    "kryst_ctx_destroy": (C.c_int32, [Handle]),
+    "kryst_ctx_synchronize": (C.c_int32, [Handle]),
+    "kryst_ctx_rank": (C.c_int32, [Handle, c_i32p, c_i32p]),
+    "kryst_comm_barrier": (C.c_int32, [Handle]),
+    "kryst_comm_all_reduce": (C.c_int32, [Handle, C.c_double, c_dp]),
+    "kryst_ctx_timer_start": (C.c_int32, [Handle]),
+    "kryst_ctx_timer_stop": (C.c_int32, [Handle, c_dp]),
+    "kryst_vec_create": (C.c_int32, [Handle, C.c_int64, C.POINTER(Handle)]),
+    "kryst_vec_destroy": (C.c_int32, [Handle]),
+    "kryst_vec_len": (C.c_int32, [Handle, c_i64p]),
+    "kryst_vec_upload": (C.c_int32, [Handle, c_dp, C.c_int64]),
+    "kryst_vec_download": (C.c_int32, [Handle, c_dp, C.c_int64]),
+    "kryst_vec_fill": (C.c_int32, [Handle, C.c_double]),
+    "kryst_vec_copy": (C.c_int32, [Handle, Handle]),
+    "kryst_vec_fill_splitmix": (C.c_int32, [Handle, C.c_uint64, C.c_int64]),
+    "kryst_csr_create": (C.c_int32, [Handle, C.c_int64, C.c_int64, c_u64p, c_u64p, c_dp, C.POINTER(Handle)]),
+    "kryst_csr_create_i32": (C.c_int32, [Handle, C.c_int64, C.c_int64, c_i64p, c_i32p, c_dp, C.POINTER(Handle)]),
+    "kryst_csr_create_dist": (C.c_int32, [Handle, C.c_int64, c_i64p, c_i64p, c_i64p, c_dp, C.POINTER(Handle)]),
+    "kryst_csr_create_stencil7": (C.c_int32, [Handle, C.c_int32, C.c_int32, C.POINTER(Handle)]),
+    "kryst_csr_destroy": (C.c_int32, [Handle]),
+    "kryst_csr_shape": (C.c_int32, [Handle, c_i64p, c_i64p, c_i64p]),
+    "kryst_csr_download": (C.c_int32, [Handle, c_i64p, c_i32p, c_dp]),
+    "kryst_spmv": (C.c_int32, [Handle, Handle, Handle]),
+    "kryst_spmv_host": (C.c_int32, [Handle, c_dp, C.c_int64, c_dp, C.c_int64]),
+    "kryst_bench_spmv": (C.c_int32, [Handle, Handle, Handle, C.c_int32, C.c_int32, c_dp]),
+    "kryst_dot": (C.c_int32, [Handle, Handle, c_dp]),
+    "kryst_norm": (C.c_int32, [Handle, c_dp]),
+    "kryst_axpy": (C.c_int32, [C.c_double, Handle, Handle]),
+    "kryst_aypx": (C.c_int32, [C.c_double, Handle, Handle]),
+    "kryst_sub": (C.c_int32, [Handle, Handle, Handle]),
+    "kryst_pc_identity": (C.c_int32, [Handle, C.POINTER(Handle)]),
+    "kryst_pc_jacobi": (C.c_int32, [Handle, C.POINTER(Handle)]),
+    "kryst_pc_ilu0": (C.c_int32, [Handle, C.c_int32, C.POINTER(Handle)]),
+    "kryst_pc_chebyshev_stub": (C.c_int32, [Handle, C.c_int32, C.POINTER(Handle)]),
+    "kryst_pc_chebyshev": (C.c_int32, [Handle, C.c_double, C.c_double, C.c_int32, C.POINTER(Handle)]),
+    "kryst_pc_apply": (C.c_int32, [Handle, Handle, Handle]),
+    "kryst_pc_destroy": (C.c_int32, [Handle]),
+    "kryst_apply_chebyshev": (C.c_int32, [Handle, Handle, Handle, C.c_double, C.c_double, C.c_int64]),
+    "kryst_cg_solve": (C.c_int32, [c_dp, c_dp, C.c_int64] + _SOLVE_TAIL),
+    "kryst_pcg_solve": (C.c_int32, [c_dp, c_dp, C.c_int64] + _SOLVE_TAIL),
+    "kryst_gmres_solve": (C.c_int32, [c_dp, c_dp, C.c_int64] + _SOLVE_TAIL),
+    "kryst_bicgstab_solve": (C.c_int32, [c_dp, c_dp, C.c_int64] + _SOLVE_TAIL),
+    "kryst_cg_solve_dev": (C.c_int32, [Handle, Handle] + _SOLVE_TAIL),
+    "kryst_pcg_solve_dev": (C.c_int32, [Handle, Handle] + _SOLVE_TAIL),
+    "kryst_gmres_solve_dev": (C.c_int32, [Handle, Handle] + _SOLVE_TAIL),
+    "kryst_bicgstab_solve_dev": (C.c_int32, [Handle, Handle] + _SOLVE_TAIL),
+    "kryst_bicgstab_rpc_solve_dev": (C.c_int32, [Handle, Handle] + _SOLVE_TAIL),
+    "kryst_session_begin": (C.c_int32, [C.c_int32, Handle, Handle, Handle, Handle, C.POINTER(Params), C.POINTER(Handle)]),
+    "kryst_session_step": (C.c_int32, [Handle, C.c_int64]),
+    "kryst_session_end": (C.c_int32, [Handle, C.POINTER(Stats), c_dp, C.c_int64, c_i64p]),
+    "kryst_host_stencil7": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i64p, c_i64p, c_dp]),
+    "kryst_host_partition_rows": (C.c_int32, [C.c_int64, C.c_int32, C.c_int64, c_i64p]),
+    "kryst_host_halo_recv_plan": (C.c_int64, [C.c_int32, C.c_int32, c_i64p, c_i64p, c_i64p, c_i64p, c_i64p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libkryst_hip.so (built by __graft_entry__.build() / make -C kryst_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: the HIP extension is not built (run `make -C kryst_amd/csrc` "
+                               "or __graft_entry__.build()).  kryst_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError = missing export
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+class KError(Exception):
+    """Mirror of kryst::error::KError (src/error.rs:6-19) plus the runtime error classes of the C ABI."""
+
+    def __init__(self, code, message="", stats=None):
+        self.code, self.kind, self.stats = code, ERR_NAMES.get(code, f"code {code}"), stats
+        super().__init__(f"{self.kind}: {message}" if message else self.kind)
+
+
+def check(rc, stats=None):
+    if rc != OK:
+        msg = lib().kryst_hip_last_error()
+        raise KError(rc, msg.decode() if msg else "", stats)

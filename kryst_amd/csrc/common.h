@@ -1,0 +1,138 @@
+// Internal definitions shared by the libkryst_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/kryst_hip.h"
+
+// ---- the fixed inner-product tree (kryst_reduce_spec) ----
+#define KR_T 256            // threads per tile
+#define KR_V 2              // elements per thread per tile
+#define KR_TILE (KR_T * KR_V)
+#define KR_F 1024           // threads of the final fold
+#define KR_MAXQ 3           // at most 3 fused reductions per kernel
+
+namespace kr {
+
+void set_error(const char* fmt, ...);
+
+#define KR_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            kr::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return KRYST_ERR_HIP;                                                             \
+        }                                                                                     \
+    } while (0)
+
+#define KR_TRY(call)                                   \
+    do {                                               \
+        int32_t rc__ = (call);                         \
+        if (rc__ != KRYST_OK) return rc__;             \
+    } while (0)
+
+#define KR_ARG(cond, msg)                                          \
+    do {                                                           \
+        if (!(cond)) { kr::set_error("bad argument: %s", msg); return KRYST_ERR_ARG; } \
+    } while (0)
+
+// Progress record in mapped host memory: the device's scalar kernels publish here, the host polls it
+// between batches without touching the stream.
+struct HostProgress {
+    volatile int64_t iter;
+    volatile double  res;
+    volatile int32_t done;
+    volatile int32_t status;
+};
+
+struct Comm;   // dist.cpp
+
+}  // namespace kr
+
+struct kryst_ctx_s {
+    int device = 0;
+    int rank = 0, nranks = 1;
+    hipStream_t s_main = nullptr;   // compute
+    hipStream_t s_comm = nullptr;   // halo exchange
+    hipEvent_t ev_x_ready = nullptr, ev_halo_done = nullptr, tm0 = nullptr, tm1 = nullptr;
+    hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};
+    kr::Comm* comm = nullptr;
+    // reduction scratch: KR_MAXQ arrays of tile partials, sized on demand
+    double* d_partials = nullptr; int64_t partials_cap = 0;     // doubles per array
+    double* d_scal = nullptr;        // small scalar arena (device), 4096 doubles
+    double* d_gather = nullptr;      // nranks * KR_MAXQ doubles (all-gather target)
+    kr::HostProgress* h_prog = nullptr; kr::HostProgress* d_prog = nullptr;   // mapped
+    double* h_pinned = nullptr;      // 4096 doubles pinned staging
+    int num_cu = 256;
+};
+
+struct kryst_vec_s {
+    kryst_ctx_t ctx = nullptr;
+    int64_t n = 0;
+    double* d = nullptr;
+};
+
+namespace kr {
+
+int32_t ensure_partials(kryst_ctx_t ctx, int64_t ntiles);
+inline int64_t ntiles_of(int64_t n) { return (n + KR_TILE - 1) / KR_TILE; }
+
+// ---- device-side reduction primitives (the association order is part of the ABI contract) ----
+#ifdef __HIPCC__
+__device__ __forceinline__ double wave_butterfly(double v) {
+    v = v + __shfl_xor(v, 32, 64);
+    v = v + __shfl_xor(v, 16, 64);
+    v = v + __shfl_xor(v, 8, 64);
+    v = v + __shfl_xor(v, 4, 64);
+    v = v + __shfl_xor(v, 2, 64);
+    v = v + __shfl_xor(v, 1, 64);
+    return v;
+}
+
+// NW waves per block; lds must hold NQ*NW doubles.  Result valid in every thread.
+template <int NQ, int NW>
+__device__ __forceinline__ void block_reduce(double (&v)[NQ], double* lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        v[q] = wave_butterfly(v[q]);
+        if (lane == 0) lds[q * NW + wave] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double s = lds[q * NW];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s = s + lds[q * NW + w];
+        v[q] = s;
+    }
+    __syncthreads();
+}
+
+// fold of NQ arrays of tile partials by a block of KR_F threads; result valid in every thread
+template <int NQ>
+__device__ __forceinline__ void final_fold(const double* partials, int64_t stride, int64_t ntiles,
+                                           double (&out)[NQ], double* lds) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double acc = 0.0;
+        for (int64_t i = threadIdx.x; i < ntiles; i += KR_F) acc = acc + partials[q * stride + i];
+        out[q] = acc;
+    }
+    block_reduce<NQ, KR_F / 64>(out, lds);
+}
+#endif
+
+// ---- launchers implemented in blas1.hip / spmv.hip / precond.hip (all enqueue on ctx->s_main) ----
+int32_t launch_dot_partials(kryst_ctx_t ctx, const double* x, const double* y, int64_t n, int slot);
+// local result of up to nq partial arrays -> d_out[0..nq) (device), single rank: the final value
+int32_t launch_final_fold(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out);
+// global (all ranks) value of nq partial arrays -> d_out[0..nq) on every rank; folds ranks in rank order
+int32_t reduce_all(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out);
+int32_t vec_check2(kryst_vec_t a, kryst_vec_t b);
+
+}  // namespace kr

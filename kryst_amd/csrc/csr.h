@@ -1,0 +1,30 @@
+// Device CSR operator (CsrMatrix<f64>, src/matrix/sparse.rs:22-46) and the SpMV launcher.
+#pragma once
+#include "dist.h"
+
+struct kryst_csr_s {
+    kryst_ctx_t ctx = nullptr;
+    int64_t nrows = 0;        // local rows
+    int64_t ncols = 0;        // global columns
+    int64_t xlen = 0;         // length the SpMV input vector must have (ncols, or local rows when distributed)
+    int64_t nnz = 0;          // local
+    int32_t* d_row_ptr = nullptr;   // nrows+1 (+pad)
+    int32_t* d_col = nullptr;       // nnz (+8 pad, zero): LOCAL column index; >= nloc means halo slot
+    double*  d_val = nullptr;       // nnz (+8 pad, zero)
+    int64_t ntiles = 0;
+    // distributed
+    bool dist = false;
+    std::vector<int64_t> row_offsets;
+    kr::HaloPlan plan;
+    int32_t* d_tiles_interior = nullptr; int64_t n_interior = 0;
+    int32_t* d_tiles_boundary = nullptr; int64_t n_boundary = 0;
+    bool send_contiguous = false;   // every send list is a contiguous run of local rows (k-slab stencils)
+};
+
+namespace kr {
+
+// y <- A x on ctx->s_main.  nq = 0: plain.  nq = 1: also tile partials of sum d[i]*y[i] into partial array 0.
+// nq = 2: additionally sum y[i]*y[i] into partial array 1.  `done` (device flag) makes the launch a no-op when set.
+int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const double* dvec, const int* done);
+
+}  // namespace kr

@@ -1,0 +1,188 @@
+// Context management, error text, host-side problem generators.
+#include "dist.h"
+#include <cstdarg>
+
+namespace kr {
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+}  // namespace kr
+using namespace kr;
+
+static int32_t ctx_init(kryst_ctx_t ctx) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        set_error("no HIP device available: libkryst_hip has no CPU fallback");
+        return KRYST_ERR_HIP;
+    }
+    KR_ARG(ctx->device >= 0 && ctx->device < count, "device id out of range");
+    KR_HIP(hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    KR_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    KR_HIP(hipStreamCreateWithFlags(&ctx->s_main, hipStreamNonBlocking));
+    KR_HIP(hipStreamCreateWithFlags(&ctx->s_comm, hipStreamNonBlocking));
+    KR_HIP(hipEventCreateWithFlags(&ctx->ev_x_ready, hipEventDisableTiming));
+    KR_HIP(hipEventCreateWithFlags(&ctx->ev_halo_done, hipEventDisableTiming));
+    KR_HIP(hipEventCreate(&ctx->tm0));
+    KR_HIP(hipEventCreate(&ctx->tm1));
+    for (auto& e : ctx->ev_ring) KR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    KR_HIP(hipMalloc(&ctx->d_scal, sizeof(double) * 4096));
+    KR_HIP(hipMemset(ctx->d_scal, 0, sizeof(double) * 4096));
+    KR_HIP(hipMalloc(&ctx->d_gather, sizeof(double) * (size_t)(ctx->nranks + 1) * KR_MAXQ));
+    KR_HIP(hipHostMalloc((void**)&ctx->h_prog, sizeof(HostProgress), hipHostMallocMapped));
+    memset((void*)ctx->h_prog, 0, sizeof(HostProgress));
+    KR_HIP(hipHostGetDevicePointer((void**)&ctx->d_prog, (void*)ctx->h_prog, 0));
+    KR_HIP(hipHostMalloc((void**)&ctx->h_pinned, sizeof(double) * 4096, hipHostMallocDefault));
+    return KRYST_OK;
+}
+
+extern "C" {
+
+const char* kryst_hip_last_error(void) { return g_err; }
+int32_t kryst_hip_abi_version(void) { return 1; }
+void kryst_reduce_spec(int32_t* T, int32_t* V, int32_t* F) {
+    if (T) *T = KR_T;
+    if (V) *V = KR_V;
+    if (F) *F = KR_F;
+}
+
+int32_t kryst_ctx_create(int32_t device_id, kryst_ctx_t* out) {
+    KR_ARG(out, "ctx_create: out");
+    kryst_ctx_t ctx = new kryst_ctx_s();
+    ctx->device = device_id;
+    int32_t rc = ctx_init(ctx);
+    if (rc != KRYST_OK) { delete ctx; return rc; }
+    *out = ctx;
+    return KRYST_OK;
+}
+
+int32_t kryst_comm_unique_id(void* out128) {
+    KR_ARG(out128, "unique_id: out");
+    return comm_unique_id(out128);
+}
+
+int32_t kryst_ctx_create_dist(int32_t device_id, int32_t rank, int32_t nranks, const void* uid, kryst_ctx_t* out) {
+    KR_ARG(out && uid && nranks >= 1 && rank >= 0 && rank < nranks, "ctx_create_dist");
+    kryst_ctx_t ctx = new kryst_ctx_s();
+    ctx->device = device_id; ctx->rank = rank; ctx->nranks = nranks;
+    int32_t rc = ctx_init(ctx);
+    if (rc == KRYST_OK) rc = comm_init(ctx, uid);
+    if (rc != KRYST_OK) { delete ctx; return rc; }
+    *out = ctx;
+    return KRYST_OK;
+}
+
+int32_t kryst_ctx_destroy(kryst_ctx_t ctx) {
+    if (!ctx) return KRYST_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->s_main);
+    hipStreamSynchronize(ctx->s_comm);
+    comm_destroy(ctx);
+    hipFree(ctx->d_partials); hipFree(ctx->d_scal); hipFree(ctx->d_gather);
+    hipHostFree((void*)ctx->h_prog); hipHostFree(ctx->h_pinned);
+    hipEventDestroy(ctx->ev_x_ready); hipEventDestroy(ctx->ev_halo_done);
+    hipEventDestroy(ctx->tm0); hipEventDestroy(ctx->tm1);
+    for (auto& e : ctx->ev_ring) hipEventDestroy(e);
+    hipStreamDestroy(ctx->s_main); hipStreamDestroy(ctx->s_comm);
+    delete ctx;
+    return KRYST_OK;
+}
+
+int32_t kryst_ctx_synchronize(kryst_ctx_t ctx) {
+    KR_ARG(ctx, "ctx");
+    KR_HIP(hipSetDevice(ctx->device));
+    KR_HIP(hipStreamSynchronize(ctx->s_comm));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    return KRYST_OK;
+}
+
+int32_t kryst_ctx_rank(kryst_ctx_t ctx, int32_t* rank, int32_t* nranks) {
+    KR_ARG(ctx, "ctx");
+    if (rank) *rank = ctx->rank;
+    if (nranks) *nranks = ctx->nranks;
+    return KRYST_OK;
+}
+
+int32_t kryst_comm_all_reduce(kryst_ctx_t ctx, double x, double* out) {
+    KR_ARG(ctx && out, "all_reduce");
+    if (ctx->nranks == 1) { *out = x; return KRYST_OK; }          // RayonComm::all_reduce: identity (rayon_comm.rs:76-78)
+    KR_HIP(hipSetDevice(ctx->device));
+    double* local = ctx->d_gather + (size_t)ctx->nranks * KR_MAXQ;
+    KR_HIP(hipMemcpyAsync(local, &x, sizeof(double), hipMemcpyHostToDevice, ctx->s_main));
+    KR_TRY(comm_all_gather(ctx, local, ctx->d_gather, 1));
+    KR_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_gather, sizeof(double) * ctx->nranks, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    double total = ctx->h_pinned[0];
+    for (int p = 1; p < ctx->nranks; ++p) total = total + ctx->h_pinned[p];   // rank order: same bits on every rank
+    *out = total;
+    return KRYST_OK;
+}
+
+int32_t kryst_comm_barrier(kryst_ctx_t ctx) {
+    KR_ARG(ctx, "ctx");
+    KR_TRY(kryst_ctx_synchronize(ctx));
+    double dummy;
+    return kryst_comm_all_reduce(ctx, 0.0, &dummy);
+}
+
+int32_t kryst_ctx_timer_start(kryst_ctx_t ctx) {
+    KR_ARG(ctx, "ctx");
+    KR_HIP(hipSetDevice(ctx->device));
+    KR_HIP(hipEventRecord(ctx->tm0, ctx->s_main));
+    return KRYST_OK;
+}
+
+int32_t kryst_ctx_timer_stop(kryst_ctx_t ctx, double* ms) {
+    KR_ARG(ctx && ms, "timer_stop");
+    KR_HIP(hipSetDevice(ctx->device));
+    KR_HIP(hipEventRecord(ctx->tm1, ctx->s_main));
+    KR_HIP(hipEventSynchronize(ctx->tm1));
+    float f = 0.f;
+    KR_HIP(hipEventElapsedTime(&f, ctx->tm0, ctx->tm1));
+    *ms = (double)f;
+    return KRYST_OK;
+}
+
+// ---- host-only synthetic problems: 7-point stencil, row = i + N*(j + N*k), ascending columns,
+// homogeneous Dirichlet by truncation.
+static void stencil_coefs(int kind, double c[7]) {
+    // order of c: -N^2 (bottom), -N (south), -1 (west), 0 (diag), +1 (east), +N (north), +N^2 (top)
+    if (kind == 0) { c[0] = c[1] = c[2] = c[4] = c[5] = c[6] = -1.0; c[3] = 6.0; }
+    else if (kind == 1) { const double cx = 1.0, cy = 1.0, cz = 0.01;
+        c[2] = c[4] = -cx; c[1] = c[5] = -cy; c[0] = c[6] = -cz; c[3] = 2.0 * (cx + cy + cz); }
+    else { const double gx = 1.0, gy = 0.5, gz = 0.25;
+        c[2] = -(1.0 + gx); c[4] = -1.0; c[1] = -(1.0 + gy); c[5] = -1.0; c[0] = -(1.0 + gz); c[6] = -1.0;
+        c[3] = 6.0 + gx + gy + gz; }
+}
+
+int64_t kryst_host_stencil7(int32_t N, int32_t kind, int32_t k_lo, int32_t k_hi, int64_t* row_ptr, int64_t* col_idx,
+                            double* vals) {
+    if (N < 1 || k_lo < 0 || k_hi > N || k_lo > k_hi || kind < 0 || kind > 2) { set_error("stencil7: bad arguments"); return -1; }
+    double c[7];
+    stencil_coefs(kind, c);
+    const int64_t N1 = N, N2 = N1 * N1;
+    int64_t nnz = 0, lr = 0;
+    if (row_ptr) row_ptr[0] = 0;
+    for (int64_t k = k_lo; k < k_hi; ++k)
+        for (int64_t j = 0; j < N1; ++j)
+            for (int64_t i = 0; i < N1; ++i, ++lr) {
+                const int64_t row = i + N1 * (j + N1 * k);
+                const bool ok[7] = {k > 0, j > 0, i > 0, true, i < N1 - 1, j < N1 - 1, k < N1 - 1};
+                const int64_t off[7] = {-N2, -N1, -1, 0, 1, N1, N2};
+                for (int s = 0; s < 7; ++s)
+                    if (ok[s]) {
+                        if (col_idx) col_idx[nnz] = row + off[s];
+                        if (vals) vals[nnz] = c[s];
+                        ++nnz;
+                    }
+                if (row_ptr) row_ptr[lr + 1] = nnz;
+            }
+    return nnz;
+}
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+// RCCL binding + halo planning.  Compiled with hipcc (host code only).
+#include "dist.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <algorithm>
+
+namespace kr {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+};
+static Rccl g_rccl;
+
+struct Comm { ncclComm_t comm = nullptr; };
+
+static int32_t rccl_load() {
+    if (g_rccl.lib) return KRYST_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) { set_error("cannot load librccl.so.1: %s", dlerror()); return KRYST_ERR_RCCL; }
+#define SYM(field, name)                                                       \
+    *(void**)(&g_rccl.field) = dlsym(h, name);                                 \
+    if (!g_rccl.field) { set_error("RCCL symbol %s missing", name); return KRYST_ERR_RCCL; }
+    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+    SYM(GetErrorString, "ncclGetErrorString") SYM(AllGather, "ncclAllGather") SYM(Send, "ncclSend")
+    SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
+#undef SYM
+    g_rccl.lib = h;
+    return KRYST_OK;
+}
+
+#define KR_NCCL(call)                                                                                  \
+    do {                                                                                               \
+        ncclResult_t r__ = (call);                                                                     \
+        if (r__ != ncclSuccess) {                                                                      \
+            set_error("%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r__) : "?"); \
+            return KRYST_ERR_RCCL;                                                                     \
+        }                                                                                              \
+    } while (0)
+
+int32_t comm_unique_id(void* out128) {
+    KR_TRY(rccl_load());
+    ncclUniqueId id;
+    KR_NCCL(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(out128, &id, 128);
+    return KRYST_OK;
+}
+
+int32_t comm_init(kryst_ctx_t ctx, const void* uid128) {
+    KR_TRY(rccl_load());
+    ncclUniqueId id;
+    memcpy(&id, uid128, 128);
+    ctx->comm = new Comm();
+    KR_NCCL(g_rccl.CommInitRank(&ctx->comm->comm, ctx->nranks, id, ctx->rank));
+    return KRYST_OK;
+}
+
+void comm_destroy(kryst_ctx_t ctx) {
+    if (ctx->comm) {
+        if (ctx->comm->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm->comm);
+        delete ctx->comm;
+        ctx->comm = nullptr;
+    }
+}
+
+int32_t comm_all_gather(kryst_ctx_t ctx, const double* send, double* recv, int count) {
+    KR_ARG(ctx->comm, "context has no communicator");
+    KR_NCCL(g_rccl.AllGather(send, recv, (size_t)count, ncclFloat64, ctx->comm->comm, ctx->s_main));
+    return KRYST_OK;
+}
+
+int32_t comm_all_gather_i64(kryst_ctx_t ctx, const int64_t* send, int64_t* recv, int count, hipStream_t s) {
+    KR_ARG(ctx->comm, "context has no communicator");
+    KR_NCCL(g_rccl.AllGather(send, recv, (size_t)count, ncclInt64, ctx->comm->comm, s));
+    return KRYST_OK;
+}
+
+int32_t comm_exchange(kryst_ctx_t ctx, const void* send, const int64_t* send_counts, const int64_t* send_off,
+                      void* recv, const int64_t* recv_counts, const int64_t* recv_off, bool is_double, hipStream_t s) {
+    KR_ARG(ctx->comm, "context has no communicator");
+    const ncclDataType_t dt = is_double ? ncclFloat64 : ncclInt64;
+    KR_NCCL(g_rccl.GroupStart());
+    for (int p = 0; p < ctx->nranks; ++p) {
+        if (p == ctx->rank) continue;
+        if (send_counts[p] > 0)
+            KR_NCCL(g_rccl.Send((const char*)send + 8 * send_off[p], (size_t)send_counts[p], dt, p, ctx->comm->comm, s));
+        if (recv_counts[p] > 0)
+            KR_NCCL(g_rccl.Recv((char*)recv + 8 * recv_off[p], (size_t)recv_counts[p], dt, p, ctx->comm->comm, s));
+    }
+    KR_NCCL(g_rccl.GroupEnd());
+    return KRYST_OK;
+}
+
+static int owner_of(const int64_t* row_offsets, int nranks, int64_t c) {
+    // row_offsets ascending, nranks+1 entries; owner p has row_offsets[p] <= c < row_offsets[p+1]
+    int lo = 0, hi = nranks;
+    while (hi - lo > 1) { int mid = (lo + hi) / 2; if (row_offsets[mid] <= c) lo = mid; else hi = mid; }
+    return lo;
+}
+
+void halo_recv_plan(int rank, int nranks, const int64_t* row_offsets, int64_t nloc, const int64_t* row_ptr,
+                    const int64_t* col_global, HaloPlan* plan) {
+    plan->nranks = nranks; plan->rank = rank;
+    plan->row_lo = row_offsets[rank]; plan->row_hi = row_offsets[rank + 1];
+    std::vector<std::vector<int64_t>> need(nranks);
+    const int64_t nnz = row_ptr[nloc];
+    for (int64_t k = 0; k < nnz; ++k) {
+        const int64_t c = col_global[k];
+        if (c >= plan->row_lo && c < plan->row_hi) continue;
+        need[owner_of(row_offsets, nranks, c)].push_back(c);
+    }
+    plan->recv_counts.assign(nranks, 0); plan->recv_off.assign(nranks, 0);
+    plan->recv_cols.clear();
+    for (int p = 0; p < nranks; ++p) {
+        auto& v = need[p];
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        plan->recv_off[p] = (int64_t)plan->recv_cols.size();
+        plan->recv_counts[p] = (int64_t)v.size();
+        plan->recv_cols.insert(plan->recv_cols.end(), v.begin(), v.end());
+    }
+    plan->total_recv = (int64_t)plan->recv_cols.size();
+}
+
+int64_t halo_slot(const HaloPlan& plan, const int64_t* row_offsets, int64_t c) {
+    const int p = owner_of(row_offsets, plan.nranks, c);
+    const int64_t* b = plan.recv_cols.data() + plan.recv_off[p];
+    const int64_t* e = b + plan.recv_counts[p];
+    const int64_t* it = std::lower_bound(b, e, c);
+    return (it != e && *it == c) ? (int64_t)(it - plan.recv_cols.data()) : -1;
+}
+
+}  // namespace kr
+
+using namespace kr;
+
+extern "C" {
+
+int32_t kryst_host_partition_rows(int64_t n, int32_t nranks, int64_t align, int64_t* row_offsets) {
+    KR_ARG(n >= 0 && nranks >= 1 && align >= 1 && row_offsets, "partition_rows");
+    const int64_t units = (n + align - 1) / align;       // e.g. grid planes
+    for (int p = 0; p <= nranks; ++p) {
+        int64_t u = units * p / nranks;                  // balanced contiguous blocks of whole units
+        int64_t r = u * align;
+        row_offsets[p] = r > n ? n : r;
+    }
+    row_offsets[nranks] = n;
+    return KRYST_OK;
+}
+
+int64_t kryst_host_halo_recv_plan(int32_t rank, int32_t nranks, const int64_t* row_offsets, const int64_t* row_ptr,
+                                  const int64_t* col_idx_global, int64_t* recv_counts, int64_t* recv_cols) {
+    HaloPlan plan;
+    const int64_t nloc = row_offsets[rank + 1] - row_offsets[rank];
+    halo_recv_plan(rank, nranks, row_offsets, nloc, row_ptr, col_idx_global, &plan);
+    if (recv_counts) for (int p = 0; p < nranks; ++p) recv_counts[p] = plan.recv_counts[p];
+    if (recv_cols) memcpy(recv_cols, plan.recv_cols.data(), sizeof(int64_t) * (size_t)plan.total_recv);
+    return plan.total_recv;
+}
+
+}  // extern "C"

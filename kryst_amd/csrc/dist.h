@@ -1,0 +1,38 @@
+// RCCL-over-xGMI layer that replaces the reference's MPI placeholder (src/parallel/mpi_comm.rs).
+// One process per GPU; librccl.so.1 is bound at run time with dlopen so that a single-GPU user never needs it
+// and so that a host process that already carries an RCCL (e.g. torch's) shares that copy.
+#pragma once
+#include "common.h"
+
+namespace kr {
+
+int32_t comm_unique_id(void* out128);
+int32_t comm_init(kryst_ctx_t ctx, const void* uid128);
+void    comm_destroy(kryst_ctx_t ctx);
+// all-gather of `count` doubles per rank on ctx->s_main: recv[p*count + i]
+int32_t comm_all_gather(kryst_ctx_t ctx, const double* send, double* recv, int count);
+int32_t comm_all_gather_i64(kryst_ctx_t ctx, const int64_t* send, int64_t* recv, int count, hipStream_t s);
+// grouped neighbour exchange: for every peer p, send send_counts[p] items at send + send_off[p] and receive
+// recv_counts[p] items at recv + recv_off[p]; elem_bytes is 8 (double or int64)
+int32_t comm_exchange(kryst_ctx_t ctx, const void* send, const int64_t* send_counts, const int64_t* send_off,
+                      void* recv, const int64_t* recv_counts, const int64_t* recv_off, bool is_double, hipStream_t s);
+
+// Halo plan of a row-partitioned operator (host side; also exported as kryst_host_halo_recv_plan)
+struct HaloPlan {
+    int nranks = 1, rank = 0;
+    int64_t row_lo = 0, row_hi = 0;
+    std::vector<int64_t> recv_counts, recv_off, send_counts, send_off;
+    std::vector<int64_t> recv_cols;      // global columns, grouped by owner, ascending inside a group
+    int64_t total_recv = 0, total_send = 0;
+    int32_t* d_send_idx = nullptr;       // local rows to pack, total_send
+    double*  d_sendbuf = nullptr;        // total_send
+    double*  d_halo = nullptr;           // total_recv
+};
+
+// recv side from the local rows (global column ids); returns the plan's recv_* fields
+void halo_recv_plan(int rank, int nranks, const int64_t* row_offsets, int64_t nloc, const int64_t* row_ptr,
+                    const int64_t* col_global, HaloPlan* plan);
+// slot of global column c in the concatenated recv list (binary search inside the owner's group)
+int64_t halo_slot(const HaloPlan& plan, const int64_t* row_offsets, int64_t c);
+
+}  // namespace kr

@@ -1,0 +1,70 @@
+// Tile-structured elementwise kernels with optional fused inner-product partials.
+//
+// Every vector kernel walks the vector in tiles of KR_TILE = KR_T*KR_V elements; thread t of a tile owns the
+// KR_V = 2 consecutive elements q*512 + 2t, +1 (one 16-byte access per array: the coalescing sweet spot on
+// gfx950).  A fused reduction folds the thread's two terms in index order, then the 64-lane xor butterfly,
+// then the 4 waves serially, and stores ONE partial per tile: the association order depends only on the
+// element index, never on the grid, so fusing a dot into any kernel gives the same bits as the standalone dot.
+//
+// Vectors are allocated padded to a multiple of KR_TILE (zero filled), so a tile is always fully addressable;
+// reductions mask i < n.
+#pragma once
+#include "common.h"
+
+namespace kr {
+
+struct d2 { double a, b; };
+__device__ __forceinline__ d2 ld2(const double* p, int64_t i) {
+    const double2 v = *reinterpret_cast<const double2*>(p + i);
+    return {v.x, v.y};
+}
+__device__ __forceinline__ void st2(double* p, int64_t i, double a, double b) {
+    *reinterpret_cast<double2*>(p + i) = make_double2(a, b);
+}
+// coefficient that lives either in a kernel argument or in device memory (written by a scalar kernel)
+struct Coef {
+    const double* ptr; double val;
+    __device__ __forceinline__ double get() const { return ptr ? *ptr : val; }
+};
+inline Coef coef_dev(const double* p) { return Coef{p, 0.0}; }
+inline Coef coef_val(double v) { return Coef{nullptr, v}; }
+
+// Op requirements:  static constexpr int NQ;  __device__ void pair(int64_t i, bool in0, bool in1, double (&acc)[max(NQ,1)]) const;
+template <class Op>
+__global__ __launch_bounds__(KR_T) void ew_kernel(Op op, int64_t n, int64_t ntiles, double* partials,
+                                                  int64_t pstride, const int* done) {
+    if (done && *done) return;
+    constexpr int NQ = Op::NQ;
+    __shared__ double lds[(NQ > 0 ? NQ : 1) * (KR_T / 64)];
+    for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
+        const int64_t i = q * KR_TILE + (int64_t)threadIdx.x * KR_V;
+        double acc[NQ > 0 ? NQ : 1];
+#pragma unroll
+        for (int k = 0; k < (NQ > 0 ? NQ : 1); ++k) acc[k] = 0.0;
+        op.pair(i, i < n, i + 1 < n, acc);
+        if constexpr (NQ > 0) {
+            block_reduce<NQ, KR_T / 64>(acc, lds);
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) partials[k * pstride + q] = acc[k];
+            }
+        }
+    }
+}
+
+template <class Op>
+inline int32_t launch_ew(kryst_ctx_t ctx, const Op& op, int64_t n, const int* done = nullptr) {
+    const int64_t ntiles = ntiles_of(n);
+    if (ntiles == 0) return KRYST_OK;
+    if (Op::NQ > 0) KR_TRY(ensure_partials(ctx, ntiles));
+    // memory-bound streaming: cap the grid and stride the rest (8 blocks of 256 per CU fill the chip)
+    int64_t grid = ntiles;
+    const int64_t cap = (int64_t)ctx->num_cu * 8;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(ew_kernel<Op>, dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, n, ntiles,
+                       ctx->d_partials, ctx->partials_cap, done);
+    KR_HIP(hipGetLastError());
+    return KRYST_OK;
+}
+
+}  // namespace kr

@@ -1,0 +1,211 @@
+// Pointwise preconditioner applies for gfx950: Jacobi (src/preconditioner/jacobi.rs), the Chebyshev filter
+// (src/preconditioner/chebyshev.rs:83-140) and the ILU(0)-family triangular solves (ilu.rs / ilup.rs; in ilu.hip).
+#include "pc.h"
+#include "ew.h"
+#include <cfloat>
+#include <cmath>
+
+namespace kr {
+
+// ---------------------------------------------------------------- Jacobi
+// jacobi.rs:53-73 builds diag[i] = (A e_i)[i] with n matvecs; the row sum that lands in diag[i] is
+// 0 + a_ii*1 (+ exact zeros) = a_ii, so reading the stored diagonal gives the same bits.
+__global__ void jacobi_setup_kernel(const int32_t* row_ptr, const int32_t* col, const double* val, int32_t nrows,
+                                    double* inv_diag) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows) return;
+    double d = 0.0;
+    for (int32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
+        if (col[k] == i) d = 0.0 + val[k] * 1.0;
+    inv_diag[i] = (d != 0.0) ? 1.0 / d : 0.0;                       // jacobi.rs:69-71
+}
+
+struct JacobiOp {                    // y[i] = inv_diag[i] * x[i]   (jacobi.rs:84-92)
+    static constexpr int NQ = 0;
+    const double* inv; const double* x; double* y;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const d2 a = ld2(inv, i), b = ld2(x, i);
+        st2(y, i, a.a * b.a, a.b * b.b);
+    }
+};
+
+// ---------------------------------------------------------------- Chebyshev filter
+struct Cheb1Op {                     // v1[i] = (v1[i] - c*v0[i]) / d            (chebyshev.rs:105-107)
+    static constexpr int NQ = 0;
+    double c, d; const double* v0; double* v1;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const d2 a = ld2(v0, i), b = ld2(v1, i);
+        st2(v1, i, (b.a - c * a.a) / d, (b.b - c * a.b) / d);
+    }
+};
+struct Cheb2Op {                     // v2[i] = (2*(v2[i] - c*v1[i]) / d) - v0[i] (chebyshev.rs:121)
+    static constexpr int NQ = 0;
+    double c, d; const double* v0; const double* v1; double* v2;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const d2 a = ld2(v0, i), b = ld2(v1, i), w = ld2(v2, i);
+        st2(v2, i, (2.0 * (w.a - c * b.a) / d) - a.a, (2.0 * (w.b - c * b.b) / d) - a.b);
+    }
+};
+struct ScaleOp {                     // z[i] = tau * v[i]                         (chebyshev.rs:130-138)
+    static constexpr int NQ = 0;
+    double tau; const double* v; double* z;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const d2 a = ld2(v, i);
+        st2(z, i, tau * a.a, tau * a.b);
+    }
+};
+
+static double chebyshev_t_host(int64_t m, double x) {       // chebyshev.rs:143-159
+    if (m == 0) return 1.0;
+    if (m == 1) return x;
+    double t0 = 1.0, t1 = x, t2;
+    for (int64_t k = 2; k <= m; ++k) { t2 = 2.0 * x * t1 - t0; t0 = t1; t1 = t2; }
+    return t1;
+}
+
+static inline int64_t padded(int64_t n) { return (n + KR_TILE - 1) / KR_TILE * KR_TILE; }
+
+int32_t chebyshev_dev(kryst_csr_t a, const double* r, double* z, double alpha, double beta, int64_t m,
+                      double* v0, double* v1, double* v2, const int* done) {
+    kryst_ctx_t ctx = a->ctx;
+    const int64_t n = a->nrows;
+    const size_t bytes = sizeof(double) * (size_t)padded(n);
+    if (std::fabs(beta - alpha) < DBL_EPSILON) {                                           // :88-92
+        KR_HIP(hipMemcpyAsync(z, r, bytes, hipMemcpyDeviceToDevice, ctx->s_main));
+        return KRYST_OK;
+    }
+    const double c = (beta + alpha) / 2.0;
+    const double d = (beta - alpha) / 2.0;
+    const double tau = 1.0 / chebyshev_t_host(m, (0.0 - c) / d);                           // :102
+    KR_HIP(hipMemcpyAsync(v0, r, bytes, hipMemcpyDeviceToDevice, ctx->s_main));            // v0 = r
+    KR_TRY(launch_spmv(a, v0, v1, 0, nullptr, done));                                      // :104
+    KR_TRY(launch_ew(ctx, Cheb1Op{c, d, v0, v1}, n, done));
+    if (m == 0) { KR_HIP(hipMemcpyAsync(z, v0, bytes, hipMemcpyDeviceToDevice, ctx->s_main)); return KRYST_OK; }
+    if (m == 1) { KR_HIP(hipMemcpyAsync(z, v1, bytes, hipMemcpyDeviceToDevice, ctx->s_main)); return KRYST_OK; }   // unscaled
+    for (int64_t k = 2; k <= m; ++k) {
+        KR_TRY(launch_spmv(a, v1, v2, 0, nullptr, done));
+        KR_TRY(launch_ew(ctx, Cheb2Op{c, d, v0, v1, v2}, n, done));
+        double* t = v0; v0 = v1; v1 = t;
+        t = v1; v1 = v2; v2 = t;
+    }
+    return launch_ew(ctx, ScaleOp{tau, v1, z}, n, done);
+}
+
+int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done);   // ilu.hip
+void    ilu_free(kryst_pc_t pc);
+
+int32_t pc_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done) {
+    kryst_ctx_t ctx = pc->ctx;
+    switch (pc->kind) {
+        case KR_PC_IDENTITY:
+            if (r != z) KR_HIP(hipMemcpyAsync(z, r, sizeof(double) * (size_t)padded(pc->n), hipMemcpyDeviceToDevice, ctx->s_main));
+            return KRYST_OK;
+        case KR_PC_JACOBI: return launch_ew(ctx, JacobiOp{pc->d_inv_diag, r, z}, pc->n, done);
+        case KR_PC_ILU: return ilu_apply_dev(pc, r, z, done);
+        case KR_PC_CHEB_STUB:
+            set_error("Chebyshev preconditioner requires matrix argument; use apply_chebyshev free function.");   // chebyshev.rs:69
+            return KRYST_SOLVE_ERROR;
+        case KR_PC_CHEB:
+            return chebyshev_dev(pc->a, r, z, pc->cheb_alpha, pc->cheb_beta, pc->cheb_degree, pc->d_v0, pc->d_v1, pc->d_v2, done);
+        default: set_error("unknown preconditioner kind %d", pc->kind); return KRYST_UNSUPPORTED;
+    }
+}
+
+}  // namespace kr
+
+using namespace kr;
+
+static int32_t alloc_vec(double** p, int64_t n) {
+    const size_t bytes = sizeof(double) * (size_t)(padded(n) + KR_TILE);
+    KR_HIP(hipMalloc(p, bytes));
+    KR_HIP(hipMemset(*p, 0, bytes));
+    return KRYST_OK;
+}
+
+extern "C" {
+
+int32_t kryst_pc_identity(kryst_ctx_t ctx, kryst_pc_t* out) {
+    KR_ARG(ctx && out, "pc_identity");
+    kryst_pc_t pc = new kryst_pc_s();
+    pc->ctx = ctx; pc->kind = KR_PC_IDENTITY; pc->n = -1;
+    *out = pc;
+    return KRYST_OK;
+}
+
+int32_t kryst_pc_jacobi(kryst_csr_t a, kryst_pc_t* out) {
+    KR_ARG(a && out, "pc_jacobi");
+    KR_HIP(hipSetDevice(a->ctx->device));
+    kryst_pc_t pc = new kryst_pc_s();
+    pc->ctx = a->ctx; pc->kind = KR_PC_JACOBI; pc->a = a; pc->n = a->nrows;
+    int32_t rc = alloc_vec(&pc->d_inv_diag, pc->n);
+    if (rc != KRYST_OK) { delete pc; return rc; }
+    if (pc->n > 0) {
+        hipLaunchKernelGGL(jacobi_setup_kernel, dim3((unsigned)((pc->n + 255) / 256)), dim3(256), 0, a->ctx->s_main,
+                           a->d_row_ptr, a->d_col, a->d_val, (int32_t)pc->n, pc->d_inv_diag);
+        KR_HIP(hipGetLastError());
+    }
+    *out = pc;
+    return KRYST_OK;
+}
+
+int32_t kryst_pc_chebyshev_stub(kryst_ctx_t ctx, int32_t degree, kryst_pc_t* out) {
+    KR_ARG(ctx && out, "pc_chebyshev_stub");
+    kryst_pc_t pc = new kryst_pc_s();
+    pc->ctx = ctx; pc->kind = KR_PC_CHEB_STUB; pc->cheb_degree = degree; pc->n = -1;
+    *out = pc;
+    return KRYST_OK;
+}
+
+int32_t kryst_pc_chebyshev(kryst_csr_t a, double alpha, double beta, int32_t degree, kryst_pc_t* out) {
+    KR_ARG(a && out && degree >= 0, "pc_chebyshev");
+    KR_ARG(a->nrows == a->xlen, "pc_chebyshev: square operator required");
+    KR_HIP(hipSetDevice(a->ctx->device));
+    kryst_pc_t pc = new kryst_pc_s();
+    pc->ctx = a->ctx; pc->kind = KR_PC_CHEB; pc->a = a; pc->n = a->nrows;
+    pc->cheb_alpha = alpha; pc->cheb_beta = beta; pc->cheb_degree = degree;
+    int32_t rc = alloc_vec(&pc->d_v0, pc->n);
+    if (rc == KRYST_OK) rc = alloc_vec(&pc->d_v1, pc->n);
+    if (rc == KRYST_OK) rc = alloc_vec(&pc->d_v2, pc->n);
+    if (rc != KRYST_OK) { kryst_pc_destroy(pc); return rc; }
+    *out = pc;
+    return KRYST_OK;
+}
+
+int32_t kryst_pc_apply(kryst_pc_t pc, kryst_vec_t r, kryst_vec_t z) {
+    KR_ARG(pc && r && z, "pc_apply");
+    KR_ARG(r->ctx == pc->ctx && z->ctx == pc->ctx, "pc_apply: context mismatch");
+    KR_ARG(r->n == z->n, "pc_apply: length mismatch");
+    KR_ARG(pc->n < 0 || pc->n == r->n, "pc_apply: vector length != operator size");
+    KR_HIP(hipSetDevice(pc->ctx->device));
+    if (pc->n < 0) {                                     // identity / stub carry no size
+        kryst_pc_s tmp = *pc; tmp.n = r->n;
+        return pc_apply_dev(&tmp, r->d, z->d, nullptr);
+    }
+    return pc_apply_dev(pc, r->d, z->d, nullptr);
+}
+
+int32_t kryst_pc_destroy(kryst_pc_t pc) {
+    if (!pc) return KRYST_OK;
+    hipSetDevice(pc->ctx->device);
+    hipStreamSynchronize(pc->ctx->s_main);
+    hipFree(pc->d_inv_diag); hipFree(pc->d_v0); hipFree(pc->d_v1); hipFree(pc->d_v2);
+    ilu_free(pc);
+    delete pc;
+    return KRYST_OK;
+}
+
+int32_t kryst_apply_chebyshev(kryst_csr_t a, kryst_vec_t r, kryst_vec_t z, double alpha, double beta, int64_t m) {
+    KR_ARG(a && r && z && m >= 0, "apply_chebyshev");
+    KR_ARG(r->n == a->nrows && z->n == a->nrows && a->nrows == a->xlen, "apply_chebyshev: size mismatch");
+    KR_HIP(hipSetDevice(a->ctx->device));
+    double *v0 = nullptr, *v1 = nullptr, *v2 = nullptr;
+    int32_t rc = alloc_vec(&v0, a->nrows);
+    if (rc == KRYST_OK) rc = alloc_vec(&v1, a->nrows);
+    if (rc == KRYST_OK) rc = alloc_vec(&v2, a->nrows);
+    if (rc == KRYST_OK) rc = chebyshev_dev(a, r->d, z->d, alpha, beta, m, v0, v1, v2, nullptr);
+    hipStreamSynchronize(a->ctx->s_main);
+    hipFree(v0); hipFree(v1); hipFree(v2);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+// Device-resident Krylov iteration: shared state, scalar "logic" kernels and the host enqueue/poll loop.
+//
+// The reference solvers interleave vector loops with scalar decisions on the host (alpha = rz/pAp, the
+// convergence test, breakdown checks).  Here the scalars never leave the GPU: every inner product ends in a
+// one-workgroup kernel that folds the tile partials (fixed order) and then runs the solver's scalar step in
+// thread 0, writing alpha/beta/... to device memory where the next vector kernel reads them.  When the
+// reference would return, the logic sets `done`; every later kernel of the stream starts with `if (*done)
+// return`, so the host can enqueue iterations ahead without a sync per iteration and the result is still
+// EXACTLY the reference's iterate (same iteration count, same x).  The host learns about `done` from a
+// progress record in mapped host memory.
+#pragma once
+#include "pc.h"
+#include "ew.h"
+#include <cfloat>
+
+namespace kr {
+
+struct DevState {
+    // generic scalars
+    double rsq, alpha, beta, res0, rz, normq, rho, rho_prev, omega, omega_prev;
+    double final_residual;
+    long long iter;          // completed iterations
+    long long iterations;    // SolveStats.iterations
+    long long hist_len;
+    int done;                // the reference would have returned / broken out
+    int status;              // KRYST_* code
+    int converged;           // SolveStats.converged
+    int early;               // BiCGStab: s-norm exit pending its x update
+};
+
+struct LogicCtx {
+    DevState* st; double* hist; HostProgress* prog; const double* red;
+    double tol; long long max_iters; int norm_type;
+    __device__ __forceinline__ void push(double v) const { hist[st->hist_len] = v; st->hist_len = st->hist_len + 1; }
+    __device__ __forceinline__ void finish(int status) const {
+        st->status = status; st->done = 1;
+        prog->iter = st->iter + 1; prog->res = st->final_residual; prog->status = status;
+        __threadfence_system();
+        prog->done = 1;
+        __threadfence_system();
+    }
+    // Convergence::check (src/utils/convergence.rs:18-34)
+    __device__ __forceinline__ bool check(double res, double res0, long long i) const {
+        const double rel = res / res0;
+        const bool conv = (rel <= tol) || (i >= max_iters);
+        st->iterations = i; st->final_residual = res; st->converged = conv ? 1 : 0;
+        return conv;
+    }
+};
+
+// correctly rounded fp64 sqrt on the device (checked bit-for-bit against the host in tests/test_gpu_kernels.py)
+__device__ __forceinline__ double dsqrt(double x) { return __builtin_sqrt(x); }
+
+// single rank: fold the tile partials and run the logic in one launch
+template <int NQ, class L>
+__global__ __launch_bounds__(KR_F) void fold_logic_kernel(const double* partials, int64_t stride, int64_t ntiles,
+                                                          double* red_out, L logic) {
+    if (logic.c.st->done && !L::RUN_WHEN_DONE) return;
+    __shared__ double lds[NQ * (KR_F / 64)];
+    double v[NQ];
+    final_fold<NQ>(partials, stride, ntiles, v, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) red_out[q] = v[q];
+        logic.run(red_out);
+    }
+}
+template <class L>
+__global__ void logic_kernel(const double* red, L logic) {
+    if (logic.c.st->done && !L::RUN_WHEN_DONE) return;
+    if (threadIdx.x == 0) logic.run(red);
+}
+
+template <int NQ, class L>
+inline int32_t reduce_then(kryst_ctx_t ctx, int64_t ntiles, double* d_red, const L& logic) {
+    if (ctx->nranks == 1) {
+        KR_TRY(ensure_partials(ctx, ntiles > 0 ? ntiles : 1));
+        hipLaunchKernelGGL((fold_logic_kernel<NQ, L>), dim3(1), dim3(KR_F), 0, ctx->s_main, ctx->d_partials,
+                           ctx->partials_cap, ntiles, d_red, logic);
+    } else {
+        KR_TRY(reduce_all(ctx, NQ, ntiles, d_red));
+        hipLaunchKernelGGL((logic_kernel<L>), dim3(1), dim3(64), 0, ctx->s_main, d_red, logic);
+    }
+    KR_HIP(hipGetLastError());
+    return KRYST_OK;
+}
+
+// Work area of one solve: device vectors, state, mapped history.  Freed by the destructor.
+struct Workspace {
+    kryst_ctx_t ctx; int64_t n;
+    std::vector<double*> vecs;
+    DevState* st = nullptr; double* red = nullptr;
+    double* h_hist = nullptr; double* d_hist = nullptr; int64_t hist_cap = 0;
+    explicit Workspace(kryst_ctx_t c, int64_t n_) : ctx(c), n(n_) {}
+    ~Workspace() {
+        hipStreamSynchronize(ctx->s_main);
+        for (double* p : vecs) hipFree(p);
+        if (h_hist) hipHostFree(h_hist);
+    }
+    int32_t vec(double** out) {
+        const size_t bytes = sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
+        double* p = nullptr;
+        KR_HIP(hipMalloc(&p, bytes));
+        KR_HIP(hipMemsetAsync(p, 0, bytes, ctx->s_main));
+        vecs.push_back(p);
+        *out = p;
+        return KRYST_OK;
+    }
+    int32_t init(int64_t hist_entries) {
+        st = reinterpret_cast<DevState*>(ctx->d_scal);
+        red = ctx->d_scal + 256;
+        KR_HIP(hipMemsetAsync(ctx->d_scal, 0, sizeof(double) * 512, ctx->s_main));
+        hist_cap = hist_entries;
+        KR_HIP(hipHostMalloc((void**)&h_hist, sizeof(double) * (size_t)hist_cap, hipHostMallocMapped));
+        KR_HIP(hipHostGetDevicePointer((void**)&d_hist, h_hist, 0));
+        ctx->h_prog->iter = 0; ctx->h_prog->res = 0; ctx->h_prog->done = 0; ctx->h_prog->status = 0;
+        return KRYST_OK;
+    }
+    LogicCtx lctx(const kryst_params_t* p) const {
+        return LogicCtx{st, d_hist, ctx->d_prog, red, p->tol, (long long)p->max_iters, p->norm_type};
+    }
+};
+
+inline size_t padded_bytes(int64_t n) { return sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE); }
+
+// Host side of the run-ahead loop: enqueue `body(i)` for i = 1..max_iters in batches, stop once the device has
+// published `done`.  With several ranks every rank must enqueue the same collectives, so a rank only acts on a
+// `done` that happened inside batches it has fully waited for (all ranks then see the same thing).
+template <class Body>
+inline int32_t run_ahead(kryst_ctx_t ctx, const kryst_params_t* p, Body body) {
+    const int64_t chk = p->check_every > 0 ? p->check_every : 8;
+    int64_t it = 0, batch = 0;
+    int64_t synced_iters = 0;
+    std::vector<int64_t> batch_end;
+    while (it < p->max_iters) {
+        const int64_t nb = std::min<int64_t>(chk, p->max_iters - it);
+        for (int64_t k = 0; k < nb; ++k) KR_TRY(body(it + k + 1));
+        it += nb;
+        batch_end.push_back(it);
+        KR_HIP(hipEventRecord(ctx->ev_ring[batch & 3], ctx->s_main));
+        if (batch >= 1) {                                   // at most two batches in flight
+            KR_HIP(hipEventSynchronize(ctx->ev_ring[(batch - 1) & 3]));
+            synced_iters = batch_end[(size_t)batch - 1];
+        }
+        ++batch;
+        if (ctx->h_prog->done && (ctx->nranks == 1 || ctx->h_prog->iter <= synced_iters)) break;
+    }
+    KR_HIP(hipStreamSynchronize(ctx->s_comm));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    return KRYST_OK;
+}
+
+struct DotOneOp {
+    static constexpr int NQ = 1;
+    const double *a, *b;
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
+        const d2 u = ld2(a, i), v = ld2(b, i);
+        if (in0) acc[0] = acc[0] + u.a * v.a;
+        if (in1) acc[0] = acc[0] + u.b * v.b;
+    }
+};
+// out = a - b, partial of out.out        (r = b - A x, `bi - ax`, cg.rs:123; ||r||^2 for the first dot)
+struct SubDotOp {
+    static constexpr int NQ = 1;
+    const double *a, *b; double* out;
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
+        const d2 u = ld2(a, i), v = ld2(b, i);
+        const double r0 = u.a - v.a, r1 = u.b - v.b;
+        st2(out, i, r0, r1);
+        if (in0) acc[0] = acc[0] + r0 * r0;
+        if (in1) acc[0] = acc[0] + r1 * r1;
+    }
+};
+// r = b - A x with ||r||^2 partials; tmp receives A x
+inline int32_t residual_dot(kryst_csr_t a, const double* b, const double* x, double* r, double* tmp, const int* done) {
+    KR_TRY(launch_spmv(a, x, tmp, 0, nullptr, done));
+    return launch_ew(a->ctx, SubDotOp{b, tmp, r}, a->nrows, done);
+}
+
+struct SolveIO {
+    kryst_csr_t a; kryst_pc_t pc; const kryst_params_t* params; kryst_stats_t* stats;
+    double* hist; int64_t hist_cap; int64_t* hist_len; kryst_monitor_fn monitor; void* user;
+};
+
+// copy stats / history out and run the monitor callbacks (in order, on the calling thread)
+inline int32_t finish_solve(Workspace& ws, const SolveIO& io) {
+    kryst_ctx_t ctx = ws.ctx;
+    DevState h;
+    KR_HIP(hipMemcpy(&h, ws.st, sizeof(DevState), hipMemcpyDeviceToHost));
+    if (io.stats) { io.stats->iterations = h.iterations; io.stats->final_residual = h.final_residual; io.stats->converged = h.converged; }
+    const int64_t len = h.hist_len;
+    if (io.hist_len) *io.hist_len = len;
+    for (int64_t k = 0; k < len && k < ws.hist_cap; ++k) {
+        if (io.hist && k < io.hist_cap) io.hist[k] = ws.h_hist[k];
+    }
+    (void)ctx;
+    return h.status;
+}
+
+}  // namespace kr

@@ -1,0 +1,602 @@
+// Device-resident CG / PCG / BiCGStab / GMRES(m): LinearSolver::solve (src/solver/mod.rs:30-52) for a HIP CSR
+// operator.  Each solver restates its reference file operation by operation (line numbers cited inline); the
+// vector work is fused into as few HBM passes as the data dependences allow without changing any rounding.
+#include "solver_common.h"
+
+namespace kr {
+
+// =================================================================== shared vector ops
+struct DotPairOp {
+    static constexpr int NQ = 2;
+    const double *a, *b, *c, *d;
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
+        const d2 u = ld2(a, i), v = ld2(b, i), w = ld2(c, i), z = ld2(d, i);
+        if (in0) { acc[0] = acc[0] + u.a * v.a; acc[1] = acc[1] + w.a * z.a; }
+        if (in1) { acc[0] = acc[0] + u.b * v.b; acc[1] = acc[1] + w.b * z.b; }
+    }
+};
+struct AypxDevOp {                   // y = x + beta*y  (cg.rs:274-276, pcg.rs:215-217), beta on the device
+    static constexpr int NQ = 0;
+    const double* beta; const double* x; double* y;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const double be = *beta;
+        const d2 a = ld2(x, i), b = ld2(y, i);
+        st2(y, i, a.a + be * b.a, a.b + be * b.b);
+    }
+};
+
+// =================================================================== CG (src/solver/cg.rs:114-288)
+// x += alpha p ; r -= alpha Ap (cg.rs:207-212) ; partial r.r (cg.rs:223) [; partial r.p for the Natural norm, :227]
+struct CgUpdate1 {
+    static constexpr int NQ = 1;
+    const double* alpha; const double* p; const double* ap; double* x; double* r;
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
+        const double al = *alpha;
+        const d2 pp = ld2(p, i), aa = ld2(ap, i), xx = ld2(x, i), rr = ld2(r, i);
+        const double x0 = xx.a + al * pp.a, x1 = xx.b + al * pp.b;
+        const double r0 = rr.a - al * aa.a, r1 = rr.b - al * aa.b;
+        st2(x, i, x0, x1); st2(r, i, r0, r1);
+        if (in0) acc[0] = acc[0] + r0 * r0;
+        if (in1) acc[0] = acc[0] + r1 * r1;
+    }
+};
+struct CgUpdate2 {                   // + r.p (old p) for CgNormType::Natural
+    static constexpr int NQ = 2;
+    const double* alpha; const double* p; const double* ap; double* x; double* r;
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
+        const double al = *alpha;
+        const d2 pp = ld2(p, i), aa = ld2(ap, i), xx = ld2(x, i), rr = ld2(r, i);
+        const double x0 = xx.a + al * pp.a, x1 = xx.b + al * pp.b;
+        const double r0 = rr.a - al * aa.a, r1 = rr.b - al * aa.b;
+        st2(x, i, x0, x1); st2(r, i, r0, r1);
+        if (in0) { acc[0] = acc[0] + r0 * r0; acc[1] = acc[1] + r0 * pp.a; }
+        if (in1) { acc[0] = acc[0] + r1 * r1; acc[1] = acc[1] + r1 * pp.b; }
+    }
+};
+struct CgUpdate0 {                   // no fused dot (PCG with a non-pointwise preconditioner)
+    static constexpr int NQ = 0;
+    const double* alpha; const double* p; const double* ap; double* x; double* r;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const double al = *alpha;
+        const d2 pp = ld2(p, i), aa = ld2(ap, i), xx = ld2(x, i), rr = ld2(r, i);
+        st2(x, i, xx.a + al * pp.a, xx.b + al * pp.b);
+        st2(r, i, rr.a - al * aa.a, rr.b - al * aa.b);
+    }
+};
+
+struct CgInitLogic {                 // cg.rs:127-140
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        st->rsq = red[0];
+        st->res0 = dsqrt(st->rsq);
+        st->iterations = 0; st->final_residual = st->res0; st->converged = 0; st->iter = 0;
+        // dp: Preconditioned/Unpreconditioned = (r,r); Natural = (r,p) with p == r; None = 0
+        const double dp = (c.norm_type == 3) ? 0.0 : st->rsq;
+        c.push(dsqrt(dp));
+        if (c.max_iters <= 0) c.finish(KRYST_OK);
+    }
+};
+struct CgAlphaLogic {                // cg.rs:164-175
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        const double p_dot_ap = red[0];
+        if (p_dot_ap <= 0.0) {                                         // :168-174
+            st->iterations = st->iter + 1; st->final_residual = dsqrt(st->rsq); st->converged = 0;
+            c.finish(KRYST_INDEFINITE_MATRIX);
+            return;
+        }
+        st->alpha = st->rsq / p_dot_ap;                                // :175
+    }
+};
+struct CgBetaLogic {                 // cg.rs:223-284
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        const long long i = st->iter + 1;
+        const double rsq_new = red[0];
+        double res_norm;
+        switch (c.norm_type) {                                         // :224-229
+            case 0: case 1: res_norm = dsqrt(rsq_new); break;
+            case 2: res_norm = dsqrt(fabs(red[1])); break;
+            default: res_norm = 0.0;
+        }
+        if (rsq_new / st->rsq < 0.0) {                                 // :254-259
+            st->iterations = i; st->final_residual = res_norm; st->converged = 0;
+            c.finish(KRYST_INDEFINITE_PRECONDITIONER);
+            return;
+        }
+        c.push(res_norm);                                              // :260-263
+        st->iter = i;
+        if (c.check(res_norm, st->res0, i)) { c.finish(KRYST_OK); return; }   // :264-269
+        st->beta = rsq_new / st->rsq;                                  // :270
+        st->rsq = rsq_new;                                             // :284
+    }
+};
+
+static int32_t solve_args_check(const SolveIO& io, kryst_vec_t b, kryst_vec_t x) {
+    KR_ARG(io.a && io.params && b && x, "solve: null argument");
+    KR_ARG(b->ctx == io.a->ctx && x->ctx == io.a->ctx, "solve: context mismatch");
+    KR_ARG(io.a->nrows == io.a->xlen, "solve: square operator required");
+    KR_ARG(b->n == io.a->nrows && x->n == io.a->nrows, "solve: vector length != operator size");
+    KR_ARG(io.params->max_iters >= 0, "solve: max_iters < 0");
+    KR_ARG(!io.pc || io.pc->ctx == io.a->ctx, "solve: preconditioner belongs to another context");
+    KR_ARG(!io.pc || io.pc->n < 0 || io.pc->n == io.a->nrows, "solve: preconditioner size mismatch");
+    return KRYST_OK;
+}
+
+static void run_monitor(const SolveIO& io, Workspace& ws, int64_t first_iter) {
+    if (!io.monitor) return;
+    DevState h;
+    if (hipMemcpy(&h, ws.st, sizeof(DevState), hipMemcpyDeviceToHost) != hipSuccess) return;
+    for (int64_t k = 0; k < h.hist_len && k < ws.hist_cap; ++k) io.monitor(first_iter + k, ws.h_hist[k], io.user);
+}
+
+// A solve split into begin / iterate / end so that the same code serves the one-shot LinearSolver::solve
+// entry points and the stepping session bench.py uses to time exactly K iterations.
+struct SolverRun {
+    kryst_vec_t bv, xv; SolveIO io; kryst_params_t prm;
+    kryst_csr_t a; kryst_ctx_t ctx; int64_t n, nt;
+    Workspace ws; LogicCtx lc; const int* done = nullptr; double* xw = nullptr;
+    kryst_pc_s pcl; kryst_pc_t pc = nullptr;
+    int64_t next_iter = 1;
+    SolverRun(kryst_vec_t b, kryst_vec_t x, const SolveIO& io_)
+        : bv(b), xv(x), io(io_), prm(*io_.params), a(io_.a), ctx(io_.a->ctx), n(io_.a->nrows), nt(ntiles_of(io_.a->nrows)),
+          ws(io_.a->ctx, io_.a->nrows) { io.params = &prm; }
+    virtual ~SolverRun() {}
+    virtual int32_t begin() = 0;
+    virtual int32_t iterate(int64_t i) = 0;
+    int32_t common_begin(int64_t hist_entries) {
+        KR_HIP(hipSetDevice(ctx->device));
+        if (io.pc) { pcl = *io.pc; if (pcl.n < 0) pcl.n = n; pc = &pcl; }
+        KR_TRY(ws.init(hist_entries));
+        lc = ws.lctx(&prm);
+        done = &ws.st->done;
+        KR_TRY(ws.vec(&xw));
+        KR_HIP(hipMemcpyAsync(xw, xv->d, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));
+        return KRYST_OK;
+    }
+    int32_t step(int64_t k) {                // enqueue k more iterations, no host synchronisation
+        for (int64_t j = 0; j < k && next_iter <= prm.max_iters; ++j, ++next_iter) KR_TRY(iterate(next_iter));
+        return KRYST_OK;
+    }
+    int32_t end() {
+        KR_HIP(hipStreamSynchronize(ctx->s_comm));
+        KR_HIP(hipStreamSynchronize(ctx->s_main));
+        const int32_t status = finish_solve(ws, io);
+        if (status == KRYST_OK)                  // on Err the reference never reaches `*x = ...`
+            KR_HIP(hipMemcpyAsync(xv->d, xw, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));
+        KR_HIP(hipStreamSynchronize(ctx->s_main));
+        run_monitor(io, ws, 0);
+        return status;
+    }
+    int32_t solve() {
+        KR_TRY(begin());
+        KR_TRY(run_ahead(ctx, &prm, [&](int64_t i) -> int32_t { next_iter = i + 1; return iterate(i); }));
+        return end();
+    }
+};
+
+struct CgRun : SolverRun {
+    using SolverRun::SolverRun;
+    double *r = nullptr, *pp = nullptr, *ap = nullptr;
+    int32_t begin() override {
+        KR_TRY(solve_args_check(io, bv, xv));
+        if (prm.has_radius || prm.has_obj_target) { set_error("CG trust-region / objective-target exits are not implemented on the device"); return KRYST_UNSUPPORTED; }
+        KR_TRY(common_begin(prm.max_iters + 2));                                                  // cg.rs:117
+        KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&ap));
+        KR_TRY(residual_dot(a, bv->d, xw, r, ap, nullptr));                                       // :120-125, :127
+        KR_HIP(hipMemcpyAsync(pp, r, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));      // :126
+        return reduce_then<1>(ctx, nt, ws.red, CgInitLogic{lc});
+    }
+    int32_t iterate(int64_t) override {
+        KR_TRY(launch_spmv(a, pp, ap, 1, pp, done));                                              // :143-144 + (p,Ap) :164
+        KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgAlphaLogic{lc})));
+        if (prm.norm_type == 2) {
+            KR_TRY(launch_ew(ctx, CgUpdate2{&ws.st->alpha, pp, ap, xw, r}, n, done));
+            KR_TRY((reduce_then<2>(ctx, nt, ws.red, CgBetaLogic{lc})));
+        } else {
+            KR_TRY(launch_ew(ctx, CgUpdate1{&ws.st->alpha, pp, ap, xw, r}, n, done));             // :207-212 + (r,r) :223
+            KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgBetaLogic{lc})));
+        }
+        return launch_ew(ctx, AypxDevOp{&ws.st->beta, r, pp}, n, done);                           // :274-276
+    }
+};
+
+int32_t cg_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
+    KR_ARG(io.a && io.params, "solve: null argument");
+    CgRun run(bv, xv, io);
+    return run.solve();
+}
+
+// =================================================================== PCG (src/solver/pcg.rs:114-222)
+// fused update for z == r (pc None / identity) and z = D^-1 r (Jacobi):
+//   x += alpha p ; r -= alpha Ap ; z = M^-1 r ; partial 0 = r.z ; partial 1 = norm quantity (z.z | r.r)
+template <bool JACOBI>
+struct PcgUpdateOp {
+    static constexpr int NQ = 2;
+    const double* alpha; const double* p; const double* ap; double* x; double* r; double* z; const double* inv;
+    int norm_type;
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
+        const double al = *alpha;
+        const d2 pp = ld2(p, i), aa = ld2(ap, i), xx = ld2(x, i), rr = ld2(r, i);
+        const double x0 = xx.a + al * pp.a, x1 = xx.b + al * pp.b;                   // pcg.rs:175-177
+        const double r0 = rr.a - al * aa.a, r1 = rr.b - al * aa.b;                   // pcg.rs:179-181
+        st2(x, i, x0, x1); st2(r, i, r0, r1);
+        double z0 = r0, z1 = r1;
+        if constexpr (JACOBI) {
+            const d2 dv = ld2(inv, i);
+            z0 = dv.a * r0; z1 = dv.b * r1;                                          // jacobi.rs:84-86
+            st2(z, i, z0, z1);
+        }
+        const bool zz = norm_type == 0;                                              // Preconditioned: (z,z); else (r,r)
+        if (in0) { acc[0] = acc[0] + r0 * z0; acc[1] = acc[1] + (zz ? z0 * z0 : r0 * r0); }
+        if (in1) { acc[0] = acc[0] + r1 * z1; acc[1] = acc[1] + (zz ? z1 * z1 : r1 * r1); }
+    }
+};
+
+struct PcgInitLogic {                // pcg.rs:133-146 ; red0 = (r,z), red1 = (z,z) | (r,r)
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        st->rz = red[0];
+        st->res0 = dsqrt(fabs(st->rz));                                // :134
+        st->iterations = 0; st->final_residual = st->res0; st->converged = 0; st->iter = 0;
+        double dp;
+        switch (c.norm_type) { case 0: case 1: dp = red[1]; break; case 2: dp = red[0]; break; default: dp = 0.0; }
+        st->normq = dp;
+        c.push(dsqrt(dp));                                             // :143-146 (no abs at iteration 0)
+        if (c.max_iters <= 0) c.finish(KRYST_OK);
+    }
+};
+struct PcgAlphaLogic {               // pcg.rs:151-173
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        const double p_dot_ap = red[0];
+        if (p_dot_ap <= 0.0) {                                         // :162-172 (the dots of the unchanged r, z)
+            st->iterations = st->iter + 1;
+            st->final_residual = (c.norm_type == 3) ? 0.0 : dsqrt(c.norm_type == 2 ? fabs(st->normq) : st->normq);
+            st->converged = 0;
+            c.finish(KRYST_INDEFINITE_MATRIX);
+            return;
+        }
+        st->alpha = st->rz / p_dot_ap;                                 // :173
+    }
+};
+struct PcgBetaLogic {                // pcg.rs:188-218
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        const long long i1 = st->iter + 1;                             // the reference's i + 1
+        const double rz_new = red[0];
+        double res_norm;
+        switch (c.norm_type) {                                         // :190-195
+            case 0: case 1: res_norm = dsqrt(red[1]); st->normq = red[1]; break;
+            case 2: res_norm = dsqrt(fabs(rz_new)); st->normq = rz_new; break;
+            default: res_norm = 0.0;
+        }
+        c.push(res_norm);                                              // :196-199
+        st->iter = i1;
+        if (c.check(res_norm, st->res0, i1)) { c.finish(KRYST_OK); return; }   // :200-205
+        const double beta = rz_new / st->rz;                           // :206
+        if (beta < 0.0) {                                              // :208-213
+            st->iterations = i1; st->final_residual = res_norm; st->converged = 0;
+            c.finish(KRYST_INDEFINITE_PRECONDITIONER);
+            return;
+        }
+        st->beta = beta;
+        st->rz = rz_new;                                               // :218
+    }
+};
+
+struct PcgRun : SolverRun {
+    using SolverRun::SolverRun;
+    double *r = nullptr, *z = nullptr, *pp = nullptr, *ap = nullptr;
+    bool alias = false, jac = false;
+    int32_t begin() override {
+        KR_TRY(solve_args_check(io, bv, xv));
+        if (prm.has_radius || prm.has_obj_target) { set_error("PCG radius / objective target are not implemented on the device"); return KRYST_UNSUPPORTED; }
+        KR_TRY(common_begin(prm.max_iters + 2));                                                  // pcg.rs:117
+        alias = !pc || pc->kind == KR_PC_IDENTITY;      // z == r  (pcg.rs:130,186 clone_from / IdentityPC)
+        jac = pc && pc->kind == KR_PC_JACOBI;
+        KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&ap));
+        if (alias) z = r; else KR_TRY(ws.vec(&z));
+        KR_TRY(launch_spmv(a, xw, ap, 0, nullptr, nullptr));                                      // :119-124
+        KR_TRY(launch_ew(ctx, SubDotOp{bv->d, ap, r}, n, nullptr));
+        if (!alias) KR_TRY(pc_apply_dev(pc, r, z, nullptr));                                      // :127-131 (`?`)
+        KR_HIP(hipMemcpyAsync(pp, z, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));      // :132
+        const double* nq_a = (prm.norm_type == 0) ? z : r;      // Preconditioned: (z,z); Unpreconditioned: (r,r)
+        KR_TRY(launch_ew(ctx, DotPairOp{r, z, nq_a, nq_a}, n, nullptr));
+        return reduce_then<2>(ctx, nt, ws.red, PcgInitLogic{lc});
+    }
+    int32_t iterate(int64_t) override {
+        const int nt_ = prm.norm_type;
+        KR_TRY(launch_spmv(a, pp, ap, 1, pp, done));                                              // :149-160
+        KR_TRY((reduce_then<1>(ctx, nt, ws.red, PcgAlphaLogic{lc})));
+        if (alias) {
+            KR_TRY(launch_ew(ctx, PcgUpdateOp<false>{&ws.st->alpha, pp, ap, xw, r, z, nullptr, nt_}, n, done));
+        } else if (jac) {
+            KR_TRY(launch_ew(ctx, PcgUpdateOp<true>{&ws.st->alpha, pp, ap, xw, r, z, pc->d_inv_diag, nt_}, n, done));
+        } else {
+            KR_TRY(launch_ew(ctx, CgUpdate0{&ws.st->alpha, pp, ap, xw, r}, n, done));             // :175-181
+            KR_TRY(pc_apply_dev(pc, r, z, done));                                                 // :183-187
+            const double* nq_a = (nt_ == 0) ? z : r;
+            KR_TRY(launch_ew(ctx, DotPairOp{r, z, nq_a, nq_a}, n, done));                         // :188-195
+        }
+        KR_TRY((reduce_then<2>(ctx, nt, ws.red, PcgBetaLogic{lc})));
+        return launch_ew(ctx, AypxDevOp{&ws.st->beta, z, pp}, n, done);                           // :215-217
+    }
+};
+
+int32_t pcg_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
+    KR_ARG(io.a && io.params, "solve: null argument");
+    PcgRun run(bv, xv, io);
+    return run.solve();
+}
+
+// =================================================================== BiCGStab (src/solver/bicgstab.rs:69-293)
+struct BicgPOp {                     // p = r + beta*(p - omega_prev*v)   (bicgstab.rs:134/140)
+    static constexpr int NQ = 0;
+    const DevState* st; const double* r; const double* v; double* p;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const double be = st->beta, om = st->omega_prev;
+        const d2 rr = ld2(r, i), vv = ld2(v, i), pp = ld2(p, i);
+        st2(p, i, rr.a + be * (pp.a - om * vv.a), rr.b + be * (pp.b - om * vv.b));
+    }
+};
+struct BicgSOp {                     // s = r - alpha*v ; partial s.s     (bicgstab.rs:166-188)
+    static constexpr int NQ = 1;
+    const DevState* st; const double* r; const double* v; double* s;
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
+        const double al = st->alpha;
+        const d2 rr = ld2(r, i), vv = ld2(v, i);
+        const double s0 = rr.a - al * vv.a, s1 = rr.b - al * vv.b;
+        st2(s, i, s0, s1);
+        if (in0) acc[0] = acc[0] + s0 * s0;
+        if (in1) acc[0] = acc[0] + s1 * s1;
+    }
+};
+// x = x + alpha*p + omega*s ; r = s - omega*t ; partials r.r and rhat.r (the next rho)   (bicgstab.rs:240-279,105-116)
+// when the s-norm exit is pending (st->early): only x = x + alpha*p   (bicgstab.rs:191-202)
+struct BicgXROp {
+    static constexpr int NQ = 2;
+    const DevState* st; const double* p; const double* s; const double* t; const double* rhat; double* x; double* r;
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
+        const double al = st->alpha;
+        const d2 pp = ld2(p, i), xx = ld2(x, i);
+        if (st->early) { st2(x, i, xx.a + al * pp.a, xx.b + al * pp.b); return; }
+        const double om = st->omega;
+        const d2 ss = ld2(s, i), tt = ld2(t, i), hh = ld2(rhat, i);
+        st2(x, i, xx.a + al * pp.a + om * ss.a, xx.b + al * pp.b + om * ss.b);
+        const double r0 = ss.a - om * tt.a, r1 = ss.b - om * tt.b;
+        st2(r, i, r0, r1);
+        if (in0) { acc[0] = acc[0] + r0 * r0; acc[1] = acc[1] + hh.a * r0; }
+        if (in1) { acc[0] = acc[0] + r1 * r1; acc[1] = acc[1] + hh.b * r1; }
+    }
+};
+// like ew_kernel's gate but keeps running for a pending early exit
+template <class Op>
+__global__ __launch_bounds__(KR_T) void ew_kernel_early(Op op, int64_t n, int64_t ntiles, double* partials,
+                                                        int64_t pstride, const DevState* st) {
+    if (st->done && !st->early) return;
+    constexpr int NQ = Op::NQ;
+    __shared__ double lds[NQ * (KR_T / 64)];
+    for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
+        const int64_t i = q * KR_TILE + (int64_t)threadIdx.x * KR_V;
+        double acc[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) acc[k] = 0.0;
+        op.pair(i, i < n, i + 1 < n, acc);
+        block_reduce<NQ, KR_T / 64>(acc, lds);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) partials[k * pstride + q] = acc[k];
+        }
+    }
+}
+
+struct BicgInitLogic {               // bicgstab.rs:79-102 ; red0 = (r,r) = (rhat,r)
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        st->res0 = dsqrt(red[0]);
+        st->iterations = 0; st->final_residual = st->res0; st->converged = 0; st->iter = 0;
+        st->rho_prev = 1.0; st->alpha = 1.0; st->omega_prev = 1.0;
+        c.push(st->res0);
+        if (st->res0 <= c.tol) { st->converged = 1; c.finish(KRYST_OK); return; }   // :98-102 absolute tolerance
+        if (c.max_iters <= 0) { c.finish(KRYST_OK); return; }
+        st->rho = red[0];                                              // i = 1: rho = (rhat, r), rhat == r
+        if (fabs(st->rho) < DBL_EPSILON) { c.finish(KRYST_OK); return; }   // :117-119 break
+        st->beta = 0.0;                                                // :120-121
+    }
+};
+struct BicgAlphaLogic {              // bicgstab.rs:149-164 ; red0 = (rhat, v)
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        const double alpha_den = red[0];
+        if (fabs(alpha_den) < DBL_EPSILON) { c.finish(KRYST_OK); return; }   // :161-163 break (stats unchanged)
+        st->alpha = st->rho / alpha_den;
+    }
+};
+struct BicgSLogic {                  // bicgstab.rs:177-206 ; red0 = (s,s)
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        const double s_norm = dsqrt(red[0]);
+        if (s_norm <= c.tol) {
+            st->iterations = st->iter + 1; st->final_residual = s_norm; st->converged = 1;
+            c.push(s_norm);
+            st->early = 1;
+            c.finish(KRYST_OK);
+        }
+    }
+};
+struct BicgOmegaLogic {              // bicgstab.rs:211-238 ; red0 = (t,s), red1 = (t,t)
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        if (fabs(red[1]) < DBL_EPSILON) { c.finish(KRYST_OK); return; }   // :235-237 break
+        st->omega = red[0] / red[1];
+    }
+};
+struct BicgEndLogic {                // bicgstab.rs:268-289 then the head of the next iteration :105-124
+    static constexpr bool RUN_WHEN_DONE = true;
+    LogicCtx c;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        if (st->early) { st->early = 0; return; }
+        if (st->done) return;
+        const long long i = st->iter + 1;
+        const double r_norm = dsqrt(red[0]);
+        st->iterations = i; st->final_residual = r_norm; st->converged = (r_norm <= c.tol) ? 1 : 0;   // :280
+        c.push(r_norm);
+        st->iter = i;
+        if (r_norm <= c.tol) { c.finish(KRYST_OK); return; }           // :281-284
+        if (fabs(st->omega) < DBL_EPSILON) { c.finish(KRYST_OK); return; }   // :285-287 break
+        st->rho_prev = st->rho; st->omega_prev = st->omega;           // :288-289
+        if (i >= c.max_iters) { c.finish(KRYST_OK); return; }          // loop `1..=max_iters` exhausted
+        st->rho = red[1];                                              // :105-116
+        if (fabs(st->rho) < DBL_EPSILON) { c.finish(KRYST_OK); return; }   // :117-119
+        st->beta = (st->rho / st->rho_prev) * (st->alpha / st->omega_prev);   // :123
+    }
+};
+
+struct BicgRun : SolverRun {
+    bool right_pc;
+    double *r = nullptr, *rhat = nullptr, *v = nullptr, *pp = nullptr, *s = nullptr, *t = nullptr, *ph = nullptr, *sh = nullptr;
+    BicgRun(kryst_vec_t b, kryst_vec_t x, const SolveIO& io_, bool rp) : SolverRun(b, x, io_), right_pc(rp) {}
+    int32_t begin() override {
+        KR_TRY(solve_args_check(io, bv, xv));
+        KR_TRY(common_begin(prm.max_iters + 2));                                                  // :73
+        if (!right_pc) pc = nullptr;                     // bicgstab.rs:70: the reference ignores pc; the _rpc extension uses it
+        if (pc && pc->kind == KR_PC_IDENTITY) pc = nullptr;
+        KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&rhat)); KR_TRY(ws.vec(&v)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&s)); KR_TRY(ws.vec(&t));
+        if (pc) { KR_TRY(ws.vec(&ph)); KR_TRY(ws.vec(&sh)); }
+        KR_TRY(residual_dot(a, bv->d, xw, r, t, nullptr));                                        // :75-77, :85-96
+        KR_HIP(hipMemcpyAsync(rhat, r, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));    // :78
+        KR_HIP(hipMemcpyAsync(pp, r, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));      // :83
+        return reduce_then<1>(ctx, nt, ws.red, BicgInitLogic{lc});
+    }
+    int32_t iterate(int64_t) override {
+        const DevState* st = ws.st;
+        KR_TRY(launch_ew(ctx, BicgPOp{st, r, v, pp}, n, done));                                   // :126-142
+        if (pc) { KR_TRY(pc_apply_dev(pc, pp, ph, done)); KR_TRY(launch_spmv(a, ph, v, 1, rhat, done)); }
+        else KR_TRY(launch_spmv(a, pp, v, 1, rhat, done));                                        // :144-146 + (rhat,v)
+        KR_TRY((reduce_then<1>(ctx, nt, ws.red, BicgAlphaLogic{lc})));
+        KR_TRY(launch_ew(ctx, BicgSOp{st, r, v, s}, n, done));                                    // :166-188
+        KR_TRY((reduce_then<1>(ctx, nt, ws.red, BicgSLogic{lc})));
+        if (pc) { KR_TRY(pc_apply_dev(pc, s, sh, done)); KR_TRY(launch_spmv(a, sh, t, 2, s, done)); }
+        else KR_TRY(launch_spmv(a, s, t, 2, s, done));                                            // :208-209 + (t,s),(t,t)
+        KR_TRY((reduce_then<2>(ctx, nt, ws.red, BicgOmegaLogic{lc})));
+        KR_TRY(ensure_partials(ctx, nt));
+        const BicgXROp op{st, pc ? ph : pp, pc ? sh : s, t, rhat, xw, r};
+        const int64_t grid = std::min<int64_t>(nt, (int64_t)ctx->num_cu * 8);
+        if (grid > 0) {
+            hipLaunchKernelGGL((ew_kernel_early<BicgXROp>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, n, nt,
+                               ctx->d_partials, ctx->partials_cap, st);
+            KR_HIP(hipGetLastError());
+        }
+        return reduce_then<2>(ctx, nt, ws.red, BicgEndLogic{lc});
+    }
+};
+
+int32_t bicgstab_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, bool right_pc) {
+    KR_ARG(io.a && io.params, "solve: null argument");
+    BicgRun run(bv, xv, io, right_pc);
+    return run.solve();
+}
+
+int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io);    // gmres.hip
+
+}  // namespace kr
+
+using namespace kr;
+
+// host-slice entry points: upload b and the initial guess, solve on the device, download x
+template <class F>
+static int32_t host_solve(const double* b, double* x, int64_t n, const SolveIO& io, F f) {
+    KR_ARG(io.a && b && x, "solve: null argument");
+    KR_ARG(n == io.a->nrows, "solve: b.len() != nrows");
+    kryst_vec_t bv = nullptr, xv = nullptr;
+    KR_TRY(kryst_vec_create(io.a->ctx, n, &bv));
+    int32_t rc = kryst_vec_create(io.a->ctx, n, &xv);
+    if (rc == KRYST_OK) rc = kryst_vec_upload(bv, b, n);
+    if (rc == KRYST_OK) rc = kryst_vec_upload(xv, x, n);
+    if (rc == KRYST_OK) {
+        rc = f(bv, xv, io);
+        if (rc == KRYST_OK) { int32_t rd = kryst_vec_download(xv, x, n); if (rd != KRYST_OK) rc = rd; }
+    }
+    kryst_vec_destroy(bv); kryst_vec_destroy(xv);
+    return rc;
+}
+
+#define IO_FROM_ARGS SolveIO io{a, pc, params, stats, hist, hist_cap, hist_len, monitor, user}
+
+struct kryst_session_s { SolverRun* run; };
+
+extern "C" {
+
+int32_t kryst_session_begin(int32_t method, kryst_vec_t b, kryst_vec_t x, kryst_csr_t a, kryst_pc_t pc,
+                            const kryst_params_t* params, kryst_session_t* out) {
+    KR_ARG(a && params && b && x && out, "session_begin: null argument");
+    SolveIO io{a, pc, params, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+    SolverRun* run = nullptr;
+    switch (method) {
+        case 0: run = new CgRun(b, x, io); break;
+        case 1: run = new PcgRun(b, x, io); break;
+        case 2: run = new BicgRun(b, x, io, false); break;
+        default: set_error("session_begin: unknown method %d", method); return KRYST_ERR_ARG;
+    }
+    const int32_t rc = run->begin();
+    if (rc != KRYST_OK) { delete run; return rc; }
+    *out = new kryst_session_s{run};
+    return KRYST_OK;
+}
+
+int32_t kryst_session_step(kryst_session_t s, int64_t k) {
+    KR_ARG(s && s->run && k >= 0, "session_step");
+    return s->run->step(k);
+}
+
+int32_t kryst_session_end(kryst_session_t s, kryst_stats_t* stats, double* hist, int64_t hist_cap, int64_t* hist_len) {
+    KR_ARG(s && s->run, "session_end");
+    s->run->io.stats = stats; s->run->io.hist = hist; s->run->io.hist_cap = hist_cap; s->run->io.hist_len = hist_len;
+    const int32_t rc = s->run->end();
+    delete s->run;
+    delete s;
+    return rc;
+}
+
+int32_t kryst_cg_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return cg_solve(b, x, io); }
+int32_t kryst_pcg_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return pcg_solve(b, x, io); }
+int32_t kryst_gmres_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return gmres_solve(b, x, io); }
+int32_t kryst_bicgstab_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return bicgstab_solve(b, x, io, false); }
+int32_t kryst_bicgstab_rpc_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return bicgstab_solve(b, x, io, true); }
+
+int32_t kryst_cg_solve(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) {
+    IO_FROM_ARGS; return host_solve(b, x, n, io, [](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return cg_solve(bv, xv, i); });
+}
+int32_t kryst_pcg_solve(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) {
+    IO_FROM_ARGS; return host_solve(b, x, n, io, [](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return pcg_solve(bv, xv, i); });
+}
+int32_t kryst_gmres_solve(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) {
+    IO_FROM_ARGS; return host_solve(b, x, n, io, [](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return gmres_solve(bv, xv, i); });
+}
+int32_t kryst_bicgstab_solve(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) {
+    IO_FROM_ARGS; return host_solve(b, x, n, io, [](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return bicgstab_solve(bv, xv, i, false); });
+}
+
+}  // extern "C"

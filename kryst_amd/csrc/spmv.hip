@@ -1,0 +1,433 @@
+// CSR SpMV for gfx950 -- replaces CsrMatrix::spmv / spmv_parallel (src/matrix/sparse.rs:56-67,103-114).
+//
+// Design (HBM-bound, 0.134 flop/B; MFMA is useless here):
+//  * a workgroup owns one ROW TILE of KR_TILE = 512 consecutive rows (thread t: rows 2t, 2t+1) and streams the
+//    tile's contiguous nnz range through LDS in windows of SPMV_LCAP entries:
+//      phase 1  every lane loads a PAIR of consecutive entries (8 B of col_idx + 16 B of values per lane, fully
+//               coalesced, 4 pairs in flight per lane), gathers x[col] (L1/L2/MALL hits: the stencil's x reuse),
+//               multiplies and writes the products to LDS with one 16-byte ds_write;
+//      phase 2  the row's owner lane sums its LDS segment in ASCENDING column order starting from 0.0 with
+//               separate mul and add -- bit-identical to the reference's per-row loop (sparse.rs:107-113).
+//    Rows longer than a window simply continue their running sum in the next window (still ascending).
+//  * y is written 16 B per lane; optional fused inner products (d.y, y.y) reuse the tile's rows and produce
+//    one partial per tile in the library-wide association order (see ew.h), so CG's (p,Ap) costs no extra pass.
+//  * XCD-aware placement: workgroups that share blockIdx%8 share an XCD (and its 4 MiB L2); each XCD walks its
+//    own contiguous eighth of the tiles so that the x planes a tile needs were fetched by that same L2.
+//  * distributed: interior tiles run while the halo planes travel over xGMI on a second stream; boundary
+//    tiles follow.  Column indices >= nloc address the halo buffer.
+#include "csr.h"
+#include "ew.h"
+#include <algorithm>
+
+#ifndef SPMV_LCAP
+#define SPMV_LCAP 3648                      // LDS window in entries (28.5 KiB): 5 workgroups per CU
+#endif
+#define SPMV_PAIRS (SPMV_LCAP / 2)
+#define SPMV_SLOTS ((SPMV_PAIRS + KR_T - 1) / KR_T)    // pair slots per lane per window (8)
+#define SPMV_BATCH 4                        // pairs in flight per lane
+
+namespace kr {
+
+typedef int    v2i __attribute__((ext_vector_type(2)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+struct SpmvArgs {
+    const int32_t* row_ptr; const int32_t* col; const double* val;
+    const double* x; const double* halo; int32_t nloc;
+    double* y; const int32_t* tiles; int32_t ntiles; int32_t nrows;
+    const double* dvec; double* partials; int64_t pstride;
+    const int* done; int32_t xcd_chunk;
+};
+
+template <bool HALO>
+__device__ __forceinline__ double gather(const SpmvArgs& a, int32_t c) {
+    if constexpr (HALO) {
+        const double* base = (c < a.nloc) ? a.x : (a.halo - a.nloc);
+        return base[c];
+    } else {
+        return a.x[c];
+    }
+}
+
+template <int NQ, bool HALO>
+__global__ __launch_bounds__(KR_T) void spmv_kernel(const SpmvArgs a) {
+    if (a.done && *a.done) return;
+    __shared__ __attribute__((aligned(16))) double prod[SPMV_LCAP];
+    __shared__ double red[(NQ > 0 ? NQ : 1) * (KR_T / 64)];
+    const int t = threadIdx.x;
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, per = gridDim.x >> 3;
+    for (int li = slot0; li < a.xcd_chunk; li += per) {
+        const int ti = xcd * a.xcd_chunk + li;
+        if (ti >= a.ntiles) break;
+        const int q = a.tiles ? a.tiles[ti] : ti;
+        const int r0 = q * KR_TILE;
+        const int r1 = min(r0 + KR_TILE, a.nrows);
+        const int row = r0 + 2 * t;
+        const int p0 = a.row_ptr[min(row, r1)];
+        const int p1 = a.row_ptr[min(row + 1, r1)];
+        const int p2 = a.row_ptr[min(row + 2, r1)];
+        const int k0 = a.row_ptr[r0], k1 = a.row_ptr[r1];
+        double s0 = 0.0, s1 = 0.0;
+        for (int base = k0 & ~1; base < k1; base += SPMV_LCAP) {
+            const int wend = min(base + SPMV_LCAP, k1);
+            const int npairs = (wend - base + 1) >> 1;
+            // ---- phase 1: coalesced pair loads, x gather, products to LDS
+            for (int jb = 0; jb * KR_T < npairs; jb += SPMV_BATCH) {
+                v2i c[SPMV_BATCH]; v2d v[SPMV_BATCH]; double xa[SPMV_BATCH], xb[SPMV_BATCH];
+#pragma unroll
+                for (int j = 0; j < SPMV_BATCH; ++j) {
+                    const int pi = min(t + (jb + j) * KR_T, npairs - 1);       // clamp: branch-free loads
+                    const int k = base + 2 * pi;
+                    c[j] = __builtin_nontemporal_load(reinterpret_cast<const v2i*>(a.col + k));
+                    v[j] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(a.val + k));
+                }
+#pragma unroll
+                for (int j = 0; j < SPMV_BATCH; ++j) {
+                    xa[j] = gather<HALO>(a, c[j].x);
+                    xb[j] = gather<HALO>(a, c[j].y);
+                }
+#pragma unroll
+                for (int j = 0; j < SPMV_BATCH; ++j) {
+                    const int pi = t + (jb + j) * KR_T;
+                    if (pi < npairs)
+                        *reinterpret_cast<double2*>(&prod[2 * pi]) = make_double2(v[j].x * xa[j], v[j].y * xb[j]);
+                }
+            }
+            __syncthreads();
+            // ---- phase 2: ascending serial row sums (continuing across windows)
+            for (int k = max(p0, base); k < min(p1, wend); ++k) s0 = s0 + prod[k - base];
+            for (int k = max(p1, base); k < min(p2, wend); ++k) s1 = s1 + prod[k - base];
+            __syncthreads();
+        }
+        if (row + 1 < r1) st2(a.y, row, s0, s1);
+        else if (row < r1) a.y[row] = s0;
+        if constexpr (NQ > 0) {
+            double acc[NQ];
+            const d2 d = ld2(a.dvec, row);
+            acc[0] = 0.0;
+            if (row < r1) acc[0] = acc[0] + d.a * s0;
+            if (row + 1 < r1) acc[0] = acc[0] + d.b * s1;
+            if constexpr (NQ > 1) {
+                acc[1] = 0.0;
+                if (row < r1) acc[1] = acc[1] + s0 * s0;
+                if (row + 1 < r1) acc[1] = acc[1] + s1 * s1;
+            }
+            block_reduce<NQ, KR_T / 64>(acc, red);
+            if (t == 0) {
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) a.partials[k * a.pstride + q] = acc[k];
+            }
+        }
+    }
+}
+
+__global__ void pack_kernel(const double* x, const int32_t* idx, double* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[idx[i]];
+}
+
+static int spmv_blocks_per_cu() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("KRYST_SPMV_BLOCKS_PER_CU"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+template <bool HALO>
+static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, const double* dvec, const int* done,
+                            const int32_t* tiles, int64_t ntiles) {
+    if (ntiles == 0) return KRYST_OK;
+    kryst_ctx_t ctx = a->ctx;
+    SpmvArgs args;
+    args.row_ptr = a->d_row_ptr; args.col = a->d_col; args.val = a->d_val;
+    args.x = x; args.halo = a->plan.d_halo; args.nloc = (int32_t)a->nrows;
+    args.y = y; args.tiles = tiles; args.ntiles = (int32_t)ntiles; args.nrows = (int32_t)a->nrows;
+    args.dvec = dvec; args.partials = ctx->d_partials; args.pstride = ctx->partials_cap; args.done = done;
+    const int64_t chunk = (ntiles + 7) / 8;
+    args.xcd_chunk = (int32_t)chunk;
+    int64_t per = chunk;                                    // one tile per workgroup by default
+    const int bpc = spmv_blocks_per_cu();
+    if (bpc > 0) per = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)ctx->num_cu * bpc / 8));
+    const dim3 grid((unsigned)(per * 8)), block(KR_T);
+    switch (nq) {
+        case 0: hipLaunchKernelGGL((spmv_kernel<0, HALO>), grid, block, 0, ctx->s_main, args); break;
+        case 1: hipLaunchKernelGGL((spmv_kernel<1, HALO>), grid, block, 0, ctx->s_main, args); break;
+        case 2: hipLaunchKernelGGL((spmv_kernel<2, HALO>), grid, block, 0, ctx->s_main, args); break;
+        default: set_error("spmv: nq=%d", nq); return KRYST_ERR_ARG;
+    }
+    KR_HIP(hipGetLastError());
+    return KRYST_OK;
+}
+
+int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const double* dvec, const int* done) {
+    kryst_ctx_t ctx = a->ctx;
+    if (nq > 0) KR_TRY(ensure_partials(ctx, a->ntiles));
+    if (!a->dist || ctx->nranks == 1)
+        return launch_tiles<false>(a, x, y, nq, dvec, done, nullptr, a->ntiles);
+    // halo exchange on s_comm, overlapped with the interior tiles
+    HaloPlan& pl = a->plan;
+    KR_HIP(hipEventRecord(ctx->ev_x_ready, ctx->s_main));
+    KR_HIP(hipStreamWaitEvent(ctx->s_comm, ctx->ev_x_ready, 0));
+    const void* sendbase = pl.d_sendbuf;
+    if (a->send_contiguous) {
+        // k-slab stencils: every send list is a contiguous run of x; ship it in place
+        // (send_off then holds the first local row of each run, see kryst_csr_create_dist)
+        sendbase = x;
+    } else if (pl.total_send > 0) {
+        hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((pl.total_send + 255) / 256)), dim3(256), 0, ctx->s_comm,
+                           x, pl.d_send_idx, pl.d_sendbuf, pl.total_send);
+        KR_HIP(hipGetLastError());
+    }
+    KR_TRY(comm_exchange(ctx, sendbase, pl.send_counts.data(), pl.send_off.data(), pl.d_halo, pl.recv_counts.data(),
+                         pl.recv_off.data(), true, ctx->s_comm));
+    KR_HIP(hipEventRecord(ctx->ev_halo_done, ctx->s_comm));
+    KR_TRY(launch_tiles<true>(a, x, y, nq, dvec, done, a->d_tiles_interior, a->n_interior));
+    KR_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_halo_done, 0));
+    KR_TRY(launch_tiles<true>(a, x, y, nq, dvec, done, a->d_tiles_boundary, a->n_boundary));
+    return KRYST_OK;
+}
+
+// ---------------------------------------------------------------- creation
+static int32_t upload_csr(kryst_csr_t a, const std::vector<int32_t>& rp, const std::vector<int32_t>& col, const double* val) {
+    kryst_ctx_t ctx = a->ctx;
+    const size_t nnz = (size_t)a->nnz;
+    KR_HIP(hipMalloc(&a->d_row_ptr, sizeof(int32_t) * (rp.size() + 8)));
+    KR_HIP(hipMalloc(&a->d_col, sizeof(int32_t) * (nnz + 8)));
+    KR_HIP(hipMalloc(&a->d_val, sizeof(double) * (nnz + 8)));
+    KR_HIP(hipMemsetAsync(a->d_col + nnz, 0, sizeof(int32_t) * 8, ctx->s_main));
+    KR_HIP(hipMemsetAsync(a->d_val + nnz, 0, sizeof(double) * 8, ctx->s_main));
+    KR_HIP(hipMemcpyAsync(a->d_row_ptr, rp.data(), sizeof(int32_t) * rp.size(), hipMemcpyHostToDevice, ctx->s_main));
+    if (nnz) {
+        KR_HIP(hipMemcpyAsync(a->d_col, col.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice, ctx->s_main));
+        KR_HIP(hipMemcpyAsync(a->d_val, val, sizeof(double) * nnz, hipMemcpyHostToDevice, ctx->s_main));
+    }
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    a->ntiles = ntiles_of(a->nrows);
+    return KRYST_OK;
+}
+
+// SymbolicSparseRowMat::new_checked (sparse.rs:36-42): monotone row_ptr, in-bounds sorted duplicate-free columns
+template <class P, class I>
+static int32_t check_csr(int64_t nrows, int64_t ncols, const P* rp, const I* col) {
+    if (rp[0] != 0) { set_error("row_ptr[0] != 0"); return KRYST_ERR_CSR; }
+    for (int64_t i = 0; i < nrows; ++i) {
+        if (rp[i + 1] < rp[i]) { set_error("row_ptr not monotone at row %lld", (long long)i); return KRYST_ERR_CSR; }
+        for (int64_t k = (int64_t)rp[i]; k < (int64_t)rp[i + 1]; ++k) {
+            if ((int64_t)col[k] < 0 || (int64_t)col[k] >= ncols) { set_error("column out of range in row %lld", (long long)i); return KRYST_ERR_CSR; }
+            if (k > (int64_t)rp[i] && col[k] <= col[k - 1]) { set_error("columns not strictly ascending in row %lld", (long long)i); return KRYST_ERR_CSR; }
+        }
+    }
+    return KRYST_OK;
+}
+
+template <class P, class I>
+static int32_t create_local(kryst_ctx_t ctx, int64_t nrows, int64_t ncols, const P* rp, const I* col, const double* val,
+                            kryst_csr_t* out) {
+    KR_ARG(ctx && rp && out && nrows >= 0 && ncols >= 0, "csr_create");
+    KR_ARG(nrows < (1ll << 31) - KR_TILE && ncols < (1ll << 31), "dimension exceeds int32 device indexing");
+    const int64_t nnz = (int64_t)rp[nrows];
+    KR_ARG(nnz < (1ll << 31) - 16, "nnz exceeds int32 device indexing");
+    KR_ARG(nnz == 0 || (col && val), "csr_create: null arrays");
+    KR_TRY(check_csr(nrows, ncols, rp, col));
+    KR_HIP(hipSetDevice(ctx->device));
+    kryst_csr_t a = new kryst_csr_s();
+    a->ctx = ctx; a->nrows = nrows; a->ncols = ncols; a->xlen = ncols; a->nnz = nnz;
+    std::vector<int32_t> rp32((size_t)nrows + 1), c32((size_t)nnz);
+    for (int64_t i = 0; i <= nrows; ++i) rp32[i] = (int32_t)rp[i];
+    for (int64_t k = 0; k < nnz; ++k) c32[k] = (int32_t)col[k];
+    int32_t rc = upload_csr(a, rp32, c32, val);
+    if (rc != KRYST_OK) { kryst_csr_destroy(a); return rc; }
+    *out = a;
+    return KRYST_OK;
+}
+
+}  // namespace kr
+
+using namespace kr;
+
+extern "C" {
+
+int32_t kryst_csr_create(kryst_ctx_t ctx, int64_t nrows, int64_t ncols, const uint64_t* row_ptr, const uint64_t* col_idx,
+                         const double* vals, kryst_csr_t* out) {
+    KR_ARG(ctx && ctx->nranks == 1, "csr_create needs a single-rank context (use kryst_csr_create_dist)");
+    return create_local(ctx, nrows, ncols, (const int64_t*)row_ptr, (const int64_t*)col_idx, vals, out);
+}
+
+int32_t kryst_csr_create_i32(kryst_ctx_t ctx, int64_t nrows, int64_t ncols, const int64_t* row_ptr, const int32_t* col_idx,
+                             const double* vals, kryst_csr_t* out) {
+    KR_ARG(ctx && ctx->nranks == 1, "csr_create needs a single-rank context (use kryst_csr_create_dist)");
+    return create_local(ctx, nrows, ncols, row_ptr, col_idx, vals, out);
+}
+
+int32_t kryst_csr_create_dist(kryst_ctx_t ctx, int64_t n_global, const int64_t* row_offsets, const int64_t* row_ptr,
+                              const int64_t* col_global, const double* vals, kryst_csr_t* out) {
+    KR_ARG(ctx && row_offsets && row_ptr && out, "csr_create_dist");
+    const int P = ctx->nranks, me = ctx->rank;
+    KR_ARG(row_offsets[0] == 0 && row_offsets[P] == n_global, "row_offsets must cover [0, n_global)");
+    const int64_t lo = row_offsets[me], hi = row_offsets[me + 1], nloc = hi - lo;
+    const int64_t nnz = row_ptr[nloc];
+    KR_ARG(nloc < (1ll << 31) - KR_TILE && nnz < (1ll << 31) - 16, "local block exceeds int32 device indexing");
+    KR_TRY(check_csr(nloc, n_global, row_ptr, col_global));
+    KR_HIP(hipSetDevice(ctx->device));
+    kryst_csr_t a = new kryst_csr_s();
+    a->ctx = ctx; a->nrows = nloc; a->ncols = n_global; a->xlen = nloc; a->nnz = nnz; a->dist = true;
+    a->row_offsets.assign(row_offsets, row_offsets + P + 1);
+    HaloPlan& pl = a->plan;
+    halo_recv_plan(me, P, row_offsets, nloc, row_ptr, col_global, &pl);
+    KR_ARG(nloc + pl.total_recv < (1ll << 31), "local + halo columns exceed int32");
+    // local column numbering: owned -> c - lo, halo -> nloc + slot; classify rows / tiles
+    std::vector<int32_t> rp32((size_t)nloc + 1), c32((size_t)nnz);
+    const int64_t ntiles = ntiles_of(nloc);
+    std::vector<char> tile_bnd((size_t)ntiles, 0);
+    for (int64_t i = 0; i <= nloc; ++i) rp32[i] = (int32_t)row_ptr[i];
+    for (int64_t i = 0; i < nloc; ++i)
+        for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+            const int64_t c = col_global[k];
+            if (c >= lo && c < hi) c32[k] = (int32_t)(c - lo);
+            else { c32[k] = (int32_t)(nloc + halo_slot(pl, row_offsets, c)); tile_bnd[i / KR_TILE] = 1; }
+        }
+    int32_t rc = upload_csr(a, rp32, c32, vals);
+    if (rc != KRYST_OK) { kryst_csr_destroy(a); return rc; }
+    std::vector<int32_t> ti, tb;
+    for (int64_t q = 0; q < ntiles; ++q) (tile_bnd[q] ? tb : ti).push_back((int32_t)q);
+    a->n_interior = (int64_t)ti.size(); a->n_boundary = (int64_t)tb.size();
+    KR_HIP(hipMalloc(&a->d_tiles_interior, sizeof(int32_t) * (ti.size() + 1)));
+    KR_HIP(hipMalloc(&a->d_tiles_boundary, sizeof(int32_t) * (tb.size() + 1)));
+    if (!ti.empty()) KR_HIP(hipMemcpy(a->d_tiles_interior, ti.data(), sizeof(int32_t) * ti.size(), hipMemcpyHostToDevice));
+    if (!tb.empty()) KR_HIP(hipMemcpy(a->d_tiles_boundary, tb.data(), sizeof(int32_t) * tb.size(), hipMemcpyHostToDevice));
+    // ---- send side: every owner learns which of its rows the others need (one exchange of index lists)
+    pl.send_counts.assign(P, 0); pl.send_off.assign(P, 0);
+    if (P > 1) {
+        int64_t *d_cnt_s = nullptr, *d_cnt_r = nullptr;
+        KR_HIP(hipMalloc(&d_cnt_s, sizeof(int64_t) * P));
+        KR_HIP(hipMalloc(&d_cnt_r, sizeof(int64_t) * (size_t)P * P));
+        KR_HIP(hipMemcpy(d_cnt_s, pl.recv_counts.data(), sizeof(int64_t) * P, hipMemcpyHostToDevice));
+        KR_TRY(comm_all_gather_i64(ctx, d_cnt_s, d_cnt_r, P, ctx->s_main));
+        std::vector<int64_t> cnt((size_t)P * P);
+        KR_HIP(hipMemcpyAsync(cnt.data(), d_cnt_r, sizeof(int64_t) * cnt.size(), hipMemcpyDeviceToHost, ctx->s_main));
+        KR_HIP(hipStreamSynchronize(ctx->s_main));
+        for (int p = 0; p < P; ++p) pl.send_counts[p] = cnt[(size_t)p * P + me];   // what p receives from me
+        pl.total_send = 0;
+        for (int p = 0; p < P; ++p) { pl.send_off[p] = pl.total_send; pl.total_send += pl.send_counts[p]; }
+        int64_t *d_req = nullptr, *d_ans = nullptr;
+        KR_HIP(hipMalloc(&d_req, sizeof(int64_t) * (size_t)(pl.total_recv + 1)));
+        KR_HIP(hipMalloc(&d_ans, sizeof(int64_t) * (size_t)(pl.total_send + 1)));
+        if (pl.total_recv) KR_HIP(hipMemcpy(d_req, pl.recv_cols.data(), sizeof(int64_t) * pl.total_recv, hipMemcpyHostToDevice));
+        KR_TRY(comm_exchange(ctx, d_req, pl.recv_counts.data(), pl.recv_off.data(), d_ans, pl.send_counts.data(),
+                             pl.send_off.data(), false, ctx->s_main));
+        std::vector<int64_t> ans((size_t)pl.total_send);
+        if (pl.total_send) KR_HIP(hipMemcpyAsync(ans.data(), d_ans, sizeof(int64_t) * pl.total_send, hipMemcpyDeviceToHost, ctx->s_main));
+        KR_HIP(hipStreamSynchronize(ctx->s_main));
+        hipFree(d_cnt_s); hipFree(d_cnt_r); hipFree(d_req); hipFree(d_ans);
+        std::vector<int32_t> sidx((size_t)pl.total_send);
+        bool contig = true;
+        for (int p = 0; p < P; ++p)
+            for (int64_t k = 0; k < pl.send_counts[p]; ++k) {
+                const int64_t g = ans[pl.send_off[p] + k];
+                if (g < lo || g >= hi) { set_error("halo request for a row this rank does not own"); kryst_csr_destroy(a); return KRYST_ERR_ARG; }
+                sidx[pl.send_off[p] + k] = (int32_t)(g - lo);
+                if (k > 0 && g != ans[pl.send_off[p] + k - 1] + 1) contig = false;
+            }
+        a->send_contiguous = contig;
+        if (contig)      // send_off then holds the first local row of each run (used as the offset into x)
+            for (int p = 0; p < P; ++p) if (pl.send_counts[p]) pl.send_off[p] = sidx[pl.send_off[p]];
+        KR_HIP(hipMalloc(&pl.d_send_idx, sizeof(int32_t) * (sidx.size() + 1)));
+        if (!sidx.empty()) KR_HIP(hipMemcpy(pl.d_send_idx, sidx.data(), sizeof(int32_t) * sidx.size(), hipMemcpyHostToDevice));
+        KR_HIP(hipMalloc(&pl.d_sendbuf, sizeof(double) * (size_t)(pl.total_send + 1)));
+    }
+    KR_HIP(hipMalloc(&pl.d_halo, sizeof(double) * (size_t)(pl.total_recv + 2)));
+    KR_HIP(hipMemset(pl.d_halo, 0, sizeof(double) * (size_t)(pl.total_recv + 2)));
+    *out = a;
+    return KRYST_OK;
+}
+
+int32_t kryst_csr_create_stencil7(kryst_ctx_t ctx, int32_t N, int32_t kind, kryst_csr_t* out) {
+    KR_ARG(ctx && out && N >= 1 && kind >= 0 && kind <= 2, "csr_create_stencil7");
+    const int P = ctx->nranks;
+    const int64_t n = (int64_t)N * N * N;
+    std::vector<int64_t> offs((size_t)P + 1);
+    KR_TRY(kryst_host_partition_rows(n, P, (int64_t)N * N, offs.data()));
+    const int64_t N2 = (int64_t)N * N;
+    const int32_t k_lo = (int32_t)(offs[ctx->rank] / N2), k_hi = (int32_t)(offs[ctx->rank + 1] / N2);
+    const int64_t nnz = kryst_host_stencil7(N, kind, k_lo, k_hi, nullptr, nullptr, nullptr);
+    if (nnz < 0) return KRYST_ERR_ARG;
+    const int64_t nloc = offs[ctx->rank + 1] - offs[ctx->rank];
+    std::vector<int64_t> rp((size_t)nloc + 1), col((size_t)nnz);
+    std::vector<double> val((size_t)nnz);
+    kryst_host_stencil7(N, kind, k_lo, k_hi, rp.data(), col.data(), val.data());
+    if (P == 1) return create_local(ctx, n, n, rp.data(), col.data(), val.data(), out);
+    return kryst_csr_create_dist(ctx, n, offs.data(), rp.data(), col.data(), val.data(), out);
+}
+
+int32_t kryst_csr_destroy(kryst_csr_t a) {
+    if (!a) return KRYST_OK;
+    hipSetDevice(a->ctx->device);
+    hipStreamSynchronize(a->ctx->s_main);
+    hipStreamSynchronize(a->ctx->s_comm);
+    hipFree(a->d_row_ptr); hipFree(a->d_col); hipFree(a->d_val);
+    hipFree(a->d_tiles_interior); hipFree(a->d_tiles_boundary);
+    hipFree(a->plan.d_send_idx); hipFree(a->plan.d_sendbuf); hipFree(a->plan.d_halo);
+    delete a;
+    return KRYST_OK;
+}
+
+int32_t kryst_csr_shape(kryst_csr_t a, int64_t* nrows, int64_t* ncols, int64_t* nnz) {
+    KR_ARG(a, "csr_shape");
+    if (nrows) *nrows = a->nrows;
+    if (ncols) *ncols = a->ncols;
+    if (nnz) *nnz = a->nnz;
+    return KRYST_OK;
+}
+
+int32_t kryst_csr_download(kryst_csr_t a, int64_t* row_ptr, int32_t* col, double* vals) {
+    KR_ARG(a, "csr_download");
+    KR_HIP(hipSetDevice(a->ctx->device));
+    if (row_ptr) {
+        std::vector<int32_t> rp((size_t)a->nrows + 1);
+        KR_HIP(hipMemcpy(rp.data(), a->d_row_ptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < rp.size(); ++i) row_ptr[i] = rp[i];
+    }
+    if (col && a->nnz) KR_HIP(hipMemcpy(col, a->d_col, sizeof(int32_t) * (size_t)a->nnz, hipMemcpyDeviceToHost));
+    if (vals && a->nnz) KR_HIP(hipMemcpy(vals, a->d_val, sizeof(double) * (size_t)a->nnz, hipMemcpyDeviceToHost));
+    return KRYST_OK;
+}
+
+int32_t kryst_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y) {
+    KR_ARG(a && x && y, "spmv");
+    KR_ARG(x->ctx == a->ctx && y->ctx == a->ctx, "spmv: context mismatch");
+    KR_ARG(x->n == a->xlen, "spmv: x.len() != ncols");      // sparse.rs:57 assert_eq!
+    KR_ARG(y->n == a->nrows, "spmv: y.len() != nrows");     // sparse.rs:58 assert_eq!
+    KR_ARG(x->d != y->d, "spmv: x and y alias");
+    KR_HIP(hipSetDevice(a->ctx->device));
+    return launch_spmv(a, x->d, y->d, 0, nullptr, nullptr);
+}
+
+int32_t kryst_bench_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t fused_dots, int32_t reps, double* avg_ms) {
+    KR_ARG(a && x && y && avg_ms && reps >= 1 && fused_dots >= 0 && fused_dots <= 2, "bench_spmv");
+    KR_ARG(x->n == a->xlen && y->n == a->nrows, "bench_spmv: size mismatch");
+    KR_ARG(fused_dots == 0 || a->nrows == a->xlen, "bench_spmv: fused dots need a square operator");
+    kryst_ctx_t ctx = a->ctx;
+    KR_HIP(hipSetDevice(ctx->device));
+    KR_TRY(launch_spmv(a, x->d, y->d, fused_dots, x->d, nullptr));             // warm-up launch
+    KR_HIP(hipEventRecord(ctx->tm0, ctx->s_main));
+    for (int r = 0; r < reps; ++r) KR_TRY(launch_spmv(a, x->d, y->d, fused_dots, x->d, nullptr));
+    KR_HIP(hipEventRecord(ctx->tm1, ctx->s_main));
+    KR_HIP(hipEventSynchronize(ctx->tm1));
+    float ms = 0.f;
+    KR_HIP(hipEventElapsedTime(&ms, ctx->tm0, ctx->tm1));
+    *avg_ms = (double)ms / reps;
+    return KRYST_OK;
+}
+
+int32_t kryst_spmv_host(kryst_csr_t a, const double* x, int64_t nx, double* y, int64_t ny) {
+    KR_ARG(a && x && y, "spmv_host");
+    kryst_vec_t vx = nullptr, vy = nullptr;
+    KR_TRY(kryst_vec_create(a->ctx, nx, &vx));
+    int32_t rc = kryst_vec_create(a->ctx, ny, &vy);
+    if (rc == KRYST_OK) rc = kryst_vec_upload(vx, x, nx);
+    if (rc == KRYST_OK) rc = kryst_spmv(a, vx, vy);
+    if (rc == KRYST_OK) rc = kryst_vec_download(vy, y, ny);
+    kryst_vec_destroy(vx); kryst_vec_destroy(vy);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,405 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar: BIT-EXACT.  SpMV and every pointwise kernel reproduce the reference's operation order; inner products are
+compared with the oracle in the library's own association order (kryst_reduce_spec -> oracle REDUCE_TILED), which
+is one admissible execution of the reference's Rayon reduce (src/core/wrappers.rs:92-100).  Against the oracle's
+strict serial fold (the --no-default-features reference) iteration counts must be equal and residual histories
+agree to the tolerance written in each test.
+"""
+import numpy as np
+import pytest
+
+import kryst_amd as K
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return K.Context(0)
+
+
+@pytest.fixture(scope="module")
+def rs():
+    T, V, F = K.reduce_spec()
+    return O.Reduce.tiled(T, V, F)
+
+
+def to_dev(ctx, a):
+    return K.CsrMatrix.from_csr(a.nrows, a.ncols, a.row_ptr, a.col_idx, a.vals, ctx=ctx)
+
+
+def random_csr(rng, nrows, ncols, row_len):
+    """row_len: callable -> length of each row (may be 0)."""
+    rp = [0]; ci = []; va = []
+    for _ in range(nrows):
+        k = min(int(row_len()), ncols)
+        cols = np.sort(rng.choice(ncols, size=k, replace=False)) if k else np.array([], dtype=np.int64)
+        ci.extend(cols.tolist()); va.extend(rng.standard_normal(k).tolist()); rp.append(len(ci))
+    return O.Csr(nrows, ncols, rp, ci, va)
+
+
+# ------------------------------------------------------------------------------------------------ SpMV
+def test_reference_spmv_known_answers(ctx):
+    # src/matrix/sparse.rs:121-144
+    m = K.CsrMatrix.from_csr(3, 3, [0, 1, 2, 3], [0, 1, 2], [1.0, 1.0, 1.0], ctx=ctx)
+    x = np.array([2.0, 3.0, 5.0]); y = np.zeros(3)
+    m.spmv(x, y)
+    assert np.array_equal(y, x)
+    m = K.CsrMatrix.from_csr(2, 3, [0, 2, 4], [0, 1, 1, 2], [1.0, 2.0, 3.0, 4.0], ctx=ctx)
+    y = np.zeros(2)
+    m.spmv(np.ones(3), y)
+    assert np.array_equal(y, [3.0, 7.0])
+
+
+def test_from_csr_rejects_what_new_checked_rejects(ctx):
+    with pytest.raises(K.KError):
+        K.CsrMatrix.from_csr(2, 2, [0, 2, 3], [1, 0, 1], [1.0, 2.0, 3.0], ctx=ctx)     # unsorted
+    with pytest.raises(K.KError):
+        K.CsrMatrix.from_csr(2, 2, [0, 1, 2], [0, 2], [1.0, 2.0], ctx=ctx)             # out of range
+    m = K.CsrMatrix.from_csr(2, 3, [0, 2, 4], [0, 1, 1, 2], [1.0, 2.0, 3.0, 4.0], ctx=ctx)
+    with pytest.raises(K.KError):
+        m.spmv(np.ones(2))                                                              # sparse.rs:57 assert_eq!
+
+
+@pytest.mark.parametrize("kind", ["poisson", "aniso", "convdiff"])
+@pytest.mark.parametrize("N", [1, 2, 7, 16, 33])
+def test_spmv_stencil_bit_exact(ctx, kind, N):
+    a = O.stencil7(N, kind)
+    x = O.splitmix64_uniform(0xC0FFEE, a.ncols) - 0.5
+    assert np.array_equal(to_dev(ctx, a).spmv(x), a.spmv(x))
+
+
+def test_spmv_general_matrices_bit_exact(ctx):
+    rng = np.random.default_rng(7)
+    cases = [
+        random_csr(rng, 1, 1, lambda: 1),
+        random_csr(rng, 1000, 777, lambda: rng.integers(0, 12)),                 # ragged, empty rows, non-square
+        random_csr(rng, 513, 513, lambda: rng.integers(0, 3)),                   # tile boundary + 1
+        random_csr(rng, 600, 9000, lambda: rng.choice([0, 1, 5, 4000, 8000])),   # rows longer than an LDS window
+        random_csr(rng, 1536, 1536, lambda: 40),                                 # several windows per tile
+        O.Csr.from_dense(rng.standard_normal((70, 70))),                         # the reference's dense test shape
+        O.Csr(5, 5, [0, 0, 0, 0, 0, 0], [], []),                                 # empty matrix
+    ]
+    for a in cases:
+        x = rng.standard_normal(a.ncols)
+        assert np.array_equal(to_dev(ctx, a).spmv(x), a.spmv(x)), (a.nrows, a.ncols, a.nnz)
+
+
+def test_spmv_device_generator_matches_host(ctx):
+    for kind in ("poisson", "aniso", "convdiff"):
+        a = K.CsrMatrix.stencil7(12, kind, ctx=ctx)
+        ref = O.stencil7(12, kind)
+        rp, ci, va = a.download()
+        assert np.array_equal(rp, ref.row_ptr) and np.array_equal(ci, ref.col_idx) and np.array_equal(va, ref.vals)
+
+
+# ------------------------------------------------------------------------------------------------ BLAS-1
+@pytest.mark.parametrize("n", [1, 2, 3, 511, 512, 513, 1024, 100003, 1 << 20])
+def test_dot_norm_bit_exact_in_library_order(ctx, rs, n):
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    dx, dy = ctx.vec(x), ctx.vec(y)
+    assert K.dot(dx, dy) == O.dot(x, y, rs)
+    assert K.norm(dx) == O.norm(x, rs)
+    # against the strict serial fold: rounding-level agreement (tolerance: 1e-12 relative to sum |x_i y_i|)
+    assert abs(K.dot(dx, dy) - O.dot(x, y)) <= 1e-12 * np.abs(x * y).sum()
+
+
+def test_reference_dot_and_norm_known_answers(ctx):
+    # tests/core_dense.rs:37-47
+    x, y = ctx.vec([1.0, 2.0, 3.0]), ctx.vec([4.0, -5.0, 6.0])
+    assert abs(K.dot(x, y) - 12.0) < 1e-12 and abs(K.norm(x) - np.sqrt(14.0)) < 1e-12
+    with pytest.raises(K.KError):
+        K.dot(x, ctx.vec(4))                                                            # wrappers.rs:91 assert_eq!
+
+
+def test_pointwise_updates_bit_exact(ctx):
+    rng = np.random.default_rng(3)
+    n = 70001
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    al = 0.3712345678901234
+    dx, dy = ctx.vec(x), ctx.vec(y)
+    K.axpy(al, dx, dy)
+    assert np.array_equal(dy.to_host(), y + al * x)            # cg.rs:208 `*xj + alpha * pj`
+    dy.upload(y)
+    K.aypx(al, dx, dy)
+    assert np.array_equal(dy.to_host(), x + al * y)            # cg.rs:275 `rj + beta * *pj`
+    v = ctx.vec(n).fill_splitmix(0x5EED, 10)
+    assert np.array_equal(v.to_host(), O.splitmix64_uniform(0x5EED, n + 10)[10:])
+
+
+# ------------------------------------------------------------------------------------------------ preconditioners
+def test_jacobi_setup_apply_bit_exact(ctx):
+    a = O.stencil7(9, "convdiff")
+    d = to_dev(ctx, a)
+    r = O.splitmix64_uniform(1, a.nrows)
+    assert np.array_equal(K.Jacobi().setup(d).apply(r), O.Pc.jacobi(a).apply(r))
+    # zero diagonal -> inv 0 (jacobi.rs:69-71); missing diagonal likewise
+    a2 = O.Csr(3, 3, [0, 1, 2, 4], [1, 1, 0, 2], [2.0, 0.0, 1.0, 4.0])
+    assert np.array_equal(K.Jacobi().setup(to_dev(ctx, a2)).apply([1.0, 1.0, 1.0]), [0.0, 0.0, 0.25])
+
+
+@pytest.mark.parametrize("m", [0, 1, 2, 5])
+def test_apply_chebyshev_bit_exact(ctx, m):
+    a = O.stencil7(10)
+    r = O.splitmix64_uniform(2, a.nrows)
+    z = np.zeros(a.nrows)
+    K.apply_chebyshev(to_dev(ctx, a), r, z, 0.2, 11.9, m)
+    assert np.array_equal(z, O.apply_chebyshev(a, r, 0.2, 11.9, m))
+    z2 = np.zeros(a.nrows)
+    K.apply_chebyshev(to_dev(ctx, a), r, z2, 1.0, 1.0, 3)       # degenerate interval copies r (chebyshev.rs:88-92)
+    assert np.array_equal(z2, r)
+
+
+def test_chebyshev_trait_apply_is_a_stub(ctx):
+    a = to_dev(ctx, O.stencil7(4))
+    with pytest.raises(K.KError) as e:
+        K.Chebyshev(3, 0.1, 12.0).setup(a).apply(np.ones(64))
+    assert e.value.code == 2                                    # KError::SolveError, chebyshev.rs:68-70
+
+
+# ------------------------------------------------------------------------------------------------ solvers
+def _check_solver(res, stats, solver, x, exact=True):
+    assert stats.iterations == res.iterations and stats.converged == res.converged
+    h = np.array(solver.residual_history)
+    assert len(h) == len(res.history)
+    if exact:
+        assert np.array_equal(h, res.history), np.max(np.abs(h - res.history) / np.abs(res.history))
+        assert stats.final_residual == res.final_residual
+        assert np.array_equal(x, res.x)
+
+
+@pytest.mark.parametrize("N", [4, 12, 24])
+@pytest.mark.parametrize("norm", [K.CgNormType.Unpreconditioned, K.CgNormType.Natural, K.CgNormType.NoNorm])
+def test_cg_bit_exact(ctx, rs, N, norm):
+    a = O.stencil7(N)
+    b = a.spmv(np.ones(a.nrows))
+    res = O.solve("cg", a, b, tol=1e-8, max_iters=400, norm_type=int(norm), rs=rs)
+    s = K.CgSolver(1e-8, 400).with_norm(norm)
+    x = np.zeros(a.nrows)
+    st = s.solve(to_dev(ctx, a), None, b, x)
+    _check_solver(res, st, s, x)
+
+
+def test_cg_vs_serial_fold_reference(ctx):
+    """Against the strict left-fold reference build: equal iteration counts; residual history within 1e-10
+    relative (dot association differs; CG amplifies it with k -- 1e-12 holds for the first iterations)."""
+    a = O.stencil7(24)
+    b = a.spmv(np.ones(a.nrows))
+    res = O.solve("cg", a, b, tol=1e-8, max_iters=400)
+    s = K.CgSolver(1e-8, 400)
+    x = np.zeros(a.nrows)
+    st = s.solve(to_dev(ctx, a), None, b, x)
+    h = np.array(s.residual_history)
+    assert st.iterations == res.iterations and st.converged
+    assert np.max(np.abs(h[:10] - res.history[:10]) / res.history[:10]) < 1e-12
+    assert np.max(np.abs(h - res.history) / res.history) < 1e-10
+    assert np.linalg.norm(x - res.x) / np.linalg.norm(res.x) < 1e-10
+
+
+@pytest.mark.parametrize("pcname", ["none", "identity", "jacobi"])
+@pytest.mark.parametrize("norm", [K.CgNormType.Preconditioned, K.CgNormType.Unpreconditioned, K.CgNormType.Natural])
+def test_pcg_bit_exact(ctx, rs, pcname, norm):
+    a = O.stencil7(14, "aniso")
+    b = O.splitmix64_uniform(0x5EED, a.nrows)
+    d = to_dev(ctx, a)
+    opc = {"none": None, "identity": O.Pc.identity(), "jacobi": O.Pc.jacobi(a)}[pcname]
+    kpc = {"none": None, "identity": K.IdentityPc().setup(d), "jacobi": K.Jacobi().setup(d)}[pcname]
+    res = O.solve("pcg", a, b, pc=opc, tol=1e-9, max_iters=500, norm_type=int(norm), rs=rs)
+    s = K.PcgSolver(1e-9, 500).with_norm(norm)
+    x = np.zeros(a.nrows)
+    st = s.solve(d, kpc, b, x)
+    _check_solver(res, st, s, x)
+
+
+def test_pcg_with_chebyshev_extension_bit_exact(ctx, rs):
+    a = O.stencil7(10)
+    b = a.spmv(np.ones(a.nrows))
+    d = to_dev(ctx, a)
+    res = O.solve("pcg", a, b, pc=O.Pc.chebyshev(a, 0.3, 11.8, 3), tol=1e-8, max_iters=200, rs=rs, raise_on_error=False)
+    s = K.PcgSolver(1e-8, 200)
+    x = np.zeros(a.nrows)
+    try:
+        st = s.solve(d, K.ChebyshevPc(3, 0.3, 11.8).setup(d), b, x)
+        code = 0
+    except K.KError as e:
+        st, code = e.stats, e.code
+    assert code == res.code
+    _check_solver(res, st, s, x, exact=(code == 0))
+
+
+def test_initial_guess_is_honoured(ctx, rs):
+    a = O.stencil7(8)
+    b = a.spmv(np.ones(a.nrows))
+    x0 = O.splitmix64_uniform(9, a.nrows)
+    res = O.solve("cg", a, b, x0=x0, tol=1e-10, max_iters=300, rs=rs)
+    s = K.CgSolver(1e-10, 300)
+    x = x0.copy()
+    st = s.solve(to_dev(ctx, a), None, b, x)
+    _check_solver(res, st, s, x)
+
+
+def test_iteration_cap_reports_converged_true(ctx, rs):
+    # convergence.rs:25
+    a = O.stencil7(8)
+    b = a.spmv(np.ones(a.nrows))
+    for cls, m in ((K.CgSolver, "cg"), (K.PcgSolver, "pcg")):
+        s = cls(1e-30, 5)
+        x = np.zeros(a.nrows)
+        st = s.solve(to_dev(ctx, a), None, b, x)
+        res = O.solve(m, a, b, tol=1e-30, max_iters=5, rs=rs)
+        assert st.iterations == 5 and st.converged
+        _check_solver(res, st, s, x)
+
+
+def test_indefinite_matrix_error_and_x_untouched(ctx):
+    a = K.CsrMatrix.from_csr(2, 2, [0, 1, 2], [0, 1], [1.0, -1.0], ctx=ctx)
+    for cls in (K.CgSolver, K.PcgSolver):
+        x = np.array([0.25, 0.5])
+        with pytest.raises(K.KError) as e:
+            cls(1e-10, 10).solve(a, None, np.array([0.0, 1.0]), x)
+        assert e.value.code == 3                              # KError::IndefiniteMatrix (cg.rs:168-174)
+        assert np.array_equal(x, [0.25, 0.5])                 # Err: `*x = ...` is never reached
+
+
+def test_monitor_and_history(ctx):
+    a = O.stencil7(6)
+    b = a.spmv(np.ones(a.nrows))
+    seen = []
+    s = K.CgSolver(1e-8, 100).with_monitor(lambda i, r: seen.append((i, r)))
+    x = np.zeros(a.nrows)
+    st = s.solve(to_dev(ctx, a), None, b, x)
+    assert [i for i, _ in seen] == list(range(st.iterations + 1))
+    assert [r for _, r in seen] == s.residual_history
+    s.solve(to_dev(ctx, a), None, b, x)                         # residual_history accumulates across solves (cg.rs:140)
+    assert len(s.residual_history) > len(seen)
+    s.clear_history()
+    assert s.residual_history == []
+
+
+@pytest.mark.parametrize("kind,N", [("convdiff", 8), ("aniso", 12), ("poisson", 5)])
+def test_bicgstab_bit_exact(ctx, rs, kind, N):
+    a = O.stencil7(N, kind)
+    b = a.spmv(np.ones(a.nrows))
+    tol = 1e-8 * np.linalg.norm(b)                              # absolute tolerance (bicgstab.rs:98,189,281)
+    res = O.solve("bicgstab", a, b, tol=tol, max_iters=300, rs=rs)
+    s = K.BiCgStabSolver(tol, 300)
+    x = np.zeros(a.nrows)
+    st = s.solve(to_dev(ctx, a), K.Jacobi().setup(to_dev(ctx, a)), b, x)     # pc is ignored (bicgstab.rs:70)
+    _check_solver(res, st, s, x)
+
+
+def test_bicgstab_edge_exits(ctx, rs):
+    a = O.stencil7(6, "convdiff")
+    d = to_dev(ctx, a)
+    b = a.spmv(np.ones(a.nrows))
+    # already converged at entry (bicgstab.rs:98-102), iteration cap (converged=false), s-norm early exit
+    for tol, mx, x0 in ((1e6, 50, None), (1e-30, 7, None), (1e-3, 50, None)):
+        res = O.solve("bicgstab", a, b, tol=tol, max_iters=mx, rs=rs)
+        s = K.BiCgStabSolver(tol, mx)
+        x = np.zeros(a.nrows)
+        st = s.solve(d, None, b, x)
+        _check_solver(res, st, s, x)
+    # exact solution in one step on a diagonal system -> s-norm exit
+    a2 = O.Csr.from_dense(np.diag([2.0, 2.0, 2.0]))
+    res = O.solve("bicgstab", a2, [1.0, 2.0, 3.0], tol=1e-12, max_iters=10, rs=rs)
+    s = K.BiCgStabSolver(1e-12, 10)
+    x = np.zeros(3)
+    st = s.solve(to_dev(ctx, a2), None, np.array([1.0, 2.0, 3.0]), x)
+    _check_solver(res, st, s, x)
+
+
+@pytest.mark.parametrize("side", [K.Preconditioning.NoPc, K.Preconditioning.Left, K.Preconditioning.Right])
+@pytest.mark.parametrize("restart", [5, 30])
+def test_gmres_bit_exact(ctx, rs, side, restart):
+    a = O.stencil7(8, "convdiff")
+    b = a.spmv(np.ones(a.nrows))
+    d = to_dev(ctx, a)
+    opc = None if side == K.Preconditioning.NoPc else O.Pc.jacobi(a)
+    kpc = None if side == K.Preconditioning.NoPc else K.Jacobi().setup(d)
+    res = O.solve("gmres", a, b, pc=opc, tol=1e-8, max_iters=90, restart=restart, side=int(side), rs=rs)
+    s = K.GmresSolver(restart, 1e-8, 90).with_preconditioning(side)
+    x = np.zeros(a.nrows)
+    st = s.solve(d, kpc, b, x)
+    _check_solver(res, st, s, x)
+
+
+def test_gmres_reference_known_answers(ctx):
+    # src/solver/gmres.rs:438-528 through the mirrored API
+    A = [[4.0, 1.0, 0.0, 0.0], [1.0, 3.0, 1.0, 0.0], [0.0, 1.0, 2.0, 1.0], [0.0, 0.0, 1.0, 3.0]]
+    ao = O.Csr.from_dense(A)
+    a = to_dev(ctx, ao)
+    xt = np.array([1.0, 2.0, 3.0, 4.0])
+    b = ao.spmv(xt)
+    x = np.zeros(4)
+    st = K.GmresSolver(4, 1e-10, 100).solve(a, None, b, x)
+    assert st.converged and np.all(np.abs(x - xt) < 1e-8)
+    x = np.zeros(4)
+    st = K.GmresSolver(4, 1e-10, 100).solve(a, K.Jacobi().setup(a), b, x)
+    assert st.converged and np.all(np.abs(x - xt) < 1e-8)
+    x = np.zeros(4)
+    K.GmresSolver(4, 1e-10, 100).with_preconditioning(K.Preconditioning.Right).solve(a, K.Jacobi().setup(a), b, x)
+    assert np.linalg.norm(ao.spmv(x) - b) < 1e-2
+
+
+def test_gmres_happy_breakdown_paths(ctx, rs):
+    # identity system: h[1][0] == 0 at the first step in every branch (gmres.rs:99-101, 300-303, 332-335)
+    ao = O.Csr.from_dense(np.eye(6))
+    a = to_dev(ctx, ao)
+    b = np.arange(1.0, 7.0)
+    for side in (0, 1, 2):
+        opc = None if side == 0 else O.Pc.jacobi(ao)
+        kpc = None if side == 0 else K.Jacobi().setup(a)
+        res = O.solve("gmres", ao, b, pc=opc, tol=1e-10, max_iters=12, restart=4, side=side, rs=rs)
+        s = K.GmresSolver(4, 1e-10, 12).with_preconditioning(K.Preconditioning(side))
+        x = np.zeros(6)
+        st = s.solve(a, kpc, b, x)
+        assert st.iterations == res.iterations and st.converged == res.converged, (side, st, res)
+        assert np.array_equal(x, res.x) and st.final_residual == res.final_residual
+
+
+def test_reference_solver_known_answers_via_api(ctx):
+    # cg.rs:310-323, pcg.rs:253-275, bicgstab.rs:316-328, tests/preconditioner_integration.rs:127-164
+    a2 = to_dev(ctx, O.Csr.from_dense([[4.0, 1.0], [1.0, 3.0]]))
+    exp = [0.09090909090909091, 0.6363636363636364]
+    for solver in (K.CgSolver(1e-10, 20), K.CgSolver(1e-10, 20).with_single_reduction(True), K.PcgSolver(1e-10, 20)):
+        x = np.zeros(2)
+        pc = K.IdentityPc().setup(a2) if isinstance(solver, K.PcgSolver) else None
+        st = solver.solve(a2, pc, np.array([1.0, 2.0]), x)
+        assert st.converged and np.all(np.abs(x - exp) < 1e-8)
+    dense = np.array([[4.0 if i == j else (i + 2 * j) + 1.0 for j in range(3)] for i in range(3)])
+    ao = O.Csr.from_dense(dense)
+    xt = np.array([1.0, 2.0, 3.0]); x = np.zeros(3)
+    st = K.BiCgStabSolver(1e-10, 100).solve(to_dev(ctx, ao), None, ao.spmv(xt), x)
+    assert st.converged and np.all(np.abs(x - xt) < 1e-8)
+    n = 10
+    ao = O.Csr.from_dense(O.tridiag(n, -1.0, 2.0, -1.0), keep_zeros=False)
+    a = to_dev(ctx, ao)
+    b = ao.spmv(np.ones(n)); x = np.zeros(n)
+    st = K.PcgSolver(1e-12, n).solve(a, K.Jacobi().setup(a), b, x)
+    assert st.converged and st.iterations <= n and np.linalg.norm(x - 1) / np.sqrt(n) < 1e-10
+    ao = O.Csr.from_dense(O.tridiag(n, -1.0, 2.0, 0.5), keep_zeros=False)
+    b = ao.spmv(np.ones(n)); x = np.zeros(n)
+    st = K.GmresSolver(10, 1e-12, 100).solve(to_dev(ctx, ao), None, b, x)
+    assert st.converged and np.linalg.norm(x - 1) / np.sqrt(n) < 1e-10
+
+
+def test_device_resident_solve_and_roundtrip_property(ctx):
+    """Size-independent property at a size the oracle would be slow on: b = A*1 => CG returns x ~ 1 with
+    ||b - A x|| <= tol * ||b|| (checked with the device SpMV)."""
+    N = 96
+    a = K.CsrMatrix.stencil7(N, "poisson", ctx=ctx)
+    n = N ** 3
+    ones = ctx.vec(n).fill(1.0)
+    b = a.spmv(ones)
+    x = ctx.vec(n)
+    s = K.CgSolver(1e-8, 2000)
+    st = s.solve(a, None, b, x)
+    assert st.converged and 0 < st.iterations < 2000
+    r = a.spmv(x)
+    K.axpy(-1.0, b, r)
+    assert K.norm(r) <= 1.0001e-8 * K.norm(b)
+    assert abs(s.residual_history[-1] - st.final_residual) == 0.0
+    assert np.max(np.abs(x.to_host() - 1.0)) < 1e-6
