@@ -32,7 +32,8 @@ static int32_t ctx_init(kryst_ctx_t ctx) {
     KR_HIP(hipEventCreate(&ctx->tm1));
     for (auto& e : ctx->ev_ring) KR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     KR_HIP(hipMalloc(&ctx->d_scal, sizeof(double) * 4096));
-    KR_HIP(hipMemset(ctx->d_scal, 0, sizeof(double) * 4096));
+    KR_HIP(hipMemsetAsync(ctx->d_scal, 0, sizeof(double) * 4096, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
     KR_HIP(hipMalloc(&ctx->d_gather, sizeof(double) * (size_t)(ctx->nranks + 1) * KR_MAXQ));
     KR_HIP(hipHostMalloc((void**)&ctx->h_prog, sizeof(HostProgress), hipHostMallocMapped));
     memset((void*)ctx->h_prog, 0, sizeof(HostProgress));

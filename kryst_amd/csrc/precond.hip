@@ -115,10 +115,11 @@ int32_t pc_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done)
 
 using namespace kr;
 
-static int32_t alloc_vec(double** p, int64_t n) {
+// all device work of a context is ordered on ctx->s_main (a non-blocking stream: the null stream does NOT order with it)
+static int32_t alloc_vec(kryst_ctx_t ctx, double** p, int64_t n) {
     const size_t bytes = sizeof(double) * (size_t)(padded(n) + KR_TILE);
     KR_HIP(hipMalloc(p, bytes));
-    KR_HIP(hipMemset(*p, 0, bytes));
+    KR_HIP(hipMemsetAsync(*p, 0, bytes, ctx->s_main));
     return KRYST_OK;
 }
 
@@ -137,7 +138,7 @@ int32_t kryst_pc_jacobi(kryst_csr_t a, kryst_pc_t* out) {
     KR_HIP(hipSetDevice(a->ctx->device));
     kryst_pc_t pc = new kryst_pc_s();
     pc->ctx = a->ctx; pc->kind = KR_PC_JACOBI; pc->a = a; pc->n = a->nrows;
-    int32_t rc = alloc_vec(&pc->d_inv_diag, pc->n);
+    int32_t rc = alloc_vec(a->ctx, &pc->d_inv_diag, pc->n);
     if (rc != KRYST_OK) { delete pc; return rc; }
     if (pc->n > 0) {
         hipLaunchKernelGGL(jacobi_setup_kernel, dim3((unsigned)((pc->n + 255) / 256)), dim3(256), 0, a->ctx->s_main,
@@ -163,9 +164,9 @@ int32_t kryst_pc_chebyshev(kryst_csr_t a, double alpha, double beta, int32_t deg
     kryst_pc_t pc = new kryst_pc_s();
     pc->ctx = a->ctx; pc->kind = KR_PC_CHEB; pc->a = a; pc->n = a->nrows;
     pc->cheb_alpha = alpha; pc->cheb_beta = beta; pc->cheb_degree = degree;
-    int32_t rc = alloc_vec(&pc->d_v0, pc->n);
-    if (rc == KRYST_OK) rc = alloc_vec(&pc->d_v1, pc->n);
-    if (rc == KRYST_OK) rc = alloc_vec(&pc->d_v2, pc->n);
+    int32_t rc = alloc_vec(a->ctx, &pc->d_v0, pc->n);
+    if (rc == KRYST_OK) rc = alloc_vec(a->ctx, &pc->d_v1, pc->n);
+    if (rc == KRYST_OK) rc = alloc_vec(a->ctx, &pc->d_v2, pc->n);
     if (rc != KRYST_OK) { kryst_pc_destroy(pc); return rc; }
     *out = pc;
     return KRYST_OK;
@@ -199,9 +200,9 @@ int32_t kryst_apply_chebyshev(kryst_csr_t a, kryst_vec_t r, kryst_vec_t z, doubl
     KR_ARG(r->n == a->nrows && z->n == a->nrows && a->nrows == a->xlen, "apply_chebyshev: size mismatch");
     KR_HIP(hipSetDevice(a->ctx->device));
     double *v0 = nullptr, *v1 = nullptr, *v2 = nullptr;
-    int32_t rc = alloc_vec(&v0, a->nrows);
-    if (rc == KRYST_OK) rc = alloc_vec(&v1, a->nrows);
-    if (rc == KRYST_OK) rc = alloc_vec(&v2, a->nrows);
+    int32_t rc = alloc_vec(a->ctx, &v0, a->nrows);
+    if (rc == KRYST_OK) rc = alloc_vec(a->ctx, &v1, a->nrows);
+    if (rc == KRYST_OK) rc = alloc_vec(a->ctx, &v2, a->nrows);
     if (rc == KRYST_OK) rc = chebyshev_dev(a, r->d, z->d, alpha, beta, m, v0, v1, v2, nullptr);
     hipStreamSynchronize(a->ctx->s_main);
     hipFree(v0); hipFree(v1); hipFree(v2);

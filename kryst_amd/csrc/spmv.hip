@@ -335,7 +335,8 @@ int32_t kryst_csr_create_dist(kryst_ctx_t ctx, int64_t n_global, const int64_t* 
         KR_HIP(hipMalloc(&pl.d_sendbuf, sizeof(double) * (size_t)(pl.total_send + 1)));
     }
     KR_HIP(hipMalloc(&pl.d_halo, sizeof(double) * (size_t)(pl.total_recv + 2)));
-    KR_HIP(hipMemset(pl.d_halo, 0, sizeof(double) * (size_t)(pl.total_recv + 2)));
+    KR_HIP(hipMemsetAsync(pl.d_halo, 0, sizeof(double) * (size_t)(pl.total_recv + 2), ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
     *out = a;
     return KRYST_OK;
 }
