@@ -120,7 +120,16 @@ __device__ __forceinline__ void final_fold(const double* partials, int64_t strid
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         double acc = 0.0;
-        for (int64_t i = threadIdx.x; i < ntiles; i += KR_F) acc = acc + partials[q * stride + i];
+        const double* p = partials + q * stride;
+        int64_t i = threadIdx.x;
+        for (; i + 7 * KR_F < ntiles; i += 8 * KR_F) {      // 8 loads in flight, folded in index order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[i + u * KR_F];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = acc + v[u];
+        }
+        for (; i < ntiles; i += KR_F) acc = acc + p[i];
         out[q] = acc;
     }
     block_reduce<NQ, KR_F / 64>(out, lds);

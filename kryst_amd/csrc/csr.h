@@ -12,6 +12,7 @@ struct kryst_csr_s {
     int32_t* d_col = nullptr;       // nnz (+8 pad, zero): LOCAL column index; >= nloc means halo slot
     double*  d_val = nullptr;       // nnz (+8 pad, zero)
     int64_t ntiles = 0;
+    int slots = 7;            // SpMV pair slots per lane (picked from the average nnz of a 128-row slice)
     // distributed
     bool dist = false;
     std::vector<int64_t> row_offsets;

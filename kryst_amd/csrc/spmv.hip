@@ -19,12 +19,12 @@
 #include "ew.h"
 #include <algorithm>
 
-#ifndef SPMV_LCAP
-#define SPMV_LCAP 3648                      // LDS window in entries (28.5 KiB): 5 workgroups per CU
+#ifndef SPMV_SLOTS
+#define SPMV_SLOTS 4                        // pair slots per lane per LDS window: window = 2048 entries = 16 KiB
 #endif
-#define SPMV_PAIRS (SPMV_LCAP / 2)
-#define SPMV_SLOTS ((SPMV_PAIRS + KR_T - 1) / KR_T)    // pair slots per lane per window (8)
-#define SPMV_BATCH 4                        // pairs in flight per lane
+#ifndef SPMV_NT
+#define SPMV_NT 1                           // non-temporal loads for the once-read col_idx / values streams
+#endif
 
 namespace kr {
 
@@ -36,8 +36,14 @@ struct SpmvArgs {
     const double* x; const double* halo; int32_t nloc;
     double* y; const int32_t* tiles; int32_t ntiles; int32_t nrows;
     const double* dvec; double* partials; int64_t pstride;
-    const int* done; int32_t xcd_chunk;
+    const int* done; int32_t xcd_chunk; int32_t swizzle; int32_t group;
 };
+
+template <bool NT, class T>
+__device__ __forceinline__ T stream_load(const T* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
 
 template <bool HALO>
 __device__ __forceinline__ double gather(const SpmvArgs& a, int32_t c) {
@@ -49,16 +55,38 @@ __device__ __forceinline__ double gather(const SpmvArgs& a, int32_t c) {
     }
 }
 
-template <int NQ, bool HALO>
+// ascending serial sum of prod[beg-base .. end-base) continued into s: LDS reads are issued four at a time
+// (clamped, branch-free) and folded in index order
+__device__ __forceinline__ double row_sum(const double* prod, int base, int beg, int end, double s) {
+    for (int k = beg; k < end; k += 4) {
+        const int last = end - 1 - base;
+        const double v0 = prod[k - base];
+        const double v1 = prod[min(k + 1 - base, last)];
+        const double v2 = prod[min(k + 2 - base, last)];
+        const double v3 = prod[min(k + 3 - base, last)];
+        s = s + v0;
+        if (k + 1 < end) s = s + v1;
+        if (k + 2 < end) s = s + v2;
+        if (k + 3 < end) s = s + v3;
+    }
+    return s;
+}
+
+// LCAP = SLOTS * 2 * KR_T entries per LDS window; every lane owns SLOTS pair slots, all loaded in one batch
+template <int NQ, bool HALO, int SLOTS = SPMV_SLOTS, bool NT = (SPMV_NT != 0), int DIAG = 0>
 __global__ __launch_bounds__(KR_T) void spmv_kernel(const SpmvArgs a) {
     if (a.done && *a.done) return;
-    __shared__ __attribute__((aligned(16))) double prod[SPMV_LCAP];
+    constexpr int LCAP = SLOTS * 2 * KR_T;
+    __shared__ __attribute__((aligned(16))) double prod[LCAP];
     __shared__ double red[(NQ > 0 ? NQ : 1) * (KR_T / 64)];
     const int t = threadIdx.x;
     const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, per = gridDim.x >> 3;
     for (int li = slot0; li < a.xcd_chunk; li += per) {
-        const int ti = xcd * a.xcd_chunk + li;
-        if (ti >= a.ntiles) break;
+        // tile -> workgroup map: groups of `a.group` consecutive tiles are dealt round-robin to the 8 XCDs
+        int ti;
+        if (a.swizzle) ti = xcd * a.xcd_chunk + li;
+        else ti = ((li / a.group) * 8 + xcd) * a.group + (li % a.group);
+        if (ti >= a.ntiles) { if (a.swizzle) break; else continue; }
         const int q = a.tiles ? a.tiles[ti] : ti;
         const int r0 = q * KR_TILE;
         const int r1 = min(r0 + KR_TILE, a.nrows);
@@ -68,36 +96,112 @@ __global__ __launch_bounds__(KR_T) void spmv_kernel(const SpmvArgs a) {
         const int p2 = a.row_ptr[min(row + 2, r1)];
         const int k0 = a.row_ptr[r0], k1 = a.row_ptr[r1];
         double s0 = 0.0, s1 = 0.0;
-        for (int base = k0 & ~1; base < k1; base += SPMV_LCAP) {
-            const int wend = min(base + SPMV_LCAP, k1);
+        for (int base = k0 & ~1; base < k1; base += LCAP) {
+            const int wend = min(base + LCAP, k1);
             const int npairs = (wend - base + 1) >> 1;
-            // ---- phase 1: coalesced pair loads, x gather, products to LDS
-            for (int jb = 0; jb * KR_T < npairs; jb += SPMV_BATCH) {
-                v2i c[SPMV_BATCH]; v2d v[SPMV_BATCH]; double xa[SPMV_BATCH], xb[SPMV_BATCH];
+            // ---- phase 1: coalesced pair loads (8 B of col_idx + 16 B of values per lane), x gather, products to
+            // LDS.  Branch-free: out-of-window slots re-read the window's last pair and store it to their own
+            // (unused) LDS slot, so every load of the batch is in flight before the first use.
+            v2i c[SLOTS]; v2d v[SLOTS]; double xa[SLOTS], xb[SLOTS];
 #pragma unroll
-                for (int j = 0; j < SPMV_BATCH; ++j) {
-                    const int pi = min(t + (jb + j) * KR_T, npairs - 1);       // clamp: branch-free loads
-                    const int k = base + 2 * pi;
-                    c[j] = __builtin_nontemporal_load(reinterpret_cast<const v2i*>(a.col + k));
-                    v[j] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(a.val + k));
-                }
-#pragma unroll
-                for (int j = 0; j < SPMV_BATCH; ++j) {
-                    xa[j] = gather<HALO>(a, c[j].x);
-                    xb[j] = gather<HALO>(a, c[j].y);
-                }
-#pragma unroll
-                for (int j = 0; j < SPMV_BATCH; ++j) {
-                    const int pi = t + (jb + j) * KR_T;
-                    if (pi < npairs)
-                        *reinterpret_cast<double2*>(&prod[2 * pi]) = make_double2(v[j].x * xa[j], v[j].y * xb[j]);
-                }
+            for (int j = 0; j < SLOTS; ++j) {
+                const int pi = min(t + j * KR_T, npairs - 1);
+                const int k = base + 2 * pi;
+                c[j] = stream_load<NT>(reinterpret_cast<const v2i*>(a.col + k));
+                v[j] = stream_load<NT>(reinterpret_cast<const v2d*>(a.val + k));
             }
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j) {
+                if constexpr (DIAG == 1) { xa[j] = (double)c[j].x; xb[j] = (double)c[j].y; }      // timing only: no gather
+                else { xa[j] = gather<HALO>(a, c[j].x); xb[j] = gather<HALO>(a, c[j].y); }
+            }
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j)
+                *reinterpret_cast<double2*>(&prod[2 * (t + j * KR_T)]) = make_double2(v[j].x * xa[j], v[j].y * xb[j]);
             __syncthreads();
             // ---- phase 2: ascending serial row sums (continuing across windows)
-            for (int k = max(p0, base); k < min(p1, wend); ++k) s0 = s0 + prod[k - base];
-            for (int k = max(p1, base); k < min(p2, wend); ++k) s1 = s1 + prod[k - base];
+            if constexpr (DIAG == 2) { s0 = prod[2 * t]; s1 = prod[2 * t + 1]; }                   // timing only: no row sums
+            else {
+                s0 = row_sum(prod, base, max(p0, base), min(p1, wend), s0);
+                s1 = row_sum(prod, base, max(p1, base), min(p2, wend), s1);
+            }
             __syncthreads();
+        }
+        if (row + 1 < r1) st2(a.y, row, s0, s1);
+        else if (row < r1) a.y[row] = s0;
+        if constexpr (NQ > 0) {
+            double acc[NQ];
+            const d2 d = ld2(a.dvec, row);
+            acc[0] = 0.0;
+            if (row < r1) acc[0] = acc[0] + d.a * s0;
+            if (row + 1 < r1) acc[0] = acc[0] + d.b * s1;
+            if constexpr (NQ > 1) {
+                acc[1] = 0.0;
+                if (row < r1) acc[1] = acc[1] + s0 * s0;
+                if (row + 1 < r1) acc[1] = acc[1] + s1 * s1;
+            }
+            block_reduce<NQ, KR_T / 64>(acc, red);
+            if (t == 0) {
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) a.partials[k * a.pstride + q] = acc[k];
+            }
+        }
+    }
+}
+
+// Wave-independent form: each of the 4 waves streams the nnz range of ITS 128 rows (lane l: rows 2l, 2l+1 of the
+// wave's slice -- the same thread->row map as above) through a private LDS window.  Same-wave LDS traffic is
+// ordered by the hardware, so the main path has NO workgroup barrier: waves run their load / gather / LDS / sum
+// phases out of step and hide each other's latency.  Only the optional fused inner product meets at one barrier.
+template <int NQ, bool HALO, int SLOTS, bool NT, int MINW = 1>
+__global__ __launch_bounds__(KR_T, MINW) void spmv_wave_kernel(const SpmvArgs a) {
+    if (a.done && *a.done) return;
+    constexpr int WCAP = SLOTS * 128;                       // entries per wave window
+    __shared__ __attribute__((aligned(16))) double prod_all[4 * WCAP];
+    __shared__ double red[(NQ > 0 ? NQ : 1) * (KR_T / 64)];
+    const int t = threadIdx.x, l = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    double* prod = prod_all + w * WCAP;
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, per = gridDim.x >> 3;
+    for (int li = slot0; li < a.xcd_chunk; li += per) {
+        int ti;
+        if (a.swizzle) ti = xcd * a.xcd_chunk + li;
+        else ti = ((li / a.group) * 8 + xcd) * a.group + (li % a.group);
+        if (ti >= a.ntiles) { if (a.swizzle) break; else continue; }
+        const int q = a.tiles ? a.tiles[ti] : ti;
+        const int r0 = q * KR_TILE;
+        const int r1 = min(r0 + KR_TILE, a.nrows);
+        const int wr0 = min(r0 + 128 * w, r1), wr1 = min(wr0 + 128, r1);
+        const int row = r0 + 2 * t;
+        const int p0 = a.row_ptr[min(row, r1)];
+        const int p1 = a.row_ptr[min(row + 1, r1)];
+        const int p2 = a.row_ptr[min(row + 2, r1)];
+        const int k0 = a.row_ptr[wr0], k1 = a.row_ptr[wr1];         // wave-uniform
+        double s0 = 0.0, s1 = 0.0;
+        for (int base = k0 & ~1; base < k1; base += WCAP) {
+            const int wend = min(base + WCAP, k1);
+            const int npairs = (wend - base + 1) >> 1;
+            v2i c[SLOTS]; v2d v[SLOTS]; double xa[SLOTS], xb[SLOTS];
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j) {
+                const int pi = min(l + j * 64, npairs - 1);
+                const int k = base + 2 * pi;
+                c[j] = stream_load<NT>(reinterpret_cast<const v2i*>(a.col + k));
+                v[j] = stream_load<NT>(reinterpret_cast<const v2d*>(a.val + k));
+            }
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j) { xa[j] = gather<HALO>(a, c[j].x); xb[j] = gather<HALO>(a, c[j].y); }
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j)
+                *reinterpret_cast<double2*>(&prod[2 * (l + j * 64)]) = make_double2(v[j].x * xa[j], v[j].y * xb[j]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            s0 = row_sum(prod, base, max(p0, base), min(p1, wend), s0);
+            s1 = row_sum(prod, base, max(p1, base), min(p2, wend), s1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (row + 1 < r1) st2(a.y, row, s0, s1);
         else if (row < r1) a.y[row] = s0;
@@ -126,11 +230,9 @@ __global__ void pack_kernel(const double* x, const int32_t* idx, double* out, in
     if (i < n) out[i] = x[idx[i]];
 }
 
-static int spmv_blocks_per_cu() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("KRYST_SPMV_BLOCKS_PER_CU"); v = e ? atoi(e) : 0; }
-    return v;
-}
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// tuning knobs (read per launch so that one process can A/B them)
+static int spmv_blocks_per_cu() { return env_int("KRYST_SPMV_BLOCKS_PER_CU", 0); }
 
 template <bool HALO>
 static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, const double* dvec, const int* done,
@@ -148,12 +250,50 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
     const int bpc = spmv_blocks_per_cu();
     if (bpc > 0) per = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)ctx->num_cu * bpc / 8));
     const dim3 grid((unsigned)(per * 8)), block(KR_T);
+    args.swizzle = env_int("KRYST_SPMV_SWIZZLE", 0);
+    args.group = std::max(1, env_int("KRYST_SPMV_GROUP", 1));
+#ifdef KRYST_TUNING
+    const int variant = env_int("KRYST_SPMV_VARIANT", 0);
+    if (nq == 1 && !HALO && variant > 0) {
+        switch (variant) {
+            case 1: hipLaunchKernelGGL((spmv_kernel<1, false, 2, true>), grid, block, 0, ctx->s_main, args); break;
+            case 2: hipLaunchKernelGGL((spmv_kernel<1, false, 7, true>), grid, block, 0, ctx->s_main, args); break;
+            case 3: hipLaunchKernelGGL((spmv_kernel<1, false, 4, false>), grid, block, 0, ctx->s_main, args); break;
+            case 4: hipLaunchKernelGGL((spmv_kernel<1, false, 3, true>), grid, block, 0, ctx->s_main, args); break;
+            case 5: hipLaunchKernelGGL((spmv_kernel<1, false, 7, false>), grid, block, 0, ctx->s_main, args); break;
+            case 6: hipLaunchKernelGGL((spmv_kernel<1, false, 8, false>), grid, block, 0, ctx->s_main, args); break;
+            case 7: hipLaunchKernelGGL((spmv_kernel<1, false, 7, false, 1>), grid, block, 0, ctx->s_main, args); break;
+            case 8: hipLaunchKernelGGL((spmv_kernel<1, false, 7, false, 2>), grid, block, 0, ctx->s_main, args); break;
+            case 9: hipLaunchKernelGGL((spmv_kernel<0, false, 7, false>), grid, block, 0, ctx->s_main, args); break;
+            case 10: hipLaunchKernelGGL((spmv_wave_kernel<1, false, 7, false>), grid, block, 0, ctx->s_main, args); break;
+            case 11: hipLaunchKernelGGL((spmv_wave_kernel<1, false, 7, true>), grid, block, 0, ctx->s_main, args); break;
+            case 12: hipLaunchKernelGGL((spmv_wave_kernel<1, false, 7, false, 5>), grid, block, 0, ctx->s_main, args); break;
+            case 13: hipLaunchKernelGGL((spmv_wave_kernel<1, false, 4, false>), grid, block, 0, ctx->s_main, args); break;
+            case 14: hipLaunchKernelGGL((spmv_wave_kernel<0, false, 7, false>), grid, block, 0, ctx->s_main, args); break;
+            case 15: hipLaunchKernelGGL((spmv_wave_kernel<1, false, 8, false>), grid, block, 0, ctx->s_main, args); break;
+            default: set_error("unknown KRYST_SPMV_VARIANT"); return KRYST_ERR_ARG;
+        }
+        KR_HIP(hipGetLastError());
+        return KRYST_OK;
+    }
+#endif
+    // production path: wave-independent kernel; pair slots per lane sized to the matrix's average slice length
+    // (a wave streams the nnz of 128 rows: <= 256 nnz -> 2 slots, <= 512 -> 4, else 7 = a 7-point stencil's 896)
+#define KR_SPMV_LAUNCH(NQ_, SL_) hipLaunchKernelGGL((spmv_wave_kernel<NQ_, HALO, SL_, false>), grid, block, 0, ctx->s_main, args)
+#define KR_SPMV_BY_SLOTS(NQ_)                                   \
+    do {                                                        \
+        if (a->slots <= 2) KR_SPMV_LAUNCH(NQ_, 2);              \
+        else if (a->slots <= 4) KR_SPMV_LAUNCH(NQ_, 4);         \
+        else KR_SPMV_LAUNCH(NQ_, 7);                            \
+    } while (0)
     switch (nq) {
-        case 0: hipLaunchKernelGGL((spmv_kernel<0, HALO>), grid, block, 0, ctx->s_main, args); break;
-        case 1: hipLaunchKernelGGL((spmv_kernel<1, HALO>), grid, block, 0, ctx->s_main, args); break;
-        case 2: hipLaunchKernelGGL((spmv_kernel<2, HALO>), grid, block, 0, ctx->s_main, args); break;
+        case 0: KR_SPMV_BY_SLOTS(0); break;
+        case 1: KR_SPMV_BY_SLOTS(1); break;
+        case 2: KR_SPMV_BY_SLOTS(2); break;
         default: set_error("spmv: nq=%d", nq); return KRYST_ERR_ARG;
     }
+#undef KR_SPMV_BY_SLOTS
+#undef KR_SPMV_LAUNCH
     KR_HIP(hipGetLastError());
     return KRYST_OK;
 }
@@ -202,6 +342,8 @@ static int32_t upload_csr(kryst_csr_t a, const std::vector<int32_t>& rp, const s
     }
     KR_HIP(hipStreamSynchronize(ctx->s_main));
     a->ntiles = ntiles_of(a->nrows);
+    const double per_slice = a->nrows > 0 ? (double)a->nnz / (double)((a->nrows + 127) / 128) : 0.0;
+    a->slots = per_slice <= 256.0 ? 2 : (per_slice <= 512.0 ? 4 : 7);
     return KRYST_OK;
 }
 
