@@ -475,6 +475,11 @@ class _Solver:
         tail = (a.h, pch, C.byref(prm), C.byref(st), _dp(hist), cap, C.byref(hlen), cb, None)
         if isinstance(b, DeviceVec):
             rc = getattr(lib(), self._DEV)(b.h, x.h, *tail)
+        elif self._HOST is None:                     # extension solvers only exist in device-vector form
+            bv, xv = DeviceVec(a.ctx, b), DeviceVec(a.ctx, x)
+            rc = getattr(lib(), self._DEV)(bv.h, xv.h, *tail)
+            if rc == 0:
+                x[:] = xv.to_host()
         else:
             bb = _f64(b)
             if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags.c_contiguous):

@@ -368,14 +368,17 @@ struct BicgSOp {                     // s = r - alpha*v ; partial s.s     (bicgs
 // when the s-norm exit is pending (st->early): only x = x + alpha*p   (bicgstab.rs:191-202)
 struct BicgXROp {
     static constexpr int NQ = 2;
-    const DevState* st; const double* p; const double* s; const double* t; const double* rhat; double* x; double* r;
+    // p / sx: the directions x is updated with (M^-1 p, M^-1 s in the right-preconditioned extension); s: the true s
+    const DevState* st; const double* p; const double* sx; const double* s; const double* t; const double* rhat; double* x; double* r;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
         const double al = st->alpha;
         const d2 pp = ld2(p, i), xx = ld2(x, i);
         if (st->early) { st2(x, i, xx.a + al * pp.a, xx.b + al * pp.b); return; }
         const double om = st->omega;
         const d2 ss = ld2(s, i), tt = ld2(t, i), hh = ld2(rhat, i);
-        st2(x, i, xx.a + al * pp.a + om * ss.a, xx.b + al * pp.b + om * ss.b);
+        d2 sd = ss;
+        if (sx != s) sd = ld2(sx, i);
+        st2(x, i, xx.a + al * pp.a + om * sd.a, xx.b + al * pp.b + om * sd.b);
         const double r0 = ss.a - om * tt.a, r1 = ss.b - om * tt.b;
         st2(r, i, r0, r1);
         if (in0) { acc[0] = acc[0] + r0 * r0; acc[1] = acc[1] + hh.a * r0; }
@@ -502,7 +505,7 @@ struct BicgRun : SolverRun {
         else KR_TRY(launch_spmv(a, s, t, 2, s, done));                                            // :208-209 + (t,s),(t,t)
         KR_TRY((reduce_then<2>(ctx, nt, ws.red, BicgOmegaLogic{lc})));
         KR_TRY(ensure_partials(ctx, nt));
-        const BicgXROp op{st, pc ? ph : pp, pc ? sh : s, t, rhat, xw, r};
+        const BicgXROp op{st, pc ? ph : pp, pc ? sh : s, s, t, rhat, xw, r};
         const int64_t grid = std::min<int64_t>(nt, (int64_t)ctx->num_cu * 8);
         if (grid > 0) {
             hipLaunchKernelGGL((ew_kernel_early<BicgXROp>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, n, nt,

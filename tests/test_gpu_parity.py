@@ -160,6 +160,34 @@ def test_chebyshev_trait_apply_is_a_stub(ctx):
     assert e.value.code == 2                                    # KError::SolveError, chebyshev.rs:68-70
 
 
+ILU_MODES = [("compat", K.Ilu0, O.Pc.ilu0_compat), ("ilup0", K.Ilup, O.Pc.ilup0), ("true", K.TrueIlu0, O.Pc.ilu0_true)]
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_ilu_apply_bit_exact(ctx, mode):
+    """Level-scheduled triangular solve == the reference's row-sequential loops (ilu.rs:105-122, ilup.rs:138-167)."""
+    _, kcls, ofn = ILU_MODES[mode]
+    rng = np.random.default_rng(11 + mode)
+    mats = [O.stencil7(5, "convdiff"), O.stencil7(17, "aniso"), O.stencil7(30, "poisson"),
+            O.Csr.from_dense(O.tridiag(10, -1.0, 2.0, 0.5), keep_zeros=False)]
+    d = rng.random((40, 40)) * (rng.random((40, 40)) < 0.2) + np.diag(3.0 + rng.random(40))
+    mats.append(O.Csr.from_dense(d, keep_zeros=False))
+    mats.append(O.Csr.from_dense(d, keep_zeros=True))                   # stored zeros are skipped (`!= T::zero()`)
+    for a in mats:
+        r = rng.standard_normal(a.nrows)
+        z = kcls().setup(to_dev(ctx, a)).apply(r)
+        assert np.array_equal(z, ofn(a).apply(r)), (mode, a.nrows)
+
+
+def test_ilu_apply_twice_reuses_graph(ctx):
+    a = O.stencil7(20)
+    pc = K.Ilu0().setup(to_dev(ctx, a))
+    ref = O.Pc.ilu0_compat(a)
+    for seed in (1, 2, 3):
+        r = O.splitmix64_uniform(seed, a.nrows)
+        assert np.array_equal(pc.apply(r), ref.apply(r))
+
+
 # ------------------------------------------------------------------------------------------------ solvers
 def _check_solver(res, stats, solver, x, exact=True):
     assert stats.iterations == res.iterations and stats.converged == res.converged
@@ -325,6 +353,46 @@ def test_gmres_bit_exact(ctx, rs, side, restart):
     x = np.zeros(a.nrows)
     st = s.solve(d, kpc, b, x)
     _check_solver(res, st, s, x)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_solvers_with_ilu_bit_exact(ctx, rs, mode):
+    _, kcls, ofn = ILU_MODES[mode]
+    a = O.stencil7(10, "aniso")
+    b = a.spmv(np.ones(a.nrows))
+    d = to_dev(ctx, a)
+    kpc, opc = kcls().setup(d), ofn(a)
+    # PCG (the symmetric modes are SPD preconditioners; compat is not symmetric: errors must match too)
+    res = O.solve("pcg", a, b, pc=opc, tol=1e-9, max_iters=200, rs=rs, raise_on_error=False)
+    s = K.PcgSolver(1e-9, 200); x = np.zeros(a.nrows)
+    try:
+        st, code = s.solve(d, kpc, b, x), 0
+    except K.KError as e:
+        st, code = e.stats, e.code
+    assert code == res.code
+    _check_solver(res, st, s, x, exact=(code == 0))
+    # GMRES-Left (tests/preconditioner_integration.rs:169-179 shape) and the right-preconditioned BiCGStab extension
+    an = O.stencil7(9, "convdiff"); bn = an.spmv(np.ones(an.nrows)); dn = to_dev(ctx, an)
+    kpc, opc = kcls().setup(dn), ofn(an)
+    res = O.solve("gmres", an, bn, pc=opc, tol=1e-9, max_iters=60, restart=20, side=O.SIDE_LEFT, rs=rs)
+    s = K.GmresSolver(20, 1e-9, 60); x = np.zeros(an.nrows)
+    st = s.solve(dn, kpc, bn, x)
+    _check_solver(res, st, s, x)
+    tol = 1e-9 * np.linalg.norm(bn)
+    res = O.solve("bicgstab_rpc", an, bn, pc=opc, tol=tol, max_iters=100, rs=rs)
+    s = K.BiCgStabRightPcSolver(tol, 100); x = np.zeros(an.nrows)
+    st = s.solve(dn, kpc, bn, x)
+    _check_solver(res, st, s, x)
+
+
+def test_nonsym_left_ilu0_gmres_reference_test(ctx, rs):
+    # tests/preconditioner_integration.rs:169-179: needs two restart cycles = 20 iterations
+    n = 10
+    ao = O.Csr.from_dense(O.tridiag(n, -1.0, 2.0, 0.5), keep_zeros=False)
+    a = to_dev(ctx, ao)
+    b = ao.spmv(np.ones(n)); x = np.zeros(n)
+    st = K.GmresSolver(10, 1e-12, 100).with_preconditioning(K.Preconditioning.Left).solve(a, K.Ilu0().setup(a), b, x)
+    assert st.converged and st.iterations == 20 and np.linalg.norm(x - 1) / np.sqrt(n) < 1e-10
 
 
 def test_gmres_reference_known_answers(ctx):
