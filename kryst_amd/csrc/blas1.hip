@@ -85,6 +85,15 @@ __global__ void rank_fold_kernel(const double* gathered, int nq, int nranks, dou
     out[q] = total;
 }
 
+// A one-rank communicator normally skips RCCL; KRYST_FORCE_COMM=1 keeps the collective path (used by the
+// single-GPU rehearsal of the multi-rank code in tests/test_gpu_dist_single.py).
+bool use_collectives(kryst_ctx_t ctx) {
+    if (ctx->nranks > 1) return true;
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("KRYST_FORCE_COMM"); force = (e && atoi(e) != 0) ? 1 : 0; }
+    return force == 1 && ctx->comm != nullptr;
+}
+
 int32_t ensure_partials(kryst_ctx_t ctx, int64_t ntiles) {
     if (ntiles <= ctx->partials_cap) return KRYST_OK;
     if (ctx->d_partials) { KR_HIP(hipStreamSynchronize(ctx->s_main)); KR_HIP(hipFree(ctx->d_partials)); ctx->d_partials = nullptr; }
@@ -112,7 +121,7 @@ int32_t launch_final_fold(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out
 }
 
 int32_t reduce_all(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out) {
-    if (ctx->nranks == 1) return launch_final_fold(ctx, nq, ntiles, d_out);
+    if (!use_collectives(ctx)) return launch_final_fold(ctx, nq, ntiles, d_out);
     // local fold -> all-gather of nq doubles per rank -> fold in rank order (bitwise identical on every rank)
     double* local = ctx->d_gather + (size_t)ctx->nranks * KR_MAXQ;      // staging after the gather area
     KR_TRY(launch_final_fold(ctx, nq, ntiles, local));

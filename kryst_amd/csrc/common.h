@@ -143,5 +143,6 @@ int32_t launch_final_fold(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out
 // global (all ranks) value of nq partial arrays -> d_out[0..nq) on every rank; folds ranks in rank order
 int32_t reduce_all(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out);
 int32_t vec_check2(kryst_vec_t a, kryst_vec_t b);
+bool use_collectives(kryst_ctx_t ctx);
 
 }  // namespace kr

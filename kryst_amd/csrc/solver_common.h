@@ -73,7 +73,7 @@ __global__ void logic_kernel(const double* red, L logic) {
 
 template <int NQ, class L>
 inline int32_t reduce_then(kryst_ctx_t ctx, int64_t ntiles, double* d_red, const L& logic) {
-    if (ctx->nranks == 1) {
+    if (!use_collectives(ctx)) {
         KR_TRY(ensure_partials(ctx, ntiles > 0 ? ntiles : 1));
         hipLaunchKernelGGL((fold_logic_kernel<NQ, L>), dim3(1), dim3(KR_F), 0, ctx->s_main, ctx->d_partials,
                            ctx->partials_cap, ntiles, d_red, logic);

@@ -301,7 +301,7 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
 int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const double* dvec, const int* done) {
     kryst_ctx_t ctx = a->ctx;
     if (nq > 0) KR_TRY(ensure_partials(ctx, a->ntiles));
-    if (!a->dist || ctx->nranks == 1)
+    if (!a->dist || !use_collectives(ctx))
         return launch_tiles<false>(a, x, y, nq, dvec, done, nullptr, a->ntiles);
     // halo exchange on s_comm, overlapped with the interior tiles
     HaloPlan& pl = a->plan;
@@ -497,7 +497,7 @@ int32_t kryst_csr_create_stencil7(kryst_ctx_t ctx, int32_t N, int32_t kind, krys
     std::vector<int64_t> rp((size_t)nloc + 1), col((size_t)nnz);
     std::vector<double> val((size_t)nnz);
     kryst_host_stencil7(N, kind, k_lo, k_hi, rp.data(), col.data(), val.data());
-    if (P == 1) return create_local(ctx, n, n, rp.data(), col.data(), val.data(), out);
+    if (P == 1 && !use_collectives(ctx)) return create_local(ctx, n, n, rp.data(), col.data(), val.data(), out);
     return kryst_csr_create_dist(ctx, n, offs.data(), rp.data(), col.data(), val.data(), out);
 }
 
