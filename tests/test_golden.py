@@ -1,0 +1,82 @@
+"""Committed golden vectors (tests/golden/krylov_golden.npz, made by tests/golden/make_golden.py):
+CPU: the oracle still reproduces them (both dot orders).  GPU: the HIP path reproduces the tile-order vectors
+bit for bit and the serial-fold vectors to 1e-12 of the initial residual with equal iteration counts."""
+import os
+import sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as MG            # noqa: E402
+from oracle import oracle as O      # noqa: E402
+
+G = np.load(os.path.join(HERE, "golden", "krylov_golden.npz"))
+
+
+@pytest.mark.parametrize("case", MG.CASES, ids=[c[0] for c in MG.CASES])
+@pytest.mark.parametrize("mode", ["serial", "tiled"])
+def test_oracle_reproduces_golden(case, mode):
+    _, b, _, res = MG.run_case(case, mode)
+    name = case[0]
+    assert np.array_equal(b, G[f"{name}/b"])
+    st = G[f"{name}/{mode}/stats"]
+    assert (res.iterations, float(res.converged), res.final_residual, res.code) == tuple(st)
+    assert np.array_equal(res.history, G[f"{name}/{mode}/history"]) and np.array_equal(res.x, G[f"{name}/{mode}/x"])
+
+
+def test_golden_spmv_oracle():
+    a = O.Csr(64, 64, G["spmv4/row_ptr"], G["spmv4/col_idx"], G["spmv4/vals"])
+    assert np.array_equal(a.spmv(G["spmv4/x"]), G["spmv4/y"])
+
+
+def _hip_solve(K, ctx, case):
+    name, N, kind, method, pcname, kw = case[:6]
+    a = K.CsrMatrix.stencil7(N, kind, ctx=ctx)
+    b = G[f"{name}/b"]
+    tol = float(G[f"{name}/tol"][0])
+    pc = {None: lambda: None, "jacobi": lambda: K.Jacobi().setup(a), "ilu0_true": lambda: K.TrueIlu0().setup(a),
+          "ilup0": lambda: K.Ilup(0).setup(a), "ilu0_compat": lambda: K.Ilu0().setup(a)}[pcname]()
+    if method == "cg":
+        s = K.CgSolver(tol, kw["max_iters"])
+    elif method == "pcg":
+        s = K.PcgSolver(tol, kw["max_iters"])
+    elif method == "gmres":
+        s = K.GmresSolver(kw["restart"], tol, kw["max_iters"]).with_preconditioning(K.Preconditioning(kw.get("side", 1)))
+    elif method == "bicgstab":
+        s = K.BiCgStabSolver(tol, kw["max_iters"])
+    else:
+        s = K.BiCgStabRightPcSolver(tol, kw["max_iters"])
+    x = np.zeros(N ** 3)
+    try:
+        st, code = s.solve(a, pc, b, x), 0
+    except K.KError as e:
+        st, code = e.stats, e.code
+    return s, st, x, code
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in MG.CASES if len(c) == 6], ids=[c[0] for c in MG.CASES if len(c) == 6])
+def test_hip_reproduces_golden(case):
+    import kryst_amd as K
+    ctx = K.Context.default()
+    assert K.reduce_spec() == (MG.T, MG.V, MG.F), "golden vectors were made for another reduction spec: regenerate"
+    name = case[0]
+    s, st, x, code = _hip_solve(K, ctx, case)
+    gt, gs = G[f"{name}/tiled/stats"], G[f"{name}/serial/stats"]
+    assert (st.iterations, float(st.converged), st.final_residual, code) == tuple(gt)
+    h = np.array(s.residual_history)
+    assert np.array_equal(h, G[f"{name}/tiled/history"])
+    if code == 0:
+        assert np.array_equal(x, G[f"{name}/tiled/x"])
+        # against the strict serial-fold reference build
+        hs = G[f"{name}/serial/history"]
+        assert st.iterations == int(gs[0]) and len(h) == len(hs)
+        assert np.max(np.abs(h - hs)) <= 1e-12 * hs[0]
+
+
+@pytest.mark.gpu
+def test_hip_golden_spmv():
+    import kryst_amd as K
+    a = K.CsrMatrix.from_csr(64, 64, G["spmv4/row_ptr"], G["spmv4/col_idx"], G["spmv4/vals"], ctx=K.Context.default())
+    assert np.array_equal(a.spmv(G["spmv4/x"]), G["spmv4/y"])
