@@ -9,8 +9,10 @@ W warm-up iterations and exactly K timed iterations run inside one stepping sess
 never stops early); the timed region is bracketed by barrier + device synchronize on both sides and the maximum
 over ranks is reported.  One JSON line on rank 0.
 
-N = 1: the workload of BASELINE.json configs[1] (256^3).  N > 1: the SAME global problem is row-partitioned in
-k-slabs over the ranks (strong scaling, north_star), halo planes over xGMI, inner products by RCCL all-gather.
+Workload: ONE fixed 512^3 system for every N (BASELINE.json's metric is quoted on 256^3/512^3; north_star asks for
+strong scaling of CG iterations/sec on 512^3, which fits a single 288 GB GPU).  N > 1: row-partitioned in k-slabs over
+the ranks, halo planes over xGMI, inner products by RCCL all-gather.  At N = 1 the line also carries the same
+measurement on configs[1]'s 256^3 grid ("config1_256").
 """
 import argparse
 import json
@@ -30,17 +32,20 @@ def spmv_bytes(n, nnz):
     return 12 * nnz + 4 * (n + 1) + 16 * n
 
 
-def cpu_baseline(grid, seconds=15.0):
-    """The oracle's CG (the CPU restatement of the reference path) timed on the host cores on a bounded sample of
-    the same workload: as many CG iterations on the same grid as fit in ~`seconds`."""
+def cpu_baseline(grid, seconds=12.0):
+    """The oracle's CG (the CPU restatement of the reference path, OpenMP over rows / tiles like the reference's
+    Rayon loops) timed on the host cores on a BOUNDED sample of the same workload: CG on the 256^3 Poisson system
+    (1/8 of the 512^3 rows when grid = 512; every pass is a bandwidth-bound stream, so a 512^3 iteration costs 8x),
+    as many iterations as fit in ~`seconds`."""
     import numpy as np
     import kryst_amd as K
     from oracle import oracle as O
     cores = min(len(os.sched_getaffinity(0)), 16)      # the GPU box's CPU share for one GPU
     O.set_threads(cores)
     T, V, F = K.reduce_spec()
-    rp, ci, va = K.host_stencil7(grid, "poisson")
-    a = O.Csr(grid ** 3, grid ** 3, rp, ci, va, check=False)
+    sgrid = min(grid, 256)
+    rp, ci, va = K.host_stencil7(sgrid, "poisson")
+    a = O.Csr(sgrid ** 3, sgrid ** 3, rp, ci, va, check=False)
     b = a.spmv(np.ones(a.nrows))
     rs = O.Reduce.tiled(T, V, F)
     t0 = time.perf_counter(); O.solve("cg", a, b, tol=0.0, max_iters=3, rs=rs); t3 = time.perf_counter() - t0
@@ -48,9 +53,44 @@ def cpu_baseline(grid, seconds=15.0):
     t0 = time.perf_counter()
     res = O.solve("cg", a, b, tol=0.0, max_iters=iters, rs=rs)
     dt = time.perf_counter() - t0
-    return {"value": res.iterations / dt, "unit": "cg_iterations/s", "cores": cores, "kind": "port",
-            "sample": f"{res.iterations} oracle CG iterations on the same {grid}^3 Poisson system ({dt:.1f} s, "
-                      f"OpenMP rows/tiles over {cores} threads, device-order dot)"}
+    scale = (sgrid / grid) ** 3
+    return {"value": res.iterations / dt * scale, "unit": "cg_iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{res.iterations} oracle CG iterations on a {sgrid}^3 Poisson system in {dt:.1f} s "
+                      f"({res.iterations / dt:.1f} it/s, OpenMP rows/tiles over {cores} threads, device-order dot)"
+                      + (f"; scaled by {scale:.4f} = ({sgrid}/{grid})^3 rows to the {grid}^3 workload" if scale != 1 else "")}
+
+
+def run_cg(K, ctx, dist, grid, solver, warmup, steps):
+    """W warm-up + exactly K timed iterations of one stepping session; returns (seconds, stats, spmv_ms, a)."""
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    a = K.CsrMatrix.stencil7(grid, "poisson", ctx=ctx)
+    nloc = a.nrows()
+    ones = ctx.vec(nloc).fill(1.0)
+    b = a.spmv(ones)                      # b = A*1 (tests/preconditioner_integration.rs:25-31 convention)
+    x = ctx.vec(nloc)
+    pc = K.Jacobi().setup(a) if solver == "pcg" else None
+    sess = K.Session(solver, a, pc, b, x, tol=0.0, max_iters=warmup + steps)
+    sess.step(warmup)
+    barrier()
+    t0 = time.perf_counter()
+    sess.step(steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    stats = sess.end()
+    assert stats.iterations == warmup + steps, stats
+    # dominant kernel: the SpMV with the fused (p,Ap) partials, timed live with HIP events on its own stream
+    y = ctx.vec(nloc)
+    spmv_ms = a.bench_spmv(b, y, fused_dots=1, reps=50)
+    return dt, stats, spmv_ms, nloc, a.nnz
 
 
 def main():
@@ -58,7 +98,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--grid", type=int, default=0, help="grid edge (default 256 on one GPU, 512 on several)")
+    ap.add_argument("--grid", type=int, default=0, help="grid edge (default 512 for every N)")
     ap.add_argument("--solver", default="cg", choices=["cg", "pcg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -70,7 +110,7 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    grid = args.grid or (256 if world == 1 else 512)
+    grid = args.grid or 512          # ONE fixed problem for every N (strong scaling, north_star): 512^3
 
     dist = None
     if world > 1:
@@ -86,39 +126,10 @@ def main():
     else:
         ctx = K.Context(0)
 
-    def barrier():
-        ctx.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    a = K.CsrMatrix.stencil7(grid, "poisson", ctx=ctx)
-    nloc = a.nrows()
     n = grid ** 3
     nnz = 7 * n - 6 * grid * grid
-    ones = ctx.vec(nloc).fill(1.0)
-    b = a.spmv(ones)                      # b = A*1 (tests/preconditioner_integration.rs:25-31 convention)
-    x = ctx.vec(nloc)
-    pc = K.Jacobi().setup(a) if args.solver == "pcg" else None
-
-    sess = K.Session(args.solver, a, pc, b, x, tol=0.0, max_iters=args.warmup + args.steps)
-    sess.step(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    sess.step(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    stats = sess.end()
-    assert stats.iterations == args.warmup + args.steps, stats
-
-    # dominant kernel: the SpMV with the fused (p,Ap) partials, timed live with HIP events on its own stream
-    y = ctx.vec(nloc)
-    spmv_ms = a.bench_spmv(b, y, fused_dots=1, reps=50)
-    bytes_local = spmv_bytes(nloc, a.nnz)
+    dt, stats, spmv_ms, nloc, nnz_loc = run_cg(K, ctx, dist, grid, args.solver, args.warmup, args.steps)
+    bytes_local = spmv_bytes(nloc, nnz_loc)
     achieved = bytes_local / (spmv_ms * 1e-3) / 1e9
 
     out = {
@@ -140,6 +151,14 @@ def main():
                 out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
         except Exception:
             pass
+    if world == 1 and grid != 256:
+        dt2, st2, ms2, nl2, nz2 = run_cg(K, ctx, None, 256, args.solver, args.warmup, args.steps)
+        b2 = spmv_bytes(nl2, nz2)
+        out["config1_256"] = {"workload": f"{'jacobi_pcg' if args.solver == 'pcg' else 'cg'}_poisson7_256^3",
+                              "value": args.steps / dt2, "unit": "iterations/s", "ms_per_step": dt2 / args.steps * 1e3,
+                              "roofline": {"achieved": b2 / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": ms2,
+                                           "bytes_per_launch": b2}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(grid)

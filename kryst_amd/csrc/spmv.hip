@@ -483,8 +483,116 @@ int32_t kryst_csr_create_dist(kryst_ctx_t ctx, int64_t n_global, const int64_t* 
     return KRYST_OK;
 }
 
-int32_t kryst_csr_create_stencil7(kryst_ctx_t ctx, int32_t N, int32_t kind, kryst_csr_t* out) {
-    KR_ARG(ctx && out && N >= 1 && kind >= 0 && kind <= 2, "csr_create_stencil7");
+// ---- device-side generation of the synthetic 7-point operators (no host arrays, no PCIe) ----
+// global prefix of the row lengths: 7*row minus the neighbours that fall outside the grid in rows < row
+__host__ __device__ static inline int64_t stencil_gptr(int64_t row, int64_t N) {
+    const int64_t N2 = N * N;
+    const int64_t plane = row / N2, inpl = row % N2;
+    const int64_t f_bottom = row < N2 ? row : N2;                                  // rows with k == 0
+    const int64_t f_top = row > (N - 1) * N2 ? row - (N - 1) * N2 : 0;             // rows with k == N-1
+    const int64_t f_south = plane * N + (inpl < N ? inpl : N);                     // j == 0
+    const int64_t f_north = plane * N + (inpl > (N - 1) * N ? inpl - (N - 1) * N : 0);   // j == N-1
+    const int64_t f_west = (row + N - 1) / N;                                      // i == 0
+    const int64_t f_east = row / N;                                                // i == N-1
+    return 7 * row - (f_bottom + f_top + f_south + f_north + f_west + f_east);
+}
+
+struct StencilCoef { double c[7]; };
+
+__global__ void stencil7_gen_kernel(int32_t N, int64_t lo, int64_t hi, int64_t n_lower, StencilCoef sc,
+                                    int32_t* row_ptr, int32_t* col, double* val) {
+    const int64_t nloc = hi - lo;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nloc) return;
+    const int64_t row = lo + i;
+    const int64_t base = stencil_gptr(lo, N);
+    int64_t k = stencil_gptr(row, N) - base;
+    row_ptr[i] = (int32_t)k;
+    if (i == nloc) return;
+    const int64_t N1 = N, N2 = N1 * N1;
+    const int64_t ii = row % N1, jj = (row / N1) % N1, kk = row / N2;
+    const bool ok[7] = {kk > 0, jj > 0, ii > 0, true, ii < N1 - 1, jj < N1 - 1, kk < N1 - 1};
+    const int64_t off[7] = {-N2, -N1, -1, 0, 1, N1, N2};
+#pragma unroll
+    for (int s = 0; s < 7; ++s)
+        if (ok[s]) {
+            const int64_t c = row + off[s];
+            int64_t lc;
+            if (c >= lo && c < hi) lc = c - lo;
+            else if (c < lo) lc = nloc + (c - (lo - N2));           // halo plane from rank-1
+            else lc = nloc + n_lower + (c - hi);                    // halo plane from rank+1
+            col[k] = (int32_t)lc; val[k] = sc.c[s];
+            ++k;
+        }
+}
+
+static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, kryst_csr_t* out) {
+    const int P = ctx->nranks, me = ctx->rank;
+    const int64_t N2 = (int64_t)N * N, n = N2 * N;
+    std::vector<int64_t> offs((size_t)P + 1);
+    KR_TRY(kryst_host_partition_rows(n, P, N2, offs.data()));
+    const int64_t lo = offs[me], hi = offs[me + 1], nloc = hi - lo;
+    const int64_t nnz = stencil_gptr(hi, N) - stencil_gptr(lo, N);
+    KR_ARG(nloc < (1ll << 31) - KR_TILE && nnz < (1ll << 31) - 16, "local block exceeds int32 device indexing");
+    const bool dist = use_collectives(ctx);
+    const bool has_lower = dist && me > 0 && nloc > 0, has_upper = dist && me < P - 1 && nloc > 0;
+    KR_ARG(!dist || P == 1 || nloc >= N2, "stencil7: more ranks than grid planes");
+    KR_HIP(hipSetDevice(ctx->device));
+    kryst_csr_t a = new kryst_csr_s();
+    a->ctx = ctx; a->nrows = nloc; a->ncols = n; a->nnz = nnz; a->dist = dist; a->xlen = dist ? nloc : n;
+    a->row_offsets = offs;
+    StencilCoef sc;
+    {   // same coefficients as kryst_host_stencil7
+        double* c = sc.c;
+        if (kind == 0) { c[0] = c[1] = c[2] = c[4] = c[5] = c[6] = -1.0; c[3] = 6.0; }
+        else if (kind == 1) { const double cx = 1.0, cy = 1.0, cz = 0.01; c[2] = c[4] = -cx; c[1] = c[5] = -cy; c[0] = c[6] = -cz; c[3] = 2.0 * (cx + cy + cz); }
+        else { const double gx = 1.0, gy = 0.5, gz = 0.25; c[2] = -(1.0 + gx); c[4] = -1.0; c[1] = -(1.0 + gy); c[5] = -1.0; c[0] = -(1.0 + gz); c[6] = -1.0; c[3] = 6.0 + gx + gy + gz; }
+    }
+    int32_t rc = KRYST_OK;
+    do {
+        if (hipMalloc(&a->d_row_ptr, sizeof(int32_t) * (size_t)(nloc + 1 + 8)) != hipSuccess ||
+            hipMalloc(&a->d_col, sizeof(int32_t) * (size_t)(nnz + 8)) != hipSuccess ||
+            hipMalloc(&a->d_val, sizeof(double) * (size_t)(nnz + 8)) != hipSuccess) { set_error("hipMalloc failed (stencil7)"); rc = KRYST_ERR_HIP; break; }
+        hipMemsetAsync(a->d_col + nnz, 0, sizeof(int32_t) * 8, ctx->s_main);
+        hipMemsetAsync(a->d_val + nnz, 0, sizeof(double) * 8, ctx->s_main);
+        const int64_t nthreads = nloc + 1;
+        hipLaunchKernelGGL(stencil7_gen_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->s_main, N, lo, hi,
+                           has_lower ? N2 : 0, sc, a->d_row_ptr, a->d_col, a->d_val);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("stencil7 generation failed"); rc = KRYST_ERR_HIP; break; }
+        a->ntiles = ntiles_of(nloc);
+        a->slots = 7;
+        if (!dist) break;
+        // analytic halo plan of a k-slab partition: one grid plane from each neighbour, sent in place
+        HaloPlan& pl = a->plan;
+        pl.nranks = P; pl.rank = me; pl.row_lo = lo; pl.row_hi = hi;
+        pl.recv_counts.assign(P, 0); pl.recv_off.assign(P, 0); pl.send_counts.assign(P, 0); pl.send_off.assign(P, 0);
+        if (has_lower) { pl.recv_counts[me - 1] = N2; pl.recv_off[me - 1] = 0; pl.send_counts[me - 1] = N2; pl.send_off[me - 1] = 0; }
+        if (has_upper) { pl.recv_counts[me + 1] = N2; pl.recv_off[me + 1] = has_lower ? N2 : 0;
+                         pl.send_counts[me + 1] = N2; pl.send_off[me + 1] = nloc - N2; }
+        pl.total_recv = (has_lower ? N2 : 0) + (has_upper ? N2 : 0);
+        pl.total_send = pl.total_recv;
+        a->send_contiguous = true;                      // send_off = first local row of each run
+        std::vector<int32_t> ti, tb;
+        for (int64_t q = 0; q < a->ntiles; ++q) {
+            const int64_t r0 = q * KR_TILE, r1 = std::min<int64_t>(r0 + KR_TILE, nloc);
+            const bool bnd = (has_lower && r0 < N2) || (has_upper && r1 > nloc - N2);
+            (bnd ? tb : ti).push_back((int32_t)q);
+        }
+        a->n_interior = (int64_t)ti.size(); a->n_boundary = (int64_t)tb.size();
+        if (hipMalloc(&a->d_tiles_interior, sizeof(int32_t) * (ti.size() + 1)) != hipSuccess ||
+            hipMalloc(&a->d_tiles_boundary, sizeof(int32_t) * (tb.size() + 1)) != hipSuccess ||
+            hipMalloc(&pl.d_halo, sizeof(double) * (size_t)(pl.total_recv + 2)) != hipSuccess) { set_error("hipMalloc failed (halo)"); rc = KRYST_ERR_HIP; break; }
+        if (!ti.empty()) hipMemcpyAsync(a->d_tiles_interior, ti.data(), sizeof(int32_t) * ti.size(), hipMemcpyHostToDevice, ctx->s_main);
+        if (!tb.empty()) hipMemcpyAsync(a->d_tiles_boundary, tb.data(), sizeof(int32_t) * tb.size(), hipMemcpyHostToDevice, ctx->s_main);
+        hipMemsetAsync(pl.d_halo, 0, sizeof(double) * (size_t)(pl.total_recv + 2), ctx->s_main);
+        if (hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("halo setup failed"); rc = KRYST_ERR_HIP; }
+    } while (0);
+    if (rc != KRYST_OK) { kryst_csr_destroy(a); return rc; }
+    *out = a;
+    return KRYST_OK;
+}
+
+static int32_t create_stencil7_host(kryst_ctx_t ctx, int32_t N, int32_t kind, kryst_csr_t* out) {
     const int P = ctx->nranks;
     const int64_t n = (int64_t)N * N * N;
     std::vector<int64_t> offs((size_t)P + 1);
@@ -499,6 +607,14 @@ int32_t kryst_csr_create_stencil7(kryst_ctx_t ctx, int32_t N, int32_t kind, krys
     kryst_host_stencil7(N, kind, k_lo, k_hi, rp.data(), col.data(), val.data());
     if (P == 1 && !use_collectives(ctx)) return create_local(ctx, n, n, rp.data(), col.data(), val.data(), out);
     return kryst_csr_create_dist(ctx, n, offs.data(), rp.data(), col.data(), val.data(), out);
+}
+
+int32_t kryst_csr_create_stencil7(kryst_ctx_t ctx, int32_t N, int32_t kind, kryst_csr_t* out) {
+    KR_ARG(ctx && out && N >= 1 && kind >= 0 && kind <= 2, "csr_create_stencil7");
+    // KRYST_STENCIL_HOST=1: build through the general host path (kryst_host_stencil7 + csr_create[_dist]); the two
+    // paths must give identical operators (tests/test_gpu_parity.py)
+    if (env_int("KRYST_STENCIL_HOST", 0)) return create_stencil7_host(ctx, N, kind, out);
+    return create_stencil7_device(ctx, N, kind, out);
 }
 
 int32_t kryst_csr_destroy(kryst_csr_t a) {

@@ -16,3 +16,8 @@ y = ctx.vec(n)
 ms = a.bench_spmv(x, y, fused_dots=nq, reps=reps)
 b = 12 * a.nnz + 4 * (n + 1) + 16 * n
 print(f"grid {grid} nq {nq}: {ms:.4f} ms/launch  {b / ms / 1e6:.1f} GB/s  ({b / ms / 1e6 / 8000:.3f} of 8 TB/s)")
+# calibration launches with a KNOWN byte count (MI355X_MICROARCH.md, HBM: calibrate FETCH_SIZE on your own access pattern):
+# ew_kernel<DotOp> reads 2*n*8 bytes with 16 B/lane loads and writes n/512*8 bytes
+for _ in range(5):
+    K.dot(x, y)
+print(f"calibration: ew_kernel<DotOp> reads {2 * n * 8} bytes per launch")
