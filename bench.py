@@ -90,7 +90,13 @@ def run_cg(K, ctx, dist, grid, solver, warmup, steps):
     # dominant kernel: the SpMV with the fused (p,Ap) partials, timed live with HIP events on its own stream
     y = ctx.vec(nloc)
     spmv_ms = a.bench_spmv(b, y, fused_dots=1, reps=50)
-    return dt, stats, spmv_ms, nloc, a.nnz
+    # context for the roofline: the device-copy rate at this footprint (hipMemcpy D2D of one vector, read + write)
+    y.copy_from(b); ctx.synchronize()
+    ctx.timer_start()
+    for _ in range(10):
+        y.copy_from(b)
+    copy_gbs = 10 * 16.0 * nloc / (ctx.timer_stop() * 1e-3) / 1e9
+    return dt, stats, spmv_ms, nloc, a.nnz, copy_gbs
 
 
 def main():
@@ -128,7 +134,7 @@ def main():
 
     n = grid ** 3
     nnz = 7 * n - 6 * grid * grid
-    dt, stats, spmv_ms, nloc, nnz_loc = run_cg(K, ctx, dist, grid, args.solver, args.warmup, args.steps)
+    dt, stats, spmv_ms, nloc, nnz_loc, copy_gbs = run_cg(K, ctx, dist, grid, args.solver, args.warmup, args.steps)
     bytes_local = spmv_bytes(nloc, nnz_loc)
     achieved = bytes_local / (spmv_ms * 1e-3) / 1e9
 
@@ -141,7 +147,8 @@ def main():
                    "final_residual": stats.final_residual},
         "roofline": {"bound": "hbm", "kernel": "spmv_kernel<1> (CSR SpMV + fused (p,Ap) partials)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "bytes_per_launch": bytes_local, "ms_per_launch": spmv_ms, "traffic": None},
+                     "bytes_per_launch": bytes_local, "ms_per_launch": spmv_ms, "traffic": None,
+                     "measured_copy_GBs": copy_gbs},
     }
     tf = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     if os.path.exists(tf):
@@ -152,13 +159,13 @@ def main():
         except Exception:
             pass
     if world == 1 and grid != 256:
-        dt2, st2, ms2, nl2, nz2 = run_cg(K, ctx, None, 256, args.solver, args.warmup, args.steps)
+        dt2, st2, ms2, nl2, nz2, cp2 = run_cg(K, ctx, None, 256, args.solver, args.warmup, args.steps)
         b2 = spmv_bytes(nl2, nz2)
         out["config1_256"] = {"workload": f"{'jacobi_pcg' if args.solver == 'pcg' else 'cg'}_poisson7_256^3",
                               "value": args.steps / dt2, "unit": "iterations/s", "ms_per_step": dt2 / args.steps * 1e3,
                               "roofline": {"achieved": b2 / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": ms2,
-                                           "bytes_per_launch": b2}}
+                                           "bytes_per_launch": b2, "measured_copy_GBs": cp2}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(grid)

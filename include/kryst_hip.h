@@ -48,7 +48,8 @@ typedef struct kryst_pc_s*  kryst_pc_t;
 const char* kryst_hip_last_error(void);
 int32_t     kryst_hip_abi_version(void);
 /* The fixed inner-product tree: tile = T*V elements; thread t folds its V elements, 64-lane xor butterfly,
- * serial across the T/64 waves; tile partials folded by F threads (stride F), butterfly, serial across waves. */
+ * serial across the T/64 waves; the tile partials are folded in chunks of F (one per thread, butterfly, serial
+ * across the F/64 waves) and, when there is more than one chunk, the chunk values by F threads (stride F) likewise. */
 void        kryst_reduce_spec(int32_t* T, int32_t* V, int32_t* F);
 
 /* ---- context: one per GPU / per rank.  Replaces src/parallel (Comm trait, parallel/mod.rs:4-35) ---- */

@@ -66,10 +66,10 @@ struct SplitmixOp {                  // SURVEY 8d synthetic data
 // ---------------------------------------------------------------- final fold
 template <int NQ>
 __global__ __launch_bounds__(KR_F) void final_fold_kernel(const double* partials, int64_t stride, int64_t ntiles,
-                                                          double* out) {
+                                                          double* chunks, int64_t cstride, unsigned int* ticket, double* out) {
     __shared__ double lds[NQ * (KR_F / 64)];
     double v[NQ];
-    final_fold<NQ>(partials, stride, ntiles, v, lds);
+    if (!fold2<NQ>(partials, stride, ntiles, chunks, cstride, ticket, v, lds)) return;
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) out[q] = v[q];
@@ -100,6 +100,9 @@ int32_t ensure_partials(kryst_ctx_t ctx, int64_t ntiles) {
     int64_t cap = ntiles + 64;
     KR_HIP(hipMalloc(&ctx->d_partials, sizeof(double) * (size_t)cap * KR_MAXQ));
     ctx->partials_cap = cap;
+    if (ctx->d_chunks) { KR_HIP(hipFree(ctx->d_chunks)); ctx->d_chunks = nullptr; }
+    ctx->chunks_cap = nchunks_of(cap) + 8;
+    KR_HIP(hipMalloc(&ctx->d_chunks, sizeof(double) * (size_t)ctx->chunks_cap * KR_MAXQ));
     return KRYST_OK;
 }
 
@@ -111,9 +114,9 @@ int32_t launch_dot_partials(kryst_ctx_t ctx, const double* x, const double* y, i
 int32_t launch_final_fold(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out) {
     KR_TRY(ensure_partials(ctx, ntiles > 0 ? ntiles : 1));
     switch (nq) {
-        case 1: hipLaunchKernelGGL(final_fold_kernel<1>, dim3(1), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, d_out); break;
-        case 2: hipLaunchKernelGGL(final_fold_kernel<2>, dim3(1), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, d_out); break;
-        case 3: hipLaunchKernelGGL(final_fold_kernel<3>, dim3(1), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, d_out); break;
+        case 1: hipLaunchKernelGGL(final_fold_kernel<1>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
+        case 2: hipLaunchKernelGGL(final_fold_kernel<2>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
+        case 3: hipLaunchKernelGGL(final_fold_kernel<3>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
         default: set_error("final fold: nq=%d", nq); return KRYST_ERR_ARG;
     }
     KR_HIP(hipGetLastError());

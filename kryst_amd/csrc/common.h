@@ -63,6 +63,8 @@ struct kryst_ctx_s {
     kr::Comm* comm = nullptr;
     // reduction scratch: KR_MAXQ arrays of tile partials, sized on demand
     double* d_partials = nullptr; int64_t partials_cap = 0;     // doubles per array
+    double* d_chunks = nullptr; int64_t chunks_cap = 0;         // stage-1 results of the two-level fold
+    unsigned int* d_ticket = nullptr;
     double* d_scal = nullptr;        // small scalar arena (device), 4096 doubles
     double* d_gather = nullptr;      // nranks * KR_MAXQ doubles (all-gather target)
     kr::HostProgress* h_prog = nullptr; kr::HostProgress* d_prog = nullptr;   // mapped
@@ -80,6 +82,7 @@ namespace kr {
 
 int32_t ensure_partials(kryst_ctx_t ctx, int64_t ntiles);
 inline int64_t ntiles_of(int64_t n) { return (n + KR_TILE - 1) / KR_TILE; }
+inline int64_t nchunks_of(int64_t ntiles) { return ntiles > KR_F ? (ntiles + KR_F - 1) / KR_F : 1; }
 
 // ---- device-side reduction primitives (the association order is part of the ABI contract) ----
 #ifdef __HIPCC__
@@ -113,26 +116,45 @@ __device__ __forceinline__ void block_reduce(double (&v)[NQ], double* lds) {
     __syncthreads();
 }
 
-// fold of NQ arrays of tile partials by a block of KR_F threads; result valid in every thread
+// Two-level fold of NQ arrays of tile partials (one launch, gridDim.x = nchunks = ceil(ntiles / KR_F) workgroups of
+// KR_F threads):
+//   stage 1  workgroup c folds partials [c*KR_F, (c+1)*KR_F): thread t takes partial c*KR_F + t (0.0 past the end),
+//            64-lane butterfly, serial fold over the 16 waves -> chunk value c;
+//   stage 2  (only when nchunks > 1) the workgroup that finishes LAST folds the chunk values: thread t folds chunks
+//            t, t+KR_F, ... in ascending order, butterfly, serial over waves.
+// The association tree depends only on ntiles, never on which workgroup happens to be last.  Hand-off: relaxed
+// agent-scope stores of the chunk values, agent release fence, ticket atomic; the last workgroup acquires and reads
+// them with agent-scope loads (cdna_hip_programming.md, Guideline 16).  Returns true in the workgroup that holds
+// the final result (valid in every thread of it).
 template <int NQ>
-__device__ __forceinline__ void final_fold(const double* partials, int64_t stride, int64_t ntiles,
-                                           double (&out)[NQ], double* lds) {
+__device__ __forceinline__ bool fold2(const double* partials, int64_t stride, int64_t ntiles, double* chunks,
+                                      int64_t cstride, unsigned int* ticket, double (&out)[NQ], double* lds) {
+    __shared__ int is_last;
+    const int64_t i = (int64_t)blockIdx.x * KR_F + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) out[q] = (i < ntiles) ? partials[q * stride + i] : 0.0;
+    block_reduce<NQ, KR_F / 64>(out, lds);
+    if (gridDim.x == 1) return true;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) __hip_atomic_store(&chunks[q * cstride + blockIdx.x], out[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned int t = atomicAdd(ticket, 1u);
+        is_last = (t == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!is_last) return false;
+    __threadfence();
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         double acc = 0.0;
-        const double* p = partials + q * stride;
-        int64_t i = threadIdx.x;
-        for (; i + 7 * KR_F < ntiles; i += 8 * KR_F) {      // 8 loads in flight, folded in index order
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[i + u * KR_F];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = acc + v[u];
-        }
-        for (; i < ntiles; i += KR_F) acc = acc + p[i];
+        for (int64_t j = threadIdx.x; j < (int64_t)gridDim.x; j += KR_F)
+            acc = acc + __hip_atomic_load(&chunks[q * cstride + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         out[q] = acc;
     }
     block_reduce<NQ, KR_F / 64>(out, lds);
+    if (threadIdx.x == 0) *ticket = 0u;            // ready for the next (stream-ordered) fold
+    return true;
 }
 #endif
 

@@ -34,6 +34,9 @@ static int32_t ctx_init(kryst_ctx_t ctx) {
     KR_HIP(hipMalloc(&ctx->d_scal, sizeof(double) * 4096));
     KR_HIP(hipMemsetAsync(ctx->d_scal, 0, sizeof(double) * 4096, ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
+    KR_HIP(hipMalloc(&ctx->d_ticket, 64));
+    KR_HIP(hipMemsetAsync(ctx->d_ticket, 0, 64, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
     KR_HIP(hipMalloc(&ctx->d_gather, sizeof(double) * (size_t)(ctx->nranks + 1) * KR_MAXQ));
     KR_HIP(hipHostMalloc((void**)&ctx->h_prog, sizeof(HostProgress), hipHostMallocMapped));
     memset((void*)ctx->h_prog, 0, sizeof(HostProgress));
@@ -84,7 +87,7 @@ int32_t kryst_ctx_destroy(kryst_ctx_t ctx) {
     hipStreamSynchronize(ctx->s_main);
     hipStreamSynchronize(ctx->s_comm);
     comm_destroy(ctx);
-    hipFree(ctx->d_partials); hipFree(ctx->d_scal); hipFree(ctx->d_gather);
+    hipFree(ctx->d_partials); hipFree(ctx->d_chunks); hipFree(ctx->d_ticket); hipFree(ctx->d_scal); hipFree(ctx->d_gather);
     hipHostFree((void*)ctx->h_prog); hipHostFree(ctx->h_pinned);
     hipEventDestroy(ctx->ev_x_ready); hipEventDestroy(ctx->ev_halo_done);
     hipEventDestroy(ctx->tm0); hipEventDestroy(ctx->tm1);

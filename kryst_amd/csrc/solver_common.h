@@ -54,11 +54,12 @@ __device__ __forceinline__ double dsqrt(double x) { return __builtin_sqrt(x); }
 // single rank: fold the tile partials and run the logic in one launch
 template <int NQ, class L>
 __global__ __launch_bounds__(KR_F) void fold_logic_kernel(const double* partials, int64_t stride, int64_t ntiles,
+                                                          double* chunks, int64_t cstride, unsigned int* ticket,
                                                           double* red_out, L logic) {
-    if (logic.c.st->done && !L::RUN_WHEN_DONE) return;
+    if (logic.c.st->done && !L::RUN_WHEN_DONE) return;      // uniform over the grid: only the LAST workgroup ever sets done
     __shared__ double lds[NQ * (KR_F / 64)];
     double v[NQ];
-    final_fold<NQ>(partials, stride, ntiles, v, lds);
+    if (!fold2<NQ>(partials, stride, ntiles, chunks, cstride, ticket, v, lds)) return;
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) red_out[q] = v[q];
@@ -75,8 +76,8 @@ template <int NQ, class L>
 inline int32_t reduce_then(kryst_ctx_t ctx, int64_t ntiles, double* d_red, const L& logic) {
     if (!use_collectives(ctx)) {
         KR_TRY(ensure_partials(ctx, ntiles > 0 ? ntiles : 1));
-        hipLaunchKernelGGL((fold_logic_kernel<NQ, L>), dim3(1), dim3(KR_F), 0, ctx->s_main, ctx->d_partials,
-                           ctx->partials_cap, ntiles, d_red, logic);
+        hipLaunchKernelGGL((fold_logic_kernel<NQ, L>), dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main,
+                           ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_red, logic);
     } else {
         KR_TRY(reduce_all(ctx, NQ, ntiles, d_red));
         hipLaunchKernelGGL((logic_kernel<L>), dim3(1), dim3(64), 0, ctx->s_main, d_red, logic);

@@ -68,14 +68,27 @@ static double dot_tiled_part(const kro_reduce_t* rs, const double* x, const doub
         }
         partial[q] = block_reduce(th, T);
     }
+    /* two-level fold of the tile partials (kryst_amd/csrc/common.h fold2): chunk c = partials [cF,(c+1)F) -- thread t
+     * takes partial cF+t (0.0 past the end), butterfly, serial over waves; with more than one chunk the chunk values are
+     * folded by F threads (thread t: chunks t, t+F, ... ascending), butterfly, serial over waves. */
+    const int64_t nchunks = ntiles > F ? (ntiles + F - 1) / F : 1;
+    double* chunk = dalloc(nchunks);
     double th[1024];
-    for (int t = 0; t < F; ++t) {
-        double acc = 0.0;
-        for (int64_t i = t; i < ntiles; i += F) acc = acc + partial[i];
-        th[t] = acc;
+    for (int64_t c = 0; c < nchunks; ++c) {
+        for (int t = 0; t < F; ++t) { int64_t i = c * F + t; th[t] = (i < ntiles) ? partial[i] : 0.0; }
+        chunk[c] = block_reduce(th, F);
     }
-    double r = block_reduce(th, F);
-    free(partial);
+    double r;
+    if (nchunks == 1) r = chunk[0];
+    else {
+        for (int t = 0; t < F; ++t) {
+            double acc = 0.0;
+            for (int64_t i = t; i < nchunks; i += F) acc = acc + chunk[i];
+            th[t] = acc;
+        }
+        r = block_reduce(th, F);
+    }
+    free(partial); free(chunk);
     return r;
 }
 

@@ -30,8 +30,9 @@
  *   KRO_REDUCE_SERIAL  strict left fold  == the reference built with --no-default-features
  *                      (wrappers.rs:101-107,120-126); the canonical, deterministic definition.
  *   KRO_REDUCE_TILED   the fixed tree the HIP kernels use (tile = T*V elements; per-thread fold,
- *                      64-lane xor butterfly, serial across waves; partials folded by F threads,
- *                      butterfly, serial across waves; rank partials folded in rank order).
+ *                      64-lane xor butterfly, serial across waves; tile partials folded in chunks of F
+ *                      -- one per thread, butterfly, serial across waves -- and the chunk values likewise;
+ *                      rank partials folded in rank order).
  *                      The default-feature reference uses Rayon's reduce (wrappers.rs:92-100), whose
  *                      association is unspecified and run-dependent, so every fixed tree is one of its
  *                      admissible executions.  This mode lets the GPU be checked BIT-FOR-BIT.
