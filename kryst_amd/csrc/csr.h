@@ -11,6 +11,8 @@ struct kryst_csr_s {
     int32_t* d_row_ptr = nullptr;   // nrows+1 (+pad)
     int32_t* d_col = nullptr;       // nnz (+8 pad, zero): LOCAL column index; >= nloc means halo slot
     double*  d_val = nullptr;       // nnz (+8 pad, zero)
+    uint8_t* d_code = nullptr;      // CSR-D8: nnz (+32 pad) codes into d_dict, or nullptr (> 256 distinct col-row offsets)
+    int32_t* d_dict = nullptr;      // 256 offsets: col = row + d_dict[code]
     int64_t ntiles = 0;
     int slots = 7;            // SpMV pair slots per lane (picked from the average nnz of a 128-row slice)
     // distributed

@@ -37,6 +37,7 @@ struct SpmvArgs {
     double* y; const int32_t* tiles; int32_t ntiles; int32_t nrows;
     const double* dvec; double* partials; int64_t pstride;
     const int* done; int32_t xcd_chunk; int32_t swizzle; int32_t group;
+    const uint8_t* code; const int32_t* dict;      // CSR-D8: col = row + dict[code] (nullptr when not compressed)
 };
 
 template <bool NT, class T>
@@ -225,6 +226,127 @@ __global__ __launch_bounds__(KR_T, MINW) void spmv_wave_kernel(const SpmvArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// "rows" form: phase 1 only STREAMS the matrix (values + column indices, or values + 1-byte column codes) into the
+// wave's LDS window -- no dependent gather, every load of the window in flight at once; phase 2 walks each row in
+// ascending column order, and the row's owner lane gathers x itself: neighbouring lanes own neighbouring rows, so
+// for banded / stencil matrices one gather instruction touches a contiguous run of x (8 cache lines, all used by
+// the lane's second row) instead of the 14 scattered lines of an entry-order gather.
+//
+// CSR-D8 index compression (COMP): when the operator has at most 256 distinct (col - row) offsets -- every
+// structured-grid discretisation, whatever its coefficients -- kryst_csr_create stores one byte per entry, a code
+// into a 256-entry offset dictionary, beside the plain int32 columns.  The kernel then moves 9 instead of 12 bytes
+// per nonzero; the arithmetic (values, ascending column order, un-fused mul/add) is unchanged, so results are
+// bit-identical to the plain path.  Matrices with more distinct offsets use the plain int32 columns.
+template <int NQ, bool HALO, int SLOTS, bool COMP>
+__global__ __launch_bounds__(KR_T) void spmv_rows_kernel(const SpmvArgs a) {
+    if (a.done && *a.done) return;
+    constexpr int WCAP = SLOTS * 128;                       // entries per wave window
+    constexpr int CCAP = WCAP + 32;                         // code bytes per wave window (16-byte aligned start + slack)
+    __shared__ __attribute__((aligned(16))) double val_all[4 * WCAP];
+    __shared__ __attribute__((aligned(16))) int32_t col_all[COMP ? 4 : 4 * WCAP];
+    __shared__ __attribute__((aligned(16))) uint8_t code_all[COMP ? 4 * CCAP : 16];
+    __shared__ int32_t dict[COMP ? 256 : 1];
+    __shared__ double red[(NQ > 0 ? NQ : 1) * (KR_T / 64)];
+    const int t = threadIdx.x, l = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    double* lval = val_all + w * WCAP;
+    int32_t* lcol = col_all + (COMP ? 0 : w * WCAP);
+    uint8_t* lcode = code_all + (COMP ? w * CCAP : 0);
+    if constexpr (COMP) { dict[t] = a.dict[t]; __syncthreads(); }
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, per = gridDim.x >> 3;
+    for (int li = slot0; li < a.xcd_chunk; li += per) {
+        int ti;
+        if (a.swizzle) ti = xcd * a.xcd_chunk + li;
+        else ti = ((li / a.group) * 8 + xcd) * a.group + (li % a.group);
+        if (ti >= a.ntiles) { if (a.swizzle) break; else continue; }
+        const int q = a.tiles ? a.tiles[ti] : ti;
+        const int r0 = q * KR_TILE;
+        const int r1 = min(r0 + KR_TILE, a.nrows);
+        const int wr0 = min(r0 + 128 * w, r1), wr1 = min(wr0 + 128, r1);
+        const int row = r0 + 2 * t;
+        const int p0 = a.row_ptr[min(row, r1)];
+        const int p1 = a.row_ptr[min(row + 1, r1)];
+        const int p2 = a.row_ptr[min(row + 2, r1)];
+        const int k0 = a.row_ptr[wr0], k1 = a.row_ptr[wr1];         // wave-uniform
+        double s0 = 0.0, s1 = 0.0;
+        for (int base = k0 & ~1; base < k1; base += WCAP) {
+            const int wend = min(base + WCAP, k1);
+            const int npairs = (wend - base + 1) >> 1;
+            // ---- phase 1: stream the window into LDS
+            v2d v[SLOTS];
+            [[maybe_unused]] v2i c[SLOTS];
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j) {
+                const int pi = min(l + j * 64, npairs - 1);
+                const int k = base + 2 * pi;
+                v[j] = *reinterpret_cast<const v2d*>(a.val + k);
+                if constexpr (!COMP) c[j] = *reinterpret_cast<const v2i*>(a.col + k);
+            }
+            int cbase = 0;
+            if constexpr (COMP) {
+                cbase = base & ~15;                                   // 16-byte aligned start of the code window
+                const int nbytes = wend - cbase;
+                const int off = min(16 * l, ((nbytes + 15) & ~15) - 16);
+                const uint4 cw = *reinterpret_cast<const uint4*>(a.code + cbase + off);
+                if (16 * l < nbytes + 16) *reinterpret_cast<uint4*>(lcode + off) = cw;
+            }
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j) {
+                *reinterpret_cast<double2*>(&lval[2 * (l + j * 64)]) = make_double2(v[j].x, v[j].y);
+                if constexpr (!COMP) *reinterpret_cast<int2*>(&lcol[2 * (l + j * 64)]) = make_int2(c[j].x, c[j].y);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- phase 2: the two rows of the lane, four entries of each in flight, folded in ascending column order
+            int ka = max(p0, base), kb = max(p1, base);
+            const int ea = min(p1, wend), eb = min(p2, wend);
+            while (ka < ea || kb < eb) {
+                double va[4], vb[4], xa[4], xb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ia = min(ka + u, max(ea - 1, base)), ib = min(kb + u, max(eb - 1, base));
+                    int ca, cb;
+                    if constexpr (COMP) { ca = row + dict[lcode[ia - cbase]]; cb = row + 1 + dict[lcode[ib - cbase]]; }
+                    else { ca = lcol[ia - base]; cb = lcol[ib - base]; }
+                    va[u] = lval[ia - base]; vb[u] = lval[ib - base];
+                    xa[u] = (ka + u < ea) ? gather<HALO>(a, ca) : 0.0;
+                    xb[u] = (kb + u < eb) ? gather<HALO>(a, cb) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (ka + u < ea) s0 = s0 + va[u] * xa[u];
+                    if (kb + u < eb) s1 = s1 + vb[u] * xb[u];
+                }
+                ka += 4; kb += 4;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (row + 1 < r1) st2(a.y, row, s0, s1);
+        else if (row < r1) a.y[row] = s0;
+        if constexpr (NQ > 0) {
+            double acc[NQ];
+            const d2 d = ld2(a.dvec, row);
+            acc[0] = 0.0;
+            if (row < r1) acc[0] = acc[0] + d.a * s0;
+            if (row + 1 < r1) acc[0] = acc[0] + d.b * s1;
+            if constexpr (NQ > 1) {
+                acc[1] = 0.0;
+                if (row < r1) acc[1] = acc[1] + s0 * s0;
+                if (row + 1 < r1) acc[1] = acc[1] + s1 * s1;
+            }
+            block_reduce<NQ, KR_T / 64>(acc, red);
+            if (t == 0) {
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) a.partials[k * a.pstride + q] = acc[k];
+            }
+        }
+    }
+}
+
 __global__ void pack_kernel(const double* x, const int32_t* idx, double* out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = x[idx[i]];
@@ -279,6 +401,33 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
 #endif
     // production path: wave-independent kernel; pair slots per lane sized to the matrix's average slice length
     // (a wave streams the nnz of 128 rows: <= 256 nnz -> 2 slots, <= 512 -> 4, else 7 = a 7-point stencil's 896)
+    const int kern = env_int("KRYST_SPMV_KERNEL", 2);          // 2: products-in-LDS wave kernel; 3: rows kernel (+ CSR-D8)
+    const bool comp = a->d_code && env_int("KRYST_SPMV_COMPRESS", 1) != 0;
+    args.code = comp ? a->d_code : nullptr; args.dict = comp ? a->d_dict : nullptr;
+    const int slots_env = env_int("KRYST_SPMV_SLOTS", 0);
+    // measured (tools/tune_spmv.py): with vectors beyond the 256 MiB Infinity Cache the smaller window (more resident
+    // waves) wins, below it the one-window-per-slice form does
+    int slots_sel = a->slots;
+    if (comp && a->slots > 4 && a->nrows * 8 > (256ll << 20)) slots_sel = 4;
+    if (slots_env > 0) slots_sel = slots_env;
+    if (kern == 3 || comp) {
+#define KR_ROWS(NQ_, SL_, C_) hipLaunchKernelGGL((spmv_rows_kernel<NQ_, HALO, SL_, C_>), grid, block, 0, ctx->s_main, args)
+#define KR_ROWS_BY(NQ_)                                                                 \
+        do {                                                                            \
+            if (comp) { if (slots_sel <= 4) KR_ROWS(NQ_, 4, true); else KR_ROWS(NQ_, 7, true); }      \
+            else { if (slots_sel <= 4) KR_ROWS(NQ_, 4, false); else KR_ROWS(NQ_, 7, false); }         \
+        } while (0)
+        switch (nq) {
+            case 0: KR_ROWS_BY(0); break;
+            case 1: KR_ROWS_BY(1); break;
+            case 2: KR_ROWS_BY(2); break;
+            default: set_error("spmv: nq=%d", nq); return KRYST_ERR_ARG;
+        }
+#undef KR_ROWS_BY
+#undef KR_ROWS
+        KR_HIP(hipGetLastError());
+        return KRYST_OK;
+    }
 #define KR_SPMV_LAUNCH(NQ_, SL_) hipLaunchKernelGGL((spmv_wave_kernel<NQ_, HALO, SL_, false>), grid, block, 0, ctx->s_main, args)
 #define KR_SPMV_BY_SLOTS(NQ_)                                   \
     do {                                                        \
@@ -342,6 +491,27 @@ static int32_t upload_csr(kryst_csr_t a, const std::vector<int32_t>& rp, const s
     }
     KR_HIP(hipStreamSynchronize(ctx->s_main));
     a->ntiles = ntiles_of(a->nrows);
+    {   // CSR-D8: one byte per entry when the operator has <= 256 distinct (col - row) offsets
+        std::vector<int32_t> dict; dict.reserve(256);
+        std::vector<uint8_t> codes(nnz + 32, 0);
+        bool ok = nnz > 0;
+        for (int64_t i = 0; i < a->nrows && ok; ++i)
+            for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+                const int32_t d = col[k] - (int32_t)i;
+                int code = -1;
+                for (size_t u = 0; u < dict.size(); ++u) if (dict[u] == d) { code = (int)u; break; }
+                if (code < 0) { if (dict.size() == 256) { ok = false; break; } dict.push_back(d); code = (int)dict.size() - 1; }
+                codes[k] = (uint8_t)code;
+            }
+        if (ok) {
+            dict.resize(256, 0);
+            KR_HIP(hipMalloc(&a->d_code, codes.size()));
+            KR_HIP(hipMalloc(&a->d_dict, sizeof(int32_t) * 256));
+            KR_HIP(hipMemcpyAsync(a->d_code, codes.data(), codes.size(), hipMemcpyHostToDevice, ctx->s_main));
+            KR_HIP(hipMemcpyAsync(a->d_dict, dict.data(), sizeof(int32_t) * 256, hipMemcpyHostToDevice, ctx->s_main));
+            KR_HIP(hipStreamSynchronize(ctx->s_main));
+        }
+    }
     const double per_slice = a->nrows > 0 ? (double)a->nnz / (double)((a->nrows + 127) / 128) : 0.0;
     a->slots = per_slice <= 256.0 ? 2 : (per_slice <= 512.0 ? 4 : 7);
     return KRYST_OK;
@@ -500,7 +670,7 @@ __host__ __device__ static inline int64_t stencil_gptr(int64_t row, int64_t N) {
 struct StencilCoef { double c[7]; };
 
 __global__ void stencil7_gen_kernel(int32_t N, int64_t lo, int64_t hi, int64_t n_lower, StencilCoef sc,
-                                    int32_t* row_ptr, int32_t* col, double* val) {
+                                    int32_t* row_ptr, int32_t* col, double* val, uint8_t* code) {
     const int64_t nloc = hi - lo;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > nloc) return;
@@ -518,10 +688,11 @@ __global__ void stencil7_gen_kernel(int32_t N, int64_t lo, int64_t hi, int64_t n
         if (ok[s]) {
             const int64_t c = row + off[s];
             int64_t lc;
+            int cd = s;                                             // dictionary: 0..6 in-block offsets
             if (c >= lo && c < hi) lc = c - lo;
-            else if (c < lo) lc = nloc + (c - (lo - N2));           // halo plane from rank-1
-            else lc = nloc + n_lower + (c - hi);                    // halo plane from rank+1
-            col[k] = (int32_t)lc; val[k] = sc.c[s];
+            else if (c < lo) { lc = nloc + (c - (lo - N2)); cd = 7; }          // halo plane from rank-1: lc - i == nloc
+            else { lc = nloc + n_lower + (c - hi); cd = 8; }                   // halo plane from rank+1: lc - i == n_lower + N^2
+            col[k] = (int32_t)lc; val[k] = sc.c[s]; code[k] = (uint8_t)cd;
             ++k;
         }
 }
@@ -552,12 +723,23 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
     do {
         if (hipMalloc(&a->d_row_ptr, sizeof(int32_t) * (size_t)(nloc + 1 + 8)) != hipSuccess ||
             hipMalloc(&a->d_col, sizeof(int32_t) * (size_t)(nnz + 8)) != hipSuccess ||
-            hipMalloc(&a->d_val, sizeof(double) * (size_t)(nnz + 8)) != hipSuccess) { set_error("hipMalloc failed (stencil7)"); rc = KRYST_ERR_HIP; break; }
+            hipMalloc(&a->d_val, sizeof(double) * (size_t)(nnz + 8)) != hipSuccess ||
+            hipMalloc(&a->d_code, (size_t)(nnz + 32)) != hipSuccess || hipMalloc(&a->d_dict, sizeof(int32_t) * 256) != hipSuccess) { set_error("hipMalloc failed (stencil7)"); rc = KRYST_ERR_HIP; break; }
+        {
+            int32_t dict[256] = {0};
+            const int32_t offs7[7] = {(int32_t)-N2, -N, -1, 0, 1, N, (int32_t)N2};
+            for (int u = 0; u < 7; ++u) dict[u] = offs7[u];
+            dict[7] = (int32_t)nloc;                                   // lower halo slot - local row
+            dict[8] = (int32_t)((has_lower ? N2 : 0) + N2);            // upper halo slot - local row
+            hipMemcpyAsync(a->d_dict, dict, sizeof dict, hipMemcpyHostToDevice, ctx->s_main);
+            hipStreamSynchronize(ctx->s_main);
+            hipMemsetAsync(a->d_code + nnz, 0, 32, ctx->s_main);
+        }
         hipMemsetAsync(a->d_col + nnz, 0, sizeof(int32_t) * 8, ctx->s_main);
         hipMemsetAsync(a->d_val + nnz, 0, sizeof(double) * 8, ctx->s_main);
         const int64_t nthreads = nloc + 1;
         hipLaunchKernelGGL(stencil7_gen_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->s_main, N, lo, hi,
-                           has_lower ? N2 : 0, sc, a->d_row_ptr, a->d_col, a->d_val);
+                           has_lower ? N2 : 0, sc, a->d_row_ptr, a->d_col, a->d_val, a->d_code);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("stencil7 generation failed"); rc = KRYST_ERR_HIP; break; }
         a->ntiles = ntiles_of(nloc);
         a->slots = 7;
@@ -622,7 +804,7 @@ int32_t kryst_csr_destroy(kryst_csr_t a) {
     hipSetDevice(a->ctx->device);
     hipStreamSynchronize(a->ctx->s_main);
     hipStreamSynchronize(a->ctx->s_comm);
-    hipFree(a->d_row_ptr); hipFree(a->d_col); hipFree(a->d_val);
+    hipFree(a->d_row_ptr); hipFree(a->d_col); hipFree(a->d_val); hipFree(a->d_code); hipFree(a->d_dict);
     hipFree(a->d_tiles_interior); hipFree(a->d_tiles_boundary);
     hipFree(a->plan.d_send_idx); hipFree(a->plan.d_sendbuf); hipFree(a->plan.d_halo);
     delete a;
