@@ -19,8 +19,8 @@
 
 namespace kr {
 
-struct TriArgs {                    // device-resident argument block, rewritten before every apply (graph-friendly)
-    const double* r; double* z; const int* done;
+struct TriArgs {                    // device-resident argument block, rewritten before every apply (graph-friendly):
+    const double* r; double* z; long long skip;   // one scalar load gives a level kernel everything it needs
 };
 
 struct TriFactor {                  // one triangular factor in level order
@@ -29,9 +29,13 @@ struct TriFactor {                  // one triangular factor in level order
     double*  d_val = nullptr;
     int32_t* d_row = nullptr;       // npos: original row id
     double*  d_diag = nullptr;      // npos: divisor (1.0 when the apply does not divide)
+    // ELL copy (rows of <= ELLW kept entries, e.g. any 7-point factor): slot-major, so a lane's loads do not depend
+    // on a row pointer -- one round trip less on a latency-bound kernel
+    int32_t* d_ecol = nullptr; double* d_eval = nullptr; uint8_t* d_elen = nullptr; int64_t npos = 0; bool ell = false;
     std::vector<int32_t> lvl_off;   // host: position offsets per level
     int32_t* d_lvl_off = nullptr;
-    void free_all() { hipFree(d_ptr); hipFree(d_col); hipFree(d_val); hipFree(d_row); hipFree(d_diag); hipFree(d_lvl_off); }
+    void free_all() { hipFree(d_ptr); hipFree(d_col); hipFree(d_val); hipFree(d_row); hipFree(d_diag); hipFree(d_lvl_off);
+                      hipFree(d_ecol); hipFree(d_eval); hipFree(d_elen); }
 };
 
 struct IluData {
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) void tri_level_kernel(const TriArgs* args, con
                                                         const int32_t* __restrict__ col, const double* __restrict__ val,
                                                         const int32_t* __restrict__ rowid, const double* __restrict__ diag,
                                                         int32_t p0, int32_t p1) {
-    if (args->done && *args->done) return;
+    if (args->skip) return;
     const int32_t p = p0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= p1) return;
     double* z = args->z;
@@ -57,13 +61,57 @@ __global__ __launch_bounds__(256) void tri_level_kernel(const TriArgs* args, con
     z[i] = FORWARD ? s : s / diag[p];                       // ilup.rs:160-164 (diag == 1.0: exact no-op)
 }
 
+#define ELLW 4
+struct EllView { const int32_t* col; const double* val; const uint8_t* len; int64_t npos; };
+
+__device__ __forceinline__ double ell_row(const EllView& E, int32_t p, double s, const double* z) {
+    int32_t c[ELLW]; double v[ELLW], zz[ELLW];
+    const int len = E.len[p];
+#pragma unroll
+    for (int u = 0; u < ELLW; ++u) { c[u] = E.col[u * E.npos + p]; v[u] = E.val[u * E.npos + p]; }
+#pragma unroll
+    for (int u = 0; u < ELLW; ++u) zz[u] = z[c[u]];                 // padding slots point at column 0 (valid, unused)
+#pragma unroll
+    for (int u = 0; u < ELLW; ++u) if (u < len) s = s - v[u] * zz[u];   // ascending column order
+    return s;
+}
+
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void tri_level_ell_kernel(const TriArgs* args, EllView E, const int32_t* __restrict__ rowid,
+                                                            const double* __restrict__ diag, int32_t p0, int32_t p1) {
+    if (args->skip) return;
+    const int32_t p = p0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= p1) return;
+    double* z = args->z;
+    const int32_t i = rowid[p];
+    const double s = ell_row(E, p, FORWARD ? args->r[i] : z[i], z);
+    z[i] = FORWARD ? s : s / diag[p];
+}
+
+template <bool FORWARD>
+__global__ __launch_bounds__(1024) void tri_run_ell_kernel(const TriArgs* args, EllView E, const int32_t* __restrict__ rowid,
+                                                           const double* __restrict__ diag, const int32_t* __restrict__ lvl_off,
+                                                           int32_t l0, int32_t l1) {
+    if (args->skip) return;
+    double* z = args->z;
+    for (int32_t lv = l0; lv < l1; ++lv) {
+        const int32_t p0 = lvl_off[lv], p1 = lvl_off[lv + 1];
+        for (int32_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+            const int32_t i = rowid[p];
+            const double s = ell_row(E, p, FORWARD ? args->r[i] : z[i], z);
+            z[i] = FORWARD ? s : s / diag[p];
+        }
+        __syncthreads();
+    }
+}
+
 // a run of consecutive NARROW levels [l0, l1) in one workgroup: workgroup barrier between levels
 template <bool FORWARD>
 __global__ __launch_bounds__(1024) void tri_run_kernel(const TriArgs* args, const int32_t* __restrict__ ptr,
                                                        const int32_t* __restrict__ col, const double* __restrict__ val,
                                                        const int32_t* __restrict__ rowid, const double* __restrict__ diag,
                                                        const int32_t* __restrict__ lvl_off, int32_t l0, int32_t l1) {
-    if (args->done && *args->done) return;
+    if (args->skip) return;
     double* z = args->z;
     for (int32_t lv = l0; lv < l1; ++lv) {
         const int32_t p0 = lvl_off[lv], p1 = lvl_off[lv + 1];
@@ -77,7 +125,8 @@ __global__ __launch_bounds__(1024) void tri_run_kernel(const TriArgs* args, cons
     }
 }
 
-__global__ void tri_set_args(TriArgs* a, const double* r, double* z, const int* done) { a->r = r; a->z = z; a->done = done; }
+// runs in stream order before the level kernels, so it sees the solver's `done` flag as of this apply
+__global__ void tri_set_args(TriArgs* a, const double* r, double* z, const int* done) { a->r = r; a->z = z; a->skip = (done && *done) ? 1 : 0; }
 
 static const int NARROW = 2048;     // levels with at most this many rows are folded into one-workgroup runs
 
@@ -90,12 +139,20 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
         if (rows <= NARROW) {
             int l1 = lv + 1;
             while (l1 < nl && F.lvl_off[l1 + 1] - F.lvl_off[l1] <= NARROW) ++l1;
-            hipLaunchKernelGGL((tri_run_kernel<FORWARD>), dim3(1), dim3(1024), 0, s, d_args, F.d_ptr, F.d_col, F.d_val, F.d_row,
-                               F.d_diag, F.d_lvl_off, lv, l1);
+            if (F.ell)
+                hipLaunchKernelGGL((tri_run_ell_kernel<FORWARD>), dim3(1), dim3(1024), 0, s, d_args,
+                                   EllView{F.d_ecol, F.d_eval, F.d_elen, F.npos}, F.d_row, F.d_diag, F.d_lvl_off, lv, l1);
+            else
+                hipLaunchKernelGGL((tri_run_kernel<FORWARD>), dim3(1), dim3(1024), 0, s, d_args, F.d_ptr, F.d_col, F.d_val, F.d_row,
+                                   F.d_diag, F.d_lvl_off, lv, l1);
             lv = l1;
         } else {
-            hipLaunchKernelGGL((tri_level_kernel<FORWARD>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_args, F.d_ptr,
-                               F.d_col, F.d_val, F.d_row, F.d_diag, F.lvl_off[lv], F.lvl_off[lv + 1]);
+            if (F.ell)
+                hipLaunchKernelGGL((tri_level_ell_kernel<FORWARD>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_args,
+                                   EllView{F.d_ecol, F.d_eval, F.d_elen, F.npos}, F.d_row, F.d_diag, F.lvl_off[lv], F.lvl_off[lv + 1]);
+            else
+                hipLaunchKernelGGL((tri_level_kernel<FORWARD>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_args, F.d_ptr,
+                                   F.d_col, F.d_val, F.d_row, F.d_diag, F.lvl_off[lv], F.lvl_off[lv + 1]);
             lv += 1;
         }
         KR_HIP(hipGetLastError());
@@ -109,7 +166,8 @@ int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done
     if (D->n == 0) return KRYST_OK;
     hipLaunchKernelGGL(tri_set_args, dim3(1), dim3(1), 0, ctx->s_main, D->d_args, r, z, done);
     KR_HIP(hipGetLastError());
-    if (!D->exec) {
+    static const int use_graph = getenv("KRYST_ILU_GRAPH") ? atoi(getenv("KRYST_ILU_GRAPH")) : 1;
+    if (!D->exec && use_graph) {
         // capture the level sequence once; the graph only refers to the device argument block
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(ctx->s_main, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -168,6 +226,19 @@ static int32_t build_factor(int64_t n, const std::vector<std::vector<std::pair<i
         for (auto& e : ent[i]) { col.push_back(e.first); val.push_back(e.second); }
         ptr[p + 1] = (int32_t)col.size();
         dg[p] = diag[i];
+    }
+    size_t maxlen = 0;
+    for (int64_t i = 0; i < n; ++i) maxlen = std::max(maxlen, ent[i].size());
+    F->npos = n;
+    if (maxlen <= ELLW && n > 0) {
+        std::vector<int32_t> ecol((size_t)ELLW * n, 0); std::vector<double> eval((size_t)ELLW * n, 0.0); std::vector<uint8_t> elen((size_t)n, 0);
+        for (int64_t p = 0; p < n; ++p) {
+            const auto& e = ent[rowid[p]];
+            elen[p] = (uint8_t)e.size();
+            for (size_t u = 0; u < e.size(); ++u) { ecol[u * n + p] = e[u].first; eval[u * n + p] = e[u].second; }
+        }
+        KR_TRY(up(&F->d_ecol, ecol)); KR_TRY(up(&F->d_eval, eval)); KR_TRY(up(&F->d_elen, elen));
+        F->ell = true;
     }
     KR_TRY(up(&F->d_ptr, ptr)); KR_TRY(up(&F->d_col, col)); KR_TRY(up(&F->d_val, val)); KR_TRY(up(&F->d_row, rowid));
     KR_TRY(up(&F->d_diag, dg)); KR_TRY(up(&F->d_lvl_off, F->lvl_off));
