@@ -506,7 +506,7 @@ struct BicgRun : SolverRun {
         KR_TRY((reduce_then<2>(ctx, nt, ws.red, BicgOmegaLogic{lc})));
         KR_TRY(ensure_partials(ctx, nt));
         const BicgXROp op{st, pc ? ph : pp, pc ? sh : s, s, t, rhat, xw, r};
-        const int64_t grid = std::min<int64_t>(nt, (int64_t)ctx->num_cu * 8);
+        const int64_t grid = std::min<int64_t>(nt, (int64_t)ctx->num_cu * 2);
         if (grid > 0) {
             hipLaunchKernelGGL((ew_kernel_early<BicgXROp>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, n, nt,
                                ctx->d_partials, ctx->partials_cap, st);
