@@ -155,8 +155,8 @@ def main():
     tf = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     if os.path.exists(tf):
         try:
-            tr = json.load(open(tf))
-            if tr.get("grid") == grid and world == 1:
+            tr = json.load(open(tf)).get(str(grid))       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated
+            if tr and world == 1:                         # (tools/pmc_traffic.py; summaries under profiles/r01/)
                 out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
         except Exception:
             pass
