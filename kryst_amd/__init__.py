@@ -23,7 +23,7 @@ from ._ffi import KError, lib, check
 
 __all__ = ["Context", "DeviceVec", "CsrMatrix", "dot", "norm", "Jacobi", "Ilu0", "Ilup", "TrueIlu0", "Chebyshev",
            "ChebyshevPc", "IdentityPc", "apply_chebyshev", "Convergence", "SolveStats", "CgNormType",
-           "Preconditioning", "CgSolver", "PcgSolver", "GmresSolver", "BiCgStabSolver", "BiCgStabRightPcSolver", "Session", "KError", "reduce_spec",
+           "Preconditioning", "CgSolver", "PcgSolver", "GmresSolver", "BiCgStabSolver", "BiCgStabRightPcSolver", "Session", "KspContext", "SolverKind", "KError", "reduce_spec",
            "host_stencil7", "partition_rows", "halo_recv_plan"]
 
 
@@ -548,6 +548,38 @@ class BiCgStabSolver(_Solver):
 class BiCgStabRightPcSolver(_Solver):
     """Extension: right-preconditioned BiCGStab (device vectors only)."""
     _HOST, _DEV = None, "kryst_bicgstab_rpc_solve_dev"
+
+
+class SolverKind(enum.Enum):                      # src/context/ksp_context.rs:25-48 (the kinds on the hot path)
+    Cg = "cg"
+    Pcg = "pcg"
+    GmresLeft = "gmres_left"
+    GmresRight = "gmres_right"
+    Bicgstab = "bicgstab"
+
+
+class KspContext:
+    """KspContext { kind, a, pc, tol, max_it, restart } + solve_context (src/context/ksp_context.rs:54-148): builds a
+    fresh solver per call and forwards (a, pc, b, x).  Kinds outside the hot path raise KError(Unsupported)."""
+
+    def __init__(self, kind, a, pc=None, tol=1e-8, max_it=1000, restart=30):
+        self.kind, self.a, self.pc, self.tol, self.max_it, self.restart = kind, a, pc, tol, max_it, restart
+
+    def solve_context(self, b, x, comm=None):
+        k = self.kind
+        if k == SolverKind.GmresLeft:
+            s = GmresSolver(self.restart, self.tol, self.max_it).with_preconditioning(Preconditioning.Left)
+        elif k == SolverKind.GmresRight:
+            s = GmresSolver(self.restart, self.tol, self.max_it).with_preconditioning(Preconditioning.Right)
+        elif k == SolverKind.Cg:
+            s = CgSolver(self.tol, self.max_it)
+        elif k == SolverKind.Pcg:
+            s = PcgSolver(self.tol, self.max_it)
+        elif k == SolverKind.Bicgstab:
+            s = BiCgStabSolver(self.tol, self.max_it)
+        else:
+            raise KError(6, f"solver kind {k} is outside the accelerated path")
+        return s.solve(self.a, self.pc, b, x)
 
 
 class Session:

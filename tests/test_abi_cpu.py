@@ -68,3 +68,14 @@ def test_compute_fails_loudly_without_gpu():
             "except K.KError as e:\n    print('KERROR', e.code)\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT).stdout
     assert "HAVE_GPU" in out or "KERROR 100" in out, out
+
+
+def test_cpp_mirror_compiles_against_the_abi(tmp_path):
+    """include/kryst_hip.hpp (the C++ mirror of MatVec / Preconditioner / LinearSolver) + its test program build and link."""
+    import subprocess
+    out = tmp_path / "test_mirror"
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "test_mirror.cpp"), "-o", str(out),
+                        "-L" + os.path.join(ROOT, "kryst_amd", "lib"), "-lkryst_hip", "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

@@ -500,3 +500,21 @@ def test_device_resident_solve_and_roundtrip_property(ctx):
     assert K.norm(r) <= 1.0001e-8 * K.norm(b)
     assert abs(s.residual_history[-1] - st.final_residual) == 0.0
     assert np.max(np.abs(x.to_host() - 1.0)) < 1e-6
+
+
+def test_ksp_context_factory(ctx, rs):
+    # src/context/ksp_context.rs:88-148: one level of dispatch, a fresh solver per call
+    a = O.stencil7(8, "convdiff")
+    b = a.spmv(np.ones(a.nrows))
+    d = to_dev(ctx, a)
+    for kind, method, side in ((K.SolverKind.Cg, "cg", 1), (K.SolverKind.Pcg, "pcg", 1), (K.SolverKind.GmresLeft, "gmres", 1),
+                               (K.SolverKind.GmresRight, "gmres", 2), (K.SolverKind.Bicgstab, "bicgstab", 1)):
+        res = O.solve(method, a, b, pc=O.Pc.jacobi(a), tol=1e-8, max_iters=60, restart=30, side=side, rs=rs, raise_on_error=False)
+        x = np.zeros(a.nrows)
+        try:
+            st, code = K.KspContext(kind, d, K.Jacobi().setup(d), 1e-8, 60, 30).solve_context(b, x), 0
+        except K.KError as e:
+            st, code = e.stats, e.code
+        assert code == res.code and st.iterations == res.iterations and st.converged == res.converged
+        if code == 0:
+            assert np.array_equal(x, res.x)
