@@ -109,6 +109,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # a hung collective must not hang the node: give up loudly after 20 minutes
+    import threading
+    def _watchdog():
+        sys.stderr.write("bench.py: watchdog timeout (1200 s), aborting\n"); sys.stderr.flush(); os._exit(124)
+    wd = threading.Timer(1200.0, _watchdog); wd.daemon = True; wd.start()
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
