@@ -71,6 +71,19 @@ __global__ void logic_kernel(const double* red, L logic) {
     if (logic.c.st->done && !L::RUN_WHEN_DONE) return;
     if (threadIdx.x == 0) logic.run(red);
 }
+// several ranks: fold the all-gathered rank results in rank order (total = r0; total = total + r_p), then the logic
+template <int NQ, class L>
+__global__ void rank_fold_logic_kernel(const double* gathered, int nranks, double* red_out, L logic) {
+    if (logic.c.st->done && !L::RUN_WHEN_DONE) return;
+    if (threadIdx.x != 0) return;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double total = gathered[q];
+        for (int p = 1; p < nranks; ++p) total = total + gathered[p * NQ + q];
+        red_out[q] = total;
+    }
+    logic.run(red_out);
+}
 
 template <int NQ, class L>
 inline int32_t reduce_then(kryst_ctx_t ctx, int64_t ntiles, double* d_red, const L& logic) {
@@ -79,8 +92,11 @@ inline int32_t reduce_then(kryst_ctx_t ctx, int64_t ntiles, double* d_red, const
         hipLaunchKernelGGL((fold_logic_kernel<NQ, L>), dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main,
                            ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_red, logic);
     } else {
-        KR_TRY(reduce_all(ctx, NQ, ntiles, d_red));
-        hipLaunchKernelGGL((logic_kernel<L>), dim3(1), dim3(64), 0, ctx->s_main, d_red, logic);
+        // local two-level fold -> RCCL all-gather of NQ doubles per rank -> rank-ordered fold + logic in one launch
+        double* local = ctx->d_gather + (size_t)ctx->nranks * KR_MAXQ;
+        KR_TRY(launch_final_fold(ctx, NQ, ntiles, local));
+        KR_TRY(comm_all_gather(ctx, local, ctx->d_gather, NQ));
+        hipLaunchKernelGGL((rank_fold_logic_kernel<NQ, L>), dim3(1), dim3(64), 0, ctx->s_main, ctx->d_gather, ctx->nranks, d_red, logic);
     }
     KR_HIP(hipGetLastError());
     return KRYST_OK;
