@@ -136,8 +136,8 @@ typedef struct {
     int32_t precond_side;        /* gmres.rs:28-32 Preconditioning: 0 None, 1 Left (default), 2 Right */
     int32_t norm_type;           /* CgNormType cg.rs:35: 0 Preconditioned, 1 Unpreconditioned (default), 2 Natural, 3 None */
     int32_t single_reduction;    /* with_single_reduction cg.rs:69 (same fold on the device; accepted, no effect) */
-    int32_t has_radius;  double radius;        /* with_radius     cg.rs:74  (-> KRYST_UNSUPPORTED when set) */
-    int32_t has_obj_target; double obj_target; /* with_obj_target cg.rs:79  (-> KRYST_UNSUPPORTED when set) */
+    int32_t has_radius;  double radius;        /* with_radius     cg.rs:74  (CG: trust-region exit cg.rs:177-202; PCG ignores it like the reference) */
+    int32_t has_obj_target; double obj_target; /* with_obj_target cg.rs:79  (CG: objective exit cg.rs:231-252) */
     int32_t check_every;         /* host polls the device convergence flag every this many iterations (0 = default);
                                     the device stops at the exact reference iteration regardless */
 } kryst_params_t;

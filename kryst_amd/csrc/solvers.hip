@@ -118,6 +118,90 @@ struct CgBetaLogic {                 // cg.rs:223-284
     }
 };
 
+// ---- CG side exits (off by default in the reference): trust region cg.rs:177-202, objective target cg.rs:231-252
+struct CgRadiusLogic {               // red0 = (p,p), red1 = (x,x)
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c; double radius;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        const double p_norm = dsqrt(red[0]), x_norm = dsqrt(red[1]);                       // :178-179
+        if (x_norm + fabs(st->alpha) * p_norm > radius) {                                  // :180
+            st->alpha = (radius - x_norm) / p_norm;                                        // :181 max_step, applied by AxpyIfOp
+            st->iterations = st->iter + 1; st->final_residual = dsqrt(st->rsq); st->converged = 0;   // :196-199
+            st->early = 1;
+            c.finish(KRYST_OK);
+        }
+    }
+};
+struct ClearEarlyLogic {
+    static constexpr bool RUN_WHEN_DONE = true;
+    LogicCtx c;
+    __device__ void run(const double*) const { c.st->early = 0; }
+};
+struct CgRsqLogic {                  // first half of cg.rs:223-229 when the objective exit sits in between
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        st->rz = red[0];                                                                    // rsq_new
+        switch (c.norm_type) { case 0: case 1: st->normq = dsqrt(red[0]); break; case 2: st->normq = dsqrt(fabs(red[1])); break; default: st->normq = 0.0; }
+    }
+};
+struct StoreLogic {                  // keeps one reduced value for a later logic step
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c; double* slot;
+    __device__ void run(const double* red) const { *slot = red[0]; }
+};
+struct CgObjLogic {                  // cg.rs:231-252 ; red0 = (x,b), *xax = (x,Ax)
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c; const double* xax; double target;
+    __device__ void run(const double* red) const {
+        DevState* st = c.st;
+        const double obj = 0.5 * (*xax) - red[0];                                           // :237
+        if (obj <= target) {                                                                // :245-251
+            st->iterations = st->iter + 1; st->final_residual = st->normq; st->converged = 1;
+            c.finish(KRYST_OK);
+        }
+    }
+};
+struct CgBetaStoredLogic {           // second half: cg.rs:254-284 on the stored rsq_new / res_norm
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c;
+    __device__ void run(const double*) const {
+        DevState* st = c.st;
+        const long long i = st->iter + 1;
+        const double rsq_new = st->rz, res_norm = st->normq;
+        if (rsq_new / st->rsq < 0.0) {
+            st->iterations = i; st->final_residual = res_norm; st->converged = 0;
+            c.finish(KRYST_INDEFINITE_PRECONDITIONER);
+            return;
+        }
+        c.push(res_norm);
+        st->iter = i;
+        if (c.check(res_norm, st->res0, i)) { c.finish(KRYST_OK); return; }
+        st->beta = rsq_new / st->rsq;
+        st->rsq = rsq_new;
+    }
+};
+struct AxpyIfOp {                    // x += alpha*p, only while st->early is raised (cg.rs:185-187 max_step update)
+    static constexpr int NQ = 0;
+    const DevState* st; const double* p; double* x;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const double al = st->alpha;
+        const d2 pp = ld2(p, i), xx = ld2(x, i);
+        st2(x, i, xx.a + al * pp.a, xx.b + al * pp.b);
+    }
+};
+template <class Op>
+__global__ __launch_bounds__(KR_T) void ew_kernel_if_early(Op op, int64_t n, int64_t ntiles, const DevState* st) {
+    if (!st->early) return;
+    double dummy[1] = {0.0};
+    for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
+        const int64_t i = q * KR_TILE + (int64_t)threadIdx.x * KR_V;
+        op.pair(i, i < n, i + 1 < n, dummy);
+    }
+}
+
 static int32_t solve_args_check(const SolveIO& io, kryst_vec_t b, kryst_vec_t x) {
     KR_ARG(io.a && io.params && b && x, "solve: null argument");
     KR_ARG(b->ctx == io.a->ctx && x->ctx == io.a->ctx, "solve: context mismatch");
@@ -183,12 +267,12 @@ struct SolverRun {
 
 struct CgRun : SolverRun {
     using SolverRun::SolverRun;
-    double *r = nullptr, *pp = nullptr, *ap = nullptr;
+    double *r = nullptr, *pp = nullptr, *ap = nullptr, *ax = nullptr;
     int32_t begin() override {
         KR_TRY(solve_args_check(io, bv, xv));
-        if (prm.has_radius || prm.has_obj_target) { set_error("CG trust-region / objective-target exits are not implemented on the device"); return KRYST_UNSUPPORTED; }
         KR_TRY(common_begin(prm.max_iters + 2));                                                  // cg.rs:117
         KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&ap));
+        if (prm.has_obj_target) KR_TRY(ws.vec(&ax));
         KR_TRY(residual_dot(a, bv->d, xw, r, ap, nullptr));                                       // :120-125, :127
         KR_HIP(hipMemcpyAsync(pp, r, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));      // :126
         return reduce_then<1>(ctx, nt, ws.red, CgInitLogic{lc});
@@ -196,12 +280,33 @@ struct CgRun : SolverRun {
     int32_t iterate(int64_t) override {
         KR_TRY(launch_spmv(a, pp, ap, 1, pp, done));                                              // :143-144 + (p,Ap) :164
         KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgAlphaLogic{lc})));
-        if (prm.norm_type == 2) {
-            KR_TRY(launch_ew(ctx, CgUpdate2{&ws.st->alpha, pp, ap, xw, r}, n, done));
-            KR_TRY((reduce_then<2>(ctx, nt, ws.red, CgBetaLogic{lc})));
-        } else {
-            KR_TRY(launch_ew(ctx, CgUpdate1{&ws.st->alpha, pp, ap, xw, r}, n, done));             // :207-212 + (r,r) :223
-            KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgBetaLogic{lc})));
+        if (prm.has_radius) {                                                                     // :177-202 (Steihaug-Toint)
+            KR_TRY(launch_ew(ctx, DotPairOp{pp, pp, xw, xw}, n, done));
+            KR_TRY((reduce_then<2>(ctx, nt, ws.red, CgRadiusLogic{lc, prm.radius})));
+            const int64_t grid = std::min<int64_t>(nt, (int64_t)ctx->num_cu * 2);
+            if (grid > 0) {
+                hipLaunchKernelGGL((ew_kernel_if_early<AxpyIfOp>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main,
+                                   AxpyIfOp{ws.st, pp, xw}, n, nt, ws.st);
+                KR_HIP(hipGetLastError());
+            }
+            hipLaunchKernelGGL((logic_kernel<ClearEarlyLogic>), dim3(1), dim3(64), 0, ctx->s_main, ws.red, ClearEarlyLogic{lc});
+            KR_HIP(hipGetLastError());
+        }
+        const bool nat = prm.norm_type == 2;
+        if (nat) KR_TRY(launch_ew(ctx, CgUpdate2{&ws.st->alpha, pp, ap, xw, r}, n, done));
+        else KR_TRY(launch_ew(ctx, CgUpdate1{&ws.st->alpha, pp, ap, xw, r}, n, done));            // :207-212 + (r,r) :223
+        if (!prm.has_obj_target) {
+            if (nat) KR_TRY((reduce_then<2>(ctx, nt, ws.red, CgBetaLogic{lc})));
+            else KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgBetaLogic{lc})));
+        } else {                                                                                  // :231-252
+            if (nat) KR_TRY((reduce_then<2>(ctx, nt, ws.red, CgRsqLogic{lc})));
+            else KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgRsqLogic{lc})));
+            KR_TRY(launch_spmv(a, xw, ax, 1, xw, done));                                          // ax = A x, (x, Ax)
+            KR_TRY((reduce_then<1>(ctx, nt, ws.red, StoreLogic{lc, &ws.st->omega})));
+            KR_TRY(launch_ew(ctx, DotOneOp{xw, bv->d}, n, done));                                 // (x, b)
+            KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgObjLogic{lc, &ws.st->omega, prm.obj_target})));
+            hipLaunchKernelGGL((logic_kernel<CgBetaStoredLogic>), dim3(1), dim3(64), 0, ctx->s_main, ws.red, CgBetaStoredLogic{lc});
+            KR_HIP(hipGetLastError());
         }
         return launch_ew(ctx, AypxDevOp{&ws.st->beta, r, pp}, n, done);                           // :274-276
     }
@@ -303,7 +408,7 @@ struct PcgRun : SolverRun {
     bool alias = false, jac = false;
     int32_t begin() override {
         KR_TRY(solve_args_check(io, bv, xv));
-        if (prm.has_radius || prm.has_obj_target) { set_error("PCG radius / objective target are not implemented on the device"); return KRYST_UNSUPPORTED; }
+        // radius / obj_target are fields of PcgSolver (pcg.rs:39-41) but PcgSolver::solve never reads them: accepted, ignored
         KR_TRY(common_begin(prm.max_iters + 2));                                                  // pcg.rs:117
         alias = !pc || pc->kind == KR_PC_IDENTITY;      // z == r  (pcg.rs:130,186 clone_from / IdentityPC)
         jac = pc && pc->kind == KR_PC_JACOBI;

@@ -518,3 +518,36 @@ def test_ksp_context_factory(ctx, rs):
         assert code == res.code and st.iterations == res.iterations and st.converged == res.converged
         if code == 0:
             assert np.array_equal(x, res.x)
+
+
+@pytest.mark.parametrize("radius", [0.5, 3.0, 7.5, 1e9])
+def test_cg_trust_region_exit_bit_exact(ctx, rs, radius):
+    # cg.rs:177-202 (Steihaug-Toint): stop on the radius with x += max_step * p, converged = false
+    a = O.stencil7(10)
+    b = a.spmv(np.ones(a.nrows))
+    res = O.solve("cg", a, b, tol=1e-8, max_iters=200, radius=radius, rs=rs)
+    s = K.CgSolver(1e-8, 200).with_radius(radius)
+    x = np.zeros(a.nrows)
+    st = s.solve(to_dev(ctx, a), None, b, x)
+    _check_solver(res, st, s, x)
+    if radius < 1e8:
+        assert not st.converged and abs(np.linalg.norm(x) - radius) < 1e-9 * radius
+
+
+@pytest.mark.parametrize("norm", [K.CgNormType.Unpreconditioned, K.CgNormType.Natural])
+def test_cg_objective_target_exit_bit_exact(ctx, rs, norm):
+    # cg.rs:231-252: obj = 0.5 x.Ax - x.b, stop (converged = true) once obj <= target
+    a = O.stencil7(10)
+    b = a.spmv(np.ones(a.nrows))
+    obj_final = -0.5 * float(np.ones(a.nrows) @ b)            # at the solution x = 1
+    for target in (0.9 * obj_final, 0.999999 * obj_final, 2.0 * obj_final):
+        res = O.solve("cg", a, b, tol=1e-8, max_iters=200, obj_target=target, norm_type=int(norm), rs=rs)
+        s = K.CgSolver(1e-8, 200).with_obj_target(target).with_norm(norm)
+        x = np.zeros(a.nrows)
+        st = s.solve(to_dev(ctx, a), None, b, x)
+        _check_solver(res, st, s, x)
+    # PcgSolver carries the same fields but its solve never reads them (pcg.rs:114-222)
+    res = O.solve("pcg", a, b, tol=1e-8, max_iters=200, rs=rs)
+    s = K.PcgSolver(1e-8, 200).with_radius(0.1).with_obj_target(1e30)
+    x = np.zeros(a.nrows)
+    _check_solver(res, s.solve(to_dev(ctx, a), None, b, x), s, x)
