@@ -121,6 +121,10 @@ enum { KRYST_ILU_KRYST_COMPAT = 0,   /* Ilu0 exactly as written, src/preconditio
 int32_t kryst_pc_identity(kryst_ctx_t ctx, kryst_pc_t* out);                        /* test IdentityPC, pcg.rs:245-251 */
 int32_t kryst_pc_jacobi(kryst_csr_t a, kryst_pc_t* out);                            /* Jacobi::setup jacobi.rs:53-73 */
 int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out);                /* Ilu0::setup / Ilup::setup */
+/* Ilup::new(fill).setup(a), src/preconditioner/ilup.rs:77-134 exactly as written (level-of-fill p), on sparse rows */
+int32_t kryst_pc_ilup(kryst_csr_t a, int32_t fill, kryst_pc_t* out);
+/* Ilut::new(fill, droptol).setup(a), src/preconditioner/ilut.rs:80-117 exactly as written */
+int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kryst_pc_t* out);
 int32_t kryst_pc_chebyshev_stub(kryst_ctx_t ctx, int32_t degree, kryst_pc_t* out);  /* Chebyshev trait object: apply -> SolveError, chebyshev.rs:68-70 */
 int32_t kryst_pc_chebyshev(kryst_csr_t a, double alpha, double beta, int32_t degree, kryst_pc_t* out); /* extension: apply == apply_chebyshev */
 int32_t kryst_pc_apply(kryst_pc_t pc, kryst_vec_t r, kryst_vec_t z);                /* Preconditioner::apply */

@@ -128,13 +128,15 @@ struct Jacobi : DevicePc {                                   // jacobi.rs:26-95
 struct Ilu0 : DevicePc {                                     // ilu.rs:32-122 (as written)
     void setup(const HipCsrMatrix& a) override { kryst_pc_t h = nullptr; check(kryst_pc_ilu0(a.handle(), KRYST_ILU_KRYST_COMPAT, &h)); reset(h, a.context()->handle()); }
 };
-struct Ilup : DevicePc {                                     // ilup.rs:54-167, fill = 0 only
+struct Ilup : DevicePc {                                     // ilup.rs:54-167 (level-of-fill p, as written)
     explicit Ilup(size_t fill = 0) : fill(fill) {}
     size_t fill;
-    void setup(const HipCsrMatrix& a) override {
-        if (fill != 0) throw KError(KRYST_UNSUPPORTED);
-        kryst_pc_t h = nullptr; check(kryst_pc_ilu0(a.handle(), KRYST_ILU_ILUP0, &h)); reset(h, a.context()->handle());
-    }
+    void setup(const HipCsrMatrix& a) override { kryst_pc_t h = nullptr; check(kryst_pc_ilup(a.handle(), (int32_t)fill, &h)); reset(h, a.context()->handle()); }
+};
+struct Ilut : DevicePc {                                     // ilut.rs:55-150 (as written)
+    Ilut(size_t fill, double droptol) : fill(fill), droptol(droptol) {}
+    size_t fill; double droptol;
+    void setup(const HipCsrMatrix& a) override { kryst_pc_t h = nullptr; check(kryst_pc_ilut(a.handle(), (int32_t)fill, droptol, &h)); reset(h, a.context()->handle()); }
 };
 struct TrueIlu0 : DevicePc {                                 // extension
     void setup(const HipCsrMatrix& a) override { kryst_pc_t h = nullptr; check(kryst_pc_ilu0(a.handle(), KRYST_ILU_TRUE_ILU0, &h)); reset(h, a.context()->handle()); }

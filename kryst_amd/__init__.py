@@ -21,7 +21,7 @@ import numpy as np
 from . import _ffi
 from ._ffi import KError, lib, check
 
-__all__ = ["Context", "DeviceVec", "CsrMatrix", "dot", "norm", "Jacobi", "Ilu0", "Ilup", "TrueIlu0", "Chebyshev",
+__all__ = ["Context", "DeviceVec", "CsrMatrix", "dot", "norm", "Jacobi", "Ilu0", "Ilup", "Ilut", "TrueIlu0", "Chebyshev",
            "ChebyshevPc", "IdentityPc", "apply_chebyshev", "Convergence", "SolveStats", "CgNormType",
            "Preconditioning", "CgSolver", "PcgSolver", "GmresSolver", "BiCgStabSolver", "BiCgStabRightPcSolver", "Session", "KspContext", "SolverKind", "KError", "reduce_spec",
            "host_stencil7", "partition_rows", "halo_recv_plan"]
@@ -339,14 +339,36 @@ class Ilu0(_IluBase):
 
 
 class Ilup(_IluBase):
-    """Ilup::new(0) exactly as written in src/preconditioner/ilup.rs:77-167 (only fill = 0 is built)."""
+    """Ilup::new(fill) exactly as written in src/preconditioner/ilup.rs:54-167 (level-of-fill p; p = 0 performs no
+    elimination at all)."""
     MODE = 1
 
     def __init__(self, fill=0):
         super().__init__()
-        if fill != 0:
-            raise KError(6, "only fill level 0 is built on the device")
         self.fill = fill
+
+    def setup(self, a):
+        h = _ffi.Handle()
+        check(lib().kryst_pc_ilup(a.h, self.fill, C.byref(h)))
+        self._set(a.ctx, h)
+        self._a = a
+        return self
+
+
+class Ilut(_IluBase):
+    """Ilut::new(fill, droptol) exactly as written in src/preconditioner/ilut.rs:55-150 (no elimination: drop by
+    magnitude, keep the `fill` largest entries of each row, split at the diagonal)."""
+
+    def __init__(self, fill, droptol):
+        super().__init__()
+        self.fill, self.droptol = fill, droptol
+
+    def setup(self, a):
+        h = _ffi.Handle()
+        check(lib().kryst_pc_ilut(a.h, self.fill, self.droptol, C.byref(h)))
+        self._set(a.ctx, h)
+        self._a = a
+        return self
 
 
 class TrueIlu0(_IluBase):

@@ -73,6 +73,8 @@ SIGNATURES = {
     "kryst_pc_identity": (C.c_int32, [Handle, C.POINTER(Handle)]),
     "kryst_pc_jacobi": (C.c_int32, [Handle, C.POINTER(Handle)]),
     "kryst_pc_ilu0": (C.c_int32, [Handle, C.c_int32, C.POINTER(Handle)]),
+    "kryst_pc_ilup": (C.c_int32, [Handle, C.c_int32, C.POINTER(Handle)]),
+    "kryst_pc_ilut": (C.c_int32, [Handle, C.c_int32, C.c_double, C.POINTER(Handle)]),
     "kryst_pc_chebyshev_stub": (C.c_int32, [Handle, C.c_int32, C.POINTER(Handle)]),
     "kryst_pc_chebyshev": (C.c_int32, [Handle, C.c_double, C.c_double, C.c_int32, C.POINTER(Handle)]),
     "kryst_pc_apply": (C.c_int32, [Handle, Handle, Handle]),

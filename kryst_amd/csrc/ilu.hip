@@ -16,6 +16,8 @@
 #include "pc.h"
 #include "ew.h"
 #include <algorithm>
+#include <cmath>
+#include <map>
 
 namespace kr {
 
@@ -249,6 +251,33 @@ static int32_t build_factor(int64_t n, const std::vector<std::vector<std::pair<i
 
 using namespace kr;
 
+typedef std::vector<std::vector<std::pair<int32_t, double>>> RowLists;
+
+// shared tail of every ILU-family setup: level-order both factors and hand out the preconditioner object
+static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const RowLists& le, const RowLists& ue,
+                             const std::vector<double>& dg, kryst_pc_t* out) {
+    kryst_ctx_t ctx = a->ctx;
+    const int64_t n = a->nrows;
+    std::vector<double> ones((size_t)n, 1.0);
+    kryst_pc_t pc = new kryst_pc_s();
+    pc->ctx = ctx; pc->kind = KR_PC_ILU; pc->a = a; pc->n = n; pc->ilu_mode = mode; pc->divide_diag = divide;
+    IluData* D = new IluData();
+    D->n = n;
+    pc->d_work = reinterpret_cast<double*>(D);
+    int32_t rc = build_factor(n, le, ones, true, &D->L);
+    if (rc == KRYST_OK) rc = build_factor(n, ue, dg, false, &D->U);
+    if (rc == KRYST_OK && hipMalloc(&D->d_args, sizeof(TriArgs)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+    if (rc != KRYST_OK) { kryst_pc_destroy(pc); return rc; }
+    *out = pc;
+    return KRYST_OK;
+}
+
+static int32_t download_rows(kryst_csr_t a, std::vector<int64_t>& rp, std::vector<int32_t>& col, std::vector<double>& val) {
+    rp.resize((size_t)a->nrows + 1); col.resize((size_t)a->nnz); val.resize((size_t)a->nnz);
+    return kryst_csr_download(a, rp.data(), col.data(), val.data());
+}
+
+
 extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
     KR_ARG(a && out && mode >= 0 && mode <= 2, "pc_ilu0");
     KR_ARG(a->nrows == a->xlen, "pc_ilu0: square operator required");
@@ -295,8 +324,8 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
             }
     }
     const bool divide = mode != KRYST_ILU_KRYST_COMPAT;                    // ilu.rs:115-119 never divides
-    std::vector<std::vector<std::pair<int32_t, double>>> le((size_t)n), ue((size_t)n);
-    std::vector<double> ones((size_t)n, 1.0), dg((size_t)n, 1.0);
+    RowLists le((size_t)n), ue((size_t)n);
+    std::vector<double> dg((size_t)n, 1.0);
     for (int64_t i = 0; i < n; ++i)
         for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
             const int64_t j = col[k];
@@ -305,15 +334,93 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
             else if (j > i) ue[i].push_back({(int32_t)j, w[k]});
             else if (divide) dg[i] = w[k];                                 // ilup.rs:160-164 (missing diagonal: no divide)
         }
-    kryst_pc_t pc = new kryst_pc_s();
-    pc->ctx = ctx; pc->kind = KR_PC_ILU; pc->a = a; pc->n = n; pc->ilu_mode = mode; pc->divide_diag = divide;
-    IluData* D = new IluData();
-    D->n = n;
-    pc->d_work = reinterpret_cast<double*>(D);
-    int32_t rc = build_factor(n, le, ones, true, &D->L);
-    if (rc == KRYST_OK) rc = build_factor(n, ue, dg, false, &D->U);
-    if (rc == KRYST_OK && hipMalloc(&D->d_args, sizeof(TriArgs)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
-    if (rc != KRYST_OK) { kryst_pc_destroy(pc); return rc; }
-    *out = pc;
-    return KRYST_OK;
+    return finish_ilu_pc(a, mode, divide, le, ue, dg, out);
+}
+
+// Ilup::new(fill).setup(a) exactly as written (src/preconditioner/ilup.rs:77-134), on sparse rows instead of the reference's
+// dense n x n `level` / `a_work` arrays: an entry that the dense code never touches is (0.0, usize::MAX) here too.
+extern "C" int32_t kryst_pc_ilup(kryst_csr_t a, int32_t fill, kryst_pc_t* out) {
+    KR_ARG(a && out && fill >= 0, "pc_ilup");
+    KR_ARG(a->nrows == a->xlen, "pc_ilup: square operator required");
+    if (fill == 0) return kryst_pc_ilu0(a, KRYST_ILU_ILUP0, out);
+    KR_HIP(hipSetDevice(a->ctx->device));
+    const int64_t n = a->nrows;
+    std::vector<int64_t> rp; std::vector<int32_t> col; std::vector<double> val;
+    KR_TRY(download_rows(a, rp, col, val));
+    struct Ent { double v; uint64_t lev; };
+    const uint64_t UMAX = ~0ull;
+    struct UEnt { int32_t k; double v; uint64_t lev; };
+    std::vector<std::vector<UEnt>> urows((size_t)n);       // every nonzero a_work[j][k], k > j, of a finished row j
+    std::vector<double> udiag((size_t)n, 0.0);             // a_work[j][j] of a finished row
+    RowLists le((size_t)n), ue((size_t)n);
+    std::vector<double> dg((size_t)n, 1.0);
+    std::map<int32_t, Ent> W;
+    for (int64_t i = 0; i < n; ++i) {
+        W.clear();
+        for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
+            if (col[k] < n) W[col[k]] = Ent{val[k], val[k] != 0.0 ? 0ull : UMAX};            // ilup.rs:88-101 (halo columns dropped)
+        for (auto it = W.begin(); it != W.end() && it->first < i; ++it) {                  // :104 `for j in 0..i`
+            const int32_t j = it->first;
+            const Ent ej = it->second;
+            if (!(ej.v != 0.0 && ej.lev <= (uint64_t)fill)) continue;                      // :106
+            const double u_jj = udiag[j];
+            if (u_jj == 0.0) { set_error("ILUP: zero diagonal in U at row %d", j); return KRYST_SOLVE_ERROR; }   // :108-110
+            const double lij = ej.v / u_jj;                                                // :112
+            le[i].push_back({j, lij});
+            for (const UEnt& u : urows[j]) {                                               // :116 `for k in (j+1)..n`
+                uint64_t nl = ej.lev;                                                      // saturating adds (:118)
+                nl = (nl > UMAX - u.lev) ? UMAX : nl + u.lev;
+                nl = (nl == UMAX) ? UMAX : nl + 1;
+                if (nl <= (uint64_t)fill) {
+                    auto w = W.find(u.k);
+                    if (w == W.end()) w = W.emplace(u.k, Ent{0.0, UMAX}).first;
+                    const double update = lij * u.v;
+                    w->second.v = w->second.v - update;                                    // :121
+                    if (nl < w->second.lev) w->second.lev = nl;                            // :122
+                }
+            }
+        }
+        for (auto& kv : W) {
+            if (kv.first < i) continue;
+            if (kv.first == i) udiag[i] = kv.second.v;
+            if (kv.second.v != 0.0 && kv.second.lev <= (uint64_t)fill) {                   // :129-134
+                if (kv.first == i) dg[i] = kv.second.v;
+                else ue[i].push_back({kv.first, kv.second.v});
+            }
+            if (kv.first > i && kv.second.v != 0.0) urows[i].push_back(UEnt{kv.first, kv.second.v, kv.second.lev});
+        }
+    }
+    return finish_ilu_pc(a, 10 + fill, true, le, ue, dg, out);
+}
+
+// Ilut::new(fill, droptol).setup(a) exactly as written (src/preconditioner/ilut.rs:80-117): no elimination; drop by
+// magnitude, keep the `fill` largest (stable descending sort), split at the diagonal.  Entries keep their STORED order
+// (descending magnitude after a truncation), which is the order the apply subtracts them in (ilut.rs:129-141).
+extern "C" int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kryst_pc_t* out) {
+    KR_ARG(a && out && fill >= 0, "pc_ilut");
+    KR_ARG(a->nrows == a->xlen, "pc_ilut: square operator required");
+    KR_HIP(hipSetDevice(a->ctx->device));
+    const int64_t n = a->nrows;
+    std::vector<int64_t> rp; std::vector<int32_t> col; std::vector<double> val;
+    KR_TRY(download_rows(a, rp, col, val));
+    RowLists le((size_t)n), ue((size_t)n);
+    std::vector<double> dg((size_t)n, 1.0);
+    std::vector<std::pair<int32_t, double>> row;
+    for (int64_t i = 0; i < n; ++i) {
+        row.clear();
+        for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
+            if (col[k] < n && val[k] != 0.0 && std::fabs(val[k]) >= droptol) row.push_back({col[k], val[k]});     // :88-95
+        if ((int64_t)row.size() > fill) {                                                                        // :97-100
+            std::stable_sort(row.begin(), row.end(), [](const std::pair<int32_t, double>& x, const std::pair<int32_t, double>& y) {
+                return std::fabs(x.second) > std::fabs(y.second); });
+            row.resize((size_t)fill);
+        }
+        bool have_d = false;
+        for (auto& e : row) {                                                                                    // :104-112
+            if (e.first < i) le[i].push_back(e);
+            else if (e.first > i) ue[i].push_back(e);
+            else if (!have_d) { dg[i] = e.second; have_d = true; }                                               // :143-144
+        }
+    }
+    return finish_ilu_pc(a, 100, true, le, ue, dg, out);
 }

@@ -283,6 +283,124 @@ static void tri_apply(const kro_pc_t* pc, const double* r, double* z, int64_t n)
     }
 }
 
+/* ---- Ilup(p) and Ilut as written ------------------------------------------------------------------------ */
+typedef struct { int64_t* col; double* val; int64_t len, cap; } rowbuf_t;
+static void rb_push(rowbuf_t* r, int64_t c, double v) {
+    if (r->len == r->cap) { r->cap = r->cap ? 2 * r->cap : 8; r->col = realloc(r->col, sizeof(int64_t) * r->cap); r->val = realloc(r->val, sizeof(double) * r->cap); }
+    r->col[r->len] = c; r->val[r->len] = v; r->len++;
+}
+static void rows_to_tri(int64_t n, rowbuf_t* l, rowbuf_t* u, kro_trirows_t* out) {
+    out->n = n;
+    out->l_ptr = malloc(sizeof(int64_t) * (n + 1)); out->u_ptr = malloc(sizeof(int64_t) * (n + 1));
+    int64_t nl = 0, nu = 0;
+    for (int64_t i = 0; i < n; ++i) { nl += l[i].len; nu += u[i].len; }
+    out->l_col = malloc(sizeof(int64_t) * (nl + 1)); out->l_val = malloc(sizeof(double) * (nl + 1));
+    out->u_col = malloc(sizeof(int64_t) * (nu + 1)); out->u_val = malloc(sizeof(double) * (nu + 1));
+    nl = nu = 0; out->l_ptr[0] = out->u_ptr[0] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        for (int64_t k = 0; k < l[i].len; ++k) { out->l_col[nl] = l[i].col[k]; out->l_val[nl++] = l[i].val[k]; }
+        for (int64_t k = 0; k < u[i].len; ++k) { out->u_col[nu] = u[i].col[k]; out->u_val[nu++] = u[i].val[k]; }
+        out->l_ptr[i + 1] = nl; out->u_ptr[i + 1] = nu;
+        free(l[i].col); free(l[i].val); free(u[i].col); free(u[i].val);
+    }
+}
+void kro_trirows_free(kro_trirows_t* t) {
+    free(t->l_ptr); free(t->l_col); free(t->l_val); free(t->u_ptr); free(t->u_col); free(t->u_val);
+    memset(t, 0, sizeof *t);
+}
+
+/* ilup.rs:77-134, dense level[][] and a_work[][] as written */
+int32_t kro_ilup_build(const kro_csr_t* a, int64_t fill, kro_trirows_t* out) {
+    const int64_t n = a->nrows;
+    const uint64_t UMAX = UINT64_MAX;
+    uint64_t* level = malloc(sizeof(uint64_t) * (size_t)(n * n + 1));
+    double* w = calloc((size_t)(n * n + 1), sizeof(double));
+    for (int64_t k = 0; k < n * n; ++k) level[k] = UMAX;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t k = a->row_ptr[i]; k < a->row_ptr[i + 1]; ++k) {
+            w[i * n + a->col_idx[k]] = a->vals[k];
+            if (a->vals[k] != 0.0) level[i * n + a->col_idx[k]] = 0;                       /* :88-94 */
+        }
+    rowbuf_t* l = calloc((size_t)n + 1, sizeof(rowbuf_t)); rowbuf_t* u = calloc((size_t)n + 1, sizeof(rowbuf_t));
+    int32_t rc = KRO_OK;
+    for (int64_t i = 0; i < n && rc == KRO_OK; ++i) {                                       /* :103 */
+        for (int64_t j = 0; j < i; ++j) {
+            if (w[i * n + j] != 0.0 && level[i * n + j] <= (uint64_t)fill) {                /* :106 */
+                const double u_jj = w[j * n + j];
+                if (u_jj == 0.0) { rc = KRO_SOLVE_ERROR; break; }                           /* :108-110 */
+                const double lij = w[i * n + j] / u_jj;
+                rb_push(&l[i], j, lij);
+                for (int64_t k = j + 1; k < n; ++k)
+                    if (w[j * n + k] != 0.0) {                                              /* :117 */
+                        uint64_t nl = level[i * n + j];                                     /* saturating_add chain :118 */
+                        nl = (nl > UMAX - level[j * n + k]) ? UMAX : nl + level[j * n + k];
+                        nl = (nl == UMAX) ? UMAX : nl + 1;
+                        if (nl <= (uint64_t)fill) {
+                            const double update = lij * w[j * n + k];
+                            w[i * n + k] = w[i * n + k] - update;
+                            if (nl < level[i * n + k]) level[i * n + k] = nl;
+                        }
+                    }
+            }
+        }
+        for (int64_t k = i; k < n; ++k)
+            if (w[i * n + k] != 0.0 && level[i * n + k] <= (uint64_t)fill) rb_push(&u[i], k, w[i * n + k]);   /* :129-134 */
+    }
+    rows_to_tri(n, l, u, out);
+    free(l); free(u); free(level); free(w);
+    if (rc != KRO_OK) kro_trirows_free(out);
+    return rc;
+}
+
+/* ilut.rs:80-117: no elimination -- drop by magnitude, keep the `fill` largest (stable descending sort), split at the diagonal */
+int32_t kro_ilut_build(const kro_csr_t* a, int64_t fill, double droptol, kro_trirows_t* out) {
+    const int64_t n = a->nrows;
+    rowbuf_t* l = calloc((size_t)n + 1, sizeof(rowbuf_t)); rowbuf_t* u = calloc((size_t)n + 1, sizeof(rowbuf_t));
+    for (int64_t i = 0; i < n; ++i) {
+        rowbuf_t row = {0};
+        for (int64_t k = a->row_ptr[i]; k < a->row_ptr[i + 1]; ++k)
+            if (a->vals[k] != 0.0 && fabs(a->vals[k]) >= droptol) rb_push(&row, a->col_idx[k], a->vals[k]);   /* :88-95 */
+        if (row.len > fill) {                                                               /* :97-100 stable sort by |v| descending */
+            for (int64_t p = 1; p < row.len; ++p) {                                         /* insertion sort == stable */
+                const int64_t c = row.col[p]; const double v = row.val[p];
+                int64_t q = p - 1;
+                while (q >= 0 && fabs(row.val[q]) < fabs(v)) { row.col[q + 1] = row.col[q]; row.val[q + 1] = row.val[q]; --q; }
+                row.col[q + 1] = c; row.val[q + 1] = v;
+            }
+            row.len = fill;
+        }
+        for (int64_t k = 0; k < row.len; ++k) {                                             /* :104-112 */
+            if (row.col[k] < i) rb_push(&l[i], row.col[k], row.val[k]);
+            else rb_push(&u[i], row.col[k], row.val[k]);
+        }
+        free(row.col); free(row.val);
+    }
+    rows_to_tri(n, l, u, out);
+    free(l); free(u);
+    return KRO_OK;
+}
+
+/* ilup.rs:138-167 == ilut.rs:121-150 */
+static void trirows_apply(const kro_trirows_t* t, const double* r, double* z) {
+    const int64_t n = t->n;
+    double* y = dzeros(n);
+    for (int64_t i = 0; i < n; ++i) {
+        double sum = r[i];
+        for (int64_t k = t->l_ptr[i]; k < t->l_ptr[i + 1]; ++k) sum = sum - t->l_val[k] * y[t->l_col[k]];
+        y[i] = sum;
+    }
+    for (int64_t i = n - 1; i >= 0; --i) {
+        double sum = y[i];
+        int64_t dpos = -1;
+        for (int64_t k = t->u_ptr[i]; k < t->u_ptr[i + 1]; ++k) {
+            if (t->u_col[k] > i) sum = sum - t->u_val[k] * z[t->u_col[k]];
+            else if (t->u_col[k] == i && dpos < 0) dpos = k;                                /* .position(|col| col == i): first match */
+        }
+        z[i] = (dpos >= 0) ? sum / t->u_val[dpos] : sum;
+    }
+    free(y);
+}
+
 /* chebyshev.rs:143-159 */
 double kro_chebyshev_t(int64_t m, double x) {
     if (m == 0) return 1.0;
@@ -322,6 +440,7 @@ int32_t kro_pc_apply(const kro_pc_t* pc, const double* r, double* z, int64_t n) 
     case KRO_PC_IDENTITY: memcpy(z, r, sizeof(double) * (size_t)n); return KRO_OK;
     case KRO_PC_JACOBI: { PFOR(i, n) z[i] = pc->inv_diag[i] * r[i]; return KRO_OK; }               /* jacobi.rs:84-92 */
     case KRO_PC_ILU0_COMPAT: case KRO_PC_ILUP0: case KRO_PC_ILU0_TRUE: tri_apply(pc, r, z, n); return KRO_OK;
+    case KRO_PC_TRIROWS: trirows_apply(pc->rows, r, z); return KRO_OK;
     case KRO_PC_CHEBYSHEV_STUB: return KRO_SOLVE_ERROR;                                             /* chebyshev.rs:68-70 */
     case KRO_PC_CHEBYSHEV: kro_apply_chebyshev(pc->a, r, z, n, pc->cheb_alpha, pc->cheb_beta, pc->cheb_degree); return KRO_OK;
     default: return KRO_UNSUPPORTED;

@@ -73,7 +73,15 @@ enum { KRO_PC_NONE = 0,       /* pc == None */
        KRO_PC_ILUP0 = 4,      /* ilup.rs with fill = 0 as written */
        KRO_PC_ILU0_TRUE = 5,  /* extension: textbook IKJ ILU(0) on A's pattern (Saad Alg. 10.4) */
        KRO_PC_CHEBYSHEV_STUB = 6, /* chebyshev.rs:68-70: apply returns Err(SolveError) */
-       KRO_PC_CHEBYSHEV = 7   /* extension: apply == apply_chebyshev(a, r, z, alpha, beta, m) */ };
+       KRO_PC_CHEBYSHEV = 7,  /* extension: apply == apply_chebyshev(a, r, z, alpha, beta, m) */
+       KRO_PC_TRIROWS = 8     /* Ilup(p) / Ilut factors as explicit sparse rows (ilup.rs:54-59, ilut.rs:55-61) */ };
+
+/* L and U as Vec<SparseRow> (ilup.rs:29-33): per row the (col, val) pairs IN STORED ORDER */
+typedef struct {
+    int64_t n;
+    int64_t* l_ptr; int64_t* l_col; double* l_val;
+    int64_t* u_ptr; int64_t* u_col; double* u_val;
+} kro_trirows_t;
 
 typedef struct {
     int32_t kind;
@@ -83,6 +91,7 @@ typedef struct {
     const double* ufac;     /* ILU kinds: value per nnz of A; meaningful where col >= row */
     int32_t divide_diag;    /* ILU kinds: 1 = back substitution divides by the stored diagonal */
     double cheb_alpha, cheb_beta; int32_t cheb_degree;
+    const kro_trirows_t* rows;  /* TRIROWS */
 } kro_pc_t;
 
 typedef struct {
@@ -117,6 +126,11 @@ int32_t kro_jacobi_setup(const kro_csr_t* a, double* inv_diag);
 int32_t kro_ilu0_compat_setup(const kro_csr_t* a, double* lfac, double* ufac);
 int32_t kro_ilup0_setup(const kro_csr_t* a, double* lfac, double* ufac);
 int32_t kro_ilu0_true_setup(const kro_csr_t* a, double* lfac, double* ufac);
+/* Ilup::setup (ilup.rs:77-134) and Ilut::setup (ilut.rs:80-117) exactly as written, dense n x n work arrays included
+ * (small n only); the rows come back in the order the reference pushes them */
+int32_t kro_ilup_build(const kro_csr_t* a, int64_t fill, kro_trirows_t* out);
+int32_t kro_ilut_build(const kro_csr_t* a, int64_t fill, double droptol, kro_trirows_t* out);
+void    kro_trirows_free(kro_trirows_t* t);
 int32_t kro_pc_apply(const kro_pc_t* pc, const double* r, double* z, int64_t n);
 void   kro_apply_chebyshev(const kro_csr_t* a, const double* r, double* z, int64_t n,
                            double alpha, double beta, int64_t m);

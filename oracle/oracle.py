@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(_HERE, "_build", "libkryst_oracle.so")
 
 OK, FACTOR_ERROR, SOLVE_ERROR, INDEFINITE_MATRIX, INDEFINITE_PC, ZERO_PIVOT, UNSUPPORTED = range(7)
 REDUCE_SERIAL, REDUCE_TILED = 0, 1
-PC_NONE, PC_IDENTITY, PC_JACOBI, PC_ILU0_COMPAT, PC_ILUP0, PC_ILU0_TRUE, PC_CHEB_STUB, PC_CHEB = range(8)
+PC_NONE, PC_IDENTITY, PC_JACOBI, PC_ILU0_COMPAT, PC_ILUP0, PC_ILU0_TRUE, PC_CHEB_STUB, PC_CHEB, PC_TRIROWS = range(9)
 SIDE_NONE, SIDE_LEFT, SIDE_RIGHT = 0, 1, 2
 NORM_PRECONDITIONED, NORM_UNPRECONDITIONED, NORM_NATURAL, NORM_NONE = 0, 1, 2, 3
 
@@ -33,10 +33,14 @@ class _Csr(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("row_ptr", _ip), ("col_idx", _ip), ("vals", _dp)]
 
 
+class _TriRows(C.Structure):
+    _fields_ = [("n", C.c_int64), ("l_ptr", _ip), ("l_col", _ip), ("l_val", _dp), ("u_ptr", _ip), ("u_col", _ip), ("u_val", _dp)]
+
+
 class _Pc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("a", C.POINTER(_Csr)), ("inv_diag", _dp), ("lfac", _dp), ("ufac", _dp),
                 ("divide_diag", C.c_int32), ("cheb_alpha", C.c_double), ("cheb_beta", C.c_double),
-                ("cheb_degree", C.c_int32)]
+                ("cheb_degree", C.c_int32), ("rows", C.POINTER(_TriRows))]
 
 
 class _Params(C.Structure):
@@ -87,6 +91,11 @@ def lib():
         for nm in ("kro_ilu0_compat_setup", "kro_ilup0_setup", "kro_ilu0_true_setup"):
             getattr(L, nm).restype = C.c_int32
             getattr(L, nm).argtypes = [C.POINTER(_Csr), _dp, _dp]
+        L.kro_ilup_build.restype = C.c_int32
+        L.kro_ilup_build.argtypes = [C.POINTER(_Csr), C.c_int64, C.POINTER(_TriRows)]
+        L.kro_ilut_build.restype = C.c_int32
+        L.kro_ilut_build.argtypes = [C.POINTER(_Csr), C.c_int64, C.c_double, C.POINTER(_TriRows)]
+        L.kro_trirows_free.argtypes = [C.POINTER(_TriRows)]
         L.kro_pc_apply.restype = C.c_int32
         L.kro_pc_apply.argtypes = [C.POINTER(_Pc), _dp, _dp, C.c_int64]
         L.kro_apply_chebyshev.restype = None
@@ -248,6 +257,34 @@ class Pc:
     @staticmethod
     def ilu0_true(a):
         return Pc._ilu(a, PC_ILU0_TRUE, "kro_ilu0_true_setup", 1)
+
+    @staticmethod
+    def _trirows(a, rc, t):
+        if rc:
+            raise KrylovError(rc)
+        p = Pc(PC_TRIROWS, a)
+        p.tri = t
+        p.c.rows = C.pointer(t)
+        return p
+
+    @staticmethod
+    def ilup(a, fill):
+        """Ilup::new(fill).setup(a) as written (dense work arrays: small n only)."""
+        t = _TriRows()
+        return Pc._trirows(a, lib().kro_ilup_build(C.byref(a.c), fill, C.byref(t)), t)
+
+    @staticmethod
+    def ilut(a, fill, droptol):
+        """Ilut::new(fill, droptol).setup(a) as written."""
+        t = _TriRows()
+        return Pc._trirows(a, lib().kro_ilut_build(C.byref(a.c), fill, droptol, C.byref(t)), t)
+
+    def tri_rows(self):
+        """(l_ptr, l_col, l_val, u_ptr, u_col, u_val) of a TRIROWS preconditioner as numpy arrays."""
+        t, n = self.tri, self.tri.n
+        lp = np.ctypeslib.as_array(t.l_ptr, (n + 1,)).copy(); up = np.ctypeslib.as_array(t.u_ptr, (n + 1,)).copy()
+        f = lambda ptr, m, dt: (np.ctypeslib.as_array(ptr, (max(m, 1),))[:m].copy() if m else np.zeros(0, dtype=dt))
+        return lp, f(t.l_col, lp[-1], np.int64), f(t.l_val, lp[-1], float), up, f(t.u_col, up[-1], np.int64), f(t.u_val, up[-1], float)
 
     @staticmethod
     def chebyshev_stub():

@@ -551,3 +551,40 @@ def test_cg_objective_target_exit_bit_exact(ctx, rs, norm):
     s = K.PcgSolver(1e-8, 200).with_radius(0.1).with_obj_target(1e30)
     x = np.zeros(a.nrows)
     _check_solver(res, s.solve(to_dev(ctx, a), None, b, x), s, x)
+
+
+@pytest.mark.parametrize("fill", [0, 1, 2, 3])
+def test_ilup_level_of_fill_bit_exact(ctx, rs, fill):
+    """Ilup::new(p) (ilup.rs:77-167): the sparse-row setup of the library against the reference's dense algorithm as
+    written (oracle), then the level-scheduled apply against its row-sequential apply -- bit for bit."""
+    rng = np.random.default_rng(40 + fill)
+    d = rng.random((60, 60)) * (rng.random((60, 60)) < 0.12) + np.diag(4.0 + rng.random(60))
+    for a in (O.stencil7(6, "convdiff"), O.stencil7(7, "aniso"), O.Csr.from_dense(d, keep_zeros=False)):
+        r = rng.standard_normal(a.nrows)
+        opc = O.Pc.ilup(a, fill)
+        z = K.Ilup(fill).setup(to_dev(ctx, a)).apply(r)
+        assert np.array_equal(z, opc.apply(r)), (fill, a.nrows)
+    a = O.stencil7(6, "convdiff"); b = a.spmv(np.ones(a.nrows)); dev = to_dev(ctx, a)
+    res = O.solve("gmres", a, b, pc=O.Pc.ilup(a, fill), tol=1e-10, max_iters=60, restart=20, side=O.SIDE_LEFT, rs=rs)
+    s = K.GmresSolver(20, 1e-10, 60); x = np.zeros(a.nrows)
+    _check_solver(res, s.solve(dev, K.Ilup(fill).setup(dev), b, x), s, x)
+
+
+@pytest.mark.parametrize("fill,droptol", [(7, 1e-12), (3, 1e-12), (4, 0.6), (1, 0.0), (0, 0.0)])
+def test_ilut_bit_exact(ctx, rs, fill, droptol):
+    """Ilut::new(fill, droptol) (ilut.rs:80-150): rows truncated to the `fill` largest entries keep their sorted
+    (descending magnitude) order, which is the order the apply subtracts them in."""
+    rng = np.random.default_rng(50 + fill)
+    d = rng.standard_normal((50, 50)) * (rng.random((50, 50)) < 0.2) + np.diag(5.0 + rng.random(50))
+    for a in (O.stencil7(6, "convdiff"), O.Csr.from_dense(d, keep_zeros=False)):
+        r = rng.standard_normal(a.nrows)
+        z = K.Ilut(fill, droptol).setup(to_dev(ctx, a)).apply(r)
+        assert np.array_equal(z, O.Pc.ilut(a, fill, droptol).apply(r)), (fill, droptol, a.nrows)
+    # reference tests ilut.rs:185-211
+    ident = to_dev(ctx, O.Csr.from_dense([[1.0, 0.0], [0.0, 1.0]]))
+    assert np.array_equal(K.Ilut(2, 1e-12).setup(ident).apply(np.array([2.0, 3.0])), [2.0, 3.0])
+    a = O.stencil7(6, "convdiff"); b = a.spmv(np.ones(a.nrows)); dev = to_dev(ctx, a)
+    res = O.solve("gmres", a, b, pc=O.Pc.ilut(a, fill, droptol), tol=1e-10, max_iters=40, restart=20, side=O.SIDE_LEFT, rs=rs,
+                  raise_on_error=False)
+    s = K.GmresSolver(20, 1e-10, 40); x = np.zeros(a.nrows)
+    _check_solver(res, s.solve(dev, K.Ilut(fill, droptol).setup(dev), b, x), s, x)

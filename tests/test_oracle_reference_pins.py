@@ -257,3 +257,21 @@ def test_indefinite_matrix_error():
         with pytest.raises(O.KrylovError) as e:
             O.solve(m, a, [0.0, 1.0], tol=1e-10, max_iters=10)
         assert e.value.code == O.INDEFINITE_MATRIX
+
+
+# ---- src/preconditioner/ilut.rs:185-211 and the level-of-fill path of ilup.rs
+def test_ilut_identity_and_tridiag():
+    a = O.Csr.from_dense([[1.0, 0.0], [0.0, 1.0]])
+    assert np.array_equal(O.Pc.ilut(a, 2, 1e-12).apply([2.0, 3.0]), [2.0, 3.0])
+    a = O.Csr.from_dense([[2.0, -1.0, 0.0], [-1.0, 2.0, -1.0], [0.0, -1.0, 2.0]])
+    assert np.all(np.isfinite(O.Pc.ilut(a, 3, 1e-12).apply([1.0, 2.0, 3.0])))
+
+
+def test_ilup_dense_as_written_equals_sparse_restatement_at_fill_0():
+    a = O.stencil7(5, "convdiff")
+    r = O.splitmix64_uniform(3, a.nrows)
+    assert np.array_equal(O.Pc.ilup(a, 0).apply(r), O.Pc.ilup0(a).apply(r))
+    # with fill >= 1 eliminations happen: on a tridiagonal matrix (no fill-in possible) Ilup(1) is the exact LU
+    t = O.Csr.from_dense(O.tridiag(12, -1.0, 2.0, -1.0), keep_zeros=False)
+    x = np.arange(1.0, 13.0)
+    assert np.allclose(O.Pc.ilup(t, 1).apply(t.spmv(x)), x, rtol=1e-12)
