@@ -6,12 +6,16 @@
 //                                at fill 0 (new_level = 1 > fill), same L, U = triu(A), apply divides by the stored diagonal.
 //   mode KRYST_ILU_TRUE_ILU0     extension: textbook IKJ ILU(0) on A's pattern (Saad Alg. 10.4).
 //
-// Setup (host, once): factor values on A's pattern, dependency levels of L (ascending rows) and U (descending rows), and a
-// LEVEL-ORDERED copy of each factor so that the rows of one level are contiguous in HBM (streamed once, coalesced).
-// Apply (device): one kernel per level -- a lane owns a row and subtracts its entries in ascending column order, exactly
-// the reference's loop -- with runs of narrow levels folded into a single one-workgroup kernel (workgroup barriers instead
-// of launches).  The whole launch sequence is captured once into a hipGraph: a 7-point 256^3 grid has 3N-2 = 766 levels
-// per factor, so the solve is bound by the ~1.5 us kernel boundary, not by bandwidth, and the graph removes the host cost.
+// Setup (host, once): factor values, dependency levels of L (ascending rows) and U (descending rows), and a LEVEL-ORDERED
+// copy of each factor (rows of one level contiguous, columns renumbered to level-order positions).
+// Apply (device): the vectors are permuted into level order, then one kernel per level -- a lane owns a row and subtracts
+// its entries in stored order, exactly the reference's loop -- and permuted back.  The launch sequence is captured once
+// into a hipGraph.  A 7-point 256^3 grid has 3N-2 = 766 levels per factor and each level is a chain of ~3 dependent
+// memory round trips from a cold start (~1 us each), so the solve is LATENCY-bound: measured 3.4 us per level (5.2 ms per
+// apply; 7.4 ms before the level-permuted layout).  An experimental band schedule (KRYST_ILU_BAND=B: B levels per launch,
+// each workgroup recomputing the in-band dependency closure of its rows so that workgroup barriers replace kernel
+// boundaries) is kept behind the knob: it is bit-identical but measured no faster (the in-band steps still pay an L2
+// round trip each), so the default is one launch per level.
 // In a distributed context the factors are block-local (block-Jacobi ILU): halo columns are dropped.
 #include "pc.h"
 #include "ew.h"
@@ -25,6 +29,9 @@ struct TriArgs {                    // device-resident argument block, rewritten
     const double* r; double* z; long long skip;   // one scalar load gives a level kernel everything it needs
 };
 
+#define ELLW 4
+struct EllView { const int32_t* col; const double* val; const uint8_t* len; int64_t npos; };
+
 struct TriFactor {                  // one triangular factor in level order
     int32_t* d_ptr = nullptr;       // npos+1: entry range of the row at level-position p
     int32_t* d_col = nullptr;       // column (original numbering)
@@ -36,35 +43,45 @@ struct TriFactor {                  // one triangular factor in level order
     int32_t* d_ecol = nullptr; double* d_eval = nullptr; uint8_t* d_elen = nullptr; int64_t npos = 0; bool ell = false;
     std::vector<int32_t> lvl_off;   // host: position offsets per level
     int32_t* d_lvl_off = nullptr;
+    // band schedule (ELL factors): B consecutive levels per launch, see build_bands()
+    struct Band { int nwg, nlev; int64_t ptr_off; int maxcnt; };
+    std::vector<Band> bands;
+    int32_t* d_band_ptr = nullptr; int32_t* d_band_list = nullptr;
+    double inflation = 1.0;
     void free_all() { hipFree(d_ptr); hipFree(d_col); hipFree(d_val); hipFree(d_row); hipFree(d_diag); hipFree(d_lvl_off);
-                      hipFree(d_ecol); hipFree(d_eval); hipFree(d_elen); }
+                      hipFree(d_ecol); hipFree(d_eval); hipFree(d_elen); hipFree(d_band_ptr); hipFree(d_band_list); }
+    EllView view() const { return EllView{d_ecol, d_eval, d_elen, npos}; }
 };
 
 struct IluData {
     TriFactor L, U;
     TriArgs* d_args = nullptr;
+    double* d_rL = nullptr; double* d_y = nullptr; double* d_yU = nullptr; double* d_zU = nullptr;   // level-permuted work vectors
+    int32_t* d_mapLU = nullptr;     // L-position of the row at U-position q
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     int64_t n = 0;
 };
 
+// forward:  y[i] = r[i] - sum l_ij y[j]            (ilu.rs:107-113, ilup.rs:143-149)
+// backward: z[i] = (y[i] - sum u_ij z[j]) / d_i     (ilu.rs:115-119 with d = 1, ilup.rs:151-165)
+// All level kernels work on LEVEL-PERMUTED vectors (`in`, `out` indexed by the level-order position p; the factor's column
+// indices are positions too): the rows of a level and, for banded operators, their dependencies in the previous level are
+// contiguous in memory, so a level touches a few pages instead of one page per row (the scattered form spent ~5 us per
+// level on address translation and uncoalesced 8-byte accesses).  perm_gather / perm_scatter convert at the ends.
+
 // rows of ONE level: positions [p0, p1)
 template <bool FORWARD>
-__global__ __launch_bounds__(256) void tri_level_kernel(const TriArgs* args, const int32_t* __restrict__ ptr,
-                                                        const int32_t* __restrict__ col, const double* __restrict__ val,
-                                                        const int32_t* __restrict__ rowid, const double* __restrict__ diag,
+__global__ __launch_bounds__(256) void tri_level_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
+                                                        const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                                                        const double* __restrict__ val, const double* __restrict__ diag,
                                                         int32_t p0, int32_t p1) {
     if (args->skip) return;
     const int32_t p = p0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= p1) return;
-    double* z = args->z;
-    const int32_t i = rowid[p];
-    double s = FORWARD ? args->r[i] : z[i];                 // ilu.rs:107 y1 = x.clone() / ilup.rs:145,153
-    for (int32_t k = ptr[p]; k < ptr[p + 1]; ++k) s = s - val[k] * z[col[k]];   // ilu.rs:111,117 ; ilup.rs:147,156
-    z[i] = FORWARD ? s : s / diag[p];                       // ilup.rs:160-164 (diag == 1.0: exact no-op)
+    double s = in[p];
+    for (int32_t k = ptr[p]; k < ptr[p + 1]; ++k) s = s - val[k] * out[col[k]];    // stored order
+    out[p] = FORWARD ? s : s / diag[p];                                             // diag == 1.0: exact no-op
 }
-
-#define ELLW 4
-struct EllView { const int32_t* col; const double* val; const uint8_t* len; int64_t npos; };
 
 __device__ __forceinline__ double ell_row(const EllView& E, int32_t p, double s, const double* z) {
     int32_t c[ELLW]; double v[ELLW], zz[ELLW];
@@ -74,91 +91,175 @@ __device__ __forceinline__ double ell_row(const EllView& E, int32_t p, double s,
 #pragma unroll
     for (int u = 0; u < ELLW; ++u) zz[u] = z[c[u]];                 // padding slots point at column 0 (valid, unused)
 #pragma unroll
-    for (int u = 0; u < ELLW; ++u) if (u < len) s = s - v[u] * zz[u];   // ascending column order
+    for (int u = 0; u < ELLW; ++u) if (u < len) s = s - v[u] * zz[u];   // stored order
     return s;
 }
 
 template <bool FORWARD>
-__global__ __launch_bounds__(256) void tri_level_ell_kernel(const TriArgs* args, EllView E, const int32_t* __restrict__ rowid,
+__global__ __launch_bounds__(256) void tri_level_ell_kernel(const TriArgs* args, const double* __restrict__ in, double* out, EllView E,
                                                             const double* __restrict__ diag, int32_t p0, int32_t p1) {
     if (args->skip) return;
     const int32_t p = p0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= p1) return;
-    double* z = args->z;
-    const int32_t i = rowid[p];
-    const double s = ell_row(E, p, FORWARD ? args->r[i] : z[i], z);
-    z[i] = FORWARD ? s : s / diag[p];
+    const double s = ell_row(E, p, in[p], out);
+    out[p] = FORWARD ? s : s / diag[p];
 }
 
+// BAND schedule: one launch covers `nlev` consecutive dependency levels.  Workgroup w owns a proportional chunk of every
+// level of the band and ALSO recomputes, level by level, every in-band ancestor of its rows (the dependency closure,
+// built at setup), so it never needs another workgroup's result inside the launch: workgroup barriers replace
+// nlev-1 kernel boundaries.  Rows computed by several workgroups get the same bits from each (same inputs, same order).
 template <bool FORWARD>
-__global__ __launch_bounds__(1024) void tri_run_ell_kernel(const TriArgs* args, EllView E, const int32_t* __restrict__ rowid,
-                                                           const double* __restrict__ diag, const int32_t* __restrict__ lvl_off,
-                                                           int32_t l0, int32_t l1) {
+__global__ __launch_bounds__(256) void tri_band_kernel(const TriArgs* args, const double* __restrict__ in, double* out, EllView E,
+                                                       const double* __restrict__ diag, const int32_t* __restrict__ band_ptr,
+                                                       const int32_t* __restrict__ band_list, int32_t nlev) {
     if (args->skip) return;
-    double* z = args->z;
-    for (int32_t lv = l0; lv < l1; ++lv) {
-        const int32_t p0 = lvl_off[lv], p1 = lvl_off[lv + 1];
-        for (int32_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
-            const int32_t i = rowid[p];
-            const double s = ell_row(E, p, FORWARD ? args->r[i] : z[i], z);
-            z[i] = FORWARD ? s : s / diag[p];
+    const int32_t* myptr = band_ptr + (int64_t)blockIdx.x * (nlev + 1);
+    for (int32_t b = 0; b < nlev; ++b) {
+        const int32_t e0 = myptr[b], e1 = myptr[b + 1];
+        for (int32_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+            const int32_t p = band_list[e];
+            const double s = ell_row(E, p, in[p], out);
+            out[p] = FORWARD ? s : s / diag[p];
         }
-        __syncthreads();
+        __syncthreads();                                    // workgroup-scope release/acquire of `out` between levels
     }
 }
 
-// a run of consecutive NARROW levels [l0, l1) in one workgroup: workgroup barrier between levels
+// Same schedule with everything that does not depend on the running solution fetched UP FRONT: the row lists, the factor
+// rows, `in` and the divisors of all NLEV levels go to registers in one burst of independent loads; the dependent part
+// of a level is then a single gather of values this workgroup has just written (L2 hits) plus the store and the barrier.
+template <bool FORWARD, int NLEV, int R>
+__global__ __launch_bounds__(256) void tri_band_pre_kernel(const TriArgs* args, const double* __restrict__ in, double* out, EllView E,
+                                                           const double* __restrict__ diag, const int32_t* __restrict__ band_ptr,
+                                                           const int32_t* __restrict__ band_list, int32_t nlev) {
+    if (args->skip) return;
+    const int32_t* myptr = band_ptr + (int64_t)blockIdx.x * (nlev + 1);
+    int32_t pp[NLEV][R]; int32_t cc[NLEV][R][ELLW]; double vv[NLEV][R][ELLW]; double s0[NLEV][R], dg[NLEV][R]; int ln[NLEV][R];
+#pragma unroll
+    for (int b = 0; b < NLEV; ++b) {
+        const int32_t e0 = b < nlev ? myptr[b] : 0, e1 = b < nlev ? myptr[b + 1] : 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int32_t e = e0 + (int32_t)threadIdx.x + r * 256;
+            const bool on = e < e1;
+            const int32_t p = on ? band_list[e] : -1;
+            pp[b][r] = p;
+            const int32_t q = on ? p : 0;
+            ln[b][r] = on ? (int)E.len[q] : 0;
+#pragma unroll
+            for (int u = 0; u < ELLW; ++u) { cc[b][r][u] = E.col[u * E.npos + q]; vv[b][r][u] = E.val[u * E.npos + q]; }
+            s0[b][r] = in[q]; dg[b][r] = diag[q];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NLEV; ++b) {
+        if (b < nlev) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (pp[b][r] >= 0) {
+                    double zz[ELLW];
+#pragma unroll
+                    for (int u = 0; u < ELLW; ++u) zz[u] = out[cc[b][r][u]];
+                    double s = s0[b][r];
+#pragma unroll
+                    for (int u = 0; u < ELLW; ++u) if (u < ln[b][r]) s = s - vv[b][r][u] * zz[u];     // stored order
+                    out[pp[b][r]] = FORWARD ? s : s / dg[b][r];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// a run of consecutive NARROW levels [l0, l1) in one workgroup (CSR fallback for factors that do not fit the ELL form)
 template <bool FORWARD>
-__global__ __launch_bounds__(1024) void tri_run_kernel(const TriArgs* args, const int32_t* __restrict__ ptr,
-                                                       const int32_t* __restrict__ col, const double* __restrict__ val,
-                                                       const int32_t* __restrict__ rowid, const double* __restrict__ diag,
+__global__ __launch_bounds__(1024) void tri_run_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
+                                                       const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                                                       const double* __restrict__ val, const double* __restrict__ diag,
                                                        const int32_t* __restrict__ lvl_off, int32_t l0, int32_t l1) {
     if (args->skip) return;
-    double* z = args->z;
     for (int32_t lv = l0; lv < l1; ++lv) {
         const int32_t p0 = lvl_off[lv], p1 = lvl_off[lv + 1];
         for (int32_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
-            const int32_t i = rowid[p];
-            double s = FORWARD ? args->r[i] : z[i];
-            for (int32_t k = ptr[p]; k < ptr[p + 1]; ++k) s = s - val[k] * z[col[k]];
-            z[i] = FORWARD ? s : s / diag[p];
+            double s = in[p];
+            for (int32_t k = ptr[p]; k < ptr[p + 1]; ++k) s = s - val[k] * out[col[k]];
+            out[p] = FORWARD ? s : s / diag[p];
         }
-        __syncthreads();                                    // workgroup-scope release/acquire of z between levels
+        __syncthreads();
     }
 }
 
 // runs in stream order before the level kernels, so it sees the solver's `done` flag as of this apply
 __global__ void tri_set_args(TriArgs* a, const double* r, double* z, const int* done) { a->r = r; a->z = z; a->skip = (done && *done) ? 1 : 0; }
 
-static const int NARROW = 2048;     // levels with at most this many rows are folded into one-workgroup runs
+// dst[p] = src[map[p]]   (MODE 0: src = the caller's r;  MODE 1: plain gather;  MODE 2: scatter into the caller's z: z[map[p]] = src[p])
+template <int MODE>
+__global__ __launch_bounds__(256) void perm_kernel(const TriArgs* args, double* dst, const double* src, const int32_t* __restrict__ map, int64_t n) {
+    if (args->skip) return;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (MODE == 0) dst[p] = args->r[map[p]];
+    else if (MODE == 1) dst[p] = src[map[p]];
+    else args->z[map[p]] = src[p];
+}
+
+static const int NARROW = 2048;     // levels with at most this many rows are folded into one-workgroup runs (CSR fallback)
 
 template <bool FORWARD>
-static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* d_args) {
+static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* d_args, const double* in, double* out) {
+    if (F.ell && !F.bands.empty()) {
+        for (const TriFactor::Band& b : F.bands) {
+#define KR_BAND_PRE(NL_, R_) hipLaunchKernelGGL((tri_band_pre_kernel<FORWARD, NL_, R_>), dim3((unsigned)b.nwg), dim3(256), 0, s, d_args, in, out, \
+                                               F.view(), F.d_diag, F.d_band_ptr + b.ptr_off, F.d_band_list, b.nlev)
+            const int rr = (b.maxcnt + 255) / 256;
+            if (b.nlev <= 2 && rr <= 2) KR_BAND_PRE(2, 2);
+            else if (b.nlev <= 2 && rr <= 4) KR_BAND_PRE(2, 4);
+            else if (b.nlev <= 4 && rr <= 2) KR_BAND_PRE(4, 2);
+            else if (b.nlev <= 4 && rr <= 3) KR_BAND_PRE(4, 3);
+            else
+            hipLaunchKernelGGL((tri_band_kernel<FORWARD>), dim3((unsigned)b.nwg), dim3(256), 0, s, d_args, in, out, F.view(), F.d_diag,
+                               F.d_band_ptr + b.ptr_off, F.d_band_list, b.nlev);
+#undef KR_BAND_PRE
+            KR_HIP(hipGetLastError());
+        }
+        return KRYST_OK;
+    }
     const int nl = (int)F.lvl_off.size() - 1;
     int lv = 0;
     while (lv < nl) {
         const int rows = F.lvl_off[lv + 1] - F.lvl_off[lv];
-        if (rows <= NARROW) {
+        if (rows <= NARROW && !F.ell) {
             int l1 = lv + 1;
             while (l1 < nl && F.lvl_off[l1 + 1] - F.lvl_off[l1] <= NARROW) ++l1;
-            if (F.ell)
-                hipLaunchKernelGGL((tri_run_ell_kernel<FORWARD>), dim3(1), dim3(1024), 0, s, d_args,
-                                   EllView{F.d_ecol, F.d_eval, F.d_elen, F.npos}, F.d_row, F.d_diag, F.d_lvl_off, lv, l1);
-            else
-                hipLaunchKernelGGL((tri_run_kernel<FORWARD>), dim3(1), dim3(1024), 0, s, d_args, F.d_ptr, F.d_col, F.d_val, F.d_row,
-                                   F.d_diag, F.d_lvl_off, lv, l1);
+            hipLaunchKernelGGL((tri_run_kernel<FORWARD>), dim3(1), dim3(1024), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
+                               F.d_diag, F.d_lvl_off, lv, l1);
             lv = l1;
         } else {
             if (F.ell)
-                hipLaunchKernelGGL((tri_level_ell_kernel<FORWARD>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_args,
-                                   EllView{F.d_ecol, F.d_eval, F.d_elen, F.npos}, F.d_row, F.d_diag, F.lvl_off[lv], F.lvl_off[lv + 1]);
+                hipLaunchKernelGGL((tri_level_ell_kernel<FORWARD>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_args, in, out,
+                                   F.view(), F.d_diag, F.lvl_off[lv], F.lvl_off[lv + 1]);
             else
-                hipLaunchKernelGGL((tri_level_kernel<FORWARD>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_args, F.d_ptr,
-                                   F.d_col, F.d_val, F.d_row, F.d_diag, F.lvl_off[lv], F.lvl_off[lv + 1]);
+                hipLaunchKernelGGL((tri_level_kernel<FORWARD>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_args, in, out, F.d_ptr,
+                                   F.d_col, F.d_val, F.d_diag, F.lvl_off[lv], F.lvl_off[lv + 1]);
             lv += 1;
         }
         KR_HIP(hipGetLastError());
     }
+    return KRYST_OK;
+}
+
+// r -> rL (L level order) -> forward -> yL -> yU (U level order) -> backward -> zU -> z
+static int32_t enqueue_apply(hipStream_t s, IluData* D) {
+    const unsigned g = (unsigned)((D->n + 255) / 256);
+    hipLaunchKernelGGL((perm_kernel<0>), dim3(g), dim3(256), 0, s, D->d_args, D->d_rL, (const double*)nullptr, D->L.d_row, D->n);
+    KR_HIP(hipGetLastError());
+    KR_TRY(enqueue_factor<true>(s, D->L, D->d_args, D->d_rL, D->d_y));
+    hipLaunchKernelGGL((perm_kernel<1>), dim3(g), dim3(256), 0, s, D->d_args, D->d_yU, (const double*)D->d_y, D->d_mapLU, D->n);
+    KR_HIP(hipGetLastError());
+    KR_TRY(enqueue_factor<false>(s, D->U, D->d_args, D->d_yU, D->d_zU));
+    hipLaunchKernelGGL((perm_kernel<2>), dim3(g), dim3(256), 0, s, D->d_args, (double*)nullptr, (const double*)D->d_zU, D->U.d_row, D->n);
+    KR_HIP(hipGetLastError());
     return KRYST_OK;
 }
 
@@ -170,11 +271,10 @@ int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done
     KR_HIP(hipGetLastError());
     static const int use_graph = getenv("KRYST_ILU_GRAPH") ? atoi(getenv("KRYST_ILU_GRAPH")) : 1;
     if (!D->exec && use_graph) {
-        // capture the level sequence once; the graph only refers to the device argument block
+        // capture the launch sequence once; the graph only refers to the device argument block
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(ctx->s_main, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            int32_t rc = enqueue_factor<true>(ctx->s_main, D->L, D->d_args);
-            if (rc == KRYST_OK) rc = enqueue_factor<false>(ctx->s_main, D->U, D->d_args);
+            int32_t rc = enqueue_apply(ctx->s_main, D);
             hipError_t e = hipStreamEndCapture(ctx->s_main, &g);
             if (rc == KRYST_OK && e == hipSuccess && g && hipGraphInstantiate(&D->exec, g, nullptr, nullptr, 0) == hipSuccess) {
                 D->graph = g;
@@ -186,8 +286,7 @@ int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done
         }
     }
     if (D->exec) { KR_HIP(hipGraphLaunch(D->exec, ctx->s_main)); return KRYST_OK; }
-    KR_TRY(enqueue_factor<true>(ctx->s_main, D->L, D->d_args));      // eager fallback (same kernels)
-    return enqueue_factor<false>(ctx->s_main, D->U, D->d_args);
+    return enqueue_apply(ctx->s_main, D);                             // eager fallback (same kernels)
 }
 
 void ilu_free(kryst_pc_t pc) {
@@ -195,7 +294,7 @@ void ilu_free(kryst_pc_t pc) {
     IluData* D = reinterpret_cast<IluData*>(pc->d_work);
     if (D->exec) hipGraphExecDestroy(D->exec);
     if (D->graph) hipGraphDestroy(D->graph);
-    D->L.free_all(); D->U.free_all(); hipFree(D->d_args);
+    D->L.free_all(); D->U.free_all(); hipFree(D->d_args); hipFree(D->d_y); hipFree(D->d_rL); hipFree(D->d_yU); hipFree(D->d_zU); hipFree(D->d_mapLU);
     delete D;
     pc->d_work = nullptr;
 }
@@ -207,9 +306,61 @@ static int32_t up(T** dst, const std::vector<T>& v) {
     return KRYST_OK;
 }
 
+static int env_i(const char* nm, int d) { const char* e = getenv(nm); return e ? atoi(e) : d; }
+
+// Band schedule of one factor: groups of B consecutive levels; per band and workgroup the level-by-level row lists
+// (own chunk + in-band dependency closure).  pos[] maps a row to its level-order position.
+static int32_t build_bands(int64_t n, const std::vector<std::vector<std::pair<int32_t, double>>>& ent, const std::vector<int32_t>& lvl,
+                           const std::vector<int32_t>& rowid, TriFactor* F) {
+    const int B = std::max(1, env_i("KRYST_ILU_BAND", 4));   // KRYST_ILU_BAND=0 (default): one launch per level
+    const int CHUNK = std::max(64, env_i("KRYST_ILU_CHUNK", 512));
+    const int nl = (int)F->lvl_off.size() - 1;
+    std::vector<int32_t> pos((size_t)n);
+    for (int64_t p = 0; p < n; ++p) pos[rowid[p]] = (int32_t)p;
+    std::vector<int32_t> band_ptr, band_list;
+    std::vector<int64_t> mark((size_t)n, -1);
+    int64_t stamp = 0, owned_total = 0;
+    std::vector<std::vector<int32_t>> S;
+    for (int l0 = 0; l0 < nl; l0 += B) {
+        const int nlev = std::min(B, nl - l0);
+        int64_t maxlen = 0;
+        for (int b = 0; b < nlev; ++b) maxlen = std::max<int64_t>(maxlen, F->lvl_off[l0 + b + 1] - F->lvl_off[l0 + b]);
+        const int nwg = (int)std::max<int64_t>(1, (maxlen + CHUNK - 1) / CHUNK);
+        F->bands.push_back(TriFactor::Band{nwg, nlev, (int64_t)band_ptr.size(), 0});
+        for (int w = 0; w < nwg; ++w) {
+            ++stamp;
+            S.assign((size_t)nlev, {});
+            for (int b = 0; b < nlev; ++b) {                      // own chunk of every level of the band
+                const int64_t o = F->lvl_off[l0 + b], len = F->lvl_off[l0 + b + 1] - o;
+                for (int64_t p = o + len * w / nwg; p < o + len * (w + 1) / nwg; ++p) { S[b].push_back((int32_t)p); mark[p] = stamp; }
+                owned_total += len * (w + 1) / nwg - len * w / nwg;
+            }
+            for (int b = nlev - 1; b > 0; --b)                    // in-band ancestors, top level first
+                for (size_t q = 0; q < S[b].size(); ++q)
+                    for (const auto& e : ent[rowid[S[b][q]]]) {
+                        const int lb = lvl[e.first] - l0;
+                        if (lb < 0) continue;                     // finished in an earlier launch
+                        const int32_t pc = pos[e.first];
+                        if (mark[pc] != stamp) { mark[pc] = stamp; S[lb].push_back(pc); }
+                    }
+            for (int b = 0; b < nlev; ++b) {
+                F->bands.back().maxcnt = std::max<int>(F->bands.back().maxcnt, (int)S[b].size());
+                std::sort(S[b].begin(), S[b].end());
+                band_ptr.push_back((int32_t)band_list.size());
+                band_list.insert(band_list.end(), S[b].begin(), S[b].end());
+            }
+            band_ptr.push_back((int32_t)band_list.size());
+        }
+        if (band_list.size() > (size_t)2000000000) { F->bands.clear(); return KRYST_OK; }   // int32 offsets: fall back to per-level launches
+    }
+    F->inflation = owned_total ? (double)band_list.size() / (double)owned_total : 1.0;
+    KR_TRY(up(&F->d_band_ptr, band_ptr)); KR_TRY(up(&F->d_band_list, band_list));
+    return KRYST_OK;
+}
+
 // level order of one factor.  rows/cols/vals: per row the kept entries in ascending column order.
 static int32_t build_factor(int64_t n, const std::vector<std::vector<std::pair<int32_t, double>>>& ent,
-                            const std::vector<double>& diag, bool forward, TriFactor* F) {
+                            const std::vector<double>& diag, bool forward, TriFactor* F, std::vector<int32_t>* pos_out) {
     std::vector<int32_t> lvl((size_t)n, 0);
     int32_t nl = 0;
     if (forward) {
@@ -222,10 +373,13 @@ static int32_t build_factor(int64_t n, const std::vector<std::vector<std::pair<i
     for (int l = 0; l < nl; ++l) F->lvl_off[l + 1] += F->lvl_off[l];
     std::vector<int32_t> cursor(F->lvl_off.begin(), F->lvl_off.end() - 1), rowid((size_t)n), ptr((size_t)n + 1, 0);
     for (int64_t i = 0; i < n; ++i) rowid[cursor[lvl[i]]++] = (int32_t)i;        // ascending row inside a level
+    std::vector<int32_t> pos((size_t)n);
+    for (int64_t p = 0; p < n; ++p) pos[rowid[p]] = (int32_t)p;
+    if (pos_out) *pos_out = pos;
     std::vector<int32_t> col; std::vector<double> val, dg((size_t)n);
     for (int64_t p = 0; p < n; ++p) {
         const int32_t i = rowid[p];
-        for (auto& e : ent[i]) { col.push_back(e.first); val.push_back(e.second); }
+        for (auto& e : ent[i]) { col.push_back(pos[e.first]); val.push_back(e.second); }      // columns as level-order positions
         ptr[p + 1] = (int32_t)col.size();
         dg[p] = diag[i];
     }
@@ -237,11 +391,12 @@ static int32_t build_factor(int64_t n, const std::vector<std::vector<std::pair<i
         for (int64_t p = 0; p < n; ++p) {
             const auto& e = ent[rowid[p]];
             elen[p] = (uint8_t)e.size();
-            for (size_t u = 0; u < e.size(); ++u) { ecol[u * n + p] = e[u].first; eval[u * n + p] = e[u].second; }
+            for (size_t u = 0; u < e.size(); ++u) { ecol[u * n + p] = pos[e[u].first]; eval[u * n + p] = e[u].second; }
         }
         KR_TRY(up(&F->d_ecol, ecol)); KR_TRY(up(&F->d_eval, eval)); KR_TRY(up(&F->d_elen, elen));
         F->ell = true;
     }
+    if (F->ell && env_i("KRYST_ILU_BAND", 0) > 0) KR_TRY(build_bands(n, ent, lvl, rowid, F));
     KR_TRY(up(&F->d_ptr, ptr)); KR_TRY(up(&F->d_col, col)); KR_TRY(up(&F->d_val, val)); KR_TRY(up(&F->d_row, rowid));
     KR_TRY(up(&F->d_diag, dg)); KR_TRY(up(&F->d_lvl_off, F->lvl_off));
     return KRYST_OK;
@@ -264,9 +419,27 @@ static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const RowList
     IluData* D = new IluData();
     D->n = n;
     pc->d_work = reinterpret_cast<double*>(D);
-    int32_t rc = build_factor(n, le, ones, true, &D->L);
-    if (rc == KRYST_OK) rc = build_factor(n, ue, dg, false, &D->U);
+    std::vector<int32_t> posL, posU;
+    int32_t rc = build_factor(n, le, ones, true, &D->L, &posL);
+    if (rc == KRYST_OK) rc = build_factor(n, ue, dg, false, &D->U, &posU);
+    if (rc == KRYST_OK) {
+        std::vector<int32_t> mapLU((size_t)n);
+        for (int64_t i = 0; i < n; ++i) mapLU[posU[i]] = posL[i];
+        rc = up(&D->d_mapLU, mapLU);
+    }
     if (rc == KRYST_OK && hipMalloc(&D->d_args, sizeof(TriArgs)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+    if (rc == KRYST_OK) {
+        const size_t bytes = sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
+        for (double** pp : {&D->d_y, &D->d_rL, &D->d_yU, &D->d_zU}) {
+            if (rc != KRYST_OK) break;
+            if (hipMalloc(pp, bytes) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+            else if (hipMemsetAsync(*pp, 0, bytes, ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
+        }
+        if (rc == KRYST_OK && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
+    }
+    if (getenv("KRYST_ILU_VERBOSE"))
+        fprintf(stderr, "[kryst ilu] n=%lld levels L/U=%zu/%zu bands=%zu/%zu redundancy L/U=%.3f/%.3f\n", (long long)n,
+                D->L.lvl_off.size() - 1, D->U.lvl_off.size() - 1, D->L.bands.size(), D->U.bands.size(), D->L.inflation, D->U.inflation);
     if (rc != KRYST_OK) { kryst_pc_destroy(pc); return rc; }
     *out = pc;
     return KRYST_OK;
