@@ -18,6 +18,7 @@
 #include "csr.h"
 #include "ew.h"
 #include <algorithm>
+#include <unordered_map>
 
 #ifndef SPMV_SLOTS
 #define SPMV_SLOTS 4                        // pair slots per lane per LDS window: window = 2048 entries = 16 KiB
@@ -493,14 +494,24 @@ static int32_t upload_csr(kryst_csr_t a, const std::vector<int32_t>& rp, const s
     a->ntiles = ntiles_of(a->nrows);
     {   // CSR-D8: one byte per entry when the operator has <= 256 distinct (col - row) offsets
         std::vector<int32_t> dict; dict.reserve(256);
+        std::unordered_map<int32_t, int> code_of;
         std::vector<uint8_t> codes(nnz + 32, 0);
         bool ok = nnz > 0;
+        int32_t last_d = 0; int last_code = -1;                    // consecutive entries often repeat an offset
         for (int64_t i = 0; i < a->nrows && ok; ++i)
             for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
                 const int32_t d = col[k] - (int32_t)i;
-                int code = -1;
-                for (size_t u = 0; u < dict.size(); ++u) if (dict[u] == d) { code = (int)u; break; }
-                if (code < 0) { if (dict.size() == 256) { ok = false; break; } dict.push_back(d); code = (int)dict.size() - 1; }
+                int code;
+                if (last_code >= 0 && d == last_d) code = last_code;
+                else {
+                    auto it = code_of.find(d);
+                    if (it != code_of.end()) code = it->second;
+                    else {
+                        if (dict.size() == 256) { ok = false; break; }
+                        dict.push_back(d); code = (int)dict.size() - 1; code_of.emplace(d, code);
+                    }
+                    last_d = d; last_code = code;
+                }
                 codes[k] = (uint8_t)code;
             }
         if (ok) {
