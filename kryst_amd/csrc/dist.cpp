@@ -26,7 +26,12 @@ static int32_t rccl_load() {
     if (g_rccl.lib) return KRYST_OK;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
-    for (const char* nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    // KRYST_RCCL_LIB: an alternative library exporting the same nine symbols (the tests' shared-GPU stand-in)
+    if (const char* alt = getenv("KRYST_RCCL_LIB")) {
+        h = dlopen(alt, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { set_error("cannot load KRYST_RCCL_LIB=%s: %s", alt, dlerror()); return KRYST_ERR_RCCL; }
+    }
+    for (const char* nm : names) { if (h) break; h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); }
     if (!h) { set_error("cannot load librccl.so.1: %s", dlerror()); return KRYST_ERR_RCCL; }
 #define SYM(field, name)                                                       \
     *(void**)(&g_rccl.field) = dlsym(h, name);                                 \

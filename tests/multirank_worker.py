@@ -1,0 +1,61 @@
+"""One rank of the shared-GPU multi-rank test (tests/test_gpu_multirank_shim.py): P processes on ONE GPU run the library's
+real distributed code path with tests/shim/librccl_shim.so standing in for RCCL.  Results are written to
+<outdir>/rank<r>.npz; rank 0 compares them with the partition-aware oracle bit for bit."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import kryst_amd as K                      # noqa: E402
+
+
+def main():
+    rank, P, outdir, N = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    kind = sys.argv[5]
+    idfile = os.path.join(outdir, "uid.bin")
+    if rank == 0:
+        uid = K.Context.unique_id()
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(idfile + ".tmp", idfile)
+    else:
+        for _ in range(6000):
+            if os.path.exists(idfile):
+                break
+            time.sleep(0.01)
+        uid = open(idfile, "rb").read()
+    ctx = K.Context(0, rank, P, uid)
+    a = K.CsrMatrix.stencil7(N, kind, ctx=ctx)        # device generator or (KRYST_STENCIL_HOST=1) kryst_csr_create_dist
+    nloc = a.nrows()
+    b = a.spmv(ctx.vec(nloc).fill(1.0))
+    out = {"b": b.to_host(), "nloc": np.array([nloc])}
+    bn = K.norm(b)
+    out["bnorm"] = np.array([bn])
+    assert ctx.all_reduce(float(rank + 1)) == P * (P + 1) / 2
+    pcj = K.Jacobi().setup(a)
+    runs = [("cg", K.CgSolver(1e-9, 300), None), ("pcg", K.PcgSolver(1e-9, 300), pcj),
+            ("bicgstab", K.BiCgStabSolver(1e-9 * bn, 300), None),
+            ("gmres", K.GmresSolver(10, 1e-9, 40).with_preconditioning(K.Preconditioning.Left), pcj)]
+    for name, s, pc in runs:
+        x = ctx.vec(nloc)
+        st = s.solve(a, pc, b, x)
+        out[name + "_x"] = x.to_host()
+        out[name + "_hist"] = np.array(s.residual_history)
+        out[name + "_stats"] = np.array([st.iterations, float(st.converged), st.final_residual])
+    # a stepping session like bench.py's
+    x = ctx.vec(nloc)
+    sess = K.Session("cg", a, None, b, x, tol=0.0, max_iters=25)
+    sess.step(5); sess.step(20)
+    st = sess.end()
+    out["sess_stats"] = np.array([st.iterations, float(st.converged), st.final_residual])
+    out["sess_x"] = x.to_host()
+    ctx.barrier()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+    print(f"RANK_OK {rank}")
+
+
+if __name__ == "__main__":
+    main()

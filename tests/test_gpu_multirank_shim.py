@@ -1,0 +1,63 @@
+"""P ranks on ONE GPU through the library's real multi-rank path (RCCL replaced by tests/shim/librccl_shim.so, which stages
+through shared memory).  Checks, bit for bit against the partition-aware oracle: the row-partitioned operator (device
+generator AND kryst_csr_create_dist with its index-list exchange), halo exchange + interior/boundary SpMV, rank-ordered
+inner products, and the multi-rank termination rule of the run-ahead loop, for CG / PCG / BiCGStab / GMRES."""
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "tests", "shim", "librccl_shim.so")
+
+
+def _build_shim():
+    src = os.path.join(ROOT, "tests", "shim", "rccl_shim.cpp")
+    if not os.path.exists(SHIM) or os.path.getmtime(SHIM) < os.path.getmtime(src):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950", src,
+                        "-o", SHIM, "-I/opt/rocm/include", "-lrt"], check=True, capture_output=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,N,kind,hostgen", [(2, 12, "poisson", "0"), (3, 12, "convdiff", "0"), (2, 10, "aniso", "1"), (4, 16, "poisson", "1")])
+def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
+    from oracle import oracle as O
+    import kryst_amd as K
+    _build_shim()
+    env = dict(os.environ, KRYST_RCCL_LIB=SHIM, KRYST_STENCIL_HOST=hostgen)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), str(r), str(P), str(tmp_path), str(N), kind],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(P)]
+    outs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=600)
+            outs.append(o)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    R = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(P)]
+    T, V, F = K.reduce_spec()
+    offs = K.partition_rows(N ** 3, P, N * N)
+    assert [int(r["nloc"][0]) for r in R] == [int(offs[i + 1] - offs[i]) for i in range(P)]
+    a = O.stencil7(N, kind)
+    b = a.spmv(np.ones(a.nrows))
+    assert np.array_equal(np.concatenate([r["b"] for r in R]), b)                 # halo exchange + SpMV
+    rs = O.Reduce.tiled(T, V, F, part_off=offs)
+    bn = O.norm(b, rs)
+    assert all(float(r["bnorm"][0]) == bn for r in R)                              # rank-ordered dot, same bits on every rank
+    cases = [("cg", "cg", None, dict(tol=1e-9, max_iters=300)), ("pcg", "pcg", O.Pc.jacobi(a), dict(tol=1e-9, max_iters=300)),
+             ("bicgstab", "bicgstab", None, dict(tol=1e-9 * bn, max_iters=300)),
+             ("gmres", "gmres", O.Pc.jacobi(a), dict(tol=1e-9, max_iters=40, restart=10, side=O.SIDE_LEFT))]
+    for name, method, pc, kw in cases:
+        ref = O.solve(method, a, b, pc=pc, rs=rs, **kw)
+        for r in R:
+            st = r[name + "_stats"]
+            assert (int(st[0]), bool(st[1]), float(st[2])) == (ref.iterations, ref.converged, ref.final_residual), (name, st, ref)
+            assert np.array_equal(r[name + "_hist"], ref.history), name
+        assert np.array_equal(np.concatenate([r[name + "_x"] for r in R]), ref.x), name
+    ref = O.solve("cg", a, b, tol=0.0, max_iters=25, rs=rs)
+    assert np.array_equal(np.concatenate([r["sess_x"] for r in R]), ref.x)
+    assert all(int(r["sess_stats"][0]) == 25 for r in R)
