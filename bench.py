@@ -134,7 +134,9 @@ def main():
     if world > 1:
         box = [K.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        ctx = K.Context(local_rank, rank, world, box[0])
+        # KRYST_BENCH_DEVICE: rehearsal of the N > 1 flow on a one-GPU box (all ranks on one device, RCCL stand-in)
+        dev = int(os.environ.get("KRYST_BENCH_DEVICE", local_rank))
+        ctx = K.Context(dev, rank, world, box[0])
     else:
         ctx = K.Context(0)
 
