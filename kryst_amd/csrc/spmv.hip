@@ -1,31 +1,26 @@
 // CSR SpMV for gfx950 -- replaces CsrMatrix::spmv / spmv_parallel (src/matrix/sparse.rs:56-67,103-114).
 //
-// Design (HBM-bound, 0.134 flop/B; MFMA is useless here):
-//  * a workgroup owns one ROW TILE of KR_TILE = 512 consecutive rows (thread t: rows 2t, 2t+1) and streams the
-//    tile's contiguous nnz range through LDS in windows of SPMV_LCAP entries:
-//      phase 1  every lane loads a PAIR of consecutive entries (8 B of col_idx + 16 B of values per lane, fully
-//               coalesced, 4 pairs in flight per lane), gathers x[col] (L1/L2/MALL hits: the stencil's x reuse),
-//               multiplies and writes the products to LDS with one 16-byte ds_write;
-//      phase 2  the row's owner lane sums its LDS segment in ASCENDING column order starting from 0.0 with
-//               separate mul and add -- bit-identical to the reference's per-row loop (sparse.rs:107-113).
-//    Rows longer than a window simply continue their running sum in the next window (still ascending).
-//  * y is written 16 B per lane; optional fused inner products (d.y, y.y) reuse the tile's rows and produce
-//    one partial per tile in the library-wide association order (see ew.h), so CG's (p,Ap) costs no extra pass.
-//  * XCD-aware placement: workgroups that share blockIdx%8 share an XCD (and its 4 MiB L2); each XCD walks its
-//    own contiguous eighth of the tiles so that the x planes a tile needs were fetched by that same L2.
-//  * distributed: interior tiles run while the halo planes travel over xGMI on a second stream; boundary
-//    tiles follow.  Column indices >= nloc address the halo buffer.
+// Design (HBM-bound, 0.134 flop/B; MFMA is useless here), shared by both kernels of this file:
+//  * a workgroup owns one ROW TILE of KR_TILE = 512 consecutive rows (thread t: rows 2t, 2t+1); each of its 4 waves
+//    streams the contiguous nnz range of ITS 128 rows through a private LDS window with coalesced pair loads (16 B of
+//    values + 8 B of column indices -- or 1-byte column codes -- per lane, every load of the window in flight before the
+//    first use, branch-free); the row's owner lane then sums its row in ASCENDING column order starting from 0.0 with
+//    separate mul and add -- bit-identical to the reference's per-row loop (sparse.rs:107-113).  Rows longer than a
+//    window continue their running sum in the next window (still ascending).  Same-wave LDS traffic is ordered by the
+//    hardware, so the main path has NO workgroup barrier.
+//  * y is written 16 B per lane; optional fused inner products (d.y, y.y) reuse the tile's rows and produce one
+//    partial per tile in the library-wide association order (see ew.h), so CG's (p,Ap) costs no extra pass.
+//  * tile -> workgroup map: consecutive tiles round-robin over the 8 XCDs (measured 12 % faster than a contiguous
+//    eighth per XCD: the chip streams one sequential region; x re-fetches are served by the Infinity Cache).
+//  * distributed: interior tiles run while the halo planes travel over xGMI on a second stream; boundary tiles
+//    follow.  Column indices >= nloc address the halo buffer.
+//  spmv_rows_kernel (default): raw values in LDS, x gathered in row order, optional CSR-D8 index compression.
+//  spmv_wave_kernel: x gathered in entry order, products in LDS (plain int32 columns; > 256 distinct offsets).
 #include "csr.h"
 #include "ew.h"
 #include <algorithm>
 #include <unordered_map>
 
-#ifndef SPMV_SLOTS
-#define SPMV_SLOTS 4                        // pair slots per lane per LDS window: window = 2048 entries = 16 KiB
-#endif
-#ifndef SPMV_NT
-#define SPMV_NT 1                           // non-temporal loads for the once-read col_idx / values streams
-#endif
 
 namespace kr {
 
@@ -74,85 +69,8 @@ __device__ __forceinline__ double row_sum(const double* prod, int base, int beg,
     return s;
 }
 
-// LCAP = SLOTS * 2 * KR_T entries per LDS window; every lane owns SLOTS pair slots, all loaded in one batch
-template <int NQ, bool HALO, int SLOTS = SPMV_SLOTS, bool NT = (SPMV_NT != 0), int DIAG = 0>
-__global__ __launch_bounds__(KR_T) void spmv_kernel(const SpmvArgs a) {
-    if (a.done && *a.done) return;
-    constexpr int LCAP = SLOTS * 2 * KR_T;
-    __shared__ __attribute__((aligned(16))) double prod[LCAP];
-    __shared__ double red[(NQ > 0 ? NQ : 1) * (KR_T / 64)];
-    const int t = threadIdx.x;
-    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, per = gridDim.x >> 3;
-    for (int li = slot0; li < a.xcd_chunk; li += per) {
-        // tile -> workgroup map: groups of `a.group` consecutive tiles are dealt round-robin to the 8 XCDs
-        int ti;
-        if (a.swizzle) ti = xcd * a.xcd_chunk + li;
-        else ti = ((li / a.group) * 8 + xcd) * a.group + (li % a.group);
-        if (ti >= a.ntiles) { if (a.swizzle) break; else continue; }
-        const int q = a.tiles ? a.tiles[ti] : ti;
-        const int r0 = q * KR_TILE;
-        const int r1 = min(r0 + KR_TILE, a.nrows);
-        const int row = r0 + 2 * t;
-        const int p0 = a.row_ptr[min(row, r1)];
-        const int p1 = a.row_ptr[min(row + 1, r1)];
-        const int p2 = a.row_ptr[min(row + 2, r1)];
-        const int k0 = a.row_ptr[r0], k1 = a.row_ptr[r1];
-        double s0 = 0.0, s1 = 0.0;
-        for (int base = k0 & ~1; base < k1; base += LCAP) {
-            const int wend = min(base + LCAP, k1);
-            const int npairs = (wend - base + 1) >> 1;
-            // ---- phase 1: coalesced pair loads (8 B of col_idx + 16 B of values per lane), x gather, products to
-            // LDS.  Branch-free: out-of-window slots re-read the window's last pair and store it to their own
-            // (unused) LDS slot, so every load of the batch is in flight before the first use.
-            v2i c[SLOTS]; v2d v[SLOTS]; double xa[SLOTS], xb[SLOTS];
-#pragma unroll
-            for (int j = 0; j < SLOTS; ++j) {
-                const int pi = min(t + j * KR_T, npairs - 1);
-                const int k = base + 2 * pi;
-                c[j] = stream_load<NT>(reinterpret_cast<const v2i*>(a.col + k));
-                v[j] = stream_load<NT>(reinterpret_cast<const v2d*>(a.val + k));
-            }
-#pragma unroll
-            for (int j = 0; j < SLOTS; ++j) {
-                if constexpr (DIAG == 1) { xa[j] = (double)c[j].x; xb[j] = (double)c[j].y; }      // timing only: no gather
-                else { xa[j] = gather<HALO>(a, c[j].x); xb[j] = gather<HALO>(a, c[j].y); }
-            }
-#pragma unroll
-            for (int j = 0; j < SLOTS; ++j)
-                *reinterpret_cast<double2*>(&prod[2 * (t + j * KR_T)]) = make_double2(v[j].x * xa[j], v[j].y * xb[j]);
-            __syncthreads();
-            // ---- phase 2: ascending serial row sums (continuing across windows)
-            if constexpr (DIAG == 2) { s0 = prod[2 * t]; s1 = prod[2 * t + 1]; }                   // timing only: no row sums
-            else {
-                s0 = row_sum(prod, base, max(p0, base), min(p1, wend), s0);
-                s1 = row_sum(prod, base, max(p1, base), min(p2, wend), s1);
-            }
-            __syncthreads();
-        }
-        if (row + 1 < r1) st2(a.y, row, s0, s1);
-        else if (row < r1) a.y[row] = s0;
-        if constexpr (NQ > 0) {
-            double acc[NQ];
-            const d2 d = ld2(a.dvec, row);
-            acc[0] = 0.0;
-            if (row < r1) acc[0] = acc[0] + d.a * s0;
-            if (row + 1 < r1) acc[0] = acc[0] + d.b * s1;
-            if constexpr (NQ > 1) {
-                acc[1] = 0.0;
-                if (row < r1) acc[1] = acc[1] + s0 * s0;
-                if (row + 1 < r1) acc[1] = acc[1] + s1 * s1;
-            }
-            block_reduce<NQ, KR_T / 64>(acc, red);
-            if (t == 0) {
-#pragma unroll
-                for (int k = 0; k < NQ; ++k) a.partials[k * a.pstride + q] = acc[k];
-            }
-        }
-    }
-}
-
-// Wave-independent form: each of the 4 waves streams the nnz range of ITS 128 rows (lane l: rows 2l, 2l+1 of the
-// wave's slice -- the same thread->row map as above) through a private LDS window.  Same-wave LDS traffic is
+// Products-in-LDS form (plain int32 columns): each of the 4 waves streams the nnz range of ITS 128 rows (lane l: rows
+// 2l, 2l+1 of the wave's slice) through a private LDS window, gathering x and storing the PRODUCTS.  Same-wave LDS traffic is
 // ordered by the hardware, so the main path has NO workgroup barrier: waves run their load / gather / LDS / sum
 // phases out of step and hide each other's latency.  Only the optional fused inner product meets at one barrier.
 template <int NQ, bool HALO, int SLOTS, bool NT, int MINW = 1>
@@ -375,31 +293,6 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
     const dim3 grid((unsigned)(per * 8)), block(KR_T);
     args.swizzle = env_int("KRYST_SPMV_SWIZZLE", 0);
     args.group = std::max(1, env_int("KRYST_SPMV_GROUP", 1));
-#ifdef KRYST_TUNING
-    const int variant = env_int("KRYST_SPMV_VARIANT", 0);
-    if (nq == 1 && !HALO && variant > 0) {
-        switch (variant) {
-            case 1: hipLaunchKernelGGL((spmv_kernel<1, false, 2, true>), grid, block, 0, ctx->s_main, args); break;
-            case 2: hipLaunchKernelGGL((spmv_kernel<1, false, 7, true>), grid, block, 0, ctx->s_main, args); break;
-            case 3: hipLaunchKernelGGL((spmv_kernel<1, false, 4, false>), grid, block, 0, ctx->s_main, args); break;
-            case 4: hipLaunchKernelGGL((spmv_kernel<1, false, 3, true>), grid, block, 0, ctx->s_main, args); break;
-            case 5: hipLaunchKernelGGL((spmv_kernel<1, false, 7, false>), grid, block, 0, ctx->s_main, args); break;
-            case 6: hipLaunchKernelGGL((spmv_kernel<1, false, 8, false>), grid, block, 0, ctx->s_main, args); break;
-            case 7: hipLaunchKernelGGL((spmv_kernel<1, false, 7, false, 1>), grid, block, 0, ctx->s_main, args); break;
-            case 8: hipLaunchKernelGGL((spmv_kernel<1, false, 7, false, 2>), grid, block, 0, ctx->s_main, args); break;
-            case 9: hipLaunchKernelGGL((spmv_kernel<0, false, 7, false>), grid, block, 0, ctx->s_main, args); break;
-            case 10: hipLaunchKernelGGL((spmv_wave_kernel<1, false, 7, false>), grid, block, 0, ctx->s_main, args); break;
-            case 11: hipLaunchKernelGGL((spmv_wave_kernel<1, false, 7, true>), grid, block, 0, ctx->s_main, args); break;
-            case 12: hipLaunchKernelGGL((spmv_wave_kernel<1, false, 7, false, 5>), grid, block, 0, ctx->s_main, args); break;
-            case 13: hipLaunchKernelGGL((spmv_wave_kernel<1, false, 4, false>), grid, block, 0, ctx->s_main, args); break;
-            case 14: hipLaunchKernelGGL((spmv_wave_kernel<0, false, 7, false>), grid, block, 0, ctx->s_main, args); break;
-            case 15: hipLaunchKernelGGL((spmv_wave_kernel<1, false, 8, false>), grid, block, 0, ctx->s_main, args); break;
-            default: set_error("unknown KRYST_SPMV_VARIANT"); return KRYST_ERR_ARG;
-        }
-        KR_HIP(hipGetLastError());
-        return KRYST_OK;
-    }
-#endif
     // production path: wave-independent kernel; pair slots per lane sized to the matrix's average slice length
     // (a wave streams the nnz of 128 rows: <= 256 nnz -> 2 slots, <= 512 -> 4, else 7 = a 7-point stencil's 896)
     const int kern = env_int("KRYST_SPMV_KERNEL", 2);          // 2: products-in-LDS wave kernel; 3: rows kernel (+ CSR-D8)

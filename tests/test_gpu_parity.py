@@ -588,3 +588,35 @@ def test_ilut_bit_exact(ctx, rs, fill, droptol):
                   raise_on_error=False)
     s = K.GmresSolver(20, 1e-10, 40); x = np.zeros(a.nrows)
     _check_solver(res, s.solve(dev, K.Ilut(fill, droptol).setup(dev), b, x), s, x)
+
+
+def test_zero_rhs_and_exact_guess_edge_cases(ctx, rs):
+    """b = 0 / x0 already exact: the reference divides by a zero initial residual (NaN comparisons are false) or hits
+    p.Ap = 0 -> Err(IndefiniteMatrix); whatever it does, the device must do the same."""
+    a = O.stencil7(6)
+    d = to_dev(ctx, a)
+    n = a.nrows
+    for b, x0 in ((np.zeros(n), np.zeros(n)), (a.spmv(np.ones(n)), np.ones(n))):
+        for method, cls in (("cg", K.CgSolver), ("pcg", K.PcgSolver), ("bicgstab", K.BiCgStabSolver)):
+            res = O.solve(method, a, b, x0=x0, tol=1e-8, max_iters=20, rs=rs, raise_on_error=False)
+            s = cls(1e-8, 20); x = x0.copy()
+            try:
+                st, code = s.solve(d, None, b, x), 0
+            except K.KError as e:
+                st, code = e.stats, e.code
+            assert code == res.code, (method, code, res.code)
+            assert st.iterations == res.iterations and st.converged == res.converged
+            assert np.array_equal(np.array(s.residual_history), res.history, equal_nan=True)
+            if code == 0:
+                assert np.array_equal(x, res.x, equal_nan=True)
+
+
+def test_max_iters_zero(ctx, rs):
+    a = O.stencil7(5); b = a.spmv(np.ones(a.nrows)); d = to_dev(ctx, a)
+    for method, mk in (("cg", lambda: K.CgSolver(1e-8, 0)), ("pcg", lambda: K.PcgSolver(1e-8, 0)),
+                       ("bicgstab", lambda: K.BiCgStabSolver(1e-8, 0)), ("gmres", lambda: K.GmresSolver(5, 1e-8, 0))):
+        res = O.solve(method, a, b, tol=1e-8, max_iters=0, restart=5, rs=rs)
+        s = mk(); x = np.zeros(a.nrows)
+        st = s.solve(d, None, b, x)
+        assert (st.iterations, st.converged, st.final_residual) == (res.iterations, res.converged, res.final_residual), method
+        assert np.array_equal(x, res.x)
