@@ -8,7 +8,7 @@
 //   trait LinearSolver<M,V>    src/solver/mod.rs:30-52         -> struct LinearSolver<M,V>   (solve(a, pc, b, x) -> SolveStats)
 //   CsrMatrix::from_csr        src/matrix/sparse.rs:28-46      -> HipCsrMatrix::from_csr
 //   Jacobi / Ilu0 / Ilup / Chebyshev / apply_chebyshev          src/preconditioner/*.rs
-//   CgSolver / PcgSolver / GmresSolver / BiCgStabSolver         src/solver/*.rs (new(..), with_norm, with_monitor, ...)
+//   CgSolver / PcgSolver / GmresSolver / FgmresSolver / BiCgStabSolver   src/solver/*.rs (new(..), with_norm, with_monitor, ...)
 //   Convergence, SolveStats    src/utils/convergence.rs:4-14 ;  KError  src/error.rs:6-19 (thrown where Rust returns Err)
 //
 // V is std::vector<double> (the reference's Vec<f64>).  `Result<T, KError>` becomes "return T or throw KError";
@@ -225,6 +225,22 @@ struct GmresSolver : SolverBase {                            // gmres.rs:38-60
     GmresSolver& with_preconditioning(Preconditioning m) { preconditioning = m; side_ = (int)m; return *this; }
 protected:
     int32_t call(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) override { return kryst_gmres_solve(b, x, n, KRYST_FWD); }
+};
+enum class Orthog { Classical = 0, Modified = 1 };           // fgmres.rs:26-31
+struct FgmresSolver : SolverBase {                           // fgmres.rs:33-101; solve_flex :114-340
+    size_t restart; Orthog orthog = Orthog::Classical; double haptol = 1e-12; bool preallocate = false; size_t delta_allocate = 10;
+    FgmresSolver(double tol, size_t max_iters, size_t restart) : SolverBase(tol, max_iters), restart(restart) { restart_ = (int)restart; }
+    FgmresSolver& with_orthog(Orthog o) { orthog = o; return *this; }
+    FgmresSolver& with_preallocate(bool f) { preallocate = f; return *this; }
+    FgmresSolver& with_delta_allocate(size_t d) { delta_allocate = d; return *this; }
+    FgmresSolver& with_haptol(double h) { haptol = h; return *this; }
+    // the FlexiblePreconditioner (preconditioner/mod.rs:16-19) is a device preconditioner object
+    SolveStats<double> solve_flex(const HipCsrMatrix& a, const Preconditioner<HipCsrMatrix, Vec>* pc, const Vec& b, Vec& x) { return solve(a, pc, b, x); }
+    FgmresSolver& with_monitor(std::function<void(size_t, double)> f) { monitor = std::move(f); return *this; }
+protected:
+    int32_t call(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) override {
+        return kryst_fgmres_solve(b, x, n, (int32_t)orthog, haptol, preallocate ? 1 : 0, KRYST_FWD);
+    }
 };
 struct BiCgStabSolver : SolverBase {                         // bicgstab.rs:36-48
     BiCgStabSolver(double tol, size_t max_iters) : SolverBase(tol, max_iters) {}

@@ -23,7 +23,7 @@ from ._ffi import KError, lib, check
 
 __all__ = ["Context", "DeviceVec", "CsrMatrix", "dot", "norm", "Jacobi", "Ilu0", "Ilup", "Ilut", "TrueIlu0", "Chebyshev",
            "ChebyshevPc", "IdentityPc", "apply_chebyshev", "Convergence", "SolveStats", "CgNormType",
-           "Preconditioning", "CgSolver", "PcgSolver", "GmresSolver", "BiCgStabSolver", "BiCgStabRightPcSolver", "Session", "KspContext", "SolverKind", "KError", "reduce_spec",
+           "Preconditioning", "CgSolver", "PcgSolver", "GmresSolver", "FgmresSolver", "Orthog", "BiCgStabSolver", "BiCgStabRightPcSolver", "Session", "KspContext", "SolverKind", "KError", "reduce_spec",
            "host_stencil7", "partition_rows", "halo_recv_plan"]
 
 
@@ -494,7 +494,7 @@ class _Solver:
         pch = pc.h if pc is not None else None
         if pc is not None and pch is None:
             raise KError(2, "preconditioner used before setup")
-        tail = (a.h, pch, C.byref(prm), C.byref(st), _dp(hist), cap, C.byref(hlen), cb, None)
+        tail = self._extra() + (a.h, pch, C.byref(prm), C.byref(st), _dp(hist), cap, C.byref(hlen), cb, None)
         if isinstance(b, DeviceVec):
             rc = getattr(lib(), self._DEV)(b.h, x.h, *tail)
         elif self._HOST is None:                     # extension solvers only exist in device-vector form
@@ -513,6 +513,9 @@ class _Solver:
         stats = SolveStats(st.iterations, st.final_residual, bool(st.converged))
         check(rc, stats)
         return stats
+
+    def _extra(self):
+        return ()
 
     def clear_history(self):
         self.residual_history.clear()
@@ -562,6 +565,48 @@ class GmresSolver(_Solver):
         return self
 
 
+class Orthog(enum.IntEnum):                      # src/solver/fgmres.rs:26-31
+    Classical = 0
+    Modified = 1
+
+
+class FgmresSolver(_Solver):
+    """FgmresSolver::new(tol, max_iters, restart)  src/solver/fgmres.rs:33-101; solve_flex :114-340.  The flexible
+    preconditioner is any device preconditioner object (its action is fixed per apply, which FGMRES permits);
+    `solve` forwards to solve_flex so the solver also fits the LinearSolver call shape used elsewhere."""
+    _HOST, _DEV = "kryst_fgmres_solve", "kryst_fgmres_solve_dev"
+
+    def __init__(self, tol, max_iters, restart):
+        super().__init__(tol, max_iters)
+        self.restart = restart
+        self.orthog = Orthog.Classical
+        self.haptol = 1e-12
+        self.preallocate = False
+        self.delta_allocate = 10                     # accepted, no effect (allocation granularity, fgmres.rs:77-80)
+
+    def _extra(self):
+        return (int(self.orthog), float(self.haptol), int(self.preallocate))
+
+    def with_orthog(self, orthog):
+        self.orthog = orthog
+        return self
+
+    def with_preallocate(self, flag):
+        self.preallocate = flag
+        return self
+
+    def with_delta_allocate(self, delta):
+        self.delta_allocate = delta
+        return self
+
+    def with_haptol(self, haptol):
+        self.haptol = haptol
+        return self
+
+    def solve_flex(self, a, pc, b, x):
+        return self.solve(a, pc, b, x)
+
+
 class BiCgStabSolver(_Solver):
     """BiCgStabSolver::new(tol, max_iters)  src/solver/bicgstab.rs:36-48,69-293 (pc ignored, absolute tolerance)."""
     _HOST, _DEV = "kryst_bicgstab_solve", "kryst_bicgstab_solve_dev"
@@ -578,14 +623,16 @@ class SolverKind(enum.Enum):                      # src/context/ksp_context.rs:2
     GmresLeft = "gmres_left"
     GmresRight = "gmres_right"
     Bicgstab = "bicgstab"
+    Fgmres = "fgmres"
 
 
 class KspContext:
     """KspContext { kind, a, pc, tol, max_it, restart } + solve_context (src/context/ksp_context.rs:54-148): builds a
     fresh solver per call and forwards (a, pc, b, x).  Kinds outside the hot path raise KError(Unsupported)."""
 
-    def __init__(self, kind, a, pc=None, tol=1e-8, max_it=1000, restart=30):
+    def __init__(self, kind, a, pc=None, tol=1e-8, max_it=1000, restart=30, flex_pc=None):
         self.kind, self.a, self.pc, self.tol, self.max_it, self.restart = kind, a, pc, tol, max_it, restart
+        self.flex_pc = flex_pc                      # ksp_context.rs:62: FGMRES uses flex_pc, never pc (:101-107)
 
     def solve_context(self, b, x, comm=None):
         k = self.kind
@@ -599,6 +646,8 @@ class KspContext:
             s = PcgSolver(self.tol, self.max_it)
         elif k == SolverKind.Bicgstab:
             s = BiCgStabSolver(self.tol, self.max_it)
+        elif k == SolverKind.Fgmres:
+            return FgmresSolver(self.tol, self.max_it, self.restart).solve_flex(self.a, self.flex_pc, b, x)
         else:
             raise KError(6, f"solver kind {k} is outside the accelerated path")
         return s.solve(self.a, self.pc, b, x)

@@ -117,6 +117,8 @@ int32_t launch_final_fold(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out
         case 1: hipLaunchKernelGGL(final_fold_kernel<1>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
         case 2: hipLaunchKernelGGL(final_fold_kernel<2>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
         case 3: hipLaunchKernelGGL(final_fold_kernel<3>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
+        case 4: hipLaunchKernelGGL(final_fold_kernel<4>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
+        case 8: hipLaunchKernelGGL(final_fold_kernel<8>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
         default: set_error("final fold: nq=%d", nq); return KRYST_ERR_ARG;
     }
     KR_HIP(hipGetLastError());

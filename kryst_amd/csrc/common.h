@@ -14,7 +14,7 @@
 #define KR_V 2              // elements per thread per tile
 #define KR_TILE (KR_T * KR_V)
 #define KR_F 1024           // threads of the final fold
-#define KR_MAXQ 3           // at most 3 fused reductions per kernel
+#define KR_MAXQ 8           // at most 8 fused reductions per kernel (FGMRES batches its Gram-Schmidt dots by 8)
 
 namespace kr {
 

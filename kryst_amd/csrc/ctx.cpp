@@ -83,16 +83,16 @@ int32_t kryst_ctx_create_dist(int32_t device_id, int32_t rank, int32_t nranks, c
 
 int32_t kryst_ctx_destroy(kryst_ctx_t ctx) {
     if (!ctx) return KRYST_OK;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->s_main);
-    hipStreamSynchronize(ctx->s_comm);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->s_main);
+    (void)hipStreamSynchronize(ctx->s_comm);
     comm_destroy(ctx);
-    hipFree(ctx->d_partials); hipFree(ctx->d_chunks); hipFree(ctx->d_ticket); hipFree(ctx->d_scal); hipFree(ctx->d_gather);
-    hipHostFree((void*)ctx->h_prog); hipHostFree(ctx->h_pinned);
-    hipEventDestroy(ctx->ev_x_ready); hipEventDestroy(ctx->ev_halo_done);
-    hipEventDestroy(ctx->tm0); hipEventDestroy(ctx->tm1);
-    for (auto& e : ctx->ev_ring) hipEventDestroy(e);
-    hipStreamDestroy(ctx->s_main); hipStreamDestroy(ctx->s_comm);
+    (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_chunks); (void)hipFree(ctx->d_ticket); (void)hipFree(ctx->d_scal); (void)hipFree(ctx->d_gather);
+    (void)hipHostFree((void*)ctx->h_prog); (void)hipHostFree(ctx->h_pinned);
+    (void)hipEventDestroy(ctx->ev_x_ready); (void)hipEventDestroy(ctx->ev_halo_done);
+    (void)hipEventDestroy(ctx->tm0); (void)hipEventDestroy(ctx->tm1);
+    for (auto& e : ctx->ev_ring) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->s_main); (void)hipStreamDestroy(ctx->s_comm);
     delete ctx;
     return KRYST_OK;
 }

@@ -628,6 +628,7 @@ int32_t bicgstab_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, bool r
 }
 
 int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io);    // gmres.hip
+int32_t fgmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, int32_t orthog, double haptol, int32_t preallocate);   // fgmres.hip
 
 }  // namespace kr
 
@@ -691,6 +692,13 @@ int32_t kryst_session_end(kryst_session_t s, kryst_stats_t* stats, double* hist,
 int32_t kryst_cg_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return cg_solve(b, x, io); }
 int32_t kryst_pcg_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return pcg_solve(b, x, io); }
 int32_t kryst_gmres_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return gmres_solve(b, x, io); }
+int32_t kryst_fgmres_solve_dev(kryst_vec_t b, kryst_vec_t x, int32_t orthog, double haptol, int32_t preallocate, KRYST_SOLVE_ARGS) {
+    IO_FROM_ARGS; return fgmres_solve(b, x, io, orthog, haptol, preallocate);
+}
+int32_t kryst_fgmres_solve(const double* b, double* x, int64_t n, int32_t orthog, double haptol, int32_t preallocate, KRYST_SOLVE_ARGS) {
+    IO_FROM_ARGS;
+    return host_solve(b, x, n, io, [=](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return fgmres_solve(bv, xv, i, orthog, haptol, preallocate); });
+}
 int32_t kryst_bicgstab_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return bicgstab_solve(b, x, io, false); }
 int32_t kryst_bicgstab_rpc_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return bicgstab_solve(b, x, io, true); }
 

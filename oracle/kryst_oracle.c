@@ -741,6 +741,112 @@ out_noupdate:
 }
 #undef H
 
+/* ------------------------------------------------------------------ FGMRES (fgmres.rs:114-340), as written */
+int32_t kro_fgmres(const kro_csr_t* a, const kro_pc_t* pc, const double* b, double* x,
+                   const kro_params_t* p, int32_t orthog, double haptol, int32_t preallocate,
+                   const kro_reduce_t* rs, kro_stats_t* st, kro_trace_t* tr) {
+    const int64_t n = a->nrows, restart = p->restart, max_iters = p->max_iters;
+    const double tol = p->tol;
+    const int has_pc = pc && pc->kind != KRO_PC_NONE;
+    const int64_t cap = (preallocate ? max_iters : restart) + 1;           /* :144-165 */
+    const int64_t ld = preallocate ? max_iters : restart;
+    double* r = dalloc(n); double* tmp = dalloc(n); double* w = dalloc(n);
+    int32_t rc = KRO_OK;
+    memcpy(r, b, sizeof(double) * (size_t)n);                               /* :134-139 */
+    kro_spmv(a, x, tmp);
+    { PFOR(i, n) r[i] = r[i] - tmp[i]; }
+    double beta = kro_norm(rs, r, n);                                       /* :140 */
+    if (beta == 0.0) {                                                      /* :141-143 */
+        st->iterations = 0; st->final_residual = 0.0; st->converged = 1;
+        free(r); free(tmp); free(w);
+        return KRO_OK;
+    }
+    double** V = (double**)calloc((size_t)cap + 1, sizeof(double*)); double** Z = (double**)calloc((size_t)cap + 1, sizeof(double*));
+    for (int64_t k = 0; k <= cap; ++k) { V[k] = dzeros(n); Z[k] = dzeros(n); }
+    double* h = dzeros((cap + 1) * (ld + 1)); double* cs = dzeros(cap + 1); double* sn = dzeros(cap + 1); double* s = dzeros(cap + 2);
+    double* hcol = dzeros(cap + 2); double* y = dzeros(cap + 1);
+#define H(i, k) h[(i) * (ld + 1) + (k)]
+    s[0] = beta;                                                            /* :166 */
+    { PFOR(i, n) V[0][i] = r[i] / beta; }                                   /* :167-169 */
+    int64_t total_iters = 0;
+    const double res_norm_outer = beta;                                     /* :171 `let res_norm = beta;` (never reassigned) */
+    st->iterations = 0; st->final_residual = res_norm_outer; st->converged = 0;
+    while (total_iters < max_iters) {                                       /* :175 */
+        const int64_t m = preallocate ? (max_iters < restart ? max_iters : restart)
+                                      : (restart < max_iters - total_iters ? restart : max_iters - total_iters);   /* :203 */
+        int converged = 0;
+        int64_t arnoldi_steps = m;
+        for (int64_t j = 0; j < m; ++j) {                                   /* :207 */
+            memcpy(Z[j], V[j], sizeof(double) * (size_t)n);                 /* :209 */
+            if (has_pc) { rc = kro_pc_apply(pc, V[j], Z[j], n); if (rc) goto out; }   /* :210-212 `?` */
+            kro_spmv(a, Z[j], w);                                           /* :214-215 */
+            for (int64_t i = 0; i <= j; ++i) hcol[i] = kro_dot(rs, w, V[i], n);        /* :220-222 / :231-233 */
+            for (int64_t i = 0; i <= j; ++i) { const double hi = hcol[i]; const double* vi = V[i]; PFOR(k, n) w[k] = w[k] - hi * vi[k]; }
+            if (orthog == 1)                                                /* :239-247 refinement (h_col is NOT corrected) */
+                for (int64_t i = 0; i <= j; ++i) {
+                    const double corr = kro_dot(rs, w, V[i], n);
+                    if (fabs(corr) > 1e-10) { const double* vi = V[i]; PFOR(k, n) w[k] = w[k] - corr * vi[k]; }
+                }
+            H(j + 1, j) = kro_norm(rs, w, n);                               /* :250 */
+            for (int64_t i = 0; i <= j; ++i) H(i, j) = hcol[i];             /* :251 */
+            const double hapbnd = haptol * fabs(s[j]);                      /* :253 */
+            const int happy = fabs(H(j + 1, j)) < hapbnd;
+            if (!happy) { const double wn = H(j + 1, j); PFOR(k, n) V[j + 1][k] = w[k] / wn; }   /* :255-258 */
+            else { PFOR(k, n) V[j + 1][k] = 0.0; }                          /* :259-261 */
+            for (int64_t i = 0; i < j; ++i) {                               /* :263-267 */
+                const double temp = cs[i] * H(i, j) + sn[i] * H(i + 1, j);
+                H(i + 1, j) = -sn[i] * H(i, j) + cs[i] * H(i + 1, j);
+                H(i, j) = temp;
+            }
+            const double h1 = H(j, j), h2 = H(j + 1, j);                    /* :269-278 */
+            const double denom = sqrt(h1 * h1 + h2 * h2);
+            double c, s_;
+            if (denom == 0.0) { c = 1.0; s_ = 0.0; } else { c = h1 / denom; s_ = h2 / denom; }
+            cs[j] = c; sn[j] = s_;
+            const double temp = c * s[j] + s_ * s[j + 1];                   /* :281-283 */
+            s[j + 1] = -s_ * s[j] + c * s[j + 1];
+            s[j] = temp;
+            H(j, j) = c * H(j, j) + s_ * H(j + 1, j);                       /* :284-285 */
+            H(j + 1, j) = 0.0;
+            const double res_norm = fabs(s[j + 1]);                         /* :286 */
+            total_iters += 1;
+            trace_push(tr, total_iters, res_norm);                          /* :289-292 */
+            const int stop = conv_check(tol, max_iters, res_norm, s[0], total_iters, st);   /* :293: res0 = the ROTATED s[0] */
+            if (stop) {                                                     /* :295-301 */
+                st->final_residual = res_norm; st->iterations = total_iters;
+                arnoldi_steps = j + 1; converged = 1;
+                break;
+            }
+        }
+        const int64_t k = arnoldi_steps;                                    /* :304-314: no zero-pivot guard */
+        for (int64_t i = k - 1; i >= 0; --i) {
+            double sum = s[i];
+            for (int64_t l = i + 1; l < k; ++l) sum = sum - H(i, l) * y[l];
+            y[i] = sum / H(i, i);
+        }
+        for (int64_t i = 0; i < k; ++i) { const double yi = y[i]; const double* zi = Z[i]; PFOR(q, n) x[q] = x[q] + yi * zi[q]; }   /* :348-353 */
+        memcpy(r, b, sizeof(double) * (size_t)n);                           /* :317-322 */
+        kro_spmv(a, x, tmp);
+        { PFOR(i, n) r[i] = r[i] - tmp[i]; }
+        const double res_true = kro_norm(rs, r, n);
+        if (res_true < tol || converged) {                                  /* :324-329 ABSOLUTE tolerance */
+            st->final_residual = res_true; st->iterations = total_iters; st->converged = 1;
+            break;
+        }
+        beta = res_true;                                                    /* :331-337 */
+        { PFOR(i, n) V[0][i] = r[i] / beta; }
+        for (int64_t q = 0; q <= restart; ++q) s[q] = 0.0;
+        s[0] = beta;
+    }
+    st->final_residual = res_norm_outer;                                    /* :339: the OUTER res_norm == the initial ||r|| */
+    st->iterations = total_iters;                                           /* :340 */
+#undef H
+out:
+    for (int64_t k = 0; k <= cap; ++k) { free(V[k]); free(Z[k]); }
+    free(V); free(Z); free(h); free(cs); free(sn); free(s); free(hcol); free(y); free(r); free(tmp); free(w);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ BiCGStab (bicgstab.rs:69-293) */
 static int32_t bicgstab_impl(const kro_csr_t* a, const kro_pc_t* pc, const double* b, double* x,
                              const kro_params_t* p, const kro_reduce_t* rs, kro_stats_t* st, kro_trace_t* tr,

@@ -144,6 +144,11 @@ int32_t kro_gmres   (const kro_csr_t* a, const kro_pc_t* pc, const double* b, do
                      const kro_params_t* p, const kro_reduce_t* rs, kro_stats_t* st, kro_trace_t* tr);
 int32_t kro_bicgstab(const kro_csr_t* a, const kro_pc_t* pc, const double* b, double* x,
                      const kro_params_t* p, const kro_reduce_t* rs, kro_stats_t* st, kro_trace_t* tr);
+/* FgmresSolver::solve_flex (src/solver/fgmres.rs:114-340): p->restart, p->tol, p->max_iters; orthog 0 Classical (default)
+ * / 1 Modified; haptol (default 1e-12); preallocate (default 0).  pc plays the FlexiblePreconditioner (mod.rs:16-19). */
+int32_t kro_fgmres  (const kro_csr_t* a, const kro_pc_t* pc, const double* b, double* x,
+                     const kro_params_t* p, int32_t orthog, double haptol, int32_t preallocate,
+                     const kro_reduce_t* rs, kro_stats_t* st, kro_trace_t* tr);
 /* extension (not in the reference, which ignores pc at bicgstab.rs:70): right-preconditioned BiCGStab */
 int32_t kro_bicgstab_rpc(const kro_csr_t* a, const kro_pc_t* pc, const double* b, double* x,
                      const kro_params_t* p, const kro_reduce_t* rs, kro_stats_t* st, kro_trace_t* tr);

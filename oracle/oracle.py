@@ -106,6 +106,9 @@ def lib():
             getattr(L, nm).restype = C.c_int32
             getattr(L, nm).argtypes = [C.POINTER(_Csr), C.POINTER(_Pc), _dp, _dp, C.POINTER(_Params),
                                        C.POINTER(_Reduce), C.POINTER(_Stats), C.POINTER(_Trace)]
+        L.kro_fgmres.restype = C.c_int32
+        L.kro_fgmres.argtypes = [C.POINTER(_Csr), C.POINTER(_Pc), _dp, _dp, C.POINTER(_Params), C.c_int32, C.c_double, C.c_int32,
+                                 C.POINTER(_Reduce), C.POINTER(_Stats), C.POINTER(_Trace)]
         L.kro_set_threads.argtypes = [C.c_int32]
         L.kro_get_threads.restype = C.c_int32
         _lib = L
@@ -337,7 +340,7 @@ class Result:
 
 def solve(method, a, b, x0=None, pc=None, tol=1e-8, max_iters=1000, restart=30, side=SIDE_LEFT,
           norm_type=NORM_UNPRECONDITIONED, single_reduction=False, radius=None, obj_target=None,
-          rs=SERIAL, monitor=None, raise_on_error=True):
+          rs=SERIAL, monitor=None, raise_on_error=True, orthog=0, haptol=1e-12, preallocate=False):
     """method in {"cg","pcg","gmres","bicgstab","bicgstab_rpc"}; returns Result (x, stats, residual history)."""
     b = _f64(b)
     x = np.zeros(a.nrows) if x0 is None else _f64(x0).copy()
@@ -350,8 +353,12 @@ def solve(method, a, b, x0=None, pc=None, tol=1e-8, max_iters=1000, restart=30, 
     cb = _MONITOR(lambda it, res, _u: monitor(it, res)) if monitor else _MONITOR()
     tr = _Trace(_d(hist), cap, 0, cb, None)
     fn = getattr(lib(), "kro_" + method)
-    rc = fn(C.byref(a.c), C.byref(pc.c) if pc is not None else None, _d(b), _d(x), C.byref(prm), rs.ref(),
-            C.byref(st), C.byref(tr))
+    if method == "fgmres":
+        rc = fn(C.byref(a.c), C.byref(pc.c) if pc is not None else None, _d(b), _d(x), C.byref(prm), int(orthog), float(haptol),
+                int(preallocate), rs.ref(), C.byref(st), C.byref(tr))
+    else:
+        rc = fn(C.byref(a.c), C.byref(pc.c) if pc is not None else None, _d(b), _d(x), C.byref(prm), rs.ref(),
+                C.byref(st), C.byref(tr))
     res = Result(x, st, hist[:min(tr.len, cap)].copy(), rc)
     if rc and raise_on_error:
         raise KrylovError(rc, res)

@@ -88,6 +88,20 @@ int main() {
         double rn = 0; for (size_t i = 0; i < 4; ++i) rn += (ax[i] - b[i]) * (ax[i] - b[i]);
         REQUIRE(std::sqrt(rn) < 1e-2);                           // gmres.rs:521-527: convergence not asserted
     }
+    {   // src/solver/fgmres.rs:532-552 fgmres_equiv_to_gmres_on_fixed_pc
+        auto a = dense({{2.0, 1.0}, {1.0, 3.0}});
+        const Vec x_true{1.0, 2.0};
+        Vec b(2); a.matvec(x_true, b);
+        Jacobi pc; pc.setup(a);
+        Vec x(2, 0.0);
+        FgmresSolver fg(1e-10, 100, 25);
+        auto st = fg.solve_flex(a, &pc, b, x);
+        REQUIRE(st.converged);
+        for (size_t i = 0; i < 2; ++i) REQUIRE(std::fabs(x[i] - x_true[i]) < 1e-6);
+        Vec xm(2, 0.0);
+        FgmresSolver fm(1e-10, 100, 25); fm.with_orthog(Orthog::Modified).with_haptol(1e-14);
+        REQUIRE(fm.solve_flex(a, nullptr, b, xm).converged && std::fabs(xm[0] - 1.0) < 1e-6 && std::fabs(xm[1] - 2.0) < 1e-6);
+    }
     {   // src/solver/bicgstab.rs:303-328
         std::vector<std::vector<double>> d(3, std::vector<double>(3));
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) d[i][j] = (i == j) ? 4.0 : (double)(i + 2 * j) + 1.0;

@@ -38,7 +38,8 @@ def main():
     pcj = K.Jacobi().setup(a)
     runs = [("cg", K.CgSolver(1e-9, 300), None), ("pcg", K.PcgSolver(1e-9, 300), pcj),
             ("bicgstab", K.BiCgStabSolver(1e-9 * bn, 300), None),
-            ("gmres", K.GmresSolver(10, 1e-9, 40).with_preconditioning(K.Preconditioning.Left), pcj)]
+            ("gmres", K.GmresSolver(10, 1e-9, 40).with_preconditioning(K.Preconditioning.Left), pcj),
+            ("fgmres", K.FgmresSolver(1e-9, 40, 12), pcj)]
     for name, s, pc in runs:
         x = ctx.vec(nloc)
         st = s.solve(a, pc, b, x)

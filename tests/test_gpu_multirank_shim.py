@@ -50,7 +50,8 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     assert all(float(r["bnorm"][0]) == bn for r in R)                              # rank-ordered dot, same bits on every rank
     cases = [("cg", "cg", None, dict(tol=1e-9, max_iters=300)), ("pcg", "pcg", O.Pc.jacobi(a), dict(tol=1e-9, max_iters=300)),
              ("bicgstab", "bicgstab", None, dict(tol=1e-9 * bn, max_iters=300)),
-             ("gmres", "gmres", O.Pc.jacobi(a), dict(tol=1e-9, max_iters=40, restart=10, side=O.SIDE_LEFT))]
+             ("gmres", "gmres", O.Pc.jacobi(a), dict(tol=1e-9, max_iters=40, restart=10, side=O.SIDE_LEFT)),
+             ("fgmres", "fgmres", O.Pc.jacobi(a), dict(tol=1e-9, max_iters=40, restart=12))]
     for name, method, pc, kw in cases:
         ref = O.solve(method, a, b, pc=pc, rs=rs, **kw)
         for r in R:

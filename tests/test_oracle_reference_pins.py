@@ -275,3 +275,15 @@ def test_ilup_dense_as_written_equals_sparse_restatement_at_fill_0():
     t = O.Csr.from_dense(O.tridiag(12, -1.0, 2.0, -1.0), keep_zeros=False)
     x = np.arange(1.0, 13.0)
     assert np.allclose(O.Pc.ilup(t, 1).apply(t.spmv(x)), x, rtol=1e-12)
+
+
+# ---- src/solver/fgmres.rs:537-552 fgmres_equiv_to_gmres_on_fixed_pc
+def test_fgmres_on_fixed_jacobi():
+    a = O.Csr.from_dense([[2.0, 1.0], [1.0, 3.0]])
+    xt = np.array([1.0, 2.0])
+    r = O.solve("fgmres", a, a.spmv(xt), pc=O.Pc.jacobi(a), tol=1e-10, max_iters=100, restart=25)
+    assert r.converged and np.all(np.abs(r.x - xt) < 1e-6)
+    # quirk: final_residual reports the INITIAL residual norm (fgmres.rs:171,339)
+    assert r.final_residual == np.linalg.norm(a.spmv(xt))
+    r0 = O.solve("fgmres", a, np.zeros(2), tol=1e-10, max_iters=100, restart=25)        # beta == 0 early return (:141-143)
+    assert r0.converged and r0.iterations == 0 and r0.final_residual == 0.0
