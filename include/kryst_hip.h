@@ -175,6 +175,13 @@ int32_t kryst_bicgstab_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS)
 /* extension: right-preconditioned BiCGStab (the reference ignores pc, bicgstab.rs:70) */
 int32_t kryst_bicgstab_rpc_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS);
 
+/* CgsSolver::solve (src/solver/cgs.rs:58-135) and TfqmrSolver::solve (src/solver/tfqmr.rs:64-221).  Both ignore pc like the
+ * reference (cgs.rs:59, tfqmr.rs:66); TFQMR also overwrites the initial guess with zeros (tfqmr.rs:72).  History (an
+ * addition): ||r|| per iteration (CGS), the residual estimate dpest per substep, two per iteration (TFQMR). */
+int32_t kryst_cgs_solve      (const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS);
+int32_t kryst_tfqmr_solve    (const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS);
+int32_t kryst_cgs_solve_dev  (kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS);
+int32_t kryst_tfqmr_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS);
 /* FgmresSolver::solve_flex (src/solver/fgmres.rs:114-340); pc plays the FlexiblePreconditioner (preconditioner/mod.rs:16-19),
  * NULL = None.  params: tol, max_iters, restart (fgmres.rs:52-54).  orthog: OrthogMethod 0 Classical (default, :59) /
  * 1 Modified; haptol: happy-breakdown tolerance (default 1e-12, :60); preallocate: set_preallocate_vectors (:77; only
@@ -183,7 +190,7 @@ int32_t kryst_fgmres_solve    (const double* b, double* x, int64_t n, int32_t or
 int32_t kryst_fgmres_solve_dev(kryst_vec_t b, kryst_vec_t x, int32_t orthog, double haptol, int32_t preallocate, KRYST_SOLVE_ARGS);
 
 /* ---- stepping session: the same solver split into begin / step / end, so that a caller (bench.py) can
- * enqueue and time exactly K iterations.  method: 0 CgSolver, 1 PcgSolver, 2 BiCgStabSolver.
+ * enqueue and time exactly K iterations.  method: 0 CgSolver, 1 PcgSolver, 2 BiCgStabSolver, 3 CgsSolver, 4 TfqmrSolver.
  * step() enqueues up to k further iterations (never past max_iters) without synchronising the host. ---- */
 typedef struct kryst_session_s* kryst_session_t;
 int32_t kryst_session_begin(int32_t method, kryst_vec_t b, kryst_vec_t x, kryst_csr_t a, kryst_pc_t pc,

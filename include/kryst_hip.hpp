@@ -8,7 +8,7 @@
 //   trait LinearSolver<M,V>    src/solver/mod.rs:30-52         -> struct LinearSolver<M,V>   (solve(a, pc, b, x) -> SolveStats)
 //   CsrMatrix::from_csr        src/matrix/sparse.rs:28-46      -> HipCsrMatrix::from_csr
 //   Jacobi / Ilu0 / Ilup / Chebyshev / apply_chebyshev          src/preconditioner/*.rs
-//   CgSolver / PcgSolver / GmresSolver / FgmresSolver / BiCgStabSolver   src/solver/*.rs (new(..), with_norm, with_monitor, ...)
+//   CgSolver / PcgSolver / GmresSolver / FgmresSolver / BiCgStabSolver / CgsSolver / TfqmrSolver   src/solver/*.rs (new(..), with_norm, with_monitor, ...)
 //   Convergence, SolveStats    src/utils/convergence.rs:4-14 ;  KError  src/error.rs:6-19 (thrown where Rust returns Err)
 //
 // V is std::vector<double> (the reference's Vec<f64>).  `Result<T, KError>` becomes "return T or throw KError";
@@ -182,7 +182,7 @@ public:
         p.has_radius = radius.has_value(); p.radius = radius.value_or(0.0);
         p.has_obj_target = obj_target.has_value(); p.obj_target = obj_target.value_or(0.0);
         kryst_stats_t st{};
-        std::vector<double> hist(conv.max_iters + (size_t)(restart_ > 0 ? restart_ : 1) + 8);
+        std::vector<double> hist((size_t)hist_per_iter_ * conv.max_iters + (size_t)(restart_ > 0 ? restart_ : 1) + 8);
         int64_t len = 0;
         const int32_t rc = call(b.data(), x.data(), (int64_t)b.size(), a.handle(), pc ? pc->device_handle() : nullptr, &p, &st,
                                 hist.data(), (int64_t)hist.size(), &len, monitor ? &SolverBase::trampoline : nullptr, this);
@@ -194,7 +194,7 @@ public:
 protected:
     SolverBase(double tol, size_t max_iters) : conv{tol, max_iters} {}
     virtual int32_t call(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) = 0;
-    int restart_ = 0, side_ = 1;
+    int restart_ = 0, side_ = 1, hist_per_iter_ = 1;
 private:
     static void trampoline(int64_t it, double res, void* user) { static_cast<SolverBase*>(user)->monitor((size_t)it, res); }
 };
@@ -246,6 +246,16 @@ struct BiCgStabSolver : SolverBase {                         // bicgstab.rs:36-4
     BiCgStabSolver(double tol, size_t max_iters) : SolverBase(tol, max_iters) {}
 protected:
     int32_t call(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) override { return kryst_bicgstab_solve(b, x, n, KRYST_FWD); }
+};
+struct CgsSolver : SolverBase {                              // cgs.rs:21-35
+    CgsSolver(double tol, size_t max_iters) : SolverBase(tol, max_iters) {}
+protected:
+    int32_t call(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) override { return kryst_cgs_solve(b, x, n, KRYST_FWD); }
+};
+struct TfqmrSolver : SolverBase {                            // tfqmr.rs:30-40
+    TfqmrSolver(double tol, size_t max_iters) : SolverBase(tol, max_iters) { hist_per_iter_ = 2; }
+protected:
+    int32_t call(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) override { return kryst_tfqmr_solve(b, x, n, KRYST_FWD); }
 };
 #undef KRYST_FWD
 

@@ -23,7 +23,7 @@ from ._ffi import KError, lib, check
 
 __all__ = ["Context", "DeviceVec", "CsrMatrix", "dot", "norm", "Jacobi", "Ilu0", "Ilup", "Ilut", "TrueIlu0", "Chebyshev",
            "ChebyshevPc", "IdentityPc", "apply_chebyshev", "Convergence", "SolveStats", "CgNormType",
-           "Preconditioning", "CgSolver", "PcgSolver", "GmresSolver", "FgmresSolver", "Orthog", "BiCgStabSolver", "BiCgStabRightPcSolver", "Session", "KspContext", "SolverKind", "KError", "reduce_spec",
+           "Preconditioning", "CgSolver", "PcgSolver", "GmresSolver", "FgmresSolver", "Orthog", "CgsSolver", "TfqmrSolver", "BiCgStabSolver", "BiCgStabRightPcSolver", "Session", "KspContext", "SolverKind", "KError", "reduce_spec",
            "host_stencil7", "partition_rows", "halo_recv_plan"]
 
 
@@ -462,6 +462,7 @@ class Preconditioning(enum.IntEnum):             # src/solver/gmres.rs:28-32
 
 class _Solver:
     _HOST = _DEV = None
+    _HIST_PER_ITER = 1
 
     def __init__(self, tol, max_iters):
         self.conv = Convergence(tol, max_iters)
@@ -487,7 +488,7 @@ class _Solver:
         DeviceVec arguments stay in HBM."""
         prm = self._params()
         st = _ffi.Stats()
-        cap = self.conv.max_iters + max(self.restart, 1) + 8
+        cap = self._HIST_PER_ITER * self.conv.max_iters + max(self.restart, 1) + 8
         hist = np.zeros(cap)
         hlen = C.c_int64(0)
         cb = _ffi.MONITOR(lambda it, res, _u: self.monitor(it, res)) if self.monitor else _ffi.MONITOR()
@@ -612,6 +613,18 @@ class BiCgStabSolver(_Solver):
     _HOST, _DEV = "kryst_bicgstab_solve", "kryst_bicgstab_solve_dev"
 
 
+class CgsSolver(_Solver):
+    """CgsSolver::new(tol, max_iters)  src/solver/cgs.rs:21-35,58-135 (pc ignored, :59)."""
+    _HOST, _DEV = "kryst_cgs_solve", "kryst_cgs_solve_dev"
+
+
+class TfqmrSolver(_Solver):
+    """TfqmrSolver::new(tol, max_iters)  src/solver/tfqmr.rs:30-40,64-221 as written (pc ignored, x starts from zero whatever
+    the caller passes, :72).  residual_history receives the residual estimate of both substeps."""
+    _HOST, _DEV = "kryst_tfqmr_solve", "kryst_tfqmr_solve_dev"
+    _HIST_PER_ITER = 2
+
+
 class BiCgStabRightPcSolver(_Solver):
     """Extension: right-preconditioned BiCGStab (device vectors only)."""
     _HOST, _DEV = None, "kryst_bicgstab_rpc_solve_dev"
@@ -624,6 +637,8 @@ class SolverKind(enum.Enum):                      # src/context/ksp_context.rs:2
     GmresRight = "gmres_right"
     Bicgstab = "bicgstab"
     Fgmres = "fgmres"
+    Cgs = "cgs"
+    Tfqmr = "tfqmr"
 
 
 class KspContext:
@@ -646,6 +661,10 @@ class KspContext:
             s = PcgSolver(self.tol, self.max_it)
         elif k == SolverKind.Bicgstab:
             s = BiCgStabSolver(self.tol, self.max_it)
+        elif k == SolverKind.Cgs:
+            s = CgsSolver(self.tol, self.max_it)
+        elif k == SolverKind.Tfqmr:
+            s = TfqmrSolver(self.tol, self.max_it)
         elif k == SolverKind.Fgmres:
             return FgmresSolver(self.tol, self.max_it, self.restart).solve_flex(self.a, self.flex_pc, b, x)
         else:
@@ -656,7 +675,7 @@ class KspContext:
 class Session:
     """Stepping form of CgSolver / PcgSolver / BiCgStabSolver on device vectors: begin, step(k) (enqueue k
     iterations without synchronising), end() -> SolveStats.  bench.py uses it to time exactly K iterations."""
-    METHODS = {"cg": 0, "pcg": 1, "bicgstab": 2}
+    METHODS = {"cg": 0, "pcg": 1, "bicgstab": 2, "cgs": 3, "tfqmr": 4}
 
     def __init__(self, method, a, pc, b, x, tol, max_iters, norm_type=CgNormType.Unpreconditioned):
         self.a, self.pc, self.b, self.x = a, pc, b, x

@@ -87,6 +87,10 @@ SIGNATURES = {
     "kryst_cg_solve_dev": (C.c_int32, [Handle, Handle] + _SOLVE_TAIL),
     "kryst_pcg_solve_dev": (C.c_int32, [Handle, Handle] + _SOLVE_TAIL),
     "kryst_gmres_solve_dev": (C.c_int32, [Handle, Handle] + _SOLVE_TAIL),
+    "kryst_cgs_solve": (C.c_int32, [c_dp, c_dp, C.c_int64] + _SOLVE_TAIL),
+    "kryst_tfqmr_solve": (C.c_int32, [c_dp, c_dp, C.c_int64] + _SOLVE_TAIL),
+    "kryst_cgs_solve_dev": (C.c_int32, [Handle, Handle] + _SOLVE_TAIL),
+    "kryst_tfqmr_solve_dev": (C.c_int32, [Handle, Handle] + _SOLVE_TAIL),
     "kryst_fgmres_solve": (C.c_int32, [c_dp, c_dp, C.c_int64, C.c_int32, C.c_double, C.c_int32] + _SOLVE_TAIL),
     "kryst_fgmres_solve_dev": (C.c_int32, [Handle, Handle, C.c_int32, C.c_double, C.c_int32] + _SOLVE_TAIL),
     "kryst_bicgstab_solve_dev": (C.c_int32, [Handle, Handle] + _SOLVE_TAIL),

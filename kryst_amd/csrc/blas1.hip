@@ -7,7 +7,7 @@ namespace kr {
 
 // ---------------------------------------------------------------- ops
 struct DotOp {                       // wrappers.rs:90-108: sum of x[i]*y[i]
-    static constexpr int NQ = 1;
+    static constexpr int NQ = 1; static constexpr int BPC = 4;
     const double* x; const double* y;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         const d2 a = ld2(x, i), b = ld2(y, i);
@@ -165,9 +165,9 @@ int32_t kryst_vec_create(kryst_ctx_t ctx, int64_t n, kryst_vec_t* out) {
 
 int32_t kryst_vec_destroy(kryst_vec_t v) {
     if (!v) return KRYST_OK;
-    hipSetDevice(v->ctx->device);
-    hipStreamSynchronize(v->ctx->s_main);
-    hipFree(v->d);
+    (void)hipSetDevice(v->ctx->device);
+    (void)hipStreamSynchronize(v->ctx->s_main);
+    (void)hipFree(v->d);
     delete v;
     return KRYST_OK;
 }

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include "../../include/kryst_hip.h"
 
@@ -116,6 +117,49 @@ __device__ __forceinline__ void block_reduce(double (&v)[NQ], double* lds) {
     __syncthreads();
 }
 
+// Same values as block_reduce for NQ = 2, 4 or 8 quantities with a fifth of the cross-lane traffic: the first log2(NQ)
+// butterfly steps exchange HALF of the quantities each (the lane whose `off` bit is clear keeps the lower half and
+// receives the partner's lower half, the other lane the upper half), so after them every lane carries one quantity;
+// the remaining steps are the plain butterfly.  Each addition is still  own + partner's  at the same offset, i.e.
+// bit-for-bit the additions of wave_butterfly.  Result valid in every thread.
+template <int NQ, int NW>
+__device__ __forceinline__ void block_reduce_pow2(double (&v)[NQ], double* lds) {
+    static_assert(NQ == 2 || NQ == 4 || NQ == 8, "power of two");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int q = 0;                                   // quantity carried in slot 0 once the halving is over
+    int off = 32;
+#pragma unroll
+    for (int h = NQ / 2; h >= 1; h >>= 1, off >>= 1) {
+        const bool up = (lane & off) != 0;
+#pragma unroll
+        for (int i = 0; i < h; ++i) {
+            const double keep = up ? v[i + h] : v[i];
+            const double send = up ? v[i] : v[i + h];
+            v[i] = keep + __shfl_xor(send, off, 64);
+        }
+        if (up) q += h;
+    }
+    double t = v[0];
+    for (; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+    // lanes whose low bits (below the halving bits) are zero publish their quantity
+    constexpr int LOW = 64 / NQ;                 // 32 / 16 / 8 lanes share one quantity
+    if ((lane & (LOW - 1)) == 0) lds[q * NW + wave] = t;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        double s = lds[k * NW];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s = s + lds[k * NW + w];
+        v[k] = s;
+    }
+    __syncthreads();
+}
+template <int NQ, int NW>
+__device__ __forceinline__ void block_reduce_any(double (&v)[NQ], double* lds) {
+    if constexpr (NQ == 2 || NQ == 4 || NQ == 8) block_reduce_pow2<NQ, NW>(v, lds);
+    else block_reduce<NQ, NW>(v, lds);
+}
+
 // Two-level fold of NQ arrays of tile partials (one launch, gridDim.x = nchunks = ceil(ntiles / KR_F) workgroups of
 // KR_F threads):
 //   stage 1  workgroup c folds partials [c*KR_F, (c+1)*KR_F): thread t takes partial c*KR_F + t (0.0 past the end),
@@ -133,7 +177,7 @@ __device__ __forceinline__ bool fold2(const double* partials, int64_t stride, in
     const int64_t i = (int64_t)blockIdx.x * KR_F + threadIdx.x;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) out[q] = (i < ntiles) ? partials[q * stride + i] : 0.0;
-    block_reduce<NQ, KR_F / 64>(out, lds);
+    block_reduce_any<NQ, KR_F / 64>(out, lds);
     if (gridDim.x == 1) return true;
     if (threadIdx.x == 0) {
 #pragma unroll
@@ -152,7 +196,7 @@ __device__ __forceinline__ bool fold2(const double* partials, int64_t stride, in
             acc = acc + __hip_atomic_load(&chunks[q * cstride + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         out[q] = acc;
     }
-    block_reduce<NQ, KR_F / 64>(out, lds);
+    block_reduce_any<NQ, KR_F / 64>(out, lds);
     if (threadIdx.x == 0) *ticket = 0u;            // ready for the next (stream-ordered) fold
     return true;
 }

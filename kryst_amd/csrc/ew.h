@@ -52,6 +52,10 @@ __global__ __launch_bounds__(KR_T) void ew_kernel(Op op, int64_t n, int64_t ntil
     }
 }
 
+// workgroups per CU of the capped grid: 2 for kernels that also write; read-only reductions declare BPC = 4
+template <class Op, class = void> struct ew_bpc { static constexpr int value = 2; };
+template <class Op> struct ew_bpc<Op, std::void_t<decltype(Op::BPC)>> { static constexpr int value = Op::BPC; };
+
 template <class Op>
 inline int32_t launch_ew(kryst_ctx_t ctx, const Op& op, int64_t n, const int* done = nullptr) {
     const int64_t ntiles = ntiles_of(n);
@@ -59,10 +63,12 @@ inline int32_t launch_ew(kryst_ctx_t ctx, const Op& op, int64_t n, const int* do
     if (Op::NQ > 0) KR_TRY(ensure_partials(ctx, ntiles));
     // memory-bound streaming: cap the grid and stride the rest.  Measured on MI355X (tools/stream_test.py, vectors of
     // 1 GiB, interleaved rounds): 2-3 workgroups per CU sustain 5.6-5.8 TB/s on mixed read/write streams, 8 per CU only
-    // 4.7-4.9 TB/s (a narrower moving window keeps DRAM pages open); CG at 512^3: +4 %.
+    // 4.7-4.9 TB/s (a narrower moving window keeps DRAM pages open); CG at 512^3: +4 %.  Pure read streams with a
+    // reduction per tile (dots) are the exception: they need 4 per CU to overlap loads with the butterfly (rocprofv3,
+    // 9 streams of 128 MiB: 420 us at 2 per CU, 250 us at 4).
     int64_t grid = ntiles;
     const char* e_bpc = getenv("KRYST_EW_BLOCKS_PER_CU");        // tuning knob (read per launch)
-    const int bpc = e_bpc ? atoi(e_bpc) : 2;
+    const int bpc = e_bpc ? atoi(e_bpc) : ew_bpc<Op>::value;
     const int64_t cap = (int64_t)ctx->num_cu * bpc;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(ew_kernel<Op>, dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, n, ntiles,

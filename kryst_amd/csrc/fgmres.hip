@@ -123,7 +123,7 @@ __global__ __launch_bounds__(KR_T) void fg_ew_kernel(Op op, int64_t n, int64_t n
         for (int k = 0; k < (NQ > 0 ? NQ : 1); ++k) acc[k] = 0.0;
         op.pair(i, i < n, i + 1 < n, acc);
         if constexpr (NQ > 0) {
-            block_reduce<NQ, KR_T / 64>(acc, lds);
+            block_reduce_any<NQ, KR_T / 64>(acc, lds);
             if (threadIdx.x == 0) {
 #pragma unroll
                 for (int k = 0; k < NQ; ++k) partials[k * pstride + q] = acc[k];
@@ -132,11 +132,11 @@ __global__ __launch_bounds__(KR_T) void fg_ew_kernel(Op op, int64_t n, int64_t n
     }
 }
 template <class Op>
-static int32_t fg_launch(kryst_ctx_t ctx, const Op& op, int64_t n, const DevState* st, const FgState* fs) {
+static int32_t fg_launch(kryst_ctx_t ctx, const Op& op, int64_t n, const DevState* st, const FgState* fs, int bpc = 2) {
     const int64_t nt = ntiles_of(n);
     if (nt == 0) return KRYST_OK;
     KR_TRY(ensure_partials(ctx, nt));
-    const int64_t grid = std::min<int64_t>(nt, (int64_t)ctx->num_cu * 2);
+    const int64_t grid = std::min<int64_t>(nt, (int64_t)ctx->num_cu * bpc);
     hipLaunchKernelGGL((fg_ew_kernel<Op>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, n, nt, ctx->d_partials,
                        ctx->partials_cap, st, fs);
     KR_HIP(hipGetLastError());
@@ -185,7 +185,7 @@ struct FgNormLogic {                 // :250-301 ; red0 = (w,w)
     static constexpr bool RUN_WHEN_DONE = false;
     LogicCtx c; FgPtrs P; int j; double haptol;
     __device__ void run(const double* red) const {
-        FgState* fs = P.fs; DevState* st = c.st;
+        FgState* fs = P.fs;
         if (fs->cyc_stop) return;
         const double hj1 = dsqrt(red[0]);
         HH(j + 1, j) = hj1; fs->hj1 = hj1;                              // :250
@@ -263,7 +263,8 @@ static int32_t dot_batch(kryst_ctx_t ctx, int64_t n, int64_t nt, double* red, co
                          const DevState* st, const double* w, double* const* v, int i0, int cnt) {
     MultiDotOp<NB> op; op.w = w;
     for (int k = 0; k < NB; ++k) op.v[k] = v[i0 + (k < cnt ? k : 0)];
-    KR_TRY(fg_launch(ctx, op, n, st, P.fs));
+    static const int bpc = [] { const char* e = getenv("KRYST_DOT_BLOCKS_PER_CU"); return e ? atoi(e) : 4; }();   // read-only reductions want more waves in flight than the mixed streams
+    KR_TRY(fg_launch(ctx, op, n, st, P.fs, bpc));
     return reduce_then<NB>(ctx, nt, red, FgHcolLogic<NB>{lc, P, i0, cnt});
 }
 template <int NB>

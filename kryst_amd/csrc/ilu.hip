@@ -48,8 +48,8 @@ struct TriFactor {                  // one triangular factor in level order
     std::vector<Band> bands;
     int32_t* d_band_ptr = nullptr; int32_t* d_band_list = nullptr;
     double inflation = 1.0;
-    void free_all() { hipFree(d_ptr); hipFree(d_col); hipFree(d_val); hipFree(d_row); hipFree(d_diag); hipFree(d_lvl_off);
-                      hipFree(d_ecol); hipFree(d_eval); hipFree(d_elen); hipFree(d_band_ptr); hipFree(d_band_list); }
+    void free_all() { (void)hipFree(d_ptr); (void)hipFree(d_col); (void)hipFree(d_val); (void)hipFree(d_row); (void)hipFree(d_diag); (void)hipFree(d_lvl_off);
+                      (void)hipFree(d_ecol); (void)hipFree(d_eval); (void)hipFree(d_elen); (void)hipFree(d_band_ptr); (void)hipFree(d_band_list); }
     EllView view() const { return EllView{d_ecol, d_eval, d_elen, npos}; }
 };
 
@@ -279,7 +279,7 @@ int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done
             if (rc == KRYST_OK && e == hipSuccess && g && hipGraphInstantiate(&D->exec, g, nullptr, nullptr, 0) == hipSuccess) {
                 D->graph = g;
             } else {
-                if (g) hipGraphDestroy(g);
+                if (g) (void)hipGraphDestroy(g);
                 D->exec = nullptr;
                 (void)hipGetLastError();
             }
@@ -292,9 +292,9 @@ int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done
 void ilu_free(kryst_pc_t pc) {
     if (pc->kind != KR_PC_ILU || !pc->d_work) return;
     IluData* D = reinterpret_cast<IluData*>(pc->d_work);
-    if (D->exec) hipGraphExecDestroy(D->exec);
-    if (D->graph) hipGraphDestroy(D->graph);
-    D->L.free_all(); D->U.free_all(); hipFree(D->d_args); hipFree(D->d_y); hipFree(D->d_rL); hipFree(D->d_yU); hipFree(D->d_zU); hipFree(D->d_mapLU);
+    if (D->exec) (void)hipGraphExecDestroy(D->exec);
+    if (D->graph) (void)hipGraphDestroy(D->graph);
+    D->L.free_all(); D->U.free_all(); (void)hipFree(D->d_args); (void)hipFree(D->d_y); (void)hipFree(D->d_rL); (void)hipFree(D->d_yU); (void)hipFree(D->d_zU); (void)hipFree(D->d_mapLU);
     delete D;
     pc->d_work = nullptr;
 }

@@ -187,9 +187,9 @@ int32_t kryst_pc_apply(kryst_pc_t pc, kryst_vec_t r, kryst_vec_t z) {
 
 int32_t kryst_pc_destroy(kryst_pc_t pc) {
     if (!pc) return KRYST_OK;
-    hipSetDevice(pc->ctx->device);
-    hipStreamSynchronize(pc->ctx->s_main);
-    hipFree(pc->d_inv_diag); hipFree(pc->d_v0); hipFree(pc->d_v1); hipFree(pc->d_v2);
+    (void)hipSetDevice(pc->ctx->device);
+    (void)hipStreamSynchronize(pc->ctx->s_main);
+    (void)hipFree(pc->d_inv_diag); (void)hipFree(pc->d_v0); (void)hipFree(pc->d_v1); (void)hipFree(pc->d_v2);
     ilu_free(pc);
     delete pc;
     return KRYST_OK;
@@ -204,8 +204,8 @@ int32_t kryst_apply_chebyshev(kryst_csr_t a, kryst_vec_t r, kryst_vec_t z, doubl
     if (rc == KRYST_OK) rc = alloc_vec(a->ctx, &v1, a->nrows);
     if (rc == KRYST_OK) rc = alloc_vec(a->ctx, &v2, a->nrows);
     if (rc == KRYST_OK) rc = chebyshev_dev(a, r->d, z->d, alpha, beta, m, v0, v1, v2, nullptr);
-    hipStreamSynchronize(a->ctx->s_main);
-    hipFree(v0); hipFree(v1); hipFree(v2);
+    (void)hipStreamSynchronize(a->ctx->s_main);
+    (void)hipFree(v0); (void)hipFree(v1); (void)hipFree(v2);
     return rc;
 }
 

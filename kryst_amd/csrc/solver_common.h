@@ -110,9 +110,9 @@ struct Workspace {
     double* h_hist = nullptr; double* d_hist = nullptr; int64_t hist_cap = 0;
     explicit Workspace(kryst_ctx_t c, int64_t n_) : ctx(c), n(n_) {}
     ~Workspace() {
-        hipStreamSynchronize(ctx->s_main);
-        for (double* p : vecs) hipFree(p);
-        if (h_hist) hipHostFree(h_hist);
+        (void)hipStreamSynchronize(ctx->s_main);
+        for (double* p : vecs) (void)hipFree(p);
+        if (h_hist) (void)hipHostFree(h_hist);
     }
     int32_t vec(double** out) {
         const size_t bytes = sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
@@ -168,7 +168,7 @@ inline int32_t run_ahead(kryst_ctx_t ctx, const kryst_params_t* p, Body body) {
 }
 
 struct DotOneOp {
-    static constexpr int NQ = 1;
+    static constexpr int NQ = 1; static constexpr int BPC = 4;
     const double *a, *b;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         const d2 u = ld2(a, i), v = ld2(b, i);

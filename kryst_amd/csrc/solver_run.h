@@ -1,0 +1,107 @@
+// The begin / iterate / end skeleton every non-restarted solver shares, plus the kernels and logic steps that handle
+// an exit whose last vector update is still pending (`early`).
+#pragma once
+#include "solver_common.h"
+
+namespace kr {
+
+struct ClearEarlyLogic {
+    static constexpr bool RUN_WHEN_DONE = true;
+    LogicCtx c;
+    __device__ void run(const double*) const { c.st->early = 0; }
+};
+// like ew_kernel's gate but keeps running for a pending early exit
+template <class Op>
+__global__ __launch_bounds__(KR_T) void ew_kernel_early(Op op, int64_t n, int64_t ntiles, double* partials,
+                                                        int64_t pstride, const DevState* st) {
+    if (st->done && !st->early) return;
+    constexpr int NQ = Op::NQ;
+    __shared__ double lds[NQ * (KR_T / 64)];
+    for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
+        const int64_t i = q * KR_TILE + (int64_t)threadIdx.x * KR_V;
+        double acc[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) acc[k] = 0.0;
+        op.pair(i, i < n, i + 1 < n, acc);
+        block_reduce<NQ, KR_T / 64>(acc, lds);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) partials[k * pstride + q] = acc[k];
+        }
+    }
+}
+
+template <class Op>
+__global__ __launch_bounds__(KR_T) void ew_kernel_if_early(Op op, int64_t n, int64_t ntiles, const DevState* st) {
+    if (!st->early) return;
+    double dummy[1] = {0.0};
+    for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
+        const int64_t i = q * KR_TILE + (int64_t)threadIdx.x * KR_V;
+        op.pair(i, i < n, i + 1 < n, dummy);
+    }
+}
+
+inline int32_t solve_args_check(const SolveIO& io, kryst_vec_t b, kryst_vec_t x) {
+    KR_ARG(io.a && io.params && b && x, "solve: null argument");
+    KR_ARG(b->ctx == io.a->ctx && x->ctx == io.a->ctx, "solve: context mismatch");
+    KR_ARG(io.a->nrows == io.a->xlen, "solve: square operator required");
+    KR_ARG(b->n == io.a->nrows && x->n == io.a->nrows, "solve: vector length != operator size");
+    KR_ARG(io.params->max_iters >= 0, "solve: max_iters < 0");
+    KR_ARG(!io.pc || io.pc->ctx == io.a->ctx, "solve: preconditioner belongs to another context");
+    KR_ARG(!io.pc || io.pc->n < 0 || io.pc->n == io.a->nrows, "solve: preconditioner size mismatch");
+    return KRYST_OK;
+}
+
+inline void run_monitor(const SolveIO& io, Workspace& ws, int64_t first_iter) {
+    if (!io.monitor) return;
+    DevState h;
+    if (hipMemcpy(&h, ws.st, sizeof(DevState), hipMemcpyDeviceToHost) != hipSuccess) return;
+    for (int64_t k = 0; k < h.hist_len && k < ws.hist_cap; ++k) io.monitor(first_iter + k, ws.h_hist[k], io.user);
+}
+
+// A solve split into begin / iterate / end so that the same code serves the one-shot LinearSolver::solve
+// entry points and the stepping session bench.py uses to time exactly K iterations.
+struct SolverRun {
+    kryst_vec_t bv, xv; SolveIO io; kryst_params_t prm;
+    kryst_csr_t a; kryst_ctx_t ctx; int64_t n, nt;
+    Workspace ws; LogicCtx lc; const int* done = nullptr; double* xw = nullptr;
+    kryst_pc_s pcl; kryst_pc_t pc = nullptr;
+    int64_t next_iter = 1;
+    SolverRun(kryst_vec_t b, kryst_vec_t x, const SolveIO& io_)
+        : bv(b), xv(x), io(io_), prm(*io_.params), a(io_.a), ctx(io_.a->ctx), n(io_.a->nrows), nt(ntiles_of(io_.a->nrows)),
+          ws(io_.a->ctx, io_.a->nrows) { io.params = &prm; }
+    virtual ~SolverRun() {}
+    virtual int32_t begin() = 0;
+    virtual int32_t iterate(int64_t i) = 0;
+    int32_t common_begin(int64_t hist_entries) {
+        KR_HIP(hipSetDevice(ctx->device));
+        if (io.pc) { pcl = *io.pc; if (pcl.n < 0) pcl.n = n; pc = &pcl; }
+        KR_TRY(ws.init(hist_entries));
+        lc = ws.lctx(&prm);
+        done = &ws.st->done;
+        KR_TRY(ws.vec(&xw));
+        KR_HIP(hipMemcpyAsync(xw, xv->d, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));
+        return KRYST_OK;
+    }
+    int32_t step(int64_t k) {                // enqueue k more iterations, no host synchronisation
+        for (int64_t j = 0; j < k && next_iter <= prm.max_iters; ++j, ++next_iter) KR_TRY(iterate(next_iter));
+        return KRYST_OK;
+    }
+    int32_t end() {
+        KR_HIP(hipStreamSynchronize(ctx->s_comm));
+        KR_HIP(hipStreamSynchronize(ctx->s_main));
+        const int32_t status = finish_solve(ws, io);
+        if (status == KRYST_OK)                  // on Err the reference never reaches `*x = ...`
+            KR_HIP(hipMemcpyAsync(xv->d, xw, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));
+        KR_HIP(hipStreamSynchronize(ctx->s_main));
+        run_monitor(io, ws, 0);
+        return status;
+    }
+    int32_t solve() {
+        KR_TRY(begin());
+        KR_TRY(run_ahead(ctx, &prm, [&](int64_t i) -> int32_t { next_iter = i + 1; return iterate(i); }));
+        return end();
+    }
+};
+
+}  // namespace kr

@@ -1,7 +1,7 @@
 // Device-resident CG / PCG / BiCGStab / GMRES(m): LinearSolver::solve (src/solver/mod.rs:30-52) for a HIP CSR
 // operator.  Each solver restates its reference file operation by operation (line numbers cited inline); the
 // vector work is fused into as few HBM passes as the data dependences allow without changing any rounding.
-#include "solver_common.h"
+#include "solver_run.h"
 
 namespace kr {
 
@@ -133,11 +133,6 @@ struct CgRadiusLogic {               // red0 = (p,p), red1 = (x,x)
         }
     }
 };
-struct ClearEarlyLogic {
-    static constexpr bool RUN_WHEN_DONE = true;
-    LogicCtx c;
-    __device__ void run(const double*) const { c.st->early = 0; }
-};
 struct CgRsqLogic {                  // first half of cg.rs:223-229 when the objective exit sits in between
     static constexpr bool RUN_WHEN_DONE = false;
     LogicCtx c;
@@ -192,79 +187,6 @@ struct AxpyIfOp {                    // x += alpha*p, only while st->early is ra
         st2(x, i, xx.a + al * pp.a, xx.b + al * pp.b);
     }
 };
-template <class Op>
-__global__ __launch_bounds__(KR_T) void ew_kernel_if_early(Op op, int64_t n, int64_t ntiles, const DevState* st) {
-    if (!st->early) return;
-    double dummy[1] = {0.0};
-    for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
-        const int64_t i = q * KR_TILE + (int64_t)threadIdx.x * KR_V;
-        op.pair(i, i < n, i + 1 < n, dummy);
-    }
-}
-
-static int32_t solve_args_check(const SolveIO& io, kryst_vec_t b, kryst_vec_t x) {
-    KR_ARG(io.a && io.params && b && x, "solve: null argument");
-    KR_ARG(b->ctx == io.a->ctx && x->ctx == io.a->ctx, "solve: context mismatch");
-    KR_ARG(io.a->nrows == io.a->xlen, "solve: square operator required");
-    KR_ARG(b->n == io.a->nrows && x->n == io.a->nrows, "solve: vector length != operator size");
-    KR_ARG(io.params->max_iters >= 0, "solve: max_iters < 0");
-    KR_ARG(!io.pc || io.pc->ctx == io.a->ctx, "solve: preconditioner belongs to another context");
-    KR_ARG(!io.pc || io.pc->n < 0 || io.pc->n == io.a->nrows, "solve: preconditioner size mismatch");
-    return KRYST_OK;
-}
-
-static void run_monitor(const SolveIO& io, Workspace& ws, int64_t first_iter) {
-    if (!io.monitor) return;
-    DevState h;
-    if (hipMemcpy(&h, ws.st, sizeof(DevState), hipMemcpyDeviceToHost) != hipSuccess) return;
-    for (int64_t k = 0; k < h.hist_len && k < ws.hist_cap; ++k) io.monitor(first_iter + k, ws.h_hist[k], io.user);
-}
-
-// A solve split into begin / iterate / end so that the same code serves the one-shot LinearSolver::solve
-// entry points and the stepping session bench.py uses to time exactly K iterations.
-struct SolverRun {
-    kryst_vec_t bv, xv; SolveIO io; kryst_params_t prm;
-    kryst_csr_t a; kryst_ctx_t ctx; int64_t n, nt;
-    Workspace ws; LogicCtx lc; const int* done = nullptr; double* xw = nullptr;
-    kryst_pc_s pcl; kryst_pc_t pc = nullptr;
-    int64_t next_iter = 1;
-    SolverRun(kryst_vec_t b, kryst_vec_t x, const SolveIO& io_)
-        : bv(b), xv(x), io(io_), prm(*io_.params), a(io_.a), ctx(io_.a->ctx), n(io_.a->nrows), nt(ntiles_of(io_.a->nrows)),
-          ws(io_.a->ctx, io_.a->nrows) { io.params = &prm; }
-    virtual ~SolverRun() {}
-    virtual int32_t begin() = 0;
-    virtual int32_t iterate(int64_t i) = 0;
-    int32_t common_begin(int64_t hist_entries) {
-        KR_HIP(hipSetDevice(ctx->device));
-        if (io.pc) { pcl = *io.pc; if (pcl.n < 0) pcl.n = n; pc = &pcl; }
-        KR_TRY(ws.init(hist_entries));
-        lc = ws.lctx(&prm);
-        done = &ws.st->done;
-        KR_TRY(ws.vec(&xw));
-        KR_HIP(hipMemcpyAsync(xw, xv->d, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));
-        return KRYST_OK;
-    }
-    int32_t step(int64_t k) {                // enqueue k more iterations, no host synchronisation
-        for (int64_t j = 0; j < k && next_iter <= prm.max_iters; ++j, ++next_iter) KR_TRY(iterate(next_iter));
-        return KRYST_OK;
-    }
-    int32_t end() {
-        KR_HIP(hipStreamSynchronize(ctx->s_comm));
-        KR_HIP(hipStreamSynchronize(ctx->s_main));
-        const int32_t status = finish_solve(ws, io);
-        if (status == KRYST_OK)                  // on Err the reference never reaches `*x = ...`
-            KR_HIP(hipMemcpyAsync(xv->d, xw, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));
-        KR_HIP(hipStreamSynchronize(ctx->s_main));
-        run_monitor(io, ws, 0);
-        return status;
-    }
-    int32_t solve() {
-        KR_TRY(begin());
-        KR_TRY(run_ahead(ctx, &prm, [&](int64_t i) -> int32_t { next_iter = i + 1; return iterate(i); }));
-        return end();
-    }
-};
-
 struct CgRun : SolverRun {
     using SolverRun::SolverRun;
     double *r = nullptr, *pp = nullptr, *ap = nullptr, *ax = nullptr;
@@ -490,27 +412,6 @@ struct BicgXROp {
         if (in1) { acc[0] = acc[0] + r1 * r1; acc[1] = acc[1] + hh.b * r1; }
     }
 };
-// like ew_kernel's gate but keeps running for a pending early exit
-template <class Op>
-__global__ __launch_bounds__(KR_T) void ew_kernel_early(Op op, int64_t n, int64_t ntiles, double* partials,
-                                                        int64_t pstride, const DevState* st) {
-    if (st->done && !st->early) return;
-    constexpr int NQ = Op::NQ;
-    __shared__ double lds[NQ * (KR_T / 64)];
-    for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
-        const int64_t i = q * KR_TILE + (int64_t)threadIdx.x * KR_V;
-        double acc[NQ];
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) acc[k] = 0.0;
-        op.pair(i, i < n, i + 1 < n, acc);
-        block_reduce<NQ, KR_T / 64>(acc, lds);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < NQ; ++k) partials[k * pstride + q] = acc[k];
-        }
-    }
-}
-
 struct BicgInitLogic {               // bicgstab.rs:79-102 ; red0 = (r,r) = (rhat,r)
     static constexpr bool RUN_WHEN_DONE = false;
     LogicCtx c;
@@ -628,6 +529,10 @@ int32_t bicgstab_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, bool r
 }
 
 int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io);    // gmres.hip
+int32_t cgs_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io);      // cgs_tfqmr.hip
+int32_t tfqmr_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io);
+SolverRun* make_cgs_run(kryst_vec_t b, kryst_vec_t x, const SolveIO& io);
+SolverRun* make_tfqmr_run(kryst_vec_t b, kryst_vec_t x, const SolveIO& io);
 int32_t fgmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, int32_t orthog, double haptol, int32_t preallocate);   // fgmres.hip
 
 }  // namespace kr
@@ -667,6 +572,8 @@ int32_t kryst_session_begin(int32_t method, kryst_vec_t b, kryst_vec_t x, kryst_
         case 0: run = new CgRun(b, x, io); break;
         case 1: run = new PcgRun(b, x, io); break;
         case 2: run = new BicgRun(b, x, io, false); break;
+        case 3: run = make_cgs_run(b, x, io); break;
+        case 4: run = make_tfqmr_run(b, x, io); break;
         default: set_error("session_begin: unknown method %d", method); return KRYST_ERR_ARG;
     }
     const int32_t rc = run->begin();
@@ -692,6 +599,14 @@ int32_t kryst_session_end(kryst_session_t s, kryst_stats_t* stats, double* hist,
 int32_t kryst_cg_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return cg_solve(b, x, io); }
 int32_t kryst_pcg_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return pcg_solve(b, x, io); }
 int32_t kryst_gmres_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return gmres_solve(b, x, io); }
+int32_t kryst_cgs_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return cgs_solve(b, x, io); }
+int32_t kryst_tfqmr_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return tfqmr_solve(b, x, io); }
+int32_t kryst_cgs_solve(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) {
+    IO_FROM_ARGS; return host_solve(b, x, n, io, [](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return cgs_solve(bv, xv, i); });
+}
+int32_t kryst_tfqmr_solve(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) {
+    IO_FROM_ARGS; return host_solve(b, x, n, io, [](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return tfqmr_solve(bv, xv, i); });
+}
 int32_t kryst_fgmres_solve_dev(kryst_vec_t b, kryst_vec_t x, int32_t orthog, double haptol, int32_t preallocate, KRYST_SOLVE_ARGS) {
     IO_FROM_ARGS; return fgmres_solve(b, x, io, orthog, haptol, preallocate);
 }

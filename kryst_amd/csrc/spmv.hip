@@ -533,7 +533,7 @@ int32_t kryst_csr_create_dist(kryst_ctx_t ctx, int64_t n_global, const int64_t* 
         std::vector<int64_t> ans((size_t)pl.total_send);
         if (pl.total_send) KR_HIP(hipMemcpyAsync(ans.data(), d_ans, sizeof(int64_t) * pl.total_send, hipMemcpyDeviceToHost, ctx->s_main));
         KR_HIP(hipStreamSynchronize(ctx->s_main));
-        hipFree(d_cnt_s); hipFree(d_cnt_r); hipFree(d_req); hipFree(d_ans);
+        (void)hipFree(d_cnt_s); (void)hipFree(d_cnt_r); (void)hipFree(d_req); (void)hipFree(d_ans);
         std::vector<int32_t> sidx((size_t)pl.total_send);
         bool contig = true;
         for (int p = 0; p < P; ++p)
@@ -635,12 +635,12 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
             for (int u = 0; u < 7; ++u) dict[u] = offs7[u];
             dict[7] = (int32_t)nloc;                                   // lower halo slot - local row
             dict[8] = (int32_t)((has_lower ? N2 : 0) + N2);            // upper halo slot - local row
-            hipMemcpyAsync(a->d_dict, dict, sizeof dict, hipMemcpyHostToDevice, ctx->s_main);
-            hipStreamSynchronize(ctx->s_main);
-            hipMemsetAsync(a->d_code + nnz, 0, 32, ctx->s_main);
+            (void)hipMemcpyAsync(a->d_dict, dict, sizeof dict, hipMemcpyHostToDevice, ctx->s_main);
+            (void)hipStreamSynchronize(ctx->s_main);
+            (void)hipMemsetAsync(a->d_code + nnz, 0, 32, ctx->s_main);
         }
-        hipMemsetAsync(a->d_col + nnz, 0, sizeof(int32_t) * 8, ctx->s_main);
-        hipMemsetAsync(a->d_val + nnz, 0, sizeof(double) * 8, ctx->s_main);
+        (void)hipMemsetAsync(a->d_col + nnz, 0, sizeof(int32_t) * 8, ctx->s_main);
+        (void)hipMemsetAsync(a->d_val + nnz, 0, sizeof(double) * 8, ctx->s_main);
         const int64_t nthreads = nloc + 1;
         hipLaunchKernelGGL(stencil7_gen_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->s_main, N, lo, hi,
                            has_lower ? N2 : 0, sc, a->d_row_ptr, a->d_col, a->d_val, a->d_code);
@@ -668,9 +668,9 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
         if (hipMalloc(&a->d_tiles_interior, sizeof(int32_t) * (ti.size() + 1)) != hipSuccess ||
             hipMalloc(&a->d_tiles_boundary, sizeof(int32_t) * (tb.size() + 1)) != hipSuccess ||
             hipMalloc(&pl.d_halo, sizeof(double) * (size_t)(pl.total_recv + 2)) != hipSuccess) { set_error("hipMalloc failed (halo)"); rc = KRYST_ERR_HIP; break; }
-        if (!ti.empty()) hipMemcpyAsync(a->d_tiles_interior, ti.data(), sizeof(int32_t) * ti.size(), hipMemcpyHostToDevice, ctx->s_main);
-        if (!tb.empty()) hipMemcpyAsync(a->d_tiles_boundary, tb.data(), sizeof(int32_t) * tb.size(), hipMemcpyHostToDevice, ctx->s_main);
-        hipMemsetAsync(pl.d_halo, 0, sizeof(double) * (size_t)(pl.total_recv + 2), ctx->s_main);
+        if (!ti.empty()) (void)hipMemcpyAsync(a->d_tiles_interior, ti.data(), sizeof(int32_t) * ti.size(), hipMemcpyHostToDevice, ctx->s_main);
+        if (!tb.empty()) (void)hipMemcpyAsync(a->d_tiles_boundary, tb.data(), sizeof(int32_t) * tb.size(), hipMemcpyHostToDevice, ctx->s_main);
+        (void)hipMemsetAsync(pl.d_halo, 0, sizeof(double) * (size_t)(pl.total_recv + 2), ctx->s_main);
         if (hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("halo setup failed"); rc = KRYST_ERR_HIP; }
     } while (0);
     if (rc != KRYST_OK) { kryst_csr_destroy(a); return rc; }
@@ -705,12 +705,12 @@ int32_t kryst_csr_create_stencil7(kryst_ctx_t ctx, int32_t N, int32_t kind, krys
 
 int32_t kryst_csr_destroy(kryst_csr_t a) {
     if (!a) return KRYST_OK;
-    hipSetDevice(a->ctx->device);
-    hipStreamSynchronize(a->ctx->s_main);
-    hipStreamSynchronize(a->ctx->s_comm);
-    hipFree(a->d_row_ptr); hipFree(a->d_col); hipFree(a->d_val); hipFree(a->d_code); hipFree(a->d_dict);
-    hipFree(a->d_tiles_interior); hipFree(a->d_tiles_boundary);
-    hipFree(a->plan.d_send_idx); hipFree(a->plan.d_sendbuf); hipFree(a->plan.d_halo);
+    (void)hipSetDevice(a->ctx->device);
+    (void)hipStreamSynchronize(a->ctx->s_main);
+    (void)hipStreamSynchronize(a->ctx->s_comm);
+    (void)hipFree(a->d_row_ptr); (void)hipFree(a->d_col); (void)hipFree(a->d_val); (void)hipFree(a->d_code); (void)hipFree(a->d_dict);
+    (void)hipFree(a->d_tiles_interior); (void)hipFree(a->d_tiles_boundary);
+    (void)hipFree(a->plan.d_send_idx); (void)hipFree(a->plan.d_sendbuf); (void)hipFree(a->plan.d_halo);
     delete a;
     return KRYST_OK;
 }

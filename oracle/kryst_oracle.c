@@ -741,6 +741,132 @@ out_noupdate:
 }
 #undef H
 
+/* ------------------------------------------------------------------ CGS (cgs.rs:58-135), as written */
+int32_t kro_cgs(const kro_csr_t* a, const kro_pc_t* pc, const double* b, double* x,
+                const kro_params_t* p, const kro_reduce_t* rs, kro_stats_t* st, kro_trace_t* tr) {
+    (void)pc;                                                               /* :59 */
+    const int64_t n = a->nrows;
+    double* xk = dalloc(n); double* r = dalloc(n); double* rt = dalloc(n); double* pp = dalloc(n);
+    double* q = dzeros(n); double* u = dzeros(n); double* v = dalloc(n); double* upq = dalloc(n); double* w = dalloc(n);
+    memcpy(xk, x, sizeof(double) * (size_t)n);                              /* :61 */
+    kro_spmv(a, xk, v);                                                     /* :64-69 */
+    { PFOR(i, n) r[i] = b[i] - v[i]; }
+    memcpy(rt, r, sizeof(double) * (size_t)n);                              /* :70 */
+    memcpy(pp, r, sizeof(double) * (size_t)n);                              /* :71 */
+    double rho = kro_dot(rs, rt, r, n);                                     /* :74 */
+    double rho_old = 0.0;
+    const double res0 = kro_norm(rs, r, n);                                 /* :76 */
+    st->iterations = 0; st->final_residual = res0; st->converged = 0;       /* :77 */
+    for (int64_t i = 1; i <= p->max_iters; ++i) {
+        if (fabs(rho) < DBL_EPSILON) break;                                 /* :80-82 */
+        if (i == 1) {                                                       /* :83-86 */
+            memcpy(u, r, sizeof(double) * (size_t)n);
+            memcpy(pp, u, sizeof(double) * (size_t)n);
+        } else {                                                            /* :87-99 */
+            const double beta = rho / rho_old;
+            PFOR(k, n) {
+                const double qo = q[k], po = pp[k];
+                u[k] = r[k] + beta * qo;
+                pp[k] = u[k] + beta * (qo + beta * po);
+            }
+        }
+        kro_spmv(a, pp, v);                                                 /* :101-103 */
+        const double alpha = rho / kro_dot(rs, rt, v, n);                   /* :105 */
+        { PFOR(k, n) q[k] = u[k] - alpha * v[k]; }                          /* :107-109 */
+        { PFOR(k, n) xk[k] += alpha * (u[k] + q[k]); }                      /* :111-113 */
+        { PFOR(k, n) upq[k] = u[k] + q[k]; }                                /* :115-118 */
+        kro_spmv(a, upq, w);                                                /* :119-120 */
+        { PFOR(k, n) r[k] = r[k] - alpha * w[k]; }                          /* :121-123 */
+        const double res_norm = kro_norm(rs, r, n);                         /* :124 */
+        trace_push(tr, i, res_norm);
+        const int stop = conv_check(p->tol, p->max_iters, res_norm, res0, i, st);   /* :126-127 */
+        if (stop && st->converged) break;                                   /* :128-131 */
+        rho_old = rho;                                                      /* :132-133 */
+        rho = kro_dot(rs, rt, r, n);
+    }
+    memcpy(x, xk, sizeof(double) * (size_t)n);                              /* :129 / :135 */
+    free(xk); free(r); free(rt); free(pp); free(q); free(u); free(v); free(upq); free(w);
+    return KRO_OK;
+}
+
+/* ------------------------------------------------------------------ TFQMR (tfqmr.rs:64-221), as written */
+int32_t kro_tfqmr(const kro_csr_t* a, const kro_pc_t* pc, const double* b, double* x,
+                  const kro_params_t* p, const kro_reduce_t* rs, kro_stats_t* st, kro_trace_t* tr) {
+    (void)pc;
+    const int64_t n = a->nrows;
+    for (int64_t i = 0; i < n; ++i) x[i] = 0.0;                             /* :72 the initial guess is discarded */
+    double* r = dalloc(n); double* rt = dalloc(n);
+    memcpy(r, b, sizeof(double) * (size_t)n);                               /* :75 */
+    memcpy(rt, r, sizeof(double) * (size_t)n);                              /* :77 */
+    double rho = kro_dot(rs, r, rt, n);                                     /* :80 */
+    if (rho == 0.0) {                                                       /* :81-83 */
+        st->iterations = 0; st->final_residual = kro_norm(rs, r, n); st->converged = 1;
+        free(r); free(rt);
+        return KRO_OK;
+    }
+    double* v = dalloc(n); double* w = dalloc(n); double* y = dalloc(n); double* u = dzeros(n); double* d = dzeros(n);
+    double* q = dalloc(n); double* t = dalloc(n); double* au = dalloc(n);
+    memcpy(w, r, sizeof(double) * (size_t)n); memcpy(y, r, sizeof(double) * (size_t)n);   /* :94-95 */
+    double psi_old = 0.0, eta_old = 0.0;
+    const double tau = kro_norm(rs, r, n);                                  /* :100 */
+    const double res0 = tau;
+    st->iterations = 0; st->final_residual = res0; st->converged = 0;       /* :102 */
+    int returned = 0;
+    if (tau == 0.0) { st->final_residual = 0.0; st->converged = 1; returned = 1; }   /* :103-105 */
+    double dpold = tau;                                                     /* :107 */
+    for (int64_t k = 1; !returned && k <= p->max_iters; ++k) {
+        kro_spmv(a, y, v);                                                  /* :110-112 */
+        const double sigma = kro_dot(rs, rt, v, n);                         /* :115 */
+        if (sigma == 0.0 || !isfinite(sigma)) {                             /* :116-121 */
+            st->final_residual = kro_norm(rs, r, n); st->iterations = k; st->converged = 0; returned = 1; break;
+        }
+        const double alpha = rho / sigma;                                   /* :122 */
+        if (alpha == 0.0 || !isfinite(alpha)) {                             /* :123-128 */
+            st->final_residual = kro_norm(rs, r, n); st->iterations = k; st->converged = 0; returned = 1; break;
+        }
+        { PFOR(i, n) u[i] = r[i] - alpha * v[i]; }                          /* :131-133 */
+        { PFOR(i, n) q[i] = u[i] - alpha * v[i]; }                          /* :136-139 */
+        { PFOR(i, n) t[i] = u[i] + q[i]; }                                  /* :142-145 */
+        kro_spmv(a, t, au);                                                 /* :146-147 */
+        { PFOR(i, n) r[i] = r[i] - alpha * au[i]; }                         /* :149-151 */
+        const double dp = kro_norm(rs, r, n);                               /* :152 */
+        const double tau_m0 = sqrt(dp * dpold);                             /* :153 */
+        double tau_local = tau_m0;
+        for (int m = 0; m < 2; ++m) {                                       /* :156 */
+            const double norm_u_m = (m == 0) ? dp : kro_norm(rs, q, n);     /* :157-161 */
+            const double tau_for_m = (m == 0) ? tau_m0 : tau_local;
+            const double* u_m = (m == 0) ? u : q;                           /* :162 */
+            const double psi = norm_u_m / tau_for_m;                        /* :165 */
+            const double c_m = 1.0 / sqrt(1.0 + psi * psi);                 /* :166 */
+            const double eta = c_m * c_m * alpha;                           /* :167 */
+            const double cf = (alpha == 0.0 || k == 1) ? 0.0 : psi_old * psi_old * eta_old / alpha;   /* :170-174 */
+            { PFOR(i, n) d[i] = u_m[i] + cf * d[i]; }                       /* :175-177 */
+            { PFOR(i, n) x[i] = x[i] + eta * d[i]; }                        /* :180-182 */
+            const double dpest = sqrt((double)(2 * k + m + 2)) * tau_for_m; /* :185 */
+            trace_push(tr, k, dpest);
+            const int stop = conv_check(p->tol, p->max_iters, dpest, res0, k, st);   /* :186-187 */
+            psi_old = psi; eta_old = eta;                                   /* :188-189 */
+            tau_local = tau_for_m * psi * c_m;                              /* :190 */
+            if (stop) {                                                     /* :191-196 */
+                st->final_residual = dpest; st->iterations = k; st->converged = 1; returned = 1; break;
+            }
+        }
+        if (returned) break;
+        memcpy(r, u, sizeof(double) * (size_t)n);                           /* :203 */
+        const double rho_new = kro_dot(rs, rt, r, n);                       /* :204 */
+        const double beta = rho_new / rho;                                  /* :205 */
+        rho = rho_new;
+        PFOR(i, n) {                                                        /* :208-211 */
+            w[i] = u[i] + beta * (q[i] + beta * w[i]);
+            y[i] = u[i] + beta * (q[i] + beta * y[i]);
+        }
+        dpold = dp;                                                         /* :212 */
+    }
+    if (!returned) { st->final_residual = kro_norm(rs, r, n); st->iterations = p->max_iters; }   /* :215-217 */
+    free(r); free(rt); free(v); free(w); free(y); free(u); free(d); free(q); free(t); free(au);
+    return KRO_OK;
+}
+
 /* ------------------------------------------------------------------ FGMRES (fgmres.rs:114-340), as written */
 int32_t kro_fgmres(const kro_csr_t* a, const kro_pc_t* pc, const double* b, double* x,
                    const kro_params_t* p, int32_t orthog, double haptol, int32_t preallocate,

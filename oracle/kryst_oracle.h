@@ -144,6 +144,14 @@ int32_t kro_gmres   (const kro_csr_t* a, const kro_pc_t* pc, const double* b, do
                      const kro_params_t* p, const kro_reduce_t* rs, kro_stats_t* st, kro_trace_t* tr);
 int32_t kro_bicgstab(const kro_csr_t* a, const kro_pc_t* pc, const double* b, double* x,
                      const kro_params_t* p, const kro_reduce_t* rs, kro_stats_t* st, kro_trace_t* tr);
+/* CgsSolver::solve (src/solver/cgs.rs:58-135; pc ignored :59) and TfqmrSolver::solve (src/solver/tfqmr.rs:64-221; pc ignored,
+ * the initial guess is overwritten with zeros :72).  The reference keeps no history; the trace receives ||r|| per
+ * iteration (CGS) and the residual estimate dpest per substep (TFQMR).  TFQMR has no enabled known-answer test in the
+ * reference (its only test is #[ignore], tfqmr.rs:241): parity for it rests on the literal restatement. */
+int32_t kro_cgs     (const kro_csr_t* a, const kro_pc_t* pc, const double* b, double* x,
+                     const kro_params_t* p, const kro_reduce_t* rs, kro_stats_t* st, kro_trace_t* tr);
+int32_t kro_tfqmr   (const kro_csr_t* a, const kro_pc_t* pc, const double* b, double* x,
+                     const kro_params_t* p, const kro_reduce_t* rs, kro_stats_t* st, kro_trace_t* tr);
 /* FgmresSolver::solve_flex (src/solver/fgmres.rs:114-340): p->restart, p->tol, p->max_iters; orthog 0 Classical (default)
  * / 1 Modified; haptol (default 1e-12); preallocate (default 0).  pc plays the FlexiblePreconditioner (mod.rs:16-19). */
 int32_t kro_fgmres  (const kro_csr_t* a, const kro_pc_t* pc, const double* b, double* x,

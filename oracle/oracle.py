@@ -106,6 +106,10 @@ def lib():
             getattr(L, nm).restype = C.c_int32
             getattr(L, nm).argtypes = [C.POINTER(_Csr), C.POINTER(_Pc), _dp, _dp, C.POINTER(_Params),
                                        C.POINTER(_Reduce), C.POINTER(_Stats), C.POINTER(_Trace)]
+        for nm in ("kro_cgs", "kro_tfqmr"):
+            getattr(L, nm).restype = C.c_int32
+            getattr(L, nm).argtypes = [C.POINTER(_Csr), C.POINTER(_Pc), _dp, _dp, C.POINTER(_Params), C.POINTER(_Reduce),
+                                       C.POINTER(_Stats), C.POINTER(_Trace)]
         L.kro_fgmres.restype = C.c_int32
         L.kro_fgmres.argtypes = [C.POINTER(_Csr), C.POINTER(_Pc), _dp, _dp, C.POINTER(_Params), C.c_int32, C.c_double, C.c_int32,
                                  C.POINTER(_Reduce), C.POINTER(_Stats), C.POINTER(_Trace)]
@@ -348,7 +352,7 @@ def solve(method, a, b, x0=None, pc=None, tol=1e-8, max_iters=1000, restart=30, 
                   int(radius is not None), 0.0 if radius is None else radius,
                   int(obj_target is not None), 0.0 if obj_target is None else obj_target)
     st = _Stats()
-    cap = max_iters + restart + 8
+    cap = (2 if method == "tfqmr" else 1) * max_iters + restart + 8
     hist = np.zeros(cap)
     cb = _MONITOR(lambda it, res, _u: monitor(it, res)) if monitor else _MONITOR()
     tr = _Trace(_d(hist), cap, 0, cb, None)

@@ -102,6 +102,19 @@ int main() {
         FgmresSolver fm(1e-10, 100, 25); fm.with_orthog(Orthog::Modified).with_haptol(1e-14);
         REQUIRE(fm.solve_flex(a, nullptr, b, xm).converged && std::fabs(xm[0] - 1.0) < 1e-6 && std::fabs(xm[1] - 2.0) < 1e-6);
     }
+    {   // src/solver/cgs.rs:155-188 cgs_solves_large_well_conditioned_nonsym
+        auto a = dense({{10, 2, 0, 0, 0}, {3, 15, 4, 0, 0}, {0, -2, 8, 1, 0}, {0, 0, 1, 7, 3}, {0, 0, 0, 2, 12}});
+        const Vec x_true{1.0, 2.0, 3.0, 4.0, 5.0};
+        Vec b(5); a.matvec(x_true, b);
+        Vec x(5, 0.0);
+        CgsSolver cgs(1e-10, 200);
+        REQUIRE(cgs.solve(a, nullptr, b, x).converged);
+        for (size_t i = 0; i < 5; ++i) REQUIRE(std::fabs(x[i] - x_true[i]) <= 1e-6);
+        TfqmrSolver tf(1e-10, 3);                                // tfqmr.rs:241 is #[ignore]: only the call shape is exercised
+        Vec xt(5, 7.0);
+        auto st = tf.solve(a, nullptr, b, xt);
+        REQUIRE(st.iterations == 3 && tf.residual_history.size() == 5);
+    }
     {   // src/solver/bicgstab.rs:303-328
         std::vector<std::vector<double>> d(3, std::vector<double>(3));
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) d[i][j] = (i == j) ? 4.0 : (double)(i + 2 * j) + 1.0;

@@ -39,7 +39,8 @@ def main():
     runs = [("cg", K.CgSolver(1e-9, 300), None), ("pcg", K.PcgSolver(1e-9, 300), pcj),
             ("bicgstab", K.BiCgStabSolver(1e-9 * bn, 300), None),
             ("gmres", K.GmresSolver(10, 1e-9, 40).with_preconditioning(K.Preconditioning.Left), pcj),
-            ("fgmres", K.FgmresSolver(1e-9, 40, 12), pcj)]
+            ("fgmres", K.FgmresSolver(1e-9, 40, 12), pcj), ("cgs", K.CgsSolver(1e-9, 60), None),
+            ("tfqmr", K.TfqmrSolver(1e-9, 30), None)]
     for name, s, pc in runs:
         x = ctx.vec(nloc)
         st = s.solve(a, pc, b, x)

@@ -51,7 +51,8 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     cases = [("cg", "cg", None, dict(tol=1e-9, max_iters=300)), ("pcg", "pcg", O.Pc.jacobi(a), dict(tol=1e-9, max_iters=300)),
              ("bicgstab", "bicgstab", None, dict(tol=1e-9 * bn, max_iters=300)),
              ("gmres", "gmres", O.Pc.jacobi(a), dict(tol=1e-9, max_iters=40, restart=10, side=O.SIDE_LEFT)),
-             ("fgmres", "fgmres", O.Pc.jacobi(a), dict(tol=1e-9, max_iters=40, restart=12))]
+             ("fgmres", "fgmres", O.Pc.jacobi(a), dict(tol=1e-9, max_iters=40, restart=12)),
+             ("cgs", "cgs", None, dict(tol=1e-9, max_iters=60)), ("tfqmr", "tfqmr", None, dict(tol=1e-9, max_iters=30))]
     for name, method, pc, kw in cases:
         ref = O.solve(method, a, b, pc=pc, rs=rs, **kw)
         for r in R:

@@ -47,3 +47,10 @@ run("5 ext: right-preconditioned BiCGStab + true ILU(0), anisotropic Poisson", g
     lambda t: K.BiCgStabRightPcSolver(t, 3000), lambda a: K.TrueIlu0().setup(a), abs_tol=True)
 run("5 ext: right-preconditioned BiCGStab + Ilup(0) as written (SGS), anisotropic Poisson", grid, "aniso",
     lambda t: K.BiCgStabRightPcSolver(t, 3000), lambda a: K.Ilup(0).setup(a), abs_tol=True)
+run("f-3: FGMRES(30) + Jacobi (classical GS), convection-diffusion", grid, "convdiff",
+    lambda t: K.FgmresSolver(t, 600, 30), lambda a: K.Jacobi().setup(a))
+run("f-3: FGMRES(30) + Jacobi (modified), convection-diffusion", grid, "convdiff",
+    lambda t: K.FgmresSolver(t, 600, 30).with_orthog(K.Orthog.Modified), lambda a: K.Jacobi().setup(a))
+run("f-3: CGS (pc ignored, as the reference), convection-diffusion", grid, "convdiff", lambda t: K.CgsSolver(t, 600), lambda a: None)
+run("f-3: TFQMR as written (does not converge; 100 iterations timed), convection-diffusion", grid, "convdiff",
+    lambda t: K.TfqmrSolver(1e-30, 100), lambda a: None)
