@@ -60,6 +60,38 @@ def cpu_baseline(grid, seconds=12.0):
                       + (f"; scaled by {scale:.4f} = ({sgrid}/{grid})^3 rows to the {grid}^3 workload" if scale != 1 else "")}
 
 
+def traffic_of(grid):
+    """HBM bytes per SpMV launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py,
+    read side calibrated on a kernel of known byte count as MI355X_MICROARCH.md prescribes), or None."""
+    tf = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    try:
+        return json.load(open(tf))[str(grid)]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def roofline(enc, nloc, nnz_loc, spmv_ms, plain_ms, copy_gbs):
+    """`achieved` prices the launch at the ALGORITHMIC CSR bytes of SURVEY 8(d) (12 B/nnz + row pointers + x + y) whatever
+    the operator's storage form; `bytes_moved_model` is what the kernel that ran actually streams (a lossless re-encoding
+    moves fewer bytes than the CSR arrays, so frac can exceed 1); `plain_csr` is the same launch on the CSR arrays."""
+    name, npat, ntab = enc
+    alg = spmv_bytes(nloc, nnz_loc)
+    moved = {"csr": alg, "csr-d8": alg - 3 * nnz_loc, "csr-d16": alg - 10 * nnz_loc,
+             "csr-p16": 2 * nloc + 16 * nloc}[name]
+    kern = {"csr": "spmv_wave_kernel<1> (plain CSR: 8 B value + 4 B column per entry)",
+            "csr-d8": "spmv_rows_kernel<1> (CSR-D8: 8 B value + 1-byte column-offset code per entry)",
+            "csr-d16": "spmv_dict_kernel<1> (CSR-D16: one 16-bit word per entry = offset code + value code)",
+            "csr-p16": f"spmv_pattern_kernel<1> (CSR-P16: one 16-bit row-pattern id per row; {npat} ids, {ntab} table entries in LDS)"}[name]
+    ach = alg / (spmv_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kern + ", fused (p,Ap) partials; achieved = ALGORITHMIC CSR bytes (12 B/nnz) / time",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "bytes_per_launch": alg, "ms_per_launch": spmv_ms, "traffic": None,
+            "encoding": name, "bytes_moved_model": moved, "moved_GBs": moved / (spmv_ms * 1e-3) / 1e9,
+            "plain_csr": {"ms_per_launch": plain_ms, "achieved": alg / (plain_ms * 1e-3) / 1e9,
+                          "frac": alg / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "measured_copy_GBs": copy_gbs}
+
+
 def run_cg(K, ctx, dist, grid, solver, warmup, steps):
     """W warm-up + exactly K timed iterations of one stepping session; returns (seconds, stats, spmv_ms, a)."""
     def barrier():
@@ -90,13 +122,22 @@ def run_cg(K, ctx, dist, grid, solver, warmup, steps):
     # dominant kernel: the SpMV with the fused (p,Ap) partials, timed live with HIP events on its own stream
     y = ctx.vec(nloc)
     spmv_ms = a.bench_spmv(b, y, fused_dots=1, reps=50)
+    enc = a.encoding()
+    # the same launch on the plain CSR arrays (12 B/nnz streamed), for reference
+    prev = os.environ.get("KRYST_SPMV_COMPRESS")
+    os.environ["KRYST_SPMV_COMPRESS"] = "0"
+    plain_ms = a.bench_spmv(b, y, fused_dots=1, reps=20)
+    if prev is None:
+        del os.environ["KRYST_SPMV_COMPRESS"]
+    else:
+        os.environ["KRYST_SPMV_COMPRESS"] = prev
     # context for the roofline: the device-copy rate at this footprint (hipMemcpy D2D of one vector, read + write)
     y.copy_from(b); ctx.synchronize()
     ctx.timer_start()
     for _ in range(10):
         y.copy_from(b)
     copy_gbs = 10 * 16.0 * nloc / (ctx.timer_stop() * 1e-3) / 1e9
-    return dt, stats, spmv_ms, nloc, a.nnz, copy_gbs
+    return dt, stats, spmv_ms, nloc, a.nnz, copy_gbs, enc, plain_ms
 
 
 def main():
@@ -142,7 +183,7 @@ def main():
 
     n = grid ** 3
     nnz = 7 * n - 6 * grid * grid
-    dt, stats, spmv_ms, nloc, nnz_loc, copy_gbs = run_cg(K, ctx, dist, grid, args.solver, args.warmup, args.steps)
+    dt, stats, spmv_ms, nloc, nnz_loc, copy_gbs, enc, plain_ms = run_cg(K, ctx, dist, grid, args.solver, args.warmup, args.steps)
     bytes_local = spmv_bytes(nloc, nnz_loc)
     achieved = bytes_local / (spmv_ms * 1e-3) / 1e9
 
@@ -153,29 +194,18 @@ def main():
         "config": {"workload": f"{'jacobi_pcg' if args.solver == 'pcg' else 'cg'}_poisson7_{grid}^3", "grid": grid,
                    "rows": n, "nnz": nnz, "partition": f"{world} k-slab(s)", "rhs": "A*1", "x0": "0",
                    "final_residual": stats.final_residual},
-        "roofline": {"bound": "hbm", "kernel": "spmv_rows_kernel<1> (CSR SpMV, 1-byte dictionary-coded column offsets, "
-                                            "fused (p,Ap) partials); achieved = ALGORITHMIC CSR bytes (12 B/nnz) / time",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "bytes_per_launch": bytes_local, "ms_per_launch": spmv_ms, "traffic": None,
-                     "bytes_moved_model": bytes_local - 3 * nnz_loc,      # 9 B/nnz actually streamed (8 B value + 1 B code)
-                     "measured_copy_GBs": copy_gbs},
+        "roofline": roofline(enc, nloc, nnz_loc, spmv_ms, plain_ms, copy_gbs),
     }
-    tf = os.path.join(ROOT, "profiles", "spmv_traffic.json")
-    if os.path.exists(tf):
-        try:
-            tr = json.load(open(tf)).get(str(grid))       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated
-            if tr and world == 1:                         # (tools/pmc_traffic.py; summaries under profiles/r01/)
-                out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+    if world == 1:
+        out["roofline"]["traffic"] = traffic_of(grid)
     if world == 1 and grid != 256:
-        dt2, st2, ms2, nl2, nz2, cp2 = run_cg(K, ctx, None, 256, args.solver, args.warmup, args.steps)
-        b2 = spmv_bytes(nl2, nz2)
+        dt2, st2, ms2, nl2, nz2, cp2, enc2, pm2 = run_cg(K, ctx, None, 256, args.solver, args.warmup, args.steps)
         out["config1_256"] = {"workload": f"{'jacobi_pcg' if args.solver == 'pcg' else 'cg'}_poisson7_256^3",
                               "value": args.steps / dt2, "unit": "iterations/s", "ms_per_step": dt2 / args.steps * 1e3,
-                              "roofline": {"achieved": b2 / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                           "frac": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": ms2,
-                                           "bytes_per_launch": b2, "measured_copy_GBs": cp2}}
+                              "roofline": roofline(enc2, nl2, nz2, ms2, pm2, cp2)}
+        tr2 = traffic_of(256)
+        if tr2:
+            out["config1_256"]["roofline"]["traffic"] = tr2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(grid)

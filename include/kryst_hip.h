@@ -96,6 +96,10 @@ int32_t kryst_csr_create_dist(kryst_ctx_t ctx, int64_t n_global, const int64_t* 
 int32_t kryst_csr_create_stencil7(kryst_ctx_t ctx, int32_t N, int32_t kind, kryst_csr_t* out);
 int32_t kryst_csr_destroy(kryst_csr_t a);
 int32_t kryst_csr_shape(kryst_csr_t a, int64_t* nrows_local, int64_t* ncols_global, int64_t* nnz_local);
+/* storage form kryst_spmv streams for this operator (all forms are lossless re-encodings made at creation beside the CSR arrays;
+ * results are bit-identical): 0 plain CSR, 1 CSR-D8 (1-byte column-offset codes), 2 CSR-D16 (offset + value codes, 2 B per
+ * entry), 3 CSR-P16 (one 16-bit row-pattern id per row).  patterns / table_entries (may be NULL): size of the P16 tables. */
+int32_t kryst_csr_encoding(kryst_csr_t a, int32_t* encoding, int32_t* patterns, int32_t* table_entries);
 int32_t kryst_csr_download(kryst_csr_t a, int64_t* row_ptr, int32_t* col_idx_local, double* vals);
 
 /* MatVec::matvec (src/core/traits.rs:4-7) == SparseMatrix::spmv (sparse.rs:56-67): y <- A x, y overwritten */
@@ -106,6 +110,9 @@ int32_t kryst_spmv_host(kryst_csr_t a, const double* x, int64_t nx, double* y, i
 /* measurement hook: `reps` back-to-back launches of the SpMV kernel (fused_dots = 0 plain, 1 = the CG kernel
  * with the (x,Ax) partials, 2 = BiCGStab's) between two HIP events on the compute stream; average ms per launch */
 int32_t kryst_bench_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t fused_dots, int32_t reps, double* avg_ms);
+/* measurement only: average time of one pass of a BLAS-1 stream shape (kind 0: Gram-Schmidt link, 3 vectors; 1: eight batched
+ * dots, 9 vectors; 2: CG x/r update, 4 vectors) over vectors of n doubles placed stride_bytes apart in one allocation */
+int32_t kryst_bench_streams(kryst_ctx_t ctx, int64_t n, int64_t stride_bytes, int32_t kind, int32_t reps, double* avg_ms);
 
 /* ---- BLAS-1: InnerProduct for () (src/core/wrappers.rs:90-127) and the solvers' pointwise loops ---- */
 int32_t kryst_dot(kryst_vec_t x, kryst_vec_t y, double* out);       /* wrappers.rs:90-108 */

@@ -248,6 +248,14 @@ class CsrMatrix:
             out[:] = tmp
         return out
 
+    ENCODINGS = ("csr", "csr-d8", "csr-d16", "csr-p16")
+
+    def encoding(self):
+        """(name, patterns, table_entries) of the storage form kryst_spmv streams (see kryst_csr_encoding)."""
+        e, p, t = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(lib().kryst_csr_encoding(self.h, C.byref(e), C.byref(p), C.byref(t)))
+        return self.ENCODINGS[e.value], p.value, t.value
+
     def bench_spmv(self, x, y, fused_dots=1, reps=50):
         """Average milliseconds per launch of the SpMV kernel (HIP events on the compute stream)."""
         ms = C.c_double()

@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkryst_hip.so")
+# KRYST_HIP_LIB: measurement knob, selects a side-by-side build (make VARIANT=...) of the same library
+LIB_PATH = os.environ.get("KRYST_HIP_LIB") or os.path.join(_HERE, "lib", "libkryst_hip.so")
 
 OK = 0
 ERR_NAMES = {1: "FactorError", 2: "SolveError", 3: "IndefiniteMatrix", 4: "IndefinitePreconditioner",
@@ -64,7 +65,9 @@ SIGNATURES = {
     "kryst_csr_download": (C.c_int32, [Handle, c_i64p, c_i32p, c_dp]),
     "kryst_spmv": (C.c_int32, [Handle, Handle, Handle]),
     "kryst_spmv_host": (C.c_int32, [Handle, c_dp, C.c_int64, c_dp, C.c_int64]),
+    "kryst_csr_encoding": (C.c_int32, [Handle, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "kryst_bench_spmv": (C.c_int32, [Handle, Handle, Handle, C.c_int32, C.c_int32, c_dp]),
+    "kryst_bench_streams": (C.c_int32, [Handle, C.c_int64, C.c_int64, C.c_int32, C.c_int32, c_dp]),
     "kryst_dot": (C.c_int32, [Handle, Handle, c_dp]),
     "kryst_norm": (C.c_int32, [Handle, c_dp]),
     "kryst_axpy": (C.c_int32, [C.c_double, Handle, Handle]),

@@ -1,0 +1,101 @@
+// Measurement-only entry point: times the library's three stream shapes (Gram-Schmidt link, batched dots, CG
+// update) on vectors carved from ONE pool at a chosen byte stride, so that the effect of the vectors' relative
+// placement in HBM can be measured in isolation (tools/stride_test.py).
+#include "solver_common.h"
+
+namespace kr {
+struct BenchLinkOp {                 // z = z - h b0 ; partial (z, b1)      -- 3 reads, 1 write
+    static constexpr int NQ = 1;
+    double h; const double* b0; const double* b1; double* z;
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
+        const d2 zz = ld2(z, i), b = ld2(b0, i), nx = ld2(b1, i);
+        const double z0 = zz.a - h * b.a, z1 = zz.b - h * b.b;
+        st2(z, i, z0, z1);
+        if (in0) acc[0] = acc[0] + z0 * nx.a;
+        if (in1) acc[0] = acc[0] + z1 * nx.b;
+    }
+};
+struct BenchDot8Op {                 // 8 dots against one w               -- 9 reads
+    static constexpr int NQ = 8; static constexpr int BPC = 4;
+    const double* w; const double* v[8];
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[8]) const {
+        const d2 ww = ld2(w, i);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const d2 vv = ld2(v[k], i);
+            if (in0) acc[k] = acc[k] + ww.a * vv.a;
+            if (in1) acc[k] = acc[k] + ww.b * vv.b;
+        }
+    }
+};
+struct BenchCgOp {                   // x += a p ; r -= a q ; partial (r,r) -- 4 reads, 2 writes
+    static constexpr int NQ = 1;
+    double al; const double* p; const double* ap; double* x; double* r;
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
+        const d2 pp = ld2(p, i), aa = ld2(ap, i), xx = ld2(x, i), rr = ld2(r, i);
+        const double r0 = rr.a - al * aa.a, r1 = rr.b - al * aa.b;
+        st2(x, i, xx.a + al * pp.a, xx.b + al * pp.b); st2(r, i, r0, r1);
+        if (in0) acc[0] = acc[0] + r0 * r0;
+        if (in1) acc[0] = acc[0] + r1 * r1;
+    }
+};
+typedef double v2dd __attribute__((ext_vector_type(2)));
+template <bool NTL, bool NTS>
+struct BenchCgNtOp {                 // BenchCgOp with nontemporal loads and/or stores
+    static constexpr int NQ = 1;
+    double al; const double* p; const double* ap; double* x; double* r;
+    __device__ __forceinline__ v2dd L(const double* q, int64_t i) const {
+        if constexpr (NTL) return __builtin_nontemporal_load(reinterpret_cast<const v2dd*>(q + i));
+        else return *reinterpret_cast<const v2dd*>(q + i);
+    }
+    __device__ __forceinline__ void S(double* q, int64_t i, double a, double b) const {
+        v2dd v; v.x = a; v.y = b;
+        if constexpr (NTS) __builtin_nontemporal_store(v, reinterpret_cast<v2dd*>(q + i));
+        else *reinterpret_cast<v2dd*>(q + i) = v;
+    }
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
+        const v2dd pp = L(p, i), aa = L(ap, i), xx = L(x, i), rr = L(r, i);
+        const double r0 = rr.x - al * aa.x, r1 = rr.y - al * aa.y;
+        S(x, i, xx.x + al * pp.x, xx.y + al * pp.y); S(r, i, r0, r1);
+        if (in0) acc[0] = acc[0] + r0 * r0;
+        if (in1) acc[0] = acc[0] + r1 * r1;
+    }
+};
+}  // namespace kr
+
+using namespace kr;
+
+extern "C" int32_t kryst_bench_streams(kryst_ctx_t ctx, int64_t n, int64_t stride_bytes, int32_t kind, int32_t reps, double* avg_ms) {
+    KR_ARG(ctx && avg_ms && n > 0 && reps >= 1 && kind >= 0 && kind <= 5, "bench_streams");
+    const int nvec = kind == 0 ? 3 : kind == 1 ? 9 : 4;
+    const size_t vbytes = padded_bytes(n) + sizeof(double) * KR_TILE;
+    KR_ARG(stride_bytes % 16 == 0 && (size_t)stride_bytes >= vbytes, "bench_streams: stride must be a multiple of 16 and hold a padded vector");
+    KR_HIP(hipSetDevice(ctx->device));
+    char* pool = nullptr;
+    KR_HIP(hipMalloc(&pool, (size_t)stride_bytes * nvec));
+    KR_HIP(hipMemsetAsync(pool, 0, (size_t)stride_bytes * nvec, ctx->s_main));
+    double* v[9];
+    for (int k = 0; k < nvec; ++k) v[k] = reinterpret_cast<double*>(pool + (size_t)k * stride_bytes);
+    int32_t rc = KRYST_OK;
+    auto once = [&]() -> int32_t {
+        if (kind == 0) return launch_ew(ctx, BenchLinkOp{0.5, v[1], v[2], v[0]}, n);
+        if (kind == 1) { BenchDot8Op op; op.w = v[0]; for (int k = 0; k < 8; ++k) op.v[k] = v[k + 1]; return launch_ew(ctx, op, n); }
+        if (kind == 3) return launch_ew(ctx, BenchCgNtOp<true, true>{0.5, v[0], v[1], v[2], v[3]}, n);
+        if (kind == 4) return launch_ew(ctx, BenchCgNtOp<false, true>{0.5, v[0], v[1], v[2], v[3]}, n);
+        if (kind == 5) return launch_ew(ctx, BenchCgNtOp<true, false>{0.5, v[0], v[1], v[2], v[3]}, n);
+        return launch_ew(ctx, BenchCgOp{0.5, v[0], v[1], v[2], v[3]}, n);
+    };
+    rc = once();
+    if (rc == KRYST_OK) {
+        (void)hipEventRecord(ctx->tm0, ctx->s_main);
+        for (int r = 0; r < reps && rc == KRYST_OK; ++r) rc = once();
+        (void)hipEventRecord(ctx->tm1, ctx->s_main);
+        (void)hipEventSynchronize(ctx->tm1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ctx->tm0, ctx->tm1);
+        *avg_ms = (double)ms / reps;
+    }
+    (void)hipStreamSynchronize(ctx->s_main);
+    (void)hipFree(pool);
+    return rc;
+}

@@ -88,7 +88,7 @@ struct CgsRun : SolverRun {
     double *r = nullptr, *rt = nullptr, *pp = nullptr, *q = nullptr, *u = nullptr, *v = nullptr, *upq = nullptr;
     int32_t begin() override {
         KR_TRY(solve_args_check(io, bv, xv));
-        KR_TRY(common_begin(prm.max_iters + 2));
+        KR_TRY(common_begin(prm.max_iters + 2, 7));
         pc = nullptr;                                                                             // cgs.rs:59
         KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&rt)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&q)); KR_TRY(ws.vec(&u)); KR_TRY(ws.vec(&v));
         KR_TRY(ws.vec(&upq));
@@ -246,7 +246,7 @@ struct TfqmrRun : SolverRun {
     TfState* tf = nullptr;
     int32_t begin() override {
         KR_TRY(solve_args_check(io, bv, xv));
-        KR_TRY(common_begin(2 * prm.max_iters + 2));
+        KR_TRY(common_begin(2 * prm.max_iters + 2, 8));
         pc = nullptr;                                                                             // tfqmr.rs:66
         tf = reinterpret_cast<TfState*>(ctx->d_scal + 128);         // d_scal: DevState at 0, TfState at +128, red at +256 doubles
         KR_TRY(ws.vec(&rbuf[0])); KR_TRY(ws.vec(&rbuf[1])); KR_TRY(ws.vec(&rt)); KR_TRY(ws.vec(&v)); KR_TRY(ws.vec(&y));

@@ -70,6 +70,10 @@ struct kryst_ctx_s {
     double* d_gather = nullptr;      // nranks * KR_MAXQ doubles (all-gather target)
     kr::HostProgress* h_prog = nullptr; kr::HostProgress* d_prog = nullptr;   // mapped
     double* h_pinned = nullptr;      // 4096 doubles pinned staging
+    // work-vector arena: ONE allocation that the vectors of a solve are carved from and that is kept between solves
+    // (separately hipMalloc'ed 128 MiB vectors land wherever the allocator has room, and multi-stream kernels then run
+    // up to 30 % slower and vary from solve to solve; a single block does not -- tools/stride_test.py)
+    char* arena = nullptr; size_t arena_bytes = 0, arena_used = 0; const void* arena_owner = nullptr;
     int num_cu = 256;
 };
 

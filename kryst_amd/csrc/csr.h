@@ -13,6 +13,14 @@ struct kryst_csr_s {
     double*  d_val = nullptr;       // nnz (+8 pad, zero)
     uint8_t* d_code = nullptr;      // CSR-D8: nnz (+32 pad) codes into d_dict, or nullptr (> 256 distinct col-row offsets)
     int32_t* d_dict = nullptr;      // 256 offsets: col = row + d_dict[code]
+    uint16_t* d_code16 = nullptr;   // CSR-D16: nnz (+32 pad) entries  (value code << 8) | offset code, or nullptr
+    double* d_vdict = nullptr;      // 256 values: val = d_vdict[code >> 8]  (<= 256 distinct value bit patterns)
+    // CSR-P16: one 16-bit pattern id per ROW; a pattern is the row's whole sequence of (col - row, value) pairs
+    uint16_t* d_pid = nullptr;      // nrows (+ KR_TILE pad) pattern ids, or nullptr
+    uint32_t* d_pmeta = nullptr;    // per pattern, 2 words: (first table entry of its base | base length << 16, presence mask)
+    int32_t* d_poff = nullptr;      // table: col - row
+    double* d_pval = nullptr;       // table: value
+    int32_t npat = 0, ntab = 0, pat_unroll = 8;   // table entries padded per pattern to a multiple of pat_unroll
     int64_t ntiles = 0;
     int slots = 7;            // SpMV pair slots per lane (picked from the average nnz of a 128-row slice)
     // distributed

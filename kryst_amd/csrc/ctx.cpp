@@ -87,7 +87,7 @@ int32_t kryst_ctx_destroy(kryst_ctx_t ctx) {
     (void)hipStreamSynchronize(ctx->s_main);
     (void)hipStreamSynchronize(ctx->s_comm);
     comm_destroy(ctx);
-    (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_chunks); (void)hipFree(ctx->d_ticket); (void)hipFree(ctx->d_scal); (void)hipFree(ctx->d_gather);
+    (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_chunks); (void)hipFree(ctx->d_ticket); (void)hipFree(ctx->d_scal); (void)hipFree(ctx->d_gather); (void)hipFree(ctx->arena);
     (void)hipHostFree((void*)ctx->h_prog); (void)hipHostFree(ctx->h_pinned);
     (void)hipEventDestroy(ctx->ev_x_ready); (void)hipEventDestroy(ctx->ev_halo_done);
     (void)hipEventDestroy(ctx->tm0); (void)hipEventDestroy(ctx->tm1);

@@ -13,13 +13,28 @@
 
 namespace kr {
 
+// KR_NT: bit 0 = nontemporal vector loads, bit 1 = nontemporal vector stores in the BLAS-1 streams (measured in
+// tools/nt_test.py)
+#ifndef KR_NT
+#define KR_NT 3
+#endif
+typedef double kr_v2d __attribute__((ext_vector_type(2)));
 struct d2 { double a, b; };
 __device__ __forceinline__ d2 ld2(const double* p, int64_t i) {
-    const double2 v = *reinterpret_cast<const double2*>(p + i);
+#if KR_NT & 1
+    const kr_v2d v = __builtin_nontemporal_load(reinterpret_cast<const kr_v2d*>(p + i));
+#else
+    const kr_v2d v = *reinterpret_cast<const kr_v2d*>(p + i);
+#endif
     return {v.x, v.y};
 }
 __device__ __forceinline__ void st2(double* p, int64_t i, double a, double b) {
-    *reinterpret_cast<double2*>(p + i) = make_double2(a, b);
+    kr_v2d v; v.x = a; v.y = b;
+#if KR_NT & 2
+    __builtin_nontemporal_store(v, reinterpret_cast<kr_v2d*>(p + i));
+#else
+    *reinterpret_cast<kr_v2d*>(p + i) = v;
+#endif
 }
 // coefficient that lives either in a kernel argument or in device memory (written by a scalar kernel)
 struct Coef {

@@ -291,6 +291,7 @@ int32_t fgmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, int32_t 
     const int R = (int)std::min<int64_t>(p->restart, std::max<int64_t>(max_iters, 1));    // no cycle is ever longer than this
     Workspace ws(ctx, n);
     KR_TRY(ws.init(max_iters + (int64_t)p->restart + 2));
+    KR_TRY(ws.reserve(4 + (R + 1) + (pc ? R : 0)));
     // small device arrays: H (R+1 x R), cs, sn, s, hcol, y, state, gate, pointer table
     const size_t nsmall = (size_t)(R + 1) * R + 2 * (size_t)R + (size_t)p->restart + 2 + 2 * (size_t)(R + 8) + 64;
     double* d_small = nullptr;

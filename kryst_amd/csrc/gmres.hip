@@ -229,6 +229,7 @@ int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
     Workspace ws(ctx, n);
     const int64_t n_outer = (p->max_iters + R - 1) / R;                                            // :231
     KR_TRY(ws.init(n_outer * R + 2));
+    KR_TRY(ws.reserve(5 + (R + 1) + (side == 1 ? 1 : side == 2 ? R + 1 : 0)));
     // small device arrays: H, g, cs, sn, y, state, gate, pointer table
     const size_t nsmall = (size_t)(R + 1) * R + (R + 1) + 3 * (size_t)R + 64;
     double* d_small = nullptr;

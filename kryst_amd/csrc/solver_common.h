@@ -108,18 +108,45 @@ struct Workspace {
     std::vector<double*> vecs;
     DevState* st = nullptr; double* red = nullptr;
     double* h_hist = nullptr; double* d_hist = nullptr; int64_t hist_cap = 0;
+    bool owns_arena = false;
     explicit Workspace(kryst_ctx_t c, int64_t n_) : ctx(c), n(n_) {}
     ~Workspace() {
         (void)hipStreamSynchronize(ctx->s_main);
         for (double* p : vecs) (void)hipFree(p);
         if (h_hist) (void)hipHostFree(h_hist);
+        if (owns_arena) { ctx->arena_owner = nullptr; ctx->arena_used = 0; }
+    }
+    size_t vec_bytes() const {
+        const size_t b = sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
+        return (b + 4095) & ~(size_t)4095;
+    }
+    // Claim the context's arena for `count` work vectors (grown if needed).  A second solve that starts while another
+    // workspace of the same context is alive (a stepping session) falls back to one allocation per vector.
+    int32_t reserve(int64_t count) {
+        if (ctx->arena_owner != nullptr) return KRYST_OK;
+        static const bool off = [] { const char* e = getenv("KRYST_NO_ARENA"); return e && atoi(e) != 0; }();   // measurement knob
+        if (off) return KRYST_OK;
+        const size_t need = vec_bytes() * (size_t)count;
+        if (need > ctx->arena_bytes) {
+            KR_HIP(hipStreamSynchronize(ctx->s_main));
+            if (ctx->arena) { KR_HIP(hipFree(ctx->arena)); ctx->arena = nullptr; ctx->arena_bytes = 0; }
+            if (hipMalloc(&ctx->arena, need) != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }   // per-vector fallback
+            ctx->arena_bytes = need;
+        }
+        ctx->arena_owner = this; ctx->arena_used = 0; owns_arena = true;
+        return KRYST_OK;
     }
     int32_t vec(double** out) {
-        const size_t bytes = sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
+        const size_t bytes = vec_bytes();
         double* p = nullptr;
-        KR_HIP(hipMalloc(&p, bytes));
+        if (owns_arena && ctx->arena_used + bytes <= ctx->arena_bytes) {
+            p = reinterpret_cast<double*>(ctx->arena + ctx->arena_used);
+            ctx->arena_used += bytes;
+        } else {
+            KR_HIP(hipMalloc(&p, bytes));
+            vecs.push_back(p);
+        }
         KR_HIP(hipMemsetAsync(p, 0, bytes, ctx->s_main));
-        vecs.push_back(p);
         *out = p;
         return KRYST_OK;
     }

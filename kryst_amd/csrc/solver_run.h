@@ -73,10 +73,11 @@ struct SolverRun {
     virtual ~SolverRun() {}
     virtual int32_t begin() = 0;
     virtual int32_t iterate(int64_t i) = 0;
-    int32_t common_begin(int64_t hist_entries) {
+    int32_t common_begin(int64_t hist_entries, int work_vectors) {
         KR_HIP(hipSetDevice(ctx->device));
         if (io.pc) { pcl = *io.pc; if (pcl.n < 0) pcl.n = n; pc = &pcl; }
         KR_TRY(ws.init(hist_entries));
+        KR_TRY(ws.reserve(work_vectors + 1));
         lc = ws.lctx(&prm);
         done = &ws.st->done;
         KR_TRY(ws.vec(&xw));

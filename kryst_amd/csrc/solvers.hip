@@ -192,7 +192,7 @@ struct CgRun : SolverRun {
     double *r = nullptr, *pp = nullptr, *ap = nullptr, *ax = nullptr;
     int32_t begin() override {
         KR_TRY(solve_args_check(io, bv, xv));
-        KR_TRY(common_begin(prm.max_iters + 2));                                                  // cg.rs:117
+        KR_TRY(common_begin(prm.max_iters + 2, 4));                                               // cg.rs:117
         KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&ap));
         if (prm.has_obj_target) KR_TRY(ws.vec(&ax));
         KR_TRY(residual_dot(a, bv->d, xw, r, ap, nullptr));                                       // :120-125, :127
@@ -331,7 +331,7 @@ struct PcgRun : SolverRun {
     int32_t begin() override {
         KR_TRY(solve_args_check(io, bv, xv));
         // radius / obj_target are fields of PcgSolver (pcg.rs:39-41) but PcgSolver::solve never reads them: accepted, ignored
-        KR_TRY(common_begin(prm.max_iters + 2));                                                  // pcg.rs:117
+        KR_TRY(common_begin(prm.max_iters + 2, 4));                                               // pcg.rs:117
         alias = !pc || pc->kind == KR_PC_IDENTITY;      // z == r  (pcg.rs:130,186 clone_from / IdentityPC)
         jac = pc && pc->kind == KR_PC_JACOBI;
         KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&ap));
@@ -489,7 +489,7 @@ struct BicgRun : SolverRun {
     BicgRun(kryst_vec_t b, kryst_vec_t x, const SolveIO& io_, bool rp) : SolverRun(b, x, io_), right_pc(rp) {}
     int32_t begin() override {
         KR_TRY(solve_args_check(io, bv, xv));
-        KR_TRY(common_begin(prm.max_iters + 2));                                                  // :73
+        KR_TRY(common_begin(prm.max_iters + 2, 8));                                               // :73
         if (!right_pc) pc = nullptr;                     // bicgstab.rs:70: the reference ignores pc; the _rpc extension uses it
         if (pc && pc->kind == KR_PC_IDENTITY) pc = nullptr;
         KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&rhat)); KR_TRY(ws.vec(&v)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&s)); KR_TRY(ws.vec(&t));

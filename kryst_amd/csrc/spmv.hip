@@ -34,7 +34,13 @@ struct SpmvArgs {
     const double* dvec; double* partials; int64_t pstride;
     const int* done; int32_t xcd_chunk; int32_t swizzle; int32_t group;
     const uint8_t* code; const int32_t* dict;      // CSR-D8: col = row + dict[code] (nullptr when not compressed)
+    const uint16_t* code16; const double* vdict;   // CSR-D16: col = row + dict[c & 255], val = vdict[c >> 8]
+    const uint16_t* pid; const uint32_t* pmeta; const int32_t* poff; const double* pval; int32_t npat, ntab;   // CSR-P16
+    int32_t pat_red_off;                           // byte offset of the reduction scratch in the kernel's dynamic LDS
+    int32_t xhi;                                   // number of addressable x entries (local + halo)
 };
+constexpr int KR_PMAX = 512;        // CSR-P16 limits: patterns and (padded) table entries held in LDS: 2 + 12 + 24 KiB at most
+constexpr int KR_TMAX = 2048;
 
 template <bool NT, class T>
 __device__ __forceinline__ T stream_load(const T* p) {
@@ -266,6 +272,239 @@ __global__ __launch_bounds__(KR_T) void spmv_rows_kernel(const SpmvArgs a) {
     }
 }
 
+// CSR-D16, the fully dictionary-coded form (spmv_dict_kernel): when, besides the <= 256 distinct (col - row) offsets of
+// CSR-D8, the operator also has at most 256 distinct VALUES (bit patterns) -- constant-coefficient discretisations on
+// uniform grids: every BASELINE config -- kryst_csr_create keeps one 16-bit word per entry, (value code << 8) | offset
+// code, and two 256-entry dictionaries.  The kernel then streams 2 instead of 12 bytes per nonzero (34 instead of 95
+// bytes per row of a 7-point stencil, vectors included).  The decoded value is the stored double bit for bit and the
+// arithmetic (ascending column order from 0.0, separate mul and add) is unchanged, so y is bit-identical to the plain
+// path; operators with more distinct values or offsets use CSR-D8 or plain CSR.  A wave's window is its slice's run
+// of code words (<= 1016 per pass), loaded 16 B per lane from an 8-entry-aligned start; no workgroup barrier after
+// the dictionaries are in LDS.
+template <int NQ, bool HALO>
+__global__ __launch_bounds__(KR_T) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmv_dict_kernel(const SpmvArgs a) {
+    if (a.done && *a.done) return;
+    constexpr int WCAP = 1016;                              // entries per wave pass (2 x 64 lanes x 8 entries, minus alignment slack)
+    constexpr int CCAP = 1024 + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t code_all[4 * CCAP];
+    __shared__ int32_t dict[256];
+    __shared__ double vdict[256];
+    __shared__ double red[(NQ > 0 ? NQ : 1) * (KR_T / 64)];
+    const int t = threadIdx.x, l = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    uint16_t* lcode = code_all + w * CCAP;
+    dict[t] = a.dict[t]; vdict[t] = a.vdict[t];
+    __syncthreads();
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, per = gridDim.x >> 3;
+    for (int li = slot0; li < a.xcd_chunk; li += per) {
+        int ti;
+        if (a.swizzle) ti = xcd * a.xcd_chunk + li;
+        else ti = ((li / a.group) * 8 + xcd) * a.group + (li % a.group);
+        if (ti >= a.ntiles) { if (a.swizzle) break; else continue; }
+        const int q = a.tiles ? a.tiles[ti] : ti;
+        const int r0 = q * KR_TILE;
+        const int r1 = min(r0 + KR_TILE, a.nrows);
+        const int wr0 = min(r0 + 128 * w, r1), wr1 = min(wr0 + 128, r1);
+        const int row = r0 + 2 * t;
+        const int p0 = a.row_ptr[min(row, r1)];
+        const int p1 = a.row_ptr[min(row + 1, r1)];
+        const int p2 = a.row_ptr[min(row + 2, r1)];
+        const int k0 = a.row_ptr[wr0], k1 = a.row_ptr[wr1];         // wave-uniform
+        double s0 = 0.0, s1 = 0.0;
+        for (int base = k0; base < k1; base += WCAP) {
+            const int wend = min(base + WCAP, k1);
+            // ---- phase 1: the window's code words -> LDS (two 16-byte loads per lane, both in flight)
+            const int cbase = base & ~7;
+            const int nent = wend - cbase;                            // <= WCAP + 7
+            const int lastoff = ((nent + 7) & ~7) - 8;
+            const int o0 = min(8 * l, lastoff), o1 = min(8 * (l + 64), lastoff);
+            const uint4 c0 = *reinterpret_cast<const uint4*>(a.code16 + cbase + o0);
+            const uint4 c1 = *reinterpret_cast<const uint4*>(a.code16 + cbase + o1);
+            if (8 * l < nent) *reinterpret_cast<uint4*>(lcode + o0) = c0;
+            if (8 * (l + 64) < nent) *reinterpret_cast<uint4*>(lcode + o1) = c1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- phase 2: the two rows of the lane, four entries of each in flight, folded in ascending column order
+            int ka = max(p0, base), kb = max(p1, base);
+            const int ea = min(p1, wend), eb = min(p2, wend);
+            while (ka < ea || kb < eb) {
+                // all gathers of the batch are issued before the first value is decoded (U = 7: a 7-point row in one trip)
+                constexpr int U = 7;
+                double xa[U], xb[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ia = min(ka + u, max(ea - 1, base)), ib = min(kb + u, max(eb - 1, base));
+                    const int ca = row + dict[lcode[ia - cbase] & 255u], cb = row + 1 + dict[lcode[ib - cbase] & 255u];
+                    xa[u] = (ka + u < ea) ? gather<HALO>(a, ca) : 0.0;
+                    xb[u] = (kb + u < eb) ? gather<HALO>(a, cb) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {                       // the code words are re-read from LDS: cheaper than holding them
+                    const int ia = min(ka + u, max(ea - 1, base)), ib = min(kb + u, max(eb - 1, base));
+                    if (ka + u < ea) s0 = s0 + vdict[lcode[ia - cbase] >> 8] * xa[u];
+                    if (kb + u < eb) s1 = s1 + vdict[lcode[ib - cbase] >> 8] * xb[u];
+                }
+                ka += U; kb += U;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (row + 1 < r1) st2(a.y, row, s0, s1);
+        else if (row < r1) a.y[row] = s0;
+        if constexpr (NQ > 0) {
+            double acc[NQ];
+            const d2 d = ld2(a.dvec, row);
+            acc[0] = 0.0;
+            if (row < r1) acc[0] = acc[0] + d.a * s0;
+            if (row + 1 < r1) acc[0] = acc[0] + d.b * s1;
+            if constexpr (NQ > 1) {
+                acc[1] = 0.0;
+                if (row < r1) acc[1] = acc[1] + s0 * s0;
+                if (row + 1 < r1) acc[1] = acc[1] + s1 * s1;
+            }
+            block_reduce<NQ, KR_T / 64>(acc, red);
+            if (t == 0) {
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) a.partials[k * a.pstride + q] = acc[k];
+            }
+        }
+    }
+}
+
+// CSR-P16, row-pattern coding (spmv_pattern_kernel): operators assembled from a few stencils -- constant-coefficient
+// discretisations on structured grids, i.e. every BASELINE config -- repeat the same ROW, as a sequence of
+// (col - row, value) pairs, millions of times (a 7-point operator on a box has 27 distinct rows, all of them
+// sub-sequences of the interior row).  kryst_csr_create numbers the distinct rows ("patterns", at most KR_PMAX) and
+// expresses each as a BASE sequence (at most KR_TMAX table entries in total) plus a 16-bit presence mask; it keeps one
+// 16-bit pattern id per row beside the CSR arrays, and the SpMV streams 2 bytes per ROW (18 bytes per row with x and y,
+// against 95 for plain CSR): no row pointers, no per-entry codes, no dependent row_ptr -> entries load chain.  Each lane
+// walks its rows' entries in the stored (ascending column) order with the reference's un-fused mul/add, skipping the
+// masked-out ones, so y is bit-identical to the plain path.  Everything else falls back to CSR-D16 / CSR-D8 / plain CSR.
+//
+// At 18 bytes per row the kernel is bound by instruction issue, not by HBM (rocprofv3 --pmc: TA busy 59 %, the texture path
+// spends ~16 cycles per 64-lane load whatever its width), so it is built around 16-BYTE gathers: thread t owns the adjacent
+// rows 2t, 2t+1; when both rows share a base (interior rows and the boundary rows next to them do) entry e of both rows
+// reads x[2t + off_e] and x[2t + 1 + off_e] -- one dwordx4 load -- and one table lookup serves both rows.  Row pairs with
+// different bases take the two-loads-per-entry path.  x is addressed with 32-bit byte offsets from a scalar base (the
+// launch checks xlen < 2^28).
+template <bool HALO>
+__device__ __forceinline__ const char* gather_base(const SpmvArgs& a, int32_t c) {
+    if constexpr (HALO) return (c < a.nloc) ? reinterpret_cast<const char*>(a.x) : reinterpret_cast<const char*>(a.halo - a.nloc);
+    else return reinterpret_cast<const char*>(a.x);
+}
+template <bool HALO>
+__device__ __forceinline__ double gather32(const SpmvArgs& a, int32_t c) {
+    return *reinterpret_cast<const double*>(gather_base<HALO>(a, c) + ((size_t)(uint32_t)c << 3));
+}
+
+template <int NQ, bool HALO, int U>
+__global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {
+    if (a.done && *a.done) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* pval = reinterpret_cast<double*>(smem);                                   // ntab + U entries
+    int32_t* poff = reinterpret_cast<int32_t*>(pval + a.ntab + U);
+    uint2* meta = reinterpret_cast<uint2*>(poff + a.ntab + U + ((a.ntab + U) & 1));   // 8-byte aligned
+    double* red = reinterpret_cast<double*>(smem + a.pat_red_off);
+    const int t = threadIdx.x;
+    for (int i = t; i < a.npat; i += KR_T) meta[i] = reinterpret_cast<const uint2*>(a.pmeta)[i];
+    for (int i = t; i < a.ntab + U; i += KR_T) { poff[i] = i < a.ntab ? a.poff[i] : 0; pval[i] = i < a.ntab ? a.pval[i] : 0.0; }
+    __syncthreads();
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, per = gridDim.x >> 3;
+    auto tile_of = [&](int li) -> int {
+        if (li >= a.xcd_chunk) return -1;
+        const int ti = ((li / a.group) * 8 + xcd) * a.group + (li % a.group);
+        if (ti >= a.ntiles) return -1;
+        return a.tiles ? a.tiles[ti] : ti;
+    };
+    const int32_t xhi = a.xhi;                                      // 16-byte gathers need 0 <= c and c + 1 < xhi
+    int q = tile_of(slot0);
+    unsigned ids = 0;
+    if (q >= 0) ids = *reinterpret_cast<const unsigned*>(a.pid + (size_t)q * KR_TILE + 2 * t);   // rows 2t, 2t+1 (padded array)
+    for (int li = slot0; li < a.xcd_chunk; li += per) {
+        const int qn = tile_of(li + per);                           // prefetch the next tile's ids
+        unsigned ids_n = 0;
+        if (qn >= 0) ids_n = *reinterpret_cast<const unsigned*>(a.pid + (size_t)qn * KR_TILE + 2 * t);
+        if (q >= 0) {
+            const int r0 = q * KR_TILE;
+            const int r1 = min(r0 + KR_TILE, a.nrows);
+            const int row = r0 + 2 * t;
+            const bool va = row < r1, vb = row + 1 < r1;
+            uint2 ma = va ? meta[ids & 0xffffu] : make_uint2(0u, 0u), mb = vb ? meta[ids >> 16] : make_uint2(0u, 0u);
+            double s0 = 0.0, s1 = 0.0;
+            if (ma.x == mb.x) {
+                // ---- same base: one table lookup and one 16-byte gather per entry serve both rows
+                const int len = ma.x >> 16;
+                const double* tv = pval + (ma.x & 0xffffu); const int32_t* to = poff + (ma.x & 0xffffu);
+                for (int e0 = 0; e0 < len; e0 += U) {
+                    v2d xx[U];
+                    const unsigned ka = e0 < 16 ? (ma.y >> e0) : 0xffffffffu, kb = e0 < 16 ? (mb.y >> e0) : 0xffffffffu;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const bool na = (e0 + u < len) && ((ka >> u) & 1u), nb = (e0 + u < len) && ((kb >> u) & 1u);
+                        const int32_t c = row + to[e0 + u];
+                        xx[u].x = 0.0; xx[u].y = 0.0;
+                        if ((na || nb) && (uint32_t)c < (uint32_t)(xhi - 1) && !(HALO && c == a.nloc - 1)) {
+                            xx[u] = *reinterpret_cast<const v2d*>(gather_base<HALO>(a, na ? c : c + 1) + ((size_t)(uint32_t)c << 3));
+                        } else {                                    // first / last element of x: one guarded load per row
+                            if (na) xx[u].x = gather32<HALO>(a, c);
+                            if (nb) xx[u].y = gather32<HALO>(a, c + 1);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const double v = tv[e0 + u];
+                        if ((e0 + u < len) && ((ka >> u) & 1u)) s0 = s0 + v * xx[u].x;
+                        if ((e0 + u < len) && ((kb >> u) & 1u)) s1 = s1 + v * xx[u].y;
+                    }
+                }
+            } else {
+                // ---- different bases: each row walks its own
+                const int la = ma.x >> 16, lb = mb.x >> 16;
+                const double* tva = pval + (ma.x & 0xffffu); const int32_t* toa = poff + (ma.x & 0xffffu);
+                const double* tvb = pval + (mb.x & 0xffffu); const int32_t* tob = poff + (mb.x & 0xffffu);
+                for (int e0 = 0; e0 < max(la, lb); e0 += U) {
+                    double xa[U], xb[U];
+                    const unsigned ka = e0 < 16 ? (ma.y >> e0) : 0xffffffffu, kb = e0 < 16 ? (mb.y >> e0) : 0xffffffffu;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int ea = min(e0 + u, max(la - 1, 0)), eb = min(e0 + u, max(lb - 1, 0));
+                        xa[u] = ((e0 + u < la) && ((ka >> u) & 1u)) ? gather32<HALO>(a, row + toa[ea]) : 0.0;
+                        xb[u] = ((e0 + u < lb) && ((kb >> u) & 1u)) ? gather32<HALO>(a, row + 1 + tob[eb]) : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int ea = min(e0 + u, max(la - 1, 0)), eb = min(e0 + u, max(lb - 1, 0));
+                        if ((e0 + u < la) && ((ka >> u) & 1u)) s0 = s0 + tva[ea] * xa[u];
+                        if ((e0 + u < lb) && ((kb >> u) & 1u)) s1 = s1 + tvb[eb] * xb[u];
+                    }
+                }
+            }
+            if (vb) st2(a.y, row, s0, s1);
+            else if (va) a.y[row] = s0;
+            if constexpr (NQ > 0) {
+                double acc[NQ];
+                const d2 d = ld2(a.dvec, row);
+                acc[0] = 0.0;
+                if (va) acc[0] = acc[0] + d.a * s0;
+                if (vb) acc[0] = acc[0] + d.b * s1;
+                if constexpr (NQ > 1) {
+                    acc[1] = 0.0;
+                    if (va) acc[1] = acc[1] + s0 * s0;
+                    if (vb) acc[1] = acc[1] + s1 * s1;
+                }
+                block_reduce<NQ, KR_T / 64>(acc, red);
+                if (t == 0) {
+#pragma unroll
+                    for (int k = 0; k < NQ; ++k) a.partials[k * a.pstride + q] = acc[k];
+                }
+            }
+        }
+        q = qn; ids = ids_n;
+    }
+}
+
 __global__ void pack_kernel(const double* x, const int32_t* idx, double* out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = x[idx[i]];
@@ -285,19 +524,63 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
     args.x = x; args.halo = a->plan.d_halo; args.nloc = (int32_t)a->nrows;
     args.y = y; args.tiles = tiles; args.ntiles = (int32_t)ntiles; args.nrows = (int32_t)a->nrows;
     args.dvec = dvec; args.partials = ctx->d_partials; args.pstride = ctx->partials_cap; args.done = done;
-    const int64_t chunk = (ntiles + 7) / 8;
+    args.swizzle = env_int("KRYST_SPMV_SWIZZLE", 0);
+    args.group = std::max(1, env_int("KRYST_SPMV_GROUP", 1));
+    int64_t chunk = (ntiles + 7) / 8;                       // tiles per XCD
+    if (!args.swizzle) chunk = (chunk + args.group - 1) / args.group * args.group;   // a whole number of runs of `group` tiles
     args.xcd_chunk = (int32_t)chunk;
     int64_t per = chunk;                                    // one tile per workgroup by default
     const int bpc = spmv_blocks_per_cu();
     if (bpc > 0) per = std::min<int64_t>(chunk, std::max<int64_t>(1, (int64_t)ctx->num_cu * bpc / 8));
     const dim3 grid((unsigned)(per * 8)), block(KR_T);
-    args.swizzle = env_int("KRYST_SPMV_SWIZZLE", 0);
-    args.group = std::max(1, env_int("KRYST_SPMV_GROUP", 1));
     // production path: wave-independent kernel; pair slots per lane sized to the matrix's average slice length
     // (a wave streams the nnz of 128 rows: <= 256 nnz -> 2 slots, <= 512 -> 4, else 7 = a 7-point stencil's 896)
     const int kern = env_int("KRYST_SPMV_KERNEL", 2);          // 2: products-in-LDS wave kernel; 3: rows kernel (+ CSR-D8)
-    const bool comp = a->d_code && env_int("KRYST_SPMV_COMPRESS", 1) != 0;
+    // 0 plain CSR, 1 CSR-D8 (offset codes), 2 CSR-D16 (offset + value codes), 3 CSR-P16 (row patterns); each level
+    // falls back to the next lower one the operator qualifies for
+    const int comp_level = env_int("KRYST_SPMV_COMPRESS", 3);
+    const bool comp = a->d_code && comp_level != 0;
     args.code = comp ? a->d_code : nullptr; args.dict = comp ? a->d_dict : nullptr;
+    args.code16 = a->d_code16; args.vdict = a->d_vdict;
+    args.pid = a->d_pid; args.pmeta = a->d_pmeta; args.poff = a->d_poff; args.pval = a->d_pval; args.npat = a->npat; args.ntab = a->ntab;
+    if (a->d_pid && comp_level >= 3 && a->xlen + (HALO ? a->plan.total_recv : 0) < (1ll << 28)) {
+        // the pattern kernel keeps its tables in LDS, so workgroups loop over several tiles (next tile's ids prefetched);
+        // 6 resident workgroups per CU (65 VGPRs -> 7 waves per SIMD) and runs of 8 consecutive tiles per XCD measured best
+        // (tools/p16_tune.sh: 0.77 ms at 512^3 against 0.95 ms with 8 per CU and round-robin tiles)
+        const int pbpc = env_int("KRYST_SPMV_PATTERN_BLOCKS_PER_CU", 6);
+        args.group = std::max(1, env_int("KRYST_SPMV_GROUP", 8));
+        const int64_t pchunk = (chunk + args.group - 1) / args.group * args.group;      // an XCD's share is a whole number of runs
+        args.xcd_chunk = (int32_t)pchunk;
+        const int64_t pper = pbpc > 0 ? std::min<int64_t>(pchunk, std::max<int64_t>(1, (int64_t)ctx->num_cu * pbpc / 8)) : pchunk;
+        const dim3 pgrid((unsigned)(pper * 8));
+        const int U = a->pat_unroll;
+        const size_t tab = (size_t)(a->ntab + U + 1) * 12 + (size_t)a->npat * 8;
+        args.pat_red_off = (int32_t)((tab + 15) & ~(size_t)15);
+        args.xhi = (int32_t)(a->xlen + (HALO ? a->plan.total_recv : 0));
+        const size_t lds = (size_t)args.pat_red_off + sizeof(double) * (size_t)(nq > 0 ? nq : 1) * (KR_T / 64);
+#define KR_PAT(NQ_, U_) hipLaunchKernelGGL((spmv_pattern_kernel<NQ_, HALO, U_>), pgrid, block, lds, ctx->s_main, args)
+#define KR_PAT_BY(NQ_) do { if (U == 7) KR_PAT(NQ_, 7); else KR_PAT(NQ_, 8); } while (0)
+        switch (nq) {
+            case 0: KR_PAT_BY(0); break;
+            case 1: KR_PAT_BY(1); break;
+            case 2: KR_PAT_BY(2); break;
+            default: set_error("spmv: nq=%d", nq); return KRYST_ERR_ARG;
+        }
+#undef KR_PAT_BY
+#undef KR_PAT
+        KR_HIP(hipGetLastError());
+        return KRYST_OK;
+    }
+    if (a->d_code16 && comp_level >= 2) {
+        switch (nq) {
+            case 0: hipLaunchKernelGGL((spmv_dict_kernel<0, HALO>), grid, block, 0, ctx->s_main, args); break;
+            case 1: hipLaunchKernelGGL((spmv_dict_kernel<1, HALO>), grid, block, 0, ctx->s_main, args); break;
+            case 2: hipLaunchKernelGGL((spmv_dict_kernel<2, HALO>), grid, block, 0, ctx->s_main, args); break;
+            default: set_error("spmv: nq=%d", nq); return KRYST_ERR_ARG;
+        }
+        KR_HIP(hipGetLastError());
+        return KRYST_OK;
+    }
     const int slots_env = env_int("KRYST_SPMV_SLOTS", 0);
     // measured (tools/tune_spmv.py): with vectors beyond the 256 MiB Infinity Cache the smaller window (more resident
     // waves) wins, below it the one-window-per-slice form does
@@ -363,10 +646,108 @@ int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const dou
     KR_TRY(comm_exchange(ctx, sendbase, pl.send_counts.data(), pl.send_off.data(), pl.d_halo, pl.recv_counts.data(),
                          pl.recv_off.data(), true, ctx->s_comm));
     KR_HIP(hipEventRecord(ctx->ev_halo_done, ctx->s_comm));
-    KR_TRY(launch_tiles<true>(a, x, y, nq, dvec, done, a->d_tiles_interior, a->n_interior));
+    KR_TRY(launch_tiles<false>(a, x, y, nq, dvec, done, a->d_tiles_interior, a->n_interior));   // interior tiles have no halo columns
     KR_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_halo_done, 0));
     KR_TRY(launch_tiles<true>(a, x, y, nq, dvec, done, a->d_tiles_boundary, a->n_boundary));
     return KRYST_OK;
+}
+
+// CSR-P16: number the distinct rows (as sequences of (col - row, value bits)); give up as soon as the tables outgrow LDS
+static int32_t upload_patterns(kryst_csr_t a, const std::vector<uint16_t>& pid, const std::vector<uint32_t>& meta /* 2 words per pattern */,
+                               const std::vector<int32_t>& poff, const std::vector<double>& pval) {
+    kryst_ctx_t ctx = a->ctx;
+    KR_HIP(hipMalloc(&a->d_pid, sizeof(uint16_t) * pid.size()));
+    KR_HIP(hipMalloc(&a->d_pmeta, sizeof(uint32_t) * 2 * KR_PMAX));
+    KR_HIP(hipMalloc(&a->d_poff, sizeof(int32_t) * (KR_TMAX + 8)));
+    KR_HIP(hipMalloc(&a->d_pval, sizeof(double) * (KR_TMAX + 8)));
+    KR_HIP(hipMemcpyAsync(a->d_pid, pid.data(), sizeof(uint16_t) * pid.size(), hipMemcpyHostToDevice, ctx->s_main));
+    KR_HIP(hipMemcpyAsync(a->d_pmeta, meta.data(), sizeof(uint32_t) * meta.size(), hipMemcpyHostToDevice, ctx->s_main));
+    if (!poff.empty()) {
+        KR_HIP(hipMemcpyAsync(a->d_poff, poff.data(), sizeof(int32_t) * poff.size(), hipMemcpyHostToDevice, ctx->s_main));
+        KR_HIP(hipMemcpyAsync(a->d_pval, pval.data(), sizeof(double) * pval.size(), hipMemcpyHostToDevice, ctx->s_main));
+    }
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    a->npat = (int32_t)(meta.size() / 2); a->ntab = (int32_t)poff.size();
+    return KRYST_OK;
+}
+static int32_t build_patterns(kryst_csr_t a, const std::vector<int32_t>& rp, const std::vector<int32_t>& col, const double* val) {
+    const int64_t n = a->nrows;
+    if (n == 0 || a->nnz == 0) return KRYST_OK;
+    struct Key { uint64_t h; int32_t row; };
+    std::unordered_multimap<uint64_t, int> by_hash;               // hash -> pattern id
+    std::vector<uint32_t> meta; std::vector<int32_t> poff; std::vector<double> pval;
+    std::vector<uint16_t> pid((size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE), 0);
+    auto same = [&](int p, int64_t i) {
+        const int b = (int)(meta[p] & 0xffffu), len = (int)(meta[p] >> 16);
+        if (len != rp[i + 1] - rp[i]) return false;
+        for (int e = 0; e < len; ++e) {
+            const int32_t k = rp[i] + e;
+            if (poff[b + e] != col[k] - (int32_t)i || memcmp(&pval[b + e], &val[k], 8) != 0) return false;
+        }
+        return true;
+    };
+    int last = -1, maxlen = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int len = rp[i + 1] - rp[i];
+        if (len > 0xffff) return KRYST_OK;
+        if (last >= 0 && same(last, i)) { pid[i] = (uint16_t)last; continue; }     // neighbouring rows usually repeat
+        uint64_t h = 1469598103934665603ull ^ (uint64_t)len;
+        for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+            uint64_t bits; memcpy(&bits, &val[k], 8);
+            h = (h ^ (uint64_t)(uint32_t)(col[k] - (int32_t)i)) * 1099511628211ull;
+            h = (h ^ bits) * 1099511628211ull;
+        }
+        int found = -1;
+        auto range = by_hash.equal_range(h);
+        for (auto it = range.first; it != range.second; ++it) if (same(it->second, i)) { found = it->second; break; }
+        if (found < 0) {
+            if ((int)meta.size() == KR_PMAX || (int)poff.size() + len > KR_TMAX) return KRYST_OK;     // not a pattern matrix
+            found = (int)meta.size();
+            meta.push_back((uint32_t)poff.size() | ((uint32_t)len << 16));
+            for (int32_t k = rp[i]; k < rp[i + 1]; ++k) { poff.push_back(col[k] - (int32_t)i); pval.push_back(val[k]); }
+            by_hash.emplace(h, found);
+            maxlen = std::max(maxlen, len);
+        }
+        pid[i] = (uint16_t)found; last = found;
+    }
+    // Express every pattern as (base, presence mask): a pattern of at most 16 entries that is a sub-sequence of a longer
+    // pattern's (offset, value) sequence shares that pattern's table entries (boundary rows of a stencil are the interior
+    // row with entries removed).  Longest patterns first; a base is padded to a multiple of the kernel's unroll factor
+    // (offset 0, value 0: never used, the kernel predicates on length and mask; the padding only keeps the clamp-free
+    // immediate-offset reads in bounds).
+    const int U = maxlen <= 7 ? 7 : 8;
+    {
+        const size_t np = meta.size();
+        std::vector<int> order(np);
+        for (size_t p = 0; p < np; ++p) order[p] = (int)p;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return (meta[x] >> 16) > (meta[y] >> 16); });
+        std::vector<uint32_t> m2(2 * np, 0u); std::vector<int32_t> o2; std::vector<double> v2;
+        struct Base { uint32_t start; int len; };
+        std::vector<Base> bases;
+        for (int p : order) {
+            const int b = (int)(meta[p] & 0xffffu), len = (int)(meta[p] >> 16);
+            bool placed = false;
+            if (len <= 16)
+                for (const Base& B : bases) {
+                    if (B.len > 16 || B.len < len) continue;
+                    uint32_t mask = 0; int e = 0;
+                    for (int f = 0; f < B.len && e < len; ++f)
+                        if (o2[B.start + f] == poff[b + e] && memcmp(&v2[B.start + f], &pval[b + e], 8) == 0) { mask |= 1u << f; ++e; }
+                    if (e == len) { m2[2 * p] = B.start | ((uint32_t)B.len << 16); m2[2 * p + 1] = mask; placed = true; break; }
+                }
+            if (placed) continue;
+            const uint32_t start = (uint32_t)o2.size();
+            for (int e = 0; e < len; ++e) { o2.push_back(poff[b + e]); v2.push_back(pval[b + e]); }
+            while (o2.size() % (size_t)U) { o2.push_back(0); v2.push_back(0.0); }
+            bases.push_back(Base{start, len});
+            m2[2 * p] = start | ((uint32_t)len << 16);
+            m2[2 * p + 1] = len >= 16 ? 0xffffu : ((1u << len) - 1u);
+        }
+        if ((int)o2.size() > KR_TMAX || o2.size() > 0xffffu) return KRYST_OK;
+        meta.swap(m2); poff.swap(o2); pval.swap(v2);
+    }
+    a->pat_unroll = U;
+    return upload_patterns(a, pid, meta, poff, pval);
 }
 
 // ---------------------------------------------------------------- creation
@@ -414,10 +795,40 @@ static int32_t upload_csr(kryst_csr_t a, const std::vector<int32_t>& rp, const s
             KR_HIP(hipMemcpyAsync(a->d_code, codes.data(), codes.size(), hipMemcpyHostToDevice, ctx->s_main));
             KR_HIP(hipMemcpyAsync(a->d_dict, dict.data(), sizeof(int32_t) * 256, hipMemcpyHostToDevice, ctx->s_main));
             KR_HIP(hipStreamSynchronize(ctx->s_main));
+            // CSR-D16: additionally <= 256 distinct value bit patterns -> one 16-bit word per entry
+            std::vector<double> vdict; vdict.reserve(256);
+            std::unordered_map<uint64_t, int> vcode_of;
+            std::vector<uint16_t> c16(nnz + 32, 0);
+            bool vok = true;
+            uint64_t last_b = 0; int last_vc = -1;
+            for (size_t k = 0; k < nnz && vok; ++k) {
+                uint64_t bits; memcpy(&bits, &val[k], 8);
+                int vc;
+                if (last_vc >= 0 && bits == last_b) vc = last_vc;
+                else {
+                    auto it = vcode_of.find(bits);
+                    if (it != vcode_of.end()) vc = it->second;
+                    else {
+                        if (vdict.size() == 256) { vok = false; break; }
+                        vdict.push_back(val[k]); vc = (int)vdict.size() - 1; vcode_of.emplace(bits, vc);
+                    }
+                    last_b = bits; last_vc = vc;
+                }
+                c16[k] = (uint16_t)((vc << 8) | codes[k]);
+            }
+            if (vok) {
+                vdict.resize(256, 0.0);
+                KR_HIP(hipMalloc(&a->d_code16, sizeof(uint16_t) * c16.size()));
+                KR_HIP(hipMalloc(&a->d_vdict, sizeof(double) * 256));
+                KR_HIP(hipMemcpyAsync(a->d_code16, c16.data(), sizeof(uint16_t) * c16.size(), hipMemcpyHostToDevice, ctx->s_main));
+                KR_HIP(hipMemcpyAsync(a->d_vdict, vdict.data(), sizeof(double) * 256, hipMemcpyHostToDevice, ctx->s_main));
+                KR_HIP(hipStreamSynchronize(ctx->s_main));
+            }
         }
     }
     const double per_slice = a->nrows > 0 ? (double)a->nnz / (double)((a->nrows + 127) / 128) : 0.0;
     a->slots = per_slice <= 256.0 ? 2 : (per_slice <= 512.0 ? 4 : 7);
+    KR_TRY(build_patterns(a, rp, col, val));
     return KRYST_OK;
 }
 
@@ -574,7 +985,7 @@ __host__ __device__ static inline int64_t stencil_gptr(int64_t row, int64_t N) {
 struct StencilCoef { double c[7]; };
 
 __global__ void stencil7_gen_kernel(int32_t N, int64_t lo, int64_t hi, int64_t n_lower, StencilCoef sc,
-                                    int32_t* row_ptr, int32_t* col, double* val, uint8_t* code) {
+                                    int32_t* row_ptr, int32_t* col, double* val, uint8_t* code, uint16_t* code16, uint16_t* pid) {
     const int64_t nloc = hi - lo;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > nloc) return;
@@ -587,6 +998,10 @@ __global__ void stencil7_gen_kernel(int32_t N, int64_t lo, int64_t hi, int64_t n
     const int64_t ii = row % N1, jj = (row / N1) % N1, kk = row / N2;
     const bool ok[7] = {kk > 0, jj > 0, ii > 0, true, ii < N1 - 1, jj < N1 - 1, kk < N1 - 1};
     const int64_t off[7] = {-N2, -N1, -1, 0, 1, N1, N2};
+    // CSR-P16 pattern id: which neighbours exist (bits 0-5, direction order without the centre) and whether the k
+    // neighbours live in a halo plane (bits 6, 7); the table is built on the host (stencil_pattern_table)
+    pid[i] = (uint16_t)((ok[0] ? 1 : 0) | (ok[1] ? 2 : 0) | (ok[2] ? 4 : 0) | (ok[4] ? 8 : 0) | (ok[5] ? 16 : 0) | (ok[6] ? 32 : 0) |
+                        ((ok[0] && row - N2 < lo) ? 64 : 0) | ((ok[6] && row + N2 >= hi) ? 128 : 0));
 #pragma unroll
     for (int s = 0; s < 7; ++s)
         if (ok[s]) {
@@ -597,6 +1012,7 @@ __global__ void stencil7_gen_kernel(int32_t N, int64_t lo, int64_t hi, int64_t n
             else if (c < lo) { lc = nloc + (c - (lo - N2)); cd = 7; }          // halo plane from rank-1: lc - i == nloc
             else { lc = nloc + n_lower + (c - hi); cd = 8; }                   // halo plane from rank+1: lc - i == n_lower + N^2
             col[k] = (int32_t)lc; val[k] = sc.c[s]; code[k] = (uint8_t)cd;
+            code16[k] = (uint16_t)((s << 8) | cd);                  // value dictionary = the 7 coefficients, by direction
             ++k;
         }
 }
@@ -628,7 +1044,11 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
         if (hipMalloc(&a->d_row_ptr, sizeof(int32_t) * (size_t)(nloc + 1 + 8)) != hipSuccess ||
             hipMalloc(&a->d_col, sizeof(int32_t) * (size_t)(nnz + 8)) != hipSuccess ||
             hipMalloc(&a->d_val, sizeof(double) * (size_t)(nnz + 8)) != hipSuccess ||
-            hipMalloc(&a->d_code, (size_t)(nnz + 32)) != hipSuccess || hipMalloc(&a->d_dict, sizeof(int32_t) * 256) != hipSuccess) { set_error("hipMalloc failed (stencil7)"); rc = KRYST_ERR_HIP; break; }
+            hipMalloc(&a->d_code, (size_t)(nnz + 32)) != hipSuccess || hipMalloc(&a->d_dict, sizeof(int32_t) * 256) != hipSuccess ||
+            hipMalloc(&a->d_code16, sizeof(uint16_t) * (size_t)(nnz + 32)) != hipSuccess || hipMalloc(&a->d_vdict, sizeof(double) * 256) != hipSuccess ||
+            hipMalloc(&a->d_pid, sizeof(uint16_t) * (size_t)((nloc + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE)) != hipSuccess ||
+            hipMalloc(&a->d_pmeta, sizeof(uint32_t) * 2 * KR_PMAX) != hipSuccess || hipMalloc(&a->d_poff, sizeof(int32_t) * (KR_TMAX + 8)) != hipSuccess ||
+            hipMalloc(&a->d_pval, sizeof(double) * (KR_TMAX + 8)) != hipSuccess) { set_error("hipMalloc failed (stencil7)"); rc = KRYST_ERR_HIP; break; }
         {
             int32_t dict[256] = {0};
             const int32_t offs7[7] = {(int32_t)-N2, -N, -1, 0, 1, N, (int32_t)N2};
@@ -638,12 +1058,43 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
             (void)hipMemcpyAsync(a->d_dict, dict, sizeof dict, hipMemcpyHostToDevice, ctx->s_main);
             (void)hipStreamSynchronize(ctx->s_main);
             (void)hipMemsetAsync(a->d_code + nnz, 0, 32, ctx->s_main);
+            double vd[256] = {0.0};
+            for (int u = 0; u < 7; ++u) vd[u] = sc.c[u];
+            (void)hipMemcpyAsync(a->d_vdict, vd, sizeof vd, hipMemcpyHostToDevice, ctx->s_main);
+            (void)hipStreamSynchronize(ctx->s_main);
+            (void)hipMemsetAsync(a->d_code16 + nnz, 0, sizeof(uint16_t) * 32, ctx->s_main);
+            // pattern table for the 256 ids of stencil7_gen_kernel: one 7-entry base per (lower halo, upper halo)
+            // combination, presence mask from the id's neighbour bits (ids that cannot occur keep length 0)
+            std::vector<uint32_t> meta(512, 0u); std::vector<int32_t> poff; std::vector<double> pval;
+            uint32_t base_start[4];
+            for (int hb = 0; hb < 4; ++hb) {
+                base_start[hb] = (uint32_t)poff.size();
+                for (int u = 0; u < 7; ++u) {
+                    int32_t o = offs7[u];
+                    if (u == 0 && (hb & 1)) o = dict[7];
+                    if (u == 6 && (hb & 2)) o = dict[8];
+                    poff.push_back(o); pval.push_back(sc.c[u]);
+                }
+            }
+            for (int id = 0; id < 256; ++id) {
+                if (((id & 64) && !(id & 1)) || ((id & 128) && !(id & 32))) continue;
+                const uint32_t mask = ((id & 1) ? 1u : 0u) | ((id & 2) ? 2u : 0u) | ((id & 4) ? 4u : 0u) | 8u |
+                                      ((id & 8) ? 16u : 0u) | ((id & 16) ? 32u : 0u) | ((id & 32) ? 64u : 0u);
+                meta[2 * (size_t)id] = base_start[(id >> 6) & 3] | (7u << 16);
+                meta[2 * (size_t)id + 1] = mask;
+            }
+            (void)hipMemcpyAsync(a->d_pmeta, meta.data(), sizeof(uint32_t) * 512, hipMemcpyHostToDevice, ctx->s_main);
+            (void)hipMemcpyAsync(a->d_poff, poff.data(), sizeof(int32_t) * poff.size(), hipMemcpyHostToDevice, ctx->s_main);
+            (void)hipMemcpyAsync(a->d_pval, pval.data(), sizeof(double) * pval.size(), hipMemcpyHostToDevice, ctx->s_main);
+            (void)hipStreamSynchronize(ctx->s_main);
+            a->npat = 256; a->ntab = (int32_t)poff.size(); a->pat_unroll = 7;
+            (void)hipMemsetAsync(a->d_pid, 0, sizeof(uint16_t) * (size_t)((nloc + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE), ctx->s_main);
         }
         (void)hipMemsetAsync(a->d_col + nnz, 0, sizeof(int32_t) * 8, ctx->s_main);
         (void)hipMemsetAsync(a->d_val + nnz, 0, sizeof(double) * 8, ctx->s_main);
         const int64_t nthreads = nloc + 1;
         hipLaunchKernelGGL(stencil7_gen_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->s_main, N, lo, hi,
-                           has_lower ? N2 : 0, sc, a->d_row_ptr, a->d_col, a->d_val, a->d_code);
+                           has_lower ? N2 : 0, sc, a->d_row_ptr, a->d_col, a->d_val, a->d_code, a->d_code16, a->d_pid);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("stencil7 generation failed"); rc = KRYST_ERR_HIP; break; }
         a->ntiles = ntiles_of(nloc);
         a->slots = 7;
@@ -708,7 +1159,8 @@ int32_t kryst_csr_destroy(kryst_csr_t a) {
     (void)hipSetDevice(a->ctx->device);
     (void)hipStreamSynchronize(a->ctx->s_main);
     (void)hipStreamSynchronize(a->ctx->s_comm);
-    (void)hipFree(a->d_row_ptr); (void)hipFree(a->d_col); (void)hipFree(a->d_val); (void)hipFree(a->d_code); (void)hipFree(a->d_dict);
+    (void)hipFree(a->d_row_ptr); (void)hipFree(a->d_col); (void)hipFree(a->d_val); (void)hipFree(a->d_code); (void)hipFree(a->d_dict); (void)hipFree(a->d_code16); (void)hipFree(a->d_vdict);
+    (void)hipFree(a->d_pid); (void)hipFree(a->d_pmeta); (void)hipFree(a->d_poff); (void)hipFree(a->d_pval);
     (void)hipFree(a->d_tiles_interior); (void)hipFree(a->d_tiles_boundary);
     (void)hipFree(a->plan.d_send_idx); (void)hipFree(a->plan.d_sendbuf); (void)hipFree(a->plan.d_halo);
     delete a;
@@ -744,6 +1196,21 @@ int32_t kryst_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y) {
     KR_ARG(x->d != y->d, "spmv: x and y alias");
     KR_HIP(hipSetDevice(a->ctx->device));
     return launch_spmv(a, x->d, y->d, 0, nullptr, nullptr);
+}
+
+// which encoding kryst_spmv streams for this operator under the current KRYST_SPMV_COMPRESS setting:
+// 0 plain CSR (12 B/nnz), 1 CSR-D8 (9 B/nnz), 2 CSR-D16 (2 B/nnz), 3 CSR-P16 (2 B/row)
+int32_t kryst_csr_encoding(kryst_csr_t a, int32_t* encoding, int32_t* patterns, int32_t* table_entries) {
+    KR_ARG(a && encoding, "csr_encoding");
+    const int lvl = env_int("KRYST_SPMV_COMPRESS", 3);
+    int e = 0;
+    if (a->d_pid && lvl >= 3) e = 3;
+    else if (a->d_code16 && lvl >= 2) e = 2;
+    else if (a->d_code && lvl >= 1) e = 1;
+    *encoding = e;
+    if (patterns) *patterns = a->d_pid ? a->npat : 0;
+    if (table_entries) *table_entries = a->d_pid ? a->ntab : 0;
+    return KRYST_OK;
 }
 
 int32_t kryst_bench_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t fused_dots, int32_t reps, double* avg_ms) {

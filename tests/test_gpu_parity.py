@@ -87,10 +87,11 @@ def test_spmv_general_matrices_bit_exact(ctx):
         assert np.array_equal(to_dev(ctx, a).spmv(x), a.spmv(x)), (a.nrows, a.ncols, a.nnz)
 
 
-@pytest.mark.parametrize("kernel,compress", [("2", "0"), ("3", "0"), ("3", "1")])
+@pytest.mark.parametrize("kernel,compress", [("2", "0"), ("3", "0"), ("3", "1"), ("3", "2"), ("3", "3")])
 def test_spmv_kernel_forms_bit_exact(ctx, kernel, compress, monkeypatch):
-    """The products-in-LDS wave kernel, the rows kernel and the rows kernel with CSR-D8 index compression must all
-    reproduce the oracle bit for bit (and therefore each other), also where compression does not apply."""
+    """The products-in-LDS wave kernel, the rows kernel, the rows kernel with CSR-D8 index compression and the fully
+    dictionary-coded CSR-D16 kernel and the row-pattern CSR-P16 kernel must all reproduce the oracle bit for bit (and
+    therefore each other), also where compression does not apply."""
     monkeypatch.setenv("KRYST_SPMV_KERNEL", kernel)
     monkeypatch.setenv("KRYST_SPMV_COMPRESS", compress)
     rng = np.random.default_rng(21)
@@ -112,6 +113,41 @@ def test_spmv_kernel_forms_bit_exact(ctx, kernel, compress, monkeypatch):
     s = K.BiCgStabSolver(1e-7 * np.linalg.norm(b), 200); xx = np.zeros(ao.nrows)
     st = s.solve(a, None, b, xx)
     assert st.iterations == res.iterations and np.array_equal(xx, res.x) and np.array_equal(np.array(s.residual_history), res.history)
+
+
+@pytest.mark.parametrize("level", ["2", "3"])
+def test_spmv_value_dictionary_cases(ctx, level, monkeypatch):
+    """CSR-D16 (offset AND value dictionary): applies with <= 256 distinct value bit patterns, else falls back.
+    CSR-P16 (row patterns) on top: applies to the few-pattern cases below, falls back to D16 / D8 / plain otherwise."""
+    monkeypatch.setenv("KRYST_SPMV_COMPRESS", level)
+    rng = np.random.default_rng(99)
+
+    def with_values(a, pool):
+        v = rng.choice(pool, size=a.nnz)
+        return O.Csr(a.nrows, a.ncols, a.row_ptr, a.col_idx, v)
+
+    banded = lambda n, offs: O.Csr.from_dense(sum(np.diag(np.ones(n - abs(o)), o) for o in offs), keep_zeros=False)      # noqa: E731
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 1.7976931348623157e308, 0.1, 1 / 3])
+    cases = [
+        with_values(banded(700, range(-20, 21)), rng.standard_normal(256)),          # exactly 256 distinct values: D16
+        with_values(banded(700, range(-20, 21)), rng.standard_normal(257)),          # 257: CSR-D8 (offsets only)
+        with_values(banded(1300, [-600, -3, -1, 0, 1, 2, 600]), special),            # signed zeros, inf, nan, denormal
+        with_values(random_csr(rng, 1000, 777, lambda: rng.integers(0, 12)), [2.0, -1.0]),    # > 256 offsets: plain CSR
+        with_values(O.Csr.from_dense(np.ones((3, 2000))), np.arange(1.0, 100.0)),    # rows longer than a 1016-entry pass
+        with_values(O.Csr.from_dense(np.ones((130, 250))), [0.5, 0.25]),             # 250 entries per row, many windows
+        with_values(banded(4, [0]), [7.0]),
+        banded(5000, [-70, -1, 0, 1, 70]),                                           # 9 row patterns, several tiles
+        with_values(banded(3000, [-2, 0, 5]), [1.5, -0.0, np.nan]),                  # 3^3 value patterns x boundary shapes
+        O.Csr.from_dense(np.ones((600, 9))),                                         # one pattern per row (offsets differ): > KR_PMAX
+        O.Csr.from_dense(np.triu(np.ones((40, 40)))),                                # 40 patterns, 820 table entries
+        O.Csr.from_dense(np.triu(np.ones((46, 46)))),                                # 1081 table entries: > KR_TMAX, falls back
+        O.Csr(1030, 1030, [0] * 513 + [1] * 518, [512], [3.0]),                       # empty rows, one entry in the second tile
+    ]
+    for a in cases:
+        x = rng.standard_normal(a.ncols)
+        got, ref = to_dev(ctx, a).spmv(x), a.spmv(x)
+        assert np.array_equal(got, ref, equal_nan=True), (a.nrows, a.ncols, a.nnz)
+        assert np.array_equal(np.signbit(got), np.signbit(ref))
 
 
 def test_spmv_device_generator_matches_host(ctx):
