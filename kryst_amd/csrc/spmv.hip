@@ -37,7 +37,8 @@ struct SpmvArgs {
     const uint16_t* code16; const double* vdict;   // CSR-D16: col = row + dict[c & 255], val = vdict[c >> 8]
     const uint16_t* pid; const uint32_t* pmeta; const int32_t* poff; const double* pval; int32_t npat, ntab;   // CSR-P16
     int32_t pat_red_off;                           // byte offset of the reduction scratch in the kernel's dynamic LDS
-    int32_t xhi;                                   // number of addressable x entries (local + halo)
+    int32_t nloc8;                                 // 8 * nloc
+    int32_t tpw;                                   // pattern kernel: consecutive tile slots per workgroup
 };
 constexpr int KR_PMAX = 512;        // CSR-P16 limits: patterns and (padded) table entries held in LDS: 2 + 12 + 24 KiB at most
 constexpr int KR_TMAX = 2048;
@@ -389,96 +390,112 @@ __global__ __launch_bounds__(KR_T) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 // reads x[2t + off_e] and x[2t + 1 + off_e] -- one dwordx4 load -- and one table lookup serves both rows.  Row pairs with
 // different bases take the two-loads-per-entry path.  x is addressed with 32-bit byte offsets from a scalar base (the
 // launch checks xlen < 2^28).
+// x[c8 / 8] for a byte offset c8 >= 0 (local entries below nloc8, halo entries above)
 template <bool HALO>
-__device__ __forceinline__ const char* gather_base(const SpmvArgs& a, int32_t c) {
-    if constexpr (HALO) return (c < a.nloc) ? reinterpret_cast<const char*>(a.x) : reinterpret_cast<const char*>(a.halo - a.nloc);
+__device__ __forceinline__ const char* gather_base8(const SpmvArgs& a, int32_t c8) {
+    if constexpr (HALO) return (c8 < a.nloc8) ? reinterpret_cast<const char*>(a.x) : reinterpret_cast<const char*>(a.halo) - a.nloc8;
     else return reinterpret_cast<const char*>(a.x);
 }
 template <bool HALO>
-__device__ __forceinline__ double gather32(const SpmvArgs& a, int32_t c) {
-    return *reinterpret_cast<const double*>(gather_base<HALO>(a, c) + ((size_t)(uint32_t)c << 3));
+__device__ __forceinline__ double gather8(const SpmvArgs& a, int32_t c8) {
+    return *reinterpret_cast<const double*>(gather_base8<HALO>(a, c8) + (uint32_t)c8);
 }
 
-template <int NQ, bool HALO, int U>
+// SINGLE: no base is longer than U entries (true for every stencil operator), so the entry loop has one trip
+template <int NQ, bool HALO, int U, bool SINGLE>
 __global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {
     if (a.done && *a.done) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* pval = reinterpret_cast<double*>(smem);                                   // ntab + U entries
-    int32_t* poff = reinterpret_cast<int32_t*>(pval + a.ntab + U);
+    int32_t* poff = reinterpret_cast<int32_t*>(pval + a.ntab + U);                    // BYTE offsets: 8 * (col - row)
     uint2* meta = reinterpret_cast<uint2*>(poff + a.ntab + U + ((a.ntab + U) & 1));   // 8-byte aligned
     double* red = reinterpret_cast<double*>(smem + a.pat_red_off);
     const int t = threadIdx.x;
     for (int i = t; i < a.npat; i += KR_T) meta[i] = reinterpret_cast<const uint2*>(a.pmeta)[i];
-    for (int i = t; i < a.ntab + U; i += KR_T) { poff[i] = i < a.ntab ? a.poff[i] : 0; pval[i] = i < a.ntab ? a.pval[i] : 0.0; }
+    for (int i = t; i < a.ntab + U; i += KR_T) { poff[i] = i < a.ntab ? 8 * a.poff[i] : 0; pval[i] = i < a.ntab ? a.pval[i] : 0.0; }
     __syncthreads();
-    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, per = gridDim.x >> 3;
+    // workgroup b of XCD x owns the tpw CONSECUTIVE tile slots [b*tpw, (b+1)*tpw) of that XCD's share; workgroups are
+    // handed out in order by the dispatcher, so the tiles in flight on an XCD stay a compact window of the grid and the
+    // x planes they share stay in its L2 (a strided persistent loop lets fast workgroups run ahead: 2.5x the x traffic)
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, tpw = a.tpw;
+    const int li_end = min((slot0 + 1) * tpw, a.xcd_chunk);
     auto tile_of = [&](int li) -> int {
-        if (li >= a.xcd_chunk) return -1;
-        const int ti = ((li / a.group) * 8 + xcd) * a.group + (li % a.group);
+        if (li >= li_end) return -1;
+        const int ti = a.swizzle ? xcd * a.xcd_chunk + li : ((li / a.group) * 8 + xcd) * a.group + (li % a.group);
         if (ti >= a.ntiles) return -1;
         return a.tiles ? a.tiles[ti] : ti;
     };
-    const int32_t xhi = a.xhi;                                      // 16-byte gathers need 0 <= c and c + 1 < xhi
-    int q = tile_of(slot0);
+    int q = tile_of(slot0 * tpw);
     unsigned ids = 0;
     if (q >= 0) ids = *reinterpret_cast<const unsigned*>(a.pid + (size_t)q * KR_TILE + 2 * t);   // rows 2t, 2t+1 (padded array)
-    for (int li = slot0; li < a.xcd_chunk; li += per) {
-        const int qn = tile_of(li + per);                           // prefetch the next tile's ids
+    for (int li = slot0 * tpw; li < li_end; ++li) {
+        const int qn = tile_of(li + 1);                             // prefetch the next tile's ids
         unsigned ids_n = 0;
         if (qn >= 0) ids_n = *reinterpret_cast<const unsigned*>(a.pid + (size_t)qn * KR_TILE + 2 * t);
         if (q >= 0) {
             const int r0 = q * KR_TILE;
             const int r1 = min(r0 + KR_TILE, a.nrows);
             const int row = r0 + 2 * t;
+            const int32_t row8 = row << 3;                          // xlen < 2^28: byte offsets fit 31 bits
             const bool va = row < r1, vb = row + 1 < r1;
             uint2 ma = va ? meta[ids & 0xffffu] : make_uint2(0u, 0u), mb = vb ? meta[ids >> 16] : make_uint2(0u, 0u);
             double s0 = 0.0, s1 = 0.0;
             if (ma.x == mb.x) {
-                // ---- same base: one table lookup and one 16-byte gather per entry serve both rows
+                // ---- same base: one table lookup and one 16-byte gather per entry serve both rows.  An entry is needed if
+                // either row has it; a needed entry addresses x[c], x[c + 1] with c >= -1 (c = -1: only row 2t+1 has it and
+                // its column is 0) and c + 1 <= xlen (c + 1 = xlen: only row 2t has it; x is padded at the end).
                 const int len = ma.x >> 16;
                 const double* tv = pval + (ma.x & 0xffffu); const int32_t* to = poff + (ma.x & 0xffffu);
-                for (int e0 = 0; e0 < len; e0 += U) {
-                    v2d xx[U];
-                    const unsigned ka = e0 < 16 ? (ma.y >> e0) : 0xffffffffu, kb = e0 < 16 ? (mb.y >> e0) : 0xffffffffu;
+                for (int e0 = 0; e0 < (SINGLE ? 1 : len); e0 += U) {
+                    // masks of the entries e0 .. e0+U-1 (a mask never has bits at or beyond the base length; bases longer than 16
+                    // entries have no sub-patterns: all ones up to the length)
+                    unsigned ka, kb;
+                    if constexpr (SINGLE) { ka = ma.y; kb = mb.y; }
+                    else {
+                        const unsigned lim = (len - e0 >= 32) ? 0xffffffffu : ((1u << (len - e0)) - 1u);
+                        ka = (e0 < 16 ? (ma.y >> e0) : 0xffffffffu) & lim; kb = (e0 < 16 ? (mb.y >> e0) : 0xffffffffu) & lim;
+                    }
+                    const unsigned kk = ka | kb;
+                    int32_t c8[U];
+                    int32_t any = 0;
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const bool na = (e0 + u < len) && ((ka >> u) & 1u), nb = (e0 + u < len) && ((kb >> u) & 1u);
-                        const int32_t c = row + to[e0 + u];
-                        xx[u].x = 0.0; xx[u].y = 0.0;
-                        if ((na || nb) && (uint32_t)c < (uint32_t)(xhi - 1) && !(HALO && c == a.nloc - 1)) {
-                            xx[u] = *reinterpret_cast<const v2d*>(gather_base<HALO>(a, na ? c : c + 1) + ((size_t)(uint32_t)c << 3));
-                        } else {                                    // first / last element of x: one guarded load per row
-                            if (na) xx[u].x = gather32<HALO>(a, c);
-                            if (nb) xx[u].y = gather32<HALO>(a, c + 1);
+                        c8[u] = ((kk >> u) & 1u) ? row8 + to[e0 + u] : row8;
+                        any |= c8[u];
+                    }
+                    v2d xx[U];
+                    if (HALO || __builtin_amdgcn_ballot_w64(any < 0) != 0) {
+                        // rare: some lane's pair starts one element before x (or the tile touches halo planes)
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            xx[u].x = 0.0; xx[u].y = 0.0;
+                            if ((ka >> u) & 1u) xx[u].x = gather8<HALO>(a, c8[u]);
+                            if ((kb >> u) & 1u) xx[u].y = gather8<HALO>(a, c8[u] + 8);
                         }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            xx[u] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(a.x) + (uint32_t)c8[u]);
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const double v = tv[e0 + u];
-                        if ((e0 + u < len) && ((ka >> u) & 1u)) s0 = s0 + v * xx[u].x;
-                        if ((e0 + u < len) && ((kb >> u) & 1u)) s1 = s1 + v * xx[u].y;
+                        const double ta = s0 + v * xx[u].x, tb = s1 + v * xx[u].y;
+                        s0 = ((ka >> u) & 1u) ? ta : s0;
+                        s1 = ((kb >> u) & 1u) ? tb : s1;
                     }
                 }
             } else {
-                // ---- different bases: each row walks its own
+                // ---- different bases (rare: adjacent rows built from unrelated stencils): each row walks its own, one entry
+                // at a time -- kept deliberately small so that it does not cost the common path registers
                 const int la = ma.x >> 16, lb = mb.x >> 16;
                 const double* tva = pval + (ma.x & 0xffffu); const int32_t* toa = poff + (ma.x & 0xffffu);
                 const double* tvb = pval + (mb.x & 0xffffu); const int32_t* tob = poff + (mb.x & 0xffffu);
-                for (int e0 = 0; e0 < max(la, lb); e0 += U) {
-                    double xa[U], xb[U];
-                    const unsigned ka = e0 < 16 ? (ma.y >> e0) : 0xffffffffu, kb = e0 < 16 ? (mb.y >> e0) : 0xffffffffu;
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int ea = min(e0 + u, max(la - 1, 0)), eb = min(e0 + u, max(lb - 1, 0));
-                        xa[u] = ((e0 + u < la) && ((ka >> u) & 1u)) ? gather32<HALO>(a, row + toa[ea]) : 0.0;
-                        xb[u] = ((e0 + u < lb) && ((kb >> u) & 1u)) ? gather32<HALO>(a, row + 1 + tob[eb]) : 0.0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int ea = min(e0 + u, max(la - 1, 0)), eb = min(e0 + u, max(lb - 1, 0));
-                        if ((e0 + u < la) && ((ka >> u) & 1u)) s0 = s0 + tva[ea] * xa[u];
-                        if ((e0 + u < lb) && ((kb >> u) & 1u)) s1 = s1 + tvb[eb] * xb[u];
-                    }
+#pragma unroll 1
+                for (int e = 0; e < max(la, lb); ++e) {
+                    const bool ia = e < la && (e >= 16 || ((ma.y >> e) & 1u)), ib = e < lb && (e >= 16 || ((mb.y >> e) & 1u));
+                    if (ia) s0 = s0 + tva[e] * gather8<HALO>(a, row8 + toa[e]);
+                    if (ib) s1 = s1 + tvb[e] * gather8<HALO>(a, row8 + 8 + tob[e]);
                 }
             }
             if (vb) st2(a.y, row, s0, s1);
@@ -544,22 +561,22 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
     args.code16 = a->d_code16; args.vdict = a->d_vdict;
     args.pid = a->d_pid; args.pmeta = a->d_pmeta; args.poff = a->d_poff; args.pval = a->d_pval; args.npat = a->npat; args.ntab = a->ntab;
     if (a->d_pid && comp_level >= 3 && a->xlen + (HALO ? a->plan.total_recv : 0) < (1ll << 28)) {
-        // the pattern kernel keeps its tables in LDS, so workgroups loop over several tiles (next tile's ids prefetched);
-        // 6 resident workgroups per CU (65 VGPRs -> 7 waves per SIMD) and runs of 8 consecutive tiles per XCD measured best
-        // (tools/p16_tune.sh: 0.77 ms at 512^3 against 0.95 ms with 8 per CU and round-robin tiles)
-        const int pbpc = env_int("KRYST_SPMV_PATTERN_BLOCKS_PER_CU", 6);
+        // a workgroup loads the tables once and walks one run of 8 consecutive tiles (next tile's ids prefetched); runs go
+        // round-robin over the XCDs.  Measured at 512^3 (tools/p16_tune5.sh, tools/p16_pmc.sh): 0.70 ms and 1.6 GB of reads
+        // per launch, against 0.79 ms and 4.1 GB for a strided persistent grid whose fast workgroups run ahead.
         args.group = std::max(1, env_int("KRYST_SPMV_GROUP", 8));
         const int64_t pchunk = (chunk + args.group - 1) / args.group * args.group;      // an XCD's share is a whole number of runs
         args.xcd_chunk = (int32_t)pchunk;
-        const int64_t pper = pbpc > 0 ? std::min<int64_t>(pchunk, std::max<int64_t>(1, (int64_t)ctx->num_cu * pbpc / 8)) : pchunk;
+        args.tpw = std::max(1, env_int("KRYST_SPMV_PATTERN_TPW", 8));
+        const int64_t pper = (pchunk + args.tpw - 1) / args.tpw;
         const dim3 pgrid((unsigned)(pper * 8));
         const int U = a->pat_unroll;
         const size_t tab = (size_t)(a->ntab + U + 1) * 12 + (size_t)a->npat * 8;
         args.pat_red_off = (int32_t)((tab + 15) & ~(size_t)15);
-        args.xhi = (int32_t)(a->xlen + (HALO ? a->plan.total_recv : 0));
+        args.nloc8 = (int32_t)(a->nrows * 8);
         const size_t lds = (size_t)args.pat_red_off + sizeof(double) * (size_t)(nq > 0 ? nq : 1) * (KR_T / 64);
-#define KR_PAT(NQ_, U_) hipLaunchKernelGGL((spmv_pattern_kernel<NQ_, HALO, U_>), pgrid, block, lds, ctx->s_main, args)
-#define KR_PAT_BY(NQ_) do { if (U == 7) KR_PAT(NQ_, 7); else KR_PAT(NQ_, 8); } while (0)
+#define KR_PAT(NQ_, U_, S_) hipLaunchKernelGGL((spmv_pattern_kernel<NQ_, HALO, U_, S_>), pgrid, block, lds, ctx->s_main, args)
+#define KR_PAT_BY(NQ_) do { if (U == 7) KR_PAT(NQ_, 7, true); else if (a->pat_single) KR_PAT(NQ_, 8, true); else KR_PAT(NQ_, 8, false); } while (0)
         switch (nq) {
             case 0: KR_PAT_BY(0); break;
             case 1: KR_PAT_BY(1); break;
@@ -746,7 +763,7 @@ static int32_t build_patterns(kryst_csr_t a, const std::vector<int32_t>& rp, con
         if ((int)o2.size() > KR_TMAX || o2.size() > 0xffffu) return KRYST_OK;
         meta.swap(m2); poff.swap(o2); pval.swap(v2);
     }
-    a->pat_unroll = U;
+    a->pat_unroll = U; a->pat_single = maxlen <= U;
     return upload_patterns(a, pid, meta, poff, pval);
 }
 
@@ -1087,7 +1104,7 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
             (void)hipMemcpyAsync(a->d_poff, poff.data(), sizeof(int32_t) * poff.size(), hipMemcpyHostToDevice, ctx->s_main);
             (void)hipMemcpyAsync(a->d_pval, pval.data(), sizeof(double) * pval.size(), hipMemcpyHostToDevice, ctx->s_main);
             (void)hipStreamSynchronize(ctx->s_main);
-            a->npat = 256; a->ntab = (int32_t)poff.size(); a->pat_unroll = 7;
+            a->npat = 256; a->ntab = (int32_t)poff.size(); a->pat_unroll = 7; a->pat_single = true;
             (void)hipMemsetAsync(a->d_pid, 0, sizeof(uint16_t) * (size_t)((nloc + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE), ctx->s_main);
         }
         (void)hipMemsetAsync(a->d_col + nnz, 0, sizeof(int32_t) * 8, ctx->s_main);
