@@ -134,6 +134,10 @@ int32_t kryst_pc_ilup(kryst_csr_t a, int32_t fill, kryst_pc_t* out);
 int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kryst_pc_t* out);
 int32_t kryst_pc_chebyshev_stub(kryst_ctx_t ctx, int32_t degree, kryst_pc_t* out);  /* Chebyshev trait object: apply -> SolveError, chebyshev.rs:68-70 */
 int32_t kryst_pc_chebyshev(kryst_csr_t a, double alpha, double beta, int32_t degree, kryst_pc_t* out); /* extension: apply == apply_chebyshev */
+/* ApproxInv with GIVEN inverse rows (ApproxInv::inv_rows, approxinv.rs:66): apply (approxinv.rs:268-298) is the sparse-row
+ * product z = M r, i.e. kryst_spmv with M.  m is borrowed (must outlive the preconditioner).  ApproxInv::setup -- a
+ * least-squares fit per column through faer's QR (approxinv.rs:129-264) -- stays on the host with the reference. */
+int32_t kryst_pc_approx_inverse(kryst_csr_t m, kryst_pc_t* out);
 int32_t kryst_pc_apply(kryst_pc_t pc, kryst_vec_t r, kryst_vec_t z);                /* Preconditioner::apply */
 int32_t kryst_pc_destroy(kryst_pc_t pc);
 /* apply_chebyshev(a, r, z, alpha, beta, m), src/preconditioner/chebyshev.rs:83-140 */
@@ -216,6 +220,12 @@ int32_t kryst_host_partition_rows(int64_t n, int32_t nranks, int64_t align, int6
 int64_t kryst_host_halo_recv_plan(int32_t rank, int32_t nranks, const int64_t* row_offsets,
                                   const int64_t* row_ptr, const int64_t* col_idx_global,
                                   int64_t* recv_counts, int64_t* recv_cols);
+
+/* Matrix Market coordinate file -> CSR (0-based, rows sorted, symmetric / skew-symmetric storage expanded, duplicates summed;
+ * real, integer and pattern fields).  Returns nnz, or -1 (kryst_hip_last_error() says why).  Call with NULL arrays to size,
+ * then with row_ptr[nrows+1], col_idx[nnz], vals[nnz].  The reference has no file I/O. */
+int64_t kryst_host_read_matrix_market(const char* path, int64_t* nrows, int64_t* ncols, int64_t* row_ptr,
+                                      int64_t* col_idx, double* vals);
 
 #ifdef __cplusplus
 }

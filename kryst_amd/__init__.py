@@ -22,9 +22,9 @@ from . import _ffi
 from ._ffi import KError, lib, check
 
 __all__ = ["Context", "DeviceVec", "CsrMatrix", "dot", "norm", "Jacobi", "Ilu0", "Ilup", "Ilut", "TrueIlu0", "Chebyshev",
-           "ChebyshevPc", "IdentityPc", "apply_chebyshev", "Convergence", "SolveStats", "CgNormType",
+           "ChebyshevPc", "IdentityPc", "ApproxInv", "apply_chebyshev", "Convergence", "SolveStats", "CgNormType",
            "Preconditioning", "CgSolver", "PcgSolver", "GmresSolver", "FgmresSolver", "Orthog", "CgsSolver", "TfqmrSolver", "BiCgStabSolver", "BiCgStabRightPcSolver", "Session", "KspContext", "SolverKind", "KError", "reduce_spec",
-           "host_stencil7", "partition_rows", "halo_recv_plan"]
+           "host_stencil7", "partition_rows", "halo_recv_plan", "read_matrix_market"]
 
 
 def _dp(a):
@@ -215,6 +215,11 @@ class CsrMatrix:
         check(lib().kryst_csr_create_dist(ctx.h, n_global, ro.ctypes.data_as(_ffi.c_i64p), rp.ctypes.data_as(_ffi.c_i64p),
                                           ci.ctypes.data_as(_ffi.c_i64p), _dp(va), C.byref(h)))
         return CsrMatrix(ctx, h)
+
+    @staticmethod
+    def from_matrix_market(path, ctx=None):
+        nr, nc, rp, ci, va = read_matrix_market(path)
+        return CsrMatrix.from_csr(nr, nc, rp, ci, va, ctx=ctx)
 
     @staticmethod
     def stencil7(N, kind="poisson", ctx=None):
@@ -421,6 +426,31 @@ class IdentityPc(_Pc):
         h = _ffi.Handle()
         check(lib().kryst_pc_identity(a.ctx.h, C.byref(h)))
         self._set(a.ctx, h)
+        return self
+
+
+class ApproxInv(_Pc):
+    """ApproxInv (SPAI) with given inverse rows: `inv_rows[i]` = [(col, value), ...] in ascending column order, the layout of
+    ApproxInv::inv_rows (src/preconditioner/approxinv.rs:66).  apply (approxinv.rs:268-298) is z = M r on the device.
+    ApproxInv::setup (per-column least squares through faer's QR, approxinv.rs:129-264) stays with the reference: compute the
+    rows there and hand them over; setup() here only checks the size against the operator."""
+
+    def __init__(self, inv_rows, ctx=None):
+        super().__init__()
+        n = len(inv_rows)
+        rp = np.zeros(n + 1, dtype=np.int64)
+        for i, row in enumerate(inv_rows):
+            rp[i + 1] = rp[i] + len(row)
+        ci = np.array([c for row in inv_rows for c, _ in row], dtype=np.int64)
+        va = np.array([v for row in inv_rows for _, v in row], dtype=np.float64)
+        self.m = CsrMatrix.from_csr(n, n, rp, ci, va, ctx=ctx)
+        h = _ffi.Handle()
+        check(lib().kryst_pc_approx_inverse(self.m.h, C.byref(h)))
+        self._set(self.m.ctx, h)
+
+    def setup(self, a):
+        if a.nrows() != self.m.nrows():
+            raise KError(102, "ApproxInv: inverse rows and operator differ in size")
         return self
 
 
@@ -710,6 +740,20 @@ class Session:
 
 
 # ----------------------------------------------------------------------------- host-only helpers
+def read_matrix_market(path):
+    """Matrix Market coordinate file -> (nrows, ncols, row_ptr, col_idx, vals) (host only; kryst_host_read_matrix_market)."""
+    nr, nc = C.c_int64(0), C.c_int64(0)
+    nnz = lib().kryst_host_read_matrix_market(str(path).encode(), C.byref(nr), C.byref(nc), None, None, None)
+    if nnz < 0:
+        raise KError(102, lib().kryst_hip_last_error().decode())
+    rp = np.zeros(nr.value + 1, dtype=np.int64); ci = np.zeros(max(nnz, 1), dtype=np.int64); va = np.zeros(max(nnz, 1))
+    got = lib().kryst_host_read_matrix_market(str(path).encode(), C.byref(nr), C.byref(nc), rp.ctypes.data_as(_ffi.c_i64p),
+                                              ci.ctypes.data_as(_ffi.c_i64p), _dp(va))
+    if got != nnz:
+        raise KError(102, "matrix market file changed while reading")
+    return nr.value, nc.value, rp, ci[:nnz], va[:nnz]
+
+
 def host_stencil7(N, kind="poisson", k_lo=0, k_hi=None):
     k_hi = N if k_hi is None else k_hi
     kk = {"poisson": 0, "aniso": 1, "convdiff": 2}[kind]

@@ -80,6 +80,7 @@ SIGNATURES = {
     "kryst_pc_ilut": (C.c_int32, [Handle, C.c_int32, C.c_double, C.POINTER(Handle)]),
     "kryst_pc_chebyshev_stub": (C.c_int32, [Handle, C.c_int32, C.POINTER(Handle)]),
     "kryst_pc_chebyshev": (C.c_int32, [Handle, C.c_double, C.c_double, C.c_int32, C.POINTER(Handle)]),
+    "kryst_pc_approx_inverse": (C.c_int32, [Handle, C.POINTER(Handle)]),
     "kryst_pc_apply": (C.c_int32, [Handle, Handle, Handle]),
     "kryst_pc_destroy": (C.c_int32, [Handle]),
     "kryst_apply_chebyshev": (C.c_int32, [Handle, Handle, Handle, C.c_double, C.c_double, C.c_int64]),
@@ -103,6 +104,7 @@ SIGNATURES = {
     "kryst_session_end": (C.c_int32, [Handle, C.POINTER(Stats), c_dp, C.c_int64, c_i64p]),
     "kryst_host_stencil7": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i64p, c_i64p, c_dp]),
     "kryst_host_partition_rows": (C.c_int32, [C.c_int64, C.c_int32, C.c_int64, c_i64p]),
+    "kryst_host_read_matrix_market": (C.c_int64, [C.c_char_p, c_i64p, c_i64p, c_i64p, c_i64p, c_dp]),
     "kryst_host_halo_recv_plan": (C.c_int64, [C.c_int32, C.c_int32, c_i64p, c_i64p, c_i64p, c_i64p, c_i64p]),
 }
 

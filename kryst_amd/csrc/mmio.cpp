@@ -1,0 +1,70 @@
+// Host-side Matrix Market reader (the reference has no file I/O at all, so real matrices could not
+// reach its solvers; this feeds CsrMatrix::from_csr / kryst_csr_create).  No GPU involved.
+//
+// Supported: "%%MatrixMarket matrix coordinate {real|integer|pattern} {general|symmetric|skew-symmetric}".
+// Entries are sorted by (row, column); symmetric / skew-symmetric files are expanded to full storage; duplicate
+// coordinates are summed in file order (assembled files have none).  pattern entries get the value 1.0.
+#include "common.h"
+#include <algorithm>
+#include <cctype>
+#include <fstream>
+#include <sstream>
+
+namespace {
+struct Entry { int64_t r, c; double v; int64_t seq; };
+
+bool parse(const char* path, int64_t& nr, int64_t& nc, std::vector<Entry>& e) {
+    std::ifstream f(path);
+    if (!f) { kr::set_error("matrix market: cannot open %s", path); return false; }
+    std::string line;
+    if (!std::getline(f, line)) { kr::set_error("matrix market: empty file"); return false; }
+    std::string lower(line);
+    std::transform(lower.begin(), lower.end(), lower.begin(), [](unsigned char ch) { return (char)std::tolower(ch); });
+    std::istringstream hs(lower);
+    std::string banner, object, format, field, symmetry;
+    hs >> banner >> object >> format >> field >> symmetry;
+    if (banner != "%%matrixmarket" || object != "matrix" || format != "coordinate") {
+        kr::set_error("matrix market: only 'matrix coordinate' files are supported"); return false;
+    }
+    const bool pattern = field == "pattern";
+    if (!pattern && field != "real" && field != "integer") { kr::set_error("matrix market: field '%s' not supported", field.c_str()); return false; }
+    const bool sym = symmetry == "symmetric", skew = symmetry == "skew-symmetric";
+    if (!sym && !skew && symmetry != "general") { kr::set_error("matrix market: symmetry '%s' not supported", symmetry.c_str()); return false; }
+    while (std::getline(f, line)) { if (!line.empty() && line[0] != '%') break; }
+    int64_t nz = 0;
+    { std::istringstream ss(line); if (!(ss >> nr >> nc >> nz) || nr < 0 || nc < 0 || nz < 0) { kr::set_error("matrix market: bad size line"); return false; } }
+    e.clear(); e.reserve((size_t)(sym || skew ? 2 * nz : nz));
+    for (int64_t k = 0; k < nz; ++k) {
+        int64_t r, c; double v = 1.0;
+        if (!(f >> r >> c)) { kr::set_error("matrix market: entry %lld missing", (long long)k); return false; }
+        if (!pattern && !(f >> v)) { kr::set_error("matrix market: value of entry %lld missing", (long long)k); return false; }
+        if (r < 1 || r > nr || c < 1 || c > nc) { kr::set_error("matrix market: entry %lld out of range", (long long)k); return false; }
+        e.push_back(Entry{r - 1, c - 1, v, (int64_t)e.size()});
+        if ((sym || skew) && r != c) e.push_back(Entry{c - 1, r - 1, skew ? -v : v, (int64_t)e.size()});
+    }
+    std::sort(e.begin(), e.end(), [](const Entry& a, const Entry& b) { return a.r != b.r ? a.r < b.r : (a.c != b.c ? a.c < b.c : a.seq < b.seq); });
+    size_t w = 0;                                            // sum duplicates in file order
+    for (size_t k = 0; k < e.size(); ++k) {
+        if (w > 0 && e[w - 1].r == e[k].r && e[w - 1].c == e[k].c) e[w - 1].v = e[w - 1].v + e[k].v;
+        else e[w++] = e[k];
+    }
+    e.resize(w);
+    return true;
+}
+}  // namespace
+
+extern "C" int64_t kryst_host_read_matrix_market(const char* path, int64_t* nrows, int64_t* ncols, int64_t* row_ptr,
+                                                 int64_t* col_idx, double* vals) {
+    if (!path || !nrows || !ncols) { kr::set_error("bad argument: read_matrix_market"); return -1; }
+    std::vector<Entry> e;
+    int64_t nr = 0, nc = 0;
+    if (!parse(path, nr, nc, e)) return -1;
+    *nrows = nr; *ncols = nc;
+    if (row_ptr && col_idx && vals) {
+        for (int64_t i = 0; i <= nr; ++i) row_ptr[i] = 0;
+        for (const Entry& x : e) row_ptr[x.r + 1] += 1;
+        for (int64_t i = 0; i < nr; ++i) row_ptr[i + 1] += row_ptr[i];
+        for (size_t k = 0; k < e.size(); ++k) { col_idx[k] = e[k].c; vals[k] = e[k].v; }
+    }
+    return (int64_t)e.size();
+}

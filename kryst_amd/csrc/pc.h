@@ -2,7 +2,7 @@
 #pragma once
 #include "csr.h"
 
-enum { KR_PC_IDENTITY = 1, KR_PC_JACOBI = 2, KR_PC_ILU = 3, KR_PC_CHEB_STUB = 6, KR_PC_CHEB = 7 };
+enum { KR_PC_IDENTITY = 1, KR_PC_JACOBI = 2, KR_PC_ILU = 3, KR_PC_CHEB_STUB = 6, KR_PC_CHEB = 7, KR_PC_SPAI = 9 };
 
 struct kryst_pc_s {
     kryst_ctx_t ctx = nullptr;

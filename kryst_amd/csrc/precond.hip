@@ -107,6 +107,8 @@ int32_t pc_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done)
             return KRYST_SOLVE_ERROR;
         case KR_PC_CHEB:
             return chebyshev_dev(pc->a, r, z, pc->cheb_alpha, pc->cheb_beta, pc->cheb_degree, pc->d_v0, pc->d_v1, pc->d_v2, done);
+        case KR_PC_SPAI:      // ApproxInv::apply (approxinv.rs:268-298): z_i = sum_j M_ij r_j, ascending j from 0 -- an SpMV with M
+            return launch_spmv(pc->a, r, z, 0, nullptr, done);
         default: set_error("unknown preconditioner kind %d", pc->kind); return KRYST_UNSUPPORTED;
     }
 }
@@ -183,6 +185,15 @@ int32_t kryst_pc_apply(kryst_pc_t pc, kryst_vec_t r, kryst_vec_t z) {
         return pc_apply_dev(&tmp, r->d, z->d, nullptr);
     }
     return pc_apply_dev(pc, r->d, z->d, nullptr);
+}
+
+int32_t kryst_pc_approx_inverse(kryst_csr_t m, kryst_pc_t* out) {
+    KR_ARG(m && out, "pc_approx_inverse");
+    KR_ARG(m->nrows == m->xlen, "pc_approx_inverse: the inverse rows must form a square operator");
+    kryst_pc_t pc = new kryst_pc_s();
+    pc->ctx = m->ctx; pc->kind = KR_PC_SPAI; pc->a = m; pc->n = m->nrows;
+    *out = pc;
+    return KRYST_OK;
 }
 
 int32_t kryst_pc_destroy(kryst_pc_t pc) {

@@ -441,6 +441,7 @@ int32_t kro_pc_apply(const kro_pc_t* pc, const double* r, double* z, int64_t n) 
     case KRO_PC_JACOBI: { PFOR(i, n) z[i] = pc->inv_diag[i] * r[i]; return KRO_OK; }               /* jacobi.rs:84-92 */
     case KRO_PC_ILU0_COMPAT: case KRO_PC_ILUP0: case KRO_PC_ILU0_TRUE: tri_apply(pc, r, z, n); return KRO_OK;
     case KRO_PC_TRIROWS: trirows_apply(pc->rows, r, z); return KRO_OK;
+    case KRO_PC_SPAI: kro_spmv(pc->a, r, z); return KRO_OK;                                         /* approxinv.rs:268-298 */
     case KRO_PC_CHEBYSHEV_STUB: return KRO_SOLVE_ERROR;                                             /* chebyshev.rs:68-70 */
     case KRO_PC_CHEBYSHEV: kro_apply_chebyshev(pc->a, r, z, n, pc->cheb_alpha, pc->cheb_beta, pc->cheb_degree); return KRO_OK;
     default: return KRO_UNSUPPORTED;

@@ -74,7 +74,8 @@ enum { KRO_PC_NONE = 0,       /* pc == None */
        KRO_PC_ILU0_TRUE = 5,  /* extension: textbook IKJ ILU(0) on A's pattern (Saad Alg. 10.4) */
        KRO_PC_CHEBYSHEV_STUB = 6, /* chebyshev.rs:68-70: apply returns Err(SolveError) */
        KRO_PC_CHEBYSHEV = 7,  /* extension: apply == apply_chebyshev(a, r, z, alpha, beta, m) */
-       KRO_PC_TRIROWS = 8     /* Ilup(p) / Ilut factors as explicit sparse rows (ilup.rs:54-59, ilut.rs:55-61) */ };
+       KRO_PC_TRIROWS = 8,    /* Ilup(p) / Ilut factors as explicit sparse rows (ilup.rs:54-59, ilut.rs:55-61) */
+       KRO_PC_SPAI = 9        /* ApproxInv::apply with given inv_rows (approxinv.rs:268-298): z = M r, M = pc->a */ };
 
 /* L and U as Vec<SparseRow> (ilup.rs:29-33): per row the (col, val) pairs IN STORED ORDER */
 typedef struct {

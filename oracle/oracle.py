@@ -235,6 +235,11 @@ class Pc:
         return Pc(PC_IDENTITY)
 
     @staticmethod
+    def approx_inverse(m):
+        """ApproxInv::apply with the given inverse rows as the CSR matrix m (approxinv.rs:268-298)."""
+        return Pc(9, m)
+
+    @staticmethod
     def jacobi(a):
         p = Pc(PC_JACOBI, a)
         p.inv_diag = np.empty(a.nrows)

@@ -79,3 +79,37 @@ def test_cpp_mirror_compiles_against_the_abi(tmp_path):
                         "-L" + os.path.join(ROOT, "kryst_amd", "lib"), "-lkryst_hip", "-Wl,-rpath,/opt/rocm/lib"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_matrix_market_reader(tmp_path):
+    """kryst_host_read_matrix_market (host only) against scipy.io.mmread on general / symmetric / skew / pattern / integer files,
+    a file with duplicates and an unsupported one."""
+    import scipy.io, scipy.sparse as sp
+    import kryst_amd as K
+    rng = np.random.default_rng(5)
+    g = sp.random(37, 23, density=0.2, random_state=1, format="coo")
+    s = sp.random(19, 19, density=0.3, random_state=2, format="coo"); s = (s + s.T).tocoo()
+    cases = {"general": (g, {}), "symmetric": (s, {"symmetry": "symmetric"}),
+             "pattern": (g, {"field": "pattern"}), "integer": ((g * 100).astype(np.int64), {"field": "integer"})}
+    for name, (m, kw) in cases.items():
+        path = tmp_path / f"{name}.mtx"
+        scipy.io.mmwrite(str(path), m, **kw)
+        ref = sp.csr_matrix(scipy.io.mmread(str(path)))
+        ref.sort_indices()
+        nr, nc, rp, ci, va = K.read_matrix_market(path)
+        assert (nr, nc) == ref.shape and np.array_equal(rp, ref.indptr) and np.array_equal(ci, ref.indices)
+        assert np.array_equal(va, ref.data.astype(np.float64)), name
+    (tmp_path / "skew.mtx").write_text("%%MatrixMarket matrix coordinate real skew-symmetric\n% comment\n3 3 2\n2 1 1.5\n3 1 -2\n")
+    nr, nc, rp, ci, va = K.read_matrix_market(tmp_path / "skew.mtx")
+    dense = np.zeros((3, 3))
+    for i in range(3):
+        dense[i, ci[rp[i]:rp[i + 1]]] = va[rp[i]:rp[i + 1]]
+    assert np.array_equal(dense, [[0, -1.5, 2.0], [1.5, 0, 0], [-2.0, 0, 0]])
+    (tmp_path / "dup.mtx").write_text("%%MatrixMarket matrix coordinate real general\n2 2 3\n1 1 1.0\n2 2 4.0\n1 1 0.5\n")
+    nr, nc, rp, ci, va = K.read_matrix_market(tmp_path / "dup.mtx")
+    assert list(rp) == [0, 1, 2] and list(ci) == [0, 1] and list(va) == [1.5, 4.0]
+    (tmp_path / "arr.mtx").write_text("%%MatrixMarket matrix array real general\n1 1\n1.0\n")
+    with pytest.raises(K.KError):
+        K.read_matrix_market(tmp_path / "arr.mtx")
+    with pytest.raises(K.KError):
+        K.read_matrix_market(tmp_path / "missing.mtx")

@@ -656,3 +656,36 @@ def test_max_iters_zero(ctx, rs):
         st = s.solve(d, None, b, x)
         assert (st.iterations, st.converged, st.final_residual) == (res.iterations, res.converged, res.final_residual), method
         assert np.array_equal(x, res.x)
+
+
+# ------------------------------------------------------------------------------------------------ SPAI apply (§8 f-4)
+def test_approx_inverse_apply_and_solve(ctx, rs):
+    """ApproxInv::apply with given inverse rows (approxinv.rs:268-298) = the sparse-row product on the device; inside PCG and
+    right-preconditioned GMRES it must match the oracle bit for bit."""
+    a = O.stencil7(8, "poisson")
+    d = to_dev(ctx, a)
+    # a crude sparse approximate inverse on A's own pattern: M = D^-1 (2I - A D^-1) restricted to the pattern (symmetric here)
+    dinv = 1.0 / np.array([a.vals[a.row_ptr[i]:a.row_ptr[i + 1]][list(a.col_idx[a.row_ptr[i]:a.row_ptr[i + 1]]).index(i)] for i in range(a.nrows)])
+    rows = []
+    for i in range(a.nrows):
+        row = []
+        for k in range(a.row_ptr[i], a.row_ptr[i + 1]):
+            j = int(a.col_idx[k])
+            v = (2.0 * dinv[i] if i == j else 0.0) - dinv[i] * a.vals[k] * dinv[j]
+            row.append((j, v))
+        rows.append(row)
+    kpc = K.ApproxInv(rows, ctx=ctx).setup(d)
+    m = O.Csr(a.nrows, a.nrows, a.row_ptr, a.col_idx, [v for row in rows for _, v in row])
+    opc = O.Pc.approx_inverse(m)
+    r = np.linspace(-1.0, 1.0, a.nrows)
+    assert np.array_equal(kpc.apply(r), opc.apply(r))
+    b = a.spmv(np.ones(a.nrows))
+    res = O.solve("pcg", a, b, pc=opc, tol=1e-10, max_iters=200, rs=rs)
+    s = K.PcgSolver(1e-10, 200); x = np.zeros(a.nrows)
+    _check_solver(res, s.solve(d, kpc, b, x), s, x)
+    assert res.converged and res.iterations < O.solve("cg", a, b, tol=1e-10, max_iters=200, rs=rs).iterations
+    res = O.solve("gmres", a, b, pc=opc, tol=1e-10, max_iters=60, restart=20, side=O.SIDE_RIGHT, rs=rs)
+    s = K.GmresSolver(20, 1e-10, 60).with_preconditioning(K.Preconditioning.Right); x = np.zeros(a.nrows)
+    _check_solver(res, s.solve(d, kpc, b, x), s, x)
+    with pytest.raises(K.KError):
+        K.ApproxInv(rows[:5], ctx=ctx).setup(d)

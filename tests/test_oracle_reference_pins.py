@@ -312,3 +312,14 @@ def test_tfqmr_as_written_structure():
     a5 = O.stencil7(4, "convdiff"); b5 = a5.spmv(np.ones(a5.nrows))
     r = O.solve("tfqmr", a5, b5, tol=1e-30, max_iters=3)
     assert r.iterations == 3 and r.converged and len(r.history) == 5              # 2 + 2 + 1 residual estimates
+
+
+# ---- src/preconditioner/approxinv.rs:384-443: the apply side of the SPAI tests, with the inverse rows those tests expect
+# from setup (diagonal / identity cases are exact; setup itself -- faer's least squares -- is not restated)
+def test_approxinv_apply_with_given_rows():
+    d = O.Csr.from_dense(np.diag([0.5, 1.0 / 3.0, 0.25]), keep_zeros=False)           # :384-397 inverse of diag(2,3,4)
+    z = O.Pc.approx_inverse(d).apply(np.array([2.0, 3.0, 4.0]))
+    assert np.array_equal(z, [1.0, 1.0, 1.0])
+    eye = O.Csr.from_dense(np.eye(4), keep_zeros=False)                               # :428-443 identity
+    x = np.array([1.0, 2.0, 3.0, 4.0])
+    assert np.array_equal(O.Pc.approx_inverse(eye).apply(x), x)
