@@ -54,7 +54,12 @@ def cpu_baseline(grid, seconds=12.0):
     res = O.solve("cg", a, b, tol=0.0, max_iters=iters, rs=rs)
     dt = time.perf_counter() - t0
     scale = (sgrid / grid) ** 3
+    # the bit-canonical single-thread figure beside it, a few iterations only
+    O.set_threads(1)
+    t0 = time.perf_counter(); r1 = O.solve("cg", a, b, tol=0.0, max_iters=4, rs=rs); dt1 = time.perf_counter() - t0
+    O.set_threads(cores)
     return {"value": res.iterations / dt * scale, "unit": "cg_iterations/s", "cores": cores, "kind": "port",
+            "single_thread_value": r1.iterations / dt1 * scale,
             "sample": f"{res.iterations} oracle CG iterations on a {sgrid}^3 Poisson system in {dt:.1f} s "
                       f"({res.iterations / dt:.1f} it/s, OpenMP rows/tiles over {cores} threads, device-order dot)"
                       + (f"; scaled by {scale:.4f} = ({sgrid}/{grid})^3 rows to the {grid}^3 workload" if scale != 1 else "")}
