@@ -132,7 +132,9 @@ __global__ __launch_bounds__(KR_T) void fg_ew_kernel(Op op, int64_t n, int64_t n
     }
 }
 template <class Op>
-static int32_t fg_launch(kryst_ctx_t ctx, const Op& op, int64_t n, const DevState* st, const FgState* fs, int bpc = 2) {
+static int32_t fg_launch(kryst_ctx_t ctx, const Op& op, int64_t n, const DevState* st, const FgState* fs, int bpc = 0) {
+    static const int dflt = [] { const char* e = getenv("KRYST_FG_BLOCKS_PER_CU"); return e ? atoi(e) : 2; }();
+    if (bpc <= 0) bpc = dflt;
     const int64_t nt = ntiles_of(n);
     if (nt == 0) return KRYST_OK;
     KR_TRY(ensure_partials(ctx, nt));

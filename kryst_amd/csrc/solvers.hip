@@ -245,7 +245,7 @@ int32_t cg_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
 //   x += alpha p ; r -= alpha Ap ; z = M^-1 r ; partial 0 = r.z ; partial 1 = norm quantity (z.z | r.r)
 template <bool JACOBI>
 struct PcgUpdateOp {
-    static constexpr int NQ = 2;
+    static constexpr int NQ = 2; static constexpr int BPC = 3;       // 5 reads + 3 writes: 3 workgroups per CU measured best (+3 %)
     const double* alpha; const double* p; const double* ap; double* x; double* r; double* z; const double* inv;
     int norm_type;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
