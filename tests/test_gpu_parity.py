@@ -689,3 +689,42 @@ def test_approx_inverse_apply_and_solve(ctx, rs):
     _check_solver(res, s.solve(d, kpc, b, x), s, x)
     with pytest.raises(K.KError):
         K.ApproxInv(rows[:5], ctx=ctx).setup(d)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_spmv_random_stencil_matrices_all_forms(ctx, seed, monkeypatch):
+    """Matrices assembled from a few random stencils with boundary truncation: many row patterns that are sub-sequences of
+    a few bases (the CSR-P16 base + mask builder), adjacent rows with equal and with different bases, bases longer than the
+    unroll factor, masks with holes.  Every storage form must equal the oracle bit for bit."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(600, 2500))
+    nst = int(rng.integers(1, 6))
+    stencils = []
+    for _ in range(nst):
+        k = int(rng.integers(1, 15))
+        offs = np.sort(rng.choice(np.arange(-40, 41), size=k, replace=False))
+        vals = rng.choice([1.0, -1.0, 0.5, 4.0, -0.25, 1e-3], size=k)
+        drop = rng.random(k) < 0.15                      # entries that some rows additionally lack (masks with holes)
+        stencils.append((offs, vals, drop))
+    rp = [0]; ci = []; va = []
+    sid = 0
+    for i in range(n):
+        if rng.random() < 0.02:
+            sid = int(rng.integers(0, nst))              # runs of rows with the same stencil
+        offs, vals, drop = stencils[sid]
+        holes = rng.random() < 0.1
+        for o, v, d in zip(offs, vals, drop):
+            c = i + int(o)
+            if 0 <= c < n and not (holes and d):
+                ci.append(c); va.append(v)
+        rp.append(len(ci))
+    a = O.Csr(n, n, rp, ci, va)
+    x = rng.standard_normal(n)
+    ref = a.spmv(x)
+    for level in ("0", "1", "2", "3"):
+        monkeypatch.setenv("KRYST_SPMV_COMPRESS", level)
+        assert np.array_equal(to_dev(ctx, a).spmv(x), ref), (seed, level)
+    monkeypatch.setenv("KRYST_SPMV_COMPRESS", "3")
+    d = to_dev(ctx, a)
+    name, npat, ntab = d.encoding()
+    assert name == "csr-p16" and npat >= nst and ntab <= 2048
