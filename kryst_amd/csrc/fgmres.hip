@@ -98,12 +98,15 @@ struct FgUpdateOp {                  // build_solution (:344-356): x += y[i] z_i
     static constexpr int NQ = 0;
     const FgState* fs; const double* y; double* const* z; double* x;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
-        const int k = (int)fs->k;
+        const int m = (int)fs->k;
         d2 xx = ld2(x, i);
-        for (int j = 0; j < k; ++j) {
-            const double yj = y[j];
-            const d2 zz = ld2(z[j], i);
-            xx.a = xx.a + yj * zz.a; xx.b = xx.b + yj * zz.b;
+        for (int j0 = 0; j0 < m; j0 += 8) {                  // 8 basis vectors in flight; the sum keeps its ascending order
+            d2 uu[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) uu[k] = ld2(z[min(j0 + k, m - 1)], i);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (j0 + k < m) { const double yj = y[j0 + k]; xx.a = xx.a + yj * uu[k].a; xx.b = xx.b + yj * uu[k].b; }
         }
         st2(x, i, xx.a, xx.b);
     }
@@ -359,7 +362,7 @@ int32_t fgmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, int32_t 
                     KR_TRY(fg_launch(ctx, RefineLinkOp{fs, V[i], i < j ? V[i + 1] : nullptr, w}, n, st, fs));
                 }
             KR_TRY((reduce_then<1>(ctx, nt, ws.red, FgNormLogic{lc, P, j, haptol})));
-            KR_TRY(fg_launch(ctx, NextBasisOp{fs, w, V[j + 1]}, n, st, fs));                      // :255-261
+            KR_TRY(fg_launch(ctx, NextBasisOp{fs, w, V[j + 1]}, n, st, fs, 4));                   // :255-261 (fp64 divisions: 4 workgroups per CU)
         }
         // ---- cycle end (:303-337)
         total += m;

@@ -52,10 +52,13 @@ struct GmUpdateOp {                  // x += sum_j y[j]*U[j], j ascending per el
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const int m = gs->m;
         d2 xx = ld2(x, i);
-        for (int j = 0; j < m; ++j) {
-            const double yj = y[j];
-            const d2 uu = ld2(u[j], i);
-            xx.a = xx.a + yj * uu.a; xx.b = xx.b + yj * uu.b;
+        for (int j0 = 0; j0 < m; j0 += 8) {                  // 8 basis vectors in flight; the sum keeps its ascending order
+            d2 uu[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) uu[k] = ld2(u[min(j0 + k, m - 1)], i);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (j0 + k < m) { const double yj = y[j0 + k]; xx.a = xx.a + yj * uu[k].a; xx.b = xx.b + yj * uu[k].b; }
         }
         st2(x, i, xx.a, xx.b);
     }
