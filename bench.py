@@ -11,8 +11,8 @@ over ranks is reported.  One JSON line on rank 0.
 
 Workload: ONE fixed 512^3 system for every N (BASELINE.json's metric is quoted on 256^3/512^3; north_star asks for
 strong scaling of CG iterations/sec on 512^3, which fits a single 288 GB GPU).  N > 1: row-partitioned in k-slabs over
-the ranks, halo planes over xGMI, inner products by RCCL all-gather.  At N = 1 the line also carries the same
-measurement on configs[1]'s 256^3 grid ("config1_256").
+the ranks, halo planes over xGMI, inner products by RCCL all-gather.  `--grid 256` measures configs[1]'s grid instead
+(profiles/r01/bench_256.json); `--with-256` adds it to the same line as "config1_256".
 """
 import argparse
 import json
@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--grid", type=int, default=0, help="grid edge (default 512 for every N)")
     ap.add_argument("--solver", default="cg", choices=["cg", "pcg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-256", action="store_true",
+                    help="also measure BASELINE configs[1]'s 256^3 grid in the same process (block `config1_256`); off by "
+                         "default so that the rocprofv3 averages of the default command refer to ONE problem size")
     args = ap.parse_args()
 
     # a hung collective must not hang the node: give up loudly after 20 minutes
@@ -203,7 +206,7 @@ def main():
     }
     if world == 1:
         out["roofline"]["traffic"] = traffic_of(grid)
-    if world == 1 and grid != 256:
+    if world == 1 and grid != 256 and args.with_256:
         dt2, st2, ms2, nl2, nz2, cp2, enc2, pm2 = run_cg(K, ctx, None, 256, args.solver, args.warmup, args.steps)
         out["config1_256"] = {"workload": f"{'jacobi_pcg' if args.solver == 'pcg' else 'cg'}_poisson7_256^3",
                               "value": args.steps / dt2, "unit": "iterations/s", "ms_per_step": dt2 / args.steps * 1e3,
