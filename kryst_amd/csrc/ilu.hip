@@ -12,10 +12,9 @@
 // its entries in stored order, exactly the reference's loop -- and permuted back.  The launch sequence is captured once
 // into a hipGraph.  A 7-point 256^3 grid has 3N-2 = 766 levels per factor and each level is a chain of ~3 dependent
 // memory round trips from a cold start (~1 us each), so the solve is LATENCY-bound: measured 3.4 us per level (5.2 ms per
-// apply; 7.4 ms before the level-permuted layout).  An experimental band schedule (KRYST_ILU_BAND=B: B levels per launch,
-// each workgroup recomputing the in-band dependency closure of its rows so that workgroup barriers replace kernel
-// boundaries) is kept behind the knob: it is bit-identical but measured no faster (the in-band steps still pay an L2
-// round trip each), so the default is one launch per level.
+// apply; 7.4 ms before the level-permuted layout).  A band schedule (B levels per launch, each workgroup recomputing the
+// in-band dependency closure of its rows so that workgroup barriers replace kernel boundaries) was built and measured: bit-
+// identical but no faster (the in-band steps still pay an L2 round trip each), so it was removed again (git history).
 // In a distributed context the factors are block-local (block-Jacobi ILU): halo columns are dropped.
 #include "pc.h"
 #include "ew.h"
@@ -43,13 +42,8 @@ struct TriFactor {                  // one triangular factor in level order
     int32_t* d_ecol = nullptr; double* d_eval = nullptr; uint8_t* d_elen = nullptr; int64_t npos = 0; bool ell = false;
     std::vector<int32_t> lvl_off;   // host: position offsets per level
     int32_t* d_lvl_off = nullptr;
-    // band schedule (ELL factors): B consecutive levels per launch, see build_bands()
-    struct Band { int nwg, nlev; int64_t ptr_off; int maxcnt; };
-    std::vector<Band> bands;
-    int32_t* d_band_ptr = nullptr; int32_t* d_band_list = nullptr;
-    double inflation = 1.0;
     void free_all() { (void)hipFree(d_ptr); (void)hipFree(d_col); (void)hipFree(d_val); (void)hipFree(d_row); (void)hipFree(d_diag); (void)hipFree(d_lvl_off);
-                      (void)hipFree(d_ecol); (void)hipFree(d_eval); (void)hipFree(d_elen); (void)hipFree(d_band_ptr); (void)hipFree(d_band_list); }
+                      (void)hipFree(d_ecol); (void)hipFree(d_eval); (void)hipFree(d_elen); }
     EllView view() const { return EllView{d_ecol, d_eval, d_elen, npos}; }
 };
 
@@ -105,73 +99,6 @@ __global__ __launch_bounds__(256) void tri_level_ell_kernel(const TriArgs* args,
     out[p] = FORWARD ? s : s / diag[p];
 }
 
-// BAND schedule: one launch covers `nlev` consecutive dependency levels.  Workgroup w owns a proportional chunk of every
-// level of the band and ALSO recomputes, level by level, every in-band ancestor of its rows (the dependency closure,
-// built at setup), so it never needs another workgroup's result inside the launch: workgroup barriers replace
-// nlev-1 kernel boundaries.  Rows computed by several workgroups get the same bits from each (same inputs, same order).
-template <bool FORWARD>
-__global__ __launch_bounds__(256) void tri_band_kernel(const TriArgs* args, const double* __restrict__ in, double* out, EllView E,
-                                                       const double* __restrict__ diag, const int32_t* __restrict__ band_ptr,
-                                                       const int32_t* __restrict__ band_list, int32_t nlev) {
-    if (args->skip) return;
-    const int32_t* myptr = band_ptr + (int64_t)blockIdx.x * (nlev + 1);
-    for (int32_t b = 0; b < nlev; ++b) {
-        const int32_t e0 = myptr[b], e1 = myptr[b + 1];
-        for (int32_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-            const int32_t p = band_list[e];
-            const double s = ell_row(E, p, in[p], out);
-            out[p] = FORWARD ? s : s / diag[p];
-        }
-        __syncthreads();                                    // workgroup-scope release/acquire of `out` between levels
-    }
-}
-
-// Same schedule with everything that does not depend on the running solution fetched UP FRONT: the row lists, the factor
-// rows, `in` and the divisors of all NLEV levels go to registers in one burst of independent loads; the dependent part
-// of a level is then a single gather of values this workgroup has just written (L2 hits) plus the store and the barrier.
-template <bool FORWARD, int NLEV, int R>
-__global__ __launch_bounds__(256) void tri_band_pre_kernel(const TriArgs* args, const double* __restrict__ in, double* out, EllView E,
-                                                           const double* __restrict__ diag, const int32_t* __restrict__ band_ptr,
-                                                           const int32_t* __restrict__ band_list, int32_t nlev) {
-    if (args->skip) return;
-    const int32_t* myptr = band_ptr + (int64_t)blockIdx.x * (nlev + 1);
-    int32_t pp[NLEV][R]; int32_t cc[NLEV][R][ELLW]; double vv[NLEV][R][ELLW]; double s0[NLEV][R], dg[NLEV][R]; int ln[NLEV][R];
-#pragma unroll
-    for (int b = 0; b < NLEV; ++b) {
-        const int32_t e0 = b < nlev ? myptr[b] : 0, e1 = b < nlev ? myptr[b + 1] : 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int32_t e = e0 + (int32_t)threadIdx.x + r * 256;
-            const bool on = e < e1;
-            const int32_t p = on ? band_list[e] : -1;
-            pp[b][r] = p;
-            const int32_t q = on ? p : 0;
-            ln[b][r] = on ? (int)E.len[q] : 0;
-#pragma unroll
-            for (int u = 0; u < ELLW; ++u) { cc[b][r][u] = E.col[u * E.npos + q]; vv[b][r][u] = E.val[u * E.npos + q]; }
-            s0[b][r] = in[q]; dg[b][r] = diag[q];
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < NLEV; ++b) {
-        if (b < nlev) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (pp[b][r] >= 0) {
-                    double zz[ELLW];
-#pragma unroll
-                    for (int u = 0; u < ELLW; ++u) zz[u] = out[cc[b][r][u]];
-                    double s = s0[b][r];
-#pragma unroll
-                    for (int u = 0; u < ELLW; ++u) if (u < ln[b][r]) s = s - vv[b][r][u] * zz[u];     // stored order
-                    out[pp[b][r]] = FORWARD ? s : s / dg[b][r];
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // a run of consecutive NARROW levels [l0, l1) in one workgroup (CSR fallback for factors that do not fit the ELL form)
 template <bool FORWARD>
 __global__ __launch_bounds__(1024) void tri_run_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
@@ -208,23 +135,6 @@ static const int NARROW = 2048;     // levels with at most this many rows are fo
 
 template <bool FORWARD>
 static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* d_args, const double* in, double* out) {
-    if (F.ell && !F.bands.empty()) {
-        for (const TriFactor::Band& b : F.bands) {
-#define KR_BAND_PRE(NL_, R_) hipLaunchKernelGGL((tri_band_pre_kernel<FORWARD, NL_, R_>), dim3((unsigned)b.nwg), dim3(256), 0, s, d_args, in, out, \
-                                               F.view(), F.d_diag, F.d_band_ptr + b.ptr_off, F.d_band_list, b.nlev)
-            const int rr = (b.maxcnt + 255) / 256;
-            if (b.nlev <= 2 && rr <= 2) KR_BAND_PRE(2, 2);
-            else if (b.nlev <= 2 && rr <= 4) KR_BAND_PRE(2, 4);
-            else if (b.nlev <= 4 && rr <= 2) KR_BAND_PRE(4, 2);
-            else if (b.nlev <= 4 && rr <= 3) KR_BAND_PRE(4, 3);
-            else
-            hipLaunchKernelGGL((tri_band_kernel<FORWARD>), dim3((unsigned)b.nwg), dim3(256), 0, s, d_args, in, out, F.view(), F.d_diag,
-                               F.d_band_ptr + b.ptr_off, F.d_band_list, b.nlev);
-#undef KR_BAND_PRE
-            KR_HIP(hipGetLastError());
-        }
-        return KRYST_OK;
-    }
     const int nl = (int)F.lvl_off.size() - 1;
     int lv = 0;
     while (lv < nl) {
@@ -308,56 +218,6 @@ static int32_t up(T** dst, const std::vector<T>& v) {
 
 static int env_i(const char* nm, int d) { const char* e = getenv(nm); return e ? atoi(e) : d; }
 
-// Band schedule of one factor: groups of B consecutive levels; per band and workgroup the level-by-level row lists
-// (own chunk + in-band dependency closure).  pos[] maps a row to its level-order position.
-static int32_t build_bands(int64_t n, const std::vector<std::vector<std::pair<int32_t, double>>>& ent, const std::vector<int32_t>& lvl,
-                           const std::vector<int32_t>& rowid, TriFactor* F) {
-    const int B = std::max(1, env_i("KRYST_ILU_BAND", 4));   // KRYST_ILU_BAND=0 (default): one launch per level
-    const int CHUNK = std::max(64, env_i("KRYST_ILU_CHUNK", 512));
-    const int nl = (int)F->lvl_off.size() - 1;
-    std::vector<int32_t> pos((size_t)n);
-    for (int64_t p = 0; p < n; ++p) pos[rowid[p]] = (int32_t)p;
-    std::vector<int32_t> band_ptr, band_list;
-    std::vector<int64_t> mark((size_t)n, -1);
-    int64_t stamp = 0, owned_total = 0;
-    std::vector<std::vector<int32_t>> S;
-    for (int l0 = 0; l0 < nl; l0 += B) {
-        const int nlev = std::min(B, nl - l0);
-        int64_t maxlen = 0;
-        for (int b = 0; b < nlev; ++b) maxlen = std::max<int64_t>(maxlen, F->lvl_off[l0 + b + 1] - F->lvl_off[l0 + b]);
-        const int nwg = (int)std::max<int64_t>(1, (maxlen + CHUNK - 1) / CHUNK);
-        F->bands.push_back(TriFactor::Band{nwg, nlev, (int64_t)band_ptr.size(), 0});
-        for (int w = 0; w < nwg; ++w) {
-            ++stamp;
-            S.assign((size_t)nlev, {});
-            for (int b = 0; b < nlev; ++b) {                      // own chunk of every level of the band
-                const int64_t o = F->lvl_off[l0 + b], len = F->lvl_off[l0 + b + 1] - o;
-                for (int64_t p = o + len * w / nwg; p < o + len * (w + 1) / nwg; ++p) { S[b].push_back((int32_t)p); mark[p] = stamp; }
-                owned_total += len * (w + 1) / nwg - len * w / nwg;
-            }
-            for (int b = nlev - 1; b > 0; --b)                    // in-band ancestors, top level first
-                for (size_t q = 0; q < S[b].size(); ++q)
-                    for (const auto& e : ent[rowid[S[b][q]]]) {
-                        const int lb = lvl[e.first] - l0;
-                        if (lb < 0) continue;                     // finished in an earlier launch
-                        const int32_t pc = pos[e.first];
-                        if (mark[pc] != stamp) { mark[pc] = stamp; S[lb].push_back(pc); }
-                    }
-            for (int b = 0; b < nlev; ++b) {
-                F->bands.back().maxcnt = std::max<int>(F->bands.back().maxcnt, (int)S[b].size());
-                std::sort(S[b].begin(), S[b].end());
-                band_ptr.push_back((int32_t)band_list.size());
-                band_list.insert(band_list.end(), S[b].begin(), S[b].end());
-            }
-            band_ptr.push_back((int32_t)band_list.size());
-        }
-        if (band_list.size() > (size_t)2000000000) { F->bands.clear(); return KRYST_OK; }   // int32 offsets: fall back to per-level launches
-    }
-    F->inflation = owned_total ? (double)band_list.size() / (double)owned_total : 1.0;
-    KR_TRY(up(&F->d_band_ptr, band_ptr)); KR_TRY(up(&F->d_band_list, band_list));
-    return KRYST_OK;
-}
-
 // level order of one factor.  rows/cols/vals: per row the kept entries in ascending column order.
 static int32_t build_factor(int64_t n, const std::vector<std::vector<std::pair<int32_t, double>>>& ent,
                             const std::vector<double>& diag, bool forward, TriFactor* F, std::vector<int32_t>* pos_out) {
@@ -396,7 +256,6 @@ static int32_t build_factor(int64_t n, const std::vector<std::vector<std::pair<i
         KR_TRY(up(&F->d_ecol, ecol)); KR_TRY(up(&F->d_eval, eval)); KR_TRY(up(&F->d_elen, elen));
         F->ell = true;
     }
-    if (F->ell && env_i("KRYST_ILU_BAND", 0) > 0) KR_TRY(build_bands(n, ent, lvl, rowid, F));
     KR_TRY(up(&F->d_ptr, ptr)); KR_TRY(up(&F->d_col, col)); KR_TRY(up(&F->d_val, val)); KR_TRY(up(&F->d_row, rowid));
     KR_TRY(up(&F->d_diag, dg)); KR_TRY(up(&F->d_lvl_off, F->lvl_off));
     return KRYST_OK;
@@ -438,8 +297,7 @@ static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const RowList
         if (rc == KRYST_OK && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
     }
     if (getenv("KRYST_ILU_VERBOSE"))
-        fprintf(stderr, "[kryst ilu] n=%lld levels L/U=%zu/%zu bands=%zu/%zu redundancy L/U=%.3f/%.3f\n", (long long)n,
-                D->L.lvl_off.size() - 1, D->U.lvl_off.size() - 1, D->L.bands.size(), D->U.bands.size(), D->L.inflation, D->U.inflation);
+        fprintf(stderr, "[kryst ilu] n=%lld levels L/U=%zu/%zu\n", (long long)n, D->L.lvl_off.size() - 1, D->U.lvl_off.size() - 1);
     if (rc != KRYST_OK) { kryst_pc_destroy(pc); return rc; }
     *out = pc;
     return KRYST_OK;
