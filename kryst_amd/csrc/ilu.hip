@@ -24,6 +24,8 @@
 
 namespace kr {
 
+static int env_i(const char* nm, int d) { const char* e = getenv(nm); return e ? atoi(e) : d; }
+
 struct TriArgs {                    // device-resident argument block, rewritten before every apply (graph-friendly):
     const double* r; double* z; long long skip;   // one scalar load gives a level kernel everything it needs
 };
@@ -40,6 +42,7 @@ struct TriFactor {                  // one triangular factor in level order
     // ELL copy (rows of <= ELLW kept entries, e.g. any 7-point factor): slot-major, so a lane's loads do not depend
     // on a row pointer -- one round trip less on a latency-bound kernel
     int32_t* d_ecol = nullptr; double* d_eval = nullptr; uint8_t* d_elen = nullptr; int64_t npos = 0; bool ell = false;
+    bool syncfree = false;          // ELL factor solved by ONE sync-free launch (KRYST_ILU_SYNCFREE=0: one launch per level)
     std::vector<int32_t> lvl_off;   // host: position offsets per level
     int32_t* d_lvl_off = nullptr;
     void free_all() { (void)hipFree(d_ptr); (void)hipFree(d_col); (void)hipFree(d_val); (void)hipFree(d_row); (void)hipFree(d_diag); (void)hipFree(d_lvl_off);
@@ -99,6 +102,86 @@ __global__ __launch_bounds__(256) void tri_level_ell_kernel(const TriArgs* args,
     out[p] = FORWARD ? s : s / diag[p];
 }
 
+// SYNC-FREE form (ELL factors): ONE launch per factor instead of one per level.  Lane = level-order position; a lane polls
+// the solution entries its row depends on until they have been written (the solution vector is pre-filled with a NaN
+// sentinel, so the value is its own ready flag: one 8-byte agent-scope load per dependency and poll), then subtracts them in
+// the stored order -- the same arithmetic as the level kernels -- and publishes its own entry with an agent-scope store.
+// Forward progress: dependencies live at SMALLER positions (earlier levels), workgroups are dispatched in index order per
+// XCD, so the lowest unfinished workgroup is always resident and depends only on finished ones.  Lanes of one wave may
+// depend on each other (a wave can span several small levels), so nobody blocks: every round each unfinished lane polls
+// once, ready lanes finish, and the wave leaves when all its lanes have.  A poll budget turns a logic error into NaNs
+// instead of a hung GPU.
+#define KR_TRI_SENTINEL 0xFFF8DEADBEEFCAFEull
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void tri_syncfree_ell_kernel(const TriArgs* args, const double* __restrict__ in, double* out, EllView E,
+                                                               const double* __restrict__ diag, int32_t npos) {
+    if (args->skip) return;
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = p < npos;
+    int len = 0; int32_t c[ELLW]; double v[ELLW], zz[ELLW]; double s = 0.0, dg = 1.0;
+#pragma unroll
+    for (int u = 0; u < ELLW; ++u) { c[u] = 0; v[u] = 0.0; zz[u] = 0.0; }
+    if (active) {
+        len = E.len[p];
+#pragma unroll
+        for (int u = 0; u < ELLW; ++u) { c[u] = E.col[u * E.npos + p]; v[u] = E.val[u * E.npos + p]; }
+        s = in[p];
+        if (!FORWARD) dg = diag[p];
+    }
+    const unsigned want = (1u << len) - 1u;
+    unsigned have = 0;
+    bool done = !active;
+    for (int budget = 1 << 22; budget > 0; --budget) {
+        if (!done) {
+#pragma unroll
+            for (int u = 0; u < ELLW; ++u)
+                if (u < len && !((have >> u) & 1u)) {
+                    const double x = __hip_atomic_load(&out[c[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned long long)__double_as_longlong(x) != KR_TRI_SENTINEL) { zz[u] = x; have |= 1u << u; }
+                }
+            if (have == want) {
+#pragma unroll
+                for (int u = 0; u < ELLW; ++u) if (u < len) s = s - v[u] * zz[u];       // stored order
+                __hip_atomic_store(&out[p], FORWARD ? s : s / dg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                done = true;
+            }
+        }
+        if (__all(done)) return;
+        __builtin_amdgcn_s_sleep(1);                        // the poll period does not matter (0..4 measured alike): the hop is two fabric trips
+    }
+    if (!done) __hip_atomic_store(&out[p], __longlong_as_double(0x7FF8000000000000ll), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // budget exhausted
+}
+
+// the same for factors with longer rows (CSR in level order): a lane advances through its entries as far as they are ready
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void tri_syncfree_csr_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
+                                                               const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                                                               const double* __restrict__ val, const double* __restrict__ diag, int32_t npos) {
+    if (args->skip) return;
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = p < npos;
+    int32_t k = 0, kend = 0; double s = 0.0, dg = 1.0;
+    if (active) { k = ptr[p]; kend = ptr[p + 1]; s = in[p]; if (!FORWARD) dg = diag[p]; }
+    bool done = !active;
+    for (int budget = 1 << 22; budget > 0; --budget) {
+        if (!done) {
+            while (k < kend) {
+                const double x = __hip_atomic_load(&out[col[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned long long)__double_as_longlong(x) == KR_TRI_SENTINEL) break;
+                s = s - val[k] * x;                                                        // stored order
+                ++k;
+            }
+            if (k == kend) {
+                __hip_atomic_store(&out[p], FORWARD ? s : s / dg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                done = true;
+            }
+        }
+        if (__all(done)) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (!done) __hip_atomic_store(&out[p], __longlong_as_double(0x7FF8000000000000ll), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // budget exhausted
+}
+
 // a run of consecutive NARROW levels [l0, l1) in one workgroup (CSR fallback for factors that do not fit the ELL form)
 template <bool FORWARD>
 __global__ __launch_bounds__(1024) void tri_run_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
@@ -122,19 +205,29 @@ __global__ void tri_set_args(TriArgs* a, const double* r, double* z, const int* 
 
 // dst[p] = src[map[p]]   (MODE 0: src = the caller's r;  MODE 1: plain gather;  MODE 2: scatter into the caller's z: z[map[p]] = src[p])
 template <int MODE>
-__global__ __launch_bounds__(256) void perm_kernel(const TriArgs* args, double* dst, const double* src, const int32_t* __restrict__ map, int64_t n) {
+__global__ __launch_bounds__(256) void perm_kernel(const TriArgs* args, double* dst, const double* src, const int32_t* __restrict__ map, int64_t n,
+                                                   double* fill) {
     if (args->skip) return;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     if (MODE == 0) dst[p] = args->r[map[p]];
     else if (MODE == 1) dst[p] = src[map[p]];
     else args->z[map[p]] = src[p];
+    if (fill) fill[p] = __longlong_as_double((long long)KR_TRI_SENTINEL);     // "not yet solved" marks for the sync-free kernel
 }
 
 static const int NARROW = 2048;     // levels with at most this many rows are folded into one-workgroup runs (CSR fallback)
 
 template <bool FORWARD>
 static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* d_args, const double* in, double* out) {
+    if (F.syncfree && F.npos > 0) {
+        const dim3 grid((unsigned)((F.npos + 255) / 256));
+        if (F.ell) hipLaunchKernelGGL((tri_syncfree_ell_kernel<FORWARD>), grid, dim3(256), 0, s, d_args, in, out, F.view(), F.d_diag, (int32_t)F.npos);
+        else hipLaunchKernelGGL((tri_syncfree_csr_kernel<FORWARD>), grid, dim3(256), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val, F.d_diag,
+                                (int32_t)F.npos);
+        KR_HIP(hipGetLastError());
+        return KRYST_OK;
+    }
     const int nl = (int)F.lvl_off.size() - 1;
     int lv = 0;
     while (lv < nl) {
@@ -162,13 +255,16 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
 // r -> rL (L level order) -> forward -> yL -> yU (U level order) -> backward -> zU -> z
 static int32_t enqueue_apply(hipStream_t s, IluData* D) {
     const unsigned g = (unsigned)((D->n + 255) / 256);
-    hipLaunchKernelGGL((perm_kernel<0>), dim3(g), dim3(256), 0, s, D->d_args, D->d_rL, (const double*)nullptr, D->L.d_row, D->n);
+    hipLaunchKernelGGL((perm_kernel<0>), dim3(g), dim3(256), 0, s, D->d_args, D->d_rL, (const double*)nullptr, D->L.d_row, D->n,
+                       D->L.syncfree ? D->d_y : (double*)nullptr);
     KR_HIP(hipGetLastError());
     KR_TRY(enqueue_factor<true>(s, D->L, D->d_args, D->d_rL, D->d_y));
-    hipLaunchKernelGGL((perm_kernel<1>), dim3(g), dim3(256), 0, s, D->d_args, D->d_yU, (const double*)D->d_y, D->d_mapLU, D->n);
+    hipLaunchKernelGGL((perm_kernel<1>), dim3(g), dim3(256), 0, s, D->d_args, D->d_yU, (const double*)D->d_y, D->d_mapLU, D->n,
+                       D->U.syncfree ? D->d_zU : (double*)nullptr);
     KR_HIP(hipGetLastError());
     KR_TRY(enqueue_factor<false>(s, D->U, D->d_args, D->d_yU, D->d_zU));
-    hipLaunchKernelGGL((perm_kernel<2>), dim3(g), dim3(256), 0, s, D->d_args, (double*)nullptr, (const double*)D->d_zU, D->U.d_row, D->n);
+    hipLaunchKernelGGL((perm_kernel<2>), dim3(g), dim3(256), 0, s, D->d_args, (double*)nullptr, (const double*)D->d_zU, D->U.d_row, D->n,
+                       (double*)nullptr);
     KR_HIP(hipGetLastError());
     return KRYST_OK;
 }
@@ -216,7 +312,6 @@ static int32_t up(T** dst, const std::vector<T>& v) {
     return KRYST_OK;
 }
 
-static int env_i(const char* nm, int d) { const char* e = getenv(nm); return e ? atoi(e) : d; }
 
 // level order of one factor.  rows/cols/vals: per row the kept entries in ascending column order.
 static int32_t build_factor(int64_t n, const std::vector<std::vector<std::pair<int32_t, double>>>& ent,
@@ -256,6 +351,7 @@ static int32_t build_factor(int64_t n, const std::vector<std::vector<std::pair<i
         KR_TRY(up(&F->d_ecol, ecol)); KR_TRY(up(&F->d_eval, eval)); KR_TRY(up(&F->d_elen, elen));
         F->ell = true;
     }
+    F->syncfree = env_i("KRYST_ILU_SYNCFREE", 1) != 0;
     KR_TRY(up(&F->d_ptr, ptr)); KR_TRY(up(&F->d_col, col)); KR_TRY(up(&F->d_val, val)); KR_TRY(up(&F->d_row, rowid));
     KR_TRY(up(&F->d_diag, dg)); KR_TRY(up(&F->d_lvl_off, F->lvl_off));
     return KRYST_OK;

@@ -242,6 +242,24 @@ def test_ilu_apply_bit_exact(ctx, mode):
         assert np.array_equal(z, ofn(a).apply(r)), (mode, a.nrows)
 
 
+@pytest.mark.parametrize("syncfree", ["0", "1"])
+def test_triangular_solve_forms_bit_exact(ctx, syncfree, monkeypatch):
+    """One launch per dependency level (KRYST_ILU_SYNCFREE=0) and the sync-free single launch (default) give the oracle's bits,
+    for ELL factors (<= 4 entries per row), CSR factors (longer rows), tiny levels sharing a wave, and a several-tile grid."""
+    monkeypatch.setenv("KRYST_ILU_SYNCFREE", syncfree)
+    rng = np.random.default_rng(77)
+    dense = rng.random((300, 300)) * (rng.random((300, 300)) < 0.05) + np.diag(5.0 + rng.random(300))
+    cases = [(K.TrueIlu0(), O.Pc.ilu0_true, O.stencil7(24, "aniso")),                           # ELL, 70 levels, 13 824 rows
+             (K.Ilu0(), O.Pc.ilu0_compat, O.Csr.from_dense(dense, keep_zeros=False)),           # CSR rows, irregular levels
+             (K.Ilup(2), lambda a: O.Pc.ilup(a, 2), O.stencil7(9, "convdiff")),                 # fill-in: long rows
+             (K.Ilup(0), O.Pc.ilup0, O.Csr.from_dense(O.tridiag(700, -1.0, 2.5, -0.5), keep_zeros=False))]   # 700 levels of one row
+    for kpc, ofn, a in cases:
+        pc = kpc.setup(to_dev(ctx, a)); ref = ofn(a)
+        for seed in (1, 2):
+            r = O.splitmix64_uniform(seed, a.nrows) - 0.5
+            assert np.array_equal(pc.apply(r), ref.apply(r)), (syncfree, a.nrows)
+
+
 def test_ilu_apply_twice_reuses_graph(ctx):
     a = O.stencil7(20)
     pc = K.Ilu0().setup(to_dev(ctx, a))
