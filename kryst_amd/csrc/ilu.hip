@@ -8,13 +8,14 @@
 //
 // Setup (host, once): factor values, dependency levels of L (ascending rows) and U (descending rows), and a LEVEL-ORDERED
 // copy of each factor (rows of one level contiguous, columns renumbered to level-order positions).
-// Apply (device): the vectors are permuted into level order, then one kernel per level -- a lane owns a row and subtracts
-// its entries in stored order, exactly the reference's loop -- and permuted back.  The launch sequence is captured once
-// into a hipGraph.  A 7-point 256^3 grid has 3N-2 = 766 levels per factor and each level is a chain of ~3 dependent
-// memory round trips from a cold start (~1 us each), so the solve is LATENCY-bound: measured 3.4 us per level (5.2 ms per
-// apply; 7.4 ms before the level-permuted layout).  A band schedule (B levels per launch, each workgroup recomputing the
-// in-band dependency closure of its rows so that workgroup barriers replace kernel boundaries) was built and measured: bit-
-// identical but no faster (the in-band steps still pay an L2 round trip each), so it was removed again (git history).
+// Apply (device): the vectors are permuted into level order, the two triangular systems are solved -- a lane owns a row and
+// subtracts its entries in stored order, exactly the reference's loop -- and the result is permuted back; the launch sequence
+// is captured once into a hipGraph.  A 7-point 256^3 grid has 3N-2 = 766 dependency levels per factor, so the solve is
+// LATENCY-bound.  Two forms with identical results: one kernel per level (3.4 us per level: kernel boundary + ~3 dependent
+// memory round trips; KRYST_ILU_SYNCFREE=0) and, by default, ONE sync-free launch per factor in which every lane polls the
+// solution entries it needs (2.05 us per dependency hop, 3.1 instead of 5.2 ms per apply; see tri_syncfree_ell_kernel).
+// A band schedule (B levels per launch, each workgroup recomputing the in-band dependency closure of its rows so that
+// workgroup barriers replace kernel boundaries) was built and measured: bit-identical but no faster, removed again.
 // In a distributed context the factors are block-local (block-Jacobi ILU): halo columns are dropped.
 #include "pc.h"
 #include "ew.h"
@@ -313,16 +314,24 @@ static int32_t up(T** dst, const std::vector<T>& v) {
 }
 
 
-// level order of one factor.  rows/cols/vals: per row the kept entries in ascending column order.
-static int32_t build_factor(int64_t n, const std::vector<std::vector<std::pair<int32_t, double>>>& ent,
-                            const std::vector<double>& diag, bool forward, TriFactor* F, std::vector<int32_t>* pos_out) {
+// kept entries of a triangular factor, row by row in STORED order (flat CSR: a vector per row costs 2n heap blocks)
+struct FlatRows {
+    std::vector<int64_t> ptr; std::vector<int32_t> col; std::vector<double> val;
+    int64_t len(int64_t i) const { return ptr[(size_t)i + 1] - ptr[(size_t)i]; }
+};
+
+// level order of one factor
+static int32_t build_factor(int64_t n, const FlatRows& ent, const std::vector<double>& diag, bool forward, TriFactor* F,
+                            std::vector<int32_t>* pos_out) {
     std::vector<int32_t> lvl((size_t)n, 0);
     int32_t nl = 0;
-    if (forward) {
-        for (int64_t i = 0; i < n; ++i) { int32_t l = 0; for (auto& e : ent[i]) l = std::max(l, lvl[e.first] + 1); lvl[i] = l; nl = std::max(nl, l + 1); }
-    } else {
-        for (int64_t i = n - 1; i >= 0; --i) { int32_t l = 0; for (auto& e : ent[i]) l = std::max(l, lvl[e.first] + 1); lvl[i] = l; nl = std::max(nl, l + 1); }
-    }
+    auto level_of = [&](int64_t i) {
+        int32_t l = 0;
+        for (int64_t k = ent.ptr[i]; k < ent.ptr[i + 1]; ++k) l = std::max(l, lvl[ent.col[k]] + 1);
+        lvl[i] = l; nl = std::max(nl, l + 1);
+    };
+    if (forward) for (int64_t i = 0; i < n; ++i) level_of(i);
+    else for (int64_t i = n - 1; i >= 0; --i) level_of(i);
     F->lvl_off.assign((size_t)nl + 1, 0);
     for (int64_t i = 0; i < n; ++i) F->lvl_off[lvl[i] + 1]++;
     for (int l = 0; l < nl; ++l) F->lvl_off[l + 1] += F->lvl_off[l];
@@ -331,22 +340,23 @@ static int32_t build_factor(int64_t n, const std::vector<std::vector<std::pair<i
     std::vector<int32_t> pos((size_t)n);
     for (int64_t p = 0; p < n; ++p) pos[rowid[p]] = (int32_t)p;
     if (pos_out) *pos_out = pos;
-    std::vector<int32_t> col; std::vector<double> val, dg((size_t)n);
+    const size_t nnz = ent.col.size();
+    std::vector<int32_t> col(nnz); std::vector<double> val(nnz), dg((size_t)n);
+    size_t w = 0; int64_t maxlen = 0;
     for (int64_t p = 0; p < n; ++p) {
         const int32_t i = rowid[p];
-        for (auto& e : ent[i]) { col.push_back(pos[e.first]); val.push_back(e.second); }      // columns as level-order positions
-        ptr[p + 1] = (int32_t)col.size();
+        for (int64_t k = ent.ptr[i]; k < ent.ptr[i + 1]; ++k) { col[w] = pos[ent.col[k]]; val[w] = ent.val[k]; ++w; }   // columns as level-order positions
+        ptr[p + 1] = (int32_t)w;
         dg[p] = diag[i];
+        maxlen = std::max(maxlen, ent.len(i));
     }
-    size_t maxlen = 0;
-    for (int64_t i = 0; i < n; ++i) maxlen = std::max(maxlen, ent[i].size());
     F->npos = n;
     if (maxlen <= ELLW && n > 0) {
         std::vector<int32_t> ecol((size_t)ELLW * n, 0); std::vector<double> eval((size_t)ELLW * n, 0.0); std::vector<uint8_t> elen((size_t)n, 0);
         for (int64_t p = 0; p < n; ++p) {
-            const auto& e = ent[rowid[p]];
-            elen[p] = (uint8_t)e.size();
-            for (size_t u = 0; u < e.size(); ++u) { ecol[u * n + p] = pos[e[u].first]; eval[u * n + p] = e[u].second; }
+            const int64_t len = ptr[p + 1] - ptr[p];
+            elen[p] = (uint8_t)len;
+            for (int64_t u = 0; u < len; ++u) { ecol[(size_t)u * n + p] = col[ptr[p] + u]; eval[(size_t)u * n + p] = val[ptr[p] + u]; }
         }
         KR_TRY(up(&F->d_ecol, ecol)); KR_TRY(up(&F->d_eval, eval)); KR_TRY(up(&F->d_elen, elen));
         F->ell = true;
@@ -362,9 +372,18 @@ static int32_t build_factor(int64_t n, const std::vector<std::vector<std::pair<i
 using namespace kr;
 
 typedef std::vector<std::vector<std::pair<int32_t, double>>> RowLists;
+static FlatRows flatten(const RowLists& r) {
+    FlatRows f;
+    f.ptr.assign(r.size() + 1, 0);
+    for (size_t i = 0; i < r.size(); ++i) f.ptr[i + 1] = f.ptr[i] + (int64_t)r[i].size();
+    f.col.resize((size_t)f.ptr.back()); f.val.resize((size_t)f.ptr.back());
+    for (size_t i = 0; i < r.size(); ++i)
+        for (size_t u = 0; u < r[i].size(); ++u) { f.col[(size_t)f.ptr[i] + u] = r[i][u].first; f.val[(size_t)f.ptr[i] + u] = r[i][u].second; }
+    return f;
+}
 
 // shared tail of every ILU-family setup: level-order both factors and hand out the preconditioner object
-static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const RowLists& le, const RowLists& ue,
+static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRows& le, const FlatRows& ue,
                              const std::vector<double>& dg, kryst_pc_t* out) {
     kryst_ctx_t ctx = a->ctx;
     const int64_t n = a->nrows;
@@ -451,16 +470,29 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
             }
     }
     const bool divide = mode != KRYST_ILU_KRYST_COMPAT;                    // ilu.rs:115-119 never divides
-    RowLists le((size_t)n), ue((size_t)n);
+    FlatRows le, ue;
+    le.ptr.assign((size_t)n + 1, 0); ue.ptr.assign((size_t)n + 1, 0);
     std::vector<double> dg((size_t)n, 1.0);
-    for (int64_t i = 0; i < n; ++i)
+    for (int64_t i = 0; i < n; ++i) {                                      // count, then fill (stored order = ascending column)
+        int64_t nl = 0, nu = 0;
         for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
             const int64_t j = col[k];
             if (j >= n || w[k] == 0.0) continue;                           // halo column / `!= T::zero()` filters
-            if (j < i) le[i].push_back({(int32_t)j, w[k]});
-            else if (j > i) ue[i].push_back({(int32_t)j, w[k]});
+            if (j < i) ++nl; else if (j > i) ++nu;
+        }
+        le.ptr[i + 1] = le.ptr[i] + nl; ue.ptr[i + 1] = ue.ptr[i] + nu;
+    }
+    le.col.resize((size_t)le.ptr[n]); le.val.resize((size_t)le.ptr[n]); ue.col.resize((size_t)ue.ptr[n]); ue.val.resize((size_t)ue.ptr[n]);
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t wl = le.ptr[i], wu = ue.ptr[i];
+        for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
+            const int64_t j = col[k];
+            if (j >= n || w[k] == 0.0) continue;
+            if (j < i) { le.col[wl] = (int32_t)j; le.val[wl] = w[k]; ++wl; }
+            else if (j > i) { ue.col[wu] = (int32_t)j; ue.val[wu] = w[k]; ++wu; }
             else if (divide) dg[i] = w[k];                                 // ilup.rs:160-164 (missing diagonal: no divide)
         }
+    }
     return finish_ilu_pc(a, mode, divide, le, ue, dg, out);
 }
 
@@ -517,7 +549,7 @@ extern "C" int32_t kryst_pc_ilup(kryst_csr_t a, int32_t fill, kryst_pc_t* out) {
             if (kv.first > i && kv.second.v != 0.0) urows[i].push_back(UEnt{kv.first, kv.second.v, kv.second.lev});
         }
     }
-    return finish_ilu_pc(a, 10 + fill, true, le, ue, dg, out);
+    return finish_ilu_pc(a, 10 + fill, true, flatten(le), flatten(ue), dg, out);
 }
 
 // Ilut::new(fill, droptol).setup(a) exactly as written (src/preconditioner/ilut.rs:80-117): no elimination; drop by
@@ -549,5 +581,5 @@ extern "C" int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kr
             else if (!have_d) { dg[i] = e.second; have_d = true; }                                               // :143-144
         }
     }
-    return finish_ilu_pc(a, 100, true, le, ue, dg, out);
+    return finish_ilu_pc(a, 100, true, flatten(le), flatten(ue), dg, out);
 }
