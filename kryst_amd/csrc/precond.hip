@@ -3,6 +3,7 @@
 #include "pc.h"
 #include "ew.h"
 #include <cfloat>
+#include <algorithm>
 #include <cmath>
 
 namespace kr {
@@ -46,6 +47,15 @@ struct Cheb2Op {                     // v2[i] = (2*(v2[i] - c*v1[i]) / d) - v0[i
         st2(v2, i, (2.0 * (w.a - c * b.a) / d) - a.a, (2.0 * (w.b - c * b.b) / d) - a.b);
     }
 };
+struct Cheb2ScaleOp {                // the last recurrence step and z[i] = tau * v2[i] (chebyshev.rs:121 then :130-138) in one pass
+    static constexpr int NQ = 0;
+    double c, d, tau; const double* v0; const double* v1; const double* v2; double* z;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const d2 a = ld2(v0, i), b = ld2(v1, i), w = ld2(v2, i);
+        const double n0 = (2.0 * (w.a - c * b.a) / d) - a.a, n1 = (2.0 * (w.b - c * b.b) / d) - a.b;   // v2 as the reference stores it
+        st2(z, i, tau * n0, tau * n1);
+    }
+};
 struct ScaleOp {                     // z[i] = tau * v[i]                         (chebyshev.rs:130-138)
     static constexpr int NQ = 0;
     double tau; const double* v; double* z;
@@ -77,18 +87,26 @@ int32_t chebyshev_dev(kryst_csr_t a, const double* r, double* z, double alpha, d
     const double c = (beta + alpha) / 2.0;
     const double d = (beta - alpha) / 2.0;
     const double tau = 1.0 / chebyshev_t_host(m, (0.0 - c) / d);                           // :102
-    KR_HIP(hipMemcpyAsync(v0, r, bytes, hipMemcpyDeviceToDevice, ctx->s_main));            // v0 = r
-    KR_TRY(launch_spmv(a, v0, v1, 0, nullptr, done));                                      // :104
-    KR_TRY(launch_ew(ctx, Cheb1Op{c, d, v0, v1}, n, done));
-    if (m == 0) { KR_HIP(hipMemcpyAsync(z, v0, bytes, hipMemcpyDeviceToDevice, ctx->s_main)); return KRYST_OK; }
-    if (m == 1) { KR_HIP(hipMemcpyAsync(z, v1, bytes, hipMemcpyDeviceToDevice, ctx->s_main)); return KRYST_OK; }   // unscaled
+    // v0 = r is never written by the recurrence, so r itself plays v0 (no copy); the three work vectors rotate behind it
+    const double* p0 = r;                                                                  // :103 v0 = r.clone()
+    double* bufs[3] = {v0, v1, v2};
+    double* p1 = bufs[1];
+    KR_TRY(launch_spmv(a, p0, p1, 0, nullptr, done));                                      // :104
+    KR_TRY(launch_ew(ctx, Cheb1Op{c, d, p0, p1}, n, done));
+    if (m == 0) { KR_HIP(hipMemcpyAsync(z, r, bytes, hipMemcpyDeviceToDevice, ctx->s_main)); return KRYST_OK; }
+    if (m == 1) { KR_HIP(hipMemcpyAsync(z, p1, bytes, hipMemcpyDeviceToDevice, ctx->s_main)); return KRYST_OK; }   // unscaled
+    int next = 2;                                                                          // index of the free buffer
     for (int64_t k = 2; k <= m; ++k) {
-        KR_TRY(launch_spmv(a, v1, v2, 0, nullptr, done));
-        KR_TRY(launch_ew(ctx, Cheb2Op{c, d, v0, v1, v2}, n, done));
-        double* t = v0; v0 = v1; v1 = t;
-        t = v1; v1 = v2; v2 = t;
+        double* p2 = bufs[next];
+        KR_TRY(launch_spmv(a, p1, p2, 0, nullptr, done));
+        if (k == m) return launch_ew(ctx, Cheb2ScaleOp{c, d, tau, p0, p1, p2, z}, n, done);   // :121 + :130-138
+        KR_TRY(launch_ew(ctx, Cheb2Op{c, d, p0, p1, p2}, n, done));
+        // swap(v0,v1); swap(v1,v2): the old v0 buffer becomes the free one (r is never recycled)
+        const double* old0 = p0;
+        p0 = p1; p1 = p2;
+        next = (old0 == r) ? 0 : (int)(std::find(bufs, bufs + 3, old0) - bufs);
     }
-    return launch_ew(ctx, ScaleOp{tau, v1, z}, n, done);
+    return KRYST_OK;
 }
 
 int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done);   // ilu.hip
