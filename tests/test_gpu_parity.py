@@ -260,6 +260,39 @@ def test_triangular_solve_forms_bit_exact(ctx, syncfree, monkeypatch):
             assert np.array_equal(pc.apply(r), ref.apply(r)), (syncfree, a.nrows)
 
 
+@pytest.mark.parametrize("grid_path", ["1", "0"])
+def test_structured_grid_triangular_solve_bit_exact(ctx, grid_path, monkeypatch):
+    """Factors of 7-point / 5-point operators on an Ni x Nj x Nk box are solved by the pipelined wavefront kernel
+    (KRYST_ILU_GRID=1, default): boxes whose sides are not multiples of the 8 x 8 line block, thin and 2-D boxes, and banded
+    matrices that LOOK like a grid but wrap around line ends (must be recognised and take the general path).  Both paths
+    give the oracle's bits."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("KRYST_ILU_GRID", grid_path)
+    rng = np.random.default_rng(5)
+
+    def box(Ni, Nj, Nk, wrap=False):
+        def lap(n, w):
+            return sp.diags([-w * np.ones(n - 1), 2 * w * np.ones(n), -0.5 * w * np.ones(n - 1)], [-1, 0, 1])
+        if wrap:                                          # plain bands: entries cross line ends -> not a grid operator
+            n = Ni * Nj * Nk
+            offs = [o for o in (-Ni * Nj, -Ni, -1, 0, 1, Ni, Ni * Nj) if abs(o) < n]
+            m = sp.diags([(-1.0 if o else 7.0) * np.ones(n - abs(o)) for o in offs], offs).tocsr()
+        else:
+            m = (sp.kron(sp.eye(Nk), sp.kron(sp.eye(Nj), lap(Ni, 1.0))) + sp.kron(sp.eye(Nk), sp.kron(lap(Nj, 0.7), sp.eye(Ni)))
+                 + sp.kron(lap(Nk, 0.3), sp.kron(sp.eye(Nj), sp.eye(Ni)))).tocsr()
+        m.sort_indices(); m.eliminate_zeros()
+        return O.Csr(m.shape[0], m.shape[1], m.indptr, m.indices, m.data)
+
+    cases = [box(5, 3, 2), box(9, 8, 8), box(16, 17, 9), box(40, 9, 20), box(7, 20, 1), box(64, 1, 1), box(6, 5, 4, wrap=True)]
+    for a in cases:
+        d = to_dev(ctx, a)
+        for kpc, ofn in ((K.TrueIlu0(), O.Pc.ilu0_true), (K.Ilu0(), O.Pc.ilu0_compat), (K.Ilup(0), O.Pc.ilup0)):
+            pc = kpc.setup(d); ref = ofn(a)
+            for _ in range(2):
+                r = rng.standard_normal(a.nrows)
+                assert np.array_equal(pc.apply(r), ref.apply(r)), (grid_path, a.nrows)
+
+
 def test_ilu_apply_twice_reuses_graph(ctx):
     a = O.stencil7(20)
     pc = K.Ilu0().setup(to_dev(ctx, a))
