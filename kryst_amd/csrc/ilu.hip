@@ -569,16 +569,20 @@ static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRow
     IluData* D = new IluData();
     D->n = n;
     pc->d_work = reinterpret_cast<double*>(D);
-    std::vector<int32_t> posL, posU;
-    int32_t rc = build_factor(n, le, ones, true, &D->L, &posL);
-    if (rc == KRYST_OK) rc = build_factor(n, ue, dg, false, &D->U, &posU);
-    if (rc == KRYST_OK) rc = build_grid(n, le, ones, true, &D->GL);
+    // structured-grid factors take the wavefront kernel; everything else is level-ordered
+    int32_t rc = build_grid(n, le, ones, true, &D->GL);
     if (rc == KRYST_OK) rc = build_grid(n, ue, dg, false, &D->GU);
-    if (D->GL.ok && D->GU.ok && (D->GL.Ni != D->GU.Ni || D->GL.Nj != D->GU.Nj)) { D->GL.ok = false; }
-    if (rc == KRYST_OK) {
-        std::vector<int32_t> mapLU((size_t)n);
-        for (int64_t i = 0; i < n; ++i) mapLU[posU[i]] = posL[i];
-        rc = up(&D->d_mapLU, mapLU);
+    if (D->GL.ok && D->GU.ok && (D->GL.Ni != D->GU.Ni || D->GL.Nj != D->GU.Nj)) D->GL.ok = false;
+    if (rc == KRYST_OK && !(D->GL.ok && D->GU.ok)) {
+        D->GL.free_all(); D->GU.free_all(); D->GL = GridFactor(); D->GU = GridFactor();
+        std::vector<int32_t> posL, posU;
+        rc = build_factor(n, le, ones, true, &D->L, &posL);
+        if (rc == KRYST_OK) rc = build_factor(n, ue, dg, false, &D->U, &posU);
+        if (rc == KRYST_OK) {
+            std::vector<int32_t> mapLU((size_t)n);
+            for (int64_t i = 0; i < n; ++i) mapLU[posU[i]] = posL[i];
+            rc = up(&D->d_mapLU, mapLU);
+        }
     }
     if (rc == KRYST_OK && hipMalloc(&D->d_args, sizeof(TriArgs)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
     if (rc == KRYST_OK) {
@@ -591,7 +595,8 @@ static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRow
         if (rc == KRYST_OK && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
     }
     if (getenv("KRYST_ILU_VERBOSE"))
-        fprintf(stderr, "[kryst ilu] n=%lld levels L/U=%zu/%zu\n", (long long)n, D->L.lvl_off.size() - 1, D->U.lvl_off.size() - 1);
+        fprintf(stderr, "[kryst ilu] n=%lld %s; levels L/U=%zu/%zu\n", (long long)n, D->GL.ok ? "structured grid (wavefront kernel)" : "level-ordered",
+                D->L.lvl_off.empty() ? (size_t)0 : D->L.lvl_off.size() - 1, D->U.lvl_off.empty() ? (size_t)0 : D->U.lvl_off.size() - 1);
     if (rc != KRYST_OK) { kryst_pc_destroy(pc); return rc; }
     *out = pc;
     return KRYST_OK;
