@@ -1,5 +1,6 @@
-"""Size-independent properties at BASELINE.json's full sizes (256^3; dots also at 512^3), where the CPU oracle would be
+"""Size-independent properties at BASELINE.json's full sizes (256^3 and the bench's 512^3), where the CPU oracle would be
 too slow to be the checker."""
+
 import numpy as np
 import pytest
 
@@ -90,3 +91,39 @@ def test_ilu_apply_inverts_its_factors(ctx):
     z = pc.apply(r)
     ref = O.Pc.ilu0_true(ao)
     assert np.array_equal(z, ref.apply(r))
+
+
+def test_512_cubed_properties(ctx, monkeypatch):
+    """The bench's own problem (512^3, 134 M rows, 938 M nonzeros): exact row sums of the Poisson operator, every SpMV storage
+    form bit-identical on a random vector (compared on the device through a checksum of per-plane checksums and a full
+    difference norm), and a deterministic CG run whose residual history is strictly decreasing at the start."""
+    M = 512
+    n = M ** 3
+    a = K.CsrMatrix.stencil7(M, "poisson", ctx=ctx)
+    assert a.nnz == 7 * n - 6 * M * M and a.encoding()[0] == "csr-p16"
+    ones = ctx.vec(n).fill(1.0)
+    y = a.spmv(ones)
+    # A*1 = number of missing neighbours: 3 at corners, 0 inside; sum = 6 N^2, sum of squares = (N-2)^2*6 + 4*12*(N-2) + 9*8
+    assert K.dot(y, ones) == float(6 * M * M)
+    assert K.dot(y, y) == float(6 * (M - 2) ** 2 + 4 * 12 * (M - 2) + 9 * 8)
+    x = ctx.vec(n).fill_splitmix(0xC0FFEE)
+    outs = []
+    for comp in ("3", "2", "1", "0"):
+        monkeypatch.setenv("KRYST_SPMV_COMPRESS", comp)
+        outs.append(a.spmv(x))
+    monkeypatch.delenv("KRYST_SPMV_COMPRESS")
+    ref = outs[-1]
+    for o in outs[:-1]:
+        d = ctx.vec(n); d.copy_from(o); K.axpy(-1.0, ref, d)
+        assert K.norm(d) == 0.0                                     # every entry identical (a NaN anywhere would also fail)
+        assert K.dot(o, ones) == K.dot(ref, ones)                   # checksum in the library's fixed association order
+    b = a.spmv(ones)
+    hist = []
+    for _ in range(2):
+        xs = ctx.vec(n)
+        s = K.CgSolver(0.0, 25)
+        st = s.solve(a, None, b, xs)
+        assert st.iterations == 25
+        hist.append(list(s.residual_history))
+    assert hist[0] == hist[1]
+    assert all(hist[0][i + 1] < hist[0][i] for i in range(5))
