@@ -560,7 +560,7 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
     args.code = comp ? a->d_code : nullptr; args.dict = comp ? a->d_dict : nullptr;
     args.code16 = a->d_code16; args.vdict = a->d_vdict;
     args.pid = a->d_pid; args.pmeta = a->d_pmeta; args.poff = a->d_poff; args.pval = a->d_pval; args.npat = a->npat; args.ntab = a->ntab;
-    if (a->d_pid && comp_level >= 3 && a->xlen + (HALO ? a->plan.total_recv : 0) < (1ll << 28)) {
+    if (a->d_pid && comp_level >= 3 && a->xlen + (HALO ? a->plan.total_recv : 0) < (1ll << 28) && a->nrows < (1ll << 28)) {   // 32-bit byte offsets
         // a workgroup loads the tables once and walks one run of 8 consecutive tiles (next tile's ids prefetched); runs go
         // round-robin over the XCDs.  Measured at 512^3 (tools/p16_tune5.sh, tools/p16_pmc.sh): 0.70 ms and 1.6 GB of reads
         // per launch, against 0.79 ms and 4.1 GB for a strided persistent grid whose fast workgroups run ahead.
