@@ -226,6 +226,10 @@ int64_t kryst_host_halo_recv_plan(int32_t rank, int32_t nranks, const int64_t* r
  * then with row_ptr[nrows+1], col_idx[nnz], vals[nnz].  The reference has no file I/O. */
 int64_t kryst_host_read_matrix_market(const char* path, int64_t* nrows, int64_t* ncols, int64_t* row_ptr,
                                       int64_t* col_idx, double* vals);
+/* PETSc binary AIJ matrix (MatView with a binary viewer: big-endian header 1211216, rows, cols, nnz, row lengths, columns,
+ * values) -> CSR, same calling convention. */
+int64_t kryst_host_read_petsc_binary(const char* path, int64_t* nrows, int64_t* ncols, int64_t* row_ptr,
+                                     int64_t* col_idx, double* vals);
 
 #ifdef __cplusplus
 }

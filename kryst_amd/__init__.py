@@ -24,7 +24,7 @@ from ._ffi import KError, lib, check
 __all__ = ["Context", "DeviceVec", "CsrMatrix", "dot", "norm", "Jacobi", "Ilu0", "Ilup", "Ilut", "TrueIlu0", "Chebyshev",
            "ChebyshevPc", "IdentityPc", "ApproxInv", "apply_chebyshev", "Convergence", "SolveStats", "CgNormType",
            "Preconditioning", "CgSolver", "PcgSolver", "GmresSolver", "FgmresSolver", "Orthog", "CgsSolver", "TfqmrSolver", "BiCgStabSolver", "BiCgStabRightPcSolver", "Session", "KspContext", "SolverKind", "KError", "reduce_spec",
-           "host_stencil7", "partition_rows", "halo_recv_plan", "read_matrix_market"]
+           "host_stencil7", "partition_rows", "halo_recv_plan", "read_matrix_market", "read_petsc_binary"]
 
 
 def _dp(a):
@@ -219,6 +219,11 @@ class CsrMatrix:
     @staticmethod
     def from_matrix_market(path, ctx=None):
         nr, nc, rp, ci, va = read_matrix_market(path)
+        return CsrMatrix.from_csr(nr, nc, rp, ci, va, ctx=ctx)
+
+    @staticmethod
+    def from_petsc_binary(path, ctx=None):
+        nr, nc, rp, ci, va = read_petsc_binary(path)
         return CsrMatrix.from_csr(nr, nc, rp, ci, va, ctx=ctx)
 
     @staticmethod
@@ -740,18 +745,26 @@ class Session:
 
 
 # ----------------------------------------------------------------------------- host-only helpers
-def read_matrix_market(path):
-    """Matrix Market coordinate file -> (nrows, ncols, row_ptr, col_idx, vals) (host only; kryst_host_read_matrix_market)."""
+def _read_matrix_file(fn, path):
     nr, nc = C.c_int64(0), C.c_int64(0)
-    nnz = lib().kryst_host_read_matrix_market(str(path).encode(), C.byref(nr), C.byref(nc), None, None, None)
+    nnz = fn(str(path).encode(), C.byref(nr), C.byref(nc), None, None, None)
     if nnz < 0:
         raise KError(102, lib().kryst_hip_last_error().decode())
     rp = np.zeros(nr.value + 1, dtype=np.int64); ci = np.zeros(max(nnz, 1), dtype=np.int64); va = np.zeros(max(nnz, 1))
-    got = lib().kryst_host_read_matrix_market(str(path).encode(), C.byref(nr), C.byref(nc), rp.ctypes.data_as(_ffi.c_i64p),
-                                              ci.ctypes.data_as(_ffi.c_i64p), _dp(va))
+    got = fn(str(path).encode(), C.byref(nr), C.byref(nc), rp.ctypes.data_as(_ffi.c_i64p), ci.ctypes.data_as(_ffi.c_i64p), _dp(va))
     if got != nnz:
-        raise KError(102, "matrix market file changed while reading")
+        raise KError(102, lib().kryst_hip_last_error().decode() if got < 0 else "matrix file changed while reading")
     return nr.value, nc.value, rp, ci[:nnz], va[:nnz]
+
+
+def read_matrix_market(path):
+    """Matrix Market coordinate file -> (nrows, ncols, row_ptr, col_idx, vals) (host only; kryst_host_read_matrix_market)."""
+    return _read_matrix_file(lib().kryst_host_read_matrix_market, path)
+
+
+def read_petsc_binary(path):
+    """PETSc binary AIJ matrix -> (nrows, ncols, row_ptr, col_idx, vals) (host only; kryst_host_read_petsc_binary)."""
+    return _read_matrix_file(lib().kryst_host_read_petsc_binary, path)
 
 
 def host_stencil7(N, kind="poisson", k_lo=0, k_hi=None):

@@ -104,6 +104,7 @@ SIGNATURES = {
     "kryst_session_end": (C.c_int32, [Handle, C.POINTER(Stats), c_dp, C.c_int64, c_i64p]),
     "kryst_host_stencil7": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i64p, c_i64p, c_dp]),
     "kryst_host_partition_rows": (C.c_int32, [C.c_int64, C.c_int32, C.c_int64, c_i64p]),
+    "kryst_host_read_petsc_binary": (C.c_int64, [C.c_char_p, c_i64p, c_i64p, c_i64p, c_i64p, c_dp]),
     "kryst_host_read_matrix_market": (C.c_int64, [C.c_char_p, c_i64p, c_i64p, c_i64p, c_i64p, c_dp]),
     "kryst_host_halo_recv_plan": (C.c_int64, [C.c_int32, C.c_int32, c_i64p, c_i64p, c_i64p, c_i64p, c_i64p]),
 }

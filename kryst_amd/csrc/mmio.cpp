@@ -1,4 +1,5 @@
-// Host-side Matrix Market reader (the reference has no file I/O at all, so real matrices could not
+// Host-side readers for on-disk matrices: Matrix Market (coordinate) and PETSc binary (MatView to a binary viewer).
+// Matrix Market reader (the reference has no file I/O at all, so real matrices could not
 // reach its solvers; this feeds CsrMatrix::from_csr / kryst_csr_create).  No GPU involved.
 //
 // Supported: "%%MatrixMarket matrix coordinate {real|integer|pattern} {general|symmetric|skew-symmetric}".
@@ -67,4 +68,57 @@ extern "C" int64_t kryst_host_read_matrix_market(const char* path, int64_t* nrow
         for (size_t k = 0; k < e.size(); ++k) { col_idx[k] = e[k].c; vals[k] = e[k].v; }
     }
     return (int64_t)e.size();
+}
+
+
+// PETSc binary matrix (MatLoad / MatView with a binary viewer, AIJ): big-endian  int32 classid 1211216, rows, cols, nnz,
+// int32 row lengths[rows], int32 column indices[nnz], float64 values[nnz].  Rows keep the file's entry order, which PETSc
+// writes sorted by column; unsorted or duplicate columns are rejected by kryst_csr_create later, like any other input.
+namespace {
+bool read_be32(std::ifstream& f, int32_t* out, size_t count) {
+    std::vector<unsigned char> buf(4 * count);
+    if (!f.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)buf.size())) return false;
+    for (size_t k = 0; k < count; ++k)
+        out[k] = (int32_t)(((uint32_t)buf[4 * k] << 24) | ((uint32_t)buf[4 * k + 1] << 16) | ((uint32_t)buf[4 * k + 2] << 8) | (uint32_t)buf[4 * k + 3]);
+    return true;
+}
+bool read_be64f(std::ifstream& f, double* out, size_t count) {
+    std::vector<unsigned char> buf(8 * count);
+    if (!f.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)buf.size())) return false;
+    for (size_t k = 0; k < count; ++k) {
+        uint64_t v = 0;
+        for (int b = 0; b < 8; ++b) v = (v << 8) | buf[8 * k + b];
+        memcpy(&out[k], &v, 8);
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int64_t kryst_host_read_petsc_binary(const char* path, int64_t* nrows, int64_t* ncols, int64_t* row_ptr,
+                                                int64_t* col_idx, double* vals) {
+    if (!path || !nrows || !ncols) { kr::set_error("bad argument: read_petsc_binary"); return -1; }
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { kr::set_error("petsc binary: cannot open %s", path); return -1; }
+    int32_t hdr[4];
+    if (!read_be32(f, hdr, 4)) { kr::set_error("petsc binary: short header"); return -1; }
+    if (hdr[0] != 1211216) { kr::set_error("petsc binary: class id %d is not a matrix (1211216)", hdr[0]); return -1; }
+    if (hdr[1] < 0 || hdr[2] < 0 || hdr[3] < 0) { kr::set_error("petsc binary: negative sizes (a dense MATSEQDENSE file has nnz = -1)"); return -1; }
+    const int64_t nr = hdr[1], nc = hdr[2], nz = hdr[3];
+    *nrows = nr; *ncols = nc;
+    if (!(row_ptr && col_idx && vals)) return nz;
+    std::vector<int32_t> len((size_t)nr), col((size_t)nz);
+    if (!read_be32(f, len.data(), (size_t)nr) || !read_be32(f, col.data(), (size_t)nz) || !read_be64f(f, vals, (size_t)nz)) {
+        kr::set_error("petsc binary: file shorter than its header says"); return -1;
+    }
+    row_ptr[0] = 0;
+    for (int64_t i = 0; i < nr; ++i) {
+        if (len[(size_t)i] < 0) { kr::set_error("petsc binary: negative row length"); return -1; }
+        row_ptr[i + 1] = row_ptr[i] + len[(size_t)i];
+    }
+    if (row_ptr[nr] != nz) { kr::set_error("petsc binary: row lengths do not add up to nnz"); return -1; }
+    for (int64_t k = 0; k < nz; ++k) {
+        if (col[(size_t)k] < 0 || col[(size_t)k] >= nc) { kr::set_error("petsc binary: column %d out of range", col[(size_t)k]); return -1; }
+        col_idx[k] = col[(size_t)k];
+    }
+    return nz;
 }

@@ -113,3 +113,26 @@ def test_matrix_market_reader(tmp_path):
         K.read_matrix_market(tmp_path / "arr.mtx")
     with pytest.raises(K.KError):
         K.read_matrix_market(tmp_path / "missing.mtx")
+
+
+def test_petsc_binary_reader(tmp_path):
+    """kryst_host_read_petsc_binary on a file written the way PETSc's MatView (binary viewer) writes AIJ matrices."""
+    import scipy.sparse as sp
+    import kryst_amd as K
+    m = sp.random(41, 29, density=0.15, random_state=3, format="csr"); m.sort_indices()
+    path = tmp_path / "a.petsc"
+    with open(path, "wb") as f:
+        np.array([1211216, m.shape[0], m.shape[1], m.nnz], dtype=">i4").tofile(f)
+        np.diff(m.indptr).astype(">i4").tofile(f)
+        m.indices.astype(">i4").tofile(f)
+        m.data.astype(">f8").tofile(f)
+    nr, nc, rp, ci, va = K.read_petsc_binary(path)
+    assert (nr, nc) == m.shape and np.array_equal(rp, m.indptr) and np.array_equal(ci, m.indices) and np.array_equal(va, m.data)
+    with open(tmp_path / "vec.petsc", "wb") as f:
+        np.array([1211214, 5], dtype=">i4").tofile(f); np.zeros(5, dtype=">f8").tofile(f)     # a Vec, not a Mat
+    with pytest.raises(K.KError):
+        K.read_petsc_binary(tmp_path / "vec.petsc")
+    with open(tmp_path / "short.petsc", "wb") as f:
+        np.array([1211216, 3, 3, 4, 2, 1], dtype=">i4").tofile(f)
+    with pytest.raises(K.KError):
+        K.read_petsc_binary(tmp_path / "short.petsc")
