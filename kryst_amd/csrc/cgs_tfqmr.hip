@@ -145,7 +145,7 @@ struct TfResNormOp {                 // partial ||r - alpha A(u+q)||^2 (:149-152
     }
 };
 struct TfXdyOp {                     // both substeps of :175-182, then y = u + beta (q + beta y) (:210)
-    static constexpr int NQ = 1;     // (no reduction; NQ = 1 only to reuse ew_kernel_early)
+    static constexpr int NQ = 0;
     const DevState* st; const TfState* tf; const double* u; const double* q; double* d; double* x; double* y;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const d2 uu = ld2(u, i), dd = ld2(d, i), xx = ld2(x, i);
@@ -269,13 +269,7 @@ struct TfqmrRun : SolverRun {
         KR_TRY(launch_spmv(a, t, v, 0, nullptr, done));                                           // :146-147 (au reuses v's storage)
         KR_TRY(launch_ew(ctx, TfResNormOp{st, r, v}, n, done));                                   // :149-152
         KR_TRY((reduce_then<1>(ctx, nt, ws.red, TfStepLogic{lc, tf})));
-        KR_TRY(ensure_partials(ctx, nt));
-        const int64_t grid = std::min<int64_t>(nt, (int64_t)ctx->num_cu * 2);
-        if (grid > 0) {
-            hipLaunchKernelGGL((ew_kernel_early<TfXdyOp>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main,
-                               TfXdyOp{st, tf, u, q, d, xw, y}, n, nt, ctx->d_partials, ctx->partials_cap, st);
-            KR_HIP(hipGetLastError());
-        }
+        KR_TRY(launch_ew_gated(ctx, TfXdyOp{st, tf, u, q, d, xw, y}, n, GateEarly{st}));
         hipLaunchKernelGGL((logic_kernel<ClearEarlyLogic>), dim3(1), dim3(64), 0, ctx->s_main, ws.red, ClearEarlyLogic{lc});
         KR_HIP(hipGetLastError());
         return KRYST_OK;

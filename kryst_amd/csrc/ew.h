@@ -10,6 +10,7 @@
 // reductions mask i < n.
 #pragma once
 #include "common.h"
+#include <algorithm>
 
 namespace kr {
 
@@ -45,10 +46,15 @@ inline Coef coef_dev(const double* p) { return Coef{p, 0.0}; }
 inline Coef coef_val(double v) { return Coef{nullptr, v}; }
 
 // Op requirements:  static constexpr int NQ;  __device__ void pair(int64_t i, bool in0, bool in1, double (&acc)[max(NQ,1)]) const;
-template <class Op>
-__global__ __launch_bounds__(KR_T) void ew_kernel(Op op, int64_t n, int64_t ntiles, double* partials,
-                                                  int64_t pstride, const int* done) {
-    if (done && *done) return;
+// Gate: decides, uniformly for the grid, whether the launch is a no-op (the solver has ended, the restart cycle has been left, ...)
+struct GateDone {                    // `done` flag of the solve (nullptr: always run)
+    const int* done;
+    __device__ __forceinline__ bool skip() const { return done && *done; }
+};
+
+template <class Op, class Gate>
+__global__ __launch_bounds__(KR_T) void ew_kernel(Op op, Gate gate, int64_t n, int64_t ntiles, double* partials, int64_t pstride) {
+    if (gate.skip()) return;
     constexpr int NQ = Op::NQ;
     __shared__ double lds[(NQ > 0 ? NQ : 1) * (KR_T / 64)];
     for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(KR_T) void ew_kernel(Op op, int64_t n, int64_t ntil
         for (int k = 0; k < (NQ > 0 ? NQ : 1); ++k) acc[k] = 0.0;
         op.pair(i, i < n, i + 1 < n, acc);
         if constexpr (NQ > 0) {
-            block_reduce<NQ, KR_T / 64>(acc, lds);
+            block_reduce_any<NQ, KR_T / 64>(acc, lds);
             if (threadIdx.x == 0) {
 #pragma unroll
                 for (int k = 0; k < NQ; ++k) partials[k * pstride + q] = acc[k];
@@ -71,8 +77,9 @@ __global__ __launch_bounds__(KR_T) void ew_kernel(Op op, int64_t n, int64_t ntil
 template <class Op, class = void> struct ew_bpc { static constexpr int value = 2; };
 template <class Op> struct ew_bpc<Op, std::void_t<decltype(Op::BPC)>> { static constexpr int value = Op::BPC; };
 
-template <class Op>
-inline int32_t launch_ew(kryst_ctx_t ctx, const Op& op, int64_t n, const int* done = nullptr) {
+// bpc <= 0: the kernel shape's default (KRYST_EW_BLOCKS_PER_CU overrides it)
+template <class Op, class Gate>
+inline int32_t launch_ew_gated(kryst_ctx_t ctx, const Op& op, int64_t n, const Gate& gate, int bpc = 0) {
     const int64_t ntiles = ntiles_of(n);
     if (ntiles == 0) return KRYST_OK;
     if (Op::NQ > 0) KR_TRY(ensure_partials(ctx, ntiles));
@@ -81,15 +88,20 @@ inline int32_t launch_ew(kryst_ctx_t ctx, const Op& op, int64_t n, const int* do
     // 4.7-4.9 TB/s (a narrower moving window keeps DRAM pages open); CG at 512^3: +4 %.  Pure read streams with a
     // reduction per tile (dots) are the exception: they need 4 per CU to overlap loads with the butterfly (rocprofv3,
     // 9 streams of 128 MiB: 420 us at 2 per CU, 250 us at 4).
-    int64_t grid = ntiles;
-    const char* e_bpc = getenv("KRYST_EW_BLOCKS_PER_CU");        // tuning knob (read per launch)
-    const int bpc = e_bpc ? atoi(e_bpc) : ew_bpc<Op>::value;
-    const int64_t cap = (int64_t)ctx->num_cu * bpc;
-    if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(ew_kernel<Op>, dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, n, ntiles,
-                       ctx->d_partials, ctx->partials_cap, done);
+    if (bpc <= 0) {
+        const char* e_bpc = getenv("KRYST_EW_BLOCKS_PER_CU");        // tuning knob (read per launch)
+        bpc = e_bpc ? atoi(e_bpc) : ew_bpc<Op>::value;
+    }
+    const int64_t grid = std::min<int64_t>(ntiles, (int64_t)ctx->num_cu * bpc);
+    hipLaunchKernelGGL((ew_kernel<Op, Gate>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, gate, n, ntiles,
+                       ctx->d_partials, ctx->partials_cap);
     KR_HIP(hipGetLastError());
     return KRYST_OK;
+}
+
+template <class Op>
+inline int32_t launch_ew(kryst_ctx_t ctx, const Op& op, int64_t n, const int* done = nullptr) {
+    return launch_ew_gated(ctx, op, n, GateDone{done});
 }
 
 }  // namespace kr

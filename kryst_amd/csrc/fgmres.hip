@@ -113,39 +113,14 @@ struct FgUpdateOp {                  // build_solution (:344-356): x += y[i] z_i
 };
 
 // kernels of the Arnoldi loop are gated on done || cyc_stop
-template <class Op>
-__global__ __launch_bounds__(KR_T) void fg_ew_kernel(Op op, int64_t n, int64_t ntiles, double* partials, int64_t pstride,
-                                                     const DevState* st, const FgState* fs) {
-    if (st->done || fs->cyc_stop) return;
-    constexpr int NQ = Op::NQ;
-    __shared__ double lds[(NQ > 0 ? NQ : 1) * (KR_T / 64)];
-    for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
-        const int64_t i = q * KR_TILE + (int64_t)threadIdx.x * KR_V;
-        double acc[NQ > 0 ? NQ : 1];
-#pragma unroll
-        for (int k = 0; k < (NQ > 0 ? NQ : 1); ++k) acc[k] = 0.0;
-        op.pair(i, i < n, i + 1 < n, acc);
-        if constexpr (NQ > 0) {
-            block_reduce_any<NQ, KR_T / 64>(acc, lds);
-            if (threadIdx.x == 0) {
-#pragma unroll
-                for (int k = 0; k < NQ; ++k) partials[k * pstride + q] = acc[k];
-            }
-        }
-    }
-}
+struct GateFgCycle {
+    const DevState* st; const FgState* fs;
+    __device__ __forceinline__ bool skip() const { return st->done || fs->cyc_stop; }
+};
 template <class Op>
 static int32_t fg_launch(kryst_ctx_t ctx, const Op& op, int64_t n, const DevState* st, const FgState* fs, int bpc = 0) {
     static const int dflt = [] { const char* e = getenv("KRYST_FG_BLOCKS_PER_CU"); return e ? atoi(e) : 2; }();
-    if (bpc <= 0) bpc = dflt;
-    const int64_t nt = ntiles_of(n);
-    if (nt == 0) return KRYST_OK;
-    KR_TRY(ensure_partials(ctx, nt));
-    const int64_t grid = std::min<int64_t>(nt, (int64_t)ctx->num_cu * bpc);
-    hipLaunchKernelGGL((fg_ew_kernel<Op>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, n, nt, ctx->d_partials,
-                       ctx->partials_cap, st, fs);
-    KR_HIP(hipGetLastError());
-    return KRYST_OK;
+    return launch_ew_gated(ctx, op, n, GateFgCycle{st, fs}, bpc > 0 ? bpc : dflt);
 }
 __global__ void fg_gate_kernel(const DevState* st, const FgState* fs, int* gate) { *gate = (st->done || fs->cyc_stop) ? 1 : 0; }
 

@@ -10,36 +10,15 @@ struct ClearEarlyLogic {
     LogicCtx c;
     __device__ void run(const double*) const { c.st->early = 0; }
 };
-// like ew_kernel's gate but keeps running for a pending early exit
-template <class Op>
-__global__ __launch_bounds__(KR_T) void ew_kernel_early(Op op, int64_t n, int64_t ntiles, double* partials,
-                                                        int64_t pstride, const DevState* st) {
-    if (st->done && !st->early) return;
-    constexpr int NQ = Op::NQ;
-    __shared__ double lds[NQ * (KR_T / 64)];
-    for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
-        const int64_t i = q * KR_TILE + (int64_t)threadIdx.x * KR_V;
-        double acc[NQ];
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) acc[k] = 0.0;
-        op.pair(i, i < n, i + 1 < n, acc);
-        block_reduce<NQ, KR_T / 64>(acc, lds);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < NQ; ++k) partials[k * pstride + q] = acc[k];
-        }
-    }
-}
-
-template <class Op>
-__global__ __launch_bounds__(KR_T) void ew_kernel_if_early(Op op, int64_t n, int64_t ntiles, const DevState* st) {
-    if (!st->early) return;
-    double dummy[1] = {0.0};
-    for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
-        const int64_t i = q * KR_TILE + (int64_t)threadIdx.x * KR_V;
-        op.pair(i, i < n, i + 1 < n, dummy);
-    }
-}
+// gates for exits whose last vector update is still pending (`early`)
+struct GateEarly {                   // runs until the solve has ended, and once more while `early` is raised
+    const DevState* st;
+    __device__ __forceinline__ bool skip() const { return st->done && !st->early; }
+};
+struct GateIfEarly {                 // runs only while `early` is raised
+    const DevState* st;
+    __device__ __forceinline__ bool skip() const { return !st->early; }
+};
 
 inline int32_t solve_args_check(const SolveIO& io, kryst_vec_t b, kryst_vec_t x) {
     KR_ARG(io.a && io.params && b && x, "solve: null argument");

@@ -205,12 +205,7 @@ struct CgRun : SolverRun {
         if (prm.has_radius) {                                                                     // :177-202 (Steihaug-Toint)
             KR_TRY(launch_ew(ctx, DotPairOp{pp, pp, xw, xw}, n, done));
             KR_TRY((reduce_then<2>(ctx, nt, ws.red, CgRadiusLogic{lc, prm.radius})));
-            const int64_t grid = std::min<int64_t>(nt, (int64_t)ctx->num_cu * 2);
-            if (grid > 0) {
-                hipLaunchKernelGGL((ew_kernel_if_early<AxpyIfOp>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main,
-                                   AxpyIfOp{ws.st, pp, xw}, n, nt, ws.st);
-                KR_HIP(hipGetLastError());
-            }
+            KR_TRY(launch_ew_gated(ctx, AxpyIfOp{ws.st, pp, xw}, n, GateIfEarly{ws.st}));
             hipLaunchKernelGGL((logic_kernel<ClearEarlyLogic>), dim3(1), dim3(64), 0, ctx->s_main, ws.red, ClearEarlyLogic{lc});
             KR_HIP(hipGetLastError());
         }
@@ -510,14 +505,8 @@ struct BicgRun : SolverRun {
         if (pc) { KR_TRY(pc_apply_dev(pc, s, sh, done)); KR_TRY(launch_spmv(a, sh, t, 2, s, done)); }
         else KR_TRY(launch_spmv(a, s, t, 2, s, done));                                            // :208-209 + (t,s),(t,t)
         KR_TRY((reduce_then<2>(ctx, nt, ws.red, BicgOmegaLogic{lc})));
-        KR_TRY(ensure_partials(ctx, nt));
         const BicgXROp op{st, pc ? ph : pp, pc ? sh : s, s, t, rhat, xw, r};
-        const int64_t grid = std::min<int64_t>(nt, (int64_t)ctx->num_cu * 2);
-        if (grid > 0) {
-            hipLaunchKernelGGL((ew_kernel_early<BicgXROp>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, n, nt,
-                               ctx->d_partials, ctx->partials_cap, st);
-            KR_HIP(hipGetLastError());
-        }
+        KR_TRY(launch_ew_gated(ctx, op, n, GateEarly{st}));
         return reduce_then<2>(ctx, nt, ws.red, BicgEndLogic{lc});
     }
 };
