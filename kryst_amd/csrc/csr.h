@@ -34,6 +34,10 @@ struct kryst_csr_s {
 
 namespace kr {
 
+constexpr int KR_PMAX = 512;        // CSR-P16 limits: patterns and (padded) table entries held in LDS: 2 + 12 + 24 KiB at most
+constexpr int KR_TMAX = 2048;
+inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
 // y <- A x on ctx->s_main.  nq = 0: plain.  nq = 1: also tile partials of sum d[i]*y[i] into partial array 0.
 // nq = 2: additionally sum y[i]*y[i] into partial array 1.  `done` (device flag) makes the launch a no-op when set.
 int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const double* dvec, const int* done);
