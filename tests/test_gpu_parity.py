@@ -779,3 +779,34 @@ def test_spmv_random_stencil_matrices_all_forms(ctx, seed, monkeypatch):
     d = to_dev(ctx, a)
     name, npat, ntab = d.encoding()
     assert name == "csr-p16" and npat >= nst and ntab <= 2048
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_solvers_on_random_sparse_matrices_bit_exact(ctx, rs, seed):
+    """Every solver on random diagonally dominant sparse matrices (unstructured pattern: the plain-CSR kernels carry the
+    SpMVs, several tiles, ragged rows), symmetric and not, against the oracle bit for bit."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(700, 1800))
+    dens = 6.0 / n
+    m = (rng.random((n, n)) < dens) * rng.standard_normal((n, n))
+    if seed % 2 == 0:
+        m = 0.5 * (m + m.T)                                          # symmetric: CG / PCG apply
+    m = m + np.diag(np.abs(m).sum(axis=1) + 1.0 + rng.random(n))
+    a = O.Csr.from_dense(m, keep_zeros=False)
+    d = to_dev(ctx, a)
+    assert d.encoding()[0] == "csr"
+    b = a.spmv(rng.standard_normal(n))
+    jac_o, jac_k = O.Pc.jacobi(a), K.Jacobi().setup(d)
+    runs = [("gmres", lambda: K.GmresSolver(15, 1e-10, 90).with_preconditioning(K.Preconditioning.Right), jac_o, jac_k,
+             dict(tol=1e-10, max_iters=90, restart=15, side=O.SIDE_RIGHT)),
+            ("fgmres", lambda: K.FgmresSolver(1e-10, 90, 15), jac_o, jac_k, dict(tol=1e-10, max_iters=90, restart=15)),
+            ("bicgstab", lambda: K.BiCgStabSolver(1e-9, 200), None, None, dict(tol=1e-9, max_iters=200)),
+            ("cgs", lambda: K.CgsSolver(1e-10, 200), None, None, dict(tol=1e-10, max_iters=200))]
+    if seed % 2 == 0:
+        runs += [("cg", lambda: K.CgSolver(1e-10, 300), None, None, dict(tol=1e-10, max_iters=300)),
+                 ("pcg", lambda: K.PcgSolver(1e-10, 300), jac_o, jac_k, dict(tol=1e-10, max_iters=300))]
+    for method, mk, opc, kpc, kw in runs:
+        res = O.solve(method, a, b, pc=opc, rs=rs, **kw)
+        s = mk(); x = np.zeros(n)
+        st = s.solve(d, kpc, b, x)
+        _check_solver(res, st, s, x)                   # parity is the point: whether the reference's variant converges is its business
