@@ -23,7 +23,7 @@ from ._ffi import KError, lib, check
 
 __all__ = ["Context", "DeviceVec", "CsrMatrix", "dot", "norm", "Jacobi", "Ilu0", "Ilup", "Ilut", "TrueIlu0", "Chebyshev",
            "ChebyshevPc", "IdentityPc", "ApproxInv", "apply_chebyshev", "Convergence", "SolveStats", "CgNormType",
-           "Preconditioning", "CgSolver", "PcgSolver", "GmresSolver", "FgmresSolver", "Orthog", "CgsSolver", "TfqmrSolver", "BiCgStabSolver", "BiCgStabRightPcSolver", "Session", "KspContext", "SolverKind", "KError", "reduce_spec",
+           "Preconditioning", "CgSolver", "PcgSolver", "GmresSolver", "FgmresSolver", "Orthog", "CgsSolver", "TfqmrSolver", "BiCgStabSolver", "BiCgStabRightPcSolver", "Session", "KspContext", "SolverKind", "PC", "KError", "reduce_spec",
            "host_stencil7", "partition_rows", "halo_recv_plan", "read_matrix_market", "read_petsc_binary"]
 
 
@@ -671,6 +671,52 @@ class TfqmrSolver(_Solver):
 class BiCgStabRightPcSolver(_Solver):
     """Extension: right-preconditioned BiCGStab (device vectors only)."""
     _HOST, _DEV = None, "kryst_bicgstab_rpc_solve_dev"
+
+
+class PC:
+    """PC<T> (src/context/pc_context.rs:36-76): the reference's configuration enum for preconditioners, plus the constructor it
+    lacks -- `PC.Ilut(fill=10, droptol=1e-3).build(a)` returns the set-up device preconditioner.  Kinds outside the hot path
+    (Ssor, ApproxInv setup, BlockJacobi, Multicolor, AMG, AdditiveSchwarz) raise KError(Unsupported)."""
+
+    def __init__(self, kind, **params):
+        self.kind, self.params = kind, params
+
+    def __repr__(self):
+        return f"PC::{self.kind}{self.params or ''}"
+
+    @staticmethod
+    def Jacobi():
+        return PC("Jacobi")
+
+    @staticmethod
+    def Ilu0():
+        return PC("Ilu0")
+
+    @staticmethod
+    def Ilup(fill):
+        return PC("Ilup", fill=fill)
+
+    @staticmethod
+    def Ilut(fill, droptol):
+        return PC("Ilut", fill=fill, droptol=droptol)
+
+    @staticmethod
+    def Chebyshev(degree, emin=None, emax=None):
+        return PC("Chebyshev", degree=degree, emin=emin, emax=emax)
+
+    def build(self, a):
+        k, q = self.kind, self.params
+        if k == "Jacobi":
+            return Jacobi().setup(a)
+        if k == "Ilu0":
+            return Ilu0().setup(a)
+        if k == "Ilup":
+            return Ilup(q["fill"]).setup(a)
+        if k == "Ilut":
+            return Ilut(q["fill"], q["droptol"]).setup(a)
+        if k == "Chebyshev":                         # the trait object of the reference (apply is the stub of chebyshev.rs:68-70)
+            return Chebyshev(q["degree"], q["emin"], q["emax"]).setup(a)
+        raise KError(6, f"preconditioner kind {k} is outside the accelerated path")
 
 
 class SolverKind(enum.Enum):                      # src/context/ksp_context.rs:25-48 (the kinds on the hot path)

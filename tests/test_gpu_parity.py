@@ -810,3 +810,21 @@ def test_solvers_on_random_sparse_matrices_bit_exact(ctx, rs, seed):
         s = mk(); x = np.zeros(n)
         st = s.solve(d, kpc, b, x)
         _check_solver(res, st, s, x)                   # parity is the point: whether the reference's variant converges is its business
+
+
+def test_pc_enum_constructor(ctx, rs):
+    """PC<T> (pc_context.rs:36-76) with the constructor the reference lacks, through KspContext (ksp_context.rs:88-148)."""
+    a = O.stencil7(8, "convdiff"); d = to_dev(ctx, a)
+    b = a.spmv(np.ones(a.nrows))
+    for cfg, opc in ((K.PC.Jacobi(), O.Pc.jacobi(a)), (K.PC.Ilu0(), O.Pc.ilu0_compat(a)), (K.PC.Ilup(1), O.Pc.ilup(a, 1)),
+                     (K.PC.Ilut(4, 1e-3), O.Pc.ilut(a, 4, 1e-3))):
+        res = O.solve("gmres", a, b, pc=opc, tol=1e-9, max_iters=60, restart=20, side=O.SIDE_LEFT, rs=rs)
+        x = np.zeros(a.nrows)
+        st = K.KspContext(K.SolverKind.GmresLeft, d, pc=cfg.build(d), tol=1e-9, max_it=60, restart=20).solve_context(b, x)
+        assert st.iterations == res.iterations and np.array_equal(x, res.x), cfg
+    with pytest.raises(K.KError) as e:
+        K.PC("AMG").build(d)
+    assert e.value.code == 6
+    with pytest.raises(K.KError) as e:                      # the Chebyshev trait object builds, its apply is the reference's stub
+        K.PC.Chebyshev(3, 0.1, 12.0).build(d).apply(np.ones(a.nrows))
+    assert e.value.code == 2
