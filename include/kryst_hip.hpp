@@ -144,6 +144,22 @@ struct TrueIlu0 : DevicePc {                                 // extension
 struct IdentityPC : DevicePc {                               // pcg.rs:245-251
     void setup(const HipCsrMatrix& a) override { kryst_pc_t h = nullptr; check(kryst_pc_identity(a.context()->handle(), &h)); reset(h, a.context()->handle()); }
 };
+// ApproxInv with GIVEN inverse rows (ApproxInv::inv_rows, approxinv.rs:66): apply (approxinv.rs:268-298) is z = M r on the device.
+// ApproxInv::setup (least squares through faer's QR) stays with the reference; setup() here only checks the size.
+struct ApproxInv : DevicePc {
+    explicit ApproxInv(const std::vector<std::vector<std::pair<size_t, double>>>& inv_rows, std::shared_ptr<Context> ctx = Context::global())
+        : m_(build(inv_rows, std::move(ctx))) {
+        kryst_pc_t h = nullptr; check(kryst_pc_approx_inverse(m_.handle(), &h)); reset(h, m_.context()->handle());
+    }
+    void setup(const HipCsrMatrix& a) override { if (a.nrows() != m_.nrows()) throw KError(KRYST_ERR_ARG); }
+private:
+    static HipCsrMatrix build(const std::vector<std::vector<std::pair<size_t, double>>>& rows, std::shared_ptr<Context> ctx) {
+        std::vector<size_t> rp(rows.size() + 1, 0), ci; Vec va;
+        for (size_t i = 0; i < rows.size(); ++i) { for (auto& e : rows[i]) { ci.push_back(e.first); va.push_back(e.second); } rp[i + 1] = ci.size(); }
+        return HipCsrMatrix::from_csr(rows.size(), rows.size(), rp, ci, va, std::move(ctx));
+    }
+    HipCsrMatrix m_;
+};
 struct Chebyshev : DevicePc {                                // chebyshev.rs:35-70: the trait apply is a stub returning Err
     size_t degree; std::optional<double> lambda_min, lambda_max;
     Chebyshev(size_t degree, std::optional<double> lmin, std::optional<double> lmax) : degree(degree), lambda_min(lmin), lambda_max(lmax) {}

@@ -150,6 +150,17 @@ int main() {
         auto sl = gl.solve(an, &ilu, bn, xl);
         REQUIRE(sl.converged && rel_error(xl, x_true) < 1e-10 && sl.iterations == 20);     // two cycles
     }
+    {   // src/preconditioner/approxinv.rs:384-397 / :428-443, apply side: the exact inverse rows of diag(2,3,4) and of the identity
+        ApproxInv inv({{{0, 0.5}}, {{1, 1.0 / 3.0}}, {{2, 0.25}}});
+        auto a = dense({{2.0, 0.0, 0.0}, {0.0, 3.0, 0.0}, {0.0, 0.0, 4.0}});
+        inv.setup(a);
+        Vec z(3, 0.0);
+        inv.apply(Vec{2.0, 3.0, 4.0}, z);
+        REQUIRE(z[0] == 1.0 && z[1] == 1.0 && z[2] == 1.0);
+        Vec x(3, 0.0);
+        PcgSolver pcg(1e-12, 10);
+        REQUIRE(pcg.solve(a, &inv, Vec{2.0, 3.0, 4.0}, x).converged && std::fabs(x[0] - 1.0) < 1e-12 && std::fabs(x[2] - 1.0) < 1e-12);
+    }
     {   // src/preconditioner/chebyshev.rs:184-206 and the stub :68-70 ; ilup.rs:202-212
         auto a = dense({{2.0, 0.0}, {0.0, 3.0}});
         Vec z(2, 0.0);
