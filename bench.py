@@ -97,6 +97,22 @@ def roofline(enc, nloc, nnz_loc, spmv_ms, plain_ms, copy_gbs):
             "measured_copy_GBs": copy_gbs}
 
 
+def blas1_streams(K, ctx, n):
+    """The two BLAS-1 kernel shapes of a CG iteration, timed live with HIP events on fresh vectors of this size
+    (kryst_bench_streams): algorithmic bytes = 48 n (x += a p, r -= a Ap, (r,r): 4 reads + 2 writes) and 24 n (p = r + b p)."""
+    import ctypes as C
+    from kryst_amd._ffi import lib, check
+    stride = ((n + 511) // 512 * 512 + 512) * 8
+    out = []
+    for kind, name, words in ((2, "ew_kernel<CgUpdate1> (x += alpha p, r -= alpha Ap, fused (r,r))", 6), (6, "ew_kernel<AypxDevOp> (p = r + beta p)", 3)):
+        ms = C.c_double(0)
+        check(lib().kryst_bench_streams(ctx.h, n, stride, kind, 20, C.byref(ms)))
+        ach = words * 8 * n / (ms.value * 1e-3) / 1e9
+        out.append({"kernel": name, "bound": "hbm", "bytes_per_launch": words * 8 * n, "ms_per_launch": ms.value,
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS})
+    return out
+
+
 def run_cg(K, ctx, dist, grid, solver, warmup, steps):
     """W warm-up + exactly K timed iterations of one stepping session; returns (seconds, stats, spmv_ms, a)."""
     def barrier():
@@ -142,7 +158,7 @@ def run_cg(K, ctx, dist, grid, solver, warmup, steps):
     for _ in range(10):
         y.copy_from(b)
     copy_gbs = 10 * 16.0 * nloc / (ctx.timer_stop() * 1e-3) / 1e9
-    return dt, stats, spmv_ms, nloc, a.nnz, copy_gbs, enc, plain_ms
+    return dt, stats, spmv_ms, nloc, a.nnz, copy_gbs, enc, plain_ms, blas1_streams(K, ctx, nloc)
 
 
 def main():
@@ -191,7 +207,7 @@ def main():
 
     n = grid ** 3
     nnz = 7 * n - 6 * grid * grid
-    dt, stats, spmv_ms, nloc, nnz_loc, copy_gbs, enc, plain_ms = run_cg(K, ctx, dist, grid, args.solver, args.warmup, args.steps)
+    dt, stats, spmv_ms, nloc, nnz_loc, copy_gbs, enc, plain_ms, streams = run_cg(K, ctx, dist, grid, args.solver, args.warmup, args.steps)
     bytes_local = spmv_bytes(nloc, nnz_loc)
     achieved = bytes_local / (spmv_ms * 1e-3) / 1e9
 
@@ -203,11 +219,12 @@ def main():
                    "rows": n, "nnz": nnz, "partition": f"{world} k-slab(s)", "rhs": "A*1", "x0": "0",
                    "final_residual": stats.final_residual},
         "roofline": roofline(enc, nloc, nnz_loc, spmv_ms, plain_ms, copy_gbs),
+        "roofline_blas1": streams,      # the other two kernels of the iteration (they take 60 % of it once the SpMV streams 18 B/row)
     }
     if world == 1:
         out["roofline"]["traffic"] = traffic_of(grid)
     if world == 1 and grid != 256 and args.with_256:
-        dt2, st2, ms2, nl2, nz2, cp2, enc2, pm2 = run_cg(K, ctx, None, 256, args.solver, args.warmup, args.steps)
+        dt2, st2, ms2, nl2, nz2, cp2, enc2, pm2, _s2 = run_cg(K, ctx, None, 256, args.solver, args.warmup, args.steps)
         out["config1_256"] = {"workload": f"{'jacobi_pcg' if args.solver == 'pcg' else 'cg'}_poisson7_256^3",
                               "value": args.steps / dt2, "unit": "iterations/s", "ms_per_step": dt2 / args.steps * 1e3,
                               "roofline": roofline(enc2, nl2, nz2, ms2, pm2, cp2)}

@@ -61,13 +61,21 @@ struct BenchCgNtOp {                 // BenchCgOp with nontemporal loads and/or 
         if (in1) acc[0] = acc[0] + r1 * r1;
     }
 };
+struct BenchAypxOp {                 // p = r + beta p                      -- 2 reads, 1 write (CG's direction update)
+    static constexpr int NQ = 0;
+    double be; const double* x; double* y;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const d2 a = ld2(x, i), b = ld2(y, i);
+        st2(y, i, a.a + be * b.a, a.b + be * b.b);
+    }
+};
 }  // namespace kr
 
 using namespace kr;
 
 extern "C" int32_t kryst_bench_streams(kryst_ctx_t ctx, int64_t n, int64_t stride_bytes, int32_t kind, int32_t reps, double* avg_ms) {
-    KR_ARG(ctx && avg_ms && n > 0 && reps >= 1 && kind >= 0 && kind <= 5, "bench_streams");
-    const int nvec = kind == 0 ? 3 : kind == 1 ? 9 : 4;
+    KR_ARG(ctx && avg_ms && n > 0 && reps >= 1 && kind >= 0 && kind <= 6, "bench_streams");
+    const int nvec = kind == 0 ? 3 : kind == 1 ? 9 : kind == 6 ? 2 : 4;
     const size_t vbytes = padded_bytes(n) + sizeof(double) * KR_TILE;
     KR_ARG(stride_bytes % 16 == 0 && (size_t)stride_bytes >= vbytes, "bench_streams: stride must be a multiple of 16 and hold a padded vector");
     KR_HIP(hipSetDevice(ctx->device));
@@ -80,6 +88,7 @@ extern "C" int32_t kryst_bench_streams(kryst_ctx_t ctx, int64_t n, int64_t strid
     auto once = [&]() -> int32_t {
         if (kind == 0) return launch_ew(ctx, BenchLinkOp{0.5, v[1], v[2], v[0]}, n);
         if (kind == 1) { BenchDot8Op op; op.w = v[0]; for (int k = 0; k < 8; ++k) op.v[k] = v[k + 1]; return launch_ew(ctx, op, n); }
+        if (kind == 6) return launch_ew(ctx, BenchAypxOp{0.5, v[0], v[1]}, n);
         if (kind == 3) return launch_ew(ctx, BenchCgNtOp<true, true>{0.5, v[0], v[1], v[2], v[3]}, n);
         if (kind == 4) return launch_ew(ctx, BenchCgNtOp<false, true>{0.5, v[0], v[1], v[2], v[3]}, n);
         if (kind == 5) return launch_ew(ctx, BenchCgNtOp<true, false>{0.5, v[0], v[1], v[2], v[3]}, n);
