@@ -37,6 +37,15 @@ __device__ __forceinline__ void st2(double* p, int64_t i, double a, double b) {
     *reinterpret_cast<kr_v2d*>(p + i) = v;
 #endif
 }
+// temporal (cacheable) accesses for a vector that the NEXT launch reads again
+__device__ __forceinline__ d2 ld2_keep(const double* p, int64_t i) {
+    const kr_v2d v = *reinterpret_cast<const kr_v2d*>(p + i);
+    return {v.x, v.y};
+}
+__device__ __forceinline__ void st2_keep(double* p, int64_t i, double a, double b) {
+    kr_v2d v; v.x = a; v.y = b;
+    *reinterpret_cast<kr_v2d*>(p + i) = v;
+}
 // coefficient that lives either in a kernel argument or in device memory (written by a scalar kernel)
 struct Coef {
     const double* ptr; double val;

@@ -30,7 +30,7 @@ struct MultiDotOp {                  // partial (w, v_k), k = 0..NB-1  (:220-222
     static constexpr int NQ = NB;
     const double* w; const double* v[NB];
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[NB]) const {
-        const d2 ww = ld2(w, i);
+        const d2 ww = ld2_keep(w, i);     // w is read by every kernel of the sweep: cacheable; the basis streams past it
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const d2 vv = ld2(v[k], i);
@@ -44,16 +44,16 @@ struct MultiAxpyOp {                 // w = w - h_k v_k, k ascending (:223-228 /
     static constexpr int NQ = 1;
     const double* h; const double* v[NB]; const double* next; double* w;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
-        d2 ww = ld2(w, i);
+        d2 ww = ld2_keep(w, i);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const double hk = h[k];
             const d2 vv = ld2(v[k], i);
             ww.a = ww.a - hk * vv.a; ww.b = ww.b - hk * vv.b;
         }
-        st2(w, i, ww.a, ww.b);
+        st2_keep(w, i, ww.a, ww.b);
         d2 nx = ww;
-        if (next) nx = ld2(next, i);
+        if (next) nx = ld2_keep(next, i);
         if (in0) acc[0] = acc[0] + ww.a * nx.a;
         if (in1) acc[0] = acc[0] + ww.b * nx.b;
     }
@@ -62,15 +62,15 @@ struct RefineLinkOp {                // if |corr| > 1e-10: w = w - corr v_i (:24
     static constexpr int NQ = 1;
     const FgState* fs; const double* vi; const double* next; double* w;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
-        d2 ww = ld2(w, i);
+        d2 ww = ld2_keep(w, i);
         if (fs->apply) {
             const double c = fs->corr;
             const d2 vv = ld2(vi, i);
             ww.a = ww.a - c * vv.a; ww.b = ww.b - c * vv.b;
-            st2(w, i, ww.a, ww.b);
+            st2_keep(w, i, ww.a, ww.b);
         }
         d2 nx = ww;
-        if (next) nx = ld2(next, i);
+        if (next) nx = ld2_keep(next, i);
         if (in0) acc[0] = acc[0] + ww.a * nx.a;
         if (in1) acc[0] = acc[0] + ww.b * nx.b;
     }

@@ -12,9 +12,11 @@ a = K.CsrMatrix.stencil7(N, "convdiff", ctx=ctx)
 n = a.nrows()
 b = a.spmv(ctx.vec(n).fill(1.0))
 pc = K.Jacobi().setup(a)
-for which in ("fgmres", "gmres"):
+for which in ("fgmres", "fgmres-modified", "gmres"):
     for rep in range(2):
-        s = K.FgmresSolver(1e-30, IT, R) if which == "fgmres" else K.GmresSolver(R, 1e-30, IT)
+        s = K.GmresSolver(R, 1e-30, IT) if which == "gmres" else K.FgmresSolver(1e-30, IT, R)
+        if which == "fgmres-modified":
+            s = s.with_orthog(K.Orthog.Modified)
         x = ctx.vec(n)
         ctx.synchronize(); t0 = time.perf_counter()
         st = s.solve(a, pc, b, x)
