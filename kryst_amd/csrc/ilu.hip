@@ -71,6 +71,7 @@ struct IluData {
     TriArgs* d_args = nullptr;
     double* d_rL = nullptr; double* d_y = nullptr; double* d_yU = nullptr; double* d_zU = nullptr;   // level-permuted work vectors
     int32_t* d_mapLU = nullptr;     // L-position of the row at U-position q
+    int32_t* d_flags = nullptr;     // wavefront solve: "this block is under way", one per block and direction
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     int64_t n = 0;
 };
@@ -208,6 +209,9 @@ __global__ __launch_bounds__(256) void tri_syncfree_csr_kernel(const TriArgs* ar
 // waits for lower-numbered ones.  The subtraction order is the stored (ascending column) order of the row: bit-identical.
 // Rows are fetched in CHUNKS of 8 steps with 16-byte loads, one chunk ahead (a lane's rows are consecutive in memory), so a
 // step issues no load of its own; an entry is present iff its coefficient is nonzero (zero entries are never stored).
+#ifndef KR_TG_SLEEP
+#define KR_TG_SLEEP 1
+#endif
 template <bool FORWARD>
 __global__ __launch_bounds__(64) void tri_grid_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, GridView G, int64_t n) {
     if (args->skip) return;
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(64) void tri_grid_kernel(const TriArgs* args, const
             for (int budget = 1 << 22; __any(need_w || need_s) && budget > 0; --budget) {
                 if (need_w) { q.wv[u] = __hip_atomic_load(&out[row + dj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); need_w = is_sentinel(q.wv[u]); }
                 if (need_s) { q.sv[u] = __hip_atomic_load(&out[row + dk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); need_s = is_sentinel(q.sv[u]); }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(KR_TG_SLEEP);
             }
             if (west_glob) yj = q.wv[u];
             if (south_glob) yk = q.sv[u];
@@ -304,8 +308,13 @@ __global__ __launch_bounds__(64) void tri_grid_kernel(const TriArgs* args, const
     }
 }
 
-__global__ __launch_bounds__(256) void tri_fill_kernel(const TriArgs* args, double* dst_ptr, int64_t n) {
+}  // namespace kr
+#include "tri_wave.h"
+namespace kr {
+
+__global__ __launch_bounds__(256) void tri_fill_kernel(const TriArgs* args, double* dst_ptr, int64_t n, int32_t* flags = nullptr, int32_t nflags = 0) {
     if (args->skip) return;
+    if (flags && (int64_t)blockIdx.x * blockDim.x + threadIdx.x < nflags) flags[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = 0;
     double* dst = dst_ptr ? dst_ptr : args->z;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n) dst[p] = __longlong_as_double((long long)KR_TRI_SENTINEL);
@@ -388,6 +397,16 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
         // structured grid: r -> forward wavefront -> y (natural order) -> backward wavefront -> z; no permutations
         const GridFactor& A = D->GL; const GridFactor& B = D->GU;
         const unsigned nb = (unsigned)(((A.Nj + 7) / 8) * ((A.Nk + 7) / 8));
+        const int wave_on = env_int("KRYST_ILU_WAVE", 1);      // 0: the one-wave predecessor of tri_wave_kernel
+        if (wave_on > 0) {
+            const GridView VA{A.Ni, A.Nj, A.Nk, A.d_c1, A.d_c2, A.d_c3, nullptr}, VB{B.Ni, B.Nj, B.Nk, B.d_c1, B.d_c2, B.d_c3, B.d_diag};
+            hipLaunchKernelGGL(tri_fill_kernel, dim3(g), dim3(256), 0, s, D->d_args, D->d_y, D->n, D->d_flags, (int32_t)(2 * nb));
+            hipLaunchKernelGGL((tri_wave_kernel<true>), dim3(nb), dim3(192), 0, s, D->d_args, (const double*)nullptr, D->d_y, VA, D->n, D->d_flags);
+            hipLaunchKernelGGL(tri_fill_kernel, dim3(g), dim3(256), 0, s, D->d_args, (double*)nullptr, D->n, (int32_t*)nullptr, 0);
+            hipLaunchKernelGGL((tri_wave_kernel<false>), dim3(nb), dim3(192), 0, s, D->d_args, (const double*)D->d_y, (double*)nullptr, VB, D->n, D->d_flags + nb);
+            KR_HIP(hipGetLastError());
+            return KRYST_OK;
+        }
         hipLaunchKernelGGL(tri_fill_kernel, dim3(g), dim3(256), 0, s, D->d_args, D->d_y, D->n);
         hipLaunchKernelGGL((tri_grid_kernel<true>), dim3(nb), dim3(64), 0, s, D->d_args, (const double*)nullptr, D->d_y,
                            GridView{A.Ni, A.Nj, A.Nk, A.d_c1, A.d_c2, A.d_c3, nullptr}, D->n);
@@ -442,7 +461,7 @@ void ilu_free(kryst_pc_t pc) {
     IluData* D = reinterpret_cast<IluData*>(pc->d_work);
     if (D->exec) (void)hipGraphExecDestroy(D->exec);
     if (D->graph) (void)hipGraphDestroy(D->graph);
-    D->L.free_all(); D->U.free_all(); D->GL.free_all(); D->GU.free_all(); (void)hipFree(D->d_args); (void)hipFree(D->d_y); (void)hipFree(D->d_rL); (void)hipFree(D->d_yU); (void)hipFree(D->d_zU); (void)hipFree(D->d_mapLU);
+    D->L.free_all(); D->U.free_all(); D->GL.free_all(); D->GU.free_all(); (void)hipFree(D->d_args); (void)hipFree(D->d_flags); (void)hipFree(D->d_y); (void)hipFree(D->d_rL); (void)hipFree(D->d_yU); (void)hipFree(D->d_zU); (void)hipFree(D->d_mapLU);
     delete D;
     pc->d_work = nullptr;
 }
@@ -593,6 +612,10 @@ static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRow
             else if (hipMemsetAsync(*pp, 0, bytes, ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
         }
         if (rc == KRYST_OK && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
+    }
+    if (rc == KRYST_OK && D->GL.ok && D->GU.ok) {
+        const size_t nb = (size_t)((D->GL.Nj + 7) / 8) * (size_t)((D->GL.Nk + 7) / 8);
+        if (hipMalloc(&D->d_flags, sizeof(int32_t) * 2 * nb) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
     }
     if (getenv("KRYST_ILU_VERBOSE"))
         fprintf(stderr, "[kryst ilu] n=%lld %s; levels L/U=%zu/%zu\n", (long long)n, D->GL.ok ? "structured grid (wavefront kernel)" : "level-ordered",
@@ -767,3 +790,9 @@ extern "C" int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kr
     }
     return finish_ilu_pc(a, 100, true, flatten(le), flatten(ue), dg, out);
 }
+
+#ifdef KR_TW_TRACE
+extern "C" int32_t kryst_debug_tw_trace(long long* host, int32_t count) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(kr::tw_trace), sizeof(long long) * count) == hipSuccess ? 0 : 1;
+}
+#endif

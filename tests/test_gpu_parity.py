@@ -260,14 +260,16 @@ def test_triangular_solve_forms_bit_exact(ctx, syncfree, monkeypatch):
             assert np.array_equal(pc.apply(r), ref.apply(r)), (syncfree, a.nrows)
 
 
-@pytest.mark.parametrize("grid_path", ["1", "0"])
+@pytest.mark.parametrize("grid_path", ["1", "wave0", "0"])
 def test_structured_grid_triangular_solve_bit_exact(ctx, grid_path, monkeypatch):
     """Factors of 7-point / 5-point operators on an Ni x Nj x Nk box are solved by the pipelined wavefront kernel
     (KRYST_ILU_GRID=1, default): boxes whose sides are not multiples of the 8 x 8 line block, thin and 2-D boxes, and banded
     matrices that LOOK like a grid but wrap around line ends (must be recognised and take the general path).  Both paths
     give the oracle's bits."""
     import scipy.sparse as sp
-    monkeypatch.setenv("KRYST_ILU_GRID", grid_path)
+    # "1": three-wave wavefront kernel; "wave0": its one-wave predecessor (KRYST_ILU_WAVE=0); "0": level-ordered forms
+    monkeypatch.setenv("KRYST_ILU_GRID", "0" if grid_path == "0" else "1")
+    monkeypatch.setenv("KRYST_ILU_WAVE", "0" if grid_path == "wave0" else "1")
     rng = np.random.default_rng(5)
 
     def box(Ni, Nj, Nk, wrap=False):
@@ -283,7 +285,8 @@ def test_structured_grid_triangular_solve_bit_exact(ctx, grid_path, monkeypatch)
         m.sort_indices(); m.eliminate_zeros()
         return O.Csr(m.shape[0], m.shape[1], m.indptr, m.indices, m.data)
 
-    cases = [box(5, 3, 2), box(9, 8, 8), box(16, 17, 9), box(40, 9, 20), box(7, 20, 1), box(64, 1, 1), box(6, 5, 4, wrap=True)]
+    cases = [box(5, 3, 2), box(9, 8, 8), box(16, 17, 9), box(40, 9, 20), box(7, 20, 1), box(64, 1, 1), box(6, 5, 4, wrap=True),
+             box(75, 24, 17), box(23, 16, 16)]          # long lines in full blocks: the predicate-free interior chunks
     for a in cases:
         d = to_dev(ctx, a)
         for kpc, ofn in ((K.TrueIlu0(), O.Pc.ilu0_true), (K.Ilu0(), O.Pc.ilu0_compat), (K.Ilup(0), O.Pc.ilup0)):
