@@ -398,7 +398,7 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
         const GridFactor& A = D->GL; const GridFactor& B = D->GU;
         const unsigned nb = (unsigned)(((A.Nj + 7) / 8) * ((A.Nk + 7) / 8));
         const int wave_on = env_int("KRYST_ILU_WAVE", 1);      // 0: the one-wave predecessor of tri_wave_kernel
-        if (wave_on > 0) {
+        if (wave_on > 0 && A.Ni >= 2) {
             const GridView VA{A.Ni, A.Nj, A.Nk, A.d_c1, A.d_c2, A.d_c3, nullptr}, VB{B.Ni, B.Nj, B.Nk, B.d_c1, B.d_c2, B.d_c3, B.d_diag};
             hipLaunchKernelGGL(tri_fill_kernel, dim3(g), dim3(256), 0, s, D->d_args, D->d_y, D->n, D->d_flags, (int32_t)(2 * nb));
             hipLaunchKernelGGL((tri_wave_kernel<true>), dim3(nb), dim3(192), 0, s, D->d_args, (const double*)nullptr, D->d_y, VA, D->n, D->d_flags);
@@ -794,5 +794,8 @@ extern "C" int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kr
 #ifdef KR_TW_TRACE
 extern "C" int32_t kryst_debug_tw_trace(long long* host, int32_t count) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(kr::tw_trace), sizeof(long long) * count) == hipSuccess ? 0 : 1;
+}
+extern "C" int32_t kryst_debug_tw_rounds(long long* host, int32_t count) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(kr::tw_rounds), sizeof(long long) * count) == hipSuccess ? 0 : 1;
 }
 #endif

@@ -18,7 +18,7 @@
 //     through costs ~1 us per step with 1024 waves in flight, tools/micro/steplat.hip).  Absent entries are handled by
 //     selecting a +0.0 operand instead of branching (s - c*0 == s for every s when c == +0.0);
 //   * the LOADER wave streams rhs / coefficients / divisor two chunks ahead through its registers into a 3-slot LDS stage;
-//   * the POLLER wave reads the 16 neighbour lines (8 j-neighbours, 8 k-neighbours) 16 steps per round trip, publishes the
+//   * the POLLER wave reads the 16 neighbour lines (8 j-neighbours, 8 k-neighbours) 8 rows per round trip, one 16-byte load per lane, publishes the
 //     leading rows that have been written into an LDS ring and asks again for the rest.  Before its producers have started
 //     it only looks at their "under way" flags, rarely: a thousand waiting blocks asking for rows around the clock slow the
 //     few that compute.
@@ -47,7 +47,7 @@ __device__ __forceinline__ double tw_poll(cgdouble* base, uint32_t off, int imm)
 }
 
 #ifdef KR_TW_TRACE
-__device__ long long tw_trace[8 * 4096];       // per block: entry, chunk 2 / 8 / 16 done, end, waits for the poller / the loader
+__device__ long long tw_trace[8 * 4096]; __device__ long long tw_rounds[16 * 4096];   // poller: end time and rows of its first 8 rounds       // per block: entry, chunk 2 / 8 / 16 done, end, waits for the poller / the loader
 #endif
 __device__ __forceinline__ int tw_lds_load(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void tw_lds_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -60,7 +60,6 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
     constexpr int S = 3;                                                  // LDS stage slots
     constexpr int P = 2;                                                  // chunks the loader keeps in flight in registers
     constexpr int R = 64;                                                 // steps in the neighbour ring
-    constexpr int W = 16;                                                 // rows the poller asks for per round trip
     __shared__ tw_v2 stage[S * NA * (C / 2) * 64];                        // [slot][array][step pair][lane]
     __shared__ double nbv[R * 16];                                        // [step % R][neighbour line]: 0-7 j-neighbours of kl, 8-15 k-neighbours of jl
     __shared__ int ctr[4];                                                // staged chunks, taken chunks, published steps
@@ -70,8 +69,8 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
     cgdouble* c1 = (cgdouble*)G.c1; cgdouble* c2 = (cgdouble*)G.c2; cgdouble* c3 = (cgdouble*)G.c3; cgdouble* dgp = (cgdouble*)G.diag;
     const int wave = threadIdx.x >> 6;                                    // 0 solves, 1 loads, 2 polls
     const int l = threadIdx.x & 63;
-    // the poller's lane p stands for the boundary lane it serves: (0, p) for p < 8, (p - 8, 0) for 8 <= p < 16
-    const int jl = wave == 2 ? (l < 8 ? 0 : (l - 8) & 7) : (l & 7), kl = wave == 2 ? (l < 8 ? l : 0) : (l >> 3), skew = jl + kl;
+    // the poller's lanes 4p..4p+3 stand for the boundary lane they serve: (0, p) for p < 8, (p - 8, 0) for 8 <= p < 16
+    const int jl = wave == 2 ? (l < 32 ? 0 : (l >> 2) - 8) : (l & 7), kl = wave == 2 ? (l < 32 ? l >> 2 : 0) : (l >> 3), skew = jl + kl;
     const int nbj = (G.Nj + 7) >> 3, nbk = (G.Nk + 7) >> 3;
     // blocks are numbered along anti-diagonals J + K = d: the hardware starts workgroups in index order, and with a few
     // hundred of them resident at a time these must be the ones next to the front, not the first rows of the (K, J) box
@@ -154,10 +153,13 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
     }
 
     if (wave == 2) {
-        // ---- the POLLER
-        const bool mine = l < 16 && line_ok && (l < 8 ? J > 0 : K > 0);   // this lane's line has a neighbour block behind it
-        const int64_t dn = l < 8 ? dj : dk;
-        gdouble* const anywhere = out + __builtin_amdgcn_readfirstlane((int)(line0 >> 1)) * (int64_t)2;   // a valid row, the same for the whole wave
+        // ---- the POLLER.  Four lanes per neighbour line, each asking for two consecutive rows with ONE 16-byte load: the
+        // 8 rows of a line and round sit in one or two memory lines and travel as one or two requests.  (Uncached requests
+        // to one memory line are served one after the other, ~0.11 us each: 16 single-row loads per line took 1.8 us a round.)
+        const int q = l & 3;
+        const bool mine = line_ok && (l < 32 ? J > 0 : K > 0);            // this lane's line has a neighbour block behind it
+        const int64_t dn = l < 32 ? dj : dk;
+        gdouble* const anywhere = out + __builtin_amdgcn_readfirstlane((int)(line0 >> 1)) * (int64_t)2;   // a valid pair of rows, the same for the whole wave
         // GATE: until the producers are under way, look at their flags only
         if (l == 0) {
             const bool has_w = J > 0, has_s = K > 0;
@@ -171,39 +173,45 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
 #ifdef KR_TW_TRACE
         if (l == 0 && FORWARD) tw_trace[8 * blk + 5] = wall_clock64();      // gate open
         bool first_pub = true;
+        long long rounds = 0, empty = 0; const long long tp0 = wall_clock64();
 #endif
         const int T = nch * C;
-        int t = 0, want = 4;                                              // rows asked for per line and round: what the last round delivered, plus two
+        const unsigned long long qmask = 0x1111111111111111ull;           // lanes with q == 0
+        int t = 0;
         for (int budget = 1 << 22; t < T && budget > 0;) {
             const int done_steps = max(tw_lds_load(taken) - 1, 0) * C;    // steps the solving wave no longer needs
             const int lim = min(T, done_steps + R);                       // ring slots free up to here
             if (t >= lim) { __builtin_amdgcn_s_sleep(2); --budget; continue; }
-            double v[W];
-            bool need[W];
-#pragma unroll
-            for (int i = 0; i < W; ++i) {                                  // every lane loads (exact load counting); idle lanes read one common row
-                const int ii = t + i - skew;
-                need[i] = mine && ii >= 0 && ii < G.Ni && i < want;
-                v[i] = __hip_atomic_load(need[i] ? &out[row_of(ii) + dn] : anywhere, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            // this lane: rows ii0, ii0 + 1 of its line = steps t + 2q, t + 2q + 1
+            const int ii0 = t + 2 * q - skew;
+            const bool n0 = mine && ii0 >= 0 && ii0 < G.Ni, n1 = mine && ii0 + 1 >= 0 && ii0 + 1 < G.Ni;
+            const int w = (n0 && !n1) ? ii0 - 1 : (!n0 && n1) ? ii0 + 1 : ii0;        // a 2-row window inside the line (Ni >= 2)
+            gdouble* const addr = (n0 || n1) ? &out[(FORWARD ? line0 + w : line0 + G.Ni - 2 - w) + dn] : anywhere;
+            tw_v2 pair;                                                   // agent-scope (sc1) 16-byte load: each 8-byte half is one row, whole or sentinel
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(pair) : "v"(addr) : "memory");
+            const double ra = FORWARD ? pair.x : pair.y, rb = FORWARD ? pair.y : pair.x;   // rows w, w + 1
+            const double r0 = (n0 && !n1) ? rb : ra, r1 = (!n0 && n1) ? ra : rb;           // rows ii0, ii0 + 1
+            const unsigned long long bad0 = __ballot(n0 && tw_is_sentinel(r0)), bad1 = __ballot(n1 && tw_is_sentinel(r1));
             int m = 0;                                                    // leading steps whose 16 rows are all there
-            bool open = true;
 #pragma unroll
-            for (int i = 0; i < W; ++i) {
-                open = open && t + i < lim && i < want && !__any(need[i] && tw_is_sentinel(v[i]));
-                if (open) m = i + 1;
+            for (int sidx = 0; sidx < C; ++sidx) {
+                const unsigned long long bad = (sidx & 1) ? bad1 : bad0;
+                if (m == sidx && t + sidx < lim && (bad & (qmask << (sidx >> 1))) == 0) m = sidx + 1;
             }
             if (budget == 1 && m == 0) m = 1;                             // out of patience: hand over the sentinel (a NaN) rather than hang
-#pragma unroll
-            for (int i = 0; i < W; ++i)
-                if (i < m && l < 16) nbv[((t + i) % R) * 16 + l] = need[i] ? v[i] : 0.0;
-            want = min(W, m + 2);
+            if (2 * q < m) nbv[((t + 2 * q) % R) * 16 + (l >> 2)] = n0 ? r0 : 0.0;
+            if (2 * q + 1 < m) nbv[((t + 2 * q + 1) % R) * 16 + (l >> 2)] = n1 ? r1 : 0.0;
             if (m > 0) { t += m; tw_lds_store(pub, t); }
 #ifdef KR_TW_TRACE
             if (m > 0 && first_pub) { first_pub = false; if (l == 0 && FORWARD) { tw_trace[8 * blk + 6] = wall_clock64(); tw_trace[8 * blk + 7] = m; } }
+            if (rounds < 8 && l == 0 && FORWARD) { tw_rounds[16 * blk + 2 * rounds] = wall_clock64(); tw_rounds[16 * blk + 2 * rounds + 1] = m * 100; }
+            rounds++; if (m == 0) empty++;
 #endif
-            else { __builtin_amdgcn_s_sleep(1); --budget; }
+            if (m == 0) { __builtin_amdgcn_s_sleep(1); --budget; }
         }
+#ifdef KR_TW_TRACE
+        if (l == 0 && FORWARD) { tw_trace[8 * blk + 3] = rounds * 1000000 + empty; tw_trace[8 * blk + 4] = wall_clock64() - tp0; }
+#endif
         return;
     }
 
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
 #endif
     }
 #ifdef KR_TW_TRACE
-    if (l == 0 && FORWARD) { tw_trace[8 * blk + 2] = wall_clock64(); tw_trace[8 * blk + 3] = tr_pub; tw_trace[8 * blk + 4] = tr_stage; }
+    if (l == 0 && FORWARD) { tw_trace[8 * blk + 2] = wall_clock64(); }
 #endif
 }
 

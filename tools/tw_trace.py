@@ -26,8 +26,16 @@ assert lib.kryst_debug_tw_trace(buf, 8 * nb) == 0
 t = np.array(buf, dtype=np.int64).reshape(nb, 8)
 t0 = t[:, 0].min()
 nbj = (Nj + 7) // 8
-print("block  J  K   entry gate-open first-pub(m) chunk1-done   end   (us)   wait-poller  wait-loader (us)")
+print("block  J  K   entry gate-open first-pub(m) chunk1-done   end   (us)   poller: rounds empty us/round")
 for b in range(nb):
     e, f, end, sp_, po, c8, c16 = t[b, 0], t[b, 1], t[b, 2], t[b, 3], t[b, 4], t[b, 5], t[b, 6]
     if nb <= 64 or b % nbj in (0, 1, nbj - 1) or b // nbj in (0, 1):
-        print(f"{b:5d} {b % nbj:2d} {b // nbj:2d} {(e - t0) / 100:7.1f} {(c8 - t0) / 100:7.1f} {(c16 - t0) / 100:7.1f}({t[b, 7]:2d}) {(f - t0) / 100:7.1f} {(end - t0) / 100:7.1f}        {sp_ / 100:8.1f} {po / 100:8.1f}")
+        print(f"{b:5d} {b % nbj:2d} {b // nbj:2d} {(e - t0) / 100:7.1f} {(c8 - t0) / 100:7.1f} {(c16 - t0) / 100:7.1f}({t[b, 7]:2d}) {(f - t0) / 100:7.1f} {(end - t0) / 100:7.1f}        {sp_ // 1000000:6d} {sp_ % 1000000:6d} {po / 100 / max(sp_ // 1000000, 1):8.2f}")
+
+rb = (C.c_longlong * (16 * nb))()
+lib.kryst_debug_tw_rounds.argtypes = [C.POINTER(C.c_longlong), C.c_int32]
+assert lib.kryst_debug_tw_rounds(rb, 16 * nb) == 0
+rr = np.array(rb, dtype=np.int64).reshape(nb, 8, 2)
+print("poller rounds (end time us : rows delivered / asked next):")
+for b in list(range(min(nb, 4))) + ([nb - 1] if nb > 4 else []):
+    print(f"  block {b:4d}: " + "  ".join(f"{(rr[b, i, 0] - t0) / 100:7.1f}:{rr[b, i, 1] // 100}/{rr[b, i, 1] % 100}" for i in range(8)))
