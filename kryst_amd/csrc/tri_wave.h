@@ -104,41 +104,59 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
     int* const staged = &ctr[0]; int* const taken = &ctr[1]; int* const pub = &ctr[2];
 
     if (wave == 1) {
-        // ---- the LOADER: chunk kc + P + 1 requested, chunk kc staged
-        auto fetch = [&](Chunk& q, int t0) {
-            if (fast_chunk(t0)) {
-                const uint32_t off = offset_of(t0), lo = FORWARD ? off : off - 8 * (C - 1);    // lowest row of the chunk
+        // ---- the LOADER: chunk kc + P + 1 requested, chunk kc staged.
+        // Interior chunks: FOUR lanes share a grid line's 64 contiguous bytes per array (lane 4g+c of pass r loads the 16-byte
+        // piece c of line 16r+g), so one load instruction touches 16 memory lines, not 64 -- with a line per lane the loaders
+        // kept each CU's address unit ~80 % busy and everybody else's requests queued behind them.  The piece goes straight
+        // to the LDS row of the lane that will use it.
+        struct Buf { tw_v2 d[NA][C / 2]; };                               // slow chunk: d[a][h] = this lane's steps 2h, 2h+1; fast: d[a][r] = piece of line 16r+g
+        const int g = l >> 2, c = l & 3;
+        uint32_t piece0[4];                                               // byte offset of (line 16r+g, step 0 of chunk 0, piece c); valid arithmetic only for fast chunks
 #pragma unroll
-                for (int h = 0; h < C / 2; ++h) {
-                    const int e0 = FORWARD ? 2 * h : C - 1 - 2 * h, e1 = FORWARD ? 2 * h + 1 : C - 2 - 2 * h;   // steps of the pair's elements
-                    const tw_v2 r2 = *(cg_v2*)tw_at(in, lo, 16 * h), x1 = *(cg_v2*)tw_at(c1, lo, 16 * h);
-                    const tw_v2 x2 = *(cg_v2*)tw_at(c2, lo, 16 * h), x3 = *(cg_v2*)tw_at(c3, lo, 16 * h);
-                    q.rv[e0] = r2.x; q.rv[e1] = r2.y; q.a1[e0] = x1.x; q.a1[e1] = x1.y; q.a2[e0] = x2.x; q.a2[e1] = x2.y; q.a3[e0] = x3.x; q.a3[e1] = x3.y;
-                    if (!FORWARD) { const tw_v2 d2v = *(cg_v2*)tw_at(dgp, lo, 16 * h); q.dg[e0] = d2v.x; q.dg[e1] = d2v.y; }
+        for (int r = 0; r < 4; ++r) {
+            const int L = 16 * r + g, jL = L & 7, kL = L >> 3;
+            const int jx = FORWARD ? J * 8 + jL : G.Nj - 1 - (J * 8 + jL), kx = FORWARD ? K * 8 + kL : G.Nk - 1 - (K * 8 + kL);
+            const int64_t row0 = (int64_t)(kx * G.Nj + jx) * G.Ni + (FORWARD ? -(jL + kL) : G.Ni - 1 + (jL + kL));   // row of step 0
+            piece0[r] = (uint32_t)(8 * row0) + (FORWARD ? 0u : (uint32_t)(-8 * (C - 1))) + 16u * c;
+        }
+        auto fetch = [&](Buf& q, int t0) {
+            if (fast_chunk(t0)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t off = piece0[r] + (uint32_t)(SG * t0);
+                    q.d[0][r] = *(cg_v2*)tw_at(in, off, 0); q.d[1][r] = *(cg_v2*)tw_at(c1, off, 0);
+                    q.d[2][r] = *(cg_v2*)tw_at(c2, off, 0); q.d[3][r] = *(cg_v2*)tw_at(c3, off, 0);
+                    if (!FORWARD) q.d[NA - 1][r] = *(cg_v2*)tw_at(dgp, off, 0);
                 }
             } else {                                                      // lines start / end inside the chunk, ragged blocks: element-wise, clamped
 #pragma unroll
-                for (int u = 0; u < C; ++u) {
-                    const int64_t row = min(max(row_of(t0 + u - skew), (int64_t)0), n - 1);
-                    q.rv[u] = in[row]; q.a1[u] = c1[row]; q.a2[u] = c2[row]; q.a3[u] = c3[row];
-                    if (!FORWARD) q.dg[u] = dgp[row];
+                for (int h = 0; h < C / 2; ++h) {
+                    const int64_t ra = min(max(row_of(t0 + 2 * h - skew), (int64_t)0), n - 1), rb = min(max(row_of(t0 + 2 * h + 1 - skew), (int64_t)0), n - 1);
+                    q.d[0][h] = tw_v2{in[ra], in[rb]}; q.d[1][h] = tw_v2{c1[ra], c1[rb]};
+                    q.d[2][h] = tw_v2{c2[ra], c2[rb]}; q.d[3][h] = tw_v2{c3[ra], c3[rb]};
+                    if (!FORWARD) q.d[NA - 1][h] = tw_v2{dgp[ra], dgp[rb]};
                 }
             }
         };
-        auto publish = [&](const Chunk& q, int kc) {
+        auto publish = [&](const Buf& q, int kc) {
             for (int budget = 1 << 24; kc - tw_lds_load(taken) >= S && budget > 0; --budget) __builtin_amdgcn_s_sleep(2);   // slot still in use
-            tw_v2* dst = stage + (size_t)(kc % S) * NA * (C / 2) * 64 + l;
+            tw_v2* dst = stage + (size_t)(kc % S) * NA * (C / 2) * 64;
+            if (fast_chunk(kc * C)) {
+                const int h = FORWARD ? c : C / 2 - 1 - c;                // the piece's step pair (the backward solve walks rows downwards)
 #pragma unroll
-            for (int h = 0; h < C / 2; ++h) {
-                dst[(0 * (C / 2) + h) * 64] = tw_v2{q.rv[2 * h], q.rv[2 * h + 1]};
-                dst[(1 * (C / 2) + h) * 64] = tw_v2{q.a1[2 * h], q.a1[2 * h + 1]};
-                dst[(2 * (C / 2) + h) * 64] = tw_v2{q.a2[2 * h], q.a2[2 * h + 1]};
-                dst[(3 * (C / 2) + h) * 64] = tw_v2{q.a3[2 * h], q.a3[2 * h + 1]};
-                if (!FORWARD) dst[(4 * (C / 2) + h) * 64] = tw_v2{q.dg[2 * h], q.dg[2 * h + 1]};
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dst[(a * (C / 2) + h) * 64 + 16 * r + g] = FORWARD ? q.d[a][r] : tw_v2{q.d[a][r].y, q.d[a][r].x};
+            } else {
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int h = 0; h < C / 2; ++h) dst[(a * (C / 2) + h) * 64 + l] = q.d[a][h];
             }
             tw_lds_store(staged, kc + 1);
         };
-        Chunk b0, b1, b2;                                                 // chunk kc lives in buffer kc % (P + 1)
+        Buf b0, b1, b2;                                                   // chunk kc lives in buffer kc % (P + 1)
         static_assert(P == 2, "three rotating buffers");
         fetch(b0, 0);
         if (1 < nch) fetch(b1, C);

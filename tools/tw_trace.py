@@ -32,6 +32,10 @@ for b in range(nb):
     if nb <= 64 or b % nbj in (0, 1, nbj - 1) or b // nbj in (0, 1):
         print(f"{b:5d} {b % nbj:2d} {b // nbj:2d} {(e - t0) / 100:7.1f} {(c8 - t0) / 100:7.1f} {(c16 - t0) / 100:7.1f}({t[b, 7]:2d}) {(f - t0) / 100:7.1f} {(end - t0) / 100:7.1f}        {sp_ // 1000000:6d} {sp_ % 1000000:6d} {po / 100 / max(sp_ // 1000000, 1):8.2f}")
 
+late = [(b % nbj, b // nbj) for b in range(1, nb) if t[b, 5] - t[b, 0] < 100]
+print(f"blocks whose gate was open within 1 us of their entry (they were waiting for a slot, not for data): {len(late)} of {nb}")
+dur = (t[:, 2] - t[:, 5]) / 100
+print(f"gate-open -> end per block: min {dur.min():.1f} median {np.median(dur):.1f} max {dur.max():.1f} us; last end {(t[:, 2].max() - t0) / 100:.1f} us")
 rb = (C.c_longlong * (16 * nb))()
 lib.kryst_debug_tw_rounds.argtypes = [C.POINTER(C.c_longlong), C.c_int32]
 assert lib.kryst_debug_tw_rounds(rb, 16 * nb) == 0
