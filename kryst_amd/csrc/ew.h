@@ -46,6 +46,9 @@ __device__ __forceinline__ void st2_keep(double* p, int64_t i, double a, double 
     kr_v2d v; v.x = a; v.y = b;
     *reinterpret_cast<kr_v2d*>(p + i) = v;
 }
+// compile-time choice per kernel instance: keep_in_cache(n) (solver_common.h) picks the instance at launch
+template <bool KEEP> __device__ __forceinline__ d2 ld2_sel(const double* p, int64_t i) { if constexpr (KEEP) return ld2_keep(p, i); else return ld2(p, i); }
+template <bool KEEP> __device__ __forceinline__ void st2_sel(double* p, int64_t i, double a, double b) { if constexpr (KEEP) st2_keep(p, i, a, b); else st2(p, i, a, b); }
 // coefficient that lives either in a kernel argument or in device memory (written by a scalar kernel)
 struct Coef {
     const double* ptr; double val;

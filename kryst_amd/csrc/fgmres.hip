@@ -25,12 +25,12 @@ struct FgState {                     // device
 struct FgPtrs { FgState* fs; double* h; double* cs; double* sn; double* s; double* hcol; double* y; int ld; int restart; };
 
 // ---- vector ops
-template <int NB>
+template <int NB, bool KEEP>
 struct MultiDotOp {                  // partial (w, v_k), k = 0..NB-1  (:220-222 / :231-233)
     static constexpr int NQ = NB;
     const double* w; const double* v[NB];
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[NB]) const {
-        const d2 ww = ld2_keep(w, i);     // w is read by every kernel of the sweep: cacheable; the basis streams past it
+        const d2 ww = ld2_sel<KEEP>(w, i);     // w is read by every kernel of the sweep: cacheable when it fits; the basis streams past it
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const d2 vv = ld2(v[k], i);
@@ -39,38 +39,39 @@ struct MultiDotOp {                  // partial (w, v_k), k = 0..NB-1  (:220-222
         }
     }
 };
-template <int NB>
+template <int NB, bool KEEP>
 struct MultiAxpyOp {                 // w = w - h_k v_k, k ascending (:223-228 / :234-236); partial (w,w) or (w,next) of the result
     static constexpr int NQ = 1;
     const double* h; const double* v[NB]; const double* next; double* w;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
-        d2 ww = ld2_keep(w, i);
+        d2 ww = ld2_sel<KEEP>(w, i);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const double hk = h[k];
             const d2 vv = ld2(v[k], i);
             ww.a = ww.a - hk * vv.a; ww.b = ww.b - hk * vv.b;
         }
-        st2_keep(w, i, ww.a, ww.b);
+        st2_sel<KEEP>(w, i, ww.a, ww.b);
         d2 nx = ww;
-        if (next) nx = ld2_keep(next, i);
+        if (next) nx = ld2_sel<KEEP>(next, i);
         if (in0) acc[0] = acc[0] + ww.a * nx.a;
         if (in1) acc[0] = acc[0] + ww.b * nx.b;
     }
 };
+template <bool KEEP>
 struct RefineLinkOp {                // if |corr| > 1e-10: w = w - corr v_i (:242-246); partial (w, next) or (w, w)
     static constexpr int NQ = 1;
     const FgState* fs; const double* vi; const double* next; double* w;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
-        d2 ww = ld2_keep(w, i);
+        d2 ww = ld2_sel<KEEP>(w, i);
         if (fs->apply) {
             const double c = fs->corr;
             const d2 vv = ld2(vi, i);
             ww.a = ww.a - c * vv.a; ww.b = ww.b - c * vv.b;
-            st2_keep(w, i, ww.a, ww.b);
+            st2_sel<KEEP>(w, i, ww.a, ww.b);
         }
         d2 nx = ww;
-        if (next) nx = ld2_keep(next, i);
+        if (next) nx = ld2_sel<KEEP>(next, i);
         if (in0) acc[0] = acc[0] + ww.a * nx.a;
         if (in1) acc[0] = acc[0] + ww.b * nx.b;
     }
@@ -241,18 +242,24 @@ static int32_t fg_logic_only(kryst_ctx_t ctx, const double* red, const L& l) {
 template <int NB>
 static int32_t dot_batch(kryst_ctx_t ctx, int64_t n, int64_t nt, double* red, const LogicCtx& lc, const FgPtrs& P,
                          const DevState* st, const double* w, double* const* v, int i0, int cnt) {
-    MultiDotOp<NB> op; op.w = w;
-    for (int k = 0; k < NB; ++k) op.v[k] = v[i0 + (k < cnt ? k : 0)];
     static const int bpc = [] { const char* e = getenv("KRYST_DOT_BLOCKS_PER_CU"); return e ? atoi(e) : 4; }();   // read-only reductions want more waves in flight than the mixed streams
-    KR_TRY(fg_launch(ctx, op, n, st, P.fs, bpc));
+    auto go = [&](auto op) -> int32_t {
+        op.w = w;
+        for (int k = 0; k < NB; ++k) op.v[k] = v[i0 + (k < cnt ? k : 0)];
+        return fg_launch(ctx, op, n, st, P.fs, bpc);
+    };
+    if (keep_in_cache(n)) KR_TRY(go(MultiDotOp<NB, true>{})); else KR_TRY(go(MultiDotOp<NB, false>{}));
     return reduce_then<NB>(ctx, nt, red, FgHcolLogic<NB>{lc, P, i0, cnt});
 }
 template <int NB>
 static int32_t axpy_batch(kryst_ctx_t ctx, int64_t n, const FgPtrs& P, const DevState* st, double* w, double* const* v,
                           int i0, const double* next) {
-    MultiAxpyOp<NB> op; op.h = P.hcol + i0; op.next = next; op.w = w;
-    for (int k = 0; k < NB; ++k) op.v[k] = v[i0 + k];
-    return fg_launch(ctx, op, n, st, P.fs);
+    auto go = [&](auto op) -> int32_t {
+        op.h = P.hcol + i0; op.next = next; op.w = w;
+        for (int k = 0; k < NB; ++k) op.v[k] = v[i0 + k];
+        return fg_launch(ctx, op, n, st, P.fs);
+    };
+    return keep_in_cache(n) ? go(MultiAxpyOp<NB, true>{}) : go(MultiAxpyOp<NB, false>{});
 }
 
 int32_t fgmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, int32_t orthog, double haptol, int32_t preallocate) {
@@ -334,7 +341,8 @@ int32_t fgmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, int32_t 
             if (orthog == 1)                                                                      // :239-247
                 for (int i = 0; i <= j; ++i) {
                     KR_TRY((reduce_then<1>(ctx, nt, ws.red, FgCorrLogic{lc, P})));
-                    KR_TRY(fg_launch(ctx, RefineLinkOp{fs, V[i], i < j ? V[i + 1] : nullptr, w}, n, st, fs));
+                    if (keep_in_cache(n)) KR_TRY(fg_launch(ctx, RefineLinkOp<true>{fs, V[i], i < j ? V[i + 1] : nullptr, w}, n, st, fs));
+                    else KR_TRY(fg_launch(ctx, RefineLinkOp<false>{fs, V[i], i < j ? V[i + 1] : nullptr, w}, n, st, fs));
                 }
             KR_TRY((reduce_then<1>(ctx, nt, ws.red, FgNormLogic{lc, P, j, haptol})));
             KR_TRY(fg_launch(ctx, NextBasisOp{fs, w, V[j + 1]}, n, st, fs, 4));                   // :255-261 (fp64 divisions: 4 workgroups per CU)

@@ -32,18 +32,19 @@ struct DivOp {                       // out = in / s      (gmres.rs:242,253,304 
         st2(out, i, a.a / d, a.b / d);
     }
 };
+template <bool KEEP>
 struct MgsLinkOp {                   // z = z - h*Bi (gmres.rs:85-87) ; partial z.Bnext (the next link's dot, :84/:91)
     static constexpr int NQ = 1;         // bnext == nullptr: partial z.z of the UPDATED z (h[j+1][j] = ||z||, :97)
     const double* h; const double* bi; const double* bnext; double* z;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         const double hv = *h;
         // z is read again by the very next link and Bnext is its Bi: cacheable accesses for those two, streaming for Bi
-        // (GMRES(30): 256^3 310 -> 336 it/s, 128^3 1377 -> 1495)
-        const d2 zz = ld2_keep(z, i), b = ld2(bi, i);
+        // when they can survive in the memory-side cache (GMRES(30): 256^3 310 -> 336 it/s, 128^3 1377 -> 1495)
+        const d2 zz = ld2_sel<KEEP>(z, i), b = ld2(bi, i);
         const double z0 = zz.a - hv * b.a, z1 = zz.b - hv * b.b;
-        st2_keep(z, i, z0, z1);
+        st2_sel<KEEP>(z, i, z0, z1);
         d2 nx{z0, z1};
-        if (bnext) nx = ld2_keep(bnext, i);
+        if (bnext) nx = ld2_sel<KEEP>(bnext, i);
         if (in0) acc[0] = acc[0] + z0 * nx.a;
         if (in1) acc[0] = acc[0] + z1 * nx.b;
     }
@@ -282,7 +283,8 @@ int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
                     KR_TRY((reduce_then<1>(ctx, nt, ws.red, GmHLogic{lc, P, i, j, sweep})));
                     const bool last = (sweep == 1 && i == j);
                     const double* nxt = last ? nullptr : (i < j ? B[i + 1] : B[0]);                    // last link: ||z||^2 (:97)
-                    KR_TRY(launch_iter(ctx, MgsLinkOp{&P.gs->hcur, B[i], nxt, zz}, n, st, gs));
+                    if (keep_in_cache(n)) KR_TRY(launch_iter(ctx, MgsLinkOp<true>{&P.gs->hcur, B[i], nxt, zz}, n, st, gs));
+                    else KR_TRY(launch_iter(ctx, MgsLinkOp<false>{&P.gs->hcur, B[i], nxt, zz}, n, st, gs));
                 }
             KR_TRY((reduce_then<1>(ctx, nt, ws.red, GmNormLogic{lc, P, j})));
             // v_{j+1} = z / h[j+1][j] (:102-103 / :304-306 / :336-341); skipped once the cycle is left

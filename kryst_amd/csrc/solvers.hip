@@ -15,18 +15,20 @@ struct DotPairOp {
         if (in1) { acc[0] = acc[0] + u.b * v.b; acc[1] = acc[1] + w.b * z.b; }
     }
 };
+template <bool KEEP = false>
 struct AypxDevOp {                   // y = x + beta*y  (cg.rs:274-276, pcg.rs:215-217), beta on the device
     static constexpr int NQ = 0;
     const double* beta; const double* x; double* y;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double be = *beta;
-        const d2 a = ld2(x, i), b = ld2(y, i);
+        const d2 a = ld2_sel<KEEP>(x, i), b = ld2(y, i);                 // x (the residual) was written by the launch before this one
         st2(y, i, a.a + be * b.a, a.b + be * b.b);
     }
 };
 
 // =================================================================== CG (src/solver/cg.rs:114-288)
 // x += alpha p ; r -= alpha Ap (cg.rs:207-212) ; partial r.r (cg.rs:223) [; partial r.p for the Natural norm, :227]
+template <bool KEEP = false>
 struct CgUpdate1 {
     static constexpr int NQ = 1;
     const double* alpha; const double* p; const double* ap; double* x; double* r;
@@ -35,7 +37,7 @@ struct CgUpdate1 {
         const d2 pp = ld2(p, i), aa = ld2(ap, i), xx = ld2(x, i), rr = ld2(r, i);
         const double x0 = xx.a + al * pp.a, x1 = xx.b + al * pp.b;
         const double r0 = rr.a - al * aa.a, r1 = rr.b - al * aa.b;
-        st2(x, i, x0, x1); st2(r, i, r0, r1);
+        st2(x, i, x0, x1); st2_sel<KEEP>(r, i, r0, r1);                   // r is read again by the next launch (p = r + beta p)
         if (in0) acc[0] = acc[0] + r0 * r0;
         if (in1) acc[0] = acc[0] + r1 * r1;
     }
@@ -211,7 +213,8 @@ struct CgRun : SolverRun {
         }
         const bool nat = prm.norm_type == 2;
         if (nat) KR_TRY(launch_ew(ctx, CgUpdate2{&ws.st->alpha, pp, ap, xw, r}, n, done));
-        else KR_TRY(launch_ew(ctx, CgUpdate1{&ws.st->alpha, pp, ap, xw, r}, n, done));            // :207-212 + (r,r) :223
+        else if (keep_in_cache(n)) KR_TRY(launch_ew(ctx, CgUpdate1<true>{&ws.st->alpha, pp, ap, xw, r}, n, done));
+        else KR_TRY(launch_ew(ctx, CgUpdate1<false>{&ws.st->alpha, pp, ap, xw, r}, n, done));            // :207-212 + (r,r) :223
         if (!prm.has_obj_target) {
             if (nat) KR_TRY((reduce_then<2>(ctx, nt, ws.red, CgBetaLogic{lc})));
             else KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgBetaLogic{lc})));
@@ -225,7 +228,8 @@ struct CgRun : SolverRun {
             hipLaunchKernelGGL((logic_kernel<CgBetaStoredLogic>), dim3(1), dim3(64), 0, ctx->s_main, ws.red, CgBetaStoredLogic{lc});
             KR_HIP(hipGetLastError());
         }
-        return launch_ew(ctx, AypxDevOp{&ws.st->beta, r, pp}, n, done);                           // :274-276
+        if (keep_in_cache(n)) return launch_ew(ctx, AypxDevOp<true>{&ws.st->beta, r, pp}, n, done);
+        return launch_ew(ctx, AypxDevOp<false>{&ws.st->beta, r, pp}, n, done);                           // :274-276
     }
 };
 
@@ -354,7 +358,7 @@ struct PcgRun : SolverRun {
             KR_TRY(launch_ew(ctx, DotPairOp{r, z, nq_a, nq_a}, n, done));                         // :188-195
         }
         KR_TRY((reduce_then<2>(ctx, nt, ws.red, PcgBetaLogic{lc})));
-        return launch_ew(ctx, AypxDevOp{&ws.st->beta, z, pp}, n, done);                           // :215-217
+        return launch_ew(ctx, AypxDevOp<false>{&ws.st->beta, z, pp}, n, done);                           // :215-217
     }
 };
 
