@@ -242,7 +242,7 @@ int32_t cg_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
 // =================================================================== PCG (src/solver/pcg.rs:114-222)
 // fused update for z == r (pc None / identity) and z = D^-1 r (Jacobi):
 //   x += alpha p ; r -= alpha Ap ; z = M^-1 r ; partial 0 = r.z ; partial 1 = norm quantity (z.z | r.r)
-template <bool JACOBI>
+template <bool JACOBI, bool KEEP = false>
 struct PcgUpdateOp {
     static constexpr int NQ = 2; static constexpr int BPC = 3;       // 5 reads + 3 writes: 3 workgroups per CU measured best (+3 %)
     const double* alpha; const double* p; const double* ap; double* x; double* r; double* z; const double* inv;
@@ -257,7 +257,7 @@ struct PcgUpdateOp {
         if constexpr (JACOBI) {
             const d2 dv = ld2(inv, i);
             z0 = dv.a * r0; z1 = dv.b * r1;                                          // jacobi.rs:84-86
-            st2(z, i, z0, z1);
+            st2_sel<KEEP>(z, i, z0, z1);                                             // z is read again by the next launch (p = z + beta p)
         }
         const bool zz = norm_type == 0;                                              // Preconditioned: (z,z); else (r,r)
         if (in0) { acc[0] = acc[0] + r0 * z0; acc[1] = acc[1] + (zz ? z0 * z0 : r0 * r0); }
@@ -350,7 +350,8 @@ struct PcgRun : SolverRun {
         if (alias) {
             KR_TRY(launch_ew(ctx, PcgUpdateOp<false>{&ws.st->alpha, pp, ap, xw, r, z, nullptr, nt_}, n, done));
         } else if (jac) {
-            KR_TRY(launch_ew(ctx, PcgUpdateOp<true>{&ws.st->alpha, pp, ap, xw, r, z, pc->d_inv_diag, nt_}, n, done));
+            if (keep_in_cache(n)) KR_TRY(launch_ew(ctx, PcgUpdateOp<true, true>{&ws.st->alpha, pp, ap, xw, r, z, pc->d_inv_diag, nt_}, n, done));
+            else KR_TRY(launch_ew(ctx, PcgUpdateOp<true, false>{&ws.st->alpha, pp, ap, xw, r, z, pc->d_inv_diag, nt_}, n, done));
         } else {
             KR_TRY(launch_ew(ctx, CgUpdate0{&ws.st->alpha, pp, ap, xw, r}, n, done));             // :175-181
             KR_TRY(pc_apply_dev(pc, r, z, done));                                                 // :183-187
@@ -358,6 +359,7 @@ struct PcgRun : SolverRun {
             KR_TRY(launch_ew(ctx, DotPairOp{r, z, nq_a, nq_a}, n, done));                         // :188-195
         }
         KR_TRY((reduce_then<2>(ctx, nt, ws.red, PcgBetaLogic{lc})));
+        if (jac && !alias && keep_in_cache(n)) return launch_ew(ctx, AypxDevOp<true>{&ws.st->beta, z, pp}, n, done);
         return launch_ew(ctx, AypxDevOp<false>{&ws.st->beta, z, pp}, n, done);                           // :215-217
     }
 };
@@ -369,12 +371,13 @@ int32_t pcg_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
 }
 
 // =================================================================== BiCGStab (src/solver/bicgstab.rs:69-293)
+template <bool KEEP = false>
 struct BicgPOp {                     // p = r + beta*(p - omega_prev*v)   (bicgstab.rs:134/140)
     static constexpr int NQ = 0;
     const DevState* st; const double* r; const double* v; double* p;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double be = st->beta, om = st->omega_prev;
-        const d2 rr = ld2(r, i), vv = ld2(v, i), pp = ld2(p, i);
+        const d2 rr = ld2_sel<KEEP>(r, i), vv = ld2(v, i), pp = ld2(p, i);      // r was written by the launch before this one
         st2(p, i, rr.a + be * (pp.a - om * vv.a), rr.b + be * (pp.b - om * vv.b));
     }
 };
@@ -392,6 +395,7 @@ struct BicgSOp {                     // s = r - alpha*v ; partial s.s     (bicgs
 };
 // x = x + alpha*p + omega*s ; r = s - omega*t ; partials r.r and rhat.r (the next rho)   (bicgstab.rs:240-279,105-116)
 // when the s-norm exit is pending (st->early): only x = x + alpha*p   (bicgstab.rs:191-202)
+template <bool KEEP = false>
 struct BicgXROp {
     static constexpr int NQ = 2;
     // p / sx: the directions x is updated with (M^-1 p, M^-1 s in the right-preconditioned extension); s: the true s
@@ -406,7 +410,7 @@ struct BicgXROp {
         if (sx != s) sd = ld2(sx, i);
         st2(x, i, xx.a + al * pp.a + om * sd.a, xx.b + al * pp.b + om * sd.b);
         const double r0 = ss.a - om * tt.a, r1 = ss.b - om * tt.b;
-        st2(r, i, r0, r1);
+        st2_sel<KEEP>(r, i, r0, r1);
         if (in0) { acc[0] = acc[0] + r0 * r0; acc[1] = acc[1] + hh.a * r0; }
         if (in1) { acc[0] = acc[0] + r1 * r1; acc[1] = acc[1] + hh.b * r1; }
     }
@@ -500,7 +504,8 @@ struct BicgRun : SolverRun {
     }
     int32_t iterate(int64_t) override {
         const DevState* st = ws.st;
-        KR_TRY(launch_ew(ctx, BicgPOp{st, r, v, pp}, n, done));                                   // :126-142
+        if (keep_in_cache(n)) KR_TRY(launch_ew(ctx, BicgPOp<true>{st, r, v, pp}, n, done));
+        else KR_TRY(launch_ew(ctx, BicgPOp<false>{st, r, v, pp}, n, done));                                   // :126-142
         if (pc) { KR_TRY(pc_apply_dev(pc, pp, ph, done)); KR_TRY(launch_spmv(a, ph, v, 1, rhat, done)); }
         else KR_TRY(launch_spmv(a, pp, v, 1, rhat, done));                                        // :144-146 + (rhat,v)
         KR_TRY((reduce_then<1>(ctx, nt, ws.red, BicgAlphaLogic{lc})));
@@ -509,8 +514,8 @@ struct BicgRun : SolverRun {
         if (pc) { KR_TRY(pc_apply_dev(pc, s, sh, done)); KR_TRY(launch_spmv(a, sh, t, 2, s, done)); }
         else KR_TRY(launch_spmv(a, s, t, 2, s, done));                                            // :208-209 + (t,s),(t,t)
         KR_TRY((reduce_then<2>(ctx, nt, ws.red, BicgOmegaLogic{lc})));
-        const BicgXROp op{st, pc ? ph : pp, pc ? sh : s, s, t, rhat, xw, r};
-        KR_TRY(launch_ew_gated(ctx, op, n, GateEarly{st}));
+        if (keep_in_cache(n)) KR_TRY(launch_ew_gated(ctx, BicgXROp<true>{st, pc ? ph : pp, pc ? sh : s, s, t, rhat, xw, r}, n, GateEarly{st}));
+        else KR_TRY(launch_ew_gated(ctx, BicgXROp<false>{st, pc ? ph : pp, pc ? sh : s, s, t, rhat, xw, r}, n, GateEarly{st}));
         return reduce_then<2>(ctx, nt, ws.red, BicgEndLogic{lc});
     }
 };
