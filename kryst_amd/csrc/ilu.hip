@@ -209,9 +209,6 @@ __global__ __launch_bounds__(256) void tri_syncfree_csr_kernel(const TriArgs* ar
 // waits for lower-numbered ones.  The subtraction order is the stored (ascending column) order of the row: bit-identical.
 // Rows are fetched in CHUNKS of 8 steps with 16-byte loads, one chunk ahead (a lane's rows are consecutive in memory), so a
 // step issues no load of its own; an entry is present iff its coefficient is nonzero (zero entries are never stored).
-#ifndef KR_TG_SLEEP
-#define KR_TG_SLEEP 1
-#endif
 template <bool FORWARD>
 __global__ __launch_bounds__(64) void tri_grid_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, GridView G, int64_t n) {
     if (args->skip) return;
@@ -276,7 +273,7 @@ __global__ __launch_bounds__(64) void tri_grid_kernel(const TriArgs* args, const
             for (int budget = 1 << 22; __any(need_w || need_s) && budget > 0; --budget) {
                 if (need_w) { q.wv[u] = __hip_atomic_load(&out[row + dj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); need_w = is_sentinel(q.wv[u]); }
                 if (need_s) { q.sv[u] = __hip_atomic_load(&out[row + dk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); need_s = is_sentinel(q.sv[u]); }
-                __builtin_amdgcn_s_sleep(KR_TG_SLEEP);
+                __builtin_amdgcn_s_sleep(1);
             }
             if (west_glob) yj = q.wv[u];
             if (south_glob) yk = q.sv[u];
