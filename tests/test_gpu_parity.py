@@ -286,7 +286,9 @@ def test_structured_grid_triangular_solve_bit_exact(ctx, grid_path, monkeypatch)
         return O.Csr(m.shape[0], m.shape[1], m.indptr, m.indices, m.data)
 
     cases = [box(5, 3, 2), box(9, 8, 8), box(16, 17, 9), box(40, 9, 20), box(7, 20, 1), box(64, 1, 1), box(6, 5, 4, wrap=True),
-             box(75, 24, 17), box(23, 16, 16)]          # long lines in full blocks: the predicate-free interior chunks
+             box(75, 24, 17), box(23, 16, 16),          # long lines in full blocks: the predicate-free interior chunks
+             box(1, 9, 9), box(2, 17, 9), box(3, 8, 16),   # lines shorter than the poller's two-row window
+             box(300, 8, 16)]                           # the neighbour ring and the LDS stage wrap many times
     for a in cases:
         d = to_dev(ctx, a)
         for kpc, ofn in ((K.TrueIlu0(), O.Pc.ilu0_true), (K.Ilu0(), O.Pc.ilu0_compat), (K.Ilup(0), O.Pc.ilup0)):
