@@ -53,7 +53,7 @@ __device__ __forceinline__ int tw_lds_load(int* p) { return __hip_atomic_load(p,
 __device__ __forceinline__ void tw_lds_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 template <bool FORWARD>
-__global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, GridView G, int64_t n, int32_t* flags) {
+__global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, GridView G, int64_t n, int32_t* flags, int32_t* abort_word) {
     if (args->skip) return;
     constexpr int C = 8;                                                  // steps per chunk
     constexpr int NA = FORWARD ? 4 : 5;                                   // arrays staged per chunk: rhs, c1, c2, c3 (, divisor)
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
                 const bool ok_w = !has_w || __hip_atomic_load(&flags[blk - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                 const bool ok_s = !has_s || __hip_atomic_load(&flags[blk - nbj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                 if (ok_w && ok_s) break;
+                if ((budget & 63) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                 __builtin_amdgcn_s_sleep(8);
             }
         }
@@ -216,7 +217,13 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
                 const unsigned long long bad = (sidx & 1) ? bad1 : bad0;
                 if (m == sidx && t + sidx < lim && (bad & (qmask << (sidx >> 1))) == 0) m = sidx + 1;
             }
-            if (budget == 1 && m == 0) m = 1;                             // out of patience: hand over the sentinel (a NaN) rather than hang
+            // out of patience (a logic error, never seen): hand over the sentinels (NaNs) and tell every block to do the same,
+            // so that the launch ends in seconds with a NaN result instead of occupying the GPU for minutes
+            if (m == 0 && (budget == 1 || ((budget & 255) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))) {
+                __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tw_lds_store(&ctr[3], 1);
+                budget = 1; m = 1;
+            }
             if (2 * q < m) nbv[((t + 2 * q) % R) * 16 + (l >> 2)] = n0 ? r0 : 0.0;
             if (2 * q + 1 < m) nbv[((t + 2 * q + 1) % R) * 16 + (l >> 2)] = n1 ? r1 : 0.0;
             if (m > 0) { t += m; tw_lds_store(pub, t); }
@@ -271,6 +278,7 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
             for (int budget = 1 << 26; budget > 0; --budget) {
                 pub_seen = __builtin_amdgcn_readfirstlane(tw_lds_load(pub));
                 if (t < pub_seen) break;
+                if ((budget & 255) == 0 && __builtin_amdgcn_readfirstlane(tw_lds_load(&ctr[3])) != 0) { pub_seen = 1 << 30; break; }   // the poller gave up
                 __builtin_amdgcn_s_sleep(1);
             }
 #ifdef KR_TW_TRACE
