@@ -397,9 +397,9 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
         const int wave_on = env_int("KRYST_ILU_WAVE", 1);      // 0: the one-wave predecessor of tri_wave_kernel
         if (wave_on > 0 && A.Ni >= 2) {
             const GridView VA{A.Ni, A.Nj, A.Nk, A.d_c1, A.d_c2, A.d_c3, nullptr}, VB{B.Ni, B.Nj, B.Nk, B.d_c1, B.d_c2, B.d_c3, B.d_diag};
-            hipLaunchKernelGGL(tri_fill_kernel, dim3(g), dim3(256), 0, s, D->d_args, D->d_y, D->n, D->d_flags, (int32_t)(2 * nb + 1));
+            hipLaunchKernelGGL((tri_wave_fill_kernel<true>), dim3(nb), dim3(256), 0, s, D->d_args, D->d_y, VA, D->d_flags, (int32_t)(2 * nb + 1));
             hipLaunchKernelGGL((tri_wave_kernel<true>), dim3(nb), dim3(192), 0, s, D->d_args, (const double*)nullptr, D->d_y, VA, D->n, D->d_flags, D->d_flags + 2 * nb);
-            hipLaunchKernelGGL(tri_fill_kernel, dim3(g), dim3(256), 0, s, D->d_args, (double*)nullptr, D->n, (int32_t*)nullptr, 0);
+            hipLaunchKernelGGL((tri_wave_fill_kernel<false>), dim3(nb), dim3(256), 0, s, D->d_args, (double*)nullptr, VB, (int32_t*)nullptr, 0);
             hipLaunchKernelGGL((tri_wave_kernel<false>), dim3(nb), dim3(192), 0, s, D->d_args, (const double*)D->d_y, (double*)nullptr, VB, D->n, D->d_flags + nb, D->d_flags + 2 * nb);
             KR_HIP(hipGetLastError());
             return KRYST_OK;

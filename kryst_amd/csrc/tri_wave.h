@@ -52,6 +52,27 @@ __device__ long long tw_trace[8 * 4096]; __device__ long long tw_rounds[16 * 409
 __device__ __forceinline__ int tw_lds_load(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void tw_lds_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// Sentinels only where somebody will look: the rows of the lines another block's poller reads (15 of a block's 64 lines).
+// One workgroup per block of lines; also clears the "under way" flags and the abort word.
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void tri_wave_fill_kernel(const TriArgs* args, double* out_ptr, GridView G, int32_t* flags, int32_t nflags) {
+    if (args->skip) return;
+    double* out = out_ptr ? out_ptr : args->z;
+    const int nbj = (G.Nj + 7) >> 3, nbk = (G.Nk + 7) >> 3;
+    const int J = blockIdx.x % nbj, K = blockIdx.x / nbj;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nflags; i += gridDim.x * 256) flags[i] = 0;
+    const double sentinel = __longlong_as_double((long long)KR_TRI_SENTINEL);
+    for (int line = 0; line < 64; ++line) {
+        const int jl = line & 7, kl = line >> 3;
+        if (!((jl == 7 && J + 1 < nbj) || (kl == 7 && K + 1 < nbk))) continue;
+        const int jj = J * 8 + jl, kk = K * 8 + kl;
+        if (jj >= G.Nj || kk >= G.Nk) continue;
+        const int j = FORWARD ? jj : G.Nj - 1 - jj, k = FORWARD ? kk : G.Nk - 1 - kk;
+        double* row0 = out + (int64_t)(k * G.Nj + j) * G.Ni;
+        for (int i = threadIdx.x; i < G.Ni; i += 256) row0[i] = sentinel;
+    }
+}
+
 template <bool FORWARD>
 __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, GridView G, int64_t n, int32_t* flags, int32_t* abort_word) {
     if (args->skip) return;
