@@ -337,11 +337,13 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
             yv[u] = y;
             if (edge) __hip_atomic_store((gdouble*)tw_at(out, off, SG * u), y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const uint32_t lo = FORWARD ? off : off - 8 * (C - 1);           // lowest row of the chunk
+        if (!edge) {                                                      // (the edge lanes' rows are in memory already)
+            const uint32_t lo = FORWARD ? off : off - 8 * (C - 1);       // lowest row of the chunk
 #pragma unroll
-        for (int h = 0; h < C / 2; ++h) {
-            tw_v2 v; v.x = yv[FORWARD ? 2 * h : C - 1 - 2 * h]; v.y = yv[FORWARD ? 2 * h + 1 : C - 2 - 2 * h];
-            *(__attribute__((address_space(1))) tw_v2*)tw_at(out, lo, 16 * h) = v;
+            for (int h = 0; h < C / 2; ++h) {
+                tw_v2 v; v.x = yv[FORWARD ? 2 * h : C - 1 - 2 * h]; v.y = yv[FORWARD ? 2 * h + 1 : C - 2 - 2 * h];
+                *(__attribute__((address_space(1))) tw_v2*)tw_at(out, lo, 16 * h) = v;
+            }
         }
     };
     // ---- 8 steps, every predicate (lines that start / end inside the chunk, ragged blocks)
