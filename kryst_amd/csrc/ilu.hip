@@ -18,6 +18,10 @@
 // workgroup barriers replace kernel boundaries) was built and measured: bit-identical but no faster, removed again.
 // In a distributed context the factors are block-local (block-Jacobi ILU): halo columns are dropped.
 #include "pc.h"
+#include <chrono>
+#include <thread>
+#include <mutex>
+#include <atomic>
 #include "ew.h"
 #include <algorithm>
 #include <cmath>
@@ -25,6 +29,19 @@
 
 namespace kr {
 
+// host-side loops over independent rows, split over the box's cores (setup only)
+template <class F>
+static void par_rows(int64_t n, F body) {
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (n < (1 << 16) || hw == 1) { body((int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    const int64_t per = (n + hw - 1) / hw;
+    for (unsigned t = 0; t < hw; ++t) {
+        const int64_t lo = std::min<int64_t>(n, per * t), hi = std::min<int64_t>(n, lo + per);
+        if (lo < hi) th.emplace_back([=] { body(lo, hi); });
+    }
+    for (auto& t : th) t.join();
+}
 static int env_i(const char* nm, int d) { const char* e = getenv(nm); return e ? atoi(e) : d; }
 
 struct TriArgs {                    // device-resident argument block, rewritten before every apply (graph-friendly):
@@ -528,30 +545,50 @@ static int32_t build_factor(int64_t n, const FlatRows& ent, const std::vector<do
 static int32_t build_grid(int64_t n, const FlatRows& ent, const std::vector<double>& diag, bool forward, GridFactor* G) {
     if (n < 2 || n >= (1ll << 31) || env_i("KRYST_ILU_GRID", 1) == 0) return KRYST_OK;
     int64_t offs[3] = {0, 0, 0}; int no = 0;                              // distinct |col - row|, at most three
-    for (int64_t i = 0; i < n; ++i)
-        for (int64_t k = ent.ptr[i]; k < ent.ptr[i + 1]; ++k) {
-            const int64_t o = (int64_t)ent.col[k] - i;
-            if ((forward && o >= 0) || (!forward && o <= 0)) return KRYST_OK;
-            if (k > ent.ptr[i] && ent.col[k] <= ent.col[k - 1]) return KRYST_OK;   // the kernel subtracts in ascending column order (Ilut stores by magnitude)
-            const int64_t ao = o < 0 ? -o : o;
-            bool seen = false;
-            for (int q = 0; q < no; ++q) seen = seen || offs[q] == ao;
-            if (!seen) { if (no == 3) return KRYST_OK; offs[no++] = ao; }
-        }
+    {
+        std::atomic<bool> reject{false};
+        std::mutex mu;
+        par_rows(n, [&](int64_t lo, int64_t hi) {
+            int64_t mine[3] = {0, 0, 0}; int nm = 0;
+            for (int64_t i = lo; i < hi && !reject.load(std::memory_order_relaxed); ++i)
+                for (int64_t k = ent.ptr[i]; k < ent.ptr[i + 1]; ++k) {
+                    const int64_t o = (int64_t)ent.col[k] - i;
+                    if ((forward && o >= 0) || (!forward && o <= 0)) { reject = true; return; }
+                    if (k > ent.ptr[i] && ent.col[k] <= ent.col[k - 1]) { reject = true; return; }   // the kernel subtracts in ascending column order (Ilut stores by magnitude)
+                    const int64_t ao = o < 0 ? -o : o;
+                    bool seen = false;
+                    for (int q = 0; q < nm; ++q) seen = seen || mine[q] == ao;
+                    if (!seen) { if (nm == 3) { reject = true; return; } mine[nm++] = ao; }
+                }
+            std::lock_guard<std::mutex> g(mu);
+            for (int q = 0; q < nm; ++q) {
+                bool seen = false;
+                for (int r = 0; r < no; ++r) seen = seen || offs[r] == mine[q];
+                if (!seen) { if (no == 3) { reject = true; return; } offs[no++] = mine[q]; }
+            }
+        });
+        if (reject) return KRYST_OK;
+    }
     std::sort(offs, offs + no);
     if (no < 2 || offs[0] != 1) return KRYST_OK;
     const int64_t s1 = offs[1], s2 = no == 3 ? offs[2] : n;
     if (s1 < 2 || s2 % s1 != 0 || n % s2 != 0 || s2 <= s1) return KRYST_OK;
     const int64_t Ni = s1, Nj = s2 / s1, Nk = n / s2;
     std::vector<double> c1((size_t)n, 0.0), c2((size_t)n, 0.0), c3((size_t)n, 0.0);
-    for (int64_t i = 0; i < n; ++i) {
-        const int64_t ii = i % Ni, jx = (i / Ni) % Nj;
-        for (int64_t k = ent.ptr[i]; k < ent.ptr[i + 1]; ++k) {
-            const int64_t ao = std::llabs((long long)ent.col[k] - (long long)i);
-            if (ao == 1) { if (forward ? ii == 0 : ii == Ni - 1) return KRYST_OK; c1[i] = ent.val[k]; }   // must stay on the line
-            else if (ao == s1) { if (forward ? jx == 0 : jx == Nj - 1) return KRYST_OK; c2[i] = ent.val[k]; }
-            else c3[i] = ent.val[k];
-        }
+    {
+        std::atomic<bool> reject{false};
+        par_rows(n, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) {
+                const int64_t ii = i % Ni, jx = (i / Ni) % Nj;
+                for (int64_t k = ent.ptr[i]; k < ent.ptr[i + 1]; ++k) {
+                    const int64_t ao = std::llabs((long long)ent.col[k] - (long long)i);
+                    if (ao == 1) { if (forward ? ii == 0 : ii == Ni - 1) { reject = true; return; } c1[i] = ent.val[k]; }   // must stay on the line
+                    else if (ao == s1) { if (forward ? jx == 0 : jx == Nj - 1) { reject = true; return; } c2[i] = ent.val[k]; }
+                    else c3[i] = ent.val[k];
+                }
+            }
+        });
+        if (reject) return KRYST_OK;
     }
     KR_TRY(up(&G->d_c1, c1)); KR_TRY(up(&G->d_c2, c2)); KR_TRY(up(&G->d_c3, c3));
     if (!forward) KR_TRY(up(&G->d_diag, diag));
@@ -603,8 +640,10 @@ static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRow
     if (rc == KRYST_OK && hipMalloc(&D->d_args, sizeof(TriArgs)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
     if (rc == KRYST_OK) {
         const size_t bytes = sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
+        const bool grid = D->GL.ok && D->GU.ok;                            // the wavefront solve works in place: one intermediate vector
         for (double** pp : {&D->d_y, &D->d_rL, &D->d_yU, &D->d_zU}) {
             if (rc != KRYST_OK) break;
+            if (grid && pp != &D->d_y) continue;
             if (hipMalloc(pp, bytes) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
             else if (hipMemsetAsync(*pp, 0, bytes, ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
         }
@@ -634,12 +673,19 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
     kryst_ctx_t ctx = a->ctx;
     KR_HIP(hipSetDevice(ctx->device));
     const int64_t n = a->nrows, nnz = a->nnz;
+    const bool verbose = getenv("KRYST_ILU_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    auto t_phase = now();
     std::vector<int64_t> rp((size_t)n + 1); std::vector<int32_t> col((size_t)nnz); std::vector<double> val((size_t)nnz);
     KR_TRY(kryst_csr_download(a, rp.data(), col.data(), val.data()));
+    if (verbose) { fprintf(stderr, "[kryst ilu] download %.0f ms\n", ms_since(t_phase)); t_phase = now(); }
     // diagonal position of every row (halo columns, col >= n, are outside the local block)
     std::vector<int64_t> dpos((size_t)n, -1);
-    for (int64_t i = 0; i < n; ++i)
-        for (int64_t k = rp[i]; k < rp[i + 1]; ++k) if (col[k] == i) dpos[i] = k;
+    par_rows(n, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i)
+            for (int64_t k = rp[i]; k < rp[i + 1]; ++k) if (col[k] == i) dpos[i] = k;
+    });
     std::vector<double> w(val);                       // factor values on A's pattern
     if (mode == KRYST_ILU_TRUE_ILU0) {                // IKJ restricted to the pattern
         std::vector<int64_t> pos((size_t)n, -1);
@@ -660,44 +706,65 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
         }
     } else {
         // ilu.rs:76-80 / ilup.rs:104-111: l_ij = a_ij / a_jj for stored nonzeros below the diagonal; U = triu(A)
-        for (int64_t i = 0; i < n; ++i)
+        std::atomic<long long> bad{-1};                                    // lowest row whose pivot is zero (the reference stops at the first)
+        par_rows(n, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i)
+                for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
+                    const int64_t j = col[k];
+                    if (j < i && val[k] != 0.0) {
+                        const double ujj = dpos[j] >= 0 ? val[dpos[j]] : 0.0;
+                        if (mode == KRYST_ILU_ILUP0 && ujj == 0.0) {       // ilup.rs:106-108
+                            long long cur = bad.load();
+                            while ((cur < 0 || (long long)i < cur) && !bad.compare_exchange_weak(cur, (long long)i)) {}
+                            return;
+                        }
+                        w[k] = val[k] / ujj;
+                    }
+                }
+        });
+        if (bad.load() >= 0) {
+            const int64_t i = bad.load();
             for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
                 const int64_t j = col[k];
-                if (j < i && val[k] != 0.0) {
-                    const double ujj = dpos[j] >= 0 ? val[dpos[j]] : 0.0;
-                    if (mode == KRYST_ILU_ILUP0 && ujj == 0.0) {           // ilup.rs:106-108
-                        set_error("ILUP: zero diagonal in U at row %lld", (long long)j);
-                        return KRYST_SOLVE_ERROR;
-                    }
-                    w[k] = val[k] / ujj;
-                }
+                if (j < i && val[k] != 0.0 && (dpos[j] < 0 || val[dpos[j]] == 0.0)) { set_error("ILUP: zero diagonal in U at row %lld", (long long)j); break; }
             }
+            return KRYST_SOLVE_ERROR;
+        }
     }
+    if (verbose) { fprintf(stderr, "[kryst ilu] factorisation %.0f ms\n", ms_since(t_phase)); t_phase = now(); }
     const bool divide = mode != KRYST_ILU_KRYST_COMPAT;                    // ilu.rs:115-119 never divides
     FlatRows le, ue;
     le.ptr.assign((size_t)n + 1, 0); ue.ptr.assign((size_t)n + 1, 0);
     std::vector<double> dg((size_t)n, 1.0);
-    for (int64_t i = 0; i < n; ++i) {                                      // count, then fill (stored order = ascending column)
-        int64_t nl = 0, nu = 0;
-        for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
-            const int64_t j = col[k];
-            if (j >= n || w[k] == 0.0) continue;                           // halo column / `!= T::zero()` filters
-            if (j < i) ++nl; else if (j > i) ++nu;
+    par_rows(n, [&](int64_t lo, int64_t hi) {                              // count, prefix, then fill (stored order = ascending column)
+        for (int64_t i = lo; i < hi; ++i) {
+            int64_t nl = 0, nu = 0;
+            for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
+                const int64_t j = col[k];
+                if (j >= n || w[k] == 0.0) continue;                       // halo column / `!= T::zero()` filters
+                if (j < i) ++nl; else if (j > i) ++nu;
+            }
+            le.ptr[i + 1] = nl; ue.ptr[i + 1] = nu;
         }
-        le.ptr[i + 1] = le.ptr[i] + nl; ue.ptr[i + 1] = ue.ptr[i] + nu;
-    }
+    });
+    for (int64_t i = 0; i < n; ++i) { le.ptr[i + 1] += le.ptr[i]; ue.ptr[i + 1] += ue.ptr[i]; }
     le.col.resize((size_t)le.ptr[n]); le.val.resize((size_t)le.ptr[n]); ue.col.resize((size_t)ue.ptr[n]); ue.val.resize((size_t)ue.ptr[n]);
-    for (int64_t i = 0; i < n; ++i) {
-        int64_t wl = le.ptr[i], wu = ue.ptr[i];
-        for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
-            const int64_t j = col[k];
-            if (j >= n || w[k] == 0.0) continue;
-            if (j < i) { le.col[wl] = (int32_t)j; le.val[wl] = w[k]; ++wl; }
-            else if (j > i) { ue.col[wu] = (int32_t)j; ue.val[wu] = w[k]; ++wu; }
-            else if (divide) dg[i] = w[k];                                 // ilup.rs:160-164 (missing diagonal: no divide)
+    par_rows(n, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            int64_t wl = le.ptr[i], wu = ue.ptr[i];
+            for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
+                const int64_t j = col[k];
+                if (j >= n || w[k] == 0.0) continue;
+                if (j < i) { le.col[wl] = (int32_t)j; le.val[wl] = w[k]; ++wl; }
+                else if (j > i) { ue.col[wu] = (int32_t)j; ue.val[wu] = w[k]; ++wu; }
+                else if (divide) dg[i] = w[k];                             // ilup.rs:160-164 (missing diagonal: no divide)
+            }
         }
-    }
-    return finish_ilu_pc(a, mode, divide, le, ue, dg, out);
+    });
+    if (verbose) { fprintf(stderr, "[kryst ilu] split into L / U rows %.0f ms\n", ms_since(t_phase)); t_phase = now(); }
+    const int32_t rc = finish_ilu_pc(a, mode, divide, le, ue, dg, out);
+    if (verbose) fprintf(stderr, "[kryst ilu] device structures %.0f ms\n", ms_since(t_phase));
+    return rc;
 }
 
 // Ilup::new(fill).setup(a) exactly as written (src/preconditioner/ilup.rs:77-134), on sparse rows instead of the reference's
