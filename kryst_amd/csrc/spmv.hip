@@ -410,9 +410,6 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {
     uint2* meta = reinterpret_cast<uint2*>(poff + a.ntab + U + ((a.ntab + U) & 1));   // 8-byte aligned
     double* red = reinterpret_cast<double*>(smem + a.pat_red_off);
     const int t = threadIdx.x;
-    for (int i = t; i < a.npat; i += KR_T) meta[i] = reinterpret_cast<const uint2*>(a.pmeta)[i];
-    for (int i = t; i < a.ntab + U; i += KR_T) { poff[i] = i < a.ntab ? 8 * a.poff[i] : 0; pval[i] = i < a.ntab ? a.pval[i] : 0.0; }
-    __syncthreads();
     // workgroup b of XCD x owns the tpw CONSECUTIVE tile slots [b*tpw, (b+1)*tpw) of that XCD's share; workgroups are
     // handed out in order by the dispatcher, so the tiles in flight on an XCD stay a compact window of the grid and the
     // x planes they share stay in its L2 (a strided persistent loop lets fast workgroups run ahead: 2.5x the x traffic)
@@ -427,6 +424,10 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {
     int q = tile_of(slot0 * tpw);
     unsigned ids = 0;
     if (q >= 0) ids = *reinterpret_cast<const unsigned*>(a.pid + (size_t)q * KR_TILE + 2 * t);   // rows 2t, 2t+1 (padded array)
+    // (the first tile's ids are on their way while the tables are copied)
+    for (int i = t; i < a.npat; i += KR_T) meta[i] = reinterpret_cast<const uint2*>(a.pmeta)[i];
+    for (int i = t; i < a.ntab + U; i += KR_T) { poff[i] = i < a.ntab ? 8 * a.poff[i] : 0; pval[i] = i < a.ntab ? a.pval[i] : 0.0; }
+    __syncthreads();
     for (int li = slot0 * tpw; li < li_end; ++li) {
         const int qn = tile_of(li + 1);                             // prefetch the next tile's ids
         unsigned ids_n = 0;
