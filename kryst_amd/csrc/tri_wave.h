@@ -42,12 +42,11 @@ __device__ __forceinline__ double tw_bperm(int byte_idx, double v) {
 __device__ __forceinline__ cgdouble* tw_at(cgdouble* base, uint32_t off, int imm) {
     return (cgdouble*)((__attribute__((address_space(1))) const char*)base + imm + (size_t)off);
 }
-__device__ __forceinline__ double tw_poll(cgdouble* base, uint32_t off, int imm) {
-    return __hip_atomic_load((gdouble*)tw_at(base, off, imm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 #ifdef KR_TW_TRACE
-__device__ long long tw_trace[8 * 4096]; __device__ long long tw_rounds[16 * 4096];   // poller: end time and rows of its first 8 rounds       // per block: entry, chunk 2 / 8 / 16 done, end, waits for the poller / the loader
+// trace build (tools/tw_trace.py): per block, forward solve: entry, chunk 1 done, end, poller rounds / time, gate open, first rows
+__device__ long long tw_trace[8 * 4096];
+__device__ long long tw_rounds[16 * 4096];     // poller: end time and rows delivered of its first 8 rounds
 #endif
 __device__ __forceinline__ int tw_lds_load(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void tw_lds_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
     constexpr int R = 64;                                                 // steps in the neighbour ring
     __shared__ tw_v2 stage[S * NA * (C / 2) * 64];                        // [slot][array][step pair][lane]
     __shared__ double nbv[R * 16];                                        // [step % R][neighbour line]: 0-7 j-neighbours of kl, 8-15 k-neighbours of jl
-    __shared__ int ctr[4];                                                // staged chunks, taken chunks, published steps
+    __shared__ int ctr[4];                                                // staged chunks, taken chunks, published steps, "the poller gave up"
     // every pointer in the global address space: no flat instructions
     cgdouble* in = (cgdouble*)(in_ptr ? in_ptr : args->r);
     gdouble* out = (gdouble*)(out_ptr ? out_ptr : args->z);
