@@ -47,6 +47,11 @@ def main():
         out[name + "_x"] = x.to_host()
         out[name + "_hist"] = np.array(s.residual_history)
         out[name + "_stats"] = np.array([st.iterations, float(st.converged), st.final_residual])
+    # the ILU family factors each rank's own diagonal block (halo columns dropped): its apply
+    r = ctx.vec(nloc).fill_splitmix(7)
+    out["ilu_r"] = r.to_host()
+    for nm, mk in (("true", K.TrueIlu0), ("compat", K.Ilu0), ("ilup0", lambda: K.Ilup(0)), ("ilup1", lambda: K.Ilup(1))):
+        out["ilu_z_" + nm] = mk().setup(a).apply(r).to_host()
     # a stepping session like bench.py's
     x = ctx.vec(nloc)
     sess = K.Session("cg", a, None, b, x, tol=0.0, max_iters=25)

@@ -60,6 +60,14 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
             assert (int(st[0]), bool(st[1]), float(st[2])) == (ref.iterations, ref.converged, ref.final_residual), (name, st, ref)
             assert np.array_equal(r[name + "_hist"], ref.history), name
         assert np.array_equal(np.concatenate([r[name + "_x"] for r in R]), ref.x), name
+    import scipy.sparse as sp
+    m = sp.csr_matrix((a.vals, a.col_idx, a.row_ptr), shape=(a.nrows, a.ncols))
+    for r_, R_ in enumerate(R):                                                       # block ILU(0): each rank's diagonal block
+        lo, hi = int(offs[r_]), int(offs[r_ + 1])
+        blk = m[lo:hi, lo:hi].tocsr(); blk.sort_indices()
+        ob = O.Csr(hi - lo, hi - lo, blk.indptr, blk.indices, blk.data)
+        for nm, mk in (("true", O.Pc.ilu0_true), ("compat", O.Pc.ilu0_compat), ("ilup0", O.Pc.ilup0), ("ilup1", lambda b_: O.Pc.ilup(b_, 1))):
+            assert np.array_equal(R_["ilu_z_" + nm], mk(ob).apply(R_["ilu_r"])), ("ilu", nm, r_)
     ref = O.solve("cg", a, b, tol=0.0, max_iters=25, rs=rs)
     assert np.array_equal(np.concatenate([r["sess_x"] for r in R]), ref.x)
     assert all(int(r["sess_stats"][0]) == 25 for r in R)
