@@ -47,6 +47,17 @@ def main():
         out[name + "_x"] = x.to_host()
         out[name + "_hist"] = np.array(s.residual_history)
         out[name + "_stats"] = np.array([st.iterations, float(st.converged), st.final_residual])
+    # Chebyshev needs the halo exchange inside a preconditioner; GMRES-right and the right-preconditioned BiCGStab extension
+    cheb = K.ChebyshevPc(3, 1.0, 11.5).setup(a)
+    extra = [("gmres_cheb", K.GmresSolver(8, 1e-9, 32).with_preconditioning(K.Preconditioning.Left), cheb),
+             ("gmres_right", K.GmresSolver(8, 1e-9, 40).with_preconditioning(K.Preconditioning.Right), pcj),
+             ("bicg_rpc", K.BiCgStabRightPcSolver(1e-9 * bn, 120), pcj)]
+    for name, s, pc in extra:
+        x = ctx.vec(nloc)
+        st = s.solve(a, pc, b, x)
+        out[name + "_x"] = x.to_host()
+        out[name + "_hist"] = np.array(s.residual_history)
+        out[name + "_stats"] = np.array([st.iterations, float(st.converged), st.final_residual])
     # the ILU family factors each rank's own diagonal block (halo columns dropped): its apply
     r = ctx.vec(nloc).fill_splitmix(7)
     out["ilu_r"] = r.to_host()
