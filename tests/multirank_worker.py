@@ -61,7 +61,8 @@ def main():
     # the ILU family factors each rank's own diagonal block (halo columns dropped): its apply
     r = ctx.vec(nloc).fill_splitmix(7)
     out["ilu_r"] = r.to_host()
-    for nm, mk in (("true", K.TrueIlu0), ("compat", K.Ilu0), ("ilup0", lambda: K.Ilup(0)), ("ilup1", lambda: K.Ilup(1))):
+    for nm, mk in (("true", K.TrueIlu0), ("compat", K.Ilu0), ("ilup0", lambda: K.Ilup(0)), ("ilup1", lambda: K.Ilup(1)),
+                   ("ilut", lambda: K.Ilut(4, 1e-3))):
         out["ilu_z_" + nm] = mk().setup(a).apply(r).to_host()
     # a stepping session like bench.py's
     x = ctx.vec(nloc)

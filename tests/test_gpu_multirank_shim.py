@@ -69,7 +69,8 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
         lo, hi = int(offs[r_]), int(offs[r_ + 1])
         blk = m[lo:hi, lo:hi].tocsr(); blk.sort_indices()
         ob = O.Csr(hi - lo, hi - lo, blk.indptr, blk.indices, blk.data)
-        for nm, mk in (("true", O.Pc.ilu0_true), ("compat", O.Pc.ilu0_compat), ("ilup0", O.Pc.ilup0), ("ilup1", lambda b_: O.Pc.ilup(b_, 1))):
+        for nm, mk in (("true", O.Pc.ilu0_true), ("compat", O.Pc.ilu0_compat), ("ilup0", O.Pc.ilup0), ("ilup1", lambda b_: O.Pc.ilup(b_, 1)),
+                       ("ilut", lambda b_: O.Pc.ilut(b_, 4, 1e-3))):
             assert np.array_equal(R_["ilu_z_" + nm], mk(ob).apply(R_["ilu_r"])), ("ilu", nm, r_)
     ref = O.solve("cg", a, b, tol=0.0, max_iters=25, rs=rs)
     assert np.array_equal(np.concatenate([r["sess_x"] for r in R]), ref.x)
