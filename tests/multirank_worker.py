@@ -12,6 +12,19 @@ sys.path.insert(0, ROOT)
 import kryst_amd as K                      # noqa: E402
 
 
+def random_system(n):
+    """A symmetric, strictly diagonally dominant random sparse operator (about 7 entries per row, couplings of any
+    distance: every rank needs halo entries from every other one); the same on every rank and in the test."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(1234 + n)
+    b = sp.random(n, n, density=3.0 / n, random_state=rng, data_rvs=lambda k: rng.uniform(-1.0, 1.0, k)).tocsr()
+    m = (b + b.T).tocsr()
+    m.setdiag(0.0); m.eliminate_zeros()
+    m = (m + sp.diags(np.asarray(abs(m).sum(axis=1)).ravel() + 1.0)).tocsr()
+    m.sort_indices()
+    return m
+
+
 def main():
     rank, P, outdir, N = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
     kind = sys.argv[5]
@@ -28,7 +41,14 @@ def main():
             time.sleep(0.01)
         uid = open(idfile, "rb").read()
     ctx = K.Context(0, rank, P, uid)
-    a = K.CsrMatrix.stencil7(N, kind, ctx=ctx)        # device generator or (KRYST_STENCIL_HOST=1) kryst_csr_create_dist
+    if kind == "random":                              # general operator: N rows, halo entries from any rank
+        m = random_system(N)
+        offs = K.partition_rows(N, P, 1)
+        sub = m[int(offs[rank]):int(offs[rank + 1])].tocsr()
+        sub.sort_indices()
+        a = K.CsrMatrix.from_csr_dist(ctx, N, offs, sub.indptr, sub.indices, sub.data)
+    else:
+        a = K.CsrMatrix.stencil7(N, kind, ctx=ctx)    # device generator or (KRYST_STENCIL_HOST=1) kryst_csr_create_dist
     nloc = a.nrows()
     b = a.spmv(ctx.vec(nloc).fill(1.0))
     out = {"b": b.to_host(), "nloc": np.array([nloc])}

@@ -20,7 +20,8 @@ def _build_shim():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,N,kind,hostgen", [(2, 12, "poisson", "0"), (3, 12, "convdiff", "0"), (2, 10, "aniso", "1"), (4, 16, "poisson", "1")])
+@pytest.mark.parametrize("P,N,kind,hostgen", [(2, 12, "poisson", "0"), (3, 12, "convdiff", "0"), (2, 10, "aniso", "1"), (4, 16, "poisson", "1"),
+                                                 (3, 2500, "random", "0"), (4, 1031, "random", "0")])
 def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     from oracle import oracle as O
     import kryst_amd as K
@@ -40,9 +41,16 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
     R = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(P)]
     T, V, F = K.reduce_spec()
-    offs = K.partition_rows(N ** 3, P, N * N)
+    if kind == "random":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from multirank_worker import random_system
+        m0 = random_system(N)
+        offs = K.partition_rows(N, P, 1)
+        a = O.Csr(N, N, m0.indptr, m0.indices, m0.data)
+    else:
+        offs = K.partition_rows(N ** 3, P, N * N)
+        a = O.stencil7(N, kind)
     assert [int(r["nloc"][0]) for r in R] == [int(offs[i + 1] - offs[i]) for i in range(P)]
-    a = O.stencil7(N, kind)
     b = a.spmv(np.ones(a.nrows))
     assert np.array_equal(np.concatenate([r["b"] for r in R]), b)                 # halo exchange + SpMV
     rs = O.Reduce.tiled(T, V, F, part_off=offs)
