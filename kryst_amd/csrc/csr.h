@@ -20,7 +20,8 @@ struct kryst_csr_s {
     uint32_t* d_pmeta = nullptr;    // per pattern, 2 words: (first table entry of its base | base length << 16, presence mask)
     int32_t* d_poff = nullptr;      // table: col - row
     double* d_pval = nullptr;       // table: value
-    int32_t npat = 0, ntab = 0, pat_unroll = 8; bool pat_single = false;   // table entries padded per pattern to a multiple of pat_unroll
+    int32_t npat = 0, ntab = 0, pat_unroll = 8; bool pat_single = false;
+    bool pat_diag3 = false;        // stencil generator: every row has its diagonal, at table position 3 of its base   // table entries padded per pattern to a multiple of pat_unroll
     int64_t ntiles = 0;
     int slots = 7;            // SpMV pair slots per lane (picked from the average nnz of a 128-row slice)
     // distributed

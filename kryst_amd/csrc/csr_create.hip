@@ -443,7 +443,7 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
             (void)hipMemcpyAsync(a->d_poff, poff.data(), sizeof(int32_t) * poff.size(), hipMemcpyHostToDevice, ctx->s_main);
             (void)hipMemcpyAsync(a->d_pval, pval.data(), sizeof(double) * pval.size(), hipMemcpyHostToDevice, ctx->s_main);
             (void)hipStreamSynchronize(ctx->s_main);
-            a->npat = 256; a->ntab = (int32_t)poff.size(); a->pat_unroll = 7; a->pat_single = true;
+            a->npat = 256; a->ntab = (int32_t)poff.size(); a->pat_unroll = 7; a->pat_single = true; a->pat_diag3 = true;
             (void)hipMemsetAsync(a->d_pid, 0, sizeof(uint16_t) * (size_t)((nloc + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE), ctx->s_main);
         }
         (void)hipMemsetAsync(a->d_col + nnz, 0, sizeof(int32_t) * 8, ctx->s_main);

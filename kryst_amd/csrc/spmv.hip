@@ -401,8 +401,8 @@ __device__ __forceinline__ double gather8(const SpmvArgs& a, int32_t c8) {
 }
 
 // SINGLE: no base is longer than U entries (true for every stencil operator), so the entry loop has one trip
-template <int NQ, bool HALO, int U, bool SINGLE>
-__global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {
+template <int NQ, bool HALO, int U, bool SINGLE, int CENTER = -1>   // CENTER >= 0: the fused dot's vector is x itself and every row
+__global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {   // has its diagonal entry at table position CENTER
     if (a.done && *a.done) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* pval = reinterpret_cast<double*>(smem);                                   // ntab + U entries
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {
             const bool va = row < r1, vb = row + 1 < r1;
             uint2 ma = va ? meta[ids & 0xffffu] : make_uint2(0u, 0u), mb = vb ? meta[ids >> 16] : make_uint2(0u, 0u);
             double s0 = 0.0, s1 = 0.0;
+            v2d xc; xc.x = 0.0; xc.y = 0.0;                         // x[row], x[row + 1] as the diagonal entry's gather saw them
             if (ma.x == mb.x) {
                 // ---- same base: one table lookup and one 16-byte gather per entry serve both rows.  An entry is needed if
                 // either row has it; a needed entry addresses x[c], x[c + 1] with c >= -1 (c = -1: only row 2t+1 has it and
@@ -484,6 +485,7 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {
                         s0 = ((ka >> u) & 1u) ? ta : s0;
                         s1 = ((kb >> u) & 1u) ? tb : s1;
                     }
+                    if constexpr (CENTER >= 0) xc = xx[CENTER];
                 }
             } else {
                 // ---- different bases (rare: adjacent rows built from unrelated stencils): each row walks its own, one entry
@@ -502,7 +504,9 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {
             else if (va) a.y[row] = s0;
             if constexpr (NQ > 0) {
                 double acc[NQ];
-                const d2 d = ld2(a.dvec, row);
+                d2 d;
+                if (CENTER >= 0 && ma.x == mb.x) { d.a = xc.x; d.b = xc.y; }   // (p, Ap): no second load of p, no second wait
+                else d = ld2(a.dvec, row);
                 acc[0] = 0.0;
                 if (va) acc[0] = acc[0] + d.a * s0;
                 if (vb) acc[0] = acc[0] + d.b * s1;
@@ -575,7 +579,9 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
         args.nloc8 = (int32_t)(a->nrows * 8);
         const size_t lds = (size_t)args.pat_red_off + sizeof(double) * (size_t)(nq > 0 ? nq : 1) * (KR_T / 64);
 #define KR_PAT(NQ_, U_, S_) hipLaunchKernelGGL((spmv_pattern_kernel<NQ_, HALO, U_, S_>), pgrid, block, lds, ctx->s_main, args)
-#define KR_PAT_BY(NQ_) do { if (U == 7) KR_PAT(NQ_, 7, true); else if (a->pat_single) KR_PAT(NQ_, 8, true); else KR_PAT(NQ_, 8, false); } while (0)
+#define KR_PAT_C(NQ_) hipLaunchKernelGGL((spmv_pattern_kernel<NQ_, HALO, 7, true, 3>), pgrid, block, lds, ctx->s_main, args)
+        const bool reuse_diag = !HALO && nq > 0 && dvec == x && a->pat_diag3 && env_int("KRYST_SPMV_REUSE_DIAG", 1);
+#define KR_PAT_BY(NQ_) do { if (U == 7 && reuse_diag && NQ_ > 0) KR_PAT_C(NQ_); else if (U == 7) KR_PAT(NQ_, 7, true); else if (a->pat_single) KR_PAT(NQ_, 8, true); else KR_PAT(NQ_, 8, false); } while (0)
         switch (nq) {
             case 0: KR_PAT_BY(0); break;
             case 1: KR_PAT_BY(1); break;
@@ -583,6 +589,7 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
             default: set_error("spmv: nq=%d", nq); return KRYST_ERR_ARG;
         }
 #undef KR_PAT_BY
+#undef KR_PAT_C
 #undef KR_PAT
         KR_HIP(hipGetLastError());
         return KRYST_OK;
