@@ -401,8 +401,11 @@ __device__ __forceinline__ double gather8(const SpmvArgs& a, int32_t c8) {
 }
 
 // SINGLE: no base is longer than U entries (true for every stencil operator), so the entry loop has one trip
-template <int NQ, bool HALO, int U, bool SINGLE, int CENTER = -1>   // CENTER >= 0: the fused dot's vector is x itself and every row
-__global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {   // has its diagonal entry at table position CENTER
+// CENTER >= 0: the fused dot's vector is x itself and every row has its diagonal entry at table position CENTER.
+// MERGE3: table positions 2, 3, 4 of every base are the columns row-1, row, row+1 (stencil generator): x[row-1 .. row+2] is
+// fetched with two 16-byte gathers instead of three (the kernel's cost is per vector-memory instruction).
+template <int NQ, bool HALO, int U, bool SINGLE, int CENTER = -1, bool MERGE3 = false>
+__global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {
     if (a.done && *a.done) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* pval = reinterpret_cast<double*>(smem);                                   // ntab + U entries
@@ -462,6 +465,8 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) { 
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         c8[u] = ((kk >> u) & 1u) ? row8 + to[e0 + u] : row8;
+                        if (MERGE3 && u == 2) c8[u] = row8 - 8;          // always: its second element is x[row]
+                        if (MERGE3 && u == 4) c8[u] = row8 + 8;          // always: its first element is x[row + 1] (x is padded at the end)
                         any |= c8[u];
                     }
                     v2d xx[U];
@@ -476,7 +481,8 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) { 
                     } else {
 #pragma unroll
                         for (int u = 0; u < U; ++u)
-                            xx[u] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(a.x) + (uint32_t)c8[u]);
+                            if (!(MERGE3 && u == 3)) xx[u] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(a.x) + (uint32_t)c8[u]);
+                        if constexpr (MERGE3) { xx[3].x = xx[2].y; xx[3].y = xx[4].x; }
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -579,9 +585,12 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
         args.nloc8 = (int32_t)(a->nrows * 8);
         const size_t lds = (size_t)args.pat_red_off + sizeof(double) * (size_t)(nq > 0 ? nq : 1) * (KR_T / 64);
 #define KR_PAT(NQ_, U_, S_) hipLaunchKernelGGL((spmv_pattern_kernel<NQ_, HALO, U_, S_>), pgrid, block, lds, ctx->s_main, args)
-#define KR_PAT_C(NQ_) hipLaunchKernelGGL((spmv_pattern_kernel<NQ_, HALO, 7, true, 3>), pgrid, block, lds, ctx->s_main, args)
-        const bool reuse_diag = !HALO && nq > 0 && dvec == x && a->pat_diag3 && env_int("KRYST_SPMV_REUSE_DIAG", 1);
-#define KR_PAT_BY(NQ_) do { if (U == 7 && reuse_diag && NQ_ > 0) KR_PAT_C(NQ_); else if (U == 7) KR_PAT(NQ_, 7, true); else if (a->pat_single) KR_PAT(NQ_, 8, true); else KR_PAT(NQ_, 8, false); } while (0)
+#define KR_PAT_C(NQ_) hipLaunchKernelGGL((spmv_pattern_kernel<NQ_, HALO, 7, true, 3, true>), pgrid, block, lds, ctx->s_main, args)
+#define KR_PAT_M(NQ_) hipLaunchKernelGGL((spmv_pattern_kernel<NQ_, HALO, 7, true, -1, true>), pgrid, block, lds, ctx->s_main, args)
+        const bool gen3 = !HALO && a->pat_diag3 && env_int("KRYST_SPMV_REUSE_DIAG", 1);      // generator-made operator, interior tiles
+        const bool reuse_diag = gen3 && nq > 0 && dvec == x;
+#define KR_PAT_BY(NQ_) do { if (U == 7 && reuse_diag && NQ_ > 0) KR_PAT_C(NQ_); else if (U == 7 && gen3) KR_PAT_M(NQ_); else if (U == 7) KR_PAT(NQ_, 7, true); \
+                            else if (a->pat_single) KR_PAT(NQ_, 8, true); else KR_PAT(NQ_, 8, false); } while (0)
         switch (nq) {
             case 0: KR_PAT_BY(0); break;
             case 1: KR_PAT_BY(1); break;
@@ -590,6 +599,7 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
         }
 #undef KR_PAT_BY
 #undef KR_PAT_C
+#undef KR_PAT_M
 #undef KR_PAT
         KR_HIP(hipGetLastError());
         return KRYST_OK;
