@@ -24,6 +24,13 @@ static int32_t upload_patterns(kryst_csr_t a, const std::vector<uint16_t>& pid, 
     }
     KR_HIP(hipStreamSynchronize(ctx->s_main));
     a->npat = (int32_t)(meta.size() / 2); a->ntab = (int32_t)poff.size();
+    // every pattern's base has the columns row-1, row, row+1 at table positions 2, 3, 4 and every row stores its diagonal:
+    // the kernel variants that fetch x[row-1 .. row+2] with two gathers and reuse x[row] for the fused dot apply
+    a->pat_diag3 = !meta.empty();
+    for (size_t p = 0; p + 1 < meta.size() && a->pat_diag3; p += 2) {
+        const size_t b = meta[p] & 0xffffu; const int len = (int)(meta[p] >> 16);
+        a->pat_diag3 = len == 7 && poff[b + 2] == -1 && poff[b + 3] == 0 && poff[b + 4] == 1 && (meta[p + 1] & 8u);
+    }
     return KRYST_OK;
 }
 static int32_t build_patterns(kryst_csr_t a, const std::vector<int32_t>& rp, const std::vector<int32_t>& col, const double* val) {
