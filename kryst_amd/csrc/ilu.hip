@@ -860,6 +860,9 @@ extern "C" int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kr
 extern "C" int32_t kryst_debug_tw_trace(long long* host, int32_t count) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(kr::tw_trace), sizeof(long long) * count) == hipSuccess ? 0 : 1;
 }
+extern "C" int32_t kryst_debug_tw_steps(long long* host, int32_t count) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(kr::tw_steps), sizeof(long long) * count) == hipSuccess ? 0 : 1;
+}
 extern "C" int32_t kryst_debug_tw_rounds(long long* host, int32_t count) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(kr::tw_rounds), sizeof(long long) * count) == hipSuccess ? 0 : 1;
 }

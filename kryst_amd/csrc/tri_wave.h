@@ -47,6 +47,7 @@ __device__ __forceinline__ cgdouble* tw_at(cgdouble* base, uint32_t off, int imm
 // trace build (tools/tw_trace.py): per block, forward solve: entry, chunk 1 done, end, poller rounds / time, gate open, first rows
 __device__ long long tw_trace[8 * 4096];
 __device__ long long tw_rounds[16 * 4096];     // poller: end time and rows delivered of its first 8 rounds
+__device__ long long tw_steps[64 * 4096];      // per block: [0..31] time the solving wave finished step t, [32..63] time step t was published
 #endif
 __device__ __forceinline__ int tw_lds_load(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void tw_lds_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
             if (2 * q + 1 < m) nbv[((t + 2 * q + 1) % R) * 16 + (l >> 2)] = n1 ? r1 : 0.0;
             if (m > 0) { t += m; tw_lds_store(pub, t); }
 #ifdef KR_TW_TRACE
+            if (m > 0 && l == 0 && FORWARD && blk < 4096) { const long long now = wall_clock64(); for (int i = t - m; i < t && i < 32; ++i) tw_steps[64 * blk + 32 + i] = now; }
             if (m > 0 && first_pub) { first_pub = false; if (l == 0 && FORWARD) { tw_trace[8 * blk + 6] = wall_clock64(); tw_trace[8 * blk + 7] = m; } }
             if (rounds < 8 && l == 0 && FORWARD) { tw_rounds[16 * blk + 2 * rounds] = wall_clock64(); tw_rounds[16 * blk + 2 * rounds + 1] = m * 100; }
             rounds++; if (m == 0) empty++;
@@ -335,6 +337,9 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
             y = row_value(q, u, yj, yk);
             yv[u] = y;
             if (edge) __hip_atomic_store((gdouble*)tw_at(out, off, SG * u), y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef KR_TW_TRACE
+            if (l == 0 && FORWARD && t0 + u < 32 && blk < 4096) tw_steps[64 * blk + t0 + u] = wall_clock64();
+#endif
         }
         if (!edge) {                                                      // (the edge lanes' rows are in memory already)
             const uint32_t lo = FORWARD ? off : off - 8 * (C - 1);       // lowest row of the chunk
@@ -365,6 +370,9 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
             }
             if (t0 == 0 && u == 0 && l == 0)                              // this block is under way: the blocks behind it may start asking
                 __hip_atomic_store(&flags[blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef KR_TW_TRACE
+            if (l == 0 && FORWARD && t0 + u < 32 && blk < 4096) tw_steps[64 * blk + t0 + u] = wall_clock64();
+#endif
         }
     };
     Chunk q;

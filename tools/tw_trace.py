@@ -43,3 +43,15 @@ rr = np.array(rb, dtype=np.int64).reshape(nb, 8, 2)
 print("poller rounds (end time us : rows delivered / asked next):")
 for b in list(range(min(nb, 4))) + ([nb - 1] if nb > 4 else []):
     print(f"  block {b:4d}: " + "  ".join(f"{(rr[b, i, 0] - t0) / 100:7.1f}:{rr[b, i, 1] // 100}/{rr[b, i, 1] % 100}" for i in range(8)))
+
+sb = (C.c_longlong * (64 * nb))()
+lib.kryst_debug_tw_steps.argtypes = [C.POINTER(C.c_longlong), C.c_int32]
+assert lib.kryst_debug_tw_steps(sb, 64 * nb) == 0
+ss = (np.array(sb, dtype=np.int64).reshape(nb, 64) - t0) / 100.0
+print("block b (west neighbour b-1): step t published - producer finished step t+7 | consumer finished step t - published   (us)")
+for b in range(1, min(nb, nbj, 5)):
+    d1 = [ss[b, 32 + t] - ss[b - 1, t + 7] for t in range(0, 24)]
+    d2 = [ss[b, t] - ss[b, 32 + t] for t in range(0, 24)]
+    print(f"  block {b}: " + " ".join(f"{x:5.2f}" for x in d1))
+    print(f"           " + " ".join(f"{x:5.2f}" for x in d2))
+print("producer step times of block 0 (us): " + " ".join(f"{x:5.2f}" for x in ss[0, :32]))
