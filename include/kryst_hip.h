@@ -16,6 +16,12 @@
  *   - inner products use ONE fixed association tree (kryst_reduce_spec): results are run-to-run and
  *     launch-configuration independent; with nranks > 1 rank results are folded in rank order.
  *   - there is no CPU fallback: without a GPU every compute call fails with KRYST_ERR_HIP.
+ *   - Contexts: the scalar state of a solve (alpha, beta, the convergence record, the progress record the host polls)
+ *     lives in per-context device scratch, so ONE solve or stepping session can be open per context at a time.  While
+ *     a session is open, kryst_*_solve[_dev] and kryst_session_begin on the same context return KRYST_ERR_BUSY;
+ *     kryst_spmv, kryst_dot / kryst_norm, the vector updates and kryst_pc_apply stay legal (they are stream-ordered
+ *     behind the session's enqueued iterations and use scratch of their own).  Use a second context for a second
+ *     concurrent solve.
  */
 #ifndef KRYST_HIP_H
 #define KRYST_HIP_H
@@ -37,7 +43,8 @@ enum {
     KRYST_ERR_HIP = 100,                /* HIP runtime error / no device */
     KRYST_ERR_RCCL = 101,               /* RCCL error / library not found */
     KRYST_ERR_ARG = 102,                /* bad argument (length mismatch = the reference's assert_eq! panics) */
-    KRYST_ERR_CSR = 103                 /* CSR violates new_checked preconditions (sparse.rs:36-42) */
+    KRYST_ERR_CSR = 103,                /* CSR violates new_checked preconditions (sparse.rs:36-42) */
+    KRYST_ERR_BUSY = 104                /* a solve / stepping session is already open on this context (see "Contexts") */
 };
 
 typedef struct kryst_ctx_s* kryst_ctx_t;
@@ -46,6 +53,8 @@ typedef struct kryst_vec_s* kryst_vec_t;
 typedef struct kryst_pc_s*  kryst_pc_t;
 
 const char* kryst_hip_last_error(void);
+/* the row of the last KRYST_ZERO_PIVOT on this thread (KError::ZeroPivot(row), src/error.rs:15-16), -1 if none yet */
+int64_t     kryst_hip_last_error_row(void);
 int32_t     kryst_hip_abi_version(void);
 /* The fixed inner-product tree: tile = T*V elements; thread t folds its V elements, 64-lane xor butterfly,
  * serial across the T/64 waves; the tile partials are folded in chunks of F (one per thread, butterfly, serial
@@ -168,8 +177,12 @@ typedef void (*kryst_monitor_fn)(int64_t iteration, double residual, void* user)
 
 /* Residual history: hist[0..min(*hist_len,hist_cap)) receives what CgSolver/PcgSolver push to
  * residual_history (cg.rs:140,263; pcg.rs:146,199); GMRES / BiCGStab record |g[j+1]| / ||r|| per iteration
- * (an addition: the reference keeps none).  monitor (if non-NULL) is called on the calling thread, in order,
- * after the solve has finished on the device. */
+ * (an addition: the reference keeps none).  At most 2^22 entries are recorded per solve; *hist_len counts every push.
+ * monitor (if non-NULL) is LIVE like the reference's (cg.rs:137-140,260-263; pcg.rs:143-146,196-199): the device
+ * publishes each history entry to mapped host memory and the host fires monitor(iteration, residual, user) on the
+ * calling thread, in order, every time its poll loop has waited for a batch of params->check_every iterations
+ * (default 8; 1 = after every iteration; GMRES / FGMRES: once per restart cycle) and for the remaining entries when
+ * the solve ends -- always before the call returns.  The callback must not call into the same context. */
 #define KRYST_SOLVE_ARGS kryst_csr_t a, kryst_pc_t pc /* NULL = None */, \
         const kryst_params_t* params, kryst_stats_t* stats, \
         double* hist, int64_t hist_cap, int64_t* hist_len, kryst_monitor_fn monitor, void* user

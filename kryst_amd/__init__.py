@@ -531,7 +531,7 @@ class _Solver:
         DeviceVec arguments stay in HBM."""
         prm = self._params()
         st = _ffi.Stats()
-        cap = self._HIST_PER_ITER * self.conv.max_iters + max(self.restart, 1) + 8
+        cap = min(self._HIST_PER_ITER * self.conv.max_iters + max(self.restart, 1) + 8, (1 << 22) + 8)   # the library records at most 2^22 entries
         hist = np.zeros(cap)
         hlen = C.c_int64(0)
         cb = _ffi.MONITOR(lambda it, res, _u: self.monitor(it, res)) if self.monitor else _ffi.MONITOR()

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("KRYST_HIP_LIB") or os.path.join(_HERE, "lib", "libkry
 OK = 0
 ERR_NAMES = {1: "FactorError", 2: "SolveError", 3: "IndefiniteMatrix", 4: "IndefinitePreconditioner",
              5: "ZeroPivot", 6: "Unsupported", 100: "HipError", 101: "RcclError", 102: "ArgumentError",
-             103: "CsrError"}
+             103: "CsrError", 104: "ContextBusy"}
 
 c_dp = C.POINTER(C.c_double)
 c_i64p = C.POINTER(C.c_int64)
@@ -36,6 +36,7 @@ _SOLVE_TAIL = [Handle, Handle, C.POINTER(Params), C.POINTER(Stats), c_dp, C.c_in
 # name -> (restype, argtypes): every symbol include/kryst_hip.h declares
 SIGNATURES = {
     "kryst_hip_last_error": (C.c_char_p, []),
+    "kryst_hip_last_error_row": (C.c_int64, []),
     "kryst_hip_abi_version": (C.c_int32, []),
     "kryst_reduce_spec": (None, [c_i32p, c_i32p, c_i32p]),
     "kryst_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(Handle)]),
@@ -130,12 +131,13 @@ def lib():
 class KError(Exception):
     """Mirror of kryst::error::KError (src/error.rs:6-19) plus the runtime error classes of the C ABI."""
 
-    def __init__(self, code, message="", stats=None):
+    def __init__(self, code, message="", stats=None, row=None):
         self.code, self.kind, self.stats = code, ERR_NAMES.get(code, f"code {code}"), stats
+        self.row = row                 # KError::ZeroPivot(row), src/error.rs:15-16
         super().__init__(f"{self.kind}: {message}" if message else self.kind)
 
 
 def check(rc, stats=None):
     if rc != OK:
         msg = lib().kryst_hip_last_error()
-        raise KError(rc, msg.decode() if msg else "", stats)
+        raise KError(rc, msg.decode() if msg else "", stats, lib().kryst_hip_last_error_row() if rc == 5 else None)

@@ -217,8 +217,11 @@ int32_t kryst_dot(kryst_vec_t x, kryst_vec_t y, double* out) {
     kryst_ctx_t ctx = x->ctx;
     KR_HIP(hipSetDevice(ctx->device));
     KR_TRY(launch_ew(ctx, DotOp{x->d, y->d}, x->n));
-    KR_TRY(reduce_all(ctx, 1, ntiles_of(x->n), ctx->d_scal));
-    KR_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
+    // result slot of its own (d_scal[1024]): d_scal[0..512) is the scalar state of an open solve / stepping session, and the
+    // partials / chunk / ticket scratch is consumed in stream order, so a dot between two session steps disturbs nothing
+    double* slot = ctx->d_scal + 1024;
+    KR_TRY(reduce_all(ctx, 1, ntiles_of(x->n), slot));
+    KR_HIP(hipMemcpyAsync(ctx->h_pinned, slot, sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
     *out = ctx->h_pinned[0];
     return KRYST_OK;

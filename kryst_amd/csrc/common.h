@@ -20,6 +20,7 @@
 namespace kr {
 
 void set_error(const char* fmt, ...);
+void set_error_row(int64_t row);      // the row of a KRYST_ZERO_PIVOT (KError::ZeroPivot(row), src/error.rs:15-16)
 
 #define KR_HIP(call)                                                                          \
     do {                                                                                      \
@@ -48,6 +49,7 @@ struct HostProgress {
     volatile double  res;
     volatile int32_t done;
     volatile int32_t status;
+    volatile int64_t hist_len;      // residual-history entries written so far (published only when a monitor is attached)
 };
 
 struct Comm;   // dist.cpp
@@ -74,6 +76,9 @@ struct kryst_ctx_s {
     // (separately hipMalloc'ed 128 MiB vectors land wherever the allocator has room, and multi-stream kernels then run
     // up to 30 % slower and vary from solve to solve; a single block does not -- tools/stride_test.py)
     char* arena = nullptr; size_t arena_bytes = 0, arena_used = 0; const void* arena_owner = nullptr;
+    // The scalar state of a solve (DevState, reduction results, progress record) lives in per-context scratch, so ONE solve
+    // or stepping session may be open per context at a time: a second one is refused with KRYST_ERR_BUSY (kryst_hip.h).
+    const void* active_ws = nullptr;
     int num_cu = 256;
 };
 

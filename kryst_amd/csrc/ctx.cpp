@@ -4,6 +4,8 @@
 
 namespace kr {
 static thread_local char g_err[1024] = "";
+static thread_local int64_t g_err_row = -1;
+void set_error_row(int64_t row) { g_err_row = row; }
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -48,7 +50,8 @@ static int32_t ctx_init(kryst_ctx_t ctx) {
 extern "C" {
 
 const char* kryst_hip_last_error(void) { return g_err; }
-int32_t kryst_hip_abi_version(void) { return 1; }
+int64_t kryst_hip_last_error_row(void) { return g_err_row; }
+int32_t kryst_hip_abi_version(void) { return 2; }
 void kryst_reduce_spec(int32_t* T, int32_t* V, int32_t* F) {
     if (T) *T = KR_T;
     if (V) *V = KR_V;

@@ -298,7 +298,8 @@ int32_t fgmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, int32_t 
     if (pc) { for (int k = 0; k < R; ++k) KR_TRY(ws.vec(&Z[k])); } else Z = V;
     KR_HIP(hipMemcpyAsync(d_zptr, Z.data(), sizeof(double*) * (size_t)(R + 1), hipMemcpyHostToDevice, ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
-    const LogicCtx lc = ws.lctx(p);
+    const LogicCtx lc = ws.lctx(p, io.monitor != nullptr);
+    LiveMonitor mon; mon.io = &io; mon.ws = &ws; mon.first = 1;
     const DevState* st = ws.st; const FgState* fs = P.fs;
     const int* done = &ws.st->done;
     int32_t rc = KRYST_OK;
@@ -355,6 +356,7 @@ int32_t fgmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, int32_t 
         KR_TRY((reduce_then<1>(ctx, nt, ws.red, FgCycleEndLogic{lc, P, total >= max_iters ? 1 : 0})));
         KR_HIP(hipStreamSynchronize(ctx->s_main));                  // one host sync per restart cycle
         if (ctx->nranks > 1) KR_HIP(hipStreamSynchronize(ctx->s_comm));
+        mon.poll();                                                                               // live monitor: once per restart cycle
         if (ctx->h_prog->done) break;
     }
     KR_HIP(hipStreamSynchronize(ctx->s_main));
@@ -363,8 +365,7 @@ int32_t fgmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, int32_t 
     KR_HIP(hipStreamSynchronize(ctx->s_main));
     if (io.monitor) {
         DevState h;
-        if (hipMemcpy(&h, ws.st, sizeof(DevState), hipMemcpyDeviceToHost) == hipSuccess)
-            for (int64_t k = 0; k < h.hist_len && k < ws.hist_cap; ++k) io.monitor(k + 1, ws.h_hist[k], io.user);
+        if (hipMemcpy(&h, ws.st, sizeof(DevState), hipMemcpyDeviceToHost) == hipSuccess) mon.upto(h.hist_len);
     }
     return status;
 }

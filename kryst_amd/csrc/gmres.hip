@@ -236,7 +236,8 @@ int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
         KR_HIP(hipMemcpyAsync(d_uptr, U.data(), sizeof(double*) * (size_t)(R + 1), hipMemcpyHostToDevice, ctx->s_main));
         KR_HIP(hipStreamSynchronize(ctx->s_main));
     }
-    const LogicCtx lc = ws.lctx(p);
+    const LogicCtx lc = ws.lctx(p, io.monitor != nullptr);
+    LiveMonitor mon; mon.io = &io; mon.ws = &ws; mon.first = 1;
     const DevState* st = ws.st; const GmState* gs = P.gs;
     const int* done = &ws.st->done;
     int32_t rc = KRYST_OK;
@@ -303,6 +304,7 @@ int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
         // one host sync per restart cycle (a cycle is tens of ms of device work)
         KR_HIP(hipStreamSynchronize(ctx->s_main));
         if (ctx->nranks > 1) KR_HIP(hipStreamSynchronize(ctx->s_comm));
+        mon.poll();                                                                               // live monitor: once per restart cycle
         if (ctx->h_prog->done) break;
     }
     KR_HIP(hipStreamSynchronize(ctx->s_main));
@@ -312,8 +314,7 @@ int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
     KR_HIP(hipStreamSynchronize(ctx->s_main));
     if (io.monitor) {
         DevState h;
-        if (hipMemcpy(&h, ws.st, sizeof(DevState), hipMemcpyDeviceToHost) == hipSuccess)
-            for (int64_t k = 0; k < h.hist_len && k < ws.hist_cap; ++k) io.monitor(k + 1, ws.h_hist[k], io.user);
+        if (hipMemcpy(&h, ws.st, sizeof(DevState), hipMemcpyDeviceToHost) == hipSuccess) mon.upto(h.hist_len);
     }
     return status;
 }

@@ -696,7 +696,7 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
                 if (c >= n) continue;                 // halo column (another rank's row): not part of this rank's block.  A LOWER
                 if (c >= i) break;                    // neighbour's halo column is stored first and numbered n + h: skip, do not stop
                 const int64_t kd = dpos[c];
-                if (kd < 0 || w[kd] == 0.0) { set_error("ILU(0): zero pivot at row %lld", (long long)c); return KRYST_ZERO_PIVOT; }
+                if (kd < 0 || w[kd] == 0.0) { set_error("ILU(0): zero pivot at row %lld", (long long)c); set_error_row(c); return KRYST_ZERO_PIVOT; }
                 w[k] = w[k] / w[kd];
                 for (int64_t kk = rp[c]; kk < rp[c + 1]; ++kk) {
                     const int64_t j = col[kk];

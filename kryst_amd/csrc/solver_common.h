@@ -40,7 +40,14 @@ struct DevState {
 struct LogicCtx {
     DevState* st; double* hist; HostProgress* prog; const double* red;
     double tol; long long max_iters; int norm_type;
-    __device__ __forceinline__ void push(double v) const { hist[st->hist_len] = v; st->hist_len = st->hist_len + 1; }
+    long long hist_cap; int live;        // entries the mapped history buffer holds; live: a monitor is attached, publish the count
+    // residual_history.push (cg.rs:140,263): the count always advances, entries beyond the buffer are not recorded
+    __device__ __forceinline__ void push(double v) const {
+        const long long k = st->hist_len;
+        if (k < hist_cap) hist[k] = v;
+        st->hist_len = k + 1;
+        if (live) { __threadfence_system(); prog->hist_len = k + 1; }
+    }
     __device__ __forceinline__ void finish(int status) const {
         st->status = status; st->done = 1;
         prog->iter = st->iter + 1; prog->res = st->final_residual; prog->status = status;
@@ -120,6 +127,7 @@ struct Workspace {
     bool owns_arena = false;
     explicit Workspace(kryst_ctx_t c, int64_t n_) : ctx(c), n(n_) {}
     ~Workspace() {
+        if (ctx->active_ws == this) ctx->active_ws = nullptr;
         (void)hipStreamSynchronize(ctx->s_main);
         for (double* p : vecs) (void)hipFree(p);
         if (h_hist) (void)hipHostFree(h_hist);
@@ -159,18 +167,27 @@ struct Workspace {
         *out = p;
         return KRYST_OK;
     }
+    // history entries kept per solve: max_iters + 2, but never more than this (a caller's "effectively unbounded"
+    // max_iters must not turn into gigabytes of pinned memory); the reported length still counts every push
+    static constexpr int64_t HIST_MAX = (int64_t)1 << 22;
     int32_t init(int64_t hist_entries) {
+        if (ctx->active_ws != nullptr) {
+            set_error("context busy: a solve or stepping session is already open on this context (one at a time)");
+            return KRYST_ERR_BUSY;
+        }
+        ctx->active_ws = this;
+        hist_entries = std::max<int64_t>(2, std::min<int64_t>(hist_entries, HIST_MAX));
         st = reinterpret_cast<DevState*>(ctx->d_scal);
         red = ctx->d_scal + 256;
         KR_HIP(hipMemsetAsync(ctx->d_scal, 0, sizeof(double) * 512, ctx->s_main));
         hist_cap = hist_entries;
         KR_HIP(hipHostMalloc((void**)&h_hist, sizeof(double) * (size_t)hist_cap, hipHostMallocMapped));
         KR_HIP(hipHostGetDevicePointer((void**)&d_hist, h_hist, 0));
-        ctx->h_prog->iter = 0; ctx->h_prog->res = 0; ctx->h_prog->done = 0; ctx->h_prog->status = 0;
+        ctx->h_prog->iter = 0; ctx->h_prog->res = 0; ctx->h_prog->done = 0; ctx->h_prog->status = 0; ctx->h_prog->hist_len = 0;
         return KRYST_OK;
     }
-    LogicCtx lctx(const kryst_params_t* p) const {
-        return LogicCtx{st, d_hist, ctx->d_prog, red, p->tol, (long long)p->max_iters, p->norm_type};
+    LogicCtx lctx(const kryst_params_t* p, bool live = false) const {
+        return LogicCtx{st, d_hist, ctx->d_prog, red, p->tol, (long long)p->max_iters, p->norm_type, (long long)hist_cap, live ? 1 : 0};
     }
 };
 
@@ -179,8 +196,9 @@ inline size_t padded_bytes(int64_t n) { return sizeof(double) * (size_t)((n + KR
 // Host side of the run-ahead loop: enqueue `body(i)` for i = 1..max_iters in batches, stop once the device has
 // published `done`.  With several ranks every rank must enqueue the same collectives, so a rank only acts on a
 // `done` that happened inside batches it has fully waited for (all ranks then see the same thing).
-template <class Body>
-inline int32_t run_ahead(kryst_ctx_t ctx, const kryst_params_t* p, Body body) {
+struct NoPoll { void operator()() const {} };
+template <class Body, class Poll = NoPoll>
+inline int32_t run_ahead(kryst_ctx_t ctx, const kryst_params_t* p, Body body, Poll poll = Poll()) {
     const int64_t chk = p->check_every > 0 ? p->check_every : 8;
     int64_t it = 0, batch = 0;
     int64_t synced_iters = 0;
@@ -195,6 +213,7 @@ inline int32_t run_ahead(kryst_ctx_t ctx, const kryst_params_t* p, Body body) {
             KR_HIP(hipEventSynchronize(ctx->ev_ring[(batch - 1) & 3]));
             synced_iters = batch_end[(size_t)batch - 1];
         }
+        poll();                                             // live monitor: report what the device has pushed so far
         ++batch;
         if (ctx->h_prog->done && (ctx->nranks == 1 || ctx->h_prog->iter <= synced_iters)) break;
     }
@@ -233,6 +252,20 @@ inline int32_t residual_dot(kryst_csr_t a, const double* b, const double* x, dou
 struct SolveIO {
     kryst_csr_t a; kryst_pc_t pc; const kryst_params_t* params; kryst_stats_t* stats;
     double* hist; int64_t hist_cap; int64_t* hist_len; kryst_monitor_fn monitor; void* user;
+};
+
+// with_monitor (cg.rs:84-88): the reference calls the monitor inside the loop (cg.rs:137-140,260-263; pcg.rs:143-146,196-199).
+// Here the device pushes every history entry into mapped host memory and publishes the count; the host fires the callbacks
+// on the calling thread, in order, each time its poll loop has waited for a batch (every `check_every` iterations) and
+// once more when the solve has ended -- always before the solve call returns.
+struct LiveMonitor {
+    const SolveIO* io = nullptr; Workspace* ws = nullptr; int64_t first = 0; int64_t reported = 0;
+    void upto(int64_t len) {
+        if (!io || !io->monitor) return;
+        len = std::min<int64_t>(len, ws->hist_cap);
+        for (; reported < len; ++reported) io->monitor(first + reported, ws->h_hist[reported], io->user);
+    }
+    void poll() { if (io && io->monitor) upto(ws->ctx->h_prog->hist_len); }
 };
 
 // copy stats / history out and run the monitor callbacks (in order, on the calling thread)

@@ -31,11 +31,12 @@ inline int32_t solve_args_check(const SolveIO& io, kryst_vec_t b, kryst_vec_t x)
     return KRYST_OK;
 }
 
-inline void run_monitor(const SolveIO& io, Workspace& ws, int64_t first_iter) {
-    if (!io.monitor) return;
+// the callbacks the poll loop has not fired yet (the stream is idle: every entry is in host memory)
+inline void finish_monitor(LiveMonitor& mon, Workspace& ws) {
+    if (!mon.io || !mon.io->monitor) return;
     DevState h;
     if (hipMemcpy(&h, ws.st, sizeof(DevState), hipMemcpyDeviceToHost) != hipSuccess) return;
-    for (int64_t k = 0; k < h.hist_len && k < ws.hist_cap; ++k) io.monitor(first_iter + k, ws.h_hist[k], io.user);
+    mon.upto(h.hist_len);
 }
 
 // A solve split into begin / iterate / end so that the same code serves the one-shot LinearSolver::solve
@@ -46,6 +47,7 @@ struct SolverRun {
     Workspace ws; LogicCtx lc; const int* done = nullptr; double* xw = nullptr;
     kryst_pc_s pcl; kryst_pc_t pc = nullptr;
     int64_t next_iter = 1;
+    LiveMonitor mon;
     SolverRun(kryst_vec_t b, kryst_vec_t x, const SolveIO& io_)
         : bv(b), xv(x), io(io_), prm(*io_.params), a(io_.a), ctx(io_.a->ctx), n(io_.a->nrows), nt(ntiles_of(io_.a->nrows)),
           ws(io_.a->ctx, io_.a->nrows) { io.params = &prm; }
@@ -57,7 +59,8 @@ struct SolverRun {
         if (io.pc) { pcl = *io.pc; if (pcl.n < 0) pcl.n = n; pc = &pcl; }
         KR_TRY(ws.init(hist_entries));
         KR_TRY(ws.reserve(work_vectors + 1));
-        lc = ws.lctx(&prm);
+        lc = ws.lctx(&prm, io.monitor != nullptr);
+        mon.io = &io; mon.ws = &ws; mon.first = 0;
         done = &ws.st->done;
         KR_TRY(ws.vec(&xw));
         KR_HIP(hipMemcpyAsync(xw, xv->d, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));
@@ -74,12 +77,12 @@ struct SolverRun {
         if (status == KRYST_OK)                  // on Err the reference never reaches `*x = ...`
             KR_HIP(hipMemcpyAsync(xv->d, xw, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));
         KR_HIP(hipStreamSynchronize(ctx->s_main));
-        run_monitor(io, ws, 0);
+        finish_monitor(mon, ws);
         return status;
     }
     int32_t solve() {
         KR_TRY(begin());
-        KR_TRY(run_ahead(ctx, &prm, [&](int64_t i) -> int32_t { next_iter = i + 1; return iterate(i); }));
+        KR_TRY(run_ahead(ctx, &prm, [&](int64_t i) -> int32_t { next_iter = i + 1; return iterate(i); }, [&] { mon.poll(); }));
         return end();
     }
 };

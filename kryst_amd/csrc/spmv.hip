@@ -40,6 +40,10 @@ struct SpmvArgs {
     int32_t pat_red_off;                           // byte offset of the reduction scratch in the kernel's dynamic LDS
     int32_t nloc8;                                 // 8 * nloc
     int32_t tpw;                                   // pattern kernel: consecutive tile slots per workgroup
+    int32_t amask;                                 // window start = k0 & ~amask (1: value pairs; 31: whole memory lines)
+#ifdef KR_TUNING
+    int32_t abl;                                   // timing-only ablation mask (tuning builds)
+#endif
 };
 
 template <bool NT, class T>
@@ -104,7 +108,12 @@ __global__ __launch_bounds__(KR_T, MINW) void spmv_wave_kernel(const SpmvArgs a)
         const int p2 = a.row_ptr[min(row + 2, r1)];
         const int k0 = a.row_ptr[wr0], k1 = a.row_ptr[wr1];         // wave-uniform
         double s0 = 0.0, s1 = 0.0;
-        for (int base = k0 & ~1; base < k1; base += WCAP) {
+#ifdef KR_TUNING
+        if (a.abl & 128) { if (row + 1 < r1) st2(a.y, row, (double)p0, (double)p1); }     // the y traffic at the START of the tile (timing only)
+#endif
+        // a window starts on a memory line of both streams when amask = 31 (32 entries = 128 B of columns, 256 B of values):
+        // every load instruction then covers whole lines, which matters for nontemporal loads (no L1 copy of a shared line)
+        for (int base = k0 & ~a.amask; base < k1; base += WCAP) {
             const int wend = min(base + WCAP, k1);
             const int npairs = (wend - base + 1) >> 1;
             v2i c[SLOTS]; v2d v[SLOTS]; double xa[SLOTS], xb[SLOTS];
@@ -115,8 +124,24 @@ __global__ __launch_bounds__(KR_T, MINW) void spmv_wave_kernel(const SpmvArgs a)
                 c[j] = stream_load<NT>(reinterpret_cast<const v2i*>(a.col + k));
                 v[j] = stream_load<NT>(reinterpret_cast<const v2d*>(a.val + k));
             }
+#ifdef KR_TUNING
+            // timing-only ablations (tools/tune_abl.py; wrong results): 1 no x gathers, 2 no LDS products / row sums, 4 no y / dot
+            if (a.abl & 1) {
+#pragma unroll
+                for (int j = 0; j < SLOTS; ++j) { xa[j] = (double)c[j].x; xb[j] = (double)c[j].y; }
+            } else
+#endif
+            {
 #pragma unroll
             for (int j = 0; j < SLOTS; ++j) { xa[j] = gather<HALO>(a, c[j].x); xb[j] = gather<HALO>(a, c[j].y); }
+            }
+#ifdef KR_TUNING
+            if (a.abl & 2) {
+#pragma unroll
+                for (int j = 0; j < SLOTS; ++j) { s0 = s0 + v[j].x * xa[j]; s1 = s1 + v[j].y * xb[j]; }
+                continue;
+            }
+#endif
 #pragma unroll
             for (int j = 0; j < SLOTS; ++j)
                 *reinterpret_cast<double2*>(&prod[2 * (l + j * 64)]) = make_double2(v[j].x * xa[j], v[j].y * xb[j]);
@@ -129,11 +154,22 @@ __global__ __launch_bounds__(KR_T, MINW) void spmv_wave_kernel(const SpmvArgs a)
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (row + 1 < r1) st2(a.y, row, s0, s1);
-        else if (row < r1) a.y[row] = s0;
+#ifdef KR_TUNING
+        if (a.abl & 4) { if (s0 + s1 == 0.123456789) a.y[row] = s0; continue; }
+        if (a.abl & 64) { if (row + 1 < r1) st2_keep(a.y, row, s0, s1); else if (row < r1) a.y[row] = s0; } else
+#endif
+        { if (row + 1 < r1) st2(a.y, row, s0, s1);
+        else if (row < r1) a.y[row] = s0; }
         if constexpr (NQ > 0) {
             double acc[NQ];
+#ifdef KR_TUNING
+            d2 d;
+            if (a.abl & 16) { d.a = s1; d.b = s0; }
+            else if (a.abl & 8) d = ld2_keep(a.dvec, row);
+            else d = ld2(a.dvec, row);
+#else
             const d2 d = ld2(a.dvec, row);
+#endif
             acc[0] = 0.0;
             if (row < r1) acc[0] = acc[0] + d.a * s0;
             if (row + 1 < r1) acc[0] = acc[0] + d.b * s1;
@@ -142,6 +178,17 @@ __global__ __launch_bounds__(KR_T, MINW) void spmv_wave_kernel(const SpmvArgs a)
                 if (row < r1) acc[1] = acc[1] + s0 * s0;
                 if (row + 1 < r1) acc[1] = acc[1] + s1 * s1;
             }
+#ifdef KR_TUNING
+            if (a.abl & 32) {
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) acc[k] = wave_butterfly(acc[k]);
+                if (l == 0) {
+#pragma unroll
+                    for (int k = 0; k < NQ; ++k) a.partials[k * a.pstride + q] = acc[k];
+                }
+                continue;
+            }
+#endif
             block_reduce<NQ, KR_T / 64>(acc, red);
             if (t == 0) {
 #pragma unroll
@@ -551,6 +598,10 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
     args.y = y; args.tiles = tiles; args.ntiles = (int32_t)ntiles; args.nrows = (int32_t)a->nrows;
     args.dvec = dvec; args.partials = ctx->d_partials; args.pstride = ctx->partials_cap; args.done = done;
     args.swizzle = env_int("KRYST_SPMV_SWIZZLE", 0);
+    args.amask = env_int("KRYST_SPMV_ALIGN", 0) ? 31 : 1;
+#ifdef KR_TUNING
+    args.abl = env_int("KRYST_SPMV_ABL", 0);
+#endif
     args.group = std::max(1, env_int("KRYST_SPMV_GROUP", 1));
     int64_t chunk = (ntiles + 7) / 8;                       // tiles per XCD
     if (!args.swizzle) chunk = (chunk + args.group - 1) / args.group * args.group;   // a whole number of runs of `group` tiles
@@ -638,11 +689,19 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
         KR_HIP(hipGetLastError());
         return KRYST_OK;
     }
-#define KR_SPMV_LAUNCH(NQ_, SL_) hipLaunchKernelGGL((spmv_wave_kernel<NQ_, HALO, SL_, false>), grid, block, 0, ctx->s_main, args)
+    const bool nt = env_int("KRYST_SPMV_NT", 0) != 0;
+    // window size of the plain kernel: one window per 128-row slice (7 pair slots for a 7-point stencil's 896 entries) while the
+    // vectors fit the 256 MiB Infinity Cache, 4 slots (74 registers, 6 waves per SIMD instead of 4) beyond it -- measured
+    // (profiles/r02/plain_csr_study.md): 256^3 0.298 / 0.309 ms with 7 / 4 slots, 512^3 2.84 / 2.62 ms
+    int wslots = a->slots;
+    if (wslots > 4 && a->nrows * 8 > (256ll << 20)) wslots = 4;
+    if (slots_env > 0) wslots = slots_env;
+#define KR_SPMV_LAUNCH(NQ_, SL_) do { if (nt) hipLaunchKernelGGL((spmv_wave_kernel<NQ_, HALO, SL_, true>), grid, block, 0, ctx->s_main, args); \
+                                      else hipLaunchKernelGGL((spmv_wave_kernel<NQ_, HALO, SL_, false>), grid, block, 0, ctx->s_main, args); } while (0)
 #define KR_SPMV_BY_SLOTS(NQ_)                                   \
     do {                                                        \
-        if (a->slots <= 2) KR_SPMV_LAUNCH(NQ_, 2);              \
-        else if (a->slots <= 4) KR_SPMV_LAUNCH(NQ_, 4);         \
+        if (wslots <= 2) KR_SPMV_LAUNCH(NQ_, 2);                \
+        else if (wslots <= 4) KR_SPMV_LAUNCH(NQ_, 4);           \
         else KR_SPMV_LAUNCH(NQ_, 7);                            \
     } while (0)
     switch (nq) {

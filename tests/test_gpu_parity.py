@@ -40,6 +40,17 @@ def random_csr(rng, nrows, ncols, row_len):
     return O.Csr(nrows, ncols, rp, ci, va)
 
 
+def random_csr_fast(rng, nrows, ncols, max_len):
+    """rows of 0..max_len distinct random columns (duplicates of the draw removed), vectorised for large matrices."""
+    rp = [0]; ci = []; va = []
+    lens = rng.integers(0, max_len + 1, size=nrows)
+    for k in lens:
+        cols = np.unique(rng.integers(0, ncols, size=int(k)))
+        ci.append(cols); rp.append(rp[-1] + len(cols))
+    ci = np.concatenate(ci) if ci else np.array([], dtype=np.int64)
+    return O.Csr(nrows, ncols, rp, ci, rng.standard_normal(len(ci)))
+
+
 # ------------------------------------------------------------------------------------------------ SpMV
 def test_reference_spmv_known_answers(ctx):
     # src/matrix/sparse.rs:121-144
@@ -113,6 +124,46 @@ def test_spmv_kernel_forms_bit_exact(ctx, kernel, compress, monkeypatch):
     s = K.BiCgStabSolver(1e-7 * np.linalg.norm(b), 200); xx = np.zeros(ao.nrows)
     st = s.solve(a, None, b, xx)
     assert st.iterations == res.iterations and np.array_equal(xx, res.x) and np.array_equal(np.array(s.residual_history), res.history)
+
+
+@pytest.mark.parametrize("slots", ["2", "4", "7"])
+@pytest.mark.parametrize("nt,align", [("0", "0"), ("1", "0"), ("1", "1")])
+def test_spmv_plain_kernel_settings_bit_exact(ctx, slots, nt, align, monkeypatch):
+    """spmv_wave_kernel with every window size (the launcher picks 7 or 4 pair slots by vector size), nontemporal stream loads
+    and line-aligned windows, on ragged / empty / long rows and through the fused inner products (CG: one quantity,
+    BiCGStab: two) -- bit for bit the oracle."""
+    monkeypatch.setenv("KRYST_SPMV_KERNEL", "2"); monkeypatch.setenv("KRYST_SPMV_COMPRESS", "0")
+    monkeypatch.setenv("KRYST_SPMV_SLOTS", slots); monkeypatch.setenv("KRYST_SPMV_NT", nt); monkeypatch.setenv("KRYST_SPMV_ALIGN", align)
+    rng = np.random.default_rng(int(slots) * 100 + int(nt) * 10 + int(align))
+    cases = [O.stencil7(19, "convdiff"), O.stencil7(40, "poisson"),                  # 125 tiles: several runs per XCD
+             random_csr(rng, 1, 1, lambda: 1),
+             random_csr(rng, 1000, 777, lambda: rng.integers(0, 12)),
+             random_csr(rng, 513, 513, lambda: rng.integers(0, 3)),                   # tile boundary + 1, many empty rows
+             random_csr(rng, 600, 9000, lambda: rng.choice([0, 1, 5, 4000, 8000])),   # rows longer than a window
+             random_csr(rng, 5000, 5000, lambda: rng.choice([0, 0, 0, 300])),         # whole 128-row slices without entries
+             random_csr(rng, 1536, 1536, lambda: 40),                                 # several windows per slice
+             random_csr_fast(rng, 20000, 20000, 8),                                  # 40 tiles, ragged
+             O.Csr.from_dense(rng.standard_normal((70, 70))),
+             O.Csr(5, 5, [0, 0, 0, 0, 0, 0], [], []),
+             O.Csr(1030, 4, [0] * 1031, [], [])]                                       # three tiles, no entry at all
+    for a in cases:
+        x = rng.standard_normal(a.ncols)
+        assert np.array_equal(to_dev(ctx, a).spmv(x), a.spmv(x)), (slots, nt, align, a.nrows, a.nnz)
+    T, V, F = K.reduce_spec()
+    rs = O.Reduce.tiled(T, V, F)
+    for kind, N in (("poisson", 20), ("aniso", 24)):
+        ao = O.stencil7(N, kind)
+        a = to_dev(ctx, ao)
+        b = ao.spmv(np.ones(ao.nrows))
+        res = O.solve("cg", ao, b, tol=1e-9, max_iters=300, rs=rs)
+        s = K.CgSolver(1e-9, 300); xx = np.zeros(ao.nrows)
+        st = s.solve(a, None, b, xx)
+        assert st.iterations == res.iterations and np.array_equal(xx, res.x) and np.array_equal(np.array(s.residual_history), res.history)
+        tol = 1e-7 * np.linalg.norm(b)
+        res = O.solve("bicgstab", ao, b, tol=tol, max_iters=200, rs=rs)
+        s = K.BiCgStabSolver(tol, 200); xx = np.zeros(ao.nrows)
+        st = s.solve(a, None, b, xx)
+        assert st.iterations == res.iterations and np.array_equal(xx, res.x) and np.array_equal(np.array(s.residual_history), res.history)
 
 
 @pytest.mark.parametrize("level", ["2", "3"])
@@ -453,6 +504,94 @@ def test_monitor_and_history(ctx):
     assert len(s.residual_history) > n1
     s.clear_history()
     assert s.residual_history == []
+
+
+@pytest.mark.parametrize("solver", ["cg", "pcg", "gmres"])
+def test_monitor_is_live_and_in_order(ctx, rs, solver):
+    """with_monitor (cg.rs:84-88): the reference calls the monitor inside the loop (cg.rs:137-140,260-263).  Here the host fires
+    it from its poll loop while the device iterates: callbacks arrive in order, each exactly once, equal to the residual
+    history, all before solve() returns -- and the early ones while later iterations have not happened yet (the value a
+    callback sees in the device's progress record lags behind the end of the solve)."""
+    import time
+    N = 48
+    ao = O.stencil7(N)
+    a = to_dev(ctx, ao)
+    b = ao.spmv(np.ones(ao.nrows))
+    seen, stamps = [], []
+    def mon(i, r):
+        seen.append((i, r)); stamps.append(time.perf_counter())
+    if solver == "gmres":
+        s = K.GmresSolver(5, 1e-10, 400).with_monitor(mon); pc = None
+    elif solver == "pcg":
+        s = K.PcgSolver(1e-12, 400).with_monitor(mon); pc = K.Jacobi().setup(a)
+    else:
+        s = K.CgSolver(1e-12, 400).with_monitor(mon); pc = None
+    s.check_every = 1 if solver == "cg" else 0
+    x = np.zeros(ao.nrows)
+    t0 = time.perf_counter()
+    st = s.solve(a, pc, b, x)
+    t1 = time.perf_counter()
+    first = 1 if solver == "gmres" else 0                       # GMRES numbers its history entries from 1
+    assert [i for i, _ in seen] == list(range(first, first + len(s.residual_history)))
+    assert [r for _, r in seen] == s.residual_history
+    assert st.iterations > 40 and len(seen) >= st.iterations
+    assert all(t0 <= t <= t1 for t in stamps)
+    # live: the first tenth of the callbacks was delivered before the last tenth of the solve's wall time began
+    k = max(1, len(stamps) // 10)
+    assert stamps[k] < t0 + 0.9 * (t1 - t0), "monitor callbacks were replayed after the solve instead of fired during it"
+
+
+def test_one_open_solve_per_context(ctx, rs):
+    """The scalar state of a solve lives in per-context scratch (kryst_hip.h, Contexts): while a stepping session is open a
+    second solve or session on the same context is refused with KRYST_ERR_BUSY, inner products, SpMV and vector updates stay
+    legal and do not disturb the session, and a second context solves concurrently."""
+    ao = O.stencil7(12)
+    a = to_dev(ctx, ao)
+    b = ao.spmv(np.ones(ao.nrows))
+    ref = O.solve("cg", ao, b, tol=1e-10, max_iters=200, rs=rs)
+    bv, xv = K.DeviceVec(ctx, b), K.DeviceVec(ctx, np.zeros(ao.nrows))
+    sess = K.Session("cg", a, None, bv, xv, tol=1e-10, max_iters=200)
+    sess.step(3)
+    with pytest.raises(K.KError) as e:
+        K.CgSolver(1e-10, 200).solve(a, None, b, np.zeros(ao.nrows))
+    assert e.value.code == 104
+    with pytest.raises(K.KError) as e:
+        K.Session("cg", a, None, bv, K.DeviceVec(ctx, np.zeros(ao.nrows)), tol=1e-10, max_iters=5)
+    assert e.value.code == 104
+    u = K.DeviceVec(ctx, b)
+    d = K.dot(u, u)                                               # legal between steps; result slot of its own
+    assert d == O.dot(b, b, rs)
+    assert np.array_equal(a.spmv(np.ones(ao.nrows)), b)
+    ctx2 = K.Context(0)                                           # a second context: independent scratch
+    a2 = K.CsrMatrix.from_csr(ao.nrows, ao.ncols, ao.row_ptr, ao.col_idx, ao.vals, ctx=ctx2)
+    x2 = np.zeros(ao.nrows)
+    st2 = K.CgSolver(1e-10, 200).solve(a2, None, b, x2)
+    assert st2.iterations == ref.iterations and np.array_equal(x2, ref.x)
+    sess.step(200)
+    st = sess.end()
+    assert st.iterations == ref.iterations and np.array_equal(np.array(sess.residual_history), ref.history)
+    assert np.array_equal(xv.to_host(), ref.x)
+    x3 = np.zeros(ao.nrows)                                       # the context is free again
+    assert K.CgSolver(1e-10, 200).solve(a, None, b, x3).iterations == ref.iterations
+
+
+def test_zero_pivot_reports_its_row(ctx):
+    """KError::ZeroPivot(row) (src/error.rs:15-16): the row travels through kryst_hip_last_error_row()."""
+    d = np.array([[2.0, 1.0, 0.0, 0.0], [1.0, 0.5, 1.0, 0.0], [0.0, 1.0, 3.0, 1.0], [0.0, 0.0, 1.0, 2.0]])   # u_11 = 0.5 - 1*1/2 = 0
+    a = to_dev(ctx, O.Csr.from_dense(d, keep_zeros=False))
+    with pytest.raises(K.KError) as e:
+        K.TrueIlu0().setup(a)
+    assert e.value.code == 5 and e.value.row == 1
+
+
+def test_huge_iteration_cap_does_not_allocate_a_huge_history(ctx, rs):
+    """max_iters = 10^9 ("unbounded"): the history buffer is capped (2^22 entries), the count is still exact."""
+    ao = O.stencil7(8)
+    b = ao.spmv(np.ones(ao.nrows))
+    ref = O.solve("cg", ao, b, tol=1e-10, max_iters=10 ** 9, rs=rs)
+    s = K.CgSolver(1e-10, 10 ** 9); x = np.zeros(ao.nrows)
+    st = s.solve(to_dev(ctx, ao), None, b, x)
+    assert st.iterations == ref.iterations and np.array_equal(np.array(s.residual_history), ref.history) and np.array_equal(x, ref.x)
 
 
 @pytest.mark.parametrize("kind,N", [("convdiff", 8), ("aniso", 12), ("poisson", 5)])
