@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- CG iterations/sec + SpMV GB/s against the HBM roofline on synthetic 3-D 7-point Poisson CSR.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is ONE iteration of the reference's unpreconditioned CG (src/solver/cg.rs:141-285: SpMV + 2 inner
-products + 3 vector updates) on a matrix, right-hand side and iterate that are already resident in HBM.
-W warm-up iterations and exactly K timed iterations run inside one stepping session (tol = 0, so the device
-never stops early); the timed region is bracketed by barrier + device synchronize on both sides and the maximum
-over ranks is reported.  One JSON line on rank 0.
+A "step" is ONE iteration of the reference's unpreconditioned CG (src/solver/cg.rs:141-285: SpMV + 2 inner products + 3
+vector updates) on a matrix, right-hand side and iterate that are already resident in HBM.  W warm-up iterations and exactly
+K timed iterations run inside one stepping session (tol = 0, so the device never stops early); the timed region is bracketed
+by barrier + device synchronize on both sides and the maximum over ranks is reported.  One JSON line on rank 0.
 
-Workload: ONE fixed 512^3 system for every N (BASELINE.json's metric is quoted on 256^3/512^3; north_star asks for
-strong scaling of CG iterations/sec on 512^3, which fits a single 288 GB GPU).  N > 1: row-partitioned in k-slabs over
-the ranks, halo planes over xGMI, inner products by RCCL all-gather.  `--grid 256` measures configs[1]'s grid instead
-(profiles/r01/bench_256.json); `--with-256` adds it to the same line as "config1_256".
+Workload: ONE fixed 512^3 system for every N (BASELINE.json's metric is quoted on 256^3 / 512^3; north_star asks for strong
+scaling of CG iterations/sec on 512^3, which fits a single 288 GB GPU).  N > 1: row-partitioned in k-slabs over the ranks, halo
+planes over xGMI, inner products by RCCL all-gather.
+
+What the line holds (every `frac` is bytes the named kernel really moves / its HIP-event time / 8 TB/s, so it is <= 1):
+  value             CG iterations/s with the operator in its default (most compact lossless) storage form
+  value_plain_csr   the same K iterations with KRYST_SPMV_COMPRESS=0: the 12-bytes-per-entry CSR arrays are streamed, which is
+                    what every matrix that is not a constant-coefficient stencil gets
+  roofline          the SpMV kernel of the timed loop (fused (p,Ap) partials): bytes it moves (model; PMC `traffic` beside it
+                    when profiles/spmv_traffic.json was measured on this very source tree), `algorithmic_*` = SURVEY 8(d)'s
+                    CSR bytes for comparison (a re-encoded operator moves fewer)
+  roofline_csr      the plain-CSR kernel on SURVEY 8(d)'s bytes: north_star's "% of HBM roofline on CSR SpMV"
+  roofline_blas1    the two vector kernels of a CG iteration
+  phase_ms          device time per iteration by phase (hipEvents between the phases, a separate short run), per rank
+  config1_256       (N = 1) the same measurements on BASELINE configs[1]'s 256^3 grid, with the CPU port timed on that grid
+  cpu_baseline      the oracle's CG timed on the host cores AT the workload's size (512^3 when host memory allows, else the
+                    256^3 sample scaled and marked "extrapolated": true)
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,69 +45,181 @@ def spmv_bytes(n, nnz):
     return 12 * nnz + 4 * (n + 1) + 16 * n
 
 
-def cpu_baseline(grid, seconds=12.0):
-    """The oracle's CG (the CPU restatement of the reference path, OpenMP over rows / tiles like the reference's
-    Rayon loops) timed on the host cores on a BOUNDED sample of the same workload: CG on the 256^3 Poisson system
-    (1/8 of the 512^3 rows when grid = 512; every pass is a bandwidth-bound stream, so a 512^3 iteration costs 8x),
-    as many iterations as fit in ~`seconds`."""
+# ---------------------------------------------------------------------------------------------------------------- launcher
+class TorchGroup:
+    """torch.distributed (gloo) as plumbing: ships the RCCL unique id, host barrier, max, gather."""
+
+    def __init__(self, rank, world):
+        import torch.distributed as dist
+        self.dist, self.rank, self.world = dist, rank, world
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def broadcast_bytes(self, payload):
+        box = [payload if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def allreduce_max(self, x):
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def gather(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
+
+
+class SoloGroup:
+    rank, world = 0, 1
+    def broadcast_bytes(self, payload): return payload
+    def barrier(self): pass
+    def allreduce_max(self, x): return x
+    def gather(self, obj): return [obj]
+    def close(self): pass
+
+
+def make_group(kind, rank, world):
+    if world == 1:
+        return SoloGroup()
+    if kind == "auto":
+        kind = os.environ.get("KRYST_LAUNCHER", "torch")
+    if kind == "socket":                                    # no torch anywhere: kryst_amd/launch.py (TCP rendezvous)
+        from kryst_amd.launch import Rendezvous
+        return Rendezvous.from_env()
+    return TorchGroup(rank, world)
+
+
+# ---------------------------------------------------------------------------------------------------------------- CPU port
+def host_mem_available_gb():
+    try:
+        avail = None
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) / 1e6
+        for p in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+            if os.path.exists(p):
+                v = open(p).read().strip()
+                if v.isdigit():
+                    used = 0
+                    for q in ("/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"):
+                        if os.path.exists(q):
+                            used = int(open(q).read().strip())
+                    avail = min(avail, (int(v) - used) / 1e9) if avail is not None else (int(v) - used) / 1e9
+        return avail or 0.0
+    except Exception:
+        return 0.0
+
+
+def cpu_cg(grid, seconds):
+    """The oracle's CG (the CPU restatement of the reference path, OpenMP over rows / tiles like the reference's Rayon loops,
+    device-order dot) on the grid^3 Poisson system: as many iterations as fit in ~`seconds`.  -> dict."""
     import numpy as np
     import kryst_amd as K
     from oracle import oracle as O
     cores = min(len(os.sched_getaffinity(0)), 16)      # the GPU box's CPU share for one GPU
     O.set_threads(cores)
     T, V, F = K.reduce_spec()
-    sgrid = min(grid, 256)
-    rp, ci, va = K.host_stencil7(sgrid, "poisson")
-    a = O.Csr(sgrid ** 3, sgrid ** 3, rp, ci, va, check=False)
+    rp, ci, va = K.host_stencil7(grid, "poisson")
+    a = O.Csr(grid ** 3, grid ** 3, rp, ci, va, check=False)
     b = a.spmv(np.ones(a.nrows))
     rs = O.Reduce.tiled(T, V, F)
-    t0 = time.perf_counter(); O.solve("cg", a, b, tol=0.0, max_iters=3, rs=rs); t3 = time.perf_counter() - t0
-    iters = int(max(5, min(400, seconds / max(t3 / 4.0, 1e-4))))     # 3 iterations + the initial residual pass
+    t0 = time.perf_counter(); O.solve("cg", a, b, tol=0.0, max_iters=2, rs=rs); t2 = time.perf_counter() - t0
+    iters = int(max(3, min(400, seconds / max(t2 / 3.0, 1e-4))))     # 2 iterations + the initial residual pass
     t0 = time.perf_counter()
     res = O.solve("cg", a, b, tol=0.0, max_iters=iters, rs=rs)
     dt = time.perf_counter() - t0
-    scale = (sgrid / grid) ** 3
-    # the bit-canonical single-thread figure beside it (SURVEY 8d), a few iterations only
-    O.set_threads(1)
-    t0 = time.perf_counter(); r1 = O.solve("cg", a, b, tol=0.0, max_iters=4, rs=rs); dt1 = time.perf_counter() - t0
-    O.set_threads(cores)
-    return {"value": res.iterations / dt * scale, "unit": "cg_iterations/s", "cores": cores, "kind": "port",
-            "single_thread_value": r1.iterations / dt1 * scale,
-            "sample": f"{res.iterations} oracle CG iterations on a {sgrid}^3 Poisson system in {dt:.1f} s "
-                      f"({res.iterations / dt:.1f} it/s, OpenMP rows/tiles over {cores} threads, device-order dot)"
-                      + (f"; scaled by {scale:.4f} = ({sgrid}/{grid})^3 rows to the {grid}^3 workload" if scale != 1 else "")}
+    out = {"value": res.iterations / dt, "unit": "cg_iterations/s", "cores": cores, "kind": "port", "grid": grid, "extrapolated": False,
+           "sample": f"{res.iterations} oracle CG iterations on the {grid}^3 Poisson system in {dt:.1f} s "
+                     f"(OpenMP rows/tiles over {cores} threads, device-order dot; usize = int64 indices like the reference)"}
+    if grid <= 256:                                     # the bit-canonical single-thread figure beside it (SURVEY 8d), a few iterations
+        O.set_threads(1)
+        t0 = time.perf_counter(); r1 = O.solve("cg", a, b, tol=0.0, max_iters=4, rs=rs); dt1 = time.perf_counter() - t0
+        O.set_threads(cores)
+        out["single_thread_value"] = r1.iterations / dt1
+    return out
 
 
-def traffic_of(grid):
-    """HBM bytes per SpMV launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py,
-    read side calibrated on a kernel of known byte count as MI355X_MICROARCH.md prescribes), or None."""
-    tf = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+def cpu_baseline(grid, base256):
+    """Measured AT the workload's size when the host has the memory for it (512^3: 24 GB of int64-indexed CSR + vectors),
+    otherwise the 256^3 measurement scaled by the row count and marked as extrapolated."""
     try:
-        return json.load(open(tf))[str(grid)]["hbm_bytes_per_launch"]
+        if grid <= 256:
+            return base256 or cpu_cg(grid, 8.0)
+        need = 16.0 * 7 * grid ** 3 / 1e9 + 8 * 8.0 * grid ** 3 / 1e9 + 6.0
+        if os.environ.get("KRYST_BENCH_CPU_FULL", "1") != "0" and host_mem_available_gb() > need:
+            return cpu_cg(grid, 10.0)
+        b = base256 or cpu_cg(256, 8.0)
+        scale = (256 / grid) ** 3
+        out = dict(b, value=b["value"] * scale, grid=grid, extrapolated=True)
+        out["sample"] = b["sample"] + f"; scaled by {scale:.4f} = (256/{grid})^3 rows (host memory below {need:.0f} GB)"
+        if "single_thread_value" in out:
+            out["single_thread_value"] = b["single_thread_value"] * scale
+        return out
+    except Exception as e:                              # the oracle is only the reported baseline, never the product
+        return {"value": None, "unit": "cg_iterations/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU side
+def traffic_of(grid, form):
+    """HBM bytes per SpMV launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh, read side
+    calibrated on a kernel of known byte count as MI355X_MICROARCH.md prescribes) -- only when that measurement was made on
+    THIS source tree (same sha of kryst_amd/csrc + include), else None."""
+    from kryst_amd._ffi import source_sha16
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json")))[str(grid)][form]
+        if e.get("source_sha16") != source_sha16():
+            return None
+        return e["hbm_bytes_per_launch"]
     except Exception:
         return None
 
 
-def roofline(enc, nloc, nnz_loc, spmv_ms, plain_ms, copy_gbs):
-    """`achieved` prices the launch at the ALGORITHMIC CSR bytes of SURVEY 8(d) (12 B/nnz + row pointers + x + y) whatever
-    the operator's storage form; `bytes_moved_model` is what the kernel that ran actually streams (a lossless re-encoding
-    moves fewer bytes than the CSR arrays, so frac can exceed 1); `plain_csr` is the same launch on the CSR arrays."""
+def kernel_name(enc):
     name, npat, ntab = enc
-    alg = spmv_bytes(nloc, nnz_loc)
-    moved = {"csr": alg, "csr-d8": alg - 3 * nnz_loc, "csr-d16": alg - 10 * nnz_loc,
-             "csr-p16": 2 * nloc + 16 * nloc}[name]
-    kern = {"csr": "spmv_wave_kernel<1> (plain CSR: 8 B value + 4 B column per entry)",
+    return {"csr": "spmv_wave_kernel<1> (plain CSR: 8 B value + 4 B column per entry)",
             "csr-d8": "spmv_rows_kernel<1> (CSR-D8: 8 B value + 1-byte column-offset code per entry)",
             "csr-d16": "spmv_dict_kernel<1> (CSR-D16: one 16-bit word per entry = offset code + value code)",
             "csr-p16": f"spmv_pattern_kernel<1> (CSR-P16: one 16-bit row-pattern id per row; {npat} ids, {ntab} table entries in LDS)"}[name]
-    ach = alg / (spmv_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": kern + ", fused (p,Ap) partials; achieved = ALGORITHMIC CSR bytes (12 B/nnz) / time",
-            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "bytes_per_launch": alg, "ms_per_launch": spmv_ms, "traffic": None,
-            "encoding": name, "bytes_moved_model": moved, "moved_GBs": moved / (spmv_ms * 1e-3) / 1e9,
-            "plain_csr": {"ms_per_launch": plain_ms, "achieved": alg / (plain_ms * 1e-3) / 1e9,
-                          "frac": alg / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "measured_copy_GBs": copy_gbs}
+
+
+def roofline_of(enc, grid, nloc, nnz_loc, ms, world):
+    """The kernel that ran, priced at the bytes IT moves."""
+    alg = spmv_bytes(nloc, nnz_loc)
+    moved = {"csr": alg, "csr-d8": alg - 3 * nnz_loc, "csr-d16": alg - 10 * nnz_loc, "csr-p16": 2 * nloc + 16 * nloc}[enc[0]]
+    ach = moved / (ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "kernel": kernel_name(enc) + ", fused (p,Ap) tile partials",
+           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+           "bytes_per_launch": moved, "bytes_model": "bytes this storage form streams: matrix description + x once + y once",
+           "ms_per_launch": ms, "traffic": None, "encoding": enc[0],
+           "algorithmic_bytes": alg, "algorithmic_GBs": alg / (ms * 1e-3) / 1e9, "algorithmic_speedup": alg / moved}
+    if world == 1:
+        tr = traffic_of(grid, "plain" if enc[0] == "csr" else "default")
+        if tr:
+            out["traffic"] = tr
+            out["frac_traffic"] = tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return out
+
+
+def roofline_csr_of(grid, nloc, nnz_loc, ms, world):
+    alg = spmv_bytes(nloc, nnz_loc)
+    ach = alg / (ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "kernel": kernel_name(("csr", 0, 0)) + ", fused (p,Ap) tile partials",
+           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+           "bytes_per_launch": alg, "bytes_model": "SURVEY 8(d): 12 nnz + 4 (n + 1) + 16 n", "ms_per_launch": ms, "traffic": None}
+    if world == 1:
+        tr = traffic_of(grid, "plain")
+        if tr:
+            out["traffic"] = tr
+    return out
 
 
 def blas1_streams(K, ctx, n):
@@ -113,52 +238,79 @@ def blas1_streams(K, ctx, n):
     return out
 
 
-def run_cg(K, ctx, dist, grid, solver, warmup, steps):
-    """W warm-up + exactly K timed iterations of one stepping session; returns (seconds, stats, spmv_ms, a)."""
+class env_override:
+    def __init__(self, **kv): self.kv, self.old = kv, {}
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = os.environ.get(k)
+            os.environ[k] = v
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
+def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters):
+    """Everything measured on one grid size -> dict (the operator is built once; the plain-CSR figures re-run the same
+    iterations with KRYST_SPMV_COMPRESS=0, which the launcher reads per launch)."""
     def barrier():
         ctx.synchronize()
-        if dist is not None:
-            dist.barrier()
+        group.barrier()
 
+    world = group.world
     a = K.CsrMatrix.stencil7(grid, "poisson", ctx=ctx)
     nloc = a.nrows()
-    ones = ctx.vec(nloc).fill(1.0)
-    b = a.spmv(ones)                      # b = A*1 (tests/preconditioner_integration.rs:25-31 convention)
-    x = ctx.vec(nloc)
+    b = a.spmv(ctx.vec(nloc).fill(1.0))                      # b = A*1 (tests/preconditioner_integration.rs:25-31 convention)
     pc = K.Jacobi().setup(a) if solver == "pcg" else None
-    sess = K.Session(solver, a, pc, b, x, tol=0.0, max_iters=warmup + steps)
-    sess.step(warmup)
-    barrier()
-    t0 = time.perf_counter()
-    sess.step(steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    stats = sess.end()
-    assert stats.iterations == warmup + steps, stats
-    # dominant kernel: the SpMV with the fused (p,Ap) partials, timed live with HIP events on its own stream
+
+    def timed_iterations():
+        x = ctx.vec(nloc)
+        sess = K.Session(solver, a, pc, b, x, tol=0.0, max_iters=warmup + steps)
+        sess.step(warmup)
+        barrier()
+        t0 = time.perf_counter()
+        sess.step(steps)
+        barrier()
+        dt = group.allreduce_max(time.perf_counter() - t0)
+        stats = sess.end()
+        assert stats.iterations == warmup + steps, stats
+        return dt, stats
+
+    dt, stats = timed_iterations()
+    enc = a.encoding()
+    with env_override(KRYST_SPMV_COMPRESS="0"):
+        dt_plain, stats_plain = timed_iterations()
+    # the dominant kernel, timed live with HIP events on the compute stream (kryst_bench_spmv), in both storage forms
     y = ctx.vec(nloc)
     spmv_ms = a.bench_spmv(b, y, fused_dots=1, reps=50)
-    enc = a.encoding()
-    # the same launch on the plain CSR arrays (12 B/nnz streamed), for reference
-    prev = os.environ.get("KRYST_SPMV_COMPRESS")
-    os.environ["KRYST_SPMV_COMPRESS"] = "0"
-    plain_ms = a.bench_spmv(b, y, fused_dots=1, reps=20)
-    if prev is None:
-        del os.environ["KRYST_SPMV_COMPRESS"]
-    else:
-        os.environ["KRYST_SPMV_COMPRESS"] = prev
-    # context for the roofline: the device-copy rate at this footprint (hipMemcpy D2D of one vector, read + write)
+    with env_override(KRYST_SPMV_COMPRESS="0"):
+        plain_ms = a.bench_spmv(b, y, fused_dots=1, reps=30)
+    # context: the device-copy rate at this footprint (hipMemcpy D2D of one vector, read + write)
     y.copy_from(b); ctx.synchronize()
     ctx.timer_start()
     for _ in range(10):
         y.copy_from(b)
     copy_gbs = 10 * 16.0 * nloc / (ctx.timer_stop() * 1e-3) / 1e9
-    return dt, stats, spmv_ms, nloc, a.nnz, copy_gbs, enc, plain_ms, blas1_streams(K, ctx, nloc)
+    # where an iteration's device time goes (a separate short run with event marks between the phases)
+    phases = None
+    if phase_iters > 0:
+        x = ctx.vec(nloc)
+        sess = K.Session(solver, a, pc, b, x, tol=0.0, max_iters=phase_iters + 2)
+        sess.step(2)
+        barrier()
+        ctx.phase_timing_begin()
+        sess.step(phase_iters)
+        ph = ctx.phase_timing_end()
+        sess.end()
+        mine = {k: v / phase_iters for k, v in ph.items() if v > 0.0}
+        mine["total"] = sum(mine.values())
+        phases = group.gather(mine)
+    nnz_loc = a.nnz
+    return {"dt": dt, "dt_plain": dt_plain, "stats": stats, "enc": enc, "nloc": nloc, "nnz_loc": nnz_loc,
+            "roofline": roofline_of(enc, grid, nloc, nnz_loc, spmv_ms, world),
+            "roofline_csr": roofline_csr_of(grid, nloc, nnz_loc, plain_ms, world),
+            "blas1": blas1_streams(K, ctx, nloc), "copy_gbs": copy_gbs, "phases": phases,
+            "final_residual_plain": stats_plain.final_residual}
 
 
 def main():
@@ -169,13 +321,13 @@ def main():
     ap.add_argument("--grid", type=int, default=0, help="grid edge (default 512 for every N)")
     ap.add_argument("--solver", default="cg", choices=["cg", "pcg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--with-256", action="store_true",
-                    help="also measure BASELINE configs[1]'s 256^3 grid in the same process (block `config1_256`); off by "
-                         "default so that the rocprofv3 averages of the default command refer to ONE problem size")
+    ap.add_argument("--no-256", action="store_true", help="skip the config1_256 block (N = 1 measures BASELINE configs[1]'s 256^3 grid too)")
+    ap.add_argument("--phase-iters", type=int, default=20, help="iterations of the per-phase timing run (0: skip)")
+    ap.add_argument("--launcher", default="auto", choices=["auto", "torch", "socket"],
+                    help="N > 1 plumbing for the RCCL id / barrier: torch.distributed gloo (default) or kryst_amd/launch.py (no torch)")
     args = ap.parse_args()
 
     # a hung collective must not hang the node: give up loudly after 20 minutes
-    import threading
     def _watchdog():
         sys.stderr.write("bench.py: watchdog timeout (1200 s), aborting\n"); sys.stderr.flush(); os._exit(124)
     wd = threading.Timer(1200.0, _watchdog); wd.daemon = True; wd.start()
@@ -189,58 +341,50 @@ def main():
         args.gpus = world
     grid = args.grid or 512          # ONE fixed problem for every N (strong scaling, north_star): 512^3
 
-    dist = None
-    if world > 1:
-        # torch.distributed (gloo) is plumbing only: ship the RCCL unique id and provide the host barrier / max
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    group = make_group(args.launcher, rank, world)
     import kryst_amd as K
-
     if world > 1:
-        box = [K.Context.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
+        uid = group.broadcast_bytes(K.Context.unique_id() if rank == 0 else None)
         # KRYST_BENCH_DEVICE: rehearsal of the N > 1 flow on a one-GPU box (all ranks on one device, RCCL stand-in)
         dev = int(os.environ.get("KRYST_BENCH_DEVICE", local_rank))
-        ctx = K.Context(dev, rank, world, box[0])
+        ctx = K.Context(dev, rank, world, uid)
     else:
         ctx = K.Context(0)
 
     n = grid ** 3
     nnz = 7 * n - 6 * grid * grid
-    dt, stats, spmv_ms, nloc, nnz_loc, copy_gbs, enc, plain_ms, streams = run_cg(K, ctx, dist, grid, args.solver, args.warmup, args.steps)
-    bytes_local = spmv_bytes(nloc, nnz_loc)
-    achieved = bytes_local / (spmv_ms * 1e-3) / 1e9
-
+    m = measure(K, ctx, group, grid, args.solver, args.warmup, args.steps, args.phase_iters)
+    wl = "jacobi_pcg" if args.solver == "pcg" else "cg"
     out = {
-        "metric": "cg_iterations_per_sec", "value": args.steps / dt, "unit": "iterations/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "metric": "cg_iterations_per_sec", "value": args.steps / m["dt"], "unit": "iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["dt"] / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{'jacobi_pcg' if args.solver == 'pcg' else 'cg'}_poisson7_{grid}^3", "grid": grid,
-                   "rows": n, "nnz": nnz, "partition": f"{world} k-slab(s)", "rhs": "A*1", "x0": "0",
-                   "final_residual": stats.final_residual},
-        "roofline": roofline(enc, nloc, nnz_loc, spmv_ms, plain_ms, copy_gbs),
-        "roofline_blas1": streams,      # the other two kernels of the iteration (they take 60 % of it once the SpMV streams 18 B/row)
+        "config": {"workload": f"{wl}_poisson7_{grid}^3", "grid": grid, "rows": n, "nnz": nnz, "partition": f"{world} k-slab(s)",
+                   "rhs": "A*1", "x0": "0", "final_residual": m["stats"].final_residual, "spmv_encoding": m["enc"][0],
+                   "launcher": type(group).__name__},
+        "value_plain_csr": args.steps / m["dt_plain"], "ms_per_step_plain_csr": m["dt_plain"] / args.steps * 1e3,
+        "roofline": m["roofline"], "roofline_csr": m["roofline_csr"], "roofline_blas1": m["blas1"],
+        "measured_copy_GBs": m["copy_gbs"],
+        "phase_ms": m["phases"],         # per rank: device ms per iteration by phase (spmv / halo_wait / spmv_boundary / reduce / blas1)
     }
-    if world == 1:
-        out["roofline"]["traffic"] = traffic_of(grid)
-    if world == 1 and grid != 256 and args.with_256:
-        dt2, st2, ms2, nl2, nz2, cp2, enc2, pm2, _s2 = run_cg(K, ctx, None, 256, args.solver, args.warmup, args.steps)
-        out["config1_256"] = {"workload": f"{'jacobi_pcg' if args.solver == 'pcg' else 'cg'}_poisson7_256^3",
-                              "value": args.steps / dt2, "unit": "iterations/s", "ms_per_step": dt2 / args.steps * 1e3,
-                              "roofline": roofline(enc2, nl2, nz2, ms2, pm2, cp2)}
-        tr2 = traffic_of(256)
-        if tr2:
-            out["config1_256"]["roofline"]["traffic"] = tr2
+    base256 = None
+    if world == 1 and grid != 256 and not args.no_256:
+        m2 = measure(K, ctx, group, 256, args.solver, args.warmup, args.steps, args.phase_iters)
+        out["config1_256"] = {"workload": f"{wl}_poisson7_256^3", "value": args.steps / m2["dt"], "unit": "iterations/s",
+                              "ms_per_step": m2["dt"] / args.steps * 1e3, "value_plain_csr": args.steps / m2["dt_plain"],
+                              "roofline": m2["roofline"], "roofline_csr": m2["roofline_csr"], "roofline_blas1": m2["blas1"],
+                              "phase_ms": m2["phases"]}
+        if not args.no_cpu_baseline:
+            try:
+                base256 = cpu_cg(256, 8.0)
+                out["config1_256"]["cpu_baseline"] = base256
+            except Exception as e:
+                out["config1_256"]["cpu_baseline"] = {"value": None, "unit": "cg_iterations/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline(grid)
-        except Exception as e:                      # the oracle is only the reported baseline, never the product
-            out["cpu_baseline"] = {"value": None, "unit": "cg_iterations/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        out["cpu_baseline"] = cpu_baseline(grid, base256)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

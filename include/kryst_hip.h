@@ -73,6 +73,14 @@ int32_t kryst_ctx_synchronize(kryst_ctx_t ctx);                    /* hipStreamS
 int32_t kryst_ctx_rank(kryst_ctx_t ctx, int32_t* rank, int32_t* nranks);   /* Comm::rank / Comm::size */
 int32_t kryst_comm_barrier(kryst_ctx_t ctx);                       /* Comm::barrier, mpi_comm.rs:67 */
 int32_t kryst_comm_all_reduce(kryst_ctx_t ctx, double x, double* out);     /* Comm::all_reduce, mpi_comm.rs:116-121 */
+/* measurement only: per-phase device time of the work enqueued between begin and end (hipEvents recorded on the compute stream
+ * after each phase: time between two marks is charged to the later one).  ms[p] for p < kryst_phase_count(): "spmv" (tiles
+ * without halo columns; single rank: the whole SpMV), "halo_wait" (compute stream waiting for the neighbour planes),
+ * "spmv_boundary", "reduce" (tile-partial fold + RCCL all-gather + rank-ordered fold + scalar step), "blas1", "pc". */
+int32_t kryst_phase_timing_begin(kryst_ctx_t ctx);
+int32_t kryst_phase_timing_end(kryst_ctx_t ctx, double* ms, int32_t count);
+int32_t kryst_phase_count(void);
+const char* kryst_phase_name(int32_t phase);
 /* wall-clock of the device work enqueued between the two marks, in ms (hipEvent on the ctx compute stream) */
 int32_t kryst_ctx_timer_start(kryst_ctx_t ctx);
 int32_t kryst_ctx_timer_stop(kryst_ctx_t ctx, double* ms);

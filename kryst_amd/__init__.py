@@ -90,6 +90,17 @@ class Context:
         check(lib().kryst_ctx_timer_stop(self.h, C.byref(ms)))
         return ms.value
 
+    def phase_timing_begin(self):
+        """Start charging device time to phases (spmv / halo_wait / spmv_boundary / reduce / blas1 / pc): measurement only."""
+        check(lib().kryst_phase_timing_begin(self.h))
+
+    def phase_timing_end(self):
+        """-> {phase name: ms} of the work enqueued since phase_timing_begin (synchronises the context)."""
+        n = lib().kryst_phase_count()
+        ms = (C.c_double * n)()
+        check(lib().kryst_phase_timing_end(self.h, ms, n))
+        return {lib().kryst_phase_name(i).decode(): ms[i] for i in range(n)}
+
     def vec(self, n_or_array):
         return DeviceVec(self, n_or_array)
 

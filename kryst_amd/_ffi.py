@@ -47,6 +47,10 @@ SIGNATURES = {
     "kryst_ctx_rank": (C.c_int32, [Handle, c_i32p, c_i32p]),
     "kryst_comm_barrier": (C.c_int32, [Handle]),
     "kryst_comm_all_reduce": (C.c_int32, [Handle, C.c_double, c_dp]),
+    "kryst_phase_timing_begin": (C.c_int32, [Handle]),
+    "kryst_phase_timing_end": (C.c_int32, [Handle, c_dp, C.c_int32]),
+    "kryst_phase_count": (C.c_int32, []),
+    "kryst_phase_name": (C.c_char_p, [C.c_int32]),
     "kryst_ctx_timer_start": (C.c_int32, [Handle]),
     "kryst_ctx_timer_stop": (C.c_int32, [Handle, c_dp]),
     "kryst_vec_create": (C.c_int32, [Handle, C.c_int64, C.POINTER(Handle)]),
@@ -126,6 +130,21 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib
+
+
+def source_sha16():
+    """sha256 (first 16 hex digits) over the library's sources (kryst_amd/csrc/*.{hip,h,cpp}, Makefile, include/kryst_hip.h):
+    measurements kept under profiles/ carry it, so that bench.py only quotes one beside numbers from the same source tree."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(_HERE, "csrc", "Makefile"),
+                                                                       os.path.join(os.path.dirname(_HERE), "include", "kryst_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 class KError(Exception):

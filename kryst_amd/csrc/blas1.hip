@@ -76,15 +76,6 @@ __global__ __launch_bounds__(KR_F) void final_fold_kernel(const double* partials
     }
 }
 
-// fold of the rank results in rank order: total = r0; total = total + r_p (p = 1..P-1)
-__global__ void rank_fold_kernel(const double* gathered, int nq, int nranks, double* out) {
-    const int q = threadIdx.x;
-    if (q >= nq) return;
-    double total = gathered[q];
-    for (int p = 1; p < nranks; ++p) total = total + gathered[p * nq + q];
-    out[q] = total;
-}
-
 // A one-rank communicator normally skips RCCL; KRYST_FORCE_COMM=1 keeps the collective path (used by the
 // single-GPU rehearsal of the multi-rank code in tests/test_gpu_dist_single.py).
 bool use_collectives(kryst_ctx_t ctx) {
@@ -121,17 +112,6 @@ int32_t launch_final_fold(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out
         case 8: hipLaunchKernelGGL(final_fold_kernel<8>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
         default: set_error("final fold: nq=%d", nq); return KRYST_ERR_ARG;
     }
-    KR_HIP(hipGetLastError());
-    return KRYST_OK;
-}
-
-int32_t reduce_all(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out) {
-    if (!use_collectives(ctx)) return launch_final_fold(ctx, nq, ntiles, d_out);
-    // local fold -> all-gather of nq doubles per rank -> fold in rank order (bitwise identical on every rank)
-    double* local = ctx->d_gather + (size_t)ctx->nranks * KR_MAXQ;      // staging after the gather area
-    KR_TRY(launch_final_fold(ctx, nq, ntiles, local));
-    KR_TRY(comm_all_gather(ctx, local, ctx->d_gather, nq));
-    hipLaunchKernelGGL(rank_fold_kernel, dim3(1), dim3(64), 0, ctx->s_main, ctx->d_gather, nq, ctx->nranks, d_out);
     KR_HIP(hipGetLastError());
     return KRYST_OK;
 }
@@ -220,10 +200,25 @@ int32_t kryst_dot(kryst_vec_t x, kryst_vec_t y, double* out) {
     // result slot of its own (d_scal[1024]): d_scal[0..512) is the scalar state of an open solve / stepping session, and the
     // partials / chunk / ticket scratch is consumed in stream order, so a dot between two session steps disturbs nothing
     double* slot = ctx->d_scal + 1024;
-    KR_TRY(reduce_all(ctx, 1, ntiles_of(x->n), slot));
-    KR_HIP(hipMemcpyAsync(ctx->h_pinned, slot, sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
+    if (!use_collectives(ctx)) {
+        KR_TRY(launch_final_fold(ctx, 1, ntiles_of(x->n), slot));
+        KR_HIP(hipMemcpyAsync(ctx->h_pinned, slot, sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
+        KR_HIP(hipStreamSynchronize(ctx->s_main));
+        *out = ctx->h_pinned[0];
+        return KRYST_OK;
+    }
+    // several ranks: local fold -> all-gather of one double per rank -> the result goes to the host anyway, so the rank-ordered
+    // fold (total = r0; total = total + r_p: the same bits on every rank) runs there: two launches and one collective per dot,
+    // like the solvers' reduce_then (whose rank-ordered fold shares a launch with the scalar step that consumes it)
+    double* gathered = ctx->d_scal + 1032;                               // nranks doubles (<= 2048 ranks)
+    KR_ARG(ctx->nranks <= 2048, "dot: too many ranks for the scalar scratch");
+    KR_TRY(launch_final_fold(ctx, 1, ntiles_of(x->n), slot));
+    KR_TRY(comm_all_gather(ctx, slot, gathered, 1));
+    KR_HIP(hipMemcpyAsync(ctx->h_pinned, gathered, sizeof(double) * (size_t)ctx->nranks, hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
-    *out = ctx->h_pinned[0];
+    double total = ctx->h_pinned[0];
+    for (int p = 1; p < ctx->nranks; ++p) total = total + ctx->h_pinned[p];
+    *out = total;
     return KRYST_OK;
 }
 

@@ -54,6 +54,21 @@ struct HostProgress {
 
 struct Comm;   // dist.cpp
 
+// Optional per-phase timing of the compute stream (kryst_phase_timing_begin / _end; bench.py's `phase_ms`): while it is on, the
+// launchers record a hipEvent after each phase of an iteration and the time between two consecutive marks is charged to the
+// later mark's phase.  Off (the default) a mark is one pointer test.
+enum { KR_PH_SPMV = 0,          // SpMV tiles that need no halo (single rank: the whole SpMV)
+       KR_PH_HALO_WAIT,         // compute stream waiting for the halo exchange after the interior tiles
+       KR_PH_SPMV_BOUNDARY,     // tiles with halo columns
+       KR_PH_REDUCE,            // tile-partial fold, RCCL all-gather, rank-ordered fold + the solver's scalar step
+       KR_PH_BLAS1,             // fused vector updates (incl. their tile partials)
+       KR_PH_PC,                // preconditioner apply
+       KR_PH_COUNT };
+struct PhaseTimer {
+    std::vector<std::pair<int, hipEvent_t>> marks;      // (phase, event recorded after it); phase -1: the start mark
+    std::vector<hipEvent_t> pool;                       // events to reuse
+};
+
 }  // namespace kr
 
 struct kryst_ctx_s {
@@ -79,6 +94,7 @@ struct kryst_ctx_s {
     // The scalar state of a solve (DevState, reduction results, progress record) lives in per-context scratch, so ONE solve
     // or stepping session may be open per context at a time: a second one is refused with KRYST_ERR_BUSY (kryst_hip.h).
     const void* active_ws = nullptr;
+    kr::PhaseTimer* phase = nullptr;     // non-null while kryst_phase_timing is on
     int num_cu = 256;
 };
 
@@ -91,6 +107,8 @@ struct kryst_vec_s {
 namespace kr {
 
 int32_t ensure_partials(kryst_ctx_t ctx, int64_t ntiles);
+void phase_mark_slow(kryst_ctx_t ctx, int phase);                       // ctx.cpp
+inline void phase_mark(kryst_ctx_t ctx, int phase) { if (ctx->phase) phase_mark_slow(ctx, phase); }
 inline int64_t ntiles_of(int64_t n) { return (n + KR_TILE - 1) / KR_TILE; }
 inline int64_t nchunks_of(int64_t ntiles) { return ntiles > KR_F ? (ntiles + KR_F - 1) / KR_F : 1; }
 
@@ -215,8 +233,6 @@ __device__ __forceinline__ bool fold2(const double* partials, int64_t stride, in
 int32_t launch_dot_partials(kryst_ctx_t ctx, const double* x, const double* y, int64_t n, int slot);
 // local result of up to nq partial arrays -> d_out[0..nq) (device), single rank: the final value
 int32_t launch_final_fold(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out);
-// global (all ranks) value of nq partial arrays -> d_out[0..nq) on every rank; folds ranks in rank order
-int32_t reduce_all(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out);
 int32_t vec_check2(kryst_vec_t a, kryst_vec_t b);
 bool use_collectives(kryst_ctx_t ctx);
 

@@ -248,18 +248,20 @@ int32_t kryst_csr_create_i32(kryst_ctx_t ctx, int64_t nrows, int64_t ncols, cons
     return create_local(ctx, nrows, ncols, row_ptr, col_idx, vals, out);
 }
 
-int32_t kryst_csr_create_dist(kryst_ctx_t ctx, int64_t n_global, const int64_t* row_offsets, const int64_t* row_ptr,
-                              const int64_t* col_global, const double* vals, kryst_csr_t* out) {
-    KR_ARG(ctx && row_offsets && row_ptr && out, "csr_create_dist");
+// Phase 1 of kryst_csr_create_dist: everything that involves this rank alone (validation, halo receive plan, local column
+// numbering, upload).  No collective is entered here, so a rank may fail without the others noticing -- the caller agrees on the
+// outcome across ranks before phase 2.
+static int32_t create_dist_local(kryst_csr_t a, int64_t n_global, const int64_t* row_offsets, const int64_t* row_ptr,
+                                 const int64_t* col_global, const double* vals) {
+    kryst_ctx_t ctx = a->ctx;
     const int P = ctx->nranks, me = ctx->rank;
     KR_ARG(row_offsets[0] == 0 && row_offsets[P] == n_global, "row_offsets must cover [0, n_global)");
     const int64_t lo = row_offsets[me], hi = row_offsets[me + 1], nloc = hi - lo;
+    KR_ARG(nloc >= 0, "row_offsets must be non-decreasing");
     const int64_t nnz = row_ptr[nloc];
     KR_ARG(nloc < (1ll << 31) - KR_TILE && nnz < (1ll << 31) - 16, "local block exceeds int32 device indexing");
     KR_TRY(check_csr(nloc, n_global, row_ptr, col_global));
-    KR_HIP(hipSetDevice(ctx->device));
-    kryst_csr_t a = new kryst_csr_s();
-    a->ctx = ctx; a->nrows = nloc; a->ncols = n_global; a->xlen = nloc; a->nnz = nnz; a->dist = true;
+    a->nrows = nloc; a->ncols = n_global; a->xlen = nloc; a->nnz = nnz; a->dist = true;
     a->row_offsets.assign(row_offsets, row_offsets + P + 1);
     HaloPlan& pl = a->plan;
     halo_recv_plan(me, P, row_offsets, nloc, row_ptr, col_global, &pl);
@@ -275,8 +277,7 @@ int32_t kryst_csr_create_dist(kryst_ctx_t ctx, int64_t n_global, const int64_t* 
             if (c >= lo && c < hi) c32[k] = (int32_t)(c - lo);
             else { c32[k] = (int32_t)(nloc + halo_slot(pl, row_offsets, c)); tile_bnd[i / KR_TILE] = 1; }
         }
-    int32_t rc = upload_csr(a, rp32, c32, vals);
-    if (rc != KRYST_OK) { kryst_csr_destroy(a); return rc; }
+    KR_TRY(upload_csr(a, rp32, c32, vals));
     std::vector<int32_t> ti, tb;
     for (int64_t q = 0; q < ntiles; ++q) (tile_bnd[q] ? tb : ti).push_back((int32_t)q);
     a->n_interior = (int64_t)ti.size(); a->n_boundary = (int64_t)tb.size();
@@ -284,49 +285,103 @@ int32_t kryst_csr_create_dist(kryst_ctx_t ctx, int64_t n_global, const int64_t* 
     KR_HIP(hipMalloc(&a->d_tiles_boundary, sizeof(int32_t) * (tb.size() + 1)));
     if (!ti.empty()) KR_HIP(hipMemcpy(a->d_tiles_interior, ti.data(), sizeof(int32_t) * ti.size(), hipMemcpyHostToDevice));
     if (!tb.empty()) KR_HIP(hipMemcpy(a->d_tiles_boundary, tb.data(), sizeof(int32_t) * tb.size(), hipMemcpyHostToDevice));
-    // ---- send side: every owner learns which of its rows the others need (one exchange of index lists)
-    pl.send_counts.assign(P, 0); pl.send_off.assign(P, 0);
-    if (P > 1) {
-        int64_t *d_cnt_s = nullptr, *d_cnt_r = nullptr;
-        KR_HIP(hipMalloc(&d_cnt_s, sizeof(int64_t) * P));
-        KR_HIP(hipMalloc(&d_cnt_r, sizeof(int64_t) * (size_t)P * P));
-        KR_HIP(hipMemcpy(d_cnt_s, pl.recv_counts.data(), sizeof(int64_t) * P, hipMemcpyHostToDevice));
-        KR_TRY(comm_all_gather_i64(ctx, d_cnt_s, d_cnt_r, P, ctx->s_main));
-        std::vector<int64_t> cnt((size_t)P * P);
-        KR_HIP(hipMemcpyAsync(cnt.data(), d_cnt_r, sizeof(int64_t) * cnt.size(), hipMemcpyDeviceToHost, ctx->s_main));
-        KR_HIP(hipStreamSynchronize(ctx->s_main));
-        for (int p = 0; p < P; ++p) pl.send_counts[p] = cnt[(size_t)p * P + me];   // what p receives from me
-        pl.total_send = 0;
-        for (int p = 0; p < P; ++p) { pl.send_off[p] = pl.total_send; pl.total_send += pl.send_counts[p]; }
-        int64_t *d_req = nullptr, *d_ans = nullptr;
-        KR_HIP(hipMalloc(&d_req, sizeof(int64_t) * (size_t)(pl.total_recv + 1)));
-        KR_HIP(hipMalloc(&d_ans, sizeof(int64_t) * (size_t)(pl.total_send + 1)));
-        if (pl.total_recv) KR_HIP(hipMemcpy(d_req, pl.recv_cols.data(), sizeof(int64_t) * pl.total_recv, hipMemcpyHostToDevice));
-        KR_TRY(comm_exchange(ctx, d_req, pl.recv_counts.data(), pl.recv_off.data(), d_ans, pl.send_counts.data(),
-                             pl.send_off.data(), false, ctx->s_main));
-        std::vector<int64_t> ans((size_t)pl.total_send);
-        if (pl.total_send) KR_HIP(hipMemcpyAsync(ans.data(), d_ans, sizeof(int64_t) * pl.total_send, hipMemcpyDeviceToHost, ctx->s_main));
-        KR_HIP(hipStreamSynchronize(ctx->s_main));
-        (void)hipFree(d_cnt_s); (void)hipFree(d_cnt_r); (void)hipFree(d_req); (void)hipFree(d_ans);
-        std::vector<int32_t> sidx((size_t)pl.total_send);
-        bool contig = true;
-        for (int p = 0; p < P; ++p)
-            for (int64_t k = 0; k < pl.send_counts[p]; ++k) {
-                const int64_t g = ans[pl.send_off[p] + k];
-                if (g < lo || g >= hi) { set_error("halo request for a row this rank does not own"); kryst_csr_destroy(a); return KRYST_ERR_ARG; }
-                sidx[pl.send_off[p] + k] = (int32_t)(g - lo);
-                if (k > 0 && g != ans[pl.send_off[p] + k - 1] + 1) contig = false;
-            }
-        a->send_contiguous = contig;
-        if (contig)      // send_off then holds the first local row of each run (used as the offset into x)
-            for (int p = 0; p < P; ++p) if (pl.send_counts[p]) pl.send_off[p] = sidx[pl.send_off[p]];
-        KR_HIP(hipMalloc(&pl.d_send_idx, sizeof(int32_t) * (sidx.size() + 1)));
-        if (!sidx.empty()) KR_HIP(hipMemcpy(pl.d_send_idx, sidx.data(), sizeof(int32_t) * sidx.size(), hipMemcpyHostToDevice));
-        KR_HIP(hipMalloc(&pl.d_sendbuf, sizeof(double) * (size_t)(pl.total_send + 1)));
-    }
     KR_HIP(hipMalloc(&pl.d_halo, sizeof(double) * (size_t)(pl.total_recv + 2)));
     KR_HIP(hipMemsetAsync(pl.d_halo, 0, sizeof(double) * (size_t)(pl.total_recv + 2), ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
+    return KRYST_OK;
+}
+
+// device scratch of the index-list exchange, freed on every path
+struct DistScratch {
+    int64_t *cnt_s = nullptr, *cnt_r = nullptr, *req = nullptr, *ans = nullptr;
+    ~DistScratch() { (void)hipFree(cnt_s); (void)hipFree(cnt_r); (void)hipFree(req); (void)hipFree(ans); }
+};
+
+// Phase 2: every owner learns which of its rows the others need (one all-gather of counts, one exchange of index lists).
+// All ranks enter it together (the caller has agreed that phase 1 succeeded everywhere).
+static int32_t create_dist_exchange(kryst_csr_t a) {
+    kryst_ctx_t ctx = a->ctx;
+    const int P = ctx->nranks, me = ctx->rank;
+    HaloPlan& pl = a->plan;
+    const int64_t lo = a->row_offsets[me], hi = a->row_offsets[me + 1];
+    pl.send_counts.assign(P, 0); pl.send_off.assign(P, 0);
+    if (P == 1) return KRYST_OK;
+    DistScratch d;
+    KR_HIP(hipMalloc(&d.cnt_s, sizeof(int64_t) * P));
+    KR_HIP(hipMalloc(&d.cnt_r, sizeof(int64_t) * (size_t)P * P));
+    KR_HIP(hipMemcpy(d.cnt_s, pl.recv_counts.data(), sizeof(int64_t) * P, hipMemcpyHostToDevice));
+    KR_TRY(comm_all_gather_i64(ctx, d.cnt_s, d.cnt_r, P, ctx->s_main));
+    std::vector<int64_t> cnt((size_t)P * P);
+    KR_HIP(hipMemcpyAsync(cnt.data(), d.cnt_r, sizeof(int64_t) * cnt.size(), hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    for (int p = 0; p < P; ++p) pl.send_counts[p] = cnt[(size_t)p * P + me];   // what p receives from me
+    pl.total_send = 0;
+    for (int p = 0; p < P; ++p) { pl.send_off[p] = pl.total_send; pl.total_send += pl.send_counts[p]; }
+    KR_HIP(hipMalloc(&d.req, sizeof(int64_t) * (size_t)(pl.total_recv + 1)));
+    KR_HIP(hipMalloc(&d.ans, sizeof(int64_t) * (size_t)(pl.total_send + 1)));
+    if (pl.total_recv) KR_HIP(hipMemcpy(d.req, pl.recv_cols.data(), sizeof(int64_t) * pl.total_recv, hipMemcpyHostToDevice));
+    KR_TRY(comm_exchange(ctx, d.req, pl.recv_counts.data(), pl.recv_off.data(), d.ans, pl.send_counts.data(),
+                         pl.send_off.data(), false, ctx->s_main));
+    std::vector<int64_t> ans((size_t)pl.total_send);
+    if (pl.total_send) KR_HIP(hipMemcpyAsync(ans.data(), d.ans, sizeof(int64_t) * pl.total_send, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    std::vector<int32_t> sidx((size_t)pl.total_send);
+    bool contig = true;
+    for (int p = 0; p < P; ++p)
+        for (int64_t k = 0; k < pl.send_counts[p]; ++k) {
+            const int64_t g = ans[pl.send_off[p] + k];
+            KR_ARG(g >= lo && g < hi, "halo request for a row this rank does not own");
+            sidx[pl.send_off[p] + k] = (int32_t)(g - lo);
+            if (k > 0 && g != ans[pl.send_off[p] + k - 1] + 1) contig = false;
+        }
+    a->send_contiguous = contig;
+    if (contig)      // send_off then holds the first local row of each run (used as the offset into x)
+        for (int p = 0; p < P; ++p) if (pl.send_counts[p]) pl.send_off[p] = sidx[pl.send_off[p]];
+    KR_HIP(hipMalloc(&pl.d_send_idx, sizeof(int32_t) * (sidx.size() + 1)));
+    if (!sidx.empty()) KR_HIP(hipMemcpy(pl.d_send_idx, sidx.data(), sizeof(int32_t) * sidx.size(), hipMemcpyHostToDevice));
+    KR_HIP(hipMalloc(&pl.d_sendbuf, sizeof(double) * (size_t)(pl.total_send + 1)));
+    return KRYST_OK;
+}
+
+// All ranks learn whether any of them failed so far (one all-gather of the status words): 0 if none did, else this rank's own
+// code, or KRYST_ERR_ARG with a message naming the first failed rank.
+static int32_t agree_on_status(kryst_ctx_t ctx, int32_t rc_mine) {
+    const int P = ctx->nranks;
+    if (P == 1) return rc_mine;
+    int64_t *d_s = nullptr, *d_r = nullptr;
+    std::vector<int64_t> all((size_t)P, 0);
+    const int64_t mine = rc_mine;
+    int32_t rc = KRYST_OK;
+    if (hipMalloc(&d_s, sizeof(int64_t)) != hipSuccess || hipMalloc(&d_r, sizeof(int64_t) * P) != hipSuccess) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK && hipMemcpy(d_s, &mine, sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK) rc = comm_all_gather_i64(ctx, d_s, d_r, 1, ctx->s_main);
+    if (rc == KRYST_OK && (hipMemcpyAsync(all.data(), d_r, sizeof(int64_t) * P, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess ||
+                           hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
+    (void)hipFree(d_s); (void)hipFree(d_r);
+    if (rc != KRYST_OK) return rc_mine != KRYST_OK ? rc_mine : rc;
+    if (rc_mine != KRYST_OK) return rc_mine;
+    for (int p = 0; p < P; ++p)
+        if (all[p] != KRYST_OK) { set_error("csr_create_dist failed on rank %d (status %lld)", p, (long long)all[p]); return KRYST_ERR_ARG; }
+    return KRYST_OK;
+}
+
+int32_t kryst_csr_create_dist(kryst_ctx_t ctx, int64_t n_global, const int64_t* row_offsets, const int64_t* row_ptr,
+                              const int64_t* col_global, const double* vals, kryst_csr_t* out) {
+    // collective over the context's ranks: a rank whose arguments are bad must still take part in the status agreement
+    // below, or the others would wait for it inside the index-list exchange forever
+    KR_ARG(ctx && out, "csr_create_dist");
+    kryst_csr_t a = nullptr;
+    int32_t rc = KRYST_OK;
+    if (!(row_offsets && row_ptr)) { set_error("bad argument: csr_create_dist"); rc = KRYST_ERR_ARG; }
+    if (rc == KRYST_OK && hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); rc = KRYST_ERR_HIP; }
+    if (rc == KRYST_OK) {
+        a = new kryst_csr_s();
+        a->ctx = ctx;
+        rc = create_dist_local(a, n_global, row_offsets, row_ptr, col_global, vals);
+    }
+    rc = agree_on_status(ctx, rc);
+    if (rc == KRYST_OK) rc = agree_on_status(ctx, create_dist_exchange(a));
+    if (rc != KRYST_OK) { if (a) kryst_csr_destroy(a); return rc; }
     *out = a;
     return KRYST_OK;
 }

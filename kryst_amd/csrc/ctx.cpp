@@ -13,6 +13,16 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 }  // namespace kr
+namespace kr {
+void phase_mark_slow(kryst_ctx_t ctx, int phase) {
+    PhaseTimer* T = ctx->phase;
+    hipEvent_t e = nullptr;
+    if (!T->pool.empty()) { e = T->pool.back(); T->pool.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipEventRecord(e, ctx->s_main) != hipSuccess) { (void)hipGetLastError(); T->pool.push_back(e); return; }
+    T->marks.emplace_back(phase, e);
+}
+}  // namespace kr
 using namespace kr;
 
 static int32_t ctx_init(kryst_ctx_t ctx) {
@@ -63,7 +73,7 @@ int32_t kryst_ctx_create(int32_t device_id, kryst_ctx_t* out) {
     kryst_ctx_t ctx = new kryst_ctx_s();
     ctx->device = device_id;
     int32_t rc = ctx_init(ctx);
-    if (rc != KRYST_OK) { delete ctx; return rc; }
+    if (rc != KRYST_OK) { kryst_ctx_destroy(ctx); return rc; }
     *out = ctx;
     return KRYST_OK;
 }
@@ -79,7 +89,7 @@ int32_t kryst_ctx_create_dist(int32_t device_id, int32_t rank, int32_t nranks, c
     ctx->device = device_id; ctx->rank = rank; ctx->nranks = nranks;
     int32_t rc = ctx_init(ctx);
     if (rc == KRYST_OK) rc = comm_init(ctx, uid);
-    if (rc != KRYST_OK) { delete ctx; return rc; }
+    if (rc != KRYST_OK) { kryst_ctx_destroy(ctx); return rc; }      // frees whatever ctx_init / comm_init got as far as creating
     *out = ctx;
     return KRYST_OK;
 }
@@ -87,15 +97,17 @@ int32_t kryst_ctx_create_dist(int32_t device_id, int32_t rank, int32_t nranks, c
 int32_t kryst_ctx_destroy(kryst_ctx_t ctx) {
     if (!ctx) return KRYST_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->s_main);
-    (void)hipStreamSynchronize(ctx->s_comm);
+    if (ctx->s_main) (void)hipStreamSynchronize(ctx->s_main);
+    if (ctx->s_comm) (void)hipStreamSynchronize(ctx->s_comm);
     comm_destroy(ctx);
+    if (ctx->phase) { for (auto& m : ctx->phase->marks) (void)hipEventDestroy(m.second); for (auto& e : ctx->phase->pool) (void)hipEventDestroy(e); delete ctx->phase; }
     (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_chunks); (void)hipFree(ctx->d_ticket); (void)hipFree(ctx->d_scal); (void)hipFree(ctx->d_gather); (void)hipFree(ctx->arena);
     (void)hipHostFree((void*)ctx->h_prog); (void)hipHostFree(ctx->h_pinned);
-    (void)hipEventDestroy(ctx->ev_x_ready); (void)hipEventDestroy(ctx->ev_halo_done);
-    (void)hipEventDestroy(ctx->tm0); (void)hipEventDestroy(ctx->tm1);
-    for (auto& e : ctx->ev_ring) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(ctx->s_main); (void)hipStreamDestroy(ctx->s_comm);
+    for (hipEvent_t e : {ctx->ev_x_ready, ctx->ev_halo_done, ctx->tm0, ctx->tm1}) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->ev_ring) if (e) (void)hipEventDestroy(e);
+    if (ctx->s_main) (void)hipStreamDestroy(ctx->s_main);
+    if (ctx->s_comm) (void)hipStreamDestroy(ctx->s_comm);
+    (void)hipGetLastError();
     delete ctx;
     return KRYST_OK;
 }
@@ -135,6 +147,44 @@ int32_t kryst_comm_barrier(kryst_ctx_t ctx) {
     KR_TRY(kryst_ctx_synchronize(ctx));
     double dummy;
     return kryst_comm_all_reduce(ctx, 0.0, &dummy);
+}
+
+int32_t kryst_phase_timing_begin(kryst_ctx_t ctx) {
+    KR_ARG(ctx, "ctx");
+    KR_HIP(hipSetDevice(ctx->device));
+    if (!ctx->phase) ctx->phase = new PhaseTimer();
+    for (auto& m : ctx->phase->marks) ctx->phase->pool.push_back(m.second);
+    ctx->phase->marks.clear();
+    phase_mark_slow(ctx, -1);
+    return KRYST_OK;
+}
+
+int32_t kryst_phase_timing_end(kryst_ctx_t ctx, double* ms, int32_t count) {
+    KR_ARG(ctx && ms && count >= KR_PH_COUNT, "phase_timing_end: need room for every phase");
+    KR_ARG(ctx->phase, "phase_timing_end without phase_timing_begin");
+    KR_HIP(hipSetDevice(ctx->device));
+    KR_HIP(hipStreamSynchronize(ctx->s_comm));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    for (int i = 0; i < count; ++i) ms[i] = 0.0;
+    PhaseTimer* T = ctx->phase;
+    for (size_t k = 1; k < T->marks.size(); ++k) {
+        float f = 0.f;
+        if (hipEventElapsedTime(&f, T->marks[k - 1].second, T->marks[k].second) != hipSuccess) { (void)hipGetLastError(); continue; }
+        const int ph = T->marks[k].first;
+        if (ph >= 0 && ph < KR_PH_COUNT) ms[ph] += (double)f;
+    }
+    for (auto& m : T->marks) (void)hipEventDestroy(m.second);
+    for (auto& e : T->pool) (void)hipEventDestroy(e);
+    delete T;
+    ctx->phase = nullptr;
+    return KRYST_OK;
+}
+
+int32_t kryst_phase_count(void) { return KR_PH_COUNT; }
+
+const char* kryst_phase_name(int32_t phase) {
+    static const char* names[KR_PH_COUNT] = {"spmv", "halo_wait", "spmv_boundary", "reduce", "blas1", "pc"};
+    return (phase >= 0 && phase < KR_PH_COUNT) ? names[phase] : "";
 }
 
 int32_t kryst_ctx_timer_start(kryst_ctx_t ctx) {

@@ -108,6 +108,7 @@ inline int32_t launch_ew_gated(kryst_ctx_t ctx, const Op& op, int64_t n, const G
     hipLaunchKernelGGL((ew_kernel<Op, Gate>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, gate, n, ntiles,
                        ctx->d_partials, ctx->partials_cap);
     KR_HIP(hipGetLastError());
+    phase_mark(ctx, KR_PH_BLAS1);
     return KRYST_OK;
 }
 

@@ -89,6 +89,10 @@ struct IluData {
     double* d_rL = nullptr; double* d_y = nullptr; double* d_yU = nullptr; double* d_zU = nullptr;   // level-permuted work vectors
     int32_t* d_mapLU = nullptr;     // L-position of the row at U-position q
     int32_t* d_flags = nullptr;     // wavefront solve: "this block is under way", one per block and direction
+    int32_t* h_gave_up = nullptr;   // mapped host word the wavefront kernel raises when a poller runs out of patience (never cleared on the device)
+    int32_t* d_gave_up = nullptr;   // its device address
+    bool safe = false;              // the wavefront kernel gave up once: this preconditioner now uses the plane kernels (no inter-workgroup waits)
+    bool fell_back = false;         // ... and the switch happened since the last pc_fell_back() query
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     int64_t n = 0;
 };
@@ -334,6 +338,36 @@ __global__ __launch_bounds__(256) void tri_fill_kernel(const TriArgs* args, doub
     if (p < n) dst[p] = __longlong_as_double((long long)KR_TRI_SENTINEL);
 }
 
+// Structured-grid factor, one launch per hyperplane i + j + k = level (schedule coordinates; mirrored for the backward solve):
+// no workgroup waits for another, so it needs no assumption about dispatch order.  ~4 us per level: the fallback of the
+// wavefront kernel (tri_wave.h), never the default.  Same subtraction order, same bits.
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void tri_plane_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, GridView G, int level) {
+    if (args->skip) return;
+    const double* in = in_ptr ? in_ptr : args->r;
+    double* out = out_ptr ? out_ptr : args->z;
+    const int jk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (jk >= G.Nj * G.Nk) return;
+    const int jj = jk % G.Nj, kk = jk / G.Nj, ii = level - jj - kk;
+    if (ii < 0 || ii >= G.Ni) return;
+    const int i = FORWARD ? ii : G.Ni - 1 - ii, j = FORWARD ? jj : G.Nj - 1 - jj, k = FORWARD ? kk : G.Nk - 1 - kk;
+    const int64_t s1 = G.Ni, s2 = (int64_t)G.Ni * G.Nj;
+    const int64_t row = i + s1 * j + s2 * k;
+    const double a1 = G.c1[row], a2 = G.c2[row], a3 = G.c3[row];      // 0.0 = no such entry
+    double s = in[row];
+    if (FORWARD) {                                                     // stored order: k-, j-, i-neighbour (ascending column)
+        if (a3 != 0.0) s = s - a3 * out[row - s2];
+        if (a2 != 0.0) s = s - a2 * out[row - s1];
+        if (a1 != 0.0) s = s - a1 * out[row - 1];
+    } else {
+        if (a1 != 0.0) s = s - a1 * out[row + 1];
+        if (a2 != 0.0) s = s - a2 * out[row + s1];
+        if (a3 != 0.0) s = s - a3 * out[row + s2];
+        s = s / G.diag[row];
+    }
+    out[row] = s;
+}
+
 // a run of consecutive NARROW levels [l0, l1) in one workgroup (CSR fallback for factors that do not fit the ELL form)
 template <bool FORWARD>
 __global__ __launch_bounds__(1024) void tri_run_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
@@ -412,12 +446,24 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
         const GridFactor& A = D->GL; const GridFactor& B = D->GU;
         const unsigned nb = (unsigned)(((A.Nj + 7) / 8) * ((A.Nk + 7) / 8));
         const int wave_on = env_int("KRYST_ILU_WAVE", 1);      // 0: the one-wave predecessor of tri_wave_kernel
+        const GridView VA{A.Ni, A.Nj, A.Nk, A.d_c1, A.d_c2, A.d_c3, nullptr}, VB{B.Ni, B.Nj, B.Nk, B.d_c1, B.d_c2, B.d_c3, B.d_diag};
+        if (D->safe || env_int("KRYST_ILU_PLANES", 0)) {
+            // the wavefront kernel gave up once on this preconditioner (or the caller asks for it): one launch per hyperplane
+            const int nlev = A.Ni + A.Nj + A.Nk - 2;
+            const unsigned pg = (unsigned)(((int64_t)A.Nj * A.Nk + 255) / 256);
+            for (int lv = 0; lv < nlev; ++lv)
+                hipLaunchKernelGGL((tri_plane_kernel<true>), dim3(pg), dim3(256), 0, s, D->d_args, (const double*)nullptr, D->d_y, VA, lv);
+            for (int lv = 0; lv < nlev; ++lv)
+                hipLaunchKernelGGL((tri_plane_kernel<false>), dim3(pg), dim3(256), 0, s, D->d_args, (const double*)D->d_y, (double*)nullptr, VB, lv);
+            KR_HIP(hipGetLastError());
+            return KRYST_OK;
+        }
         if (wave_on > 0 && A.Ni >= 2) {
-            const GridView VA{A.Ni, A.Nj, A.Nk, A.d_c1, A.d_c2, A.d_c3, nullptr}, VB{B.Ni, B.Nj, B.Nk, B.d_c1, B.d_c2, B.d_c3, B.d_diag};
+            const int budget = std::max(1, env_int("KRYST_ILU_POLL_BUDGET", 1 << 22));   // (tests force the give-up path with a tiny budget)
             hipLaunchKernelGGL((tri_wave_fill_kernel<true>), dim3(nb), dim3(256), 0, s, D->d_args, D->d_y, VA, D->d_flags, (int32_t)(2 * nb + 1));
-            hipLaunchKernelGGL((tri_wave_kernel<true>), dim3(nb), dim3(192), 0, s, D->d_args, (const double*)nullptr, D->d_y, VA, D->n, D->d_flags, D->d_flags + 2 * nb);
+            hipLaunchKernelGGL((tri_wave_kernel<true>), dim3(nb), dim3(192), 0, s, D->d_args, (const double*)nullptr, D->d_y, VA, D->n, D->d_flags, D->d_flags + 2 * nb, D->d_gave_up, budget);
             hipLaunchKernelGGL((tri_wave_fill_kernel<false>), dim3(nb), dim3(256), 0, s, D->d_args, (double*)nullptr, VB, (int32_t*)nullptr, 0);
-            hipLaunchKernelGGL((tri_wave_kernel<false>), dim3(nb), dim3(192), 0, s, D->d_args, (const double*)D->d_y, (double*)nullptr, VB, D->n, D->d_flags + nb, D->d_flags + 2 * nb);
+            hipLaunchKernelGGL((tri_wave_kernel<false>), dim3(nb), dim3(192), 0, s, D->d_args, (const double*)D->d_y, (double*)nullptr, VB, D->n, D->d_flags + nb, D->d_flags + 2 * nb, D->d_gave_up, budget);
             KR_HIP(hipGetLastError());
             return KRYST_OK;
         }
@@ -470,9 +516,34 @@ int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done
     return enqueue_apply(ctx->s_main, D);                             // eager fallback (same kernels)
 }
 
+// After a stream synchronisation: has the wavefront solve given up during an apply since the last check?  If so the
+// preconditioner switches to the plane kernels for good (the captured graph is dropped) and the caller must repeat the work.
+int32_t ilu_health(kryst_pc_t pc) {
+    IluData* D = reinterpret_cast<IluData*>(pc->d_work);
+    if (!D || !D->h_gave_up || *(volatile int32_t*)D->h_gave_up == 0) return KRYST_OK;
+    *(volatile int32_t*)D->h_gave_up = 0;
+    D->safe = true; D->fell_back = true;
+    if (D->exec) { (void)hipGraphExecDestroy(D->exec); D->exec = nullptr; }
+    if (D->graph) { (void)hipGraphDestroy(D->graph); D->graph = nullptr; }
+    set_error("ILU apply: the wavefront triangular solve gave up waiting for a neighbour block (workgroups not dispatched in index "
+              "order?); its result was discarded and this preconditioner now uses the level-per-launch plane kernels");
+    return KRYST_SOLVE_ERROR;
+}
+bool ilu_fell_back(kryst_pc_t pc) {
+    IluData* D = reinterpret_cast<IluData*>(pc->d_work);
+    if (!D || !D->fell_back) return false;
+    D->fell_back = false;
+    return true;
+}
+bool ilu_is_wavefront(kryst_pc_t pc) {
+    IluData* D = reinterpret_cast<IluData*>(pc->d_work);
+    return D && D->GL.ok && D->GU.ok && !D->safe;
+}
+
 void ilu_free(kryst_pc_t pc) {
     if (pc->kind != KR_PC_ILU || !pc->d_work) return;
     IluData* D = reinterpret_cast<IluData*>(pc->d_work);
+    if (D->h_gave_up) (void)hipHostFree(D->h_gave_up);
     if (D->exec) (void)hipGraphExecDestroy(D->exec);
     if (D->graph) (void)hipGraphDestroy(D->graph);
     D->L.free_all(); D->U.free_all(); D->GL.free_all(); D->GU.free_all(); (void)hipFree(D->d_args); (void)hipFree(D->d_flags); (void)hipFree(D->d_y); (void)hipFree(D->d_rL); (void)hipFree(D->d_yU); (void)hipFree(D->d_zU); (void)hipFree(D->d_mapLU);
@@ -652,6 +723,9 @@ static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRow
     if (rc == KRYST_OK && D->GL.ok && D->GU.ok) {
         const size_t nb = (size_t)((D->GL.Nj + 7) / 8) * (size_t)((D->GL.Nk + 7) / 8);
         if (hipMalloc(&D->d_flags, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (rc == KRYST_OK && (hipHostMalloc((void**)&D->h_gave_up, 64, hipHostMallocMapped) != hipSuccess ||
+                               hipHostGetDevicePointer((void**)&D->d_gave_up, D->h_gave_up, 0) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (rc == KRYST_OK) *D->h_gave_up = 0;
     }
     if (getenv("KRYST_ILU_VERBOSE"))
         fprintf(stderr, "[kryst ilu] n=%lld %s; levels L/U=%zu/%zu\n", (long long)n, D->GL.ok ? "structured grid (wavefront kernel)" : "level-ordered",

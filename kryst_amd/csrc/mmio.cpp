@@ -8,6 +8,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cctype>
+#include <exception>
 #include <fstream>
 #include <sstream>
 
@@ -54,8 +55,8 @@ bool parse(const char* path, int64_t& nr, int64_t& nc, std::vector<Entry>& e) {
 }
 }  // namespace
 
-extern "C" int64_t kryst_host_read_matrix_market(const char* path, int64_t* nrows, int64_t* ncols, int64_t* row_ptr,
-                                                 int64_t* col_idx, double* vals) {
+static int64_t read_matrix_market_impl(const char* path, int64_t* nrows, int64_t* ncols, int64_t* row_ptr,
+                                       int64_t* col_idx, double* vals) {
     if (!path || !nrows || !ncols) { kr::set_error("bad argument: read_matrix_market"); return -1; }
     std::vector<Entry> e;
     int64_t nr = 0, nc = 0;
@@ -94,8 +95,8 @@ bool read_be64f(std::ifstream& f, double* out, size_t count) {
 }
 }  // namespace
 
-extern "C" int64_t kryst_host_read_petsc_binary(const char* path, int64_t* nrows, int64_t* ncols, int64_t* row_ptr,
-                                                int64_t* col_idx, double* vals) {
+static int64_t read_petsc_binary_impl(const char* path, int64_t* nrows, int64_t* ncols, int64_t* row_ptr,
+                                      int64_t* col_idx, double* vals) {
     if (!path || !nrows || !ncols) { kr::set_error("bad argument: read_petsc_binary"); return -1; }
     std::ifstream f(path, std::ios::binary);
     if (!f) { kr::set_error("petsc binary: cannot open %s", path); return -1; }
@@ -121,4 +122,24 @@ extern "C" int64_t kryst_host_read_petsc_binary(const char* path, int64_t* nrows
         col_idx[k] = col[(size_t)k];
     }
     return nz;
+}
+
+
+// Nothing unwinds across the C ABI: a file whose header promises more entries than memory holds (std::bad_alloc,
+// std::length_error from the reserve) or any other C++ exception becomes -1 with a message.
+template <class F>
+static int64_t no_throw(const char* what, F f) {
+    try { return f(); }
+    catch (const std::exception& e) { kr::set_error("%s: %s", what, e.what()); return -1; }
+    catch (...) { kr::set_error("%s: unknown C++ exception", what); return -1; }
+}
+
+extern "C" int64_t kryst_host_read_matrix_market(const char* path, int64_t* nrows, int64_t* ncols, int64_t* row_ptr,
+                                                 int64_t* col_idx, double* vals) {
+    return no_throw("matrix market reader", [&] { return read_matrix_market_impl(path, nrows, ncols, row_ptr, col_idx, vals); });
+}
+
+extern "C" int64_t kryst_host_read_petsc_binary(const char* path, int64_t* nrows, int64_t* ncols, int64_t* row_ptr,
+                                                int64_t* col_idx, double* vals) {
+    return no_throw("petsc binary reader", [&] { return read_petsc_binary_impl(path, nrows, ncols, row_ptr, col_idx, vals); });
 }

@@ -27,6 +27,11 @@ struct kryst_pc_s {
 namespace kr {
 // z <- M^-1 r on ctx->s_main (device pointers, padded vectors).  `done`: device flag that turns kernels into no-ops.
 int32_t pc_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done);
+// Call after the stream has been synchronised: KRYST_OK, or KRYST_SOLVE_ERROR when an apply since the last check was abandoned
+// by the device (the ILU wavefront solve's give-up path, tri_wave.h); the preconditioner has then switched itself to kernels
+// that cannot stall, pc_fell_back() reports that switch once, and the caller repeats the work.
+int32_t pc_health(kryst_pc_t pc);
+bool pc_fell_back(kryst_pc_t pc);
 int32_t chebyshev_dev(kryst_csr_t a, const double* r, double* z, double alpha, double beta, int64_t m,
                       double* v0, double* v1, double* v2, const int* done);
 }

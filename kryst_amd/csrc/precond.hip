@@ -111,8 +111,13 @@ int32_t chebyshev_dev(kryst_csr_t a, const double* r, double* z, double alpha, d
 
 int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done);   // ilu.hip
 void    ilu_free(kryst_pc_t pc);
+int32_t ilu_health(kryst_pc_t pc);
+bool    ilu_fell_back(kryst_pc_t pc);
+bool    ilu_is_wavefront(kryst_pc_t pc);
+int32_t pc_health(kryst_pc_t pc) { return (pc && pc->kind == KR_PC_ILU && pc->d_work) ? ilu_health(pc) : KRYST_OK; }
+bool pc_fell_back(kryst_pc_t pc) { return pc && pc->kind == KR_PC_ILU && pc->d_work && ilu_fell_back(pc); }
 
-int32_t pc_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done) {
+static int32_t pc_apply_kind(kryst_pc_t pc, const double* r, double* z, const int* done) {
     kryst_ctx_t ctx = pc->ctx;
     switch (pc->kind) {
         case KR_PC_IDENTITY:
@@ -129,6 +134,11 @@ int32_t pc_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done)
             return launch_spmv(pc->a, r, z, 0, nullptr, done);
         default: set_error("unknown preconditioner kind %d", pc->kind); return KRYST_UNSUPPORTED;
     }
+}
+int32_t pc_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done) {
+    const int32_t rc = pc_apply_kind(pc, r, z, done);
+    phase_mark(pc->ctx, KR_PH_PC);
+    return rc;
 }
 
 }  // namespace kr
@@ -202,7 +212,17 @@ int32_t kryst_pc_apply(kryst_pc_t pc, kryst_vec_t r, kryst_vec_t z) {
         kryst_pc_s tmp = *pc; tmp.n = r->n;
         return pc_apply_dev(&tmp, r->d, z->d, nullptr);
     }
-    return pc_apply_dev(pc, r->d, z->d, nullptr);
+    KR_TRY(pc_apply_dev(pc, r->d, z->d, nullptr));
+    if (pc->kind == KR_PC_ILU && pc->d_work && ilu_is_wavefront(pc)) {
+        // the wavefront solve relies on in-order workgroup dispatch (tri_wave.h): wait, and if it gave up repeat the apply
+        // with the plane kernels (same bits)
+        KR_HIP(hipStreamSynchronize(pc->ctx->s_main));
+        if (pc_health(pc) != KRYST_OK) {
+            (void)pc_fell_back(pc);
+            KR_TRY(pc_apply_dev(pc, r->d, z->d, nullptr));
+        }
+    }
+    return KRYST_OK;
 }
 
 int32_t kryst_pc_approx_inverse(kryst_csr_t m, kryst_pc_t* out) {

@@ -115,6 +115,7 @@ inline int32_t reduce_then(kryst_ctx_t ctx, int64_t ntiles, double* d_red, const
         hipLaunchKernelGGL((rank_fold_logic_kernel<NQ, L>), dim3(1), dim3(64), 0, ctx->s_main, ctx->d_gather, ctx->nranks, d_red, logic);
     }
     KR_HIP(hipGetLastError());
+    phase_mark(ctx, KR_PH_REDUCE);
     return KRYST_OK;
 }
 
@@ -280,6 +281,8 @@ inline int32_t finish_solve(Workspace& ws, const SolveIO& io) {
         if (io.hist && k < io.hist_cap) io.hist[k] = ws.h_hist[k];
     }
     (void)ctx;
+    // a preconditioner apply abandoned by the device (pc.h: pc_health) voids the whole solve, whatever the recurrences made of it
+    if (io.pc && pc_health(io.pc) != KRYST_OK) return KRYST_SOLVE_ERROR;
     return h.status;
 }
 

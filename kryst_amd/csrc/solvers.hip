@@ -557,6 +557,15 @@ static int32_t host_solve(const double* b, double* x, int64_t n, const SolveIO& 
 
 #define IO_FROM_ARGS SolveIO io{a, pc, params, stats, hist, hist_cap, hist_len, monitor, user}
 
+// A solve whose preconditioner had to switch kernels mid-way (pc.h: pc_health) is repeated once from the caller's x: on an
+// error the solvers never touch x, like the reference (monitor callbacks then start over).
+template <class F>
+static int32_t retry_on_pc_fallback(kryst_pc_t pc, F f) {
+    int32_t rc = f();
+    if (rc == KRYST_SOLVE_ERROR && pc_fell_back(pc)) rc = f();
+    return rc;
+}
+
 struct kryst_session_s { SolverRun* run; };
 
 extern "C" {
@@ -595,8 +604,8 @@ int32_t kryst_session_end(kryst_session_t s, kryst_stats_t* stats, double* hist,
 }
 
 int32_t kryst_cg_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return cg_solve(b, x, io); }
-int32_t kryst_pcg_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return pcg_solve(b, x, io); }
-int32_t kryst_gmres_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return gmres_solve(b, x, io); }
+int32_t kryst_pcg_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return retry_on_pc_fallback(pc, [&] { return pcg_solve(b, x, io); }); }
+int32_t kryst_gmres_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return retry_on_pc_fallback(pc, [&] { return gmres_solve(b, x, io); }); }
 int32_t kryst_cgs_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return cgs_solve(b, x, io); }
 int32_t kryst_tfqmr_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return tfqmr_solve(b, x, io); }
 int32_t kryst_cgs_solve(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) {
@@ -606,23 +615,23 @@ int32_t kryst_tfqmr_solve(const double* b, double* x, int64_t n, KRYST_SOLVE_ARG
     IO_FROM_ARGS; return host_solve(b, x, n, io, [](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return tfqmr_solve(bv, xv, i); });
 }
 int32_t kryst_fgmres_solve_dev(kryst_vec_t b, kryst_vec_t x, int32_t orthog, double haptol, int32_t preallocate, KRYST_SOLVE_ARGS) {
-    IO_FROM_ARGS; return fgmres_solve(b, x, io, orthog, haptol, preallocate);
+    IO_FROM_ARGS; return retry_on_pc_fallback(pc, [&] { return fgmres_solve(b, x, io, orthog, haptol, preallocate); });
 }
 int32_t kryst_fgmres_solve(const double* b, double* x, int64_t n, int32_t orthog, double haptol, int32_t preallocate, KRYST_SOLVE_ARGS) {
     IO_FROM_ARGS;
-    return host_solve(b, x, n, io, [=](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return fgmres_solve(bv, xv, i, orthog, haptol, preallocate); });
+    return host_solve(b, x, n, io, [=](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return retry_on_pc_fallback(i.pc, [&] { return fgmres_solve(bv, xv, i, orthog, haptol, preallocate); }); });
 }
 int32_t kryst_bicgstab_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return bicgstab_solve(b, x, io, false); }
-int32_t kryst_bicgstab_rpc_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return bicgstab_solve(b, x, io, true); }
+int32_t kryst_bicgstab_rpc_solve_dev(kryst_vec_t b, kryst_vec_t x, KRYST_SOLVE_ARGS) { IO_FROM_ARGS; return retry_on_pc_fallback(pc, [&] { return bicgstab_solve(b, x, io, true); }); }
 
 int32_t kryst_cg_solve(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) {
     IO_FROM_ARGS; return host_solve(b, x, n, io, [](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return cg_solve(bv, xv, i); });
 }
 int32_t kryst_pcg_solve(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) {
-    IO_FROM_ARGS; return host_solve(b, x, n, io, [](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return pcg_solve(bv, xv, i); });
+    IO_FROM_ARGS; return host_solve(b, x, n, io, [](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return retry_on_pc_fallback(i.pc, [&] { return pcg_solve(bv, xv, i); }); });
 }
 int32_t kryst_gmres_solve(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) {
-    IO_FROM_ARGS; return host_solve(b, x, n, io, [](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return gmres_solve(bv, xv, i); });
+    IO_FROM_ARGS; return host_solve(b, x, n, io, [](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return retry_on_pc_fallback(i.pc, [&] { return gmres_solve(bv, xv, i); }); });
 }
 int32_t kryst_bicgstab_solve(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) {
     IO_FROM_ARGS; return host_solve(b, x, n, io, [](kryst_vec_t bv, kryst_vec_t xv, const SolveIO& i) { return bicgstab_solve(bv, xv, i, false); });

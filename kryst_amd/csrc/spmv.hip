@@ -719,8 +719,11 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
 int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const double* dvec, const int* done) {
     kryst_ctx_t ctx = a->ctx;
     if (nq > 0) KR_TRY(ensure_partials(ctx, a->ntiles));
-    if (!a->dist || !use_collectives(ctx))
-        return launch_tiles<false>(a, x, y, nq, dvec, done, nullptr, a->ntiles);
+    if (!a->dist || !use_collectives(ctx)) {
+        const int32_t rc = launch_tiles<false>(a, x, y, nq, dvec, done, nullptr, a->ntiles);
+        phase_mark(ctx, KR_PH_SPMV);
+        return rc;
+    }
     // halo exchange on s_comm, overlapped with the interior tiles
     HaloPlan& pl = a->plan;
     KR_HIP(hipEventRecord(ctx->ev_x_ready, ctx->s_main));
@@ -739,8 +742,11 @@ int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const dou
                          pl.recv_off.data(), true, ctx->s_comm));
     KR_HIP(hipEventRecord(ctx->ev_halo_done, ctx->s_comm));
     KR_TRY(launch_tiles<false>(a, x, y, nq, dvec, done, a->d_tiles_interior, a->n_interior));   // interior tiles have no halo columns
+    phase_mark(ctx, KR_PH_SPMV);
     KR_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_halo_done, 0));
+    phase_mark(ctx, KR_PH_HALO_WAIT);
     KR_TRY(launch_tiles<true>(a, x, y, nq, dvec, done, a->d_tiles_boundary, a->n_boundary));
+    phase_mark(ctx, KR_PH_SPMV_BOUNDARY);
     return KRYST_OK;
 }
 

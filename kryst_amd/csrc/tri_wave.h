@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void tri_wave_fill_kernel(const TriArgs* args,
 }
 
 template <bool FORWARD>
-__global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, GridView G, int64_t n, int32_t* flags, int32_t* abort_word) {
+__global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, GridView G, int64_t n, int32_t* flags, int32_t* abort_word,
+                                                       int32_t* gave_up, int poll_budget) {
     if (args->skip) return;
     constexpr int C = 8;                                                  // steps per chunk
     constexpr int NA = FORWARD ? 4 : 5;                                   // arrays staged per chunk: rhs, c1, c2, c3 (, divisor)
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
         const int T = nch * C;
         const unsigned long long qmask = 0x1111111111111111ull;           // lanes with q == 0
         int t = 0;
-        for (int budget = 1 << 22; t < T && budget > 0;) {
+        for (int budget = poll_budget; t < T && budget > 0;) {
             const int done_steps = max(tw_lds_load(taken) - 1, 0) * C;    // steps the solving wave no longer needs
             const int lim = min(T, done_steps + R);                       // ring slots free up to here
             if (t >= lim) { __builtin_amdgcn_s_sleep(2); --budget; continue; }
@@ -238,10 +239,14 @@ __global__ __launch_bounds__(192) void tri_wave_kernel(const TriArgs* args, cons
                 const unsigned long long bad = (sidx & 1) ? bad1 : bad0;
                 if (m == sidx && t + sidx < lim && (bad & (qmask << (sidx >> 1))) == 0) m = sidx + 1;
             }
-            // out of patience (a logic error, never seen): hand over the sentinels (NaNs) and tell every block to do the same,
-            // so that the launch ends in seconds with a NaN result instead of occupying the GPU for minutes
+            // out of patience: the rows this block waits for never came.  The pipeline only makes progress if the blocks a resident
+            // block waits for are resident or finished, which holds because the hardware starts workgroups in index order -- an
+            // observed property, not a HIP guarantee.  Should it ever fail (or a logic error stall the front), hand over the
+            // sentinels (NaNs), tell every block to do the same so that the launch ends at once, and raise the host-visible word:
+            // the host then repeats the work with the barrier-free plane kernels (ilu.hip: ilu_health)
             if (m == 0 && (budget == 1 || ((budget & 255) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))) {
                 __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // mapped host word, never cleared by the device: the host reads it at its next sync
                 tw_lds_store(&ctr[3], 1);
                 budget = 1; m = 1;
             }

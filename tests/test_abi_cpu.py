@@ -113,6 +113,10 @@ def test_matrix_market_reader(tmp_path):
         K.read_matrix_market(tmp_path / "arr.mtx")
     with pytest.raises(K.KError):
         K.read_matrix_market(tmp_path / "missing.mtx")
+    # a header that promises more entries than memory holds must come back as an error, not as a C++ exception across the ABI
+    (tmp_path / "huge.mtx").write_text("%%MatrixMarket matrix coordinate real general\n3 3 4611686018427387904\n1 1 1.0\n")
+    with pytest.raises(K.KError):
+        K.read_matrix_market(tmp_path / "huge.mtx")
 
 
 def test_petsc_binary_reader(tmp_path):

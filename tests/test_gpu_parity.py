@@ -376,6 +376,51 @@ def test_structured_grid_solve_random_boxes_and_missing_entries(ctx, seed, monke
                 assert np.array_equal(kpc.setup(d).apply(r), ofn(a).apply(r)), (seed, (Ni, Nj, Nk), wave)
 
 
+def test_wavefront_give_up_path_falls_back_to_plane_kernels(ctx, rs, monkeypatch):
+    """The wavefront triangular solve waits for neighbour blocks and so relies on in-order workgroup dispatch.  With a poll
+    budget of ONE empty poll every block gives up at once (NaN results on the device): the host must notice (mapped give-up
+    word), discard the result and repeat the work with the plane kernels (one launch per hyperplane, no inter-workgroup
+    waits) -- the caller sees the oracle's bits, from pc.apply and from whole solves, and never a NaN."""
+    monkeypatch.setenv("KRYST_ILU_POLL_BUDGET", "1")
+    ao = O.stencil7(24, "aniso")
+    a = to_dev(ctx, ao)
+    r = O.splitmix64_uniform(7, ao.nrows) - 0.5
+    for kpc, ofn in ((K.TrueIlu0(), O.Pc.ilu0_true), (K.Ilu0(), O.Pc.ilu0_compat)):
+        pc = kpc.setup(a); ref = ofn(ao)
+        assert np.array_equal(pc.apply(r), ref.apply(r))          # gives up, repeated with the plane kernels
+        assert np.array_equal(pc.apply(2.0 * r), ref.apply(2.0 * r))   # stays on the plane kernels
+    b = ao.spmv(np.ones(ao.nrows))
+    pc = K.TrueIlu0().setup(a)                                      # a fresh preconditioner: the give-up happens inside the solve
+    res = O.solve("pcg", ao, b, pc=O.Pc.ilu0_true(ao), tol=1e-9, max_iters=200, rs=rs)
+    s = K.PcgSolver(1e-9, 200); x = np.zeros(ao.nrows)
+    st = s.solve(a, pc, b, x)
+    assert st.iterations == res.iterations and np.array_equal(x, res.x)
+    pc = K.Ilu0().setup(a)
+    res = O.solve("gmres", ao, b, pc=O.Pc.ilu0_compat(ao), tol=1e-9, max_iters=100, restart=10, side=O.SIDE_RIGHT, rs=rs)
+    g = K.GmresSolver(10, 1e-9, 100); g.preconditioning = K.Preconditioning.Right; x = np.zeros(ao.nrows)
+    st = g.solve(a, pc, b, x)
+    assert st.iterations == res.iterations and np.array_equal(x, res.x)
+    # a stepping session cannot repeat itself: it reports the abandoned apply as a SolveError
+    pc = K.TrueIlu0().setup(a)
+    sess = K.Session("pcg", a, pc, K.DeviceVec(ctx, b), K.DeviceVec(ctx, np.zeros(ao.nrows)), tol=1e-9, max_iters=50)
+    sess.step(50)
+    with pytest.raises(K.KError) as e:
+        sess.end()
+    assert e.value.code == 2
+
+
+def test_plane_kernels_bit_exact(ctx, monkeypatch):
+    """KRYST_ILU_PLANES=1: the fallback of the wavefront solve on its own, ragged boxes included."""
+    monkeypatch.setenv("KRYST_ILU_PLANES", "1")
+    rng = np.random.default_rng(11)
+    for N, kind in ((9, "poisson"), (17, "convdiff"), (20, "aniso")):
+        ao = O.stencil7(N, kind)
+        a = to_dev(ctx, ao)
+        r = rng.standard_normal(ao.nrows)
+        for kpc, ofn in ((K.TrueIlu0(), O.Pc.ilu0_true), (K.Ilu0(), O.Pc.ilu0_compat), (K.Ilup(0), O.Pc.ilup0)):
+            assert np.array_equal(kpc.setup(a).apply(r), ofn(ao).apply(r)), (N, kind)
+
+
 def test_ilu_apply_twice_reuses_graph(ctx):
     a = O.stencil7(20)
     pc = K.Ilu0().setup(to_dev(ctx, a))
