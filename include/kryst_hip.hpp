@@ -28,14 +28,16 @@ using Vec = std::vector<double>;
 
 struct KError : std::runtime_error {            // src/error.rs:6-19
     enum Kind { FactorError = 1, SolveError = 2, IndefiniteMatrix = 3, IndefinitePreconditioner = 4, ZeroPivot = 5,
-                Unsupported = 6, HipError = 100, RcclError = 101, ArgumentError = 102, CsrError = 103 };
+                Unsupported = 6, HipError = 100, RcclError = 101, ArgumentError = 102, CsrError = 103, ContextBusy = 104 };
     int code;
-    explicit KError(int c) : std::runtime_error(std::string("kryst: ") + kind_name(c) + ": " + kryst_hip_last_error()), code(c) {}
+    long long row;                              // KError::ZeroPivot(row), error.rs:15-16 (-1 for every other kind)
+    explicit KError(int c) : std::runtime_error(std::string("kryst: ") + kind_name(c) + ": " + kryst_hip_last_error()), code(c),
+                             row(c == KRYST_ZERO_PIVOT ? (long long)kryst_hip_last_error_row() : -1) {}
     static const char* kind_name(int c) {
         switch (c) { case 1: return "FactorError"; case 2: return "SolveError"; case 3: return "IndefiniteMatrix";
                      case 4: return "IndefinitePreconditioner"; case 5: return "ZeroPivot"; case 6: return "Unsupported";
                      case 100: return "HipError"; case 101: return "RcclError"; case 102: return "ArgumentError";
-                     case 103: return "CsrError"; default: return "Error"; }
+                     case 103: return "CsrError"; case 104: return "ContextBusy"; default: return "Error"; }
     }
 };
 inline void check(int32_t rc) { if (rc != KRYST_OK) throw KError(rc); }
@@ -187,8 +189,9 @@ public:
     CgNormType norm_type = CgNormType::Unpreconditioned;
     bool single_reduction = false;
     std::optional<double> radius, obj_target;
-    std::function<void(size_t, double)> monitor;
+    std::function<void(size_t, double)> monitor;     // with_monitor (cg.rs:84-88): fired live, in order, on the calling thread
     std::vector<double> residual_history;
+    int check_every = 0;                             // iterations between two rounds of monitor callbacks (0: the library's 8)
     void clear_history() { residual_history.clear(); }
     SolveStats<double> solve(const HipCsrMatrix& a, const Preconditioner<HipCsrMatrix, Vec>* pc, const Vec& b, Vec& x) override {
         if (b.size() != x.size()) throw KError(KRYST_ERR_ARG);
@@ -197,8 +200,10 @@ public:
         p.norm_type = (int)norm_type; p.single_reduction = single_reduction;
         p.has_radius = radius.has_value(); p.radius = radius.value_or(0.0);
         p.has_obj_target = obj_target.has_value(); p.obj_target = obj_target.value_or(0.0);
+        p.check_every = check_every;
         kryst_stats_t st{};
-        std::vector<double> hist((size_t)hist_per_iter_ * conv.max_iters + (size_t)(restart_ > 0 ? restart_ : 1) + 8);
+        std::vector<double> hist(std::min<size_t>((size_t)hist_per_iter_ * conv.max_iters + (size_t)(restart_ > 0 ? restart_ : 1) + 8,
+                                                  ((size_t)1 << 22) + 8));      // the library records at most 2^22 entries
         int64_t len = 0;
         const int32_t rc = call(b.data(), x.data(), (int64_t)b.size(), a.handle(), pc ? pc->device_handle() : nullptr, &p, &st,
                                 hist.data(), (int64_t)hist.size(), &len, monitor ? &SolverBase::trampoline : nullptr, this);
@@ -274,5 +279,64 @@ protected:
     int32_t call(const double* b, double* x, int64_t n, KRYST_SOLVE_ARGS) override { return kryst_tfqmr_solve(b, x, n, KRYST_FWD); }
 };
 #undef KRYST_FWD
+
+// ---- context/: PC<T> (src/context/pc_context.rs:36-76) and KspContext (src/context/ksp_context.rs:25-148) ---------------------
+// PC<T>: the reference's configuration enum for preconditioners, plus the constructor it lacks -- build(a) returns the set-up
+// device preconditioner.  Kinds outside the hot path (Ssor, ApproxInv setup, BlockJacobi, Multicolor, AMG, AdditiveSchwarz)
+// throw KError{Unsupported}.
+struct PC {
+    enum Kind { JacobiKind, SsorKind, Ilu0Kind, IlupKind, IlutKind, ChebyshevKind, ApproxInvKind, BlockJacobiKind, MulticolorKind, AMGKind, AdditiveSchwarzKind };
+    Kind kind; size_t fill = 0; double droptol = 0.0; size_t degree = 0; std::optional<double> emin, emax;
+    static PC Jacobi() { return PC{JacobiKind}; }
+    static PC Ilu0() { return PC{Ilu0Kind}; }
+    static PC Ilup(size_t fill) { PC p{IlupKind}; p.fill = fill; return p; }
+    static PC Ilut(size_t fill, double droptol) { PC p{IlutKind}; p.fill = fill; p.droptol = droptol; return p; }
+    static PC Chebyshev(size_t degree, std::optional<double> emin = std::nullopt, std::optional<double> emax = std::nullopt) {
+        PC p{ChebyshevKind}; p.degree = degree; p.emin = emin; p.emax = emax; return p;
+    }
+    std::unique_ptr<Preconditioner<HipCsrMatrix, Vec>> build(const HipCsrMatrix& a) const {
+        std::unique_ptr<Preconditioner<HipCsrMatrix, Vec>> pc;
+        switch (kind) {
+            case JacobiKind: pc = std::make_unique<kryst::Jacobi>(); break;
+            case Ilu0Kind: pc = std::make_unique<kryst::Ilu0>(); break;
+            case IlupKind: pc = std::make_unique<kryst::Ilup>(fill); break;
+            case IlutKind: pc = std::make_unique<kryst::Ilut>(fill, droptol); break;
+            case ChebyshevKind: pc = std::make_unique<kryst::Chebyshev>(degree, emin, emax); break;     // the trait object: apply is the stub
+            default: throw KError(KRYST_UNSUPPORTED);
+        }
+        pc->setup(a);
+        return pc;
+    }
+};
+
+enum class SolverKind { Cg, Pcg, GmresLeft, GmresRight, Fgmres, Bicgstab, Cgs, Qmr, Tfqmr, Minres, Cgnr };   // ksp_context.rs:25-50
+
+// KspContext { kind, a, pc, flex_pc, tol, max_it, restart } + solve_context (ksp_context.rs:54-148): a fresh solver of `kind` per
+// call, forwarded (a, pc, b, x) exactly as the reference's match does -- FGMRES uses flex_pc, never pc (:101-107); the kinds that
+// need A^T or are outside the accelerated path (Qmr, Minres, Cgnr) throw KError{Unsupported}.  `a` is borrowed (the reference
+// owns an M by value; a device operator is not copyable).
+struct KspContext {
+    SolverKind kind;
+    const HipCsrMatrix& a;
+    std::unique_ptr<Preconditioner<HipCsrMatrix, Vec>> pc;
+    std::unique_ptr<Preconditioner<HipCsrMatrix, Vec>> flex_pc;
+    double tol; size_t max_it; size_t restart;
+    KspContext(SolverKind kind, const HipCsrMatrix& a, std::unique_ptr<Preconditioner<HipCsrMatrix, Vec>> pc, double tol, size_t max_it,
+               size_t restart = 30, std::unique_ptr<Preconditioner<HipCsrMatrix, Vec>> flex_pc = nullptr)
+        : kind(kind), a(a), pc(std::move(pc)), flex_pc(std::move(flex_pc)), tol(tol), max_it(max_it), restart(restart) {}
+    SolveStats<double> solve_context(const Vec& b, Vec& x) {
+        switch (kind) {
+            case SolverKind::GmresLeft: { GmresSolver s(restart, tol, max_it); s.with_preconditioning(Preconditioning::Left); return s.solve(a, pc.get(), b, x); }
+            case SolverKind::GmresRight: { GmresSolver s(restart, tol, max_it); s.with_preconditioning(Preconditioning::Right); return s.solve(a, pc.get(), b, x); }
+            case SolverKind::Fgmres: { FgmresSolver s(tol, max_it, restart); return s.solve_flex(a, flex_pc.get(), b, x); }
+            case SolverKind::Cg: { CgSolver s(tol, max_it); return s.solve(a, pc.get(), b, x); }
+            case SolverKind::Pcg: { PcgSolver s(tol, max_it); return s.solve(a, pc.get(), b, x); }
+            case SolverKind::Bicgstab: { BiCgStabSolver s(tol, max_it); return s.solve(a, pc.get(), b, x); }
+            case SolverKind::Cgs: { CgsSolver s(tol, max_it); return s.solve(a, pc.get(), b, x); }
+            case SolverKind::Tfqmr: { TfqmrSolver s(tol, max_it); return s.solve(a, pc.get(), b, x); }
+            default: throw KError(KRYST_UNSUPPORTED);
+        }
+    }
+};
 
 }  // namespace kryst

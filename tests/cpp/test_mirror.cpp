@@ -191,6 +191,34 @@ int main() {
         REQUIRE(st.converged && its.size() == st.iterations + 1 && its.front() == 0 && its.back() == st.iterations);
         REQUIRE(s.residual_history.size() == its.size());
     }
+    {   // src/context/ksp_context.rs:88-148 (KspContext::solve_context) + pc_context.rs:36-76 (PC<T>) with the constructor it lacks;
+        // tests/preconditioner_integration.rs:126-179: tridiag(10) through the factory, every kind on the accelerated path
+        auto an = tridiag(10, -1.0, 2.0, -1.0);
+        Vec x_true(10, 1.0), bn(10);
+        an.matvec(x_true, bn);
+        for (SolverKind k : {SolverKind::Cg, SolverKind::Pcg, SolverKind::GmresLeft, SolverKind::GmresRight, SolverKind::Bicgstab, SolverKind::Fgmres}) {
+            KspContext ksp(k, an, PC::Jacobi().build(an), k == SolverKind::Bicgstab ? 1e-12 : 1e-10, 200, 10, PC::Jacobi().build(an));
+            Vec x(10, 0.0);
+            auto st = ksp.solve_context(bn, x);
+            REQUIRE(st.converged && rel_error(x, x_true) < 1e-8);
+        }
+        KspContext ilu(SolverKind::GmresLeft, an, PC::Ilut(10, 1e-3).build(an), 1e-10, 200, 10);
+        Vec xi(10, 0.0);
+        REQUIRE(ilu.solve_context(bn, xi).converged && rel_error(xi, x_true) < 1e-8);
+        bool threw = false;
+        try { KspContext q(SolverKind::Qmr, an, nullptr, 1e-8, 10); Vec xq(10, 0.0); q.solve_context(bn, xq); } catch (const KError& e) { threw = e.code == KError::Unsupported; }
+        REQUIRE(threw);
+        threw = false;
+        try { PC{PC::AMGKind}.build(an); } catch (const KError& e) { threw = e.code == KError::Unsupported; }
+        REQUIRE(threw);
+    }
+    {   // KError::ZeroPivot(row) (error.rs:15-16) carries its row; a second solve on a busy context is refused, not corrupted
+        auto z = HipCsrMatrix::from_csr(3, 3, {0, 2, 5, 7}, {0, 1, 0, 1, 2, 1, 2}, {2.0, 1.0, 1.0, 0.5, 1.0, 1.0, 3.0});
+        TrueIlu0 t;
+        bool threw = false;
+        try { t.setup(z); } catch (const KError& e) { threw = e.code == KError::ZeroPivot && e.row == 1; }
+        REQUIRE(threw);
+    }
     std::printf("CPP_MIRROR_OK\n");
     return 0;
 }
