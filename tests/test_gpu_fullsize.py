@@ -147,3 +147,88 @@ def test_512_cubed_properties(ctx, monkeypatch):
         hist.append(list(s.residual_history))
     assert hist[0] == hist[1]
     assert all(hist[0][i + 1] < hist[0][i] for i in range(5))
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs 3 and 5 at full size
+def _true_residual(ctx, a, b, x):
+    """||b - A x|| with the device's own SpMV, subtraction (`bi - ax`, cg.rs:123 / gmres.rs:224) and norm."""
+    ax = a.spmv(x)
+    r = ctx.vec(a.nrows())
+    K.check(K.lib().kryst_sub(b.h, ax.h, r.h))
+    return K.norm(r)
+
+
+def test_config3_gmres30_left_jacobi_convdiff_256(ctx):
+    """BASELINE configs[2]: GmresSolver(30) Left + Jacobi on the 256^3 upwind convection-diffusion operator, tol 1e-8, max 600
+    (src/solver/gmres.rs:216-402).  At this size the oracle cannot be the checker, so: two runs give the same bits; the
+    reported final_residual IS the true residual ||b - A x|| of the returned x (gmres.rs:387-393 recomputes it after the last
+    cycle), recomputed here with the device SpMV; `converged` is exactly `final_residual < tol * res0` (:394); the iteration
+    count is a whole number of cycles or the cap.  (As written, Left-preconditioned GMRES orthogonalises against Z with
+    Z[0] = M^-1 v0 -- DESIGN.md section 2 -- and does not reach 1e-8 on this operator within 600 iterations: the reference's
+    behaviour, reproduced, not a defect of the port; the bit-level check against the oracle is the 64^3 test below.)"""
+    n = N ** 3
+    a = K.CsrMatrix.stencil7(N, "convdiff", ctx=ctx)
+    b = a.spmv(ctx.vec(n).fill(1.0))
+    res0 = K.norm(b)
+    pc = K.Jacobi().setup(a)
+    runs = []
+    for _ in range(2):
+        x = ctx.vec(n)
+        s = K.GmresSolver(30, 1e-8, 600)
+        st = s.solve(a, pc, b, x)
+        runs.append((st.iterations, st.converged, st.final_residual, tuple(s.residual_history)))
+    assert runs[0] == runs[1]                                              # run-to-run bit-identical
+    its, conv, fin, hist = runs[0]
+    assert its == 600 or its % 30 == 0 or conv
+    true_res = _true_residual(ctx, a, b, x)
+    assert abs(true_res - fin) <= 1e-12 * res0, (true_res, fin)          # tolerance: 1e-12 relative to ||b|| (north_star)
+    assert conv == (fin < 1e-8 * res0)
+    assert np.isfinite(fin) and fin < res0                                 # it does make progress
+    assert len(hist) == its and all(np.isfinite(hist))
+
+
+def test_config3_first_cycles_match_the_oracle_bitwise_64(ctx):
+    """The same solver at 64^3 (262 144 rows), where the oracle can follow: two restart cycles of GMRES(30) Left + Jacobi on
+    the convection-diffusion operator -- every residual-history entry, the iteration count and x, bit for bit."""
+    from oracle import oracle as O
+    M = 64
+    ao = O.stencil7(M, "convdiff")
+    a = K.CsrMatrix.stencil7(M, "convdiff", ctx=ctx)
+    b = ao.spmv(np.ones(ao.nrows))
+    T, V, F = K.reduce_spec()
+    ref = O.solve("gmres", ao, b, pc=O.Pc.jacobi(ao), tol=1e-8, max_iters=60, restart=30, side=O.SIDE_LEFT, rs=O.Reduce.tiled(T, V, F))
+    s = K.GmresSolver(30, 1e-8, 60); x = np.zeros(ao.nrows)
+    st = s.solve(a, K.Jacobi().setup(a), b, x)
+    assert (st.iterations, st.converged, st.final_residual) == (ref.iterations, ref.converged, ref.final_residual)
+    assert np.array_equal(np.array(s.residual_history), ref.history) and np.array_equal(x, ref.x)
+
+
+def test_config5_bicgstab_true_ilu0_aniso_256(ctx, monkeypatch):
+    """BASELINE configs[4] as the labelled extension (the reference's BiCgStabSolver ignores pc, bicgstab.rs:70): right-
+    preconditioned BiCGStab + textbook ILU(0) on the 256^3 anisotropic operator, absolute tol 1e-8 ||b|| (bicgstab.rs:69-293).
+    Converges; two runs give the same bits; the true residual of the returned x meets the tolerance; and the wavefront
+    triangular solve it runs on is checked at this size against the plane kernels (one launch per hyperplane, no
+    inter-workgroup waits: an independent implementation of the same row order): identical bits for z = U^-1 L^-1 r."""
+    n = N ** 3
+    a = K.CsrMatrix.stencil7(N, "aniso", ctx=ctx)
+    b = a.spmv(ctx.vec(n).fill(1.0))
+    bn = K.norm(b)
+    pc = K.TrueIlu0().setup(a)
+    runs = []
+    for _ in range(2):
+        x = ctx.vec(n)
+        s = K.BiCgStabRightPcSolver(1e-8 * bn, 1000)
+        st = s.solve(a, pc, b, x)
+        runs.append((st.iterations, st.converged, st.final_residual, tuple(s.residual_history)))
+    assert runs[0] == runs[1]
+    its, conv, fin, _ = runs[0]
+    assert conv and 10 < its < 1000
+    assert _true_residual(ctx, a, b, x) <= 1.5e-8 * bn                    # the recurrence residual met 1e-8 ||b||; the true one follows it
+    assert np.max(np.abs(x.to_host() - 1.0)) < 1e-4
+    r = ctx.vec(n).fill_splitmix(77)
+    z_wave = ctx.vec(n); pc.apply(r, z_wave)
+    monkeypatch.setenv("KRYST_ILU_PLANES", "1")
+    pc2 = K.TrueIlu0().setup(a)
+    z_planes = ctx.vec(n); pc2.apply(r, z_planes)
+    d = ctx.vec(n); d.copy_from(z_wave); K.axpy(-1.0, z_planes, d)
+    assert K.norm(d) == 0.0 and np.isfinite(K.norm(z_wave))

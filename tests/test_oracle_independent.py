@@ -1,0 +1,300 @@
+"""A SECOND, independent transcription of the reference's quirkiest code, written directly from the Rust source (not from
+oracle/kryst_oracle.c) in plain Python floats (IEEE double, one rounding per operation, no FMA), dense like the reference's own
+tests: restarted GMRES with its None / Left / Right branches (src/solver/gmres.rs:216-402, helpers :65-105,:154-192), Ilu0's
+setup and apply (src/preconditioner/ilu.rs:59-122), Jacobi (jacobi.rs:53-95), the dense row loop (src/core/wrappers.rs:27-38)
+and the serial dot / norm folds (wrappers.rs:101-107,120-126).
+
+The C oracle (serial-fold mode) must agree with it BIT FOR BIT -- iteration counts, converged flags, final residuals and every
+entry of x -- on the reference's own test systems (gmres.rs:438-528, tests/preconditioner_integration.rs:16-57,126-179) and on
+a few seeded dense systems.  Two transcriptions by different routes agreeing to the last bit is the strongest pin the
+reference allows: its own tests only hold answers to 1e-8 .. 1e-10."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+EPS = 1e-14            # gmres.rs:233
+
+
+# ------------------------------------------------------------------------------------------------ wrappers.rs
+def matvec(a, x):                                   # wrappers.rs:27-38: y[i] = 0; y[i] = y[i] + a[i][j] * x[j], j ascending
+    y = []
+    for row in a:
+        s = 0.0
+        for aij, xj in zip(row, x):
+            s = s + aij * xj
+        y.append(s)
+    return y
+
+
+def dot(x, y):                                      # wrappers.rs:101-107 (no-rayon build): fold(0, acc + x_i * y_i)
+    acc = 0.0
+    for xi, yi in zip(x, y):
+        acc = acc + xi * yi
+    return acc
+
+
+def norm(x):                                        # wrappers.rs:120-126
+    acc = 0.0
+    for xi in x:
+        acc = acc + xi * xi
+    return math.sqrt(acc)
+
+
+# ------------------------------------------------------------------------------------------------ preconditioners
+class Jacobi:                                       # jacobi.rs:53-95
+    def __init__(self, a):
+        n = len(a)
+        self.inv = []
+        for i in range(n):
+            e = [0.0] * n
+            e[i] = 1.0
+            d = matvec(a, e)[i]                     # diag via A e_i (:56-67)
+            self.inv.append(1.0 / d if d != 0.0 else 0.0)      # :69-71
+
+    def apply(self, x):
+        return [self.inv[i] * x[i] for i in range(len(x))]      # :84-86
+
+
+class Ilu0:                                         # ilu.rs:59-122, exactly as written (dense, every quirk included)
+    def __init__(self, a):
+        n = len(a)
+        l = [[0.0] * n for _ in range(n)]
+        u = [[0.0] * n for _ in range(n)]
+        for i in range(n):
+            u[i][i] = a[i][i]                       # :66
+            for j in range(i + 1, n):               # :68-72
+                if a[i][j] != 0.0:
+                    u[i][j] = a[i][j]
+            l[i][i] = 1.0                           # :74
+            for j in range(i + 1, n):               # :76-80
+                if a[j][i] != 0.0:
+                    l[j][i] = a[j][i] / u[i][i]
+            for j in range(i + 1, n):               # :82-96: "Schur complement update" from the ORIGINAL a, overwriting
+                for k in range(i + 1, n):
+                    if a[j][k] != 0.0:
+                        v = a[j][k] - l[j][i] * u[i][k]
+                        if v != 0.0:
+                            if k >= j:
+                                u[j][k] = v
+                            else:
+                                l[j][k] = v
+        self.l, self.u = l, u
+
+    def apply(self, x):                             # :107-121: forward with L (unit diagonal never divided), backward with U
+        y = list(x)                                 # (NO division by u_ii: the reference never divides)
+        n = len(x)
+        for i in range(n):
+            for j in range(i):
+                y[i] = y[i] - self.l[i][j] * y[j]
+        for i in reversed(range(n)):
+            for j in range(i + 1, n):
+                y[i] = y[i] - self.u[i][j] * y[j]
+        return y
+
+
+# ------------------------------------------------------------------------------------------------ gmres.rs
+def givens(h, g, cs, sn, j):                        # gmres.rs:154-176
+    for i in range(j):
+        temp = cs[i] * h[i][j] + sn[i] * h[i + 1][j]
+        h[i + 1][j] = -sn[i] * h[i][j] + cs[i] * h[i + 1][j]
+        h[i][j] = temp
+    h_kk, h_k1k = h[j][j], h[j + 1][j]
+    r = math.sqrt(h_kk * h_kk + h_k1k * h_k1k)
+    if abs(r) < EPS:
+        cs[j], sn[j] = 1.0, 0.0
+    else:
+        cs[j], sn[j] = h_kk / r, h_k1k / r
+    h[j][j] = cs[j] * h_kk + sn[j] * h_k1k
+    h[j + 1][j] = 0.0
+    temp = cs[j] * g[j] + sn[j] * g[j + 1]
+    g[j + 1] = -sn[j] * g[j] + cs[j] * g[j + 1]
+    g[j] = temp
+
+
+def back_substitution(h, g, m):                     # gmres.rs:180-192
+    y = [0.0] * m
+    for i in reversed(range(m)):
+        y[i] = g[i]
+        for j in range(i + 1, m):
+            y[i] = y[i] - h[i][j] * y[j]
+        y[i] = y[i] / h[i][i] if abs(h[i][i]) > EPS else 0.0
+    return y
+
+
+def mgs2(z, basis, h, j):                           # the double modified Gram-Schmidt every branch repeats (:83-96,:286-298,:318-330)
+    for i in range(j + 1):
+        h[i][j] = dot(z, basis[i])
+        z = [zk - h[i][j] * bk for zk, bk in zip(z, basis[i])]
+    for i in range(j + 1):
+        tmp = dot(z, basis[i])
+        h[i][j] = h[i][j] + tmp
+        z = [zk - tmp * bk for zk, bk in zip(z, basis[i])]
+    return z
+
+
+def gmres(a, pc, side, b, x0, restart, tol, max_iters):     # gmres.rs:216-402
+    n = len(b)
+    xk = list(x0)
+    r0 = [bi - axi for axi, bi in zip(matvec(a, xk), b)]     # :221-227
+    beta = norm(r0)
+    res0 = beta
+    iterations, final_residual, converged = 0, beta, False
+    n_outer = -(-max_iters // restart)                       # div_ceil :231
+    iteration = 0
+    for _ in range(n_outer):
+        v, zb = [], []
+        r0_norm = beta
+        if side == "left" and pc is not None:                # :239-246
+            v0 = [ri / r0_norm for ri in r0]
+            v.append(v0)
+            zb.append(pc.apply(v0))
+        elif side == "right" and pc is not None:             # :247-260
+            z0 = pc.apply(r0)
+            r0_norm = norm(z0)
+            v0 = [zi / r0_norm for zi in z0]
+            v.append(v0)
+            zb.append(pc.apply(v0))
+            beta = r0_norm
+        else:                                                # :261-265
+            v.append([ri / r0_norm for ri in r0])
+        h = [[0.0] * restart for _ in range(restart + 1)]
+        g = [0.0] * (restart + 1)
+        g[0] = r0_norm
+        cs, sn = [0.0] * restart, [0.0] * restart
+        m = 0
+        happy = False
+        for j in range(restart):
+            iteration += 1
+            if side == "left" and pc is not None:            # :279-307: orthogonalise against Z, push v_{j+1} into BOTH bases
+                z = pc.apply(matvec(a, v[j]))
+                z = mgs2(z, zb, h, j)
+                h[j + 1][j] = norm(z)
+                if abs(h[j + 1][j]) < EPS:
+                    happy = True
+                    break                                    # leaves the loop BEFORE the rotation and `m = j + 1`
+                vj1 = [zi / h[j + 1][j] for zi in z]
+                v.append(vj1)
+                zb.append(list(vj1))
+            elif side == "right" and pc is not None:         # :308-343
+                w2 = matvec(a, pc.apply(v[j]))
+                w2 = mgs2(w2, v, h, j)
+                h[j + 1][j] = norm(w2)
+                if abs(h[j + 1][j]) < EPS:
+                    happy = True
+                    break
+                vj1 = [wi / h[j + 1][j] for wi in w2]
+                v.append(vj1)
+                zb.append(pc.apply(vj1))
+            else:                                            # arnoldi :65-105: the rotation still runs after a happy breakdown
+                w = mgs2(matvec(a, v[j]), v, h, j)
+                h[j + 1][j] = norm(w)
+                if abs(h[j + 1][j]) < EPS:
+                    happy = True
+                else:
+                    v.append([wi / h[j + 1][j] for wi in w])
+            givens(h, g, cs, sn, j)                          # :347
+            res_norm = abs(g[j + 1])
+            rel = res_norm / res0                            # Convergence::check, convergence.rs:18-34
+            stop = rel <= tol or iteration >= max_iters
+            iterations, final_residual, converged = iteration, res_norm, stop
+            m = j + 1
+            if (stop and converged) or happy:
+                break
+        y = back_substitution([row[:m] for row in h[:m]], g[:m], m)      # :358-361
+        basis = zb if (side == "right" and pc is not None) else v       # :363-386
+        for j in range(m):
+            xk = [xi + y[j] * bj for xi, bj in zip(xk, basis[j])]
+        r0 = [bi - axi for axi, bi in zip(matvec(a, xk), b)]             # :388-391
+        beta = norm(r0)
+        final_residual = beta                                            # :393
+        converged = beta < tol * res0                                    # :394
+        if converged or iteration >= max_iters:
+            break
+    return xk, iterations, final_residual, converged
+
+
+# ------------------------------------------------------------------------------------------------ the comparison
+def dense_csr(a):
+    return O.Csr.from_dense(np.array(a, dtype=np.float64))             # every entry stored: the dense row loop, zeros included
+
+
+def tridiag(n, lo, di, up):
+    a = [[0.0] * n for _ in range(n)]
+    for i in range(n):
+        a[i][i] = di
+        if i > 0:
+            a[i][i - 1] = lo
+        if i + 1 < n:
+            a[i][i + 1] = up
+    return a
+
+
+A4 = [[4.0, 1.0, 0.0, 0.0], [1.0, 3.0, 1.0, 0.0], [0.0, 1.0, 2.0, 1.0], [0.0, 0.0, 1.0, 3.0]]        # gmres.rs:441-450
+SIDES = {"none": O.SIDE_NONE, "left": O.SIDE_LEFT, "right": O.SIDE_RIGHT}
+
+
+def _cases():
+    rng = np.random.default_rng(2024)
+    out = [("gmres.rs 4x4", A4, [1.0, 2.0, 3.0, 4.0], 4, 1e-10, 100),
+           ("integration nonsym tridiag 10", tridiag(10, -1.0, 2.0, 0.5), [1.0] * 10, 10, 1e-12, 100),   # preconditioner_integration.rs:41-57
+           ("integration spd tridiag 10", tridiag(10, -1.0, 2.0, -1.0), [1.0] * 10, 10, 1e-12, 100)]
+    for n, restart in ((7, 3), (12, 5), (9, 9)):                         # seeded dense systems, diagonally dominant, restarts that bite
+        m = rng.uniform(-1.0, 1.0, (n, n))
+        m[rng.random((n, n)) < 0.4] = 0.0
+        m += np.diag(np.abs(m).sum(axis=1) + 1.0)
+        out.append((f"random {n} restart {restart}", m.tolist(), rng.uniform(-2.0, 2.0, n).tolist(), restart, 1e-11, 60))
+    return out
+
+
+@pytest.mark.parametrize("name,a,x_true,restart,tol,max_iters", _cases(), ids=[c[0] for c in _cases()])
+@pytest.mark.parametrize("side,pcname", [("none", None), ("left", "jacobi"), ("right", "jacobi"), ("left", "ilu0"), ("right", "ilu0")])
+def test_c_oracle_equals_the_independent_transcription_bitwise(name, a, x_true, restart, tol, max_iters, side, pcname):
+    b = matvec(a, x_true)
+    pc_py = {None: None, "jacobi": Jacobi, "ilu0": Ilu0}[pcname]
+    pc_py = pc_py(a) if pc_py else None
+    x_py, its, fin, conv = gmres(a, pc_py, side, b, [0.0] * len(b), restart, tol, max_iters)
+    ao = dense_csr(a)
+    pc_c = {None: None, "jacobi": O.Pc.jacobi, "ilu0": O.Pc.ilu0_compat}[pcname]
+    ref = O.solve("gmres", ao, np.array(b), pc=pc_c(ao) if pc_c else None, tol=tol, max_iters=max_iters, restart=restart,
+                  side=SIDES[side], rs=O.SERIAL)
+    assert (ref.iterations, ref.converged) == (its, conv), (name, side, pcname)
+    assert ref.final_residual == fin, (name, side, pcname, ref.final_residual, fin)
+    assert np.array_equal(ref.x, np.array(x_py)), (name, side, pcname, np.max(np.abs(ref.x - np.array(x_py))))
+
+
+def test_ilu0_factors_and_apply_bitwise():
+    """Ilu0::setup / apply (ilu.rs:59-122) alone, on matrices where its "Schur complement update from the original a" differs
+    visibly from a textbook ILU(0): dense-ish rows, zeros inside the band, an unsymmetric pattern."""
+    rng = np.random.default_rng(7)
+    mats = [tridiag(10, -1.0, 2.0, 0.5), A4]
+    for n in (6, 11):
+        m = rng.uniform(-1.0, 1.0, (n, n))
+        m[rng.random((n, n)) < 0.5] = 0.0
+        m += np.diag(np.abs(m).sum(axis=1) + 1.0)
+        mats.append(m.tolist())
+    for a in mats:
+        pc = Ilu0(a)
+        ref = O.Pc.ilu0_compat(dense_csr(a))
+        for _ in range(3):
+            r = rng.standard_normal(len(a)).tolist()
+            assert np.array_equal(ref.apply(np.array(r)), np.array(pc.apply(r)))
+
+
+def test_reference_expectations_hold_for_the_transcription():
+    """The transcription itself satisfies the reference's own assertions (gmres.rs:452-460,484-491,517-527 and
+    tests/preconditioner_integration.rs:158-179) -- so a disagreement above could never be blamed on a wrong reading here."""
+    b = matvec(A4, [1.0, 2.0, 3.0, 4.0])
+    x, _, _, conv = gmres(A4, None, "none", b, [0.0] * 4, 4, 1e-10, 100)
+    assert conv and all(abs(xi - ei) < 1e-8 for xi, ei in zip(x, [1.0, 2.0, 3.0, 4.0]))
+    x, _, _, conv = gmres(A4, Jacobi(A4), "left", b, [0.0] * 4, 4, 1e-10, 100)
+    assert conv and all(abs(xi - ei) < 1e-8 for xi, ei in zip(x, [1.0, 2.0, 3.0, 4.0]))
+    x, _, _, _ = gmres(A4, Jacobi(A4), "right", b, [0.0] * 4, 4, 1e-10, 100)
+    assert norm([ai - bi for ai, bi in zip(matvec(A4, x), b)]) < 1e-2
+    an = tridiag(10, -1.0, 2.0, 0.5)
+    bn = matvec(an, [1.0] * 10)
+    x, its, _, conv = gmres(an, Ilu0(an), "left", bn, [0.0] * 10, 10, 1e-12, 100)
+    rel = math.sqrt(sum((xi - 1.0) ** 2 for xi in x) / 10.0)
+    assert conv and rel < 1e-10 and its == 20                            # two cycles: SURVEY 3.3
