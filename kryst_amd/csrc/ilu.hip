@@ -78,7 +78,11 @@ struct GridFactor {
     double* d_c1 = nullptr; double* d_c2 = nullptr; double* d_c3 = nullptr;   // coefficient of the i / j / k neighbour
                                                                             // (0.0 = no such entry: zero entries are never stored)
     double* d_diag = nullptr;                                               // divisor (backward factor only)
-    void free_all() { (void)hipFree(d_c1); (void)hipFree(d_c2); (void)hipFree(d_c3); (void)hipFree(d_diag); }
+    // blocked copy for tri_quad_kernel (16 x 16 lines per workgroup): [block][chunk][array][step pair][line], built on the device
+    void* d_blocked = nullptr; int32_t nbj = 0, nbk = 0, nch = 0;
+    double* d_edge_e = nullptr; double* d_edge_n = nullptr;                // edge rows handed to the next workgroup: [block][steps + 8][16]
+    void free_all() { (void)hipFree(d_c1); (void)hipFree(d_c2); (void)hipFree(d_c3); (void)hipFree(d_diag);
+                      (void)hipFree(d_blocked); (void)hipFree(d_edge_e); (void)hipFree(d_edge_n); }
 };
 struct GridView { int32_t Ni, Nj, Nk; const double* c1; const double* c2; const double* c3; const double* diag; };
 
@@ -328,6 +332,7 @@ __global__ __launch_bounds__(64) void tri_grid_kernel(const TriArgs* args, const
 
 }  // namespace kr
 #include "tri_wave.h"
+#include "tri_quad.h"
 namespace kr {
 
 __global__ __launch_bounds__(256) void tri_fill_kernel(const TriArgs* args, double* dst_ptr, int64_t n, int32_t* flags = nullptr, int32_t nflags = 0) {
@@ -445,7 +450,11 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
         // structured grid: r -> forward wavefront -> y (natural order) -> backward wavefront -> z; no permutations
         const GridFactor& A = D->GL; const GridFactor& B = D->GU;
         const unsigned nb = (unsigned)(((A.Nj + 7) / 8) * ((A.Nk + 7) / 8));
-        const int wave_on = env_int("KRYST_ILU_WAVE", 1);      // 0: the one-wave predecessor of tri_wave_kernel
+        // KRYST_ILU_WAVE: 2 = 16 x 16 lines per workgroup (tri_quad.h), 1 = 8 x 8 lines (tri_wave.h), 0 = its one-wave predecessor.
+        // Default by size (measured, MI355X, true ILU(0) apply): while every 8 x 8 block is resident at once (<= 1024 blocks: up to
+        // 256^3) the two wavefront kernels are within 5 % of each other and the 8 x 8 one is ahead on small grids (128^3: 0.355 vs
+        // 0.40 ms, 256^3: 1.01 vs 1.01); beyond that the 16 x 16 kernel wins (384^3: 1.97 vs 2.68 ms, 512^3: 3.87 vs 5.50 ms)
+        const int wave_on = env_int("KRYST_ILU_WAVE", nb > 1024 ? 2 : 1);
         const GridView VA{A.Ni, A.Nj, A.Nk, A.d_c1, A.d_c2, A.d_c3, nullptr}, VB{B.Ni, B.Nj, B.Nk, B.d_c1, B.d_c2, B.d_c3, B.d_diag};
         if (D->safe || env_int("KRYST_ILU_PLANES", 0)) {
             // the wavefront kernel gave up once on this preconditioner (or the caller asks for it): one launch per hyperplane
@@ -458,8 +467,21 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
             KR_HIP(hipGetLastError());
             return KRYST_OK;
         }
+        const int budget = std::max(1, env_int("KRYST_ILU_POLL_BUDGET", 1 << 22));   // (tests force the give-up path with a tiny budget)
+        if (wave_on >= 2 && A.d_blocked && B.d_blocked) {
+            // 16 x 16 lines per workgroup (tri_quad.h): blocked coefficients, edge buffers between workgroups
+            const unsigned nq = (unsigned)(A.nbj * A.nbk);
+            const QuadView QA{A.Ni, A.Nj, A.Nk, A.nbj, A.nbk, A.nch, (const tw_v2*)A.d_blocked, A.d_edge_e, A.d_edge_n};
+            const QuadView QB{B.Ni, B.Nj, B.Nk, B.nbj, B.nbk, B.nch, (const tw_v2*)B.d_blocked, B.d_edge_e, B.d_edge_n};
+            const unsigned fg = std::min<unsigned>(1024u, nq * 4u);
+            hipLaunchKernelGGL(tri_quad_fill_kernel, dim3(fg), dim3(256), 0, s, D->d_args, A.d_edge_e, A.d_edge_n, (int)nq, A.nch, D->d_flags, (int32_t)(2 * nb + 1));
+            hipLaunchKernelGGL(tri_quad_fill_kernel, dim3(fg), dim3(256), 0, s, D->d_args, B.d_edge_e, B.d_edge_n, (int)nq, B.nch, (int32_t*)nullptr, 0);
+            hipLaunchKernelGGL((tri_quad_kernel<true>), dim3(nq), dim3(512), 0, s, D->d_args, (const double*)nullptr, D->d_y, QA, D->n, D->d_flags, D->d_flags + 2 * nb, D->d_gave_up, budget);
+            hipLaunchKernelGGL((tri_quad_kernel<false>), dim3(nq), dim3(512), 0, s, D->d_args, (const double*)D->d_y, (double*)nullptr, QB, D->n, D->d_flags + nb, D->d_flags + 2 * nb, D->d_gave_up, budget);
+            KR_HIP(hipGetLastError());
+            return KRYST_OK;
+        }
         if (wave_on > 0 && A.Ni >= 2) {
-            const int budget = std::max(1, env_int("KRYST_ILU_POLL_BUDGET", 1 << 22));   // (tests force the give-up path with a tiny budget)
             hipLaunchKernelGGL((tri_wave_fill_kernel<true>), dim3(nb), dim3(256), 0, s, D->d_args, D->d_y, VA, D->d_flags, (int32_t)(2 * nb + 1));
             hipLaunchKernelGGL((tri_wave_kernel<true>), dim3(nb), dim3(192), 0, s, D->d_args, (const double*)nullptr, D->d_y, VA, D->n, D->d_flags, D->d_flags + 2 * nb, D->d_gave_up, budget);
             hipLaunchKernelGGL((tri_wave_fill_kernel<false>), dim3(nb), dim3(256), 0, s, D->d_args, (double*)nullptr, VB, (int32_t*)nullptr, 0);
@@ -726,6 +748,25 @@ static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRow
         if (rc == KRYST_OK && (hipHostMalloc((void**)&D->h_gave_up, 64, hipHostMallocMapped) != hipSuccess ||
                                hipHostGetDevicePointer((void**)&D->d_gave_up, D->h_gave_up, 0) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = KRYST_ERR_HIP; }
         if (rc == KRYST_OK) *D->h_gave_up = 0;
+        if (rc == KRYST_OK && D->GL.Ni >= 2 && env_i("KRYST_ILU_WAVE", (size_t)((D->GL.Nj + 7) / 8) * (size_t)((D->GL.Nk + 7) / 8) > 1024 ? 2 : 1) >= 2) {
+            // blocked coefficient layout + edge buffers of the 16 x 16 kernel (tri_quad.h), one device pass per factor
+            for (GridFactor* G : {&D->GL, &D->GU}) {
+                if (rc != KRYST_OK) break;
+                const bool fwd = G == &D->GL;
+                G->nbj = (G->Nj + 15) / 16; G->nbk = (G->Nk + 15) / 16; G->nch = (G->Ni + 14 + TQ_C - 1) / TQ_C;
+                const size_t nq = (size_t)G->nbj * G->nbk;
+                const int NA = fwd ? 3 : 4;
+                const size_t cbytes = nq * G->nch * NA * 4 * TQ_LINES * sizeof(tw_v2);
+                const size_t ebytes = nq * (size_t)(G->nch * TQ_C + 8) * 16 * sizeof(double);
+                if (hipMalloc(&G->d_blocked, cbytes) != hipSuccess || hipMalloc(&G->d_edge_e, ebytes) != hipSuccess ||
+                    hipMalloc(&G->d_edge_n, ebytes) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; break; }
+                const GridView V{G->Ni, G->Nj, G->Nk, G->d_c1, G->d_c2, G->d_c3, G->d_diag};
+                const unsigned lg = (unsigned)(nq * G->nch);
+                if (fwd) hipLaunchKernelGGL((tri_quad_layout_kernel<true, 3>), dim3(lg), dim3(256), 0, ctx->s_main, V, G->nbj, G->nbk, G->nch, (tw_v2*)G->d_blocked);
+                else hipLaunchKernelGGL((tri_quad_layout_kernel<false, 4>), dim3(lg), dim3(256), 0, ctx->s_main, V, G->nbj, G->nbk, G->nch, (tw_v2*)G->d_blocked);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("blocked layout kernel failed"); rc = KRYST_ERR_HIP; }
+            }
+        }
     }
     if (getenv("KRYST_ILU_VERBOSE"))
         fprintf(stderr, "[kryst ilu] n=%lld %s; levels L/U=%zu/%zu\n", (long long)n, D->GL.ok ? "structured grid (wavefront kernel)" : "level-ordered",
@@ -931,6 +972,9 @@ extern "C" int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kr
 }
 
 #ifdef KR_TW_TRACE
+extern "C" int32_t kryst_debug_tq_trace(long long* host, int32_t count) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(kr::tq_trace), sizeof(long long) * count) == hipSuccess ? 0 : 1;
+}
 extern "C" int32_t kryst_debug_tw_trace(long long* host, int32_t count) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(kr::tw_trace), sizeof(long long) * count) == hipSuccess ? 0 : 1;
 }

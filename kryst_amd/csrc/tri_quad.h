@@ -1,0 +1,494 @@
+// PIPELINED WAVEFRONT solve of a structured-grid factor, third generation: 16 x 16 grid lines per workgroup.
+//
+// tri_wave.h solves an 8 x 8 block of lines with ONE solving wave per workgroup and is bound, at 256^3, by (i) the block hops of
+// the pipeline fill -- 62 of them, each a trip through memory and a poller round -- and (ii) the chip holding only one such
+// workgroup per CU (its loader wave streams five arrays through 284 registers), i.e. 64 lines per CU.  Here a workgroup owns a
+// 16 x 16 block as FOUR 8 x 8 quadrants, one solving wave each, and
+//   * neighbouring quadrants hand their edge rows over through rings in LDS (~0.1 us) -- only the 16 + 16 lines on the
+//     workgroup's west and south boundary come through memory, so a 256^3 solve has 30 memory hops instead of 62 and every
+//     block of the grid is resident at once (256 workgroups);
+//   * the factor's coefficients are stored at setup in BLOCKED layout -- [block][chunk of 8 steps][array][step pair][lane],
+//     zero where a lane is outside its line -- so a solving wave loads them itself, 1 KiB per instruction, two chunks ahead, and
+//     needs no activity predicate in its step (a zero coefficient selects a +0.0 operand, as in tri_wave.h); only the right-hand
+//     side, which lives in the caller's natural layout, still goes through a LOADER wave and an LDS stage;
+//   * what a neighbouring workgroup needs is written to compact EDGE buffers -- [block][producer step][16 lines], one memory
+//     line per step -- instead of being picked out of the solution vector: a POLLER round is two contiguous 1 KiB reads.
+// Lane (jl, kl) of a quadrant walks its line one row per step, skewed by jl + kl; quadrants run on their own clocks: a consumer
+// at step t needs its producer (sibling quadrant or neighbouring workgroup) to have finished step t + 7.
+// Same arithmetic and order as every other triangular-solve form (stored, i.e. ascending-column, order): bit-identical.
+//
+// Progress relies on the blocks a resident block waits for being resident or finished (workgroups start in index order, blocks
+// are numbered along anti-diagonals): an observed property, not a HIP guarantee -- every spin has a budget, and a poller that
+// runs out of patience raises the host-visible give-up word (ilu.hip: ilu_health -> plane kernels).
+#pragma once
+
+namespace kr {
+
+constexpr int TQ_C = 8;            // steps per chunk
+constexpr int TQ_S = 4;            // LDS stage slots (right-hand side) -- per loader half, whose two quadrants run 8+ steps apart
+constexpr int TQ_YR = 32;          // steps in a solving wave's result ring
+constexpr int TQ_R = 64;           // steps in a neighbour ring
+constexpr int TQ_LINES = 256;      // lines per workgroup (4 quadrants x 64 lanes)
+
+struct QuadView {
+    int32_t Ni, Nj, Nk, nbj, nbk, nch;
+    const tw_v2* coef;             // blocked coefficients: [block][chunk][array][step pair][line] (array: i-, j-, k-neighbour[, divisor])
+    double* edge_e; double* edge_n;   // [block][nch * 8 + 8 producer steps][16 lines]
+};
+
+// Counters in LDS that tie the waves of a workgroup together.  The payload they guard is in LDS as well, and the LDS executes
+// one wave's operations in issue order, so publishing needs NO wait at all: the ring write and the counter write that follows it
+// reach the LDS in that order, and a reader that has seen the counter issues its ring reads afterwards.  Only the compiler must
+// keep the program order (the empty asm).  The workgroup-scope release / acquire forms would wait for lgkmcnt(0) -- one LDS
+// round trip per publish on the solving wave's critical path -- and for vmcnt(0): every outstanding GLOBAL load and store of
+// the wave, i.e. an HBM round trip per step for a wave that keeps a chunk of coefficient loads in flight.
+__device__ __forceinline__ void tq_publish(int* p, int v) {
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ int tq_peek(int* p) {
+    asm volatile("" ::: "memory");
+    const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    return v;
+}
+
+#ifdef KR_TW_TRACE
+// trace build (tools/tq_trace.py): per block and quadrant of the FORWARD solve: [0] entry, [1] first coefficients in registers,
+// [2 + c] chunk c done (c < 8), [10] last chunk done, [11] ticks waiting for neighbour rows, [12] for the stage, [13] for sibling ring space
+__device__ long long tq_trace[4096 * 4 * 16];
+#define TQ_STAMP(slot) do { if (FORWARD && l == 0 && blk < 4096) tq_trace[(blk * 4 + q) * 16 + (slot)] = wall_clock64(); } while (0)
+#define TQ_ACC(slot, t0_) do { tq_acc[(slot) - 11] += wall_clock64() - (t0_); } while (0)      // (registers: a read-modify-write of memory would stall the wave)
+#else
+#define TQ_STAMP(slot) do { } while (0)
+#define TQ_ACC(slot, t0_) do { } while (0)
+#endif
+
+__device__ __forceinline__ void tq_block_of(int b, int nbj, int nbk, int& J, int& K) {     // anti-diagonal numbering
+    int d = 0, rem = b, lo = 0;
+    for (;; ++d) {
+        lo = max(0, d - (nbk - 1));
+        const int cnt = min(d, nbj - 1) - lo + 1;
+        if (rem < cnt) break;
+        rem -= cnt;
+    }
+    J = lo + rem; K = d - J;
+}
+
+// line index L (0..255) of a workgroup: quadrant q = L >> 6 (qj = q & 1, qk = q >> 1), lane l8 = L & 63 (jl8 = l8 & 7, kl8 = l8 >> 3)
+struct TqLine { int jj, kk, skew; };
+__device__ __forceinline__ TqLine tq_line(int J, int K, int L) {
+    const int q = L >> 6, l8 = L & 63;
+    return TqLine{16 * J + 8 * (q & 1) + (l8 & 7), 16 * K + 8 * (q >> 1) + (l8 >> 3), (l8 & 7) + (l8 >> 3)};
+}
+
+// ---- setup: natural-order coefficient streams -> blocked layout.  One workgroup of 256 threads per (block, chunk).
+template <bool FORWARD, int NA>
+__global__ __launch_bounds__(256) void tri_quad_layout_kernel(GridView G, int nbj, int nbk, int nch, tw_v2* coef) {
+    const int blk_lin = blockIdx.x / nch, c = blockIdx.x % nch, L = threadIdx.x;
+    const int J = blk_lin % nbj, K = blk_lin / nbj;                        // (layout is indexed by K * nbj + J)
+    const TqLine ln = tq_line(J, K, L);
+    const bool line_ok = ln.jj < G.Nj && ln.kk < G.Nk;
+    const int j = FORWARD ? ln.jj : G.Nj - 1 - ln.jj, k = FORWARD ? ln.kk : G.Nk - 1 - ln.kk;
+    const int64_t line0 = line_ok ? (int64_t)(k * G.Nj + j) * G.Ni : 0;
+    const double* src[4] = {G.c1, G.c2, G.c3, G.diag};
+    tw_v2* dst = coef + ((size_t)blk_lin * nch + c) * NA * 4 * TQ_LINES + L;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            double v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ii = c * TQ_C + 2 * h + e - ln.skew;
+                const bool ok = line_ok && ii >= 0 && ii < G.Ni;
+                const int64_t row = line0 + (FORWARD ? ii : G.Ni - 1 - ii);
+                v[e] = ok ? src[a][row] : (a == 3 ? 1.0 : 0.0);           // outside the line: no entries, divisor 1
+            }
+            dst[(a * 4 + h) * TQ_LINES] = tw_v2{v[0], v[1]};
+        }
+}
+
+// ---- per apply: sentinels into the edge buffers (zeros in the 8 steps past the last chunk: rows nobody has), flags and abort word cleared
+__global__ __launch_bounds__(256) void tri_quad_fill_kernel(const TriArgs* args, double* edge_e, double* edge_n, int nblk, int nch, int32_t* flags, int32_t nflags) {
+    if (args->skip) return;
+    const int64_t per = (int64_t)(nch * TQ_C + 8) * 16;                   // doubles per block and direction
+    const int64_t total = per * nblk;
+    const double sentinel = __longlong_as_double((long long)KR_TRI_SENTINEL);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const double v = (i % per) < (int64_t)nch * TQ_C * 16 ? sentinel : 0.0;
+        edge_e[i] = v; edge_n[i] = v;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nflags; i += gridDim.x * 256) flags[i] = 0;
+}
+
+template <bool FORWARD>
+__global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, QuadView Q, int64_t n,
+                                                          int32_t* flags, int32_t* abort_word, int32_t* gave_up, int poll_budget) {
+    if (args->skip) return;
+    constexpr int C = TQ_C, S = TQ_S, R = TQ_R;
+    constexpr int NA = FORWARD ? 3 : 4;                                    // coefficient arrays per chunk
+    constexpr int YR = TQ_YR;
+    __shared__ double stage[S * C * TQ_LINES];                             // right-hand side: [slot][step][line]                       64 KiB
+    __shared__ double yring[4 * YR * 64];                                  // every solving wave's last YR steps, all 64 lanes             64 KiB
+    __shared__ double pring[4 * R * 8];                                    // poller streams (west of q0, west of q2, south of q0, south of q1): [step % R][edge lane]  16 KiB
+    __shared__ int prog[4];                                                // steps each solving wave has finished (its rows are in its ring)
+    __shared__ int pavail[4];                                              // consumer steps each poller stream has delivered
+    __shared__ int taken[4];                                               // chunks each solving wave has taken off the stage
+    __shared__ int exported[4];                                            // producer steps each exporter stream has written to the edge buffers
+    __shared__ int staged[2], quit, always;                                // chunks each loader wave has staged (quadrants 0-1 / 2-3)
+    cgdouble* in = (cgdouble*)(in_ptr ? in_ptr : args->r);
+    gdouble* out = (gdouble*)(out_ptr ? out_ptr : args->z);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // 0-3 solve, 4-5 load the right-hand side (128 lines each), 6 polls, 7 exports
+    const int l = threadIdx.x & 63;
+    int J, K;
+    tq_block_of(blockIdx.x, Q.nbj, Q.nbk, J, K);
+    const int blk = K * Q.nbj + J;
+    const int nch = Q.nch, T = nch * C;
+    const int64_t edge_stride = (int64_t)(T + 8) * 16;                    // doubles per block in an edge buffer
+    constexpr int HUGE_STEPS = 1 << 30;
+    
+    if (threadIdx.x < 4) {
+        const int i = threadIdx.x;
+        prog[i] = 0; taken[i] = 0; pavail[i] = 0;
+        // exporter streams: 0 east rows of q1, 1 east rows of q3, 2 north rows of q2, 3 north rows of q3
+        exported[i] = (i < 2 ? J + 1 < Q.nbj : K + 1 < Q.nbk) ? 0 : HUGE_STEPS;
+    }
+    if (threadIdx.x == 0) { staged[0] = 0; staged[1] = 0; quit = 0; always = HUGE_STEPS; }
+    for (int i = threadIdx.x; i < 4 * R * 8; i += 512) pring[i] = 0.0;
+    for (int i = threadIdx.x; i < 4 * YR * 64; i += 512) yring[i] = 0.0;
+    __syncthreads();                                                      // the only barrier
+
+    // ------------------------------------------------------------------------------------------------ the LOADER
+    if (wave == 4 || wave == 5) {
+        const int half = wave - 4;                                        // lines 128 half .. 128 half + 127 (quadrants 2 half, 2 half + 1)
+        // right-hand side, natural layout -> stage.  Interior chunks: four lanes share a line's 64 contiguous bytes (lane 4g + c
+        // of pass r loads the 16-byte piece c of line 16 r + g), so one load instruction touches 16 memory lines, not 64.
+        const int g = l >> 2, c = l & 3;
+        const bool full = 16 * J + 16 <= Q.Nj && 16 * K + 16 <= Q.Nk;
+        auto fast_chunk = [&](int t0) { return full && t0 >= 14 && t0 + C <= Q.Ni; };     // every line of the block inside [0, Ni) for all 8 steps
+        auto row0 = [&](int r) -> int64_t {                               // row of step 0 of line 16 r + g (may lie outside the line)
+            const TqLine ln = tq_line(J, K, 128 * half + 16 * r + g);
+            const int jx = FORWARD ? ln.jj : Q.Nj - 1 - ln.jj, kx = FORWARD ? ln.kk : Q.Nk - 1 - ln.kk;
+            return (int64_t)(kx * Q.Nj + jx) * Q.Ni + (FORWARD ? -ln.skew : Q.Ni - 1 + ln.skew);
+        };
+        // The loads are issued and waited for BY HAND (inline asm + s_waitcnt with the exact number of younger loads): three
+        // chunks are in flight and the two paths below differ, and the compiler's automatic vmcnt then assumes the worst at every
+        // merge and drains all buffers at each publish -- one HBM round trip per chunk, which was the whole kernel's pace.
+        struct Buf { tw_v2 d[8]; };
+        // slow path (lines start / end inside the chunk, ragged blocks): two lines per lane (l, l + 64 of this half), their 8
+        // steps as four 16-byte pairs each -- eight loads like the fast path; a pair that sticks out of its line by one row is
+        // loaded one row further in and the missing half replaced by zero when the buffer is published
+        auto slow_pair = [&](int t0, int qd, int h, bool& oka, bool& okb, int64_t& lo) {
+            const TqLine ln = tq_line(J, K, 128 * half + 64 * qd + l);
+            const bool line_ok = ln.jj < Q.Nj && ln.kk < Q.Nk;
+            const int jx = FORWARD ? ln.jj : Q.Nj - 1 - ln.jj, kx = FORWARD ? ln.kk : Q.Nk - 1 - ln.kk;
+            const int64_t line0 = line_ok ? (int64_t)(kx * Q.Nj + jx) * Q.Ni : 0;
+            const int ia = t0 + 2 * h - ln.skew, ib = ia + 1;               // line coordinates of the pair's two steps
+            oka = line_ok && ia >= 0 && ia < Q.Ni; okb = line_ok && ib >= 0 && ib < Q.Ni;
+            const int w = (oka && !okb) ? ia - 1 : (!oka && okb) ? ib : ia;  // a 2-row window inside the line (Ni >= 2)
+            const int wc = (oka || okb) ? w : 0;
+            lo = line0 + (FORWARD ? wc : Q.Ni - 2 - wc);                     // lower memory row of the window
+        };
+        auto fetch = [&](Buf& b, int t0) {
+            if (fast_chunk(t0)) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int64_t lo = FORWARD ? row0(r) + t0 : row0(r) - t0 - (C - 1);       // lowest row of the chunk
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b.d[r]) : "v"(in + lo + 2 * c) : "memory");
+                }
+            } else {
+#pragma unroll
+                for (int qd = 0; qd < 2; ++qd)
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        bool oka, okb; int64_t lo;
+                        slow_pair(t0, qd, h, oka, okb, lo);
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b.d[4 * qd + h]) : "v"(in + lo) : "memory");
+                    }
+            }
+        };
+        // `younger`: loads issued after this buffer's eight (0, 8 or 16)
+        auto publish = [&](Buf& b, int kc, int younger) {
+            // slot kc % S is free once every solving wave has taken chunk kc - S
+            for (int budget = 1 << 24; budget > 0; --budget) {
+                const int m = min(tq_peek(&taken[2 * half]), tq_peek(&taken[2 * half + 1]));
+                if (kc - m < S || tq_peek(&quit)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (younger >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (younger >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 8; ++r) asm volatile("" : "+v"(b.d[r]));     // (the values exist from here on)
+            double* dst = stage + (size_t)(kc % S) * C * TQ_LINES;
+            if (fast_chunk(kc * C)) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int L = 128 * half + 16 * r + g;
+                    const int u0 = FORWARD ? 2 * c : C - 1 - 2 * c, u1 = FORWARD ? 2 * c + 1 : C - 2 - 2 * c;   // steps of the piece's two rows
+                    dst[u0 * TQ_LINES + L] = b.d[r].x; dst[u1 * TQ_LINES + L] = b.d[r].y;
+                }
+            } else {
+#pragma unroll
+                for (int qd = 0; qd < 2; ++qd)
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        bool oka, okb; int64_t lo;
+                        slow_pair(kc * C, qd, h, oka, okb, lo);
+                        const tw_v2 pr = b.d[4 * qd + h];
+                        const double ra = FORWARD ? pr.x : pr.y, rb = FORWARD ? pr.y : pr.x;  // line rows wc, wc + 1
+                        const double va = (oka && !okb) ? rb : ra, vb = (!oka && okb) ? ra : rb;
+                        dst[(2 * h) * TQ_LINES + 128 * half + 64 * qd + l] = oka ? va : 0.0;
+                        dst[(2 * h + 1) * TQ_LINES + 128 * half + 64 * qd + l] = okb ? vb : 0.0;
+                    }
+            }
+            tq_publish(&staged[half], kc + 1);
+        };
+        Buf b0, b1, b2;                                                    // chunk kc lives in buffer kc % 3
+        fetch(b0, 0);
+        if (1 < nch) fetch(b1, C);
+        if (2 < nch) fetch(b2, 2 * C);
+        for (int kc = 0; kc < nch; kc += 3) {
+            // loads younger than the buffer being published: the chunks kc + 1 .. that have been requested by now
+            publish(b0, kc, 8 * (min(nch, kc + 3) - (kc + 1)));
+            if (kc + 3 < nch) fetch(b0, (kc + 3) * C);
+            if (kc + 1 < nch) { publish(b1, kc + 1, 8 * (min(nch, kc + 4) - (kc + 2))); if (kc + 4 < nch) fetch(b1, (kc + 4) * C); }
+            if (kc + 2 < nch) { publish(b2, kc + 2, 8 * (min(nch, kc + 5) - (kc + 3))); if (kc + 5 < nch) fetch(b2, (kc + 5) * C); }
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------------ the POLLER
+    if (wave == 6) {
+        // four streams of 16 lanes each: g = 0 / 1 west inputs of quadrants (0,0) / (0,1), g = 2 / 3 south inputs of quadrants
+        // (0,0) / (1,0).  Lane idx of a stream: step offset idx >> 2 (and + 4 for the second load), 16-byte piece idx & 3 = edge
+        // lanes 2 piece, 2 piece + 1.  Consumer step t of a stream reads the producer's step t + 7.
+        const int gI = l >> 4, idx = l & 15, so = idx >> 2, piece = idx & 3;
+        const bool west = gI < 2;
+        const int cq = gI == 0 ? 0 : gI == 1 ? 2 : gI == 2 ? 0 : 1;      // consumer quadrant (q = qj + 2 qk)
+        const bool has_src = west ? J > 0 : K > 0;
+        const int src_blk = west ? blk - 1 : blk - Q.nbj;
+        gdouble* const src = (gdouble*)(west ? Q.edge_e : Q.edge_n) + (int64_t)(has_src ? src_blk : blk) * edge_stride + 8 * (gI & 1) + 2 * piece;
+        double* const ring = pring + gI * R * 8;
+        int* const avail = &pavail[gI];
+        // GATE: until the producers are under way, look at their flags only
+        if (l == 0) {
+            for (int budget = 1 << 22; budget > 0; --budget) {
+                const bool ok_w = J == 0 || __hip_atomic_load(&flags[blk - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                const bool ok_s = K == 0 || __hip_atomic_load(&flags[blk - Q.nbj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (ok_w && ok_s) break;
+                if ((budget & 63) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        int t = has_src ? 0 : T;                                           // next consumer step of this lane's stream
+        for (int budget = poll_budget; budget > 0;) {
+            if (__ballot(t < T) == 0) break;
+            const int free_upto = max(tq_peek(&taken[cq]) - 1, 0) * C + R;      // ring slots below this consumer step are free
+            const bool go = t < T && t + 8 <= free_upto;
+            if (__ballot(go) == 0) { __builtin_amdgcn_s_sleep(2); --budget; continue; }
+            gdouble* const a0 = go ? src + (int64_t)(t + 7 + so) * 16 : (gdouble*)Q.edge_e + (int64_t)blk * edge_stride;
+            gdouble* const a1 = go ? a0 + 4 * 16 : a0;
+            tw_v2 p0, p1;                                                 // agent-scope (sc1) 16-byte loads: each 8-byte half whole or sentinel
+            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(p0), "=&v"(p1) : "v"(a0), "v"(a1) : "memory");
+            const bool bad0 = go && (tw_is_sentinel(p0.x) || tw_is_sentinel(p0.y)), bad1 = go && (tw_is_sentinel(p1.x) || tw_is_sentinel(p1.y));
+            const unsigned long long b0m = __ballot(bad0), b1m = __ballot(bad1);
+            // leading complete steps of this lane's stream: step offset s of load 0 = lanes 4 s .. 4 s + 3 of the stream
+            const unsigned s0 = (unsigned)(b0m >> (16 * gI)) & 0xffffu, s1 = (unsigned)(b1m >> (16 * gI)) & 0xffffu;
+            int m = 0;
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx) {
+                const unsigned bits = sidx < 4 ? (s0 >> (4 * sidx)) & 0xfu : (s1 >> (4 * (sidx - 4))) & 0xfu;
+                if (m == sidx && bits == 0) m = sidx + 1;
+            }
+            if (!go) m = 0;
+            const unsigned long long stuck = __ballot(go && m == 0);
+            if (stuck && (budget == 1 || ((budget & 255) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))) {
+                // out of patience (tri_wave.h: same rule): hand over what there is, tell every block, raise the host-visible word
+                __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                tq_publish(&quit, 1);
+                if (l < 4) { tq_publish(&pavail[l], HUGE_STEPS); tq_publish(&prog[l], HUGE_STEPS); tq_publish(&exported[l], HUGE_STEPS); }
+                return;
+            }
+            if (so < m) { ring[((t + so) % R) * 8 + 2 * piece] = p0.x; ring[((t + so) % R) * 8 + 2 * piece + 1] = p0.y; }
+            if (so + 4 < m) { ring[((t + so + 4) % R) * 8 + 2 * piece] = p1.x; ring[((t + so + 4) % R) * 8 + 2 * piece + 1] = p1.y; }
+            if (m > 0) { t += m; if (idx == 0) tq_publish(avail, t); }
+            if (stuck) { __builtin_amdgcn_s_sleep(1); --budget; }
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------------ the EXPORTER
+    if (wave == 7) {
+        // copies the rows the next workgroups need out of the solving waves' rings into the edge buffers (write-through 8-byte
+        // stores), so that a solving wave's step holds no global store and no branch on where its rows go.  Four streams of 16
+        // lanes: e = 0 east rows of q1 (edge lines 0-7), 1 east rows of q3 (8-15), 2 north rows of q2 (0-7), 3 north rows of q3;
+        // lane idx of a stream: step offset idx >> 3 (two steps per round), edge lane idx & 7.
+        const int es = l >> 4, idx = l & 15, so = idx >> 3, e = idx & 7;
+        const int sq = es == 0 ? 1 : es == 2 ? 2 : 3;
+        const bool east = es < 2;
+        const bool on = east ? J + 1 < Q.nbj : K + 1 < Q.nbk;
+        const double* const src = yring + sq * YR * 64 + (east ? 7 + 8 * e : 56 + e);
+        gdouble* const dst = (gdouble*)(east ? Q.edge_e : Q.edge_n) + (int64_t)blk * edge_stride + 8 * (es & 1) + e;
+        int te = on ? 0 : T;
+        for (int budget = 1 << 26; budget > 0; --budget) {
+            if (__ballot(te < T) == 0) break;
+            const int n = max(0, min(min(tq_peek(&prog[sq]), T) - te, 2));
+            if (te < T && so < n) __hip_atomic_store(dst + (int64_t)(te + so) * 16, src[((te + so) & (YR - 1)) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (te < T && n > 0) { te += n; if (idx == 0) tq_publish(&exported[es], te); }
+            if (__ballot(n > 0) == 0) { if (tq_peek(&quit)) break; __builtin_amdgcn_s_sleep(1); }
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------------ the SOLVING waves
+    const int q = wave, qj = q & 1, qk = q >> 1;
+    const int jl = l & 7, kl = l >> 3, skew = jl + kl;
+    const int jj = 16 * J + 8 * qj + jl, kk = 16 * K + 8 * qk + kl;
+    const bool line_ok = jj < Q.Nj && kk < Q.Nk;
+    const int j = FORWARD ? jj : Q.Nj - 1 - jj, k = FORWARD ? kk : Q.Nk - 1 - kk;
+    const int64_t line0 = line_ok ? (int64_t)(k * Q.Nj + j) * Q.Ni : 0;
+    const bool full = 16 * J + 16 <= Q.Nj && 16 * K + 16 <= Q.Nk;
+    auto fast_chunk = [&](int t0) { return full && t0 >= 14 && t0 + C <= Q.Ni; };
+    // Where this quadrant's west / south rows come from -- a sibling's result ring (its step t + 7), a poller stream (step t), or
+    // nowhere -- as DATA (pointer, step offset, ring mask, stride, counter), so that the step itself has no branch on it.
+    const bool w_sib = qj == 1, w_poll = qj == 0 && J > 0, s_sib = qk == 1, s_poll = qk == 0 && K > 0;
+    const double* const w_ptr = w_sib ? yring + (q - 1) * YR * 64 + 7 + 8 * kl : pring + (qk == 0 ? 0 : 1) * R * 8 + kl;
+    const double* const s_ptr = s_sib ? yring + (q - 2) * YR * 64 + 56 + jl : pring + (2 + qj) * R * 8 + jl;
+    const int w_off = w_sib ? 7 : 0, w_mask = w_sib ? YR - 1 : R - 1, w_stride = w_sib ? 64 : 8;
+    const int s_off = s_sib ? 7 : 0, s_mask = s_sib ? YR - 1 : R - 1, s_stride = s_sib ? 64 : 8;
+    int* const w_cnt = w_sib ? &prog[q - 1] : w_poll ? &pavail[qk == 0 ? 0 : 1] : &always;
+    int* const s_cnt = s_sib ? &prog[q - 2] : s_poll ? &pavail[2 + qj] : &always;
+    // who reads this quadrant's ring (back-pressure): sibling quadrants and exporter streams
+    const int cons_a = qj == 0 ? q + 1 : -1, cons_b = qk == 0 ? q + 2 : -1;
+    const int exp_a = q == 1 ? 0 : q == 3 ? 1 : -1, exp_b = q == 2 ? 2 : q == 3 ? 3 : -1;
+    double* const my_ring = yring + q * YR * 64 + l;
+    const int idx1 = max(l - 1, 0) * 4, idx8 = max(l - 8, 0) * 4;
+    cg_v2* const coef = (cg_v2*)Q.coef + (size_t)blk * nch * NA * 4 * TQ_LINES + 64 * q + l;
+
+    struct Coef { tw_v2 a[NA][4]; };
+    auto fetch = [&](Coef& cf, int kc) {
+        cg_v2* p = coef + (size_t)kc * NA * 4 * TQ_LINES;
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) cf.a[a][h] = p[(a * 4 + h) * TQ_LINES];
+    };
+    double y = 0.0;
+    int seen = 0;
+#ifdef KR_TW_TRACE
+    long long tq_acc[3] = {0, 0, 0};
+#endif
+    auto process = [&](const Coef& cf, int kc) {
+        const int t0 = kc * C;
+        // right-hand side of the chunk off the stage
+#ifdef KR_TW_TRACE
+        const long long ts0 = wall_clock64();
+#endif
+        for (int budget = 1 << 24; tq_peek(&staged[q >> 1]) <= kc && budget > 0; --budget) __builtin_amdgcn_s_sleep(1);
+        TQ_ACC(12, ts0);
+        double rv[C];
+        const double* sp = stage + (size_t)(kc % S) * C * TQ_LINES + 64 * q + l;
+#pragma unroll
+        for (int u = 0; u < C; ++u) rv[u] = sp[u * TQ_LINES];
+        if (l == 0) tq_publish(&taken[q], kc + 1);                       // (same-wave LDS operations complete in order: the reads above are done)
+        // back-pressure: this chunk overwrites the ring slots of steps t0 - YR .. t0 + 7 - YR: every reader must be past them
+        {
+#ifdef KR_TW_TRACE
+            const long long tb0 = wall_clock64();
+#endif
+            const int need = t0 - YR + 1;                                  // a sibling reads my step p at its step p - 7
+            for (int budget = 1 << 24; need > 0 && budget > 0; --budget) {
+                bool ok = true;
+                if (cons_a >= 0) ok = ok && max(tq_peek(&taken[cons_a]) - 1, 0) * C >= need;
+                if (cons_b >= 0) ok = ok && max(tq_peek(&taken[cons_b]) - 1, 0) * C >= need;
+                if (exp_a >= 0) ok = ok && tq_peek(&exported[exp_a]) >= need + 7;
+                if (exp_b >= 0) ok = ok && tq_peek(&exported[exp_b]) >= need + 7;
+                if (ok || tq_peek(&quit)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            TQ_ACC(13, tb0);
+        }
+        if (kc == 0 && q == 0 && l == 0)                                   // this block is under way: the blocks behind it may start asking
+            __hip_atomic_store(&flags[blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double yv[C];
+#pragma unroll
+        for (int u = 0; u < C; ++u) {
+            const int t = t0 + u;
+            if (t >= seen) {                                               // rows of the west / south neighbours for this step not yet known to be there
+#ifdef KR_TW_TRACE
+                const long long tw0 = wall_clock64();
+#endif
+                for (int budget = 1 << 26; budget > 0; --budget) {
+                    seen = __builtin_amdgcn_readfirstlane(min(tq_peek(w_cnt) - w_off, tq_peek(s_cnt) - s_off));
+                    if (t < seen) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                TQ_ACC(11, tw0);
+            }
+            const double wv = w_ptr[((t + w_off) & w_mask) * w_stride], sv = s_ptr[((t + s_off) & s_mask) * s_stride];
+            double yj = tw_bperm(idx1, y), yk = tw_bperm(idx8, y);
+            if (jl == 0) yj = wv;
+            if (kl == 0) yk = sv;
+            const double a1 = (u & 1) ? cf.a[0][u >> 1].y : cf.a[0][u >> 1].x, a2 = (u & 1) ? cf.a[1][u >> 1].y : cf.a[1][u >> 1].x;
+            const double a3 = (u & 1) ? cf.a[2][u >> 1].y : cf.a[2][u >> 1].x;
+            yj = a2 != 0.0 ? yj : 0.0;                                     // absent entry (coefficient +0.0): operand +0.0, s unchanged
+            yk = a3 != 0.0 ? yk : 0.0;
+            const double yi = a1 != 0.0 ? y : 0.0;
+            double s = rv[u];
+            if (FORWARD) {                                                 // stored order: k-, j-, i-neighbour (ascending column)
+                s = s - a3 * yk; s = s - a2 * yj; s = s - a1 * yi;
+            } else {                                                       // i-, j-, k-neighbour, then the divisor
+                s = s - a1 * yi; s = s - a2 * yj; s = s - a3 * yk;
+                const double dg = (u & 1) ? cf.a[NA - 1][u >> 1].y : cf.a[NA - 1][u >> 1].x;
+                s = s / dg;
+            }
+            y = s;
+            yv[u] = s;
+            my_ring[(t & (YR - 1)) * 64] = s;                              // all 64 rows of the step, one unmasked store;
+            if (l == 0) tq_publish(&prog[q], t + 1);                       // then the count (LDS executes a wave's operations in order)
+        }
+        // ---- results into the caller's vector (natural layout)
+        if (fast_chunk(t0)) {
+            const int64_t lo = line0 + (FORWARD ? t0 - skew : Q.Ni - 1 - (t0 + C - 1 - skew));     // lowest row of the chunk
+#pragma unroll
+            for (int h = 0; h < C / 2; ++h) {
+                tw_v2 v; v.x = yv[FORWARD ? 2 * h : C - 1 - 2 * h]; v.y = yv[FORWARD ? 2 * h + 1 : C - 2 - 2 * h];
+                *(__attribute__((address_space(1))) tw_v2*)(out + lo + 2 * h) = v;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < C; ++u) {
+                const int ii = t0 + u - skew;
+                if (line_ok && ii >= 0 && ii < Q.Ni) out[line0 + (FORWARD ? ii : Q.Ni - 1 - ii)] = yv[u];
+            }
+        }
+        if (kc < 8) TQ_STAMP(2 + kc);
+        if (kc == nch - 1) TQ_STAMP(10);
+    };
+    // Coefficients: chunks kc + 1 and kc + 2 are in flight while chunk kc is computed (an HBM round trip is two chunks of
+    // compute); the requests are unconditional (past the end the last chunk is simply requested again), so that the compiler's
+    // counted vmcnt before the first use of chunk kc's registers leaves the younger loads in flight -- a request issued under a
+    // condition makes it assume the worst and wait for vmcnt(0).  One copy of the step code (the kernel is instruction-cache
+    // sized): the buffers rotate by register moves.
+    Coef cur, n1, n2;
+    TQ_STAMP(0);
+    fetch(cur, 0);
+    fetch(n1, min(1, nch - 1));
+    for (int kc = 0; kc < nch; ++kc) {
+        fetch(n2, min(kc + 2, nch - 1));
+        process(cur, kc);
+        cur = n1; n1 = n2;
+    }
+#ifdef KR_TW_TRACE
+    if (FORWARD && l == 0 && blk < 4096) for (int i = 0; i < 3; ++i) tq_trace[(blk * 4 + q) * 16 + 11 + i] = tq_acc[i];
+#endif
+    // the readers' last 7 steps want my steps T .. T + 6: rows past the end of every line, operands nobody uses
+    if (l == 0) tq_publish(&prog[q], HUGE_STEPS);
+}
+
+}  // namespace kr

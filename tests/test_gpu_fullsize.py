@@ -94,14 +94,14 @@ def test_ilu_apply_inverts_its_factors(ctx):
 
 
 def test_ilu_forms_agree_at_scale(ctx, monkeypatch):
-    """192^3 (7 M rows, 576 line blocks: more than are resident at once): the three-wave wavefront solve, its one-wave
-    predecessor and the level-ordered sync-free solve give the same bits for the same factors."""
+    """192^3 (7 M rows, 576 8 x 8 line blocks: more than are resident at once): the 16 x 16 wavefront solve, the 8 x 8 three-wave
+    solve, its one-wave predecessor and the level-ordered sync-free solve give the same bits for the same factors."""
     M = 192
     a = K.CsrMatrix.stencil7(M, "aniso", ctx=ctx)
     n = a.nrows()
     r = ctx.vec(n).fill_splitmix(11)
     outs = []
-    for grid, wave in (("1", "1"), ("1", "0"), ("0", "1")):
+    for grid, wave in (("1", "2"), ("1", "1"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("KRYST_ILU_GRID", grid); monkeypatch.setenv("KRYST_ILU_WAVE", wave)
         pc = K.TrueIlu0().setup(a)
         z = ctx.vec(n)
@@ -109,7 +109,7 @@ def test_ilu_forms_agree_at_scale(ctx, monkeypatch):
         outs.append(z.to_host())
         del pc
     assert np.all(np.isfinite(outs[0]))
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
 
 
 def test_512_cubed_properties(ctx, monkeypatch):

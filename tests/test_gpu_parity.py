@@ -311,16 +311,17 @@ def test_triangular_solve_forms_bit_exact(ctx, syncfree, monkeypatch):
             assert np.array_equal(pc.apply(r), ref.apply(r)), (syncfree, a.nrows)
 
 
-@pytest.mark.parametrize("grid_path", ["1", "wave0", "0"])
+@pytest.mark.parametrize("grid_path", ["quad", "1", "wave0", "0"])
 def test_structured_grid_triangular_solve_bit_exact(ctx, grid_path, monkeypatch):
     """Factors of 7-point / 5-point operators on an Ni x Nj x Nk box are solved by the pipelined wavefront kernel
     (KRYST_ILU_GRID=1, default): boxes whose sides are not multiples of the 8 x 8 line block, thin and 2-D boxes, and banded
     matrices that LOOK like a grid but wrap around line ends (must be recognised and take the general path).  Both paths
     give the oracle's bits."""
     import scipy.sparse as sp
-    # "1": three-wave wavefront kernel; "wave0": its one-wave predecessor (KRYST_ILU_WAVE=0); "0": level-ordered forms
+    # "quad": 16 x 16 lines per workgroup (tri_quad.h, the default); "1": the 8 x 8 three-wave kernel; "wave0": its one-wave
+    # predecessor (KRYST_ILU_WAVE=0); "0": level-ordered forms
     monkeypatch.setenv("KRYST_ILU_GRID", "0" if grid_path == "0" else "1")
-    monkeypatch.setenv("KRYST_ILU_WAVE", "0" if grid_path == "wave0" else "1")
+    monkeypatch.setenv("KRYST_ILU_WAVE", {"wave0": "0", "1": "1"}.get(grid_path, "2"))
     rng = np.random.default_rng(5)
 
     def box(Ni, Nj, Nk, wrap=False):
@@ -370,18 +371,20 @@ def test_structured_grid_solve_random_boxes_and_missing_entries(ctx, seed, monke
         a = O.Csr(n, n, m.indptr, m.indices, m.data)
         d = to_dev(ctx, a)
         r = rng.standard_normal(n)
-        for wave in ("1", "0"):
+        for wave in ("2", "1", "0"):
             monkeypatch.setenv("KRYST_ILU_WAVE", wave)
             for kpc, ofn in ((K.TrueIlu0(), O.Pc.ilu0_true), (K.Ilu0(), O.Pc.ilu0_compat), (K.Ilup(0), O.Pc.ilup0)):
                 assert np.array_equal(kpc.setup(d).apply(r), ofn(a).apply(r)), (seed, (Ni, Nj, Nk), wave)
 
 
-def test_wavefront_give_up_path_falls_back_to_plane_kernels(ctx, rs, monkeypatch):
+@pytest.mark.parametrize("wave", ["1", "2"])
+def test_wavefront_give_up_path_falls_back_to_plane_kernels(ctx, rs, wave, monkeypatch):
     """The wavefront triangular solve waits for neighbour blocks and so relies on in-order workgroup dispatch.  With a poll
     budget of ONE empty poll every block gives up at once (NaN results on the device): the host must notice (mapped give-up
     word), discard the result and repeat the work with the plane kernels (one launch per hyperplane, no inter-workgroup
     waits) -- the caller sees the oracle's bits, from pc.apply and from whole solves, and never a NaN."""
     monkeypatch.setenv("KRYST_ILU_POLL_BUDGET", "1")
+    monkeypatch.setenv("KRYST_ILU_WAVE", wave)                     # the 8 x 8 (tri_wave.h) and the 16 x 16 (tri_quad.h) kernel
     ao = O.stencil7(24, "aniso")
     a = to_dev(ctx, ao)
     r = O.splitmix64_uniform(7, ao.nrows) - 0.5
