@@ -705,6 +705,57 @@ static FlatRows flatten(const RowLists& r) {
 }
 
 // shared tail of every ILU-family setup: level-order both factors and hand out the preconditioner object
+// device buffers every ILU-family preconditioner needs once its factors are on the device (grid form or level-ordered form)
+static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
+    kryst_ctx_t ctx = pc->ctx;
+    const int64_t n = D->n;
+    int32_t rc = KRYST_OK;
+    if (hipMalloc(&D->d_args, sizeof(TriArgs)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+    if (rc == KRYST_OK) {
+        const size_t bytes = sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
+        const bool grid = D->GL.ok && D->GU.ok;                            // the wavefront solve works in place: one intermediate vector
+        for (double** pp : {&D->d_y, &D->d_rL, &D->d_yU, &D->d_zU}) {
+            if (rc != KRYST_OK) break;
+            if (grid && pp != &D->d_y) continue;
+            if (hipMalloc(pp, bytes) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+            else if (hipMemsetAsync(*pp, 0, bytes, ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
+        }
+        if (rc == KRYST_OK && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
+    }
+    if (rc == KRYST_OK && D->GL.ok && D->GU.ok) {
+        const size_t nb = (size_t)((D->GL.Nj + 7) / 8) * (size_t)((D->GL.Nk + 7) / 8);
+        if (hipMalloc(&D->d_flags, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (rc == KRYST_OK && (hipHostMalloc((void**)&D->h_gave_up, 64, hipHostMallocMapped) != hipSuccess ||
+                               hipHostGetDevicePointer((void**)&D->d_gave_up, D->h_gave_up, 0) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (rc == KRYST_OK) *D->h_gave_up = 0;
+        if (rc == KRYST_OK && D->GL.Ni >= 2 && env_i("KRYST_ILU_WAVE", nb > 1024 ? 2 : 1) >= 2) {
+            // blocked coefficient layout + edge buffers of the 16 x 16 kernel (tri_quad.h), one device pass per factor
+            for (GridFactor* G : {&D->GL, &D->GU}) {
+                if (rc != KRYST_OK) break;
+                const bool fwd = G == &D->GL;
+                G->nbj = (G->Nj + 15) / 16; G->nbk = (G->Nk + 15) / 16; G->nch = (G->Ni + 14 + TQ_C - 1) / TQ_C;
+                const size_t nq = (size_t)G->nbj * G->nbk;
+                const int NA = fwd ? 3 : 4;
+                const size_t cbytes = nq * G->nch * NA * 4 * TQ_LINES * sizeof(tw_v2);
+                const size_t ebytes = nq * (size_t)(G->nch * TQ_C + 8) * 16 * sizeof(double);
+                if (hipMalloc(&G->d_blocked, cbytes) != hipSuccess || hipMalloc(&G->d_edge_e, ebytes) != hipSuccess ||
+                    hipMalloc(&G->d_edge_n, ebytes) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; break; }
+                const GridView V{G->Ni, G->Nj, G->Nk, G->d_c1, G->d_c2, G->d_c3, G->d_diag};
+                const unsigned lg = (unsigned)(nq * G->nch);
+                if (fwd) hipLaunchKernelGGL((tri_quad_layout_kernel<true, 3>), dim3(lg), dim3(256), 0, ctx->s_main, V, G->nbj, G->nbk, G->nch, (tw_v2*)G->d_blocked);
+                else hipLaunchKernelGGL((tri_quad_layout_kernel<false, 4>), dim3(lg), dim3(256), 0, ctx->s_main, V, G->nbj, G->nbk, G->nch, (tw_v2*)G->d_blocked);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("blocked layout kernel failed"); rc = KRYST_ERR_HIP; }
+            }
+        }
+    }
+    if (getenv("KRYST_ILU_VERBOSE"))
+        fprintf(stderr, "[kryst ilu] n=%lld %s; levels L/U=%zu/%zu\n", (long long)n, D->GL.ok ? "structured grid (wavefront kernel)" : "level-ordered",
+                D->L.lvl_off.empty() ? (size_t)0 : D->L.lvl_off.size() - 1, D->U.lvl_off.empty() ? (size_t)0 : D->U.lvl_off.size() - 1);
+    return rc;
+}
+
+// shared tail of every host-side ILU-family setup: recognise a structured grid or level-order both factors, then hand out the
+// preconditioner object
 static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRows& le, const FlatRows& ue,
                              const std::vector<double>& dg, kryst_pc_t* out) {
     kryst_ctx_t ctx = a->ctx;
@@ -730,47 +781,216 @@ static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRow
             rc = up(&D->d_mapLU, mapLU);
         }
     }
-    if (rc == KRYST_OK && hipMalloc(&D->d_args, sizeof(TriArgs)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+    if (rc == KRYST_OK) rc = finish_ilu_device(pc, D);
+    if (rc != KRYST_OK) { kryst_pc_destroy(pc); return rc; }
+    *out = pc;
+    return KRYST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Device-side setup for grid operators.  A matrix whose stored entries couple row (i,j,k) of an Ni x Nj x Nk box only to itself
+// and its six axis neighbours, in natural ordering (recognised from the CSR-D8 offset dictionary: at most the offsets 0, +-1,
+// +-Ni, +-Ni*Nj, no entry wrapping around a line end), never leaves the GPU: one pass pulls the seven coefficient streams out
+// of the CSR arrays, the compat / Ilup(0) factors are pointwise quotients, and the textbook ILU(0) -- on this pattern only the
+// DIAGONAL is ever updated, u_dd(i) = a_dd - sum_c l_ic u_ci over the lower neighbours c in ascending column order -- is a
+// recurrence over the hyperplanes i + j + k = const: one small launch per plane (766 at 256^3, ~3 ms).  Same operations in the
+// same order as the host loops above (which remain for every other matrix): same bits.  256^3: 1.8 s -> a few ms.
+struct GridStreams {                 // natural row order, n entries each; absent entry = 0.0 and its presence bit clear
+    double *km, *jm, *im, *dd, *ip, *jp, *kp; uint8_t* have;     // presence bits: 0 km, 1 jm, 2 im, 3 dd, 4 ip, 5 jp, 6 kp
+};
+
+__global__ __launch_bounds__(256) void grid_extract_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                           int64_t n, int32_t s1, int64_t s2, GridStreams G, int32_t* reject) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned have = 0;
+    const int32_t ii = (int32_t)(i % s1), jx = (int32_t)((i / s1) % (s2 / s1));
+    const int32_t nj = (int32_t)(s2 / s1);
+    bool bad = false;
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+        const int64_t o = (int64_t)col[k] - i;
+        int slot = -1;
+        if (o == -s2) slot = 0; else if (o == -(int64_t)s1) slot = 1; else if (o == -1) slot = 2; else if (o == 0) slot = 3;
+        else if (o == 1) slot = 4; else if (o == (int64_t)s1) slot = 5; else if (o == s2) slot = 6;
+        if (slot < 0) { bad = true; continue; }
+        // an entry must stay on its grid line / plane (a band that wraps around a line end is not a grid operator)
+        if ((slot == 2 && ii == 0) || (slot == 4 && ii == s1 - 1) || (slot == 1 && jx == 0) || (slot == 5 && jx == nj - 1)) bad = true;
+        v[slot] = val[k]; have |= 1u << slot;
+    }
+    if (bad) atomicOr(reject, 1);
+    G.km[i] = v[0]; G.jm[i] = v[1]; G.im[i] = v[2]; G.dd[i] = v[3]; G.ip[i] = v[4]; G.jp[i] = v[5]; G.kp[i] = v[6];
+    G.have[i] = (uint8_t)have;
+}
+
+// which of the 256 offset codes occur at all (the stencil generator's dictionary also lists halo offsets it may not use)
+__global__ __launch_bounds__(256) void code_usage_kernel(const uint8_t* __restrict__ code, int64_t nnz, int32_t* used) {
+    __shared__ int32_t mine[256];
+    mine[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * 256) mine[code[k]] = 1;
+    __syncthreads();
+    if (mine[threadIdx.x]) used[threadIdx.x] = 1;
+}
+
+// Ilu0 as written (mode 0) and Ilup::new(0) (mode 1): l_ij = a_ij / a_jj for stored nonzeros below the diagonal, U = triu(A)
+// (ilu.rs:76-80, ilup.rs:104-111); bad_row: lowest row whose pivot is zero (Ilup only, ilup.rs:106-108)
+__global__ __launch_bounds__(256) void grid_pointwise_factor_kernel(GridStreams G, int64_t n, int32_t s1, int64_t s2, int mode,
+                                                                    double* l1, double* l2, double* l3, double* u1, double* u2, double* u3, double* dg,
+                                                                    long long* bad_row) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned have = G.have[i];
+    const double a[3] = {G.km[i], G.jm[i], G.im[i]};
+    const int64_t nb[3] = {i - s2, i - s1, i - 1};
+    double l[3];
+    bool zero_pivot = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        l[c] = 0.0;
+        if (((have >> c) & 1u) && a[c] != 0.0) {
+            const double ujj = (G.have[nb[c]] & 8u) ? G.dd[nb[c]] : 0.0;
+            if (mode == KRYST_ILU_ILUP0 && ujj == 0.0) zero_pivot = true;
+            l[c] = a[c] / ujj;
+        }
+    }
+    if (zero_pivot) atomicMin((unsigned long long*)bad_row, (unsigned long long)i);
+    auto kept = [](double x) { return x == 0.0 ? 0.0 : x; };               // a zero entry (either sign) is not kept: +0.0 = "no entry"
+    l3[i] = kept(l[0]); l2[i] = kept(l[1]); l1[i] = kept(l[2]);            // coefficient of the k- / j- / i-neighbour
+    u1[i] = kept(G.ip[i]); u2[i] = kept(G.jp[i]); u3[i] = kept(G.kp[i]);
+    dg[i] = (mode != KRYST_ILU_KRYST_COMPAT && (have & 8u)) ? G.dd[i] : 1.0;   // ilu.rs:115-119 never divides; ilup.rs:160-164 (missing diagonal: no divide)
+}
+
+// Textbook ILU(0), the rows of ONE hyperplane (they only need lower planes): the host loop's operations in its order --
+// for c ascending: pivot check, l = a_ic / u_cc, then u_ii -= l * u_ci when row c reaches i and row i has a diagonal.
+__global__ __launch_bounds__(256) void grid_true_ilu0_plane_kernel(GridStreams G, int32_t Ni, int32_t Nj, int32_t Nk, int level,
+                                                                   double* wdd, double* l1, double* l2, double* l3, long long* bad_key) {
+    const int jk = blockIdx.x * 256 + threadIdx.x;
+    if (jk >= Nj * Nk) return;
+    const int j = jk % Nj, k = jk / Nj, ii = level - j - k;
+    if (ii < 0 || ii >= Ni) return;
+    const int64_t s1 = Ni, s2 = (int64_t)Ni * Nj, i = ii + s1 * j + s2 * k;
+    const unsigned have = G.have[i];
+    const double a[3] = {G.km[i], G.jm[i], G.im[i]};
+    const int64_t nb[3] = {i - s2, i - s1, i - 1};
+    const double* up[3] = {G.kp, G.jp, G.ip};                              // row c's entry that points at row i
+    const unsigned upbit[3] = {64u, 32u, 16u};
+    double wd = G.dd[i];
+    double l[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (!((have >> c) & 1u)) continue;
+        const unsigned hc = G.have[nb[c]];
+        const double piv = wdd[nb[c]];
+        if (!(hc & 8u) || piv == 0.0) atomicMin((unsigned long long*)bad_key, (unsigned long long)(i * 4 + c));
+        l[c] = a[c] / piv;
+        if ((hc & upbit[c]) && (have & 8u)) wd = wd - l[c] * up[c][nb[c]];
+    }
+    wdd[i] = wd;
+    auto kept = [](double x) { return x == 0.0 ? 0.0 : x; };
+    l3[i] = kept(l[0]); l2[i] = kept(l[1]); l1[i] = kept(l[2]);
+}
+
+// -> KRYST_OK and *out set when the operator was handled on the device; *out left null when it is not a grid operator (the host
+// path takes over); an error code for a zero pivot.
+static int32_t grid_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out) {
+    *out = nullptr;
+    kryst_ctx_t ctx = a->ctx;
+    const int64_t n = a->nrows;
+    if (a->dist || !a->d_dict || !a->d_code || n < 27 || n >= (1ll << 31) || env_i("KRYST_ILU_GRID", 1) == 0 || env_i("KRYST_ILU_DEVICE_SETUP", 1) == 0)
+        return KRYST_OK;
+    int32_t dict[256], used[256];
+    {
+        int32_t* d_used = nullptr;
+        KR_HIP(hipMalloc(&d_used, sizeof used));
+        (void)hipMemsetAsync(d_used, 0, sizeof used, ctx->s_main);
+        hipLaunchKernelGGL(code_usage_kernel, dim3((unsigned)std::min<int64_t>(4096, (a->nnz + 255) / 256 + 1)), dim3(256), 0, ctx->s_main, a->d_code, a->nnz, d_used);
+        const hipError_t e1 = hipMemcpyAsync(used, d_used, sizeof used, hipMemcpyDeviceToHost, ctx->s_main);
+        const hipError_t e2 = hipMemcpyAsync(dict, a->d_dict, sizeof dict, hipMemcpyDeviceToHost, ctx->s_main);
+        const hipError_t e3 = hipStreamSynchronize(ctx->s_main);
+        (void)hipFree(d_used);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { set_error("code usage scan failed"); return KRYST_ERR_HIP; }
+    }
+    int64_t offs[3] = {0, 0, 0}; int no = 0;
+    for (int q = 0; q < 256; ++q) {
+        if (!used[q]) continue;
+        const int64_t ao = dict[q] < 0 ? -(int64_t)dict[q] : dict[q];
+        if (ao == 0) continue;
+        bool seen = false;
+        for (int r = 0; r < no; ++r) seen = seen || offs[r] == ao;
+        if (!seen) { if (no == 3) return KRYST_OK; offs[no++] = ao; }
+    }
+    std::sort(offs, offs + no);
+    if (no < 2 || offs[0] != 1) return KRYST_OK;
+    const int64_t s1 = offs[1], s2 = no == 3 ? offs[2] : n;
+    // Ni >= 3 and Nj >= 3 (in 3-D): with a dimension of 2 a lower neighbour's row reaches a SECOND entry of row i and the
+    // elimination is no longer confined to the diagonal
+    if (s1 < 3 || s2 % s1 != 0 || n % s2 != 0 || s2 <= s1 || (no == 3 && s2 / s1 < 3)) return KRYST_OK;
+    const int32_t Ni = (int32_t)s1, Nj = (int32_t)(s2 / s1), Nk = (int32_t)(n / s2);
+    const bool verbose = getenv("KRYST_ILU_VERBOSE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    // ---- seven coefficient streams + presence bits
+    GridStreams G{};
+    double* work[8] = {};
+    struct Guard { double** w; uint8_t** h; long long** f; int32_t** r; ~Guard() { for (int i = 0; i < 8; ++i) (void)hipFree(w[i]); (void)hipFree(*h); (void)hipFree(*f); (void)hipFree(*r); } };
+    uint8_t* d_have = nullptr; long long* d_flag = nullptr; int32_t* d_reject = nullptr;
+    Guard guard{work, &d_have, &d_flag, &d_reject};
+    const size_t vb = sizeof(double) * (size_t)(n + 8);
+    for (int q = 0; q < 8; ++q) KR_HIP(hipMalloc(&work[q], vb));
+    KR_HIP(hipMalloc(&d_have, (size_t)n + 8)); KR_HIP(hipMalloc(&d_flag, 16)); KR_HIP(hipMalloc(&d_reject, 4));
+    KR_HIP(hipMemsetAsync(d_reject, 0, 4, ctx->s_main));
+    KR_HIP(hipMemsetAsync(d_flag, 0xff, 16, ctx->s_main));
+    G.km = work[0]; G.jm = work[1]; G.im = work[2]; G.dd = work[3]; G.ip = work[4]; G.jp = work[5]; G.kp = work[6]; G.have = d_have;
+    const unsigned rg = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(grid_extract_kernel, dim3(rg), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, a->d_val, n, Ni, s2, G, d_reject);
+    KR_HIP(hipGetLastError());
+    int32_t reject = 0;
+    KR_HIP(hipMemcpyAsync(&reject, d_reject, 4, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    if (reject) return KRYST_OK;                                           // bands that wrap around line ends: the host path (level-ordered)
+    // ---- the preconditioner object with its natural-order factor streams
+    kryst_pc_t pc = new kryst_pc_s();
+    const bool divide = mode != KRYST_ILU_KRYST_COMPAT;
+    pc->ctx = ctx; pc->kind = KR_PC_ILU; pc->a = a; pc->n = n; pc->ilu_mode = mode; pc->divide_diag = divide;
+    IluData* D = new IluData();
+    D->n = n;
+    pc->d_work = reinterpret_cast<double*>(D);
+    int32_t rc = KRYST_OK;
+    for (double** pp : {&D->GL.d_c1, &D->GL.d_c2, &D->GL.d_c3, &D->GU.d_c1, &D->GU.d_c2, &D->GU.d_c3, &D->GU.d_diag})
+        if (rc == KRYST_OK && hipMalloc(pp, vb) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
     if (rc == KRYST_OK) {
-        const size_t bytes = sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
-        const bool grid = D->GL.ok && D->GU.ok;                            // the wavefront solve works in place: one intermediate vector
-        for (double** pp : {&D->d_y, &D->d_rL, &D->d_yU, &D->d_zU}) {
-            if (rc != KRYST_OK) break;
-            if (grid && pp != &D->d_y) continue;
-            if (hipMalloc(pp, bytes) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
-            else if (hipMemsetAsync(*pp, 0, bytes, ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
+        if (mode == KRYST_ILU_TRUE_ILU0) {
+            double* wdd = work[7];
+            const unsigned pg = (unsigned)(((int64_t)Nj * Nk + 255) / 256);
+            for (int lv = 0; lv < Ni + Nj + Nk - 2; ++lv)
+                hipLaunchKernelGGL(grid_true_ilu0_plane_kernel, dim3(pg), dim3(256), 0, ctx->s_main, G, Ni, Nj, Nk, lv, wdd, D->GL.d_c1, D->GL.d_c2, D->GL.d_c3, d_flag);
+            // U = the upper entries of A (never touched on this pattern) and, as divisor, the eliminated diagonal where the row
+            // has one, else 1 (ilup.rs:160-164): the pointwise kernel with the eliminated diagonal in place of A's (mode -1: its
+            // L outputs go to scratch that is no longer needed)
+            hipLaunchKernelGGL(grid_pointwise_factor_kernel, dim3(rg), dim3(256), 0, ctx->s_main,
+                               GridStreams{G.km, G.jm, G.im, wdd, G.ip, G.jp, G.kp, G.have}, n, Ni, s2, -1,
+                               work[0], work[1], work[2], D->GU.d_c1, D->GU.d_c2, D->GU.d_c3, D->GU.d_diag, d_flag + 1);
+        } else {
+            hipLaunchKernelGGL(grid_pointwise_factor_kernel, dim3(rg), dim3(256), 0, ctx->s_main, G, n, Ni, s2, mode,
+                               D->GL.d_c1, D->GL.d_c2, D->GL.d_c3, D->GU.d_c1, D->GU.d_c2, D->GU.d_c3, D->GU.d_diag, d_flag);
         }
-        if (rc == KRYST_OK && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
+        if (rc == KRYST_OK && hipGetLastError() != hipSuccess) rc = KRYST_ERR_HIP;
     }
-    if (rc == KRYST_OK && D->GL.ok && D->GU.ok) {
-        const size_t nb = (size_t)((D->GL.Nj + 7) / 8) * (size_t)((D->GL.Nk + 7) / 8);
-        if (hipMalloc(&D->d_flags, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
-        if (rc == KRYST_OK && (hipHostMalloc((void**)&D->h_gave_up, 64, hipHostMallocMapped) != hipSuccess ||
-                               hipHostGetDevicePointer((void**)&D->d_gave_up, D->h_gave_up, 0) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = KRYST_ERR_HIP; }
-        if (rc == KRYST_OK) *D->h_gave_up = 0;
-        if (rc == KRYST_OK && D->GL.Ni >= 2 && env_i("KRYST_ILU_WAVE", (size_t)((D->GL.Nj + 7) / 8) * (size_t)((D->GL.Nk + 7) / 8) > 1024 ? 2 : 1) >= 2) {
-            // blocked coefficient layout + edge buffers of the 16 x 16 kernel (tri_quad.h), one device pass per factor
-            for (GridFactor* G : {&D->GL, &D->GU}) {
-                if (rc != KRYST_OK) break;
-                const bool fwd = G == &D->GL;
-                G->nbj = (G->Nj + 15) / 16; G->nbk = (G->Nk + 15) / 16; G->nch = (G->Ni + 14 + TQ_C - 1) / TQ_C;
-                const size_t nq = (size_t)G->nbj * G->nbk;
-                const int NA = fwd ? 3 : 4;
-                const size_t cbytes = nq * G->nch * NA * 4 * TQ_LINES * sizeof(tw_v2);
-                const size_t ebytes = nq * (size_t)(G->nch * TQ_C + 8) * 16 * sizeof(double);
-                if (hipMalloc(&G->d_blocked, cbytes) != hipSuccess || hipMalloc(&G->d_edge_e, ebytes) != hipSuccess ||
-                    hipMalloc(&G->d_edge_n, ebytes) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; break; }
-                const GridView V{G->Ni, G->Nj, G->Nk, G->d_c1, G->d_c2, G->d_c3, G->d_diag};
-                const unsigned lg = (unsigned)(nq * G->nch);
-                if (fwd) hipLaunchKernelGGL((tri_quad_layout_kernel<true, 3>), dim3(lg), dim3(256), 0, ctx->s_main, V, G->nbj, G->nbk, G->nch, (tw_v2*)G->d_blocked);
-                else hipLaunchKernelGGL((tri_quad_layout_kernel<false, 4>), dim3(lg), dim3(256), 0, ctx->s_main, V, G->nbj, G->nbk, G->nch, (tw_v2*)G->d_blocked);
-                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("blocked layout kernel failed"); rc = KRYST_ERR_HIP; }
-            }
-        }
+    long long flag[2] = {-1, -1};
+    if (rc == KRYST_OK && (hipMemcpyAsync(flag, d_flag, 16, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK && flag[0] != -1) {
+        if (mode == KRYST_ILU_TRUE_ILU0) {
+            const long long i = flag[0] / 4; const int c = (int)(flag[0] % 4);
+            const long long row = c == 0 ? i - s2 : c == 1 ? i - s1 : i - 1;
+            set_error("ILU(0): zero pivot at row %lld", row); set_error_row(row); rc = KRYST_ZERO_PIVOT;
+        } else { set_error("ILUP: zero diagonal in U (first at row %lld)", flag[0]); rc = KRYST_SOLVE_ERROR; }
     }
-    if (getenv("KRYST_ILU_VERBOSE"))
-        fprintf(stderr, "[kryst ilu] n=%lld %s; levels L/U=%zu/%zu\n", (long long)n, D->GL.ok ? "structured grid (wavefront kernel)" : "level-ordered",
-                D->L.lvl_off.empty() ? (size_t)0 : D->L.lvl_off.size() - 1, D->U.lvl_off.empty() ? (size_t)0 : D->U.lvl_off.size() - 1);
+    if (rc == KRYST_OK) {
+        D->GL.Ni = D->GU.Ni = Ni; D->GL.Nj = D->GU.Nj = Nj; D->GL.Nk = D->GU.Nk = Nk; D->GL.ok = D->GU.ok = true;
+        rc = finish_ilu_device(pc, D);
+    }
+    if (verbose) fprintf(stderr, "[kryst ilu] device-side setup of a %d x %d x %d grid operator: %.1f ms\n", Ni, Nj, Nk,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (rc != KRYST_OK) { kryst_pc_destroy(pc); return rc; }
     *out = pc;
     return KRYST_OK;
@@ -787,6 +1007,11 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
     KR_ARG(a->nrows == a->xlen, "pc_ilu0: square operator required");
     kryst_ctx_t ctx = a->ctx;
     KR_HIP(hipSetDevice(ctx->device));
+    {   // grid operators are factored on the device (no download, no host loops)
+        kryst_pc_t pc = nullptr;
+        KR_TRY(grid_setup_on_device(a, mode, &pc));
+        if (pc) { *out = pc; return KRYST_OK; }
+    }
     const int64_t n = a->nrows, nnz = a->nnz;
     const bool verbose = getenv("KRYST_ILU_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };

@@ -412,6 +412,62 @@ def test_wavefront_give_up_path_falls_back_to_plane_kernels(ctx, rs, wave, monke
     assert e.value.code == 2
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_device_side_grid_setup_equals_host_setup(ctx, seed, monkeypatch):
+    """Grid operators are factored on the device (grid_setup_on_device: coefficient streams pulled out of the CSR arrays, compat /
+    Ilup(0) quotients pointwise, textbook ILU(0) as a recurrence over hyperplanes); KRYST_ILU_DEVICE_SETUP=0 keeps the host loops.
+    Both must give the oracle's bits -- random boxes, random coefficients, randomly MISSING couplings and missing diagonals'
+    neighbours, stored zeros -- and report the same zero pivot."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(500 + seed)
+    for _ in range(4):
+        Ni, Nj, Nk = (int(v) for v in rng.integers(3, 30, 3))
+        if rng.random() < 0.25:
+            Nk = 1                                                             # 2-D operators too
+        n = Ni * Nj * Nk
+        idx = np.arange(n).reshape(Nk, Nj, Ni)
+        rows, cols, vals = [np.arange(n)], [np.arange(n)], [rng.uniform(6.5, 8.0, n)]
+        for lo, hi in ((idx[:, :, :-1], idx[:, :, 1:]), (idx[:, :-1, :], idx[:, 1:, :]), (idx[:-1, :, :], idx[1:, :, :])):
+            lo, hi = lo.ravel(), hi.ravel()
+            for a_, b_ in ((lo, hi), (hi, lo)):
+                keep = rng.random(len(a_)) > 0.2
+                v = rng.uniform(-1.0, 1.0, int(keep.sum()))
+                v[rng.random(len(v)) < 0.05] = 0.0                             # stored zeros: eliminated like any entry, never kept
+                rows.append(a_[keep]); cols.append(b_[keep]); vals.append(v)
+        m = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+        m.sort_indices()
+        a = O.Csr(n, n, m.indptr, m.indices, m.data)
+        d = to_dev(ctx, a)
+        r = rng.standard_normal(n)
+        for kpc, ofn in ((K.TrueIlu0, O.Pc.ilu0_true), (K.Ilu0, O.Pc.ilu0_compat), (lambda: K.Ilup(0), O.Pc.ilup0)):
+            ref = ofn(a).apply(r)
+            for dev in ("1", "0"):
+                monkeypatch.setenv("KRYST_ILU_DEVICE_SETUP", dev)
+                assert np.array_equal(kpc().setup(d).apply(r), ref), (seed, (Ni, Nj, Nk), dev)
+    # a zero pivot in the middle of a grid: u_dd(row) = a_dd - l * u = 0 exactly; both paths name the same row
+    Ni, Nj, Nk = 5, 4, 3
+    n = Ni * Nj * Nk
+    main = np.full(n, 4.0)
+    m = sp.diags([main, -np.ones(n - 1), -np.ones(n - 1)], [0, -1, 1]).tolil()
+    for i in range(Ni, n, Ni):
+        m[i, i - 1] = 0.0; m[i - 1, i] = 0.0                                   # no coupling across line ends
+    m = m.tocsr(); m.eliminate_zeros()
+    m = (m + sp.diags([-np.ones(n - Ni), -np.ones(n - Ni)], [-Ni, Ni])).tolil()
+    for k in range(1, Nk):
+        for i in range(Ni):
+            m[k * Ni * Nj + i, k * Ni * Nj + i - Ni] = 0.0; m[k * Ni * Nj + i - Ni, k * Ni * Nj + i] = 0.0
+    m = m.tocsr(); m.eliminate_zeros()
+    m = m.tolil()
+    m[1, 1] = 0.25                                                             # row 1: u_11 = 0.25 - (-1/4)(-1) = 0
+    m = m.tocsr(); m.sort_indices()
+    d = to_dev(ctx, O.Csr(n, n, m.indptr, m.indices, m.data))
+    for dev in ("1", "0"):
+        monkeypatch.setenv("KRYST_ILU_DEVICE_SETUP", dev)
+        with pytest.raises(K.KError) as e:
+            K.TrueIlu0().setup(d)
+        assert e.value.code == 5 and e.value.row == 1, dev
+
+
 def test_plane_kernels_bit_exact(ctx, monkeypatch):
     """KRYST_ILU_PLANES=1: the fallback of the wavefront solve on its own, ragged boxes included."""
     monkeypatch.setenv("KRYST_ILU_PLANES", "1")
