@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     __shared__ int pavail[4];                                              // consumer steps each poller stream has delivered
     __shared__ int taken[4];                                               // chunks each solving wave has taken off the stage
     __shared__ int exported[4];                                            // producer steps each exporter stream has written to the edge buffers
-    __shared__ int staged[2], quit, always;                                // chunks each loader wave has staged (quadrants 0-1 / 2-3)
+    __shared__ int staged[2], quit, always, gate;                          // gate: the producers are under way (set by the poller)                                // chunks each loader wave has staged (quadrants 0-1 / 2-3)
     cgdouble* in = (cgdouble*)(in_ptr ? in_ptr : args->r);
     gdouble* out = (gdouble*)(out_ptr ? out_ptr : args->z);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // 0-3 solve, 4-5 load the right-hand side (128 lines each), 6 polls, 7 exports
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         // exporter streams: 0 east rows of q1, 1 east rows of q3, 2 north rows of q2, 3 north rows of q3
         exported[i] = (i < 2 ? J + 1 < Q.nbj : K + 1 < Q.nbk) ? 0 : HUGE_STEPS;
     }
-    if (threadIdx.x == 0) { staged[0] = 0; staged[1] = 0; quit = 0; always = HUGE_STEPS; }
+    if (threadIdx.x == 0) { staged[0] = 0; staged[1] = 0; quit = 0; always = HUGE_STEPS; gate = (J == 0 && K == 0) ? 1 : 0; }
     for (int i = threadIdx.x; i < 4 * R * 8; i += 512) pring[i] = 0.0;
     for (int i = threadIdx.x; i < 4 * YR * 64; i += 512) yring[i] = 0.0;
     __syncthreads();                                                      // the only barrier
@@ -246,6 +246,9 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             }
             tq_publish(&staged[half], kc + 1);
         };
+        // nothing is requested before the blocks this one depends on are under way: a block that will not run for another
+        // 100 us must not queue its first chunks in front of the blocks at the front
+        for (int budget = 1 << 24; tq_peek(&gate) == 0 && budget > 0; --budget) __builtin_amdgcn_s_sleep(8);
         Buf b0, b1, b2;                                                    // chunk kc lives in buffer kc % 3
         fetch(b0, 0);
         if (1 < nch) fetch(b1, C);
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
                 if ((budget & 63) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                 __builtin_amdgcn_s_sleep(8);
             }
+            tq_publish(&gate, 1);
         }
         int t = has_src ? 0 : T;                                           // next consumer step of this lane's stream
         for (int budget = poll_budget; budget > 0;) {
@@ -476,6 +480,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     // condition makes it assume the worst and wait for vmcnt(0).  One copy of the step code (the kernel is instruction-cache
     // sized): the buffers rotate by register moves.
     Coef cur, n1, n2;
+    for (int budget = 1 << 24; tq_peek(&gate) == 0 && budget > 0; --budget) __builtin_amdgcn_s_sleep(8);     // (see the loader)
     TQ_STAMP(0);
     fetch(cur, 0);
     fetch(n1, min(1, nch - 1));

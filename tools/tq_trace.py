@@ -29,6 +29,8 @@ t0 = t[:, :, 0].min()
 print(f"N {N}: {nb} blocks, {nch} chunks per block; times in us after the first entry")
 print("block  J  K  q | entry  coef  chunk0 chunk1 chunk2 chunk3 ... end | wait: nbr stage ring | us/chunk (chunks 4..end)")
 show = [b for b in range(nb) if b < 3 or b % nbj == b // nbj or b == nb - 1]
+if len(sys.argv) > 2:
+    show = [int(v.split(',')[1]) * nbj + int(v.split(',')[0]) for v in sys.argv[2:]]
 for b in show:
     for q in range(4):
         x = t[b, q]
