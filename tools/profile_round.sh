@@ -18,6 +18,9 @@ unset KRYST_SPMV_COMPRESS
 cp $O/spmv_traffic.json $R/profiles/spmv_traffic.json
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_prof -o bench -- python3 $R/bench.py > $O/bench_prof.log 2>&1 || exit 1
 python3 $R/tools/kernel_by_size.py $O/bench_prof $O/bench_default_kernel_by_size.csv || exit 1
+for g in 256 512; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ilu_prof_$g -o ilu -- python3 $R/tools/ilu_only.py $g 20 true > $O/ilu_$g.log 2>&1 || exit 1
+done
 cd $R
 timeout -k 10 900 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err || exit 1
 timeout -k 10 900 python3 tools/bench_configs.py 256 64 > $O/configs_256.jsonl 2> $O/configs.err || exit 1
