@@ -357,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     const int j = FORWARD ? jj : Q.Nj - 1 - jj, k = FORWARD ? kk : Q.Nk - 1 - kk;
     const int64_t line0 = line_ok ? (int64_t)(k * Q.Nj + j) * Q.Ni : 0;
     const bool full = 16 * J + 16 <= Q.Nj && 16 * K + 16 <= Q.Nk;
-    auto fast_chunk = [&](int t0) { return full && t0 >= 14 && t0 + C <= Q.Ni; };
+    auto group_fast = [&](int kc) { return full && kc >= 2 && 8 * kc + 8 <= Q.Ni; };   // every line's result group of this chunk lies in [0, Ni)
     // Where this quadrant's west / south rows come from -- a sibling's result ring (its step t + 7), a poller stream (step t), or
     // nowhere -- as DATA (pointer, step offset, ring mask, stride, counter), so that the step itself has no branch on it.
     const bool w_sib = qj == 1, w_poll = qj == 0 && J > 0, s_sib = qk == 1, s_poll = qk == 0 && K > 0;
@@ -374,38 +374,90 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     const int idx1 = max(l - 1, 0) * 4, idx8 = max(l - 8, 0) * 4;
     cg_v2* const coef = (cg_v2*)Q.coef + (size_t)blk * nch * NA * 4 * TQ_LINES + 64 * q + l;
 
+    // Coefficient requests are issued and waited for BY HAND, like the loader's: the compiler's counted vmcnt does not know how
+    // many result stores lie between two requests (the two store paths differ) and then waits into the youngest request.
     struct Coef { tw_v2 a[NA][4]; };
-    auto fetch = [&](Coef& cf, int kc) {
+    auto fetch = [&](Coef& cf, int kc) __attribute__((always_inline)) {
+#if defined(TQ_ABL) && (TQ_ABL & 2)
+        if (kc > 3) kc = kc & 3;                                           // timing only: the same four chunks again and again (cache hits)
+#endif
         cg_v2* p = coef + (size_t)kc * NA * 4 * TQ_LINES;
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
-            for (int h = 0; h < 4; ++h) cf.a[a][h] = p[(a * 4 + h) * TQ_LINES];
+            for (int h = 0; h < 4; ++h) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cf.a[a][h]) : "v"(p + (a * 4 + h) * TQ_LINES) : "memory");
+    };
+    // before chunk m is computed: vector-memory operations younger than its request = the two later requests (2 * 4 NA loads) and
+    // the result stores of chunks m - 2 and m - 1 -- exactly four each on the fast path, unknown (counted as none) otherwise
+    auto arrive = [&](Coef& cf, int m) __attribute__((always_inline)) {
+#if defined(TQ_ABL) && (TQ_ABL & 1)
+        const int st = 0;
+#else
+        const int st = ((m >= 2 && group_fast(m - 2)) ? 1 : 0) + ((m >= 1 && group_fast(m - 1)) ? 1 : 0);
+#endif
+        if (st == 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 * NA + 8) : "memory");
+        else if (st == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 * NA + 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 * NA) : "memory");
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) asm volatile("" : "+v"(cf.a[a][h]));      // (the values exist from here on)
+    };
+    // Result stores: a line's rows leave in aligned groups of 8 (64 bytes), four lanes per line -- one store instruction writes 16
+    // whole 64-byte segments.  (Each lane storing 16 bytes of ITS line, 64 lines per instruction and four partial writes per
+    // segment, cost 1.5 ms of a 4.2 ms apply at 512^3: these stores sit in the same in-order queue as the coefficient
+    // requests.)  The rows come back out of the ring: line L's group m = kc - ceil(skew_L / 8) is complete after chunk kc.
+    const int sg = l >> 2, sc = l & 3;                                  // store r of a chunk: line L = 16 r + sg of the quadrant, 16-byte piece sc
+    const int g_skew0 = (sg & 7) + (sg >> 3);                             // skew of line L: g_skew0 + 2 r
+    const int g_jj = 16 * J + 8 * qj + (sg & 7), g_kk = 16 * K + 8 * qk + (sg >> 3);      // (whole blocks only: the fast path is not taken otherwise)
+    const int64_t g_line00 = (int64_t)((FORWARD ? g_kk : Q.Nk - 1 - g_kk) * Q.Nj + (FORWARD ? g_jj : Q.Nj - 1 - g_jj)) * Q.Ni;
+    const int64_t g_lstride = (FORWARD ? 2 : -2) * (int64_t)Q.Nj * Q.Ni;  // lines L and L + 16 are two k-planes apart
+    const double* const ring_q = yring + q * YR * 64;
+    auto store_groups = [&](int kc) __attribute__((always_inline)) {
+#if defined(TQ_ABL) && (TQ_ABL & 1)
+        if (group_fast(kc)) return;
+#endif
+        if (group_fast(kc)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int L = 16 * r + sg, gs = g_skew0 + 2 * r, m = kc - ((gs + 7) >> 3);
+                const int ia = FORWARD ? 8 * m + 2 * sc : 8 * m + 7 - 2 * sc, ib = FORWARD ? ia + 1 : ia - 1;     // line rows of the piece, in memory order
+                tw_v2 v;
+                v.x = ring_q[((ia + gs) & (YR - 1)) * 64 + L]; v.y = ring_q[((ib + gs) & (YR - 1)) * 64 + L];
+                const int64_t lo = g_line00 + r * g_lstride + (FORWARD ? 8 * m : Q.Ni - 8 - 8 * m);                              // lowest memory row of the group
+                *(__attribute__((address_space(1))) tw_v2*)(out + lo + 2 * sc) = v;
+            }
+        } else {                                                           // first / last chunks, ragged blocks: this lane's own line, row by row
+            const int m = kc - ((skew + 7) >> 3);
+#pragma unroll
+            for (int u = 0; u < C; ++u) {
+                const int ii = 8 * m + u;
+                if (line_ok && ii >= 0 && ii < Q.Ni) out[line0 + (FORWARD ? ii : Q.Ni - 1 - ii)] = ring_q[((ii + skew) & (YR - 1)) * 64 + l];
+            }
+        }
     };
     double y = 0.0;
     int seen = 0;
 #ifdef KR_TW_TRACE
     long long tq_acc[3] = {0, 0, 0};
 #endif
-    auto process = [&](const Coef& cf, int kc) {
+    auto process = [&](const Coef& cf, int kc) __attribute__((always_inline)) {
         const int t0 = kc * C;
         // right-hand side of the chunk off the stage
 #ifdef KR_TW_TRACE
         const long long ts0 = wall_clock64();
 #endif
+#pragma unroll 1
         for (int budget = 1 << 24; tq_peek(&staged[q >> 1]) <= kc && budget > 0; --budget) __builtin_amdgcn_s_sleep(1);
         TQ_ACC(12, ts0);
-        double rv[C];
-        const double* sp = stage + (size_t)(kc % S) * C * TQ_LINES + 64 * q + l;
-#pragma unroll
-        for (int u = 0; u < C; ++u) rv[u] = sp[u * TQ_LINES];
-        if (l == 0) tq_publish(&taken[q], kc + 1);                       // (same-wave LDS operations complete in order: the reads above are done)
+        const double* sp = stage + (size_t)(kc % S) * C * TQ_LINES + 64 * q + l;      // (read step by step: eight values held per chunk cost the backward kernel its registers)
         // back-pressure: this chunk overwrites the ring slots of steps t0 - YR .. t0 + 7 - YR: every reader must be past them
         {
 #ifdef KR_TW_TRACE
             const long long tb0 = wall_clock64();
 #endif
             const int need = t0 - YR + 1;                                  // a sibling reads my step p at its step p - 7
+#pragma unroll 1
             for (int budget = 1 << 24; need > 0 && budget > 0; --budget) {
                 bool ok = true;
                 if (cons_a >= 0) ok = ok && max(tq_peek(&taken[cons_a]) - 1, 0) * C >= need;
@@ -419,7 +471,6 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         }
         if (kc == 0 && q == 0 && l == 0)                                   // this block is under way: the blocks behind it may start asking
             __hip_atomic_store(&flags[blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        double yv[C];
 #pragma unroll
         for (int u = 0; u < C; ++u) {
             const int t = t0 + u;
@@ -427,6 +478,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #ifdef KR_TW_TRACE
                 const long long tw0 = wall_clock64();
 #endif
+#pragma unroll 1
                 for (int budget = 1 << 26; budget > 0; --budget) {
                     seen = __builtin_amdgcn_readfirstlane(min(tq_peek(w_cnt) - w_off, tq_peek(s_cnt) - s_off));
                     if (t < seen) break;
@@ -443,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             yj = a2 != 0.0 ? yj : 0.0;                                     // absent entry (coefficient +0.0): operand +0.0, s unchanged
             yk = a3 != 0.0 ? yk : 0.0;
             const double yi = a1 != 0.0 ? y : 0.0;
-            double s = rv[u];
+            double s = sp[u * TQ_LINES];
             if (FORWARD) {                                                 // stored order: k-, j-, i-neighbour (ascending column)
                 s = s - a3 * yk; s = s - a2 * yj; s = s - a1 * yi;
             } else {                                                       // i-, j-, k-neighbour, then the divisor
@@ -452,43 +504,38 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
                 s = s / dg;
             }
             y = s;
-            yv[u] = s;
             my_ring[(t & (YR - 1)) * 64] = s;                              // all 64 rows of the step, one unmasked store;
             if (l == 0) tq_publish(&prog[q], t + 1);                       // then the count (LDS executes a wave's operations in order)
         }
-        // ---- results into the caller's vector (natural layout)
-        if (fast_chunk(t0)) {
-            const int64_t lo = line0 + (FORWARD ? t0 - skew : Q.Ni - 1 - (t0 + C - 1 - skew));     // lowest row of the chunk
-#pragma unroll
-            for (int h = 0; h < C / 2; ++h) {
-                tw_v2 v; v.x = yv[FORWARD ? 2 * h : C - 1 - 2 * h]; v.y = yv[FORWARD ? 2 * h + 1 : C - 2 - 2 * h];
-                *(__attribute__((address_space(1))) tw_v2*)(out + lo + 2 * h) = v;
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < C; ++u) {
-                const int ii = t0 + u - skew;
-                if (line_ok && ii >= 0 && ii < Q.Ni) out[line0 + (FORWARD ? ii : Q.Ni - 1 - ii)] = yv[u];
-            }
-        }
+        if (l == 0) tq_publish(&taken[q], kc + 1);                       // stage slot free (same-wave LDS operations complete in order: the reads above are done)
+        // ---- results into the caller's vector (natural layout), read back from this wave's ring
+        store_groups(kc);
         if (kc < 8) TQ_STAMP(2 + kc);
         if (kc == nch - 1) TQ_STAMP(10);
     };
-    // Coefficients: chunks kc + 1 and kc + 2 are in flight while chunk kc is computed (an HBM round trip is two chunks of
-    // compute); the requests are unconditional (past the end the last chunk is simply requested again), so that the compiler's
-    // counted vmcnt before the first use of chunk kc's registers leaves the younger loads in flight -- a request issued under a
-    // condition makes it assume the worst and wait for vmcnt(0).  One copy of the step code (the kernel is instruction-cache
-    // sized): the buffers rotate by register moves.
-    Coef cur, n1, n2;
+    // Coefficients: chunks kc + 1 and kc + 2 are in flight while chunk kc is computed (an HBM round trip is about one chunk of
+    // compute once the chip is busy).  Three register buffers with STATIC roles -- the loop body is three chunks long -- because a
+    // rotation by register moves makes the compiler wait for the youngest request (and for the result stores behind it) at the
+    // moves: measured as one memory round trip per chunk, 2.6-2.9 us instead of ~1 (8 steps of 0.05-0.1 us plus the chunk's LDS
+    // traffic).  The requests are unconditional (past the end the last chunk is simply requested again): a request issued under a
+    // condition makes the compiler assume the worst at the next use and wait for vmcnt(0).
+    Coef c0, c1, c2;
+#pragma unroll 1
     for (int budget = 1 << 24; tq_peek(&gate) == 0 && budget > 0; --budget) __builtin_amdgcn_s_sleep(8);     // (see the loader)
     TQ_STAMP(0);
-    fetch(cur, 0);
-    fetch(n1, min(1, nch - 1));
-    for (int kc = 0; kc < nch; ++kc) {
-        fetch(n2, min(kc + 2, nch - 1));
-        process(cur, kc);
-        cur = n1; n1 = n2;
+    fetch(c0, 0);
+    fetch(c1, min(1, nch - 1));
+#pragma unroll 1
+    for (int kc = 0; kc < nch; kc += 3) {
+        fetch(c2, min(kc + 2, nch - 1));
+        arrive(c0, kc); process(c0, kc);
+        fetch(c0, min(kc + 3, nch - 1));
+        if (kc + 1 < nch) { arrive(c1, kc + 1); process(c1, kc + 1); }
+        fetch(c1, min(kc + 4, nch - 1));
+        if (kc + 2 < nch) { arrive(c2, kc + 2); process(c2, kc + 2); }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (requests past the end: nothing of this wave's is in flight from here)
+    store_groups(nch);                                                 // lines whose last (partial) group was not complete two chunks before the end
 #ifdef KR_TW_TRACE
     if (FORWARD && l == 0 && blk < 4096) for (int i = 0; i < 3; ++i) tq_trace[(blk * 4 + q) * 16 + 11 + i] = tq_acc[i];
 #endif
