@@ -43,6 +43,8 @@ static void par_rows(int64_t n, F body) {
     for (auto& t : th) t.join();
 }
 static int env_i(const char* nm, int d) { const char* e = getenv(nm); return e ? atoi(e) : d; }
+// wavefront kernel by number of 8 x 8 line blocks in the (j, k) plane: the 16 x 16 kernel from 96^3 up (table at its use)
+static int default_wave_form(unsigned nb8) { return nb8 >= 144 ? 2 : 1; }
 
 struct TriArgs {                    // device-resident argument block, rewritten before every apply (graph-friendly):
     const double* r; double* z; long long skip;   // one scalar load gives a level kernel everything it needs
@@ -451,10 +453,9 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
         const GridFactor& A = D->GL; const GridFactor& B = D->GU;
         const unsigned nb = (unsigned)(((A.Nj + 7) / 8) * ((A.Nk + 7) / 8));
         // KRYST_ILU_WAVE: 2 = 16 x 16 lines per workgroup (tri_quad.h), 1 = 8 x 8 lines (tri_wave.h), 0 = its one-wave predecessor.
-        // Default by size (measured, MI355X, true ILU(0) apply): while every 8 x 8 block is resident at once (<= 1024 blocks: up to
-        // 256^3) the two wavefront kernels are within 5 % of each other and the 8 x 8 one is ahead on small grids (128^3: 0.355 vs
-        // 0.40 ms, 256^3: 1.01 vs 1.01); beyond that the 16 x 16 kernel wins (384^3: 1.97 vs 2.68 ms, 512^3: 3.87 vs 5.50 ms)
-        const int wave_on = env_int("KRYST_ILU_WAVE", nb > 1024 ? 2 : 1);
+        // Default by size (measured, MI355X, true ILU(0) apply, 16 x 16 vs 8 x 8): 48^3 0.147 / 0.146 ms, 64^3 0.191 / 0.184,
+        // 96^3 0.269 / 0.286, 128^3 0.345 / 0.358, 192^3 0.632 / 0.679, 256^3 0.869 / 1.004, 384^3 1.74 / 2.79, 512^3 3.3-3.5 / 5.7
+        const int wave_on = env_int("KRYST_ILU_WAVE", default_wave_form(nb));
         const GridView VA{A.Ni, A.Nj, A.Nk, A.d_c1, A.d_c2, A.d_c3, nullptr}, VB{B.Ni, B.Nj, B.Nk, B.d_c1, B.d_c2, B.d_c3, B.d_diag};
         if (D->safe || env_int("KRYST_ILU_PLANES", 0)) {
             // the wavefront kernel gave up once on this preconditioner (or the caller asks for it): one launch per hyperplane
@@ -728,7 +729,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
         if (rc == KRYST_OK && (hipHostMalloc((void**)&D->h_gave_up, 64, hipHostMallocMapped) != hipSuccess ||
                                hipHostGetDevicePointer((void**)&D->d_gave_up, D->h_gave_up, 0) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = KRYST_ERR_HIP; }
         if (rc == KRYST_OK) *D->h_gave_up = 0;
-        if (rc == KRYST_OK && D->GL.Ni >= 2 && env_i("KRYST_ILU_WAVE", nb > 1024 ? 2 : 1) >= 2) {
+        if (rc == KRYST_OK && D->GL.Ni >= 2 && env_i("KRYST_ILU_WAVE", default_wave_form(nb)) >= 2) {
             // blocked coefficient layout + edge buffers of the 16 x 16 kernel (tri_quad.h), one device pass per factor
             for (GridFactor* G : {&D->GL, &D->GU}) {
                 if (rc != KRYST_OK) break;

@@ -24,6 +24,13 @@
 
 namespace kr {
 
+// -DTQ_ABL=bits: TIMING-ONLY ablations (wrong results; never in the shipped library): 1 no result stores, 2 coefficients from four
+// cached chunks, 4 spins sleep 4x longer, 8 no west/south ring reads, 16 no lane exchange, 32 no ring write, 64 no stage read.
+#if defined(TQ_ABL) && (TQ_ABL & 4)
+#define TQ_NAP(n) __builtin_amdgcn_s_sleep(4 * (n))
+#else
+#define TQ_NAP(n) __builtin_amdgcn_s_sleep(n)
+#endif
 constexpr int TQ_C = 8;            // steps per chunk
 constexpr int TQ_S = 4;            // LDS stage slots (right-hand side) -- per loader half, whose two quadrants run 8+ steps apart
 constexpr int TQ_YR = 32;          // steps in a solving wave's result ring
@@ -59,10 +66,12 @@ __device__ __forceinline__ int tq_peek(int* p) {
 // [2 + c] chunk c done (c < 8), [10] last chunk done, [11] ticks waiting for neighbour rows, [12] for the stage, [13] for sibling ring space
 __device__ long long tq_trace[4096 * 4 * 16];
 #define TQ_STAMP(slot) do { if (FORWARD && l == 0 && blk < 4096) tq_trace[(blk * 4 + q) * 16 + (slot)] = wall_clock64(); } while (0)
+#define TQ_T0(name) const long long name = wall_clock64()
 #define TQ_ACC(slot, t0_) do { tq_acc[(slot) - 11] += wall_clock64() - (t0_); } while (0)      // (registers: a read-modify-write of memory would stall the wave)
 #else
 #define TQ_STAMP(slot) do { } while (0)
 #define TQ_ACC(slot, t0_) do { } while (0)
+#define TQ_T0(name) do { } while (0)
 #endif
 
 __device__ __forceinline__ void tq_block_of(int b, int nbj, int nbk, int& J, int& K) {     // anti-diagonal numbering
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             for (int budget = 1 << 24; budget > 0; --budget) {
                 const int m = min(tq_peek(&taken[2 * half]), tq_peek(&taken[2 * half + 1]));
                 if (kc - m < S || tq_peek(&quit)) break;
-                __builtin_amdgcn_s_sleep(2);
+                TQ_NAP(2);
             }
             if (younger >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else if (younger >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         };
         // nothing is requested before the blocks this one depends on are under way: a block that will not run for another
         // 100 us must not queue its first chunks in front of the blocks at the front
-        for (int budget = 1 << 24; tq_peek(&gate) == 0 && budget > 0; --budget) __builtin_amdgcn_s_sleep(8);
+        for (int budget = 1 << 24; tq_peek(&gate) == 0 && budget > 0; --budget) TQ_NAP(8);
         Buf b0, b1, b2;                                                    // chunk kc lives in buffer kc % 3
         fetch(b0, 0);
         if (1 < nch) fetch(b1, C);
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
                 const bool ok_s = K == 0 || __hip_atomic_load(&flags[blk - Q.nbj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                 if (ok_w && ok_s) break;
                 if ((budget & 63) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                __builtin_amdgcn_s_sleep(8);
+                TQ_NAP(8);
             }
             tq_publish(&gate, 1);
         }
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             if (__ballot(t < T) == 0) break;
             const int free_upto = max(tq_peek(&taken[cq]) - 1, 0) * C + R;      // ring slots below this consumer step are free
             const bool go = t < T && t + 8 <= free_upto;
-            if (__ballot(go) == 0) { __builtin_amdgcn_s_sleep(2); --budget; continue; }
+            if (__ballot(go) == 0) { TQ_NAP(2); --budget; continue; }
             gdouble* const a0 = go ? src + (int64_t)(t + 7 + so) * 16 : (gdouble*)Q.edge_e + (int64_t)blk * edge_stride;
             gdouble* const a1 = go ? a0 + 4 * 16 : a0;
             tw_v2 p0, p1;                                                 // agent-scope (sc1) 16-byte loads: each 8-byte half whole or sentinel
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             if (so < m) { ring[((t + so) % R) * 8 + 2 * piece] = p0.x; ring[((t + so) % R) * 8 + 2 * piece + 1] = p0.y; }
             if (so + 4 < m) { ring[((t + so + 4) % R) * 8 + 2 * piece] = p1.x; ring[((t + so + 4) % R) * 8 + 2 * piece + 1] = p1.y; }
             if (m > 0) { t += m; if (idx == 0) tq_publish(avail, t); }
-            if (stuck) { __builtin_amdgcn_s_sleep(1); --budget; }
+            if (stuck) { TQ_NAP(1); --budget; }
         }
         return;
     }
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             const int n = max(0, min(min(tq_peek(&prog[sq]), T) - te, 2));
             if (te < T && so < n) __hip_atomic_store(dst + (int64_t)(te + so) * 16, src[((te + so) & (YR - 1)) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (te < T && n > 0) { te += n; if (idx == 0) tq_publish(&exported[es], te); }
-            if (__ballot(n > 0) == 0) { if (tq_peek(&quit)) break; __builtin_amdgcn_s_sleep(1); }
+            if (__ballot(n > 0) == 0) { if (tq_peek(&quit)) break; TQ_NAP(1); }
         }
         return;
     }
@@ -437,9 +446,9 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         }
     };
     double y = 0.0;
-    int seen = 0;
+    int seen = 0, stage_seen = 0, ring_safe = 0;
 #ifdef KR_TW_TRACE
-    long long tq_acc[3] = {0, 0, 0};
+    long long tq_acc[7] = {0, 0, 0, 0, 0, 0, 0};
 #endif
     auto process = [&](const Coef& cf, int kc) __attribute__((always_inline)) {
         const int t0 = kc * C;
@@ -447,8 +456,12 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #ifdef KR_TW_TRACE
         const long long ts0 = wall_clock64();
 #endif
+        // (both counters only grow: what was seen last time often answers this chunk's question without another LDS round trip)
 #pragma unroll 1
-        for (int budget = 1 << 24; tq_peek(&staged[q >> 1]) <= kc && budget > 0; --budget) __builtin_amdgcn_s_sleep(1);
+        for (int budget = 1 << 24; stage_seen <= kc && budget > 0; --budget) {
+            stage_seen = tq_peek(&staged[q >> 1]);
+            if (stage_seen <= kc) TQ_NAP(1);
+        }
         TQ_ACC(12, ts0);
         const double* sp = stage + (size_t)(kc % S) * C * TQ_LINES + 64 * q + l;      // (read step by step: eight values held per chunk cost the backward kernel its registers)
         // back-pressure: this chunk overwrites the ring slots of steps t0 - YR .. t0 + 7 - YR: every reader must be past them
@@ -456,25 +469,27 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #ifdef KR_TW_TRACE
             const long long tb0 = wall_clock64();
 #endif
-            const int need = t0 - YR + 1;                                  // a sibling reads my step p at its step p - 7
+            const int need = t0 - YR + 1;                                  // a sibling reads my step p at its step p - 7, an exporter stream at p
 #pragma unroll 1
-            for (int budget = 1 << 24; need > 0 && budget > 0; --budget) {
-                bool ok = true;
-                if (cons_a >= 0) ok = ok && max(tq_peek(&taken[cons_a]) - 1, 0) * C >= need;
-                if (cons_b >= 0) ok = ok && max(tq_peek(&taken[cons_b]) - 1, 0) * C >= need;
-                if (exp_a >= 0) ok = ok && tq_peek(&exported[exp_a]) >= need + 7;
-                if (exp_b >= 0) ok = ok && tq_peek(&exported[exp_b]) >= need + 7;
-                if (ok || tq_peek(&quit)) break;
-                __builtin_amdgcn_s_sleep(1);
+            for (int budget = 1 << 24; need > ring_safe && budget > 0; --budget) {
+                int m = HUGE_STEPS;
+                if (cons_a >= 0) m = min(m, tq_peek(&taken[cons_a]) * C);         // (published when the chunk's steps are done)
+                if (cons_b >= 0) m = min(m, tq_peek(&taken[cons_b]) * C);
+                if (exp_a >= 0) m = min(m, tq_peek(&exported[exp_a]) - 7);
+                if (exp_b >= 0) m = min(m, tq_peek(&exported[exp_b]) - 7);
+                ring_safe = m;
+                if (need <= ring_safe || tq_peek(&quit)) break;
+                TQ_NAP(1);
             }
             TQ_ACC(13, tb0);
         }
         if (kc == 0 && q == 0 && l == 0)                                   // this block is under way: the blocks behind it may start asking
             __hip_atomic_store(&flags[blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        TQ_T0(tsteps0);
 #pragma unroll
         for (int u = 0; u < C; ++u) {
             const int t = t0 + u;
-            if (t >= seen) {                                               // rows of the west / south neighbours for this step not yet known to be there
+            if (__builtin_expect(t >= seen, 0)) {                          // rows of the west / south neighbours for this step not yet known to be there
 #ifdef KR_TW_TRACE
                 const long long tw0 = wall_clock64();
 #endif
@@ -482,12 +497,20 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
                 for (int budget = 1 << 26; budget > 0; --budget) {
                     seen = __builtin_amdgcn_readfirstlane(min(tq_peek(w_cnt) - w_off, tq_peek(s_cnt) - s_off));
                     if (t < seen) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    TQ_NAP(1);
                 }
                 TQ_ACC(11, tw0);
             }
+#if defined(TQ_ABL) && (TQ_ABL & 8)
+            const double wv = 0.5, sv = 0.25;
+#else
             const double wv = w_ptr[((t + w_off) & w_mask) * w_stride], sv = s_ptr[((t + s_off) & s_mask) * s_stride];
+#endif
+#if defined(TQ_ABL) && (TQ_ABL & 16)
+            double yj = y, yk = y;
+#else
             double yj = tw_bperm(idx1, y), yk = tw_bperm(idx8, y);
+#endif
             if (jl == 0) yj = wv;
             if (kl == 0) yk = sv;
             const double a1 = (u & 1) ? cf.a[0][u >> 1].y : cf.a[0][u >> 1].x, a2 = (u & 1) ? cf.a[1][u >> 1].y : cf.a[1][u >> 1].x;
@@ -495,7 +518,11 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             yj = a2 != 0.0 ? yj : 0.0;                                     // absent entry (coefficient +0.0): operand +0.0, s unchanged
             yk = a3 != 0.0 ? yk : 0.0;
             const double yi = a1 != 0.0 ? y : 0.0;
+#if defined(TQ_ABL) && (TQ_ABL & 64)
+            double s = 1.0;
+#else
             double s = sp[u * TQ_LINES];
+#endif
             if (FORWARD) {                                                 // stored order: k-, j-, i-neighbour (ascending column)
                 s = s - a3 * yk; s = s - a2 * yj; s = s - a1 * yi;
             } else {                                                       // i-, j-, k-neighbour, then the divisor
@@ -504,13 +531,18 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
                 s = s / dg;
             }
             y = s;
+#if !(defined(TQ_ABL) && (TQ_ABL & 32))
             my_ring[(t & (YR - 1)) * 64] = s;                              // all 64 rows of the step, one unmasked store;
+#endif
             if (l == 0) tq_publish(&prog[q], t + 1);                       // then the count (LDS executes a wave's operations in order)
         }
+        TQ_ACC(16, tsteps0);
         if (l == 0) tq_publish(&taken[q], kc + 1);                       // stage slot free (same-wave LDS operations complete in order: the reads above are done)
         // ---- results into the caller's vector (natural layout), read back from this wave's ring
+        TQ_T0(tst0);
         store_groups(kc);
-        if (kc < 8) TQ_STAMP(2 + kc);
+        TQ_ACC(15, tst0);
+        if (kc < 6) TQ_STAMP(2 + kc);
         if (kc == nch - 1) TQ_STAMP(10);
     };
     // Coefficients: chunks kc + 1 and kc + 2 are in flight while chunk kc is computed (an HBM round trip is about one chunk of
@@ -521,23 +553,23 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     // condition makes the compiler assume the worst at the next use and wait for vmcnt(0).
     Coef c0, c1, c2;
 #pragma unroll 1
-    for (int budget = 1 << 24; tq_peek(&gate) == 0 && budget > 0; --budget) __builtin_amdgcn_s_sleep(8);     // (see the loader)
+    for (int budget = 1 << 24; tq_peek(&gate) == 0 && budget > 0; --budget) TQ_NAP(8);     // (see the loader)
     TQ_STAMP(0);
     fetch(c0, 0);
     fetch(c1, min(1, nch - 1));
 #pragma unroll 1
     for (int kc = 0; kc < nch; kc += 3) {
-        fetch(c2, min(kc + 2, nch - 1));
-        arrive(c0, kc); process(c0, kc);
-        fetch(c0, min(kc + 3, nch - 1));
-        if (kc + 1 < nch) { arrive(c1, kc + 1); process(c1, kc + 1); }
-        fetch(c1, min(kc + 4, nch - 1));
-        if (kc + 2 < nch) { arrive(c2, kc + 2); process(c2, kc + 2); }
+        TQ_T0(tf0); fetch(c2, min(kc + 2, nch - 1)); TQ_ACC(17, tf0);
+        TQ_T0(ta0); arrive(c0, kc); TQ_ACC(14, ta0); process(c0, kc);
+        TQ_T0(tf1); fetch(c0, min(kc + 3, nch - 1)); TQ_ACC(17, tf1);
+        if (kc + 1 < nch) { TQ_T0(ta1); arrive(c1, kc + 1); TQ_ACC(14, ta1); process(c1, kc + 1); }
+        TQ_T0(tf2); fetch(c1, min(kc + 4, nch - 1)); TQ_ACC(17, tf2);
+        if (kc + 2 < nch) { TQ_T0(ta2); arrive(c2, kc + 2); TQ_ACC(14, ta2); process(c2, kc + 2); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (requests past the end: nothing of this wave's is in flight from here)
     store_groups(nch);                                                 // lines whose last (partial) group was not complete two chunks before the end
 #ifdef KR_TW_TRACE
-    if (FORWARD && l == 0 && blk < 4096) for (int i = 0; i < 3; ++i) tq_trace[(blk * 4 + q) * 16 + 11 + i] = tq_acc[i];
+    if (FORWARD && l == 0 && blk < 4096) { for (int i = 0; i < 5; ++i) tq_trace[(blk * 4 + q) * 16 + 11 + i] = tq_acc[i]; tq_trace[(blk * 4 + q) * 16 + 1] = tq_acc[5]; tq_trace[(blk * 4 + q) * 16 + 9] = tq_acc[6]; }
 #endif
     // the readers' last 7 steps want my steps T .. T + 6: rows past the end of every line, operands nobody uses
     if (l == 0) tq_publish(&prog[q], HUGE_STEPS);

@@ -27,7 +27,7 @@ assert lib.kryst_debug_tq_trace(buf, nb * 64) == 0
 t = np.array(buf, dtype=np.int64).reshape(nb, 4, 16).astype(np.float64) / 100.0      # us
 t0 = t[:, :, 0].min()
 print(f"N {N}: {nb} blocks, {nch} chunks per block; times in us after the first entry")
-print("block  J  K  q | entry  coef  chunk0 chunk1 chunk2 chunk3 ... end | wait: nbr stage ring | us/chunk (chunks 4..end)")
+print("block  J  K  q | entry  chunk0 chunk1 chunk2 chunk3 ... end | wait: nbr stage ring coef store steps fetch | us/chunk (chunks 4..end)")
 show = [b for b in range(nb) if b < 3 or b % nbj == b // nbj or b == nb - 1]
 if len(sys.argv) > 2:
     show = [int(v.split(',')[1]) * nbj + int(v.split(',')[0]) for v in sys.argv[2:]]
@@ -35,7 +35,7 @@ for b in show:
     for q in range(4):
         x = t[b, q]
         rate = (x[10] - x[5]) / max(nch - 4, 1)
-        print(f"{b:5d} {b % nbj:2d} {b // nbj:2d} {q:2d} | {x[0] - t0:6.1f} {x[1] - t0:6.1f} " + " ".join(f"{x[2 + c] - t0:6.1f}" for c in range(4)) +
-              f" ... {x[10] - t0:7.1f} | {x[11]:6.1f} {x[12]:6.1f} {x[13]:6.1f} | {rate:5.2f}")
+        print(f"{b:5d} {b % nbj:2d} {b // nbj:2d} {q:2d} | {x[0] - t0:6.1f} " + " ".join(f"{x[2 + c] - t0:6.1f}" for c in range(4)) +
+              f" ... {x[10] - t0:7.1f} | {x[11]:6.1f} {x[12]:6.1f} {x[13]:6.1f} {x[14]:6.1f} {x[15]:6.1f} {x[1]:6.1f} {x[9]:6.1f} | {rate:5.2f}")
 ends = t[:, :, 10] - t0
 print(f"last end {ends.max():.1f} us; block (0,0) q0 ends {ends[0, 0]:.1f}; diagonal block ends: " + " ".join(f"{ends[d * nbj + d, 3]:.0f}" for d in range(nbj)))
