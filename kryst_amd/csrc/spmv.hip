@@ -692,7 +692,7 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
     const bool nt = env_int("KRYST_SPMV_NT", 0) != 0;
     // window size of the plain kernel: one window per 128-row slice (7 pair slots for a 7-point stencil's 896 entries) while the
     // vectors fit the 256 MiB Infinity Cache, 4 slots (74 registers, 6 waves per SIMD instead of 4) beyond it -- measured
-    // (profiles/r02/plain_csr_study.md): 256^3 0.298 / 0.309 ms with 7 / 4 slots, 512^3 2.84 / 2.62 ms
+    // (profiles/r02/plain_csr_study/README.md): 256^3 0.298 / 0.309 ms with 7 / 4 slots, 512^3 2.84 / 2.62 ms
     int wslots = a->slots;
     if (wslots > 4 && a->nrows * 8 > (256ll << 20)) wslots = 4;
     if (slots_env > 0) wslots = slots_env;
