@@ -92,6 +92,11 @@ def make_group(kind, rank, world):
         return SoloGroup()
     if kind == "auto":
         kind = os.environ.get("KRYST_LAUNCHER", "torch")
+    if kind != "socket":
+        try:
+            import torch.distributed                        # noqa: F401  (the same answer on every rank of one image)
+        except ImportError:
+            kind = "socket"
     if kind == "socket":                                    # no torch anywhere: kryst_amd/launch.py (TCP rendezvous)
         from kryst_amd.launch import Rendezvous
         return Rendezvous.from_env()
@@ -332,6 +337,7 @@ def main():
         sys.stderr.write("bench.py: watchdog timeout (1200 s), aborting\n"); sys.stderr.flush(); os._exit(124)
     wd = threading.Timer(1200.0, _watchdog); wd.daemon = True; wd.start()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between processes on this driver
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
