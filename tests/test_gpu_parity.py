@@ -340,7 +340,9 @@ def test_structured_grid_triangular_solve_bit_exact(ctx, grid_path, monkeypatch)
     cases = [box(5, 3, 2), box(9, 8, 8), box(16, 17, 9), box(40, 9, 20), box(7, 20, 1), box(64, 1, 1), box(6, 5, 4, wrap=True),
              box(75, 24, 17), box(23, 16, 16),          # long lines in full blocks: the predicate-free interior chunks
              box(1, 9, 9), box(2, 17, 9), box(3, 8, 16),   # lines shorter than the poller's two-row window
-             box(300, 8, 16)]                           # the neighbour ring and the LDS stage wrap many times
+             box(300, 8, 16),                           # the neighbour ring and the LDS stage wrap many times
+             box(40, 32, 16), box(37, 16, 32), box(66, 16, 16), box(33, 48, 33)]   # whole 16 x 16 blocks: the 64-byte result groups
+                                                        # of tri_quad.h (four lanes per line), also with Ni not a multiple of 8
     for a in cases:
         d = to_dev(ctx, a)
         for kpc, ofn in ((K.TrueIlu0(), O.Pc.ilu0_true), (K.Ilu0(), O.Pc.ilu0_compat), (K.Ilup(0), O.Pc.ilup0)):
