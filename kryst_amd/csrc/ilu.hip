@@ -83,8 +83,10 @@ struct GridFactor {
     // blocked copy for tri_quad_kernel (16 x 16 lines per workgroup): [block][chunk][array][step pair][line], built on the device
     void* d_blocked = nullptr; int32_t nbj = 0, nbk = 0, nch = 0;
     double* d_edge_e = nullptr; double* d_edge_n = nullptr;                // edge rows handed to the next workgroup: [block][steps + 8][16]
+    uint8_t* d_skip = nullptr;                                              // [block][quadrant][chunk]: coefficients repeat chunk - 3's (tri_quad_dedup_kernel)
+    int64_t nskip = 0;                                                      // how many of them do (KRYST_ILU_VERBOSE)
     void free_all() { (void)hipFree(d_c1); (void)hipFree(d_c2); (void)hipFree(d_c3); (void)hipFree(d_diag);
-                      (void)hipFree(d_blocked); (void)hipFree(d_edge_e); (void)hipFree(d_edge_n); }
+                      (void)hipFree(d_blocked); (void)hipFree(d_edge_e); (void)hipFree(d_edge_n); (void)hipFree(d_skip); }
 };
 struct GridView { int32_t Ni, Nj, Nk; const double* c1; const double* c2; const double* c3; const double* diag; };
 
@@ -472,8 +474,8 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
         if (wave_on >= 2 && A.d_blocked && B.d_blocked) {
             // 16 x 16 lines per workgroup (tri_quad.h): blocked coefficients, edge buffers between workgroups
             const unsigned nq = (unsigned)(A.nbj * A.nbk);
-            const QuadView QA{A.Ni, A.Nj, A.Nk, A.nbj, A.nbk, A.nch, (const tw_v2*)A.d_blocked, A.d_edge_e, A.d_edge_n};
-            const QuadView QB{B.Ni, B.Nj, B.Nk, B.nbj, B.nbk, B.nch, (const tw_v2*)B.d_blocked, B.d_edge_e, B.d_edge_n};
+            const QuadView QA{A.Ni, A.Nj, A.Nk, A.nbj, A.nbk, A.nch, (const tw_v2*)A.d_blocked, A.d_edge_e, A.d_edge_n, A.d_skip};
+            const QuadView QB{B.Ni, B.Nj, B.Nk, B.nbj, B.nbk, B.nch, (const tw_v2*)B.d_blocked, B.d_edge_e, B.d_edge_n, B.d_skip};
             const unsigned fg = std::min<unsigned>(1024u, nq * 4u);
             hipLaunchKernelGGL(tri_quad_fill_kernel, dim3(fg), dim3(256), 0, s, D->d_args, A.d_edge_e, A.d_edge_n, (int)nq, A.nch, D->d_flags, (int32_t)(2 * nb + 1));
             hipLaunchKernelGGL(tri_quad_fill_kernel, dim3(fg), dim3(256), 0, s, D->d_args, B.d_edge_e, B.d_edge_n, (int)nq, B.nch, (int32_t*)nullptr, 0);
@@ -745,7 +747,18 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
                 const unsigned lg = (unsigned)(nq * G->nch);
                 if (fwd) hipLaunchKernelGGL((tri_quad_layout_kernel<true, 3>), dim3(lg), dim3(256), 0, ctx->s_main, V, G->nbj, G->nbk, G->nch, (tw_v2*)G->d_blocked);
                 else hipLaunchKernelGGL((tri_quad_layout_kernel<false, 4>), dim3(lg), dim3(256), 0, ctx->s_main, V, G->nbj, G->nbk, G->nch, (tw_v2*)G->d_blocked);
+                // which chunks repeat chunk - 3 bit for bit (their coefficients are in the solving wave's registers already)
+                if (env_i("KRYST_ILU_DEDUP", 1) && G->nch + 3 <= TQ_SKIPMAX) {
+                    if (hipMalloc(&G->d_skip, nq * 4 * (size_t)G->nch) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; break; }
+                    if (fwd) hipLaunchKernelGGL((tri_quad_dedup_kernel<3>), dim3(lg), dim3(256), 0, ctx->s_main, (const tw_v2*)G->d_blocked, G->nch, G->d_skip);
+                    else hipLaunchKernelGGL((tri_quad_dedup_kernel<4>), dim3(lg), dim3(256), 0, ctx->s_main, (const tw_v2*)G->d_blocked, G->nch, G->d_skip);
+                }
                 if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("blocked layout kernel failed"); rc = KRYST_ERR_HIP; }
+                if (rc == KRYST_OK && G->d_skip && getenv("KRYST_ILU_VERBOSE")) {
+                    std::vector<uint8_t> h(nq * 4 * (size_t)G->nch);
+                    if (hipMemcpy(h.data(), G->d_skip, h.size(), hipMemcpyDeviceToHost) == hipSuccess) { G->nskip = 0; for (uint8_t v : h) G->nskip += v; }
+                    fprintf(stderr, "[kryst ilu] %s factor: %lld of %zu coefficient chunks repeat (no request)\n", fwd ? "forward" : "backward", (long long)G->nskip, h.size());
+                }
             }
         }
     }

@@ -41,7 +41,9 @@ struct QuadView {
     int32_t Ni, Nj, Nk, nbj, nbk, nch;
     const tw_v2* coef;             // blocked coefficients: [block][chunk][array][step pair][line] (array: i-, j-, k-neighbour[, divisor])
     double* edge_e; double* edge_n;   // [block][nch * 8 + 8 producer steps][16 lines]
+    const uint8_t* skip;           // [block][quadrant][chunk]: this chunk's coefficients equal chunk - 3's bit for bit (nullptr: no flags)
 };
+constexpr int TQ_SKIPMAX = 544;    // chunks per line the flag table in LDS holds (lines up to 4 300 rows); longer lines run without flags
 
 // Counters in LDS that tie the waves of a workgroup together.  The payload they guard is in LDS as well, and the LDS executes
 // one wave's operations in issue order, so publishing needs NO wait at all: the ring write and the counter write that follows it
@@ -119,6 +121,26 @@ __global__ __launch_bounds__(256) void tri_quad_layout_kernel(GridView G, int nb
         }
 }
 
+// ---- setup: which coefficient chunks repeat.  A solving wave keeps chunk m in register buffer m % 3, so a chunk that equals chunk
+// m - 3 bit for bit is ALREADY there and needs no request.  The ILU factors of constant-coefficient operators settle to the last
+// bit 10-40 rows away from the low faces of the box (the BASELINE operators: 10-15 rows), so away from those faces the solve
+// streams only the right-hand side and the result: 32 instead of 88 bytes per row and apply.  Exact: equal bits, same arithmetic.
+// One workgroup per (block, chunk); a quadrant's 64 lines are one wave.
+template <int NA>
+__global__ __launch_bounds__(256) void tri_quad_dedup_kernel(const tw_v2* coef, int nch, uint8_t* skip) {
+    const int blk = blockIdx.x / nch, c = blockIdx.x % nch, L = threadIdx.x, q = L >> 6;
+    bool eq = c >= 3;
+    if (c >= 3) {
+        const unsigned long long* cur = reinterpret_cast<const unsigned long long*>(coef + ((size_t)blk * nch + c) * NA * 4 * TQ_LINES + L);
+        const unsigned long long* old = reinterpret_cast<const unsigned long long*>(coef + ((size_t)blk * nch + c - 3) * NA * 4 * TQ_LINES + L);
+#pragma unroll
+        for (int e = 0; e < NA * 4; ++e)
+            eq = eq && cur[2 * e * TQ_LINES] == old[2 * e * TQ_LINES] && cur[2 * e * TQ_LINES + 1] == old[2 * e * TQ_LINES + 1];
+    }
+    const bool all = __all(eq);                                            // (bit patterns, so that -0.0 / NaN payloads count)
+    if ((L & 63) == 0) skip[((size_t)blk * 4 + q) * nch + c] = all ? 1 : 0;
+}
+
 // ---- per apply: sentinels into the edge buffers (zeros in the 8 steps past the last chunk: rows nobody has), flags and abort word cleared
 __global__ __launch_bounds__(256) void tri_quad_fill_kernel(const TriArgs* args, double* edge_e, double* edge_n, int nblk, int nch, int32_t* flags, int32_t nflags) {
     if (args->skip) return;
@@ -146,6 +168,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     __shared__ int pavail[4];                                              // consumer steps each poller stream has delivered
     __shared__ int taken[4];                                               // chunks each solving wave has taken off the stage
     __shared__ int exported[4];                                            // producer steps each exporter stream has written to the edge buffers
+    __shared__ uint8_t skipf[4 * TQ_SKIPMAX];                              // per solving wave: chunk m needs no coefficient request (chunks past the end: 1)
     __shared__ int staged[2], quit, always, gate;                          // gate: the producers are under way (set by the poller)                                // chunks each loader wave has staged (quadrants 0-1 / 2-3)
     cgdouble* in = (cgdouble*)(in_ptr ? in_ptr : args->r);
     gdouble* out = (gdouble*)(out_ptr ? out_ptr : args->z);
@@ -165,6 +188,10 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         exported[i] = (i < 2 ? J + 1 < Q.nbj : K + 1 < Q.nbk) ? 0 : HUGE_STEPS;
     }
     if (threadIdx.x == 0) { staged[0] = 0; staged[1] = 0; quit = 0; always = HUGE_STEPS; gate = (J == 0 && K == 0) ? 1 : 0; }
+    for (int i = threadIdx.x; i < 4 * TQ_SKIPMAX; i += 512) {               // (before any hand-counted request is in flight)
+        const int qq = i / TQ_SKIPMAX, m = i % TQ_SKIPMAX;
+        skipf[i] = m >= nch ? 1 : (Q.skip && nch + 3 <= TQ_SKIPMAX) ? Q.skip[((size_t)blk * 4 + qq) * nch + m] : 0;
+    }
     for (int i = threadIdx.x; i < 4 * R * 8; i += 512) pring[i] = 0.0;
     for (int i = threadIdx.x; i < 4 * YR * 64; i += 512) yring[i] = 0.0;
     __syncthreads();                                                      // the only barrier
@@ -394,19 +421,28 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
-            for (int h = 0; h < 4; ++h) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cf.a[a][h]) : "v"(p + (a * 4 + h) * TQ_LINES) : "memory");
+            for (int h = 0; h < 4; ++h)                                     // "+v": the request may be skipped (needs(m) below) -- same register on both paths
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(cf.a[a][h]) : "v"(p + (a * 4 + h) * TQ_LINES) : "memory");
     };
-    // before chunk m is computed: vector-memory operations younger than its request = the two later requests (2 * 4 NA loads) and
-    // the result stores of chunks m - 2 and m - 1 -- exactly four each on the fast path, unknown (counted as none) otherwise
+    // Chunk m needs a request unless its coefficients equal chunk m - 3's bit for bit: those sit in its buffer already (flags from
+    // setup, tri_quad_dedup_kernel; chunks past the end count as "no request").
+    const uint8_t* const my_skip = skipf + q * TQ_SKIPMAX;
+    auto needs = [&](int m) -> bool { return my_skip[min(m, TQ_SKIPMAX - 1)] == 0; };
+    // before chunk m is computed: vector-memory operations younger than its request = the (up to) two later requests of 4 NA loads
+    // each and the result stores of chunks m - 2 and m - 1 -- exactly four each on the fast path, unknown (counted as none) otherwise
     auto arrive = [&](Coef& cf, int m) __attribute__((always_inline)) {
+        if (!needs(m)) return;                                             // nothing was requested: the values are there (and were waited for then)
 #if defined(TQ_ABL) && (TQ_ABL & 1)
         const int st = 0;
 #else
         const int st = ((m >= 2 && group_fast(m - 2)) ? 1 : 0) + ((m >= 1 && group_fast(m - 1)) ? 1 : 0);
 #endif
-        if (st == 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 * NA + 8) : "memory");
-        else if (st == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 * NA + 4) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 * NA) : "memory");
+        const int nf = (needs(m + 1) ? 1 : 0) + (needs(m + 2) ? 1 : 0);
+#define TQ_WAIT(NF_, ST_) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * NA * (NF_) + 4 * (ST_)) : "memory")
+        if (nf == 2) { if (st == 2) TQ_WAIT(2, 2); else if (st == 1) TQ_WAIT(2, 1); else TQ_WAIT(2, 0); }
+        else if (nf == 1) { if (st == 2) TQ_WAIT(1, 2); else if (st == 1) TQ_WAIT(1, 1); else TQ_WAIT(1, 0); }
+        else { if (st == 2) TQ_WAIT(0, 2); else if (st == 1) TQ_WAIT(0, 1); else TQ_WAIT(0, 0); }
+#undef TQ_WAIT
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -549,21 +585,25 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     // compute once the chip is busy).  Three register buffers with STATIC roles -- the loop body is three chunks long -- because a
     // rotation by register moves makes the compiler wait for the youngest request (and for the result stores behind it) at the
     // moves: measured as one memory round trip per chunk, 2.6-2.9 us instead of ~1 (8 steps of 0.05-0.1 us plus the chunk's LDS
-    // traffic).  The requests are unconditional (past the end the last chunk is simply requested again): a request issued under a
-    // condition makes the compiler assume the worst at the next use and wait for vmcnt(0).
+    // traffic).  The requests are inline asm the compiler knows nothing about (it would answer a request issued under a
+    // condition with vmcnt(0) at the next use); a chunk whose coefficients repeat chunk kc - 3's is not requested at all.
     Coef c0, c1, c2;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { c0.a[a][h] = tw_v2{0.0, 0.0}; c1.a[a][h] = tw_v2{0.0, 0.0}; c2.a[a][h] = tw_v2{0.0, 0.0}; }
 #pragma unroll 1
     for (int budget = 1 << 24; tq_peek(&gate) == 0 && budget > 0; --budget) TQ_NAP(8);     // (see the loader)
     TQ_STAMP(0);
-    fetch(c0, 0);
-    fetch(c1, min(1, nch - 1));
+    fetch(c0, 0);                                                      // (chunks 0-2 always need their request)
+    if (needs(1)) fetch(c1, 1);
 #pragma unroll 1
     for (int kc = 0; kc < nch; kc += 3) {
-        TQ_T0(tf0); fetch(c2, min(kc + 2, nch - 1)); TQ_ACC(17, tf0);
+        TQ_T0(tf0); if (needs(kc + 2)) fetch(c2, kc + 2); TQ_ACC(17, tf0);
         TQ_T0(ta0); arrive(c0, kc); TQ_ACC(14, ta0); process(c0, kc);
-        TQ_T0(tf1); fetch(c0, min(kc + 3, nch - 1)); TQ_ACC(17, tf1);
+        TQ_T0(tf1); if (needs(kc + 3)) fetch(c0, kc + 3); TQ_ACC(17, tf1);
         if (kc + 1 < nch) { TQ_T0(ta1); arrive(c1, kc + 1); TQ_ACC(14, ta1); process(c1, kc + 1); }
-        TQ_T0(tf2); fetch(c1, min(kc + 4, nch - 1)); TQ_ACC(17, tf2);
+        TQ_T0(tf2); if (needs(kc + 4)) fetch(c1, kc + 4); TQ_ACC(17, tf2);
         if (kc + 2 < nch) { TQ_T0(ta2); arrive(c2, kc + 2); TQ_ACC(14, ta2); process(c2, kc + 2); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (requests past the end: nothing of this wave's is in flight from here)
