@@ -168,6 +168,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     __shared__ int pavail[4];                                              // consumer steps each poller stream has delivered
     __shared__ int taken[4];                                               // chunks each solving wave has taken off the stage
     __shared__ int exported[4];                                            // producer steps each exporter stream has written to the edge buffers
+    __shared__ int written[4];                                             // chunks of each solving wave's results the loader waves have stored to the caller's vector
     __shared__ uint8_t skipf[4 * TQ_SKIPMAX];                              // per solving wave: chunk m needs no coefficient request (chunks past the end: 1)
     __shared__ int staged[2], quit, always, gate;                          // gate: the producers are under way (set by the poller)                                // chunks each loader wave has staged (quadrants 0-1 / 2-3)
     cgdouble* in = (cgdouble*)(in_ptr ? in_ptr : args->r);
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     
     if (threadIdx.x < 4) {
         const int i = threadIdx.x;
-        prog[i] = 0; taken[i] = 0; pavail[i] = 0;
+        prog[i] = 0; taken[i] = 0; pavail[i] = 0; written[i] = 0;
         // exporter streams: 0 east rows of q1, 1 east rows of q3, 2 north rows of q2, 3 north rows of q3
         exported[i] = (i < 2 ? J + 1 < Q.nbj : K + 1 < Q.nbk) ? 0 : HUGE_STEPS;
     }
@@ -282,6 +283,63 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             }
             tq_publish(&staged[half], kc + 1);
         };
+        // ---- RESULT stores of this half's two solving waves (so that a solving wave issues no store at all: 0.3 us of its 2 us
+        // per chunk, on the critical path of every hand-over).  A line's rows leave in aligned groups of 8 (64 bytes), four lanes
+        // per line -- one store instruction writes 16 whole 64-byte segments -- read out of the solving wave's ring: line L's
+        // group m = kc - ceil(skew_L / 8) is complete once the wave has finished chunk kc (taken[q] > kc).  (Each lane storing
+        // 16 bytes of ITS line, 64 lines per instruction and four partial writes per segment, cost 1.5 ms of a 4.2 ms apply at
+        // 512^3.)  Chunk nch is the tail: groups that were not complete two chunks before the end.  First / last chunks and
+        // ragged blocks: lane = line, row by row.
+        const int sg = l >> 2, sc = l & 3;                                  // store r of a chunk: line 16 r + sg of the quadrant, 16-byte piece sc
+        const int g_skew0 = (sg & 7) + (sg >> 3);                           // skew of that line: g_skew0 + 2 r
+        const int o_skew = (l & 7) + (l >> 3);                              // row-by-row path: skew of line l
+        auto write_chunk = [&](int qq, int kc) {
+            const int wqj = qq & 1, wqk = qq >> 1;
+            const double* const ring_q = yring + qq * YR * 64;
+            if (full && kc >= 2 && 8 * kc + 8 <= Q.Ni) {
+#if defined(TQ_ABL) && (TQ_ABL & 1)
+                return;
+#endif
+                const int gjj = 16 * J + 8 * wqj + (sg & 7), gkk = 16 * K + 8 * wqk + (sg >> 3);
+                const int64_t l00 = (int64_t)((FORWARD ? gkk : Q.Nk - 1 - gkk) * Q.Nj + (FORWARD ? gjj : Q.Nj - 1 - gjj)) * Q.Ni;
+                const int64_t lstride = (FORWARD ? 2 : -2) * (int64_t)Q.Nj * Q.Ni;       // lines L and L + 16 are two k-planes apart
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int L = 16 * r + sg, gs = g_skew0 + 2 * r, m = kc - ((gs + 7) >> 3);
+                    const int ia = FORWARD ? 8 * m + 2 * sc : 8 * m + 7 - 2 * sc, ib = FORWARD ? ia + 1 : ia - 1;   // line rows of the piece, in memory order
+                    tw_v2 v;
+                    v.x = ring_q[((ia + gs) & (YR - 1)) * 64 + L]; v.y = ring_q[((ib + gs) & (YR - 1)) * 64 + L];
+                    const int64_t lo = l00 + r * lstride + (FORWARD ? 8 * m : Q.Ni - 8 - 8 * m);                    // lowest memory row of the group
+                    *(__attribute__((address_space(1))) tw_v2*)(out + lo + 2 * sc) = v;
+                }
+            } else {
+                const int ojj = 16 * J + 8 * wqj + (l & 7), okk = 16 * K + 8 * wqk + (l >> 3);
+                const bool o_ok = ojj < Q.Nj && okk < Q.Nk;
+                const int64_t ol0 = o_ok ? (int64_t)((FORWARD ? okk : Q.Nk - 1 - okk) * Q.Nj + (FORWARD ? ojj : Q.Nj - 1 - ojj)) * Q.Ni : 0;
+                const int m = kc - ((o_skew + 7) >> 3);
+#pragma unroll
+                for (int u = 0; u < C; ++u) {
+                    const int ii = 8 * m + u;
+                    if (o_ok && ii >= 0 && ii < Q.Ni) out[ol0 + (FORWARD ? ii : Q.Ni - 1 - ii)] = ring_q[((ii + o_skew) & (YR - 1)) * 64 + l];
+                }
+            }
+        };
+        int wdone0 = 0, wdone1 = 0;                                        // chunks written per quadrant of this half (0 .. nch + 1: the tail counts as one)
+        auto drain = [&]() {                                               // everything the solving waves have finished since the last call
+#pragma unroll 1
+            for (int qd = 0; qd < 2; ++qd) {
+                const int qq = 2 * half + qd;
+                const int have = tq_peek(&taken[qq]);                      // chunks whose steps are done (their rows are in the ring)
+                int wd = qd ? wdone1 : wdone0;
+#pragma unroll 1
+                while (wd < have || (wd == nch && have >= nch)) {          // (chunk nch: the tail)
+                    write_chunk(qq, wd);
+                    ++wd;
+                    if (l == 0 && wd <= nch) tq_publish(&written[qq], wd); // (same-wave LDS reads above are done: the ring slots are free)
+                }
+                if (qd) wdone1 = wd; else wdone0 = wd;
+            }
+        };
         // nothing is requested before the blocks this one depends on are under way: a block that will not run for another
         // 100 us must not queue its first chunks in front of the blocks at the front
         for (int budget = 1 << 24; tq_peek(&gate) == 0 && budget > 0; --budget) TQ_NAP(8);
@@ -289,12 +347,22 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         fetch(b0, 0);
         if (1 < nch) fetch(b1, C);
         if (2 < nch) fetch(b2, 2 * C);
+        // Static buffer roles (the loop body is three chunks long): the requests are inline asm the register allocator knows
+        // nothing about, and any other loop shape (one chunk per trip, buffer chosen by a switch) made it COPY the buffers between
+        // trips while their loads were in flight.  `younger` of a publish: the loads of the chunks kc + 1 .. that have been
+        // requested by now (result stores issued in between only make the count conservative).
         for (int kc = 0; kc < nch; kc += 3) {
-            // loads younger than the buffer being published: the chunks kc + 1 .. that have been requested by now
             publish(b0, kc, 8 * (min(nch, kc + 3) - (kc + 1)));
             if (kc + 3 < nch) fetch(b0, (kc + 3) * C);
-            if (kc + 1 < nch) { publish(b1, kc + 1, 8 * (min(nch, kc + 4) - (kc + 2))); if (kc + 4 < nch) fetch(b1, (kc + 4) * C); }
-            if (kc + 2 < nch) { publish(b2, kc + 2, 8 * (min(nch, kc + 5) - (kc + 3))); if (kc + 5 < nch) fetch(b2, (kc + 5) * C); }
+            drain();
+            if (kc + 1 < nch) { publish(b1, kc + 1, 8 * (min(nch, kc + 4) - (kc + 2))); if (kc + 4 < nch) fetch(b1, (kc + 4) * C); drain(); }
+            if (kc + 2 < nch) { publish(b2, kc + 2, 8 * (min(nch, kc + 5) - (kc + 3))); if (kc + 5 < nch) fetch(b2, (kc + 5) * C); drain(); }
+        }
+#pragma unroll 1
+        for (int budget = 1 << 26; budget > 0; --budget) {                 // the solving waves' last chunks and the tails
+            drain();
+            if ((wdone0 > nch && wdone1 > nch) || tq_peek(&quit)) break;
+            TQ_NAP(1);
         }
         return;
     }
@@ -393,7 +461,6 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     const int j = FORWARD ? jj : Q.Nj - 1 - jj, k = FORWARD ? kk : Q.Nk - 1 - kk;
     const int64_t line0 = line_ok ? (int64_t)(k * Q.Nj + j) * Q.Ni : 0;
     const bool full = 16 * J + 16 <= Q.Nj && 16 * K + 16 <= Q.Nk;
-    auto group_fast = [&](int kc) { return full && kc >= 2 && 8 * kc + 8 <= Q.Ni; };   // every line's result group of this chunk lies in [0, Ni)
     // Where this quadrant's west / south rows come from -- a sibling's result ring (its step t + 7), a poller stream (step t), or
     // nowhere -- as DATA (pointer, step offset, ring mask, stride, counter), so that the step itself has no branch on it.
     const bool w_sib = qj == 1, w_poll = qj == 0 && J > 0, s_sib = qk == 1, s_poll = qk == 0 && K > 0;
@@ -429,57 +496,17 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     const uint8_t* const my_skip = skipf + q * TQ_SKIPMAX;
     auto needs = [&](int m) -> bool { return my_skip[min(m, TQ_SKIPMAX - 1)] == 0; };
     // before chunk m is computed: vector-memory operations younger than its request = the (up to) two later requests of 4 NA loads
-    // each and the result stores of chunks m - 2 and m - 1 -- exactly four each on the fast path, unknown (counted as none) otherwise
+    // each; the wave issues nothing else (its results are stored by the loader wave)
     auto arrive = [&](Coef& cf, int m) __attribute__((always_inline)) {
         if (!needs(m)) return;                                             // nothing was requested: the values are there (and were waited for then)
-#if defined(TQ_ABL) && (TQ_ABL & 1)
-        const int st = 0;
-#else
-        const int st = ((m >= 2 && group_fast(m - 2)) ? 1 : 0) + ((m >= 1 && group_fast(m - 1)) ? 1 : 0);
-#endif
         const int nf = (needs(m + 1) ? 1 : 0) + (needs(m + 2) ? 1 : 0);
-#define TQ_WAIT(NF_, ST_) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * NA * (NF_) + 4 * (ST_)) : "memory")
-        if (nf == 2) { if (st == 2) TQ_WAIT(2, 2); else if (st == 1) TQ_WAIT(2, 1); else TQ_WAIT(2, 0); }
-        else if (nf == 1) { if (st == 2) TQ_WAIT(1, 2); else if (st == 1) TQ_WAIT(1, 1); else TQ_WAIT(1, 0); }
-        else { if (st == 2) TQ_WAIT(0, 2); else if (st == 1) TQ_WAIT(0, 1); else TQ_WAIT(0, 0); }
-#undef TQ_WAIT
+        if (nf == 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 * NA) : "memory");
+        else if (nf == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * NA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int h = 0; h < 4; ++h) asm volatile("" : "+v"(cf.a[a][h]));      // (the values exist from here on)
-    };
-    // Result stores: a line's rows leave in aligned groups of 8 (64 bytes), four lanes per line -- one store instruction writes 16
-    // whole 64-byte segments.  (Each lane storing 16 bytes of ITS line, 64 lines per instruction and four partial writes per
-    // segment, cost 1.5 ms of a 4.2 ms apply at 512^3: these stores sit in the same in-order queue as the coefficient
-    // requests.)  The rows come back out of the ring: line L's group m = kc - ceil(skew_L / 8) is complete after chunk kc.
-    const int sg = l >> 2, sc = l & 3;                                  // store r of a chunk: line L = 16 r + sg of the quadrant, 16-byte piece sc
-    const int g_skew0 = (sg & 7) + (sg >> 3);                             // skew of line L: g_skew0 + 2 r
-    const int g_jj = 16 * J + 8 * qj + (sg & 7), g_kk = 16 * K + 8 * qk + (sg >> 3);      // (whole blocks only: the fast path is not taken otherwise)
-    const int64_t g_line00 = (int64_t)((FORWARD ? g_kk : Q.Nk - 1 - g_kk) * Q.Nj + (FORWARD ? g_jj : Q.Nj - 1 - g_jj)) * Q.Ni;
-    const int64_t g_lstride = (FORWARD ? 2 : -2) * (int64_t)Q.Nj * Q.Ni;  // lines L and L + 16 are two k-planes apart
-    const double* const ring_q = yring + q * YR * 64;
-    auto store_groups = [&](int kc) __attribute__((always_inline)) {
-#if defined(TQ_ABL) && (TQ_ABL & 1)
-        if (group_fast(kc)) return;
-#endif
-        if (group_fast(kc)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int L = 16 * r + sg, gs = g_skew0 + 2 * r, m = kc - ((gs + 7) >> 3);
-                const int ia = FORWARD ? 8 * m + 2 * sc : 8 * m + 7 - 2 * sc, ib = FORWARD ? ia + 1 : ia - 1;     // line rows of the piece, in memory order
-                tw_v2 v;
-                v.x = ring_q[((ia + gs) & (YR - 1)) * 64 + L]; v.y = ring_q[((ib + gs) & (YR - 1)) * 64 + L];
-                const int64_t lo = g_line00 + r * g_lstride + (FORWARD ? 8 * m : Q.Ni - 8 - 8 * m);                              // lowest memory row of the group
-                *(__attribute__((address_space(1))) tw_v2*)(out + lo + 2 * sc) = v;
-            }
-        } else {                                                           // first / last chunks, ragged blocks: this lane's own line, row by row
-            const int m = kc - ((skew + 7) >> 3);
-#pragma unroll
-            for (int u = 0; u < C; ++u) {
-                const int ii = 8 * m + u;
-                if (line_ok && ii >= 0 && ii < Q.Ni) out[line0 + (FORWARD ? ii : Q.Ni - 1 - ii)] = ring_q[((ii + skew) & (YR - 1)) * 64 + l];
-            }
-        }
     };
     double y = 0.0;
     int seen = 0, stage_seen = 0, ring_safe = 0;
@@ -513,6 +540,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
                 if (cons_b >= 0) m = min(m, tq_peek(&taken[cons_b]) * C);
                 if (exp_a >= 0) m = min(m, tq_peek(&exported[exp_a]) - 7);
                 if (exp_b >= 0) m = min(m, tq_peek(&exported[exp_b]) - 7);
+                m = min(m, 8 * tq_peek(&written[q]) - 14);                         // the stores of chunk w read steps >= 8 w - 7: like an exporter at that step
                 ring_safe = m;
                 if (need <= ring_safe || tq_peek(&quit)) break;
                 TQ_NAP(1);
@@ -574,10 +602,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         }
         TQ_ACC(16, tsteps0);
         if (l == 0) tq_publish(&taken[q], kc + 1);                       // stage slot free (same-wave LDS operations complete in order: the reads above are done)
-        // ---- results into the caller's vector (natural layout), read back from this wave's ring
-        TQ_T0(tst0);
-        store_groups(kc);
-        TQ_ACC(15, tst0);
+        // (the rows stay in the ring: the loader wave of this half stores them to the caller's vector)
         if (kc < 6) TQ_STAMP(2 + kc);
         if (kc == nch - 1) TQ_STAMP(10);
     };
@@ -607,7 +632,6 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         if (kc + 2 < nch) { TQ_T0(ta2); arrive(c2, kc + 2); TQ_ACC(14, ta2); process(c2, kc + 2); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (requests past the end: nothing of this wave's is in flight from here)
-    store_groups(nch);                                                 // lines whose last (partial) group was not complete two chunks before the end
 #ifdef KR_TW_TRACE
     if (FORWARD && l == 0 && blk < 4096) { for (int i = 0; i < 5; ++i) tq_trace[(blk * 4 + q) * 16 + 11 + i] = tq_acc[i]; tq_trace[(blk * 4 + q) * 16 + 1] = tq_acc[5]; tq_trace[(blk * 4 + q) * 16 + 9] = tq_acc[6]; }
 #endif
