@@ -51,6 +51,11 @@ constexpr int TQ_SKIPMAX = 544;    // chunks per line the flag table in LDS hold
 // keep the program order (the empty asm).  The workgroup-scope release / acquire forms would wait for lgkmcnt(0) -- one LDS
 // round trip per publish on the solving wave's critical path -- and for vmcnt(0): every outstanding GLOBAL load and store of
 // the wave, i.e. an HBM round trip per step for a wave that keeps a chunk of coefficient loads in flight.
+__device__ __forceinline__ double tq_shr1(double v) {                      // lane l <- lane l - 1 within its row of 16 lanes (row_shr:1)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ void tq_publish(int* p, int v) {
     asm volatile("" ::: "memory");
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     constexpr int C = TQ_C, S = TQ_S, R = TQ_R;
     constexpr int NA = FORWARD ? 3 : 4;                                    // coefficient arrays per chunk
     constexpr int YR = TQ_YR;
-    __shared__ double stage[S * C * TQ_LINES];                             // right-hand side: [slot][step][line]                       64 KiB
+    __shared__ __attribute__((aligned(16))) double stage[S * C * TQ_LINES];   // right-hand side: [slot][step pair][line][2]: one 16-byte read per two steps   64 KiB
     __shared__ double yring[4 * YR * 64];                                  // every solving wave's last YR steps, all 64 lanes             64 KiB
     __shared__ double pring[4 * R * 8];                                    // poller streams (west of q0, west of q2, south of q0, south of q1): [step % R][edge lane]  16 KiB
     __shared__ int prog[4];                                                // steps each solving wave has finished (its rows are in its ring)
@@ -264,8 +269,9 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int L = 128 * half + 16 * r + g;
-                    const int u0 = FORWARD ? 2 * c : C - 1 - 2 * c, u1 = FORWARD ? 2 * c + 1 : C - 2 - 2 * c;   // steps of the piece's two rows
-                    dst[u0 * TQ_LINES + L] = b.d[r].x; dst[u1 * TQ_LINES + L] = b.d[r].y;
+                    // the piece's two rows are steps 2c, 2c + 1 (forward) or 7 - 2c, 6 - 2c (backward): one step pair either way
+                    const int pr = FORWARD ? c : 3 - c;
+                    *reinterpret_cast<tw_v2*>(dst + (pr * TQ_LINES + L) * 2) = FORWARD ? b.d[r] : tw_v2{b.d[r].y, b.d[r].x};
                 }
             } else {
 #pragma unroll
@@ -277,8 +283,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
                         const tw_v2 pr = b.d[4 * qd + h];
                         const double ra = FORWARD ? pr.x : pr.y, rb = FORWARD ? pr.y : pr.x;  // line rows wc, wc + 1
                         const double va = (oka && !okb) ? rb : ra, vb = (!oka && okb) ? ra : rb;
-                        dst[(2 * h) * TQ_LINES + 128 * half + 64 * qd + l] = oka ? va : 0.0;
-                        dst[(2 * h + 1) * TQ_LINES + 128 * half + 64 * qd + l] = okb ? vb : 0.0;
+                        *reinterpret_cast<tw_v2*>(dst + (h * TQ_LINES + 128 * half + 64 * qd + l) * 2) = tw_v2{oka ? va : 0.0, okb ? vb : 0.0};
                     }
             }
             tq_publish(&staged[half], kc + 1);
@@ -455,12 +460,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 
     // ------------------------------------------------------------------------------------------------ the SOLVING waves
     const int q = wave, qj = q & 1, qk = q >> 1;
-    const int jl = l & 7, kl = l >> 3, skew = jl + kl;
-    const int jj = 16 * J + 8 * qj + jl, kk = 16 * K + 8 * qk + kl;
-    const bool line_ok = jj < Q.Nj && kk < Q.Nk;
-    const int j = FORWARD ? jj : Q.Nj - 1 - jj, k = FORWARD ? kk : Q.Nk - 1 - kk;
-    const int64_t line0 = line_ok ? (int64_t)(k * Q.Nj + j) * Q.Ni : 0;
-    const bool full = 16 * J + 16 <= Q.Nj && 16 * K + 16 <= Q.Nk;
+    const int jl = l & 7, kl = l >> 3;
     // Where this quadrant's west / south rows come from -- a sibling's result ring (its step t + 7), a poller stream (step t), or
     // nowhere -- as DATA (pointer, step offset, ring mask, stride, counter), so that the step itself has no branch on it.
     const bool w_sib = qj == 1, w_poll = qj == 0 && J > 0, s_sib = qk == 1, s_poll = qk == 0 && K > 0;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     const int cons_a = qj == 0 ? q + 1 : -1, cons_b = qk == 0 ? q + 2 : -1;
     const int exp_a = q == 1 ? 0 : q == 3 ? 1 : -1, exp_b = q == 2 ? 2 : q == 3 ? 3 : -1;
     double* const my_ring = yring + q * YR * 64 + l;
-    const int idx1 = max(l - 1, 0) * 4, idx8 = max(l - 8, 0) * 4;
+    const int idx8 = max(l - 8, 0) * 4;
     cg_v2* const coef = (cg_v2*)Q.coef + (size_t)blk * nch * NA * 4 * TQ_LINES + 64 * q + l;
 
     // Coefficient requests are issued and waited for BY HAND, like the loader's: the compiler's counted vmcnt does not know how
@@ -526,7 +526,8 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             if (stage_seen <= kc) TQ_NAP(1);
         }
         TQ_ACC(12, ts0);
-        const double* sp = stage + (size_t)(kc % S) * C * TQ_LINES + 64 * q + l;      // (read step by step: eight values held per chunk cost the backward kernel its registers)
+        const double* sp = stage + (size_t)(kc % S) * C * TQ_LINES + (64 * q + l) * 2;    // (read pair by pair: eight values held per chunk cost the backward kernel its registers)
+        tw_v2 rp{0.0, 0.0};
         // back-pressure: this chunk overwrites the ring slots of steps t0 - YR .. t0 + 7 - YR: every reader must be past them
         {
 #ifdef KR_TW_TRACE
@@ -573,7 +574,9 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #if defined(TQ_ABL) && (TQ_ABL & 16)
             double yj = y, yk = y;
 #else
-            double yj = tw_bperm(idx1, y), yk = tw_bperm(idx8, y);
+            // the j-neighbour's row sits one lane down in the same row of 16 lanes: a DPP shift (no LDS); lanes with jl == 0 (every
+            // eighth) take the west row instead.  The k-neighbour is 8 lanes down, across rows of 16: a wave permute.
+            double yj = tq_shr1(y), yk = tw_bperm(idx8, y);
 #endif
             if (jl == 0) yj = wv;
             if (kl == 0) yk = sv;
@@ -585,7 +588,8 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #if defined(TQ_ABL) && (TQ_ABL & 64)
             double s = 1.0;
 #else
-            double s = sp[u * TQ_LINES];
+            if ((u & 1) == 0) rp = *reinterpret_cast<const tw_v2*>(sp + (u >> 1) * TQ_LINES * 2);
+            double s = (u & 1) ? rp.y : rp.x;
 #endif
             if (FORWARD) {                                                 // stored order: k-, j-, i-neighbour (ascending column)
                 s = s - a3 * yk; s = s - a2 * yj; s = s - a1 * yi;
@@ -598,7 +602,8 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #if !(defined(TQ_ABL) && (TQ_ABL & 32))
             my_ring[(t & (YR - 1)) * 64] = s;                              // all 64 rows of the step, one unmasked store;
 #endif
-            if (l == 0) tq_publish(&prog[q], t + 1);                       // then the count (LDS executes a wave's operations in order)
+            tq_publish(&prog[q], t + 1);                                   // then the count (LDS executes a wave's operations in order); written by ALL lanes --
+                                                                           // same value, same word: masking it down to one lane costs 15-20 ns per step (tools/micro/quadstep.hip)
         }
         TQ_ACC(16, tsteps0);
         if (l == 0) tq_publish(&taken[q], kc + 1);                       // stage slot free (same-wave LDS operations complete in order: the reads above are done)
