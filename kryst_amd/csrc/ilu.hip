@@ -43,8 +43,8 @@ static void par_rows(int64_t n, F body) {
     for (auto& t : th) t.join();
 }
 static int env_i(const char* nm, int d) { const char* e = getenv(nm); return e ? atoi(e) : d; }
-// wavefront kernel by number of 8 x 8 line blocks in the (j, k) plane: the 16 x 16 kernel from 96^3 up (table at its use)
-static int default_wave_form(unsigned nb8) { return nb8 >= 144 ? 2 : 1; }
+// wavefront kernel by number of 8 x 8 line blocks in the (j, k) plane: the 16 x 16 kernel from 32^3 up (table at its use)
+static int default_wave_form(unsigned nb8) { return nb8 >= 16 ? 2 : 1; }
 
 struct TriArgs {                    // device-resident argument block, rewritten before every apply (graph-friendly):
     const double* r; double* z; long long skip;   // one scalar load gives a level kernel everything it needs
@@ -455,8 +455,9 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
         const GridFactor& A = D->GL; const GridFactor& B = D->GU;
         const unsigned nb = (unsigned)(((A.Nj + 7) / 8) * ((A.Nk + 7) / 8));
         // KRYST_ILU_WAVE: 2 = 16 x 16 lines per workgroup (tri_quad.h), 1 = 8 x 8 lines (tri_wave.h), 0 = its one-wave predecessor.
-        // Default by size (measured, MI355X, true ILU(0) apply, 16 x 16 vs 8 x 8): 48^3 0.147 / 0.146 ms, 64^3 0.191 / 0.184,
-        // 96^3 0.269 / 0.286, 128^3 0.345 / 0.358, 192^3 0.632 / 0.679, 256^3 0.869 / 1.004, 384^3 1.74 / 2.79, 512^3 3.3-3.5 / 5.7
+        // Default by size (measured, MI355X, true ILU(0) apply, 16 x 16 vs 8 x 8): 24^3 0.088 / 0.083 ms, 32^3 0.094 / 0.098,
+        // 48^3 0.129 / 0.148, 64^3 0.165 / 0.184, 96^3 0.231 / 0.286, 128^3 0.297 / 0.356, 256^3 0.70 / 1.00, 384^3 1.18 / 2.65,
+        // 512^3 2.06 / 5.7
         const int wave_on = env_int("KRYST_ILU_WAVE", default_wave_form(nb));
         const GridView VA{A.Ni, A.Nj, A.Nk, A.d_c1, A.d_c2, A.d_c3, nullptr}, VB{B.Ni, B.Nj, B.Nk, B.d_c1, B.d_c2, B.d_c3, B.d_diag};
         if (D->safe || env_int("KRYST_ILU_PLANES", 0)) {
