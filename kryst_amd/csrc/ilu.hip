@@ -1215,6 +1215,15 @@ extern "C" int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kr
 extern "C" int32_t kryst_debug_tq_trace(long long* host, int32_t count) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(kr::tq_trace), sizeof(long long) * count) == hipSuccess ? 0 : 1;
 }
+extern "C" int32_t kryst_debug_tq_select(int32_t a, int32_t b) {
+    const int v[2] = {a, b};
+    return hipMemcpyToSymbol(HIP_SYMBOL(kr::tq_sel), v, sizeof(v)) == hipSuccess ? 0 : 1;
+}
+extern "C" int32_t kryst_debug_tq_steps(long long* host) {          // 3 x 1024: solver steps, poller deliveries, exporter stores
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(kr::tq_steps), sizeof(long long) * 1024) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(host + 1024, HIP_SYMBOL(kr::tq_deliv), sizeof(long long) * 1024) != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(host + 2048, HIP_SYMBOL(kr::tq_export), sizeof(long long) * 1024) == hipSuccess ? 0 : 1;
+}
 extern "C" int32_t kryst_debug_tw_trace(long long* host, int32_t count) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(kr::tw_trace), sizeof(long long) * count) == hipSuccess ? 0 : 1;
 }

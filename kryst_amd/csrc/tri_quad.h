@@ -72,6 +72,11 @@ __device__ __forceinline__ int tq_peek(int* p) {
 // trace build (tools/tq_trace.py): per block and quadrant of the FORWARD solve: [0] entry, [1] first coefficients in registers,
 // [2 + c] chunk c done (c < 8), [10] last chunk done, [11] ticks waiting for neighbour rows, [12] for the stage, [13] for sibling ring space
 __device__ long long tq_trace[4096 * 4 * 16];
+// step-level trace of two chosen blocks (tq_sel, linear K * nbj + J): [which][quadrant or stream][step < 128]
+__device__ int tq_sel[2] = {-1, -1};
+__device__ long long tq_steps[2 * 4 * 128], tq_deliv[2 * 4 * 128], tq_export[2 * 4 * 128];
+#define TQ_STEP_TRACE(arr, qq, step_) do { if (FORWARD && (step_) < 128) { const int w_ = blk == tq_sel[0] ? 0 : blk == tq_sel[1] ? 1 : -1; \
+    if (w_ >= 0) arr[(w_ * 4 + (qq)) * 128 + (step_)] = wall_clock64(); } } while (0)
 #define TQ_STAMP(slot) do { if (FORWARD && l == 0 && blk < 4096) tq_trace[(blk * 4 + q) * 16 + (slot)] = wall_clock64(); } while (0)
 #define TQ_T0(name) const long long name = wall_clock64()
 #define TQ_ACC(slot, t0_) do { tq_acc[(slot) - 11] += wall_clock64() - (t0_); } while (0)      // (registers: a read-modify-write of memory would stall the wave)
@@ -79,6 +84,7 @@ __device__ long long tq_trace[4096 * 4 * 16];
 #define TQ_STAMP(slot) do { } while (0)
 #define TQ_ACC(slot, t0_) do { } while (0)
 #define TQ_T0(name) do { } while (0)
+#define TQ_STEP_TRACE(arr, qq, step_) do { } while (0)
 #endif
 
 __device__ __forceinline__ void tq_block_of(int b, int nbj, int nbk, int& J, int& K) {     // anti-diagonal numbering
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             }
             if (so < m) { ring[((t + so) % R) * 8 + 2 * piece] = p0.x; ring[((t + so) % R) * 8 + 2 * piece + 1] = p0.y; }
             if (so + 4 < m) { ring[((t + so + 4) % R) * 8 + 2 * piece] = p1.x; ring[((t + so + 4) % R) * 8 + 2 * piece + 1] = p1.y; }
-            if (m > 0) { t += m; if (idx == 0) tq_publish(avail, t); }
+            if (m > 0) { if (idx == 0) for (int z = 0; z < m; ++z) TQ_STEP_TRACE(tq_deliv, gI, t + z); t += m; if (idx == 0) tq_publish(avail, t); }
             if (stuck) { TQ_NAP(1); --budget; }
         }
         return;
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             if (__ballot(te < T) == 0) break;
             const int n = max(0, min(min(tq_peek(&prog[sq]), T) - te, 2));
             if (te < T && so < n) __hip_atomic_store(dst + (int64_t)(te + so) * 16, src[((te + so) & (YR - 1)) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (te < T && n > 0) { te += n; if (idx == 0) tq_publish(&exported[es], te); }
+            if (te < T && n > 0) { if (idx == 0) for (int z = 0; z < n; ++z) TQ_STEP_TRACE(tq_export, es, te + z); te += n; if (idx == 0) tq_publish(&exported[es], te); }
             if (__ballot(n > 0) == 0) { if (tq_peek(&quit)) break; TQ_NAP(1); }
         }
         return;
@@ -602,6 +608,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #if !(defined(TQ_ABL) && (TQ_ABL & 32))
             my_ring[(t & (YR - 1)) * 64] = s;                              // all 64 rows of the step, one unmasked store;
 #endif
+            if (l == 0) TQ_STEP_TRACE(tq_steps, q, t);
             tq_publish(&prog[q], t + 1);                                   // then the count (LDS executes a wave's operations in order); written by ALL lanes --
                                                                            // same value, same word: masking it down to one lane costs 15-20 ns per step (tools/micro/quadstep.hip)
         }
