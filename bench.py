@@ -178,10 +178,10 @@ def traffic_of(grid, form):
     """HBM bytes per SpMV launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh, read side
     calibrated on a kernel of known byte count as MI355X_MICROARCH.md prescribes) -- only when that measurement was made on
     THIS source tree (same sha of kryst_amd/csrc + include), else None."""
-    from kryst_amd._ffi import source_sha16
+    from kryst_amd._ffi import spmv_source_sha16
     try:
         e = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json")))[str(grid)][form]
-        if e.get("source_sha16") != source_sha16():
+        if e.get("source_sha16") != spmv_source_sha16():
             return None
         return e["hbm_bytes_per_launch"]
     except Exception:

@@ -132,19 +132,32 @@ def lib():
     return _lib
 
 
-def source_sha16():
-    """sha256 (first 16 hex digits) over the library's sources (kryst_amd/csrc/*.{hip,h,cpp}, Makefile, include/kryst_hip.h):
-    measurements kept under profiles/ carry it, so that bench.py only quotes one beside numbers from the same source tree."""
+def source_sha16(only=None):
+    """sha256 (first 16 hex digits) over the library's sources (kryst_amd/csrc/*.{hip,h,cpp}, Makefile, include/kryst_hip.h), or
+    over the named files of kryst_amd/csrc only: measurements kept under profiles/ carry it, so that bench.py only quotes one
+    beside numbers from the same sources."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
-                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(_HERE, "csrc", "Makefile"),
-                                                                       os.path.join(os.path.dirname(_HERE), "include", "kryst_hip.h")])
+    if only:
+        files = [os.path.join(_HERE, "csrc", f) for f in sorted(only)]
+    else:
+        files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                       glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(_HERE, "csrc", "Makefile"),
+                                                                           os.path.join(os.path.dirname(_HERE), "include", "kryst_hip.h")])
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+# what the SpMV kernels and their launch are built from: the PMC traffic of profiles/spmv_traffic.json is stamped with this, so
+# that work on other kernels (the triangular solves, the solvers) does not orphan it
+SPMV_SOURCES = ("spmv.hip", "csr_create.hip", "csr.h", "common.h", "ew.h", "Makefile")
+
+
+def spmv_source_sha16():
+    return source_sha16(SPMV_SOURCES)
 
 
 class KError(Exception):

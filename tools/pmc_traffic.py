@@ -3,11 +3,11 @@
 HBM traffic of the SpMV kernel, following MI355X_MICROARCH.md (HBM section): the counters are in KiB; on gfx950
 FETCH_SIZE under-reports wide coalesced reads by 2x, so the read side is CALIBRATED on a kernel with a known byte
 count in the same process (ew_kernel<DotOp>: 2*n*8 bytes, 16 B/lane loads).  The result carries the sha of the source tree
-it was measured on (kryst_amd._ffi.source_sha16): bench.py quotes it only beside numbers from the same sources.
+it was measured on (kryst_amd._ffi.spmv_source_sha16: the files the SpMV kernels are built from): bench.py quotes it only beside numbers from the same sources.
 usage: pmc_traffic.py <fetch_dir> <write_dir> <grid> <out.json> [merge_into.json form]"""
 import csv, glob, json, os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from kryst_amd._ffi import source_sha16
+from kryst_amd._ffi import spmv_source_sha16
 
 
 def means(d, counter):
@@ -27,7 +27,7 @@ dotk = [k for k in fm if "DotOp" in k][0]
 known = 2 * n * 8
 cal = known / (fm[dotk][0] * 1024.0)
 res = {
-    "grid": grid, "kernel": spmv, "launches": fm[spmv][1], "source_sha16": source_sha16(),
+    "grid": grid, "kernel": spmv, "launches": fm[spmv][1], "source_sha16": spmv_source_sha16(),
     "FETCH_SIZE_KiB": fm[spmv][0], "WRITE_SIZE_KiB": wm[spmv][0],
     "calibration": {"kernel": dotk, "known_read_bytes": known, "FETCH_SIZE_KiB": fm[dotk][0], "factor": cal},
     "read_bytes_per_launch": fm[spmv][0] * 1024.0 * cal, "write_bytes_per_launch": wm[spmv][0] * 1024.0,
