@@ -15,7 +15,7 @@ for g in 256 512; do
   done
 done
 unset KRYST_SPMV_COMPRESS
-cp $O/spmv_traffic.json $R/profiles/spmv_traffic.json
+cp $O/spmv_traffic.json $R/profiles/spmv_traffic.json   # (on the GPU box only: copy gpurun_out/round/spmv_traffic.json into profiles/ after the call)
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_prof -o bench -- python3 $R/bench.py > $O/bench_prof.log 2>&1 || exit 1
 python3 $R/tools/kernel_by_size.py $O/bench_prof $O/bench_default_kernel_by_size.csv || exit 1
 for g in 256 512; do
