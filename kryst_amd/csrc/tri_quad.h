@@ -8,11 +8,16 @@
 //     workgroup's west and south boundary come through memory, so a 256^3 solve has 30 memory hops instead of 62 and every
 //     block of the grid is resident at once (256 workgroups);
 //   * the factor's coefficients are stored at setup in BLOCKED layout -- [block][chunk of 8 steps][array][step pair][lane],
-//     zero where a lane is outside its line -- so a solving wave loads them itself, 1 KiB per instruction, two chunks ahead, and
-//     needs no activity predicate in its step (a zero coefficient selects a +0.0 operand, as in tri_wave.h); only the right-hand
-//     side, which lives in the caller's natural layout, still goes through a LOADER wave and an LDS stage;
-//   * what a neighbouring workgroup needs is written to compact EDGE buffers -- [block][producer step][16 lines], one memory
-//     line per step -- instead of being picked out of the solution vector: a POLLER round is two contiguous 1 KiB reads.
+//     zero where a lane is outside its line -- so a solving wave loads them itself, 1 KiB per instruction, two chunks ahead
+//     (inline-asm requests counted by hand), and needs no activity predicate in its step (a zero coefficient selects a +0.0
+//     operand, as in tri_wave.h); a chunk whose coefficients repeat chunk - 3's bit for bit (flags from setup: the factors of
+//     constant-coefficient operators settle to the last bit a few rows from the box's low faces) is not requested at all;
+//   * the right-hand side, which lives in the caller's natural layout, goes through two LOADER waves and an LDS stage; the
+//     same waves store the RESULTS, read out of the solving waves' rings as whole 64-byte groups, four lanes per line -- a
+//     solving wave issues no global store and, away from the low faces, no load;
+//   * what a neighbouring workgroup needs is written by an EXPORTER wave to compact EDGE buffers -- [block][producer step]
+//     [16 lines], one memory line per step -- instead of being picked out of the solution vector: a POLLER round is two
+//     contiguous 1 KiB reads.
 // Lane (jl, kl) of a quadrant walks its line one row per step, skewed by jl + kl; quadrants run on their own clocks: a consumer
 // at step t needs its producer (sibling quadrant or neighbouring workgroup) to have finished step t + 7.
 // Same arithmetic and order as every other triangular-solve form (stored, i.e. ascending-column, order): bit-identical.

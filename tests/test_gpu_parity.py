@@ -352,6 +352,52 @@ def test_structured_grid_triangular_solve_bit_exact(ctx, grid_path, monkeypatch)
                 assert np.array_equal(pc.apply(r), ref.apply(r)), (grid_path, a.nrows)
 
 
+def test_repeated_coefficient_chunks_are_skipped_bit_exact(ctx, monkeypatch, capfd):
+    """tri_quad.h does not request a coefficient chunk that repeats chunk - 3's bits (flags from setup).  On a constant-coefficient
+    box most chunks carry the flag (reported by KRYST_ILU_VERBOSE); on a box with random coefficients none does; the solve gives the
+    oracle's bits either way and the same bits as with KRYST_ILU_DEDUP=0."""
+    import re
+    import scipy.sparse as sp
+    monkeypatch.setenv("KRYST_ILU_WAVE", "2"); monkeypatch.setenv("KRYST_ILU_GRID", "1"); monkeypatch.setenv("KRYST_ILU_VERBOSE", "1")
+    rng = np.random.default_rng(11)
+    a = O.stencil7(96, "aniso")                                            # 96^3: 6 x 6 blocks of 16 x 16 lines, 14 chunks each (the factor settles ~15 rows in)
+    d = to_dev(ctx, a)
+    ref = O.Pc.ilu0_true(a)
+    outs = {}
+    for dedup in ("1", "0"):
+        monkeypatch.setenv("KRYST_ILU_DEDUP", dedup)
+        capfd.readouterr()
+        pc = K.TrueIlu0().setup(d)
+        err = capfd.readouterr().err
+        counts = [int(m.group(1)) for m in re.finditer(r"(\d+) of \d+ coefficient chunks repeat", err)]
+        if dedup == "1":
+            assert len(counts) == 2 and min(counts) > 0, err               # both factors have repeating chunks away from the low faces
+        else:
+            assert counts == [], err
+        r = rng.standard_normal(a.nrows)
+        rng = np.random.default_rng(11)                                    # the same right-hand side for both settings
+        outs[dedup] = pc.apply(r)
+        assert np.array_equal(outs[dedup], ref.apply(r)), dedup
+    assert np.array_equal(outs["1"], outs["0"])
+    # random coefficients: nothing repeats
+    monkeypatch.setenv("KRYST_ILU_DEDUP", "1")
+    n1 = 32
+    idx = np.arange(n1 ** 3).reshape(n1, n1, n1)
+    rows, cols, vals = [np.arange(n1 ** 3)], [np.arange(n1 ** 3)], [rng.uniform(6.5, 8.0, n1 ** 3)]
+    for lo, hi in ((idx[:, :, :-1], idx[:, :, 1:]), (idx[:, :-1, :], idx[:, 1:, :]), (idx[:-1, :, :], idx[1:, :, :])):
+        for a_, b_ in ((lo.ravel(), hi.ravel()), (hi.ravel(), lo.ravel())):
+            rows.append(a_); cols.append(b_); vals.append(rng.uniform(-1.0, 1.0, len(a_)))
+    m = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n1 ** 3, n1 ** 3)); m.sort_indices()
+    b = O.Csr(n1 ** 3, n1 ** 3, m.indptr, m.indices, m.data)
+    capfd.readouterr()
+    pc = K.TrueIlu0().setup(to_dev(ctx, b))
+    err = capfd.readouterr().err
+    counts = [int(mm.group(1)) for mm in re.finditer(r"(\d+) of \d+ coefficient chunks repeat", err)]
+    assert counts == [0, 0], err
+    r = rng.standard_normal(b.nrows)
+    assert np.array_equal(pc.apply(r), O.Pc.ilu0_true(b).apply(r))
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_structured_grid_solve_random_boxes_and_missing_entries(ctx, seed, monkeypatch):
     """Random boxes, random coefficients and randomly MISSING couplings (an entry that is absent must contribute nothing, not
