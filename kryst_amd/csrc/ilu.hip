@@ -48,6 +48,7 @@ static int default_wave_form(unsigned nb8) { return nb8 >= 16 ? 2 : 1; }
 
 struct TriArgs {                    // device-resident argument block, rewritten before every apply (graph-friendly):
     const double* r; double* z; long long skip;   // one scalar load gives a level kernel everything it needs
+    long long epoch;                              // number of this apply (tri_quad.h: the value of its "under way" flags)
 };
 
 #define ELLW 4
@@ -396,7 +397,10 @@ __global__ __launch_bounds__(1024) void tri_run_kernel(const TriArgs* args, cons
 }
 
 // runs in stream order before the level kernels, so it sees the solver's `done` flag as of this apply
-__global__ void tri_set_args(TriArgs* a, const double* r, double* z, const int* done) { a->r = r; a->z = z; a->skip = (done && *done) ? 1 : 0; }
+__global__ void tri_set_args(TriArgs* a, const double* r, double* z, const int* done) {
+    a->r = r; a->z = z; a->skip = (done && *done) ? 1 : 0;
+    a->epoch = (a->epoch & 0x3fffffff) + 1;         // 1, 2, ... (d_args is zeroed at setup); never 0, the flags' initial value
+}
 
 // dst[p] = src[map[p]]   (MODE 0: src = the caller's r;  MODE 1: plain gather;  MODE 2: scatter into the caller's z: z[map[p]] = src[p])
 template <int MODE>
@@ -477,9 +481,7 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
             const unsigned nq = (unsigned)(A.nbj * A.nbk);
             const QuadView QA{A.Ni, A.Nj, A.Nk, A.nbj, A.nbk, A.nch, (const tw_v2*)A.d_blocked, A.d_edge_e, A.d_edge_n, A.d_skip};
             const QuadView QB{B.Ni, B.Nj, B.Nk, B.nbj, B.nbk, B.nch, (const tw_v2*)B.d_blocked, B.d_edge_e, B.d_edge_n, B.d_skip};
-            const unsigned fg = std::min<unsigned>(1024u, nq * 4u);
-            hipLaunchKernelGGL(tri_quad_fill_kernel, dim3(fg), dim3(256), 0, s, D->d_args, A.d_edge_e, A.d_edge_n, (int)nq, A.nch, D->d_flags, (int32_t)(2 * nb + 1));
-            hipLaunchKernelGGL(tri_quad_fill_kernel, dim3(fg), dim3(256), 0, s, D->d_args, B.d_edge_e, B.d_edge_n, (int)nq, B.nch, (int32_t*)nullptr, 0);
+            // (no per-apply launch re-arms the edge buffers or the flags: tri_quad.h, poller / epoch)
             hipLaunchKernelGGL((tri_quad_kernel<true>), dim3(nq), dim3(512), 0, s, D->d_args, (const double*)nullptr, D->d_y, QA, D->n, D->d_flags, D->d_flags + 2 * nb, D->d_gave_up, budget);
             hipLaunchKernelGGL((tri_quad_kernel<false>), dim3(nq), dim3(512), 0, s, D->d_args, (const double*)D->d_y, (double*)nullptr, QB, D->n, D->d_flags + nb, D->d_flags + 2 * nb, D->d_gave_up, budget);
             KR_HIP(hipGetLastError());
@@ -714,7 +716,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
     kryst_ctx_t ctx = pc->ctx;
     const int64_t n = D->n;
     int32_t rc = KRYST_OK;
-    if (hipMalloc(&D->d_args, sizeof(TriArgs)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+    if (hipMalloc(&D->d_args, sizeof(TriArgs)) != hipSuccess || hipMemset(D->d_args, 0, sizeof(TriArgs)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
     if (rc == KRYST_OK) {
         const size_t bytes = sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
         const bool grid = D->GL.ok && D->GU.ok;                            // the wavefront solve works in place: one intermediate vector
@@ -728,7 +730,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
     }
     if (rc == KRYST_OK && D->GL.ok && D->GU.ok) {
         const size_t nb = (size_t)((D->GL.Nj + 7) / 8) * (size_t)((D->GL.Nk + 7) / 8);
-        if (hipMalloc(&D->d_flags, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (hipMalloc(&D->d_flags, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess || hipMemset(D->d_flags, 0, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
         if (rc == KRYST_OK && (hipHostMalloc((void**)&D->h_gave_up, 64, hipHostMallocMapped) != hipSuccess ||
                                hipHostGetDevicePointer((void**)&D->d_gave_up, D->h_gave_up, 0) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = KRYST_ERR_HIP; }
         if (rc == KRYST_OK) *D->h_gave_up = 0;
@@ -748,6 +750,8 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
                 const unsigned lg = (unsigned)(nq * G->nch);
                 if (fwd) hipLaunchKernelGGL((tri_quad_layout_kernel<true, 3>), dim3(lg), dim3(256), 0, ctx->s_main, V, G->nbj, G->nbk, G->nch, (tw_v2*)G->d_blocked);
                 else hipLaunchKernelGGL((tri_quad_layout_kernel<false, 4>), dim3(lg), dim3(256), 0, ctx->s_main, V, G->nbj, G->nbk, G->nch, (tw_v2*)G->d_blocked);
+                // edge buffers armed once (sentinels; zeros past the last step): between applies the pollers re-arm what they consume
+                hipLaunchKernelGGL(tri_quad_fill_kernel, dim3(std::min<unsigned>(1024u, (unsigned)nq * 4u)), dim3(256), 0, ctx->s_main, G->d_edge_e, G->d_edge_n, (int)nq, G->nch, (int32_t*)nullptr, 0);
                 // which chunks repeat chunk - 3 bit for bit (their coefficients are in the solving wave's registers already)
                 if (env_i("KRYST_ILU_DEDUP", 1) && G->nch + 3 <= TQ_SKIPMAX) {
                     if (hipMalloc(&G->d_skip, nq * 4 * (size_t)G->nch) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; break; }

@@ -157,9 +157,9 @@ __global__ __launch_bounds__(256) void tri_quad_dedup_kernel(const tw_v2* coef, 
     if ((L & 63) == 0) skip[((size_t)blk * 4 + q) * nch + c] = all ? 1 : 0;
 }
 
-// ---- per apply: sentinels into the edge buffers (zeros in the 8 steps past the last chunk: rows nobody has), flags and abort word cleared
-__global__ __launch_bounds__(256) void tri_quad_fill_kernel(const TriArgs* args, double* edge_e, double* edge_n, int nblk, int nch, int32_t* flags, int32_t nflags) {
-    if (args->skip) return;
+// ---- ONCE, at setup: sentinels into the edge buffers (zeros in the 8 steps past the last chunk: rows nobody has), flags and abort
+// word cleared.  Between applies the pollers re-arm the cells they consumed and the flags carry the apply's number.
+__global__ __launch_bounds__(256) void tri_quad_fill_kernel(double* edge_e, double* edge_n, int nblk, int nch, int32_t* flags, int32_t nflags) {
     const int64_t per = (int64_t)(nch * TQ_C + 8) * 16;                   // doubles per block and direction
     const int64_t total = per * nblk;
     const double sentinel = __longlong_as_double((long long)KR_TRI_SENTINEL);
@@ -174,6 +174,7 @@ template <bool FORWARD>
 __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, QuadView Q, int64_t n,
                                                           int32_t* flags, int32_t* abort_word, int32_t* gave_up, int poll_budget) {
     if (args->skip) return;
+    const int32_t epoch = (int32_t)args->epoch;                            // this apply's number: the value of an "under way" flag (nothing resets the flags)
     constexpr int C = TQ_C, S = TQ_S, R = TQ_R;
     constexpr int NA = FORWARD ? 3 : 4;                                    // coefficient arrays per chunk
     constexpr int YR = TQ_YR;
@@ -399,8 +400,8 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         // GATE: until the producers are under way, look at their flags only
         if (l == 0) {
             for (int budget = 1 << 22; budget > 0; --budget) {
-                const bool ok_w = J == 0 || __hip_atomic_load(&flags[blk - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                const bool ok_s = K == 0 || __hip_atomic_load(&flags[blk - Q.nbj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                const bool ok_w = J == 0 || __hip_atomic_load(&flags[blk - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                const bool ok_s = K == 0 || __hip_atomic_load(&flags[blk - Q.nbj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
                 if (ok_w && ok_s) break;
                 if ((budget & 63) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                 TQ_NAP(8);
@@ -438,8 +439,14 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
                 if (l < 4) { tq_publish(&pavail[l], HUGE_STEPS); tq_publish(&prog[l], HUGE_STEPS); tq_publish(&exported[l], HUGE_STEPS); }
                 return;
             }
-            if (so < m) { ring[((t + so) % R) * 8 + 2 * piece] = p0.x; ring[((t + so) % R) * 8 + 2 * piece + 1] = p0.y; }
-            if (so + 4 < m) { ring[((t + so + 4) % R) * 8 + 2 * piece] = p1.x; ring[((t + so + 4) % R) * 8 + 2 * piece + 1] = p1.y; }
+            // delivered rows go into the ring, and their cells in the edge buffer back to the sentinel for the NEXT apply (this block
+            // is their only reader; the kernel boundary orders the store before the producer's next write) -- so that no launch
+            // has to re-arm the buffers between applies.  Rows past the producer's last step are zeros for good.
+            const tw_v2 rearm{__longlong_as_double((long long)KR_TRI_SENTINEL), __longlong_as_double((long long)KR_TRI_SENTINEL)};
+            if (so < m) { ring[((t + so) % R) * 8 + 2 * piece] = p0.x; ring[((t + so) % R) * 8 + 2 * piece + 1] = p0.y;
+                          if (t + 7 + so < T) *(__attribute__((address_space(1))) tw_v2*)a0 = rearm; }
+            if (so + 4 < m) { ring[((t + so + 4) % R) * 8 + 2 * piece] = p1.x; ring[((t + so + 4) % R) * 8 + 2 * piece + 1] = p1.y;
+                              if (t + 7 + so + 4 < T) *(__attribute__((address_space(1))) tw_v2*)a1 = rearm; }
             if (m > 0) { if (idx == 0) for (int z = 0; z < m; ++z) TQ_STEP_TRACE(tq_deliv, gI, t + z); t += m; if (idx == 0) tq_publish(avail, t); }
             if (stuck) { TQ_NAP(1); --budget; }
         }
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             TQ_ACC(13, tb0);
         }
         if (kc == 0 && q == 0 && l == 0)                                   // this block is under way: the blocks behind it may start asking
-            __hip_atomic_store(&flags[blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&flags[blk], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         TQ_T0(tsteps0);
 #pragma unroll
         for (int u = 0; u < C; ++u) {
