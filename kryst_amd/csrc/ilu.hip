@@ -745,7 +745,15 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
                 const size_t cbytes = nq * G->nch * NA * 4 * TQ_LINES * sizeof(tw_v2);
                 const size_t ebytes = nq * (size_t)(G->nch * TQ_C + 8) * 16 * sizeof(double);
                 if (hipMalloc(&G->d_blocked, cbytes) != hipSuccess || hipMalloc(&G->d_edge_e, ebytes) != hipSuccess ||
-                    hipMalloc(&G->d_edge_n, ebytes) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; break; }
+                    hipMalloc(&G->d_edge_n, ebytes) != hipSuccess) {
+                    // no room for the blocked copy (it doubles the factor's footprint): the 8 x 8 kernel works on the natural-order streams
+                    (void)hipGetLastError();
+                    for (GridFactor* H : {&D->GL, &D->GU}) {
+                        (void)hipFree(H->d_blocked); (void)hipFree(H->d_edge_e); (void)hipFree(H->d_edge_n); (void)hipFree(H->d_skip);
+                        H->d_blocked = nullptr; H->d_edge_e = H->d_edge_n = nullptr; H->d_skip = nullptr;
+                    }
+                    break;
+                }
                 const GridView V{G->Ni, G->Nj, G->Nk, G->d_c1, G->d_c2, G->d_c3, G->d_diag};
                 const unsigned lg = (unsigned)(nq * G->nch);
                 if (fwd) hipLaunchKernelGGL((tri_quad_layout_kernel<true, 3>), dim3(lg), dim3(256), 0, ctx->s_main, V, G->nbj, G->nbk, G->nch, (tw_v2*)G->d_blocked);
@@ -754,8 +762,8 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
                 hipLaunchKernelGGL(tri_quad_fill_kernel, dim3(std::min<unsigned>(1024u, (unsigned)nq * 4u)), dim3(256), 0, ctx->s_main, G->d_edge_e, G->d_edge_n, (int)nq, G->nch, (int32_t*)nullptr, 0);
                 // which chunks repeat chunk - 3 bit for bit (their coefficients are in the solving wave's registers already)
                 if (env_i("KRYST_ILU_DEDUP", 1) && G->nch + 3 <= TQ_SKIPMAX) {
-                    if (hipMalloc(&G->d_skip, nq * 4 * (size_t)G->nch) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; break; }
-                    if (fwd) hipLaunchKernelGGL((tri_quad_dedup_kernel<3>), dim3(lg), dim3(256), 0, ctx->s_main, (const tw_v2*)G->d_blocked, G->nch, G->d_skip);
+                    if (hipMalloc(&G->d_skip, nq * 4 * (size_t)G->nch) != hipSuccess) { (void)hipGetLastError(); G->d_skip = nullptr; }      // (flags are optional)
+                    else if (fwd) hipLaunchKernelGGL((tri_quad_dedup_kernel<3>), dim3(lg), dim3(256), 0, ctx->s_main, (const tw_v2*)G->d_blocked, G->nch, G->d_skip);
                     else hipLaunchKernelGGL((tri_quad_dedup_kernel<4>), dim3(lg), dim3(256), 0, ctx->s_main, (const tw_v2*)G->d_blocked, G->nch, G->d_skip);
                 }
                 if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("blocked layout kernel failed"); rc = KRYST_ERR_HIP; }
