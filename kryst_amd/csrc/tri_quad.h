@@ -491,6 +491,8 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     // who reads this quadrant's ring (back-pressure): sibling quadrants and exporter streams
     const int cons_a = qj == 0 ? q + 1 : -1, cons_b = qk == 0 ? q + 2 : -1;
     const int exp_a = q == 1 ? 0 : q == 3 ? 1 : -1, exp_b = q == 2 ? 2 : q == 3 ? 3 : -1;
+    int* const rp_a = cons_a >= 0 ? &taken[cons_a] : &always; int* const rp_b = cons_b >= 0 ? &taken[cons_b] : &always;
+    int* const rp_e = exp_a >= 0 ? &exported[exp_a] : &always; int* const rp_f = exp_b >= 0 ? &exported[exp_b] : &always;
     double* const my_ring = yring + q * YR * 64 + l;
     const int idx8 = max(l - 8, 0) * 4;
     cg_v2* const coef = (cg_v2*)Q.coef + (size_t)blk * nch * NA * 4 * TQ_LINES + 64 * q + l;
@@ -554,12 +556,17 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             const int need = t0 - YR + 1;                                  // a sibling reads my step p at its step p - 7, an exporter stream at p
 #pragma unroll 1
             for (int budget = 1 << 24; need > ring_safe && budget > 0; --budget) {
-                int m = HUGE_STEPS;
-                if (cons_a >= 0) m = min(m, tq_peek(&taken[cons_a]) * C);         // (published when the chunk's steps are done)
-                if (cons_b >= 0) m = min(m, tq_peek(&taken[cons_b]) * C);
-                if (exp_a >= 0) m = min(m, tq_peek(&exported[exp_a]) - 7);
-                if (exp_b >= 0) m = min(m, tq_peek(&exported[exp_b]) - 7);
-                m = min(m, 8 * tq_peek(&written[q]) - 14);                         // the stores of chunk w read steps >= 8 w - 7: like an exporter at that step
+                // five counters, ONE LDS round trip: all reads issued back to back (a reader that does not exist reads `always`)
+                asm volatile("" ::: "memory");
+                const int va = __hip_atomic_load(rp_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), vb = __hip_atomic_load(rp_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int ve = __hip_atomic_load(rp_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), vf = __hip_atomic_load(rp_f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int vw = __hip_atomic_load(&written[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");
+                int m = 8 * vw - 14;                                               // the stores of chunk w read steps >= 8 w - 7: like an exporter at that step
+                if (cons_a >= 0) m = min(m, va * C);                               // (published when the chunk's steps are done)
+                if (cons_b >= 0) m = min(m, vb * C);
+                if (exp_a >= 0) m = min(m, ve - 7);
+                if (exp_b >= 0) m = min(m, vf - 7);
                 ring_safe = m;
                 if (need <= ring_safe || tq_peek(&quit)) break;
                 TQ_NAP(1);
