@@ -231,11 +231,13 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         // chunks are in flight and the two paths below differ, and the compiler's automatic vmcnt then assumes the worst at every
         // merge and drains all buffers at each publish -- one HBM round trip per chunk, which was the whole kernel's pace.
         struct Buf { tw_v2 d[8]; };
-        // slow path (lines start / end inside the chunk, ragged blocks): two lines per lane (l, l + 64 of this half), their 8
-        // steps as four 16-byte pairs each -- eight loads like the fast path; a pair that sticks out of its line by one row is
-        // loaded one row further in and the missing half replaced by zero when the buffer is published
-        auto slow_pair = [&](int t0, int qd, int h, bool& oka, bool& okb, int64_t& lo) {
-            const TqLine ln = tq_line(J, K, 128 * half + 64 * qd + l);
+        // careful path (lines start / end inside the chunk, ragged blocks): the SAME lane -> (line, 16-byte piece) mapping as the
+        // interior chunks, so that the block's first and last chunks -- which every hand-over to the next block waits for -- are
+        // as coalesced as the others (two whole lines per lane, 64 memory lines per instruction, cost 5-8 % of a 256^3 apply); a
+        // step pair that sticks out of its line by one row is loaded one row further in and the missing half replaced by zero
+        // when the buffer is published, a pair wholly outside is loaded from the line's first rows and published as zeros
+        auto slow_pair = [&](int t0, int Lidx, int h, bool& oka, bool& okb, int64_t& lo) {
+            const TqLine ln = tq_line(J, K, Lidx);
             const bool line_ok = ln.jj < Q.Nj && ln.kk < Q.Nk;
             const int jx = FORWARD ? ln.jj : Q.Nj - 1 - ln.jj, kx = FORWARD ? ln.kk : Q.Nk - 1 - ln.kk;
             const int64_t line0 = line_ok ? (int64_t)(kx * Q.Nj + jx) * Q.Ni : 0;
@@ -254,13 +256,11 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
                 }
             } else {
 #pragma unroll
-                for (int qd = 0; qd < 2; ++qd)
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        bool oka, okb; int64_t lo;
-                        slow_pair(t0, qd, h, oka, okb, lo);
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b.d[4 * qd + h]) : "v"(in + lo) : "memory");
-                    }
+                for (int r = 0; r < 8; ++r) {
+                    bool oka, okb; int64_t lo;
+                    slow_pair(t0, 128 * half + 16 * r + g, c, oka, okb, lo);
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b.d[r]) : "v"(in + lo) : "memory");
+                }
             }
         };
         // `younger`: loads issued after this buffer's eight (0, 8 or 16)
@@ -287,16 +287,14 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
                 }
             } else {
 #pragma unroll
-                for (int qd = 0; qd < 2; ++qd)
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        bool oka, okb; int64_t lo;
-                        slow_pair(kc * C, qd, h, oka, okb, lo);
-                        const tw_v2 pr = b.d[4 * qd + h];
-                        const double ra = FORWARD ? pr.x : pr.y, rb = FORWARD ? pr.y : pr.x;  // line rows wc, wc + 1
-                        const double va = (oka && !okb) ? rb : ra, vb = (!oka && okb) ? ra : rb;
-                        *reinterpret_cast<tw_v2*>(dst + (h * TQ_LINES + 128 * half + 64 * qd + l) * 2) = tw_v2{oka ? va : 0.0, okb ? vb : 0.0};
-                    }
+                for (int r = 0; r < 8; ++r) {
+                    bool oka, okb; int64_t lo;
+                    slow_pair(kc * C, 128 * half + 16 * r + g, c, oka, okb, lo);
+                    const tw_v2 pr = b.d[r];
+                    const double ra = FORWARD ? pr.x : pr.y, rb = FORWARD ? pr.y : pr.x;      // line rows wc, wc + 1
+                    const double va = (oka && !okb) ? rb : ra, vb = (!oka && okb) ? ra : rb;
+                    *reinterpret_cast<tw_v2*>(dst + (c * TQ_LINES + 128 * half + 16 * r + g) * 2) = tw_v2{oka ? va : 0.0, okb ? vb : 0.0};   // steps 2c, 2c + 1
+                }
             }
             tq_publish(&staged[half], kc + 1);
         };
@@ -309,7 +307,6 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         // ragged blocks: lane = line, row by row.
         const int sg = l >> 2, sc = l & 3;                                  // store r of a chunk: line 16 r + sg of the quadrant, 16-byte piece sc
         const int g_skew0 = (sg & 7) + (sg >> 3);                           // skew of that line: g_skew0 + 2 r
-        const int o_skew = (l & 7) + (l >> 3);                              // row-by-row path: skew of line l
         auto write_chunk = [&](int qq, int kc) {
             const int wqj = qq & 1, wqk = qq >> 1;
             const double* const ring_q = yring + qq * YR * 64;
@@ -330,14 +327,21 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
                     *(__attribute__((address_space(1))) tw_v2*)(out + lo + 2 * sc) = v;
                 }
             } else {
-                const int ojj = 16 * J + 8 * wqj + (l & 7), okk = 16 * K + 8 * wqk + (l >> 3);
-                const bool o_ok = ojj < Q.Nj && okk < Q.Nk;
-                const int64_t ol0 = o_ok ? (int64_t)((FORWARD ? okk : Q.Nk - 1 - okk) * Q.Nj + (FORWARD ? ojj : Q.Nj - 1 - ojj)) * Q.Ni : 0;
-                const int m = kc - ((o_skew + 7) >> 3);
+                // first / last chunks, ragged blocks: the same four-lanes-per-line mapping, every piece with its own predicate (a
+                // group not complete yet has m < 0; a piece that straddles the line's end stores its one row)
+                const int gjj = 16 * J + 8 * wqj + (sg & 7), gkk0 = 16 * K + 8 * wqk + (sg >> 3);
 #pragma unroll
-                for (int u = 0; u < C; ++u) {
-                    const int ii = 8 * m + u;
-                    if (o_ok && ii >= 0 && ii < Q.Ni) out[ol0 + (FORWARD ? ii : Q.Ni - 1 - ii)] = ring_q[((ii + o_skew) & (YR - 1)) * 64 + l];
+                for (int r = 0; r < 4; ++r) {
+                    const int L = 16 * r + sg, gs = g_skew0 + 2 * r, m = kc - ((gs + 7) >> 3), gkk = gkk0 + 2 * r;
+                    const bool line_ok = gjj < Q.Nj && gkk < Q.Nk;
+                    const int64_t ln0 = line_ok ? (int64_t)((FORWARD ? gkk : Q.Nk - 1 - gkk) * Q.Nj + (FORWARD ? gjj : Q.Nj - 1 - gjj)) * Q.Ni : 0;
+                    const int ia = FORWARD ? 8 * m + 2 * sc : 8 * m + 7 - 2 * sc, ib = FORWARD ? ia + 1 : ia - 1;   // line rows of the piece, in memory order
+                    const bool oka = line_ok && m >= 0 && ia >= 0 && ia < Q.Ni, okb = line_ok && m >= 0 && ib >= 0 && ib < Q.Ni;
+                    const double ya = ring_q[((ia + gs) & (YR - 1)) * 64 + L], yb = ring_q[((ib + gs) & (YR - 1)) * 64 + L];
+                    gdouble* const at = out + ln0 + (FORWARD ? ia : Q.Ni - 1 - ia);                                  // memory row of line row ia; ib is the next one
+                    if (oka && okb) *(__attribute__((address_space(1))) tw_v2*)at = tw_v2{ya, yb};
+                    else if (oka) at[0] = ya;
+                    else if (okb) at[1] = yb;
                 }
             }
         };
