@@ -310,8 +310,19 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters):
         mine = {k: v / phase_iters for k, v in ph.items() if v > 0.0}
         mine["total"] = sum(mine.values())
         phases = group.gather(mine)
+    # N > 1: what one scalar collective costs end to end (local value -> RCCL all-gather -> rank-ordered fold -> host), so that the
+    # first real multi-GPU run says how much of an iteration the two inner-product exchanges can be at most
+    collective_us = None
+    if world > 1:
+        for _ in range(10):
+            ctx.all_reduce(1.0)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            ctx.all_reduce(1.0)
+        collective_us = group.allreduce_max((time.perf_counter() - t0) / 100 * 1e6)
     nnz_loc = a.nnz
-    return {"dt": dt, "dt_plain": dt_plain, "stats": stats, "enc": enc, "nloc": nloc, "nnz_loc": nnz_loc,
+    return {"dt": dt, "dt_plain": dt_plain, "stats": stats, "enc": enc, "nloc": nloc, "nnz_loc": nnz_loc, "collective_us": collective_us,
             "roofline": roofline_of(enc, grid, nloc, nnz_loc, spmv_ms, world),
             "roofline_csr": roofline_csr_of(grid, nloc, nnz_loc, plain_ms, world),
             "blas1": blas1_streams(K, ctx, nloc), "copy_gbs": copy_gbs, "phases": phases,
@@ -372,6 +383,7 @@ def main():
         "roofline": m["roofline"], "roofline_csr": m["roofline_csr"], "roofline_blas1": m["blas1"],
         "measured_copy_GBs": m["copy_gbs"],
         "phase_ms": m["phases"],         # per rank: device ms per iteration by phase (spmv / halo_wait / spmv_boundary / reduce / blas1)
+        "scalar_all_reduce_us": m["collective_us"],   # N > 1: host round trip of one scalar all-reduce (all-gather + ordered fold + sync), max over ranks
     }
     base256 = None
     if world == 1 and grid != 256 and not args.no_256:
