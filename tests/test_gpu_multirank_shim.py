@@ -21,12 +21,15 @@ def _build_shim():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("P,N,kind,hostgen", [(2, 12, "poisson", "0"), (3, 12, "convdiff", "0"), (2, 10, "aniso", "1"), (4, 16, "poisson", "1"),
-                                                 (3, 2500, "random", "0"), (4, 1031, "random", "0")])
+                                                 (3, 2500, "random", "0"), (4, 1031, "random", "0"),
+                                                 (2, 20, "aniso", "0+quad")])      # "+quad": every rank's block factor through the 16 x 16 wavefront kernel
 def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     from oracle import oracle as O
     import kryst_amd as K
     _build_shim()
-    env = dict(os.environ, KRYST_RCCL_LIB=SHIM, KRYST_STENCIL_HOST=hostgen)
+    env = dict(os.environ, KRYST_RCCL_LIB=SHIM, KRYST_STENCIL_HOST=hostgen.split("+")[0])
+    if hostgen.endswith("+quad"):
+        env["KRYST_ILU_WAVE"] = "2"
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), str(r), str(P), str(tmp_path), str(N), kind],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(P)]
     outs = []
