@@ -222,11 +222,19 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         const int g = l >> 2, c = l & 3;
         const bool full = 16 * J + 16 <= Q.Nj && 16 * K + 16 <= Q.Nk;
         auto fast_chunk = [&](int t0) { return full && t0 >= 14 && t0 + C <= Q.Ni; };     // every line of the block inside [0, Ni) for all 8 steps
-        auto row0 = [&](int r) -> int64_t {                               // row of step 0 of line 16 r + g (may lie outside the line)
+        // geometry of this lane's eight lines (16 r + g of the half), once: first row, skew, inside the grid?  (Recomputing it per
+        // load -- a division-free but 64-bit multiply-heavy line lookup, eight times per chunk in both halves of the careful path --
+        // made the loader's start-up 0.7 us longer per block, and the loader's first chunk is what a block's first step waits for.)
+        int64_t ln0[8]; int lsk[8]; bool lok[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
             const TqLine ln = tq_line(J, K, 128 * half + 16 * r + g);
+            lok[r] = ln.jj < Q.Nj && ln.kk < Q.Nk;
             const int jx = FORWARD ? ln.jj : Q.Nj - 1 - ln.jj, kx = FORWARD ? ln.kk : Q.Nk - 1 - ln.kk;
-            return (int64_t)(kx * Q.Nj + jx) * Q.Ni + (FORWARD ? -ln.skew : Q.Ni - 1 + ln.skew);
-        };
+            ln0[r] = lok[r] ? (int64_t)(kx * Q.Nj + jx) * Q.Ni : 0;
+            lsk[r] = ln.skew;
+        }
+        auto row0 = [&](int r) -> int64_t { return ln0[r] + (FORWARD ? -lsk[r] : Q.Ni - 1 + lsk[r]); };   // row of step 0 of line 16 r + g (may lie outside the line)
         // The loads are issued and waited for BY HAND (inline asm + s_waitcnt with the exact number of younger loads): three
         // chunks are in flight and the two paths below differ, and the compiler's automatic vmcnt then assumes the worst at every
         // merge and drains all buffers at each publish -- one HBM round trip per chunk, which was the whole kernel's pace.
@@ -236,16 +244,12 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         // as coalesced as the others (two whole lines per lane, 64 memory lines per instruction, cost 5-8 % of a 256^3 apply); a
         // step pair that sticks out of its line by one row is loaded one row further in and the missing half replaced by zero
         // when the buffer is published, a pair wholly outside is loaded from the line's first rows and published as zeros
-        auto slow_pair = [&](int t0, int Lidx, int h, bool& oka, bool& okb, int64_t& lo) {
-            const TqLine ln = tq_line(J, K, Lidx);
-            const bool line_ok = ln.jj < Q.Nj && ln.kk < Q.Nk;
-            const int jx = FORWARD ? ln.jj : Q.Nj - 1 - ln.jj, kx = FORWARD ? ln.kk : Q.Nk - 1 - ln.kk;
-            const int64_t line0 = line_ok ? (int64_t)(kx * Q.Nj + jx) * Q.Ni : 0;
-            const int ia = t0 + 2 * h - ln.skew, ib = ia + 1;               // line coordinates of the pair's two steps
-            oka = line_ok && ia >= 0 && ia < Q.Ni; okb = line_ok && ib >= 0 && ib < Q.Ni;
+        auto slow_pair = [&](int t0, int r, int h, bool& oka, bool& okb, int64_t& lo) {
+            const int ia = t0 + 2 * h - lsk[r], ib = ia + 1;                 // line coordinates of the pair's two steps
+            oka = lok[r] && ia >= 0 && ia < Q.Ni; okb = lok[r] && ib >= 0 && ib < Q.Ni;
             const int w = (oka && !okb) ? ia - 1 : (!oka && okb) ? ib : ia;  // a 2-row window inside the line (Ni >= 2)
             const int wc = (oka || okb) ? w : 0;
-            lo = line0 + (FORWARD ? wc : Q.Ni - 2 - wc);                     // lower memory row of the window
+            lo = ln0[r] + (FORWARD ? wc : Q.Ni - 2 - wc);                    // lower memory row of the window
         };
         auto fetch = [&](Buf& b, int t0) {
             if (fast_chunk(t0)) {
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     bool oka, okb; int64_t lo;
-                    slow_pair(t0, 128 * half + 16 * r + g, c, oka, okb, lo);
+                    slow_pair(t0, r, c, oka, okb, lo);
                     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b.d[r]) : "v"(in + lo) : "memory");
                 }
             }
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     bool oka, okb; int64_t lo;
-                    slow_pair(kc * C, 128 * half + 16 * r + g, c, oka, okb, lo);
+                    slow_pair(kc * C, r, c, oka, okb, lo);
                     const tw_v2 pr = b.d[r];
                     const double ra = FORWARD ? pr.x : pr.y, rb = FORWARD ? pr.y : pr.x;      // line rows wc, wc + 1
                     const double va = (oka && !okb) ? rb : ra, vb = (!oka && okb) ? ra : rb;
