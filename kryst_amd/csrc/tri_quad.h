@@ -311,38 +311,39 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         // ragged blocks: lane = line, row by row.
         const int sg = l >> 2, sc = l & 3;                                  // store r of a chunk: line 16 r + sg of the quadrant, 16-byte piece sc
         const int g_skew0 = (sg & 7) + (sg >> 3);                           // skew of that line: g_skew0 + 2 r
+        // (geometry once: line 16 r + sg of quadrant 2 half + qd starts at w_l0 + qd * w_dq + r * w_dr)
+        const int w_jj0 = 16 * J + (sg & 7), w_kk0 = 16 * K + 8 * half + (sg >> 3);          // quadrant qd adds 8 to jj, store r adds 2 to kk
+        const int64_t w_l0 = (int64_t)((FORWARD ? w_kk0 : Q.Nk - 1 - w_kk0) * Q.Nj + (FORWARD ? w_jj0 : Q.Nj - 1 - w_jj0)) * Q.Ni;
+        const int64_t w_dq = (FORWARD ? 8 : -8) * (int64_t)Q.Ni, w_dr = (FORWARD ? 2 : -2) * (int64_t)Q.Nj * Q.Ni;
         auto write_chunk = [&](int qq, int kc) {
-            const int wqj = qq & 1, wqk = qq >> 1;
+            const int qd = qq & 1;
             const double* const ring_q = yring + qq * YR * 64;
+            const int64_t l00 = w_l0 + qd * w_dq;
             if (full && kc >= 2 && 8 * kc + 8 <= Q.Ni) {
 #if defined(TQ_ABL) && (TQ_ABL & 1)
                 return;
 #endif
-                const int gjj = 16 * J + 8 * wqj + (sg & 7), gkk = 16 * K + 8 * wqk + (sg >> 3);
-                const int64_t l00 = (int64_t)((FORWARD ? gkk : Q.Nk - 1 - gkk) * Q.Nj + (FORWARD ? gjj : Q.Nj - 1 - gjj)) * Q.Ni;
-                const int64_t lstride = (FORWARD ? 2 : -2) * (int64_t)Q.Nj * Q.Ni;       // lines L and L + 16 are two k-planes apart
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int L = 16 * r + sg, gs = g_skew0 + 2 * r, m = kc - ((gs + 7) >> 3);
                     const int ia = FORWARD ? 8 * m + 2 * sc : 8 * m + 7 - 2 * sc, ib = FORWARD ? ia + 1 : ia - 1;   // line rows of the piece, in memory order
                     tw_v2 v;
                     v.x = ring_q[((ia + gs) & (YR - 1)) * 64 + L]; v.y = ring_q[((ib + gs) & (YR - 1)) * 64 + L];
-                    const int64_t lo = l00 + r * lstride + (FORWARD ? 8 * m : Q.Ni - 8 - 8 * m);                    // lowest memory row of the group
+                    const int64_t lo = l00 + r * w_dr + (FORWARD ? 8 * m : Q.Ni - 8 - 8 * m);                       // lowest memory row of the group
                     *(__attribute__((address_space(1))) tw_v2*)(out + lo + 2 * sc) = v;
                 }
             } else {
                 // first / last chunks, ragged blocks: the same four-lanes-per-line mapping, every piece with its own predicate (a
                 // group not complete yet has m < 0; a piece that straddles the line's end stores its one row)
-                const int gjj = 16 * J + 8 * wqj + (sg & 7), gkk0 = 16 * K + 8 * wqk + (sg >> 3);
+                const bool j_ok = w_jj0 + 8 * qd < Q.Nj;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int L = 16 * r + sg, gs = g_skew0 + 2 * r, m = kc - ((gs + 7) >> 3), gkk = gkk0 + 2 * r;
-                    const bool line_ok = gjj < Q.Nj && gkk < Q.Nk;
-                    const int64_t ln0 = line_ok ? (int64_t)((FORWARD ? gkk : Q.Nk - 1 - gkk) * Q.Nj + (FORWARD ? gjj : Q.Nj - 1 - gjj)) * Q.Ni : 0;
+                    const int L = 16 * r + sg, gs = g_skew0 + 2 * r, m = kc - ((gs + 7) >> 3);
+                    const bool line_ok = j_ok && w_kk0 + 2 * r < Q.Nk;
                     const int ia = FORWARD ? 8 * m + 2 * sc : 8 * m + 7 - 2 * sc, ib = FORWARD ? ia + 1 : ia - 1;   // line rows of the piece, in memory order
                     const bool oka = line_ok && m >= 0 && ia >= 0 && ia < Q.Ni, okb = line_ok && m >= 0 && ib >= 0 && ib < Q.Ni;
                     const double ya = ring_q[((ia + gs) & (YR - 1)) * 64 + L], yb = ring_q[((ib + gs) & (YR - 1)) * 64 + L];
-                    gdouble* const at = out + ln0 + (FORWARD ? ia : Q.Ni - 1 - ia);                                  // memory row of line row ia; ib is the next one
+                    gdouble* const at = out + (line_ok ? l00 + r * w_dr : 0) + (FORWARD ? ia : Q.Ni - 1 - ia);     // memory row of line row ia; ib is the next one
                     if (oka && okb) *(__attribute__((address_space(1))) tw_v2*)at = tw_v2{ya, yb};
                     else if (oka) at[0] = ya;
                     else if (okb) at[1] = yb;
