@@ -459,9 +459,8 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
         const GridFactor& A = D->GL; const GridFactor& B = D->GU;
         const unsigned nb = (unsigned)(((A.Nj + 7) / 8) * ((A.Nk + 7) / 8));
         // KRYST_ILU_WAVE: 2 = 16 x 16 lines per workgroup (tri_quad.h), 1 = 8 x 8 lines (tri_wave.h), 0 = its one-wave predecessor.
-        // Default by size (measured, MI355X, true ILU(0) apply, 16 x 16 vs 8 x 8): 24^3 0.088 / 0.083 ms, 32^3 0.094 / 0.098,
-        // 48^3 0.129 / 0.148, 64^3 0.165 / 0.184, 96^3 0.231 / 0.286, 128^3 0.297 / 0.356, 256^3 0.70 / 1.00, 384^3 1.18 / 2.65,
-        // 512^3 2.06 / 5.7
+        // Default by size (measured, MI355X, true ILU(0) apply, 16 x 16 vs 8 x 8): 24^3 0.088 / 0.083 ms, 32^3 0.091 / 0.098,
+        // 64^3 0.154 / 0.184, 96^3 0.217 / 0.286, 128^3 0.283 / 0.356, 256^3 0.65 / 1.00, 384^3 1.13 / 2.65, 512^3 1.91 / 5.7
         const int wave_on = env_int("KRYST_ILU_WAVE", default_wave_form(nb));
         const GridView VA{A.Ni, A.Nj, A.Nk, A.d_c1, A.d_c2, A.d_c3, nullptr}, VB{B.Ni, B.Nj, B.Nk, B.d_c1, B.d_c2, B.d_c3, B.d_diag};
         if (D->safe || env_int("KRYST_ILU_PLANES", 0)) {
