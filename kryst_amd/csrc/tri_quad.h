@@ -80,8 +80,7 @@ __device__ long long tq_trace[4096 * 4 * 16];
 // step-level trace of two chosen blocks (tq_sel, linear K * nbj + J): [which][quadrant or stream][step < 128]
 __device__ int tq_sel[2] = {-1, -1};
 __device__ long long tq_steps[2 * 4 * 128], tq_deliv[2 * 4 * 128], tq_export[2 * 4 * 128];
-#define TQ_STEP_TRACE(arr, qq, step_) do { if (FORWARD && (step_) < 128) { const int w_ = blk == tq_sel[0] ? 0 : blk == tq_sel[1] ? 1 : -1; \
-    if (w_ >= 0) arr[(w_ * 4 + (qq)) * 128 + (step_)] = wall_clock64(); } } while (0)
+#define TQ_STEP_TRACE(arr, qq, step_) do { if (FORWARD && tq_which >= 0 && (step_) < 128) arr[(tq_which * 4 + (qq)) * 128 + (step_)] = wall_clock64(); } while (0)
 #define TQ_STAMP(slot) do { if (FORWARD && l == 0 && blk < 4096) tq_trace[(blk * 4 + q) * 16 + (slot)] = wall_clock64(); } while (0)
 #define TQ_T0(name) const long long name = wall_clock64()
 #define TQ_ACC(slot, t0_) do { tq_acc[(slot) - 11] += wall_clock64() - (t0_); } while (0)      // (registers: a read-modify-write of memory would stall the wave)
@@ -195,6 +194,9 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     int J, K;
     tq_block_of(blockIdx.x, Q.nbj, Q.nbk, J, K);
     const int blk = K * Q.nbj + J;
+#ifdef KR_TW_TRACE
+    const int tq_which = blk == tq_sel[0] ? 0 : blk == tq_sel[1] ? 1 : -1;   // (read once: a load of the selection per step would pace the kernel)
+#endif
     const int nch = Q.nch, T = nch * C;
     const int64_t edge_stride = (int64_t)(T + 8) * 16;                    // doubles per block in an edge buffer
     constexpr int HUGE_STEPS = 1 << 30;
@@ -457,7 +459,11 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             if (so + 4 < m) { ring[((t + so + 4) % R) * 8 + 2 * piece] = p1.x; ring[((t + so + 4) % R) * 8 + 2 * piece + 1] = p1.y;
                               if (t + 7 + so + 4 < T) *(__attribute__((address_space(1))) tw_v2*)a1 = rearm; }
             if (m > 0) { if (idx == 0) for (int z = 0; z < m; ++z) TQ_STEP_TRACE(tq_deliv, gI, t + z); t += m; if (idx == 0) tq_publish(avail, t); }
+#ifdef TQ_SLOWSTART
+            if (stuck) { if (__ballot(t > 0) == 0) TQ_NAP(TQ_SLOWSTART); else TQ_NAP(1); --budget; }
+#else
             if (stuck) { TQ_NAP(1); --budget; }
+#endif
         }
         return;
     }

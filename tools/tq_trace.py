@@ -25,6 +25,8 @@ lib = _ffi.lib()
 lib.kryst_debug_tq_trace.argtypes = [C.POINTER(C.c_longlong), C.c_int32]
 assert lib.kryst_debug_tq_trace(buf, nb * 64) == 0
 t = np.array(buf, dtype=np.int64).reshape(nb, 4, 16).astype(np.float64) / 100.0      # us
+if os.environ.get("TQ_DUMP"):
+    np.save(os.environ["TQ_DUMP"], t)                      # the whole table [block][quadrant][slot], us
 t0 = t[:, :, 0].min()
 print(f"N {N}: {nb} blocks, {nch} chunks per block; times in us after the first entry")
 print("block  J  K  q | entry  chunk0 chunk1 chunk2 chunk3 ... end | wait: nbr stage ring coef store steps fetch | us/chunk (chunks 4..end)")
