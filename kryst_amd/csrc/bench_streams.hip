@@ -1,6 +1,6 @@
 // Measurement-only entry point: times the library's three stream shapes (Gram-Schmidt link, batched dots, CG
 // update) on vectors carved from ONE pool at a chosen byte stride, so that the effect of the vectors' relative
-// placement in HBM can be measured in isolation (tools/stride_test.py).
+// placement in HBM can be measured in isolation (tools/stride_bench.py).
 #include "solver_common.h"
 
 namespace kr {

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(KR_F) void final_fold_kernel(const double* partials
 }
 
 // A one-rank communicator normally skips RCCL; KRYST_FORCE_COMM=1 keeps the collective path (used by the
-// single-GPU rehearsal of the multi-rank code in tests/test_gpu_dist_single.py).
+// single-GPU rehearsal of the multi-rank code in tests/test_gpu_y_dist_single.py).
 bool use_collectives(kryst_ctx_t ctx) {
     if (ctx->nranks > 1) return true;
     static int force = -1;

@@ -89,7 +89,7 @@ struct kryst_ctx_s {
     double* h_pinned = nullptr;      // 4096 doubles pinned staging
     // work-vector arena: ONE allocation that the vectors of a solve are carved from and that is kept between solves
     // (separately hipMalloc'ed 128 MiB vectors land wherever the allocator has room, and multi-stream kernels then run
-    // up to 30 % slower and vary from solve to solve; a single block does not -- tools/stride_test.py)
+    // up to 30 % slower and vary from solve to solve; a single block does not -- tools/stride_bench.py)
     char* arena = nullptr; size_t arena_bytes = 0, arena_used = 0; const void* arena_owner = nullptr;
     // The scalar state of a solve (DevState, reduction results, progress record) lives in per-context scratch, so ONE solve
     // or stepping session may be open per context at a time: a second one is refused with KRYST_ERR_BUSY (kryst_hip.h).

@@ -248,6 +248,15 @@ int32_t kryst_csr_create_i32(kryst_ctx_t ctx, int64_t nrows, int64_t ncols, cons
     return create_local(ctx, nrows, ncols, row_ptr, col_idx, vals, out);
 }
 
+// host -> device on the context's compute stream, waited for: the compute stream is non-blocking, so nothing issued on the null
+// stream orders with it (the round-2 fault)
+static int32_t h2d(kryst_ctx_t ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return KRYST_OK;
+    KR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    return KRYST_OK;
+}
+
 // Phase 1 of kryst_csr_create_dist: everything that involves this rank alone (validation, halo receive plan, local column
 // numbering, upload).  No collective is entered here, so a rank may fail without the others noticing -- the caller agrees on the
 // outcome across ranks before phase 2.
@@ -283,8 +292,8 @@ static int32_t create_dist_local(kryst_csr_t a, int64_t n_global, const int64_t*
     a->n_interior = (int64_t)ti.size(); a->n_boundary = (int64_t)tb.size();
     KR_HIP(hipMalloc(&a->d_tiles_interior, sizeof(int32_t) * (ti.size() + 1)));
     KR_HIP(hipMalloc(&a->d_tiles_boundary, sizeof(int32_t) * (tb.size() + 1)));
-    if (!ti.empty()) KR_HIP(hipMemcpy(a->d_tiles_interior, ti.data(), sizeof(int32_t) * ti.size(), hipMemcpyHostToDevice));
-    if (!tb.empty()) KR_HIP(hipMemcpy(a->d_tiles_boundary, tb.data(), sizeof(int32_t) * tb.size(), hipMemcpyHostToDevice));
+    KR_TRY(h2d(ctx, a->d_tiles_interior, ti.data(), sizeof(int32_t) * ti.size()));
+    KR_TRY(h2d(ctx, a->d_tiles_boundary, tb.data(), sizeof(int32_t) * tb.size()));
     KR_HIP(hipMalloc(&pl.d_halo, sizeof(double) * (size_t)(pl.total_recv + 2)));
     KR_HIP(hipMemsetAsync(pl.d_halo, 0, sizeof(double) * (size_t)(pl.total_recv + 2), ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
@@ -309,7 +318,7 @@ static int32_t create_dist_exchange(kryst_csr_t a) {
     DistScratch d;
     KR_HIP(hipMalloc(&d.cnt_s, sizeof(int64_t) * P));
     KR_HIP(hipMalloc(&d.cnt_r, sizeof(int64_t) * (size_t)P * P));
-    KR_HIP(hipMemcpy(d.cnt_s, pl.recv_counts.data(), sizeof(int64_t) * P, hipMemcpyHostToDevice));
+    KR_TRY(h2d(ctx, d.cnt_s, pl.recv_counts.data(), sizeof(int64_t) * P));
     KR_TRY(comm_all_gather_i64(ctx, d.cnt_s, d.cnt_r, P, ctx->s_main));
     std::vector<int64_t> cnt((size_t)P * P);
     KR_HIP(hipMemcpyAsync(cnt.data(), d.cnt_r, sizeof(int64_t) * cnt.size(), hipMemcpyDeviceToHost, ctx->s_main));
@@ -319,7 +328,7 @@ static int32_t create_dist_exchange(kryst_csr_t a) {
     for (int p = 0; p < P; ++p) { pl.send_off[p] = pl.total_send; pl.total_send += pl.send_counts[p]; }
     KR_HIP(hipMalloc(&d.req, sizeof(int64_t) * (size_t)(pl.total_recv + 1)));
     KR_HIP(hipMalloc(&d.ans, sizeof(int64_t) * (size_t)(pl.total_send + 1)));
-    if (pl.total_recv) KR_HIP(hipMemcpy(d.req, pl.recv_cols.data(), sizeof(int64_t) * pl.total_recv, hipMemcpyHostToDevice));
+    KR_TRY(h2d(ctx, d.req, pl.recv_cols.data(), sizeof(int64_t) * (size_t)pl.total_recv));
     KR_TRY(comm_exchange(ctx, d.req, pl.recv_counts.data(), pl.recv_off.data(), d.ans, pl.send_counts.data(),
                          pl.send_off.data(), false, ctx->s_main));
     std::vector<int64_t> ans((size_t)pl.total_send);
@@ -338,7 +347,7 @@ static int32_t create_dist_exchange(kryst_csr_t a) {
     if (contig)      // send_off then holds the first local row of each run (used as the offset into x)
         for (int p = 0; p < P; ++p) if (pl.send_counts[p]) pl.send_off[p] = sidx[pl.send_off[p]];
     KR_HIP(hipMalloc(&pl.d_send_idx, sizeof(int32_t) * (sidx.size() + 1)));
-    if (!sidx.empty()) KR_HIP(hipMemcpy(pl.d_send_idx, sidx.data(), sizeof(int32_t) * sidx.size(), hipMemcpyHostToDevice));
+    KR_TRY(h2d(ctx, pl.d_send_idx, sidx.data(), sizeof(int32_t) * sidx.size()));
     KR_HIP(hipMalloc(&pl.d_sendbuf, sizeof(double) * (size_t)(pl.total_send + 1)));
     return KRYST_OK;
 }
@@ -353,7 +362,7 @@ static int32_t agree_on_status(kryst_ctx_t ctx, int32_t rc_mine) {
     const int64_t mine = rc_mine;
     int32_t rc = KRYST_OK;
     if (hipMalloc(&d_s, sizeof(int64_t)) != hipSuccess || hipMalloc(&d_r, sizeof(int64_t) * P) != hipSuccess) rc = KRYST_ERR_HIP;
-    if (rc == KRYST_OK && hipMemcpy(d_s, &mine, sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK) rc = h2d(ctx, d_s, &mine, sizeof(int64_t));
     if (rc == KRYST_OK) rc = comm_all_gather_i64(ctx, d_s, d_r, 1, ctx->s_main);
     if (rc == KRYST_OK && (hipMemcpyAsync(all.data(), d_r, sizeof(int64_t) * P, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess ||
                            hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
@@ -567,7 +576,7 @@ static int32_t create_stencil7_host(kryst_ctx_t ctx, int32_t N, int32_t kind, kr
 int32_t kryst_csr_create_stencil7(kryst_ctx_t ctx, int32_t N, int32_t kind, kryst_csr_t* out) {
     KR_ARG(ctx && out && N >= 1 && kind >= 0 && kind <= 2, "csr_create_stencil7");
     // KRYST_STENCIL_HOST=1: build through the general host path (kryst_host_stencil7 + csr_create[_dist]); the two
-    // paths must give identical operators (tests/test_gpu_parity.py)
+    // paths must give identical operators (tests/test_gpu_0_parity.py)
     if (env_int("KRYST_STENCIL_HOST", 0)) return create_stencil7_host(ctx, N, kind, out);
     return create_stencil7_device(ctx, N, kind, out);
 }
@@ -598,11 +607,13 @@ int32_t kryst_csr_download(kryst_csr_t a, int64_t* row_ptr, int32_t* col, double
     KR_HIP(hipSetDevice(a->ctx->device));
     if (row_ptr) {
         std::vector<int32_t> rp((size_t)a->nrows + 1);
-        KR_HIP(hipMemcpy(rp.data(), a->d_row_ptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost));
+        KR_HIP(hipMemcpyAsync(rp.data(), a->d_row_ptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, a->ctx->s_main));
+        KR_HIP(hipStreamSynchronize(a->ctx->s_main));         // (in stream order behind the device generator that may have written the arrays)
         for (size_t i = 0; i < rp.size(); ++i) row_ptr[i] = rp[i];
     }
-    if (col && a->nnz) KR_HIP(hipMemcpy(col, a->d_col, sizeof(int32_t) * (size_t)a->nnz, hipMemcpyDeviceToHost));
-    if (vals && a->nnz) KR_HIP(hipMemcpy(vals, a->d_val, sizeof(double) * (size_t)a->nnz, hipMemcpyDeviceToHost));
+    if (col && a->nnz) KR_HIP(hipMemcpyAsync(col, a->d_col, sizeof(int32_t) * (size_t)a->nnz, hipMemcpyDeviceToHost, a->ctx->s_main));
+    if (vals && a->nnz) KR_HIP(hipMemcpyAsync(vals, a->d_val, sizeof(double) * (size_t)a->nnz, hipMemcpyDeviceToHost, a->ctx->s_main));
+    KR_HIP(hipStreamSynchronize(a->ctx->s_main));
     return KRYST_OK;
 }
 

@@ -15,7 +15,7 @@
 namespace kr {
 
 // KR_NT: bit 0 = nontemporal vector loads, bit 1 = nontemporal vector stores in the BLAS-1 streams (measured in
-// tools/nt_test.py)
+// tools/nt_bench.py)
 #ifndef KR_NT
 #define KR_NT 3
 #endif
@@ -95,7 +95,7 @@ inline int32_t launch_ew_gated(kryst_ctx_t ctx, const Op& op, int64_t n, const G
     const int64_t ntiles = ntiles_of(n);
     if (ntiles == 0) return KRYST_OK;
     if (Op::NQ > 0) KR_TRY(ensure_partials(ctx, ntiles));
-    // memory-bound streaming: cap the grid and stride the rest.  Measured on MI355X (tools/stream_test.py, vectors of
+    // memory-bound streaming: cap the grid and stride the rest.  Measured on MI355X (tools/stream_bench.py, vectors of
     // 1 GiB, interleaved rounds): 2-3 workgroups per CU sustain 5.6-5.8 TB/s on mixed read/write streams, 8 per CU only
     // 4.7-4.9 TB/s (a narrower moving window keeps DRAM pages open); CG at 512^3: +4 %.  Pure read streams with a
     // reduction per tile (dots) are the exception: they need 4 per CU to overlap loads with the butterfly (rocprofv3,

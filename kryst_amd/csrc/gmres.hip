@@ -314,7 +314,7 @@ int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
     KR_HIP(hipStreamSynchronize(ctx->s_main));
     if (io.monitor) {
         DevState h;
-        if (hipMemcpy(&h, ws.st, sizeof(DevState), hipMemcpyDeviceToHost) == hipSuccess) mon.upto(h.hist_len);
+        if (read_state(ws, &h) == hipSuccess) mon.upto(h.hist_len);
     }
     return status;
 }

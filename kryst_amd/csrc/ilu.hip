@@ -578,10 +578,22 @@ void ilu_free(kryst_pc_t pc) {
     pc->d_work = nullptr;
 }
 
+// Every device initialisation of a preconditioner is issued on the context's compute stream and waited for.  That stream is
+// non-blocking, so the null stream does not order with it, and hipMemset on the null stream returns before the fill has run:
+// round 2 zeroed the argument block with it, and under a time-sliced GPU the fill could land AFTER the first apply's
+// tri_set_args had written r and z there -- the level kernels then read through a null pointer.
+static thread_local hipStream_t tl_setup_stream = nullptr;       // set by the setup entry points (finish_ilu_pc, grid_setup_on_device)
+static int32_t zero_dev(void* dst, size_t bytes, hipStream_t s) {
+    KR_HIP(hipMemsetAsync(dst, 0, bytes, s));
+    KR_HIP(hipStreamSynchronize(s));
+    return KRYST_OK;
+}
 template <class T>
 static int32_t up(T** dst, const std::vector<T>& v) {
     KR_HIP(hipMalloc(dst, sizeof(T) * (v.size() + 1)));
-    if (!v.empty()) KR_HIP(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    KR_HIP(hipMemsetAsync(*dst, 0, sizeof(T) * (v.size() + 1), tl_setup_stream));
+    if (!v.empty()) KR_HIP(hipMemcpyAsync(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, tl_setup_stream));
+    KR_HIP(hipStreamSynchronize(tl_setup_stream));
     return KRYST_OK;
 }
 
@@ -715,7 +727,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
     kryst_ctx_t ctx = pc->ctx;
     const int64_t n = D->n;
     int32_t rc = KRYST_OK;
-    if (hipMalloc(&D->d_args, sizeof(TriArgs)) != hipSuccess || hipMemset(D->d_args, 0, sizeof(TriArgs)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+    if (hipMalloc(&D->d_args, sizeof(TriArgs)) != hipSuccess || zero_dev(D->d_args, sizeof(TriArgs), ctx->s_main) != KRYST_OK) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
     if (rc == KRYST_OK) {
         const size_t bytes = sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
         const bool grid = D->GL.ok && D->GU.ok;                            // the wavefront solve works in place: one intermediate vector
@@ -729,7 +741,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
     }
     if (rc == KRYST_OK && D->GL.ok && D->GU.ok) {
         const size_t nb = (size_t)((D->GL.Nj + 7) / 8) * (size_t)((D->GL.Nk + 7) / 8);
-        if (hipMalloc(&D->d_flags, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess || hipMemset(D->d_flags, 0, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (hipMalloc(&D->d_flags, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess || zero_dev(D->d_flags, sizeof(int32_t) * (2 * nb + 1), ctx->s_main) != KRYST_OK) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
         if (rc == KRYST_OK && (hipHostMalloc((void**)&D->h_gave_up, 64, hipHostMallocMapped) != hipSuccess ||
                                hipHostGetDevicePointer((void**)&D->d_gave_up, D->h_gave_up, 0) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = KRYST_ERR_HIP; }
         if (rc == KRYST_OK) *D->h_gave_up = 0;
@@ -768,7 +780,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
                 if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("blocked layout kernel failed"); rc = KRYST_ERR_HIP; }
                 if (rc == KRYST_OK && G->d_skip && getenv("KRYST_ILU_VERBOSE")) {
                     std::vector<uint8_t> h(nq * 4 * (size_t)G->nch);
-                    if (hipMemcpy(h.data(), G->d_skip, h.size(), hipMemcpyDeviceToHost) == hipSuccess) { G->nskip = 0; for (uint8_t v : h) G->nskip += v; }
+                    if (hipMemcpyAsync(h.data(), G->d_skip, h.size(), hipMemcpyDeviceToHost, ctx->s_main) == hipSuccess && hipStreamSynchronize(ctx->s_main) == hipSuccess) { G->nskip = 0; for (uint8_t v : h) G->nskip += v; }
                     fprintf(stderr, "[kryst ilu] %s factor: %lld of %zu coefficient chunks repeat (no request)\n", fwd ? "forward" : "backward", (long long)G->nskip, h.size());
                 }
             }
@@ -785,6 +797,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
 static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRows& le, const FlatRows& ue,
                              const std::vector<double>& dg, kryst_pc_t* out) {
     kryst_ctx_t ctx = a->ctx;
+    tl_setup_stream = ctx->s_main;
     const int64_t n = a->nrows;
     std::vector<double> ones((size_t)n, 1.0);
     kryst_pc_t pc = new kryst_pc_s();

@@ -192,6 +192,12 @@ struct Workspace {
     }
 };
 
+// the solve's scalar state, read in stream order on the compute stream (the product issues nothing on the null stream)
+inline hipError_t read_state(const Workspace& ws, DevState* h) {
+    const hipError_t e = hipMemcpyAsync(h, ws.st, sizeof(DevState), hipMemcpyDeviceToHost, ws.ctx->s_main);
+    return e != hipSuccess ? e : hipStreamSynchronize(ws.ctx->s_main);
+}
+
 inline size_t padded_bytes(int64_t n) { return sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE); }
 
 // Host side of the run-ahead loop: enqueue `body(i)` for i = 1..max_iters in batches, stop once the device has
@@ -273,7 +279,7 @@ struct LiveMonitor {
 inline int32_t finish_solve(Workspace& ws, const SolveIO& io) {
     kryst_ctx_t ctx = ws.ctx;
     DevState h;
-    KR_HIP(hipMemcpy(&h, ws.st, sizeof(DevState), hipMemcpyDeviceToHost));
+    KR_HIP(read_state(ws, &h));
     if (io.stats) { io.stats->iterations = h.iterations; io.stats->final_residual = h.final_residual; io.stats->converged = h.converged; }
     const int64_t len = h.hist_len;
     if (io.hist_len) *io.hist_len = len;

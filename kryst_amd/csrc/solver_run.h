@@ -35,7 +35,7 @@ inline int32_t solve_args_check(const SolveIO& io, kryst_vec_t b, kryst_vec_t x)
 inline void finish_monitor(LiveMonitor& mon, Workspace& ws) {
     if (!mon.io || !mon.io->monitor) return;
     DevState h;
-    if (hipMemcpy(&h, ws.st, sizeof(DevState), hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (read_state(ws, &h) != hipSuccess) return;
     mon.upto(h.hist_len);
 }
 

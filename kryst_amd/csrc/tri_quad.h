@@ -529,7 +529,8 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     // Chunk m needs a request unless its coefficients equal chunk m - 3's bit for bit: those sit in its buffer already (flags from
     // setup, tri_quad_dedup_kernel; chunks past the end count as "no request").
     const uint8_t* const my_skip = skipf + q * TQ_SKIPMAX;
-    auto needs = [&](int m) -> bool { return my_skip[min(m, TQ_SKIPMAX - 1)] == 0; };
+    // (m < nch explicitly: lines longer than the flag table -- Ni > 4 330 -- read its last entry, which then belongs to a real chunk)
+    auto needs = [&](int m) -> bool { return m < nch && my_skip[min(m, TQ_SKIPMAX - 1)] == 0; };
     // before chunk m is computed: vector-memory operations younger than its request = the (up to) two later requests of 4 NA loads
     // each; the wave issues nothing else (its results are stored by the loader wave)
     auto arrive = [&](Coef& cf, int m) __attribute__((always_inline)) {

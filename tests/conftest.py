@@ -5,6 +5,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Order of the -m gpu tier: the kernel-level HIP-vs-oracle parity suite first, then the solver / full-size files, and the tests
+# that start other processes (C++ mirror, RCCL with one rank, several ranks on one GPU) last -- so that `pytest -x` can never
+# again stop in a subprocess test before the parity suite has run ("What's weak" 2).
+_ORDER = ["test_gpu_0_parity", "test_golden", "test_gpu_cgs_tfqmr", "test_gpu_fgmres", "test_gpu_fullsize",
+          "test_gpu_x_cpp_mirror", "test_gpu_y_dist_single", "test_gpu_z_multirank_shim"]
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _ORDER.index(name) if name in _ORDER else len(_ORDER) // 2
+    items.sort(key=key)          # stable: the order inside a file is kept

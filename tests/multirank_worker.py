@@ -1,4 +1,4 @@
-"""One rank of the shared-GPU multi-rank test (tests/test_gpu_multirank_shim.py): P processes on ONE GPU run the library's
+"""One rank of the shared-GPU multi-rank test (tests/test_gpu_z_multirank_shim.py): P processes on ONE GPU run the library's
 real distributed code path with tests/shim/librccl_shim.so standing in for RCCL.  Results are written to
 <outdir>/rank<r>.npz; rank 0 compares them with the partition-aware oracle bit for bit."""
 import os
@@ -25,9 +25,18 @@ def random_system(n):
     return m
 
 
+_T0 = time.time()
+
+
+def stage(rank, name):
+    """Flushed stage marker: when a rank dies, the last marker in its log names the stage."""
+    print(f"[rank {rank} +{time.time() - _T0:7.3f}s] {name}", flush=True)
+
+
 def main():
     rank, P, outdir, N = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
     kind = sys.argv[5]
+    stage(rank, "start")
     idfile = os.path.join(outdir, "uid.bin")
     if rank == 0:
         uid = K.Context.unique_id()
@@ -40,7 +49,9 @@ def main():
                 break
             time.sleep(0.01)
         uid = open(idfile, "rb").read()
+    stage(rank, "ctx_create_dist")
     ctx = K.Context(0, rank, P, uid)
+    stage(rank, "operator")
     if kind == "random":                              # general operator: N rows, halo entries from any rank
         m = random_system(N)
         offs = K.partition_rows(N, P, 1)
@@ -50,11 +61,15 @@ def main():
     else:
         a = K.CsrMatrix.stencil7(N, kind, ctx=ctx)    # device generator or (KRYST_STENCIL_HOST=1) kryst_csr_create_dist
     nloc = a.nrows()
+    stage(rank, f"spmv nloc={nloc} encoding={a.encoding()[0]}")
     b = a.spmv(ctx.vec(nloc).fill(1.0))
     out = {"b": b.to_host(), "nloc": np.array([nloc])}
+    stage(rank, "norm")
     bn = K.norm(b)
     out["bnorm"] = np.array([bn])
+    stage(rank, "all_reduce")
     assert ctx.all_reduce(float(rank + 1)) == P * (P + 1) / 2
+    stage(rank, "jacobi_setup")
     pcj = K.Jacobi().setup(a)
     runs = [("cg", K.CgSolver(1e-9, 300), None), ("pcg", K.PcgSolver(1e-9, 300), pcj),
             ("bicgstab", K.BiCgStabSolver(1e-9 * bn, 300), None),
@@ -62,17 +77,20 @@ def main():
             ("fgmres", K.FgmresSolver(1e-9, 40, 12), pcj), ("cgs", K.CgsSolver(1e-9, 60), None),
             ("tfqmr", K.TfqmrSolver(1e-9, 30), None)]
     for name, s, pc in runs:
+        stage(rank, "solve " + name)
         x = ctx.vec(nloc)
         st = s.solve(a, pc, b, x)
         out[name + "_x"] = x.to_host()
         out[name + "_hist"] = np.array(s.residual_history)
         out[name + "_stats"] = np.array([st.iterations, float(st.converged), st.final_residual])
     # Chebyshev needs the halo exchange inside a preconditioner; GMRES-right and the right-preconditioned BiCGStab extension
+    stage(rank, "chebyshev_setup")
     cheb = K.ChebyshevPc(3, 1.0, 11.5).setup(a)
     extra = [("gmres_cheb", K.GmresSolver(8, 1e-9, 32).with_preconditioning(K.Preconditioning.Left), cheb),
              ("gmres_right", K.GmresSolver(8, 1e-9, 40).with_preconditioning(K.Preconditioning.Right), pcj),
              ("bicg_rpc", K.BiCgStabRightPcSolver(1e-9 * bn, 120), pcj)]
     for name, s, pc in extra:
+        stage(rank, "solve " + name)
         x = ctx.vec(nloc)
         st = s.solve(a, pc, b, x)
         out[name + "_x"] = x.to_host()
@@ -83,14 +101,22 @@ def main():
     out["ilu_r"] = r.to_host()
     for nm, mk in (("true", K.TrueIlu0), ("compat", K.Ilu0), ("ilup0", lambda: K.Ilup(0)), ("ilup1", lambda: K.Ilup(1)),
                    ("ilut", lambda: K.Ilut(4, 1e-3))):
-        out["ilu_z_" + nm] = mk().setup(a).apply(r).to_host()
+        stage(rank, "ilu setup " + nm)
+        pc_ = mk().setup(a)
+        stage(rank, "ilu apply " + nm)
+        z_ = pc_.apply(r)
+        stage(rank, "ilu download " + nm)
+        out["ilu_z_" + nm] = z_.to_host()
+        del pc_, z_
     # a stepping session like bench.py's
+    stage(rank, "session")
     x = ctx.vec(nloc)
     sess = K.Session("cg", a, None, b, x, tol=0.0, max_iters=25)
     sess.step(5); sess.step(20)
     st = sess.end()
     out["sess_stats"] = np.array([st.iterations, float(st.converged), st.final_residual])
     out["sess_x"] = x.to_host()
+    stage(rank, "barrier")
     ctx.barrier()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
     print(f"RANK_OK {rank}")

@@ -1,10 +1,12 @@
 // TEST INFRASTRUCTURE: a stand-in for librccl.so.1 that lets SEVERAL RANKS SHARE ONE GPU (real RCCL refuses that), so the
 // library's multi-rank code path -- communicator set-up from a broadcast id, the index-list exchange of
 // kryst_csr_create_dist, the halo exchange launch sequence, the all-gather behind every inner product, the run-ahead
-// termination rule -- can be executed end to end on a one-GPU test box (tests/test_gpu_multirank_shim.py).
+// termination rule -- can be executed end to end on a one-GPU test box (tests/test_gpu_z_multirank_shim.py).
 // It implements exactly the nine entry points kryst_amd/csrc/dist.cpp binds, with the same prototypes as rccl.h, by staging
 // through a POSIX shared-memory board: every call synchronises its stream, copies device -> board, meets the peers,
-// copies board -> device.  Selected with KRYST_RCCL_LIB=<path>; never used by the product otherwise.
+// copies board -> device.  Every copy is issued ON THE OPERATION'S OWN STREAM and waited for (like RCCL, which enqueues on
+// the caller's stream): the library's streams are non-blocking, so a null-stream copy would not order with them.
+// Selected with KRYST_RCCL_LIB=<path>; never used by the product otherwise.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <atomic>
@@ -40,7 +42,7 @@ void spin(std::atomic<int>& a, int want) {
     long n = 0;
     while (a.load(std::memory_order_acquire) != want) {
         if (++n > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
-        if (n > 400000) { fprintf(stderr, "rccl_shim: timeout waiting for a peer\n"); _exit(97); }
+        if (n > 1200000) { fprintf(stderr, "rccl_shim: timeout waiting for a peer\n"); _exit(97); }      // 60 s
     }
 }
 void barrier(Comm* c) {
@@ -51,6 +53,12 @@ void barrier(Comm* c) {
         b->generation.store(gen + 1, std::memory_order_release);
     } else spin(b->generation, gen + 1);
 }
+// device <-> board on stream s, complete on return
+hipError_t copy_on(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
 size_t dsize(ncclDataType_t t) { return (t == ncclFloat64 || t == ncclInt64 || t == ncclUint64) ? 8 : (t == ncclInt32 || t == ncclFloat32 || t == ncclUint32) ? 4 : 1; }
 
 ncclResult_t run_ops(Comm* c, std::vector<Op>& ops) {
@@ -59,14 +67,14 @@ ncclResult_t run_ops(Comm* c, std::vector<Op>& ops) {
     for (auto& o : ops) if (o.send) {                                  // post every send first (mailboxes are private per pair)
         if (o.bytes > SLOT) { fprintf(stderr, "rccl_shim: message of %zu bytes exceeds the mailbox\n", o.bytes); return ncclInvalidArgument; }
         spin(b->full[c->rank][o.peer], 0);
-        if (hipMemcpy(b->mail[c->rank][o.peer], o.buf, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+        if (copy_on(b->mail[c->rank][o.peer], o.buf, o.bytes, hipMemcpyDeviceToHost, o.s) != hipSuccess) return ncclUnhandledCudaError;
         b->bytes[c->rank][o.peer].store((long long)o.bytes);
         b->full[c->rank][o.peer].store(1, std::memory_order_release);
     }
     for (auto& o : ops) if (!o.send) {
         spin(b->full[o.peer][c->rank], 1);
         if ((size_t)b->bytes[o.peer][c->rank].load() != o.bytes) { fprintf(stderr, "rccl_shim: send/recv size mismatch\n"); return ncclInvalidArgument; }
-        if (hipMemcpy(o.buf, b->mail[o.peer][c->rank], o.bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+        if (copy_on(o.buf, b->mail[o.peer][c->rank], o.bytes, hipMemcpyHostToDevice, o.s) != hipSuccess) return ncclUnhandledCudaError;
         b->full[o.peer][c->rank].store(0, std::memory_order_release);
     }
     ops.clear();
@@ -140,10 +148,10 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
     const size_t bytes = count * dsize(t);
     if (bytes > 4096) return ncclInvalidArgument;
     if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
-    if (hipMemcpy(c->b->gather[c->rank], send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    if (copy_on(c->b->gather[c->rank], send, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return ncclUnhandledCudaError;
     barrier(c);
     for (int p = 0; p < c->nranks; ++p)
-        if (hipMemcpy((char*)recv + p * bytes, c->b->gather[p], bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+        if (copy_on((char*)recv + p * bytes, c->b->gather[p], bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ncclUnhandledCudaError;
     barrier(c);
     return ncclSuccess;
 }

@@ -352,6 +352,26 @@ def test_structured_grid_triangular_solve_bit_exact(ctx, grid_path, monkeypatch)
                 assert np.array_equal(pc.apply(r), ref.apply(r)), (grid_path, a.nrows)
 
 
+def test_lines_longer_than_the_chunk_flag_table(ctx, monkeypatch):
+    """A box whose lines have more 8-step chunks than the 16 x 16 kernel's flag table holds (TQ_SKIPMAX = 544 chunks, Ni > ~4 330):
+    the kernel runs without repeat flags and must not request coefficient chunks past the line's end (needs(m) read
+    the table's last entry for every m beyond it, so the last block fetched up to four chunks beyond its coefficient array)."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("KRYST_ILU_GRID", "1"); monkeypatch.setenv("KRYST_ILU_WAVE", "2")
+    Ni, Nj, Nk = 4400, 32, 32
+
+    def lap(n, w):
+        return sp.diags([-w * np.ones(n - 1), 2 * w * np.ones(n), -0.5 * w * np.ones(n - 1)], [-1, 0, 1])
+    m = (sp.kron(sp.eye(Nk), sp.kron(sp.eye(Nj), lap(Ni, 1.0))) + sp.kron(sp.eye(Nk), sp.kron(lap(Nj, 0.7), sp.eye(Ni)))
+         + sp.kron(lap(Nk, 0.3), sp.kron(sp.eye(Nj), sp.eye(Ni)))).tocsr()
+    m.sort_indices(); m.eliminate_zeros()
+    a = O.Csr(m.shape[0], m.shape[1], m.indptr, m.indices, m.data)
+    d = to_dev(ctx, a)
+    r = np.random.default_rng(9).standard_normal(a.nrows)
+    for kpc, ofn in ((K.TrueIlu0(), O.Pc.ilu0_true), (K.Ilu0(), O.Pc.ilu0_compat)):
+        assert np.array_equal(kpc.setup(d).apply(r), ofn(a).apply(r))
+
+
 def test_repeated_coefficient_chunks_are_skipped_bit_exact(ctx, monkeypatch, capfd):
     """tri_quad.h does not request a coefficient chunk that repeats chunk - 3's bits (flags from setup).  On a constant-coefficient
     box most chunks carry the flag (reported by KRYST_ILU_VERBOSE); on a box with random coefficients none does; the solve gives the

@@ -41,7 +41,9 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    # every rank prints a flushed marker before each stage (tests/multirank_worker.py): a failure names the stage it died in
+    assert all(p.returncode == 0 for p in procs), "\n".join(
+        f"---- rank {r}: exit code {p.returncode}, log tail ----\n{o[-3000:]}" for r, (p, o) in enumerate(zip(procs, outs)))
     R = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(P)]
     T, V, F = K.reduce_spec()
     if kind == "random":

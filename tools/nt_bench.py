@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CG x/r update stream (4 reads, 2 writes) with plain / nontemporal loads and stores.  usage: nt_test.py [grid=512]"""
+"""CG x/r update stream (4 reads, 2 writes) with plain / nontemporal loads and stores.  usage: nt_bench.py [grid=512]"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kryst_amd as K

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How does the byte distance between the vectors of a multi-stream BLAS-1 kernel affect its speed?
-usage: stride_test.py [grid=256]   (vectors of grid^3 doubles; prints GB/s per kind and stride offset)"""
+usage: stride_bench.py [grid=256]   (vectors of grid^3 doubles; prints GB/s per kind and stride offset)"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kryst_amd as K
