@@ -23,6 +23,13 @@ What the line holds (every `frac` is bytes the named kernel really moves / its H
   roofline_blas1    the two vector kernels of a CG iteration
   phase_ms          device time per iteration by phase (hipEvents between the phases, a separate short run), per rank
   config1_256       (N = 1) the same measurements on BASELINE configs[1]'s 256^3 grid, with the CPU port timed on that grid
+  config3_gmres30_jacobi_256, config5_bicgstab_ilu0_256, config4_jacobi_pcg_512
+                    (N = 1) the other BASELINE configs on one GPU: iterations/s of the solve to the config's tolerance (configs 3, 5)
+                    or of a fixed number of stepped iterations (config 4), each with the roofline block of ITS dominant kernel
+                    (Gram-Schmidt link; triangular solve -- priced at the bytes it moves, SURVEY 8(d)'s bytes labelled beside it)
+  variable_coefficient_256 / _512
+                    (N = 1) a 7-point operator with per-edge random coefficients (kind "varcoef"): neither CSR-P16 / D16 nor the
+                    triangular solve's chunk dedup apply -- SpMV form / ms / fraction, CG iterations/s, ILU(0) apply ms
   cpu_baseline      the oracle's CG timed on the host cores AT the workload's size (512^3 when host memory allows, else the
                     256^3 sample scaled and marked "extrapolated": true)
 """
@@ -329,6 +336,129 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters):
             "final_residual_plain": stats_plain.final_residual}
 
 
+def timed_solve(K, ctx, make_solver, a, pc, b, repeat=2):
+    """Device-resident solve to the solver's tolerance, timed on the host around the call (device idle before and after);
+    solved `repeat` times, the faster one reported (the first grows the context's work arena)."""
+    best = None
+    for _ in range(repeat):
+        s = make_solver()
+        x = ctx.vec(a.nrows())
+        ctx.synchronize(); t0 = time.perf_counter()
+        st = s.solve(a, pc, b, x)
+        ctx.synchronize(); dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, st)
+    return best
+
+
+def stream_block(ctx, n, kind, name, words, reps=20):
+    import ctypes as C
+    from kryst_amd._ffi import lib, check
+    stride = ((n + 511) // 512 * 512 + 512) * 8
+    ms = C.c_double(0)
+    check(lib().kryst_bench_streams(ctx.h, n, stride, kind, reps, C.byref(ms)))
+    ach = words * 8 * n / (ms.value * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": name, "bytes_per_launch": words * 8 * n, "ms_per_launch": ms.value, "achieved": ach,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+
+
+def tri_roofline(pc, r, z, n, nnz, reps=20):
+    """The ILU apply (forward + backward triangular solve), timed live with HIP events.  `frac` prices it at the bytes the kernels
+    MOVE by their own bookkeeping (coefficient chunks actually requested + right-hand side read + result written, both
+    directions); SURVEY 8(d)'s B_spmv + 8 n is reported beside it as `algorithmic_*` and is NOT a fraction of moved bytes when
+    repeating coefficient chunks are skipped."""
+    ms = pc.bench_apply(r, z, reps)
+    info = pc.ilu_info()
+    alg = spmv_bytes(n, nnz) + 8 * n
+    out = {"bound": "hbm", "kernel": "ILU(0) apply = forward + backward solve, " + info["form"], "ms_per_apply": ms, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "algorithmic_bytes": alg, "algorithmic_model": "SURVEY 8(d): B_spmv + 8 n", "algorithmic_GBs": alg / (ms * 1e-3) / 1e9,
+           "algorithmic_frac_note": "algorithmic_GBs / peak is not a roofline fraction where coefficient chunks are skipped", "traffic": None, "form": info}
+    if info["form"].startswith("grid 16x16"):
+        ch, sk, bpc = info["chunks"], info["chunks_not_requested"], info["bytes_per_chunk"]
+        moved = (ch[0] - sk[0]) * bpc[0] + (ch[1] - sk[1]) * bpc[1] + 32 * n
+        out.update(bytes_moved=moved, bytes_model="coefficient chunks requested x bytes per chunk + 32 n (r, y read; y, z written)",
+                   achieved=moved / (ms * 1e-3) / 1e9, frac=moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   chunks_not_requested_frac=(sk[0] + sk[1]) / max(1, ch[0] + ch[1]))
+    else:
+        out.update(bytes_moved=None, achieved=None, frac=None)
+    return out
+
+
+def other_configs(K, ctx, steps, warmup):
+    """BASELINE configs 3, 5 (256^3, solved to their tolerance), config 4's workload on one GPU (512^3 Jacobi-PCG, stepped) and the
+    variable-coefficient operator at 256^3 / 512^3.  N = 1 only."""
+    out = {}
+    # ---- config 3: GMRES(30) Left + Jacobi on 256^3 convection-diffusion, tol 1e-8, max 600 (gmres.rs:216-402)
+    a = K.CsrMatrix.stencil7(256, "convdiff", ctx=ctx); n = a.nrows()
+    b = a.spmv(ctx.vec(n).fill(1.0))
+    pc = K.Jacobi().setup(a)
+    dt, st = timed_solve(K, ctx, lambda: K.GmresSolver(30, 1e-8, 600), a, pc, b)
+    out["config3_gmres30_jacobi_256"] = {
+        "workload": "gmres30_left_jacobi_convdiff7_256^3", "value": st.iterations / dt, "unit": "iterations/s", "iterations": st.iterations,
+        "converged": bool(st.converged), "final_residual": st.final_residual, "solve_seconds": dt, "spmv_encoding": a.encoding()[0],
+        "algorithmic_bytes_per_iteration": spmv_bytes(n, a.nnz) + 1288 * n,
+        "roofline": stream_block(ctx, n, 0, "ew_kernel<MgsLinkOp> (Gram-Schmidt link z -= h v_i fused with the next link's dot: 3 reads + 1 write; "
+                                 "31 links per iteration on average)", 4)}
+    del pc, a, b
+    # ---- config 5: right-preconditioned BiCGStab + true ILU(0) on 256^3 anisotropic Poisson, absolute tol 1e-8 ||b|| (bicgstab.rs:69-293)
+    a = K.CsrMatrix.stencil7(256, "aniso", ctx=ctx); n = a.nrows()
+    b = a.spmv(ctx.vec(n).fill(1.0)); bn = K.norm(b)
+    ctx.synchronize(); t0 = time.perf_counter()
+    pc = K.TrueIlu0().setup(a)
+    ctx.synchronize(); t_setup = time.perf_counter() - t0
+    dt, st = timed_solve(K, ctx, lambda: K.BiCgStabRightPcSolver(1e-8 * bn, 3000), a, pc, b)
+    z = ctx.vec(n)
+    out["config5_bicgstab_ilu0_256"] = {
+        "workload": "bicgstab_right_true_ilu0_aniso7_256^3", "value": st.iterations / dt, "unit": "iterations/s", "iterations": st.iterations,
+        "converged": bool(st.converged), "final_residual": st.final_residual, "solve_seconds": dt, "ilu_setup_ms": t_setup * 1e3,
+        "spmv_encoding": a.encoding()[0], "note": "the reference's BiCGStab ignores pc (bicgstab.rs:70); the preconditioned form is a labelled extension",
+        "roofline": tri_roofline(pc, b, z, n, a.nnz)}
+    del pc, a, b, z
+    # ---- config 4's workload on ONE GPU: Jacobi-PCG on 512^3 Poisson (pcg.rs:114-222), fixed stepped iterations
+    k4 = min(steps, 100)
+    a = K.CsrMatrix.stencil7(512, "poisson", ctx=ctx); n = a.nrows()
+    b = a.spmv(ctx.vec(n).fill(1.0))
+    pc = K.Jacobi().setup(a)
+    x = ctx.vec(n)
+    with K.Session("pcg", a, pc, b, x, tol=0.0, max_iters=warmup + k4) as sess:
+        sess.step(warmup); ctx.synchronize(); t0 = time.perf_counter()
+        sess.step(k4); ctx.synchronize(); dt = time.perf_counter() - t0
+        st = sess.end()
+    out["config4_jacobi_pcg_512"] = {
+        "workload": "jacobi_pcg_poisson7_512^3 on one GPU (the 8-way partition is the --gpus 8 run)", "value": k4 / dt, "unit": "iterations/s", "steps": k4,
+        "ms_per_step": dt / k4 * 1e3, "final_residual": st.final_residual, "spmv_encoding": a.encoding()[0],
+        "algorithmic_bytes_per_iteration": spmv_bytes(n, a.nnz) + 136 * n}
+    del pc, a, b, x
+    # ---- variable coefficients: no row patterns, no value dictionary, no repeating coefficient chunks
+    for grid in (256, 512):
+        kv = min(steps, 100)
+        a = K.CsrMatrix.stencil7(grid, "varcoef", ctx=ctx); n = a.nrows(); nnz = a.nnz
+        b = a.spmv(ctx.vec(n).fill(1.0)); y = ctx.vec(n)
+        enc = a.encoding()
+        blk = {"workload": f"variable-coefficient 7-point diffusion operator, {grid}^3 (kind varcoef: per-edge weights from splitmix64)", "spmv_encoding": enc[0]}
+        for form, env in (("default", {}), ("plain_csr", {"KRYST_SPMV_COMPRESS": "0"})):
+            with env_override(**env):
+                x = ctx.vec(n)
+                with K.Session("cg", a, None, b, x, tol=0.0, max_iters=warmup + kv) as sess:
+                    sess.step(warmup); ctx.synchronize(); t0 = time.perf_counter()
+                    sess.step(kv); ctx.synchronize(); dt = time.perf_counter() - t0
+                    sess.end()
+                ms = a.bench_spmv(b, y, fused_dots=1, reps=20)
+                e = a.encoding()
+            if form == "default":
+                blk.update(value=kv / dt, unit="iterations/s", steps=kv, ms_per_step=dt / kv * 1e3, roofline=roofline_of(e, grid, n, nnz, ms, 2))
+            else:
+                blk.update(value_plain_csr=kv / dt, ms_per_step_plain_csr=dt / kv * 1e3, roofline_csr=roofline_csr_of(grid, n, nnz, ms, 2))
+            del x
+        ctx.synchronize(); t0 = time.perf_counter()
+        pc = K.TrueIlu0().setup(a)
+        ctx.synchronize(); blk["ilu_setup_ms"] = (time.perf_counter() - t0) * 1e3
+        blk["ilu_apply"] = tri_roofline(pc, b, y, n, nnz, reps=10)
+        out[f"variable_coefficient_{grid}"] = blk
+        del pc, a, b, y
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -338,6 +468,7 @@ def main():
     ap.add_argument("--solver", default="cg", choices=["cg", "pcg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-256", action="store_true", help="skip the config1_256 block (N = 1 measures BASELINE configs[1]'s 256^3 grid too)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs and the variable-coefficient blocks (N = 1)")
     ap.add_argument("--phase-iters", type=int, default=20, help="iterations of the per-phase timing run (0: skip)")
     ap.add_argument("--launcher", default="auto", choices=["auto", "torch", "socket"],
                     help="N > 1 plumbing for the RCCL id / barrier: torch.distributed gloo (default) or kryst_amd/launch.py (no torch)")
@@ -398,6 +529,11 @@ def main():
                 out["config1_256"]["cpu_baseline"] = base256
             except Exception as e:
                 out["config1_256"]["cpu_baseline"] = {"value": None, "unit": "cg_iterations/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    if world == 1 and not args.no_configs:
+        try:
+            out.update(other_configs(K, ctx, args.steps, args.warmup))
+        except Exception as e:                              # the headline line must survive a failing side measurement
+            out["other_configs_error"] = f"{type(e).__name__}: {e}"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(grid, base256)
     if rank == 0:

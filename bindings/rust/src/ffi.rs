@@ -115,6 +115,8 @@ extern "C" {
     pub fn kryst_pc_approx_inverse(m: Csr, out: *mut Pc) -> i32;
     pub fn kryst_pc_apply(pc: Pc, r: Vecd, z: Vecd) -> i32;
     pub fn kryst_pc_destroy(pc: Pc) -> i32;
+    pub fn kryst_bench_pc_apply(pc: Pc, r: Vecd, z: Vecd, reps: i32, avg_ms: *mut f64) -> i32;
+    pub fn kryst_pc_ilu_info(pc: Pc, info: *mut i64, count: i32) -> i32;
     pub fn kryst_apply_chebyshev(a: Csr, r: Vecd, z: Vecd, alpha: f64, beta: f64, m: i64) -> i32;
 }
 

@@ -109,7 +109,9 @@ int32_t kryst_csr_create_dist(kryst_ctx_t ctx, int64_t n_global, const int64_t* 
                               const int64_t* row_ptr, const int64_t* col_idx_global, const double* vals,
                               kryst_csr_t* out);
 /* Synthetic 7-point stencil operator generated on the device: kind 0 Poisson, 1 anisotropic,
- * 2 upwind convection-diffusion; grid N^3; in a distributed ctx each rank builds its k-slab. */
+ * 2 upwind convection-diffusion, 3 symmetric variable-coefficient diffusion (per-edge weights from splitmix64: no two rows
+ * alike, so no value dictionary / row patterns apply -- what a structured grid with real coefficients looks like);
+ * grid N^3; in a distributed ctx each rank builds its k-slab. */
 int32_t kryst_csr_create_stencil7(kryst_ctx_t ctx, int32_t N, int32_t kind, kryst_csr_t* out);
 int32_t kryst_csr_destroy(kryst_csr_t a);
 int32_t kryst_csr_shape(kryst_csr_t a, int64_t* nrows_local, int64_t* ncols_global, int64_t* nnz_local);
@@ -158,6 +160,12 @@ int32_t kryst_pc_chebyshev(kryst_csr_t a, double alpha, double beta, int32_t deg
 int32_t kryst_pc_approx_inverse(kryst_csr_t m, kryst_pc_t* out);
 int32_t kryst_pc_apply(kryst_pc_t pc, kryst_vec_t r, kryst_vec_t z);                /* Preconditioner::apply */
 int32_t kryst_pc_destroy(kryst_pc_t pc);
+/* measurement hooks (bench.py): average ms of `reps` back-to-back applies between two HIP events on the compute stream; and what
+ * an ILU-family preconditioner's apply runs and streams -- info[0] form (0 level-ordered, 1 grid 8 x 8 lines per workgroup,
+ * 2 grid 16 x 16, 3 plane kernels after a give-up), [1..3] Ni Nj Nk, [4..5] dependency levels of L / U, [6..7] coefficient chunks
+ * forward / backward, [8..9] of which repeat and are not requested, [10..11] bytes per chunk request, [12] reserved; count >= 13 */
+int32_t kryst_bench_pc_apply(kryst_pc_t pc, kryst_vec_t r, kryst_vec_t z, int32_t reps, double* avg_ms);
+int32_t kryst_pc_ilu_info(kryst_pc_t pc, int64_t* info, int32_t count);
 /* apply_chebyshev(a, r, z, alpha, beta, m), src/preconditioner/chebyshev.rs:83-140 */
 int32_t kryst_apply_chebyshev(kryst_csr_t a, kryst_vec_t r, kryst_vec_t z, double alpha, double beta, int64_t m);
 

@@ -180,6 +180,9 @@ def aypx(beta, x, y):
     check(lib().kryst_aypx(float(beta), x.h, y.h))
 
 
+STENCIL_KINDS = {"poisson": 0, "aniso": 1, "convdiff": 2, "varcoef": 3}   # kryst_csr_create_stencil7 / kryst_host_stencil7
+
+
 class CsrMatrix:
     """CsrMatrix<f64> (src/matrix/sparse.rs:22-46) living on the GPU; implements SparseMatrix::spmv and MatVec."""
 
@@ -242,7 +245,7 @@ class CsrMatrix:
         """Synthetic 7-point operator on an N^3 grid; each rank of a distributed ctx gets its k-slab."""
         ctx = ctx or Context.default()
         h = _ffi.Handle()
-        check(lib().kryst_csr_create_stencil7(ctx.h, N, {"poisson": 0, "aniso": 1, "convdiff": 2}[kind], C.byref(h)))
+        check(lib().kryst_csr_create_stencil7(ctx.h, N, STENCIL_KINDS[kind], C.byref(h)))
         return CsrMatrix(ctx, h)
 
     def nrows(self):
@@ -327,6 +330,20 @@ class _Pc:
             z[:] = out
             return z
         return out
+
+    def bench_apply(self, r, z, reps=20):
+        """Average milliseconds of one apply (HIP events on the compute stream, `reps` back-to-back applies)."""
+        ms = C.c_double()
+        check(lib().kryst_bench_pc_apply(self.h, r.h, z.h, reps, C.byref(ms)))
+        return ms.value
+
+    def ilu_info(self):
+        """What an ILU-family apply runs and streams (kryst_pc_ilu_info) -> dict."""
+        v = np.zeros(13, dtype=np.int64)
+        check(lib().kryst_pc_ilu_info(self.h, v.ctypes.data_as(_ffi.c_i64p), 13))
+        form = ("level-ordered", "grid 8x8 (tri_wave_kernel)", "grid 16x16 (tri_quad_kernel)", "grid planes (tri_plane_kernel)")[int(v[0])]
+        return {"form": form, "box": [int(v[1]), int(v[2]), int(v[3])], "levels": [int(v[4]), int(v[5])], "chunks": [int(v[6]), int(v[7])],
+                "chunks_not_requested": [int(v[8]), int(v[9])], "bytes_per_chunk": [int(v[10]), int(v[11])]}
 
     def _free(self):
         try:
@@ -788,6 +805,30 @@ class Session:
     def step(self, k):
         check(lib().kryst_session_step(self.h, k))
 
+    # A session that is never ended keeps its context busy (KRYST_ERR_BUSY for every later solve): `with Session(...) as s:`
+    # and the finaliser end it on every path (an exception between begin and end, a failing step)
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def close(self):
+        if getattr(self, "h", None):
+            st = _ffi.Stats()
+            hlen = C.c_int64(0)
+            try:
+                lib().kryst_session_end(self.h, C.byref(st), None, 0, C.byref(hlen))
+            finally:
+                self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def end(self):
         st = _ffi.Stats()
         cap = self.max_iters + 8
@@ -826,7 +867,7 @@ def read_petsc_binary(path):
 
 def host_stencil7(N, kind="poisson", k_lo=0, k_hi=None):
     k_hi = N if k_hi is None else k_hi
-    kk = {"poisson": 0, "aniso": 1, "convdiff": 2}[kind]
+    kk = STENCIL_KINDS[kind]
     nnz = lib().kryst_host_stencil7(N, kk, k_lo, k_hi, None, None, None)
     if nnz < 0:
         raise KError(102, "host_stencil7")

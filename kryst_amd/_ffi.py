@@ -88,6 +88,8 @@ SIGNATURES = {
     "kryst_pc_approx_inverse": (C.c_int32, [Handle, C.POINTER(Handle)]),
     "kryst_pc_apply": (C.c_int32, [Handle, Handle, Handle]),
     "kryst_pc_destroy": (C.c_int32, [Handle]),
+    "kryst_bench_pc_apply": (C.c_int32, [Handle, Handle, Handle, C.c_int32, c_dp]),
+    "kryst_pc_ilu_info": (C.c_int32, [Handle, c_i64p, C.c_int32]),
     "kryst_apply_chebyshev": (C.c_int32, [Handle, Handle, Handle, C.c_double, C.c_double, C.c_int64]),
     "kryst_cg_solve": (C.c_int32, [c_dp, c_dp, C.c_int64] + _SOLVE_TAIL),
     "kryst_pcg_solve": (C.c_int32, [c_dp, c_dp, C.c_int64] + _SOLVE_TAIL),

@@ -409,7 +409,21 @@ __host__ __device__ static inline int64_t stencil_gptr(int64_t row, int64_t N) {
     return 7 * row - (f_bottom + f_top + f_south + f_north + f_west + f_east);
 }
 
-struct StencilCoef { double c[7]; };
+struct StencilCoef { double c[7]; int varcoef; };
+
+// kind 3, "varcoef": a symmetric variable-coefficient diffusion operator -- no two rows alike, so no value dictionary and no row
+// patterns apply (the operator every structured grid with real coefficients looks like).  The edge between rows r and r + off
+// (off = 1, N, N^2: direction d = 0, 1, 2) carries the weight w(r, d) = 0.5 + U(splitmix64(seed 0xD1FF, counter 3 r + d)) in
+// [0.5, 1.5); a_{r, r+off} = a_{r+off, r} = -w; the diagonal is the sum, in direction order from 0.0, of the six incident weights
+// with 1.0 for a neighbour outside the box (Dirichlet by truncation): a weakly diagonally dominant SPD M-matrix.  The same
+// function in ctx.cpp (kryst_host_stencil7) and oracle/oracle.py (stencil7 "varcoef").
+__host__ __device__ static inline double varcoef_weight(int64_t r, int d) {
+    uint64_t z = 0xD1FFull + ((uint64_t)(3 * r + d) + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return 0.5 + (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
 
 __global__ void stencil7_gen_kernel(int32_t N, int64_t lo, int64_t hi, int64_t n_lower, StencilCoef sc,
                                     int32_t* row_ptr, int32_t* col, double* val, uint8_t* code, uint16_t* code16, uint16_t* pid) {
@@ -427,8 +441,19 @@ __global__ void stencil7_gen_kernel(int32_t N, int64_t lo, int64_t hi, int64_t n
     const int64_t off[7] = {-N2, -N1, -1, 0, 1, N1, N2};
     // CSR-P16 pattern id: which neighbours exist (bits 0-5, direction order without the centre) and whether the k
     // neighbours live in a halo plane (bits 6, 7); the table is built on the host (stencil_pattern_table)
-    pid[i] = (uint16_t)((ok[0] ? 1 : 0) | (ok[1] ? 2 : 0) | (ok[2] ? 4 : 0) | (ok[4] ? 8 : 0) | (ok[5] ? 16 : 0) | (ok[6] ? 32 : 0) |
+    if (pid) pid[i] = (uint16_t)((ok[0] ? 1 : 0) | (ok[1] ? 2 : 0) | (ok[2] ? 4 : 0) | (ok[4] ? 8 : 0) | (ok[5] ? 16 : 0) | (ok[6] ? 32 : 0) |
                         ((ok[0] && row - N2 < lo) ? 64 : 0) | ((ok[6] && row + N2 >= hi) ? 128 : 0));
+    double cv[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) cv[s] = sc.c[s];
+    if (sc.varcoef) {
+        const double w[7] = {ok[0] ? varcoef_weight(row - N2, 2) : 1.0, ok[1] ? varcoef_weight(row - N1, 1) : 1.0, ok[2] ? varcoef_weight(row - 1, 0) : 1.0, 0.0,
+                             ok[4] ? varcoef_weight(row, 0) : 1.0, ok[5] ? varcoef_weight(row, 1) : 1.0, ok[6] ? varcoef_weight(row, 2) : 1.0};
+        double dsum = 0.0;
+#pragma unroll
+        for (int s = 0; s < 7; ++s) if (s != 3) { dsum = dsum + w[s]; cv[s] = -w[s]; }
+        cv[3] = dsum;
+    }
 #pragma unroll
     for (int s = 0; s < 7; ++s)
         if (ok[s]) {
@@ -438,8 +463,8 @@ __global__ void stencil7_gen_kernel(int32_t N, int64_t lo, int64_t hi, int64_t n
             if (c >= lo && c < hi) lc = c - lo;
             else if (c < lo) { lc = nloc + (c - (lo - N2)); cd = 7; }          // halo plane from rank-1: lc - i == nloc
             else { lc = nloc + n_lower + (c - hi); cd = 8; }                   // halo plane from rank+1: lc - i == n_lower + N^2
-            col[k] = (int32_t)lc; val[k] = sc.c[s]; code[k] = (uint8_t)cd;
-            code16[k] = (uint16_t)((s << 8) | cd);                  // value dictionary = the 7 coefficients, by direction
+            col[k] = (int32_t)lc; val[k] = cv[s]; code[k] = (uint8_t)cd;
+            if (code16) code16[k] = (uint16_t)((s << 8) | cd);      // value dictionary = the 7 coefficients, by direction
             ++k;
         }
 }
@@ -460,11 +485,14 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
     a->ctx = ctx; a->nrows = nloc; a->ncols = n; a->nnz = nnz; a->dist = dist; a->xlen = dist ? nloc : n;
     a->row_offsets = offs;
     StencilCoef sc;
+    const bool varcoef = kind == 3;
+    sc.varcoef = varcoef ? 1 : 0;
     {   // same coefficients as kryst_host_stencil7
         double* c = sc.c;
+        for (int u = 0; u < 7; ++u) c[u] = 0.0;
         if (kind == 0) { c[0] = c[1] = c[2] = c[4] = c[5] = c[6] = -1.0; c[3] = 6.0; }
         else if (kind == 1) { const double cx = 1.0, cy = 1.0, cz = 0.01; c[2] = c[4] = -cx; c[1] = c[5] = -cy; c[0] = c[6] = -cz; c[3] = 2.0 * (cx + cy + cz); }
-        else { const double gx = 1.0, gy = 0.5, gz = 0.25; c[2] = -(1.0 + gx); c[4] = -1.0; c[1] = -(1.0 + gy); c[5] = -1.0; c[0] = -(1.0 + gz); c[6] = -1.0; c[3] = 6.0 + gx + gy + gz; }
+        else if (kind == 2) { const double gx = 1.0, gy = 0.5, gz = 0.25; c[2] = -(1.0 + gx); c[4] = -1.0; c[1] = -(1.0 + gy); c[5] = -1.0; c[0] = -(1.0 + gz); c[6] = -1.0; c[3] = 6.0 + gx + gy + gz; }
     }
     int32_t rc = KRYST_OK;
     do {
@@ -472,19 +500,19 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
             hipMalloc(&a->d_col, sizeof(int32_t) * (size_t)(nnz + 8)) != hipSuccess ||
             hipMalloc(&a->d_val, sizeof(double) * (size_t)(nnz + 8)) != hipSuccess ||
             hipMalloc(&a->d_code, (size_t)(nnz + 32)) != hipSuccess || hipMalloc(&a->d_dict, sizeof(int32_t) * 256) != hipSuccess ||
-            hipMalloc(&a->d_code16, sizeof(uint16_t) * (size_t)(nnz + 32)) != hipSuccess || hipMalloc(&a->d_vdict, sizeof(double) * 256) != hipSuccess ||
+            (!varcoef && (hipMalloc(&a->d_code16, sizeof(uint16_t) * (size_t)(nnz + 32)) != hipSuccess || hipMalloc(&a->d_vdict, sizeof(double) * 256) != hipSuccess ||
             hipMalloc(&a->d_pid, sizeof(uint16_t) * (size_t)((nloc + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE)) != hipSuccess ||
             hipMalloc(&a->d_pmeta, sizeof(uint32_t) * 2 * KR_PMAX) != hipSuccess || hipMalloc(&a->d_poff, sizeof(int32_t) * (KR_TMAX + 8)) != hipSuccess ||
-            hipMalloc(&a->d_pval, sizeof(double) * (KR_TMAX + 8)) != hipSuccess) { set_error("hipMalloc failed (stencil7)"); rc = KRYST_ERR_HIP; break; }
-        {
-            int32_t dict[256] = {0};
-            const int32_t offs7[7] = {(int32_t)-N2, -N, -1, 0, 1, N, (int32_t)N2};
-            for (int u = 0; u < 7; ++u) dict[u] = offs7[u];
-            dict[7] = (int32_t)nloc;                                   // lower halo slot - local row
-            dict[8] = (int32_t)((has_lower ? N2 : 0) + N2);            // upper halo slot - local row
-            (void)hipMemcpyAsync(a->d_dict, dict, sizeof dict, hipMemcpyHostToDevice, ctx->s_main);
-            (void)hipStreamSynchronize(ctx->s_main);
-            (void)hipMemsetAsync(a->d_code + nnz, 0, 32, ctx->s_main);
+            hipMalloc(&a->d_pval, sizeof(double) * (KR_TMAX + 8)) != hipSuccess))) { set_error("hipMalloc failed (stencil7)"); rc = KRYST_ERR_HIP; break; }
+        int32_t dict[256] = {0};
+        const int32_t offs7[7] = {(int32_t)-N2, -N, -1, 0, 1, N, (int32_t)N2};
+        for (int u = 0; u < 7; ++u) dict[u] = offs7[u];
+        dict[7] = (int32_t)nloc;                                   // lower halo slot - local row
+        dict[8] = (int32_t)((has_lower ? N2 : 0) + N2);            // upper halo slot - local row
+        (void)hipMemcpyAsync(a->d_dict, dict, sizeof dict, hipMemcpyHostToDevice, ctx->s_main);
+        (void)hipStreamSynchronize(ctx->s_main);
+        (void)hipMemsetAsync(a->d_code + nnz, 0, 32, ctx->s_main);
+        if (!varcoef) {                                            // value dictionary + row patterns: constant coefficients only
             double vd[256] = {0.0};
             for (int u = 0; u < 7; ++u) vd[u] = sc.c[u];
             (void)hipMemcpyAsync(a->d_vdict, vd, sizeof vd, hipMemcpyHostToDevice, ctx->s_main);
@@ -574,7 +602,7 @@ static int32_t create_stencil7_host(kryst_ctx_t ctx, int32_t N, int32_t kind, kr
 }
 
 int32_t kryst_csr_create_stencil7(kryst_ctx_t ctx, int32_t N, int32_t kind, kryst_csr_t* out) {
-    KR_ARG(ctx && out && N >= 1 && kind >= 0 && kind <= 2, "csr_create_stencil7");
+    KR_ARG(ctx && out && N >= 1 && kind >= 0 && kind <= 3, "csr_create_stencil7");
     // KRYST_STENCIL_HOST=1: build through the general host path (kryst_host_stencil7 + csr_create[_dist]); the two
     // paths must give identical operators (tests/test_gpu_0_parity.py)
     if (env_int("KRYST_STENCIL_HOST", 0)) return create_stencil7_host(ctx, N, kind, out);

@@ -217,11 +217,20 @@ static void stencil_coefs(int kind, double c[7]) {
         c[3] = 6.0 + gx + gy + gz; }
 }
 
+// kind 3 ("varcoef", csr_create.hip): weight of the edge between rows r and r + {1, N, N^2}[d]
+static inline double varcoef_weight(int64_t r, int d) {
+    uint64_t z = 0xD1FFull + ((uint64_t)(3 * r + d) + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return 0.5 + (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
 int64_t kryst_host_stencil7(int32_t N, int32_t kind, int32_t k_lo, int32_t k_hi, int64_t* row_ptr, int64_t* col_idx,
                             double* vals) {
-    if (N < 1 || k_lo < 0 || k_hi > N || k_lo > k_hi || kind < 0 || kind > 2) { set_error("stencil7: bad arguments"); return -1; }
-    double c[7];
-    stencil_coefs(kind, c);
+    if (N < 1 || k_lo < 0 || k_hi > N || k_lo > k_hi || kind < 0 || kind > 3) { set_error("stencil7: bad arguments"); return -1; }
+    double c[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (kind < 3) stencil_coefs(kind, c);
     const int64_t N1 = N, N2 = N1 * N1;
     int64_t nnz = 0, lr = 0;
     if (row_ptr) row_ptr[0] = 0;
@@ -231,6 +240,13 @@ int64_t kryst_host_stencil7(int32_t N, int32_t kind, int32_t k_lo, int32_t k_hi,
                 const int64_t row = i + N1 * (j + N1 * k);
                 const bool ok[7] = {k > 0, j > 0, i > 0, true, i < N1 - 1, j < N1 - 1, k < N1 - 1};
                 const int64_t off[7] = {-N2, -N1, -1, 0, 1, N1, N2};
+                if (kind == 3 && vals) {
+                    const double w[7] = {ok[0] ? varcoef_weight(row - N2, 2) : 1.0, ok[1] ? varcoef_weight(row - N1, 1) : 1.0, ok[2] ? varcoef_weight(row - 1, 0) : 1.0, 0.0,
+                                         ok[4] ? varcoef_weight(row, 0) : 1.0, ok[5] ? varcoef_weight(row, 1) : 1.0, ok[6] ? varcoef_weight(row, 2) : 1.0};
+                    double dsum = 0.0;
+                    for (int s = 0; s < 7; ++s) if (s != 3) { dsum = dsum + w[s]; c[s] = -w[s]; }
+                    c[3] = dsum;
+                }
                 for (int s = 0; s < 7; ++s)
                     if (ok[s]) {
                         if (col_idx) col_idx[nnz] = row + off[s];

@@ -1235,6 +1235,51 @@ extern "C" int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kr
     return finish_ilu_pc(a, 100, true, flatten(le), flatten(ue), dg, out);
 }
 
+// What an ILU-family preconditioner's apply runs and streams (bench.py prices the triangular solve with it):
+//   info[0] form: 0 level-ordered factors (sync-free / level kernels), 1 structured grid, 8 x 8 lines per workgroup, 2 structured
+//           grid, 16 x 16 lines per workgroup (tri_quad.h), 3 structured grid after a give-up (plane kernels)
+//   info[1..3] Ni, Nj, Nk (grid forms)          info[4], info[5] dependency levels of L, U (level-ordered forms)
+//   info[6], info[7] coefficient chunks (per block quadrant) of the forward / backward factor; info[8], info[9] how many of them
+//           repeat chunk - 3 bit for bit and are not requested; info[10], info[11] bytes per chunk request (forward, backward)
+//   info[12] stored entries of L + U (level-ordered forms)
+extern "C" int32_t kryst_pc_ilu_info(kryst_pc_t pc, int64_t* info, int32_t count) {
+    KR_ARG(pc && info && count >= 13, "pc_ilu_info: need room for 13 values");
+    KR_ARG(pc->kind == KR_PC_ILU && pc->d_work, "pc_ilu_info: not an ILU-family preconditioner");
+    IluData* D = reinterpret_cast<IluData*>(pc->d_work);
+    kryst_ctx_t ctx = pc->ctx;
+    for (int i = 0; i < count; ++i) info[i] = 0;
+    if (!(D->GL.ok && D->GU.ok)) {
+        info[0] = 0;
+        info[4] = D->L.lvl_off.empty() ? 0 : (int64_t)D->L.lvl_off.size() - 1;
+        info[5] = D->U.lvl_off.empty() ? 0 : (int64_t)D->U.lvl_off.size() - 1;
+        return KRYST_OK;
+    }
+    const unsigned nb = (unsigned)(((D->GL.Nj + 7) / 8) * ((D->GL.Nk + 7) / 8));
+    const int wave_on = env_int("KRYST_ILU_WAVE", default_wave_form(nb));
+    const bool quad = wave_on >= 2 && D->GL.d_blocked && D->GU.d_blocked;
+    info[0] = D->safe ? 3 : quad ? 2 : 1;
+    info[1] = D->GL.Ni; info[2] = D->GL.Nj; info[3] = D->GL.Nk;
+    if (quad) {
+        KR_HIP(hipSetDevice(ctx->device));
+        int q = 0;
+        for (GridFactor* G : {&D->GL, &D->GU}) {
+            const size_t cnt = (size_t)G->nbj * G->nbk * 4 * (size_t)G->nch;
+            info[6 + q] = (int64_t)cnt;
+            info[10 + q] = (int64_t)((q == 0 ? 3 : 4) * 4 * 64 * sizeof(tw_v2));
+            if (G->d_skip && cnt) {
+                std::vector<uint8_t> h(cnt);
+                KR_HIP(hipMemcpyAsync(h.data(), G->d_skip, cnt, hipMemcpyDeviceToHost, ctx->s_main));
+                KR_HIP(hipStreamSynchronize(ctx->s_main));
+                int64_t ns = 0;
+                for (uint8_t v : h) ns += v;
+                info[8 + q] = ns;
+            }
+            ++q;
+        }
+    }
+    return KRYST_OK;
+}
+
 #ifdef KR_TW_TRACE
 extern "C" int32_t kryst_debug_tq_trace(long long* host, int32_t count) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(kr::tq_trace), sizeof(long long) * count) == hipSuccess ? 0 : 1;

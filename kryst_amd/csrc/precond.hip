@@ -225,6 +225,27 @@ int32_t kryst_pc_apply(kryst_pc_t pc, kryst_vec_t r, kryst_vec_t z) {
     return KRYST_OK;
 }
 
+// measurement hook (bench.py): `reps` back-to-back applies between two HIP events on the compute stream, one warm-up apply
+// before them (it also captures the ILU apply's graph); the wavefront solve's health is checked once at the end
+int32_t kryst_bench_pc_apply(kryst_pc_t pc, kryst_vec_t r, kryst_vec_t z, int32_t reps, double* avg_ms) {
+    KR_ARG(pc && r && z && avg_ms && reps >= 1, "bench_pc_apply");
+    KR_ARG(r->ctx == pc->ctx && z->ctx == pc->ctx && r->n == z->n && pc->n == r->n, "bench_pc_apply: size or context mismatch");
+    kryst_ctx_t ctx = pc->ctx;
+    KR_HIP(hipSetDevice(ctx->device));
+    KR_TRY(pc_apply_dev(pc, r->d, z->d, nullptr));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    if (pc_health(pc) != KRYST_OK) { (void)pc_fell_back(pc); }          // measure what the preconditioner now runs
+    KR_HIP(hipEventRecord(ctx->tm0, ctx->s_main));
+    for (int k = 0; k < reps; ++k) KR_TRY(pc_apply_dev(pc, r->d, z->d, nullptr));
+    KR_HIP(hipEventRecord(ctx->tm1, ctx->s_main));
+    KR_HIP(hipEventSynchronize(ctx->tm1));
+    float ms = 0.f;
+    KR_HIP(hipEventElapsedTime(&ms, ctx->tm0, ctx->tm1));
+    *avg_ms = (double)ms / reps;
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    return pc_health(pc);
+}
+
 int32_t kryst_pc_approx_inverse(kryst_csr_t m, kryst_pc_t* out) {
     KR_ARG(m && out, "pc_approx_inverse");
     KR_ARG(m->nrows == m->xlen, "pc_approx_inverse: the inverse rows must form a square operator");

@@ -390,6 +390,8 @@ def stencil7(N, kind="poisson", k_lo=0, k_hi=None):
         gx, gy, gz = 1.0, 0.5, 0.25
         w, e, s, nn, bo, t = -(1.0 + gx), -1.0, -(1.0 + gy), -1.0, -(1.0 + gz), -1.0
         dg = 6.0 + gx + gy + gz
+    elif kind == "varcoef":
+        w = e = s = nn = bo = t = dg = 0.0               # per-row coefficients, filled in below
     else:
         raise ValueError(kind)
     N2 = N * N
@@ -400,6 +402,21 @@ def stencil7(N, kind="poisson", k_lo=0, k_hi=None):
     valid = np.stack([k > 0, j > 0, i > 0, np.ones_like(i, bool), i < N - 1, j < N - 1, k < N - 1], axis=1)
     cols = rows[:, None] + offs[None, :]
     vals = np.broadcast_to(coef, cols.shape)
+    if kind == "varcoef":
+        # the build's variable-coefficient diffusion operator (generator: kryst_amd/csrc/csr_create.hip,
+        # varcoef_weight): edge (r, r + {1, N, N^2}[d]) has weight 0.5 + U(splitmix64(0xD1FF, counter 3 r + d)); off-diagonals are
+        # -w, the diagonal is the sum in direction order from 0.0 of the six incident weights, 1.0 for a neighbour outside the box
+        def wgt(r, d):
+            return 0.5 + splitmix64_uniform_at(0xD1FF, 3 * r + d)
+        w6 = [np.where(valid[:, 0], wgt(rows - N2, 2), 1.0), np.where(valid[:, 1], wgt(rows - N, 1), 1.0),
+              np.where(valid[:, 2], wgt(rows - 1, 0), 1.0), None,
+              np.where(valid[:, 4], wgt(rows, 0), 1.0), np.where(valid[:, 5], wgt(rows, 1), 1.0), np.where(valid[:, 6], wgt(rows, 2), 1.0)]
+        vals = np.empty(cols.shape)
+        dsum = np.zeros(len(rows))
+        for q in (0, 1, 2, 4, 5, 6):
+            dsum = dsum + w6[q]
+            vals[:, q] = -w6[q]
+        vals[:, 3] = dsum
     cnt = valid.sum(axis=1)
     rp = np.zeros(len(rows) + 1, dtype=np.int64)
     np.cumsum(cnt, out=rp[1:])
@@ -416,6 +433,16 @@ def tridiag(n, lower, diag, upper):
         if i + 1 < n:
             a[i, i + 1] = upper
     return a
+
+
+def splitmix64_uniform_at(seed, counters):
+    """uniform [0,1) from splitmix64(seed, counter) for an array of counters (negative counters wrap like uint64: never used)."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (np.asarray(counters).astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
 def splitmix64_uniform(seed, n):

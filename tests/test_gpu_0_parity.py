@@ -74,7 +74,7 @@ def test_from_csr_rejects_what_new_checked_rejects(ctx):
         m.spmv(np.ones(2))                                                              # sparse.rs:57 assert_eq!
 
 
-@pytest.mark.parametrize("kind", ["poisson", "aniso", "convdiff"])
+@pytest.mark.parametrize("kind", ["poisson", "aniso", "convdiff", "varcoef"])
 @pytest.mark.parametrize("N", [1, 2, 7, 16, 33])
 def test_spmv_stencil_bit_exact(ctx, kind, N):
     a = O.stencil7(N, kind)
@@ -202,11 +202,44 @@ def test_spmv_value_dictionary_cases(ctx, level, monkeypatch):
 
 
 def test_spmv_device_generator_matches_host(ctx):
-    for kind in ("poisson", "aniso", "convdiff"):
+    for kind in ("poisson", "aniso", "convdiff", "varcoef"):
         a = K.CsrMatrix.stencil7(12, kind, ctx=ctx)
         ref = O.stencil7(12, kind)
         rp, ci, va = a.download()
         assert np.array_equal(rp, ref.row_ptr) and np.array_equal(ci, ref.col_idx) and np.array_equal(va, ref.vals)
+        hrp, hci, hva = K.host_stencil7(12, kind)
+        assert np.array_equal(hrp, ref.row_ptr) and np.array_equal(hci, ref.col_idx) and np.array_equal(hva, ref.vals)
+
+
+@pytest.mark.parametrize("N", [5, 21, 40])
+def test_variable_coefficient_operator_every_form_and_solver(ctx, rs, N, monkeypatch):
+    """The variable-coefficient 7-point operator (kind "varcoef": no two rows alike, so neither the value dictionary nor the row
+    patterns apply): the device generator keeps CSR-D8 as its most compact form; plain CSR and CSR-D8 SpMV, CG, Jacobi-PCG and
+    BiCGStab + true ILU(0) (device-side factorisation, wavefront solve without repeating coefficient chunks) give the oracle's bits."""
+    ao = O.stencil7(N, "varcoef")
+    a = K.CsrMatrix.stencil7(N, "varcoef", ctx=ctx)
+    assert a.encoding()[0] == "csr-d8"
+    x = O.splitmix64_uniform(0xC0FFEE, ao.ncols) - 0.5
+    want = ao.spmv(x)
+    for comp in ("3", "1", "0"):
+        monkeypatch.setenv("KRYST_SPMV_COMPRESS", comp)
+        assert np.array_equal(a.spmv(x), want), comp
+        assert np.array_equal(to_dev(ctx, ao).spmv(x), want), comp             # host-built operator: same encodings found by kryst_csr_create
+    monkeypatch.delenv("KRYST_SPMV_COMPRESS")
+    b = ao.spmv(np.ones(ao.nrows))
+    atol = 1e-9 * float(np.linalg.norm(b))                                     # BiCGStab's tolerance is absolute (bicgstab.rs)
+    for name, mk, pc_k, pc_o, kw in (("cg", lambda: K.CgSolver(1e-9, 400), None, None, dict(tol=1e-9, max_iters=400)),
+                                     ("pcg", lambda: K.PcgSolver(1e-9, 400), lambda: K.Jacobi().setup(a), O.Pc.jacobi, dict(tol=1e-9, max_iters=400)),
+                                     ("bicgstab_rpc", lambda: K.BiCgStabRightPcSolver(atol, 200), lambda: K.TrueIlu0().setup(a), O.Pc.ilu0_true,
+                                      dict(tol=atol, max_iters=200))):
+        ref = O.solve(name, ao, b, pc=pc_o(ao) if pc_o else None, rs=rs, **kw)
+        s = mk(); xx = np.zeros(ao.nrows)
+        st = s.solve(a, pc_k() if pc_k else None, b, xx)
+        assert (st.iterations, st.converged) == (ref.iterations, ref.converged), name
+        assert np.array_equal(np.array(s.residual_history), ref.history) and np.array_equal(xx, ref.x), name
+    r = O.splitmix64_uniform(5, ao.nrows) - 0.5
+    for kpc, ofn in ((K.TrueIlu0, O.Pc.ilu0_true), (K.Ilu0, O.Pc.ilu0_compat), (lambda: K.Ilup(0), O.Pc.ilup0)):
+        assert np.array_equal(kpc().setup(a).apply(r), ofn(ao).apply(r))
 
 
 # ------------------------------------------------------------------------------------------------ BLAS-1
