@@ -237,6 +237,10 @@ typedef struct kryst_session_s* kryst_session_t;
 int32_t kryst_session_begin(int32_t method, kryst_vec_t b, kryst_vec_t x, kryst_csr_t a, kryst_pc_t pc,
                             const kryst_params_t* params, kryst_session_t* out);
 int32_t kryst_session_step(kryst_session_t s, int64_t k);
+/* A session that is begun must be ended (the context stays busy until then: KRYST_ERR_BUSY for every other solve).  If an ILU
+ * preconditioner's wavefront solve gave up during the session (see kryst_pc_ilu0), kryst_session_end returns KRYST_SOLVE_ERROR
+ * once -- the preconditioner has switched to its plane kernels and the caller repeats the session; the one-shot kryst_*_solve
+ * entry points repeat the solve themselves. */
 int32_t kryst_session_end(kryst_session_t s, kryst_stats_t* stats, double* hist, int64_t hist_cap, int64_t* hist_len);
 
 /* ---- host-only helpers (no GPU needed) ---- */

@@ -487,7 +487,9 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
             return KRYST_OK;
         }
         if (wave_on > 0 && A.Ni >= 2) {
-            hipLaunchKernelGGL((tri_wave_fill_kernel<true>), dim3(nb), dim3(256), 0, s, D->d_args, D->d_y, VA, D->d_flags, (int32_t)(2 * nb + 1));
+            // (the abort word behind the 2 nb flags stays set once raised: later applies of a solve that has given up leave at their
+            // first poll instead of burning the poll budget again; the host switches to the plane kernels at its next sync)
+            hipLaunchKernelGGL((tri_wave_fill_kernel<true>), dim3(nb), dim3(256), 0, s, D->d_args, D->d_y, VA, D->d_flags, (int32_t)(2 * nb));
             hipLaunchKernelGGL((tri_wave_kernel<true>), dim3(nb), dim3(192), 0, s, D->d_args, (const double*)nullptr, D->d_y, VA, D->n, D->d_flags, D->d_flags + 2 * nb, D->d_gave_up, budget);
             hipLaunchKernelGGL((tri_wave_fill_kernel<false>), dim3(nb), dim3(256), 0, s, D->d_args, (double*)nullptr, VB, (int32_t*)nullptr, 0);
             hipLaunchKernelGGL((tri_wave_kernel<false>), dim3(nb), dim3(192), 0, s, D->d_args, (const double*)D->d_y, (double*)nullptr, VB, D->n, D->d_flags + nb, D->d_flags + 2 * nb, D->d_gave_up, budget);

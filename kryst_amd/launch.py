@@ -70,8 +70,8 @@ class Rendezvous:
                     c, _ = srv.accept()
                 except socket.timeout:
                     continue
-                c.settimeout(timeout)
-                try:
+                c.settimeout(2.0)                           # a stale or foreign connection that says nothing must not block the accept
+                try:                                        # loop: the long timeout is set only once the hello has been validated
                     hello = _recv(c)
                 except Exception:
                     c.close()
@@ -79,6 +79,7 @@ class Rendezvous:
                 if hello.get("token") != token or not (1 <= hello.get("rank", 0) < world) or slots[hello["rank"] - 1] is not None:
                     c.close()
                     continue
+                c.settimeout(timeout)
                 _send(c, {"token": token, "ok": True})
                 slots[hello["rank"] - 1] = c
             srv.close()

@@ -149,7 +149,7 @@ def test_512_cubed_properties(ctx, monkeypatch):
     assert all(hist[0][i + 1] < hist[0][i] for i in range(5))
 
 
-# ------------------------------------------------------------------------------------------------ BASELINE configs 3 and 5 at full size
+# ------------------------------------------------------------------------------------------------ BASELINE configs 3, 4 and 5 at full size
 def _true_residual(ctx, a, b, x):
     """||b - A x|| with the device's own SpMV, subtraction (`bi - ax`, cg.rs:123 / gmres.rs:224) and norm."""
     ax = a.spmv(x)
@@ -232,3 +232,38 @@ def test_config5_bicgstab_true_ilu0_aniso_256(ctx, monkeypatch):
     z_planes = ctx.vec(n); pc2.apply(r, z_planes)
     d = ctx.vec(n); d.copy_from(z_wave); K.axpy(-1.0, z_planes, d)
     assert K.norm(d) == 0.0 and np.isfinite(K.norm(z_wave))
+
+
+@pytest.mark.gpu
+def test_config4_jacobi_pcg_512_cubed_on_one_gpu(ctx):
+    """BASELINE configs[3]'s workload -- Jacobi-PCG (pcg.rs:114-222) on the 512^3 Poisson system, tol 1e-8, max 3000 -- on ONE GPU
+    (its 8-way partition needs 8 GPUs; the partitioned code path is covered at small sizes by the multi-rank tests).  Size-independent
+    properties: it converges below the cap, two solves give the same history bit for bit, the iteration count is close to
+    unpreconditioned CG's (the Jacobi-scaled system has the same Krylov spaces; PCG's mixed-norm test -- res0 = sqrt|r.z| = ||r0||/sqrt 6,
+    pcg.rs:134 vs :192 -- is sqrt 6 stricter), and the TRUE residual meets the tolerance the solver reports."""
+    M = 512
+    n = M ** 3
+    a = K.CsrMatrix.stencil7(M, "poisson", ctx=ctx)
+    ones = ctx.vec(n).fill(1.0)
+    b = a.spmv(ones)
+    bn = K.norm(b)
+    pc = K.Jacobi().setup(a)
+    runs = []
+    for _ in range(2):
+        x = ctx.vec(n)
+        s = K.PcgSolver(1e-8, 3000)
+        st = s.solve(a, pc, b, x)
+        runs.append((st.iterations, st.converged, st.final_residual, list(s.residual_history)))
+    assert runs[0] == runs[1]
+    its, conv, fr, hist = runs[0]
+    assert conv and 100 < its < 3000 and len(hist) == its + 1
+    assert hist[0] == bn / np.sqrt(6.0) or abs(hist[0] - bn / np.sqrt(6.0)) <= 1e-12 * bn      # res0 = sqrt(|r0 . D^-1 r0|)
+    assert fr / hist[0] <= 1e-8
+    tr = _true_residual(ctx, a, b, x)
+    assert tr <= 1e-8 * bn and abs(tr - fr) <= 1e-3 * fr + 1e-12 * bn                          # the recurrence residual is the true one
+    xc = ctx.vec(n)
+    sc = K.CgSolver(1e-8, 3000)
+    stc = sc.solve(a, None, b, xc)
+    assert stc.converged and abs(stc.iterations - its) <= 60, (stc.iterations, its)
+    K.axpy(-1.0, ones, x)
+    assert K.norm(x) <= 1e-3 * np.sqrt(n)                                                      # x* = 1: error <= kappa * 1e-8
