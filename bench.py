@@ -200,13 +200,15 @@ def kernel_name(enc):
     return {"csr": "spmv_wave_kernel<1> (plain CSR: 8 B value + 4 B column per entry)",
             "csr-d8": "spmv_rows_kernel<1> (CSR-D8: 8 B value + 1-byte column-offset code per entry)",
             "csr-d16": "spmv_dict_kernel<1> (CSR-D16: one 16-bit word per entry = offset code + value code)",
-            "csr-p16": f"spmv_pattern_kernel<1> (CSR-P16: one 16-bit row-pattern id per row; {npat} ids, {ntab} table entries in LDS)"}[name]
+            "csr-p16": f"spmv_pattern_kernel<1> (CSR-P16: one 16-bit row-pattern id per row; {npat} ids, {ntab} table entries in LDS)",
+            "csr-dia": f"spmv_dia_kernel<1> (CSR-DIA: one 8-byte value stream per diagonal, {npat} diagonals; no row pointers, no column codes)"}[name]
 
 
 def roofline_of(enc, grid, nloc, nnz_loc, ms, world):
     """The kernel that ran, priced at the bytes IT moves."""
     alg = spmv_bytes(nloc, nnz_loc)
-    moved = {"csr": alg, "csr-d8": alg - 3 * nnz_loc, "csr-d16": alg - 10 * nnz_loc, "csr-p16": 2 * nloc + 16 * nloc}[enc[0]]
+    moved = {"csr": alg, "csr-d8": alg - 3 * nnz_loc, "csr-d16": alg - 10 * nnz_loc, "csr-p16": 2 * nloc + 16 * nloc,
+             "csr-dia": 8 * enc[1] * nloc + 16 * nloc}[enc[0]]
     ach = moved / (ms * 1e-3) / 1e9
     out = {"bound": "hbm", "kernel": kernel_name(enc) + ", fused (p,Ap) tile partials",
            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

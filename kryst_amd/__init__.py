@@ -272,7 +272,7 @@ class CsrMatrix:
             out[:] = tmp
         return out
 
-    ENCODINGS = ("csr", "csr-d8", "csr-d16", "csr-p16")
+    ENCODINGS = ("csr", "csr-d8", "csr-d16", "csr-p16", "csr-dia")
 
     def encoding(self):
         """(name, patterns, table_entries) of the storage form kryst_spmv streams (see kryst_csr_encoding)."""

@@ -113,6 +113,142 @@ static int32_t build_patterns(kryst_csr_t a, const std::vector<int32_t>& rp, con
     return upload_patterns(a, pid, meta, poff, pval);
 }
 
+
+// ---------------------------------------------------------------- CSR-DIA (built on the device from the CSR-D8 form)
+// used[] : 256-bit map of the offset codes that occur
+__global__ __launch_bounds__(256) void dia_usage_kernel(const uint8_t* __restrict__ code, int64_t nnz, unsigned* used) {
+    __shared__ unsigned lds[8];
+    if (threadIdx.x < 8) lds[threadIdx.x] = 0u;
+    __syncthreads();
+    unsigned mine[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned c = code[k];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) mine[w] |= ((c >> 5) == (unsigned)w) ? (1u << (c & 31u)) : 0u;
+    }
+#pragma unroll
+    for (int w = 0; w < 8; ++w) if (mine[w]) atomicOr(&lds[w], mine[w]);
+    __syncthreads();
+    if (threadIdx.x < 8 && lds[threadIdx.x]) atomicOr(&used[threadIdx.x], lds[threadIdx.x]);
+}
+// prec[a] bit b: in some row an entry of diagonal a is stored directly before one of diagonal b;  flags[0] |= 1 when a row holds a
+// diagonal twice or is longer than the diagonal count (not a DIA operator)
+__global__ __launch_bounds__(256) void dia_precede_kernel(const int32_t* __restrict__ rp, const uint8_t* __restrict__ code, int64_t n,
+                                                          const uint8_t* __restrict__ idx_of_code, int nd, unsigned* prec, unsigned* flags) {
+    __shared__ unsigned lds[KR_DIA_MAX];
+    if (threadIdx.x < KR_DIA_MAX) lds[threadIdx.x] = 0u;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        unsigned seen = 0u; int prev = -1;
+        for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+            const int d = idx_of_code[code[k]];
+            if ((seen >> d) & 1u) atomicOr(&flags[0], 1u);
+            seen |= 1u << d;
+            if (prev >= 0 && !((lds[prev] >> d) & 1u)) atomicOr(&lds[prev], 1u << d);
+            prev = d;
+        }
+        if (rp[i + 1] - rp[i] > nd) atomicOr(&flags[0], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < KR_DIA_MAX && lds[threadIdx.x]) atomicOr(&prec[threadIdx.x], lds[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void dia_fill_kernel(double* dia, int64_t count) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (int64_t)gridDim.x * blockDim.x)
+        dia[k] = __longlong_as_double((long long)KR_DIA_ABSENT);
+}
+// one thread per row: its entries go to their diagonals' streams (rank_of_code: position of the code's diagonal in the stored order)
+__global__ __launch_bounds__(256) void dia_scatter_kernel(const int32_t* __restrict__ rp, const uint8_t* __restrict__ code, const double* __restrict__ val,
+                                                          int64_t n, const uint8_t* __restrict__ rank_of_code, double* dia, int64_t stride, unsigned* flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+        const double v = val[k];
+        if ((unsigned long long)__double_as_longlong(v) == KR_DIA_ABSENT) atomicOr(&flags[0], 2u);     // a stored value with the marker's bits
+        dia[(int64_t)rank_of_code[code[k]] * stride + i] = v;
+    }
+}
+
+// Build the CSR-DIA streams when the operator qualifies (see csr.h); not an error when it does not.  KRYST_SPMV_DIA: 0 never,
+// 1 (default) when the operator has no CSR-D16 / CSR-P16 form (those stream fewer bytes), 2 whenever it qualifies.
+static int32_t build_dia(kryst_csr_t a) {
+    kryst_ctx_t ctx = a->ctx;
+    const int want = env_int("KRYST_SPMV_DIA", 1);
+    const int64_t n = a->nrows, nnz = a->nnz;
+    if (want == 0 || !a->d_code || !a->d_dict || n == 0 || nnz == 0) return KRYST_OK;
+    if (want < 2 && a->d_code16) return KRYST_OK;
+    struct Scratch { unsigned* u = nullptr; uint8_t* b = nullptr; ~Scratch() { (void)hipFree(u); (void)hipFree(b); } } sc;
+    KR_HIP(hipMalloc(&sc.u, sizeof(unsigned) * 32)); KR_HIP(hipMalloc(&sc.b, 512));
+    KR_HIP(hipMemsetAsync(sc.u, 0, sizeof(unsigned) * 32, ctx->s_main));
+    unsigned* d_used = sc.u; unsigned* d_prec = sc.u + 8; unsigned* d_flags = sc.u + 24;
+    const unsigned eg = (unsigned)std::min<int64_t>(4096, (nnz + 255) / 256), rg = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(dia_usage_kernel, dim3(eg), dim3(256), 0, ctx->s_main, a->d_code, nnz, d_used);
+    KR_HIP(hipGetLastError());
+    unsigned used[8]; int32_t dict[256];
+    KR_HIP(hipMemcpyAsync(used, d_used, sizeof used, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipMemcpyAsync(dict, a->d_dict, sizeof dict, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    std::vector<int> codes;
+    for (int c = 0; c < 256; ++c) if ((used[c >> 5] >> (c & 31)) & 1u) codes.push_back(c);
+    const int nd = (int)codes.size();
+    if (nd == 0 || nd > KR_DIA_MAX) return KRYST_OK;
+    if ((double)nd * (double)n > 1.125 * (double)nnz + 64.0) return KRYST_OK;       // diagonals too sparsely filled: 8 nd n + 16 n would exceed CSR-D8's bytes
+    // stored order of the diagonals: ascending offset for a plain operator (columns ascend inside a row); with halo columns the
+    // local numbering breaks that, so the order is read off the rows (an entry of diagonal a directly before one of diagonal b)
+    std::sort(codes.begin(), codes.end(), [&](int x, int y) { return dict[x] < dict[y]; });
+    uint8_t idx_of_code[256] = {0}, rank_of_code[256] = {0};
+    for (int d = 0; d < nd; ++d) idx_of_code[codes[d]] = (uint8_t)d;
+    KR_HIP(hipMemcpyAsync(sc.b, idx_of_code, 256, hipMemcpyHostToDevice, ctx->s_main));
+    hipLaunchKernelGGL(dia_precede_kernel, dim3(rg), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_code, n, sc.b, nd, d_prec, d_flags);
+    KR_HIP(hipGetLastError());
+    unsigned prec[KR_DIA_MAX], flags[1];
+    KR_HIP(hipMemcpyAsync(prec, d_prec, sizeof prec, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    if (flags[0]) return KRYST_OK;
+    std::vector<int> order;                                   // topological order of the "directly before" relation (Kahn; ties: ascending offset)
+    {
+        int indeg[KR_DIA_MAX] = {0};
+        for (int x = 0; x < nd; ++x) for (int y = 0; y < nd; ++y) if ((prec[x] >> y) & 1u) ++indeg[y];
+        std::vector<bool> done((size_t)nd, false);
+        for (int step = 0; step < nd; ++step) {
+            int pick = -1;
+            for (int x = 0; x < nd && pick < 0; ++x) if (!done[x] && indeg[x] == 0) pick = x;
+            if (pick < 0) return KRYST_OK;                    // a cycle: rows disagree about the order of two diagonals
+            done[pick] = true; order.push_back(pick);
+            for (int y = 0; y < nd; ++y) if ((prec[pick] >> y) & 1u) --indeg[y];
+        }
+    }
+    // a row's entries need not be ADJACENT diagonals, so "directly before" alone does not order every pair a row holds; the closure
+    // does: require the order to be the unique linear extension on every pair that some row relates (checked by the scatter's
+    // companion below: each row's diagonal ranks must ascend)
+    for (int r = 0; r < nd; ++r) rank_of_code[codes[order[r]]] = (uint8_t)r;
+    const int64_t stride = (n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE;
+    if (hipMalloc(&a->d_dia, sizeof(double) * (size_t)stride * nd) != hipSuccess) { (void)hipGetLastError(); a->d_dia = nullptr; return KRYST_OK; }   // optional form
+    KR_HIP(hipMemcpyAsync(sc.b + 256, rank_of_code, 256, hipMemcpyHostToDevice, ctx->s_main));
+    KR_HIP(hipMemsetAsync(d_flags, 0, sizeof(unsigned) * 8, ctx->s_main));
+    hipLaunchKernelGGL(dia_fill_kernel, dim3(4096), dim3(256), 0, ctx->s_main, a->d_dia, stride * nd);
+    hipLaunchKernelGGL(dia_scatter_kernel, dim3(rg), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_code, a->d_val, n, sc.b + 256, a->d_dia, stride, d_flags);
+    // ranks ascend inside every row?  (reuses the precedence kernel with the ranks as indices: bit b of prec[a] with b <= a is a violation)
+    KR_HIP(hipMemsetAsync(d_prec, 0, sizeof(unsigned) * KR_DIA_MAX, ctx->s_main));
+    hipLaunchKernelGGL(dia_precede_kernel, dim3(rg), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_code, n, sc.b + 256, nd, d_prec, d_flags);
+    KR_HIP(hipGetLastError());
+    KR_HIP(hipMemcpyAsync(prec, d_prec, sizeof prec, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    bool ok = flags[0] == 0;
+    for (int x = 0; x < nd && ok; ++x) if (prec[x] & ((2u << x) - 1u)) ok = false;
+    if (!ok) { (void)hipFree(a->d_dia); a->d_dia = nullptr; return KRYST_OK; }
+    a->dia_stride = stride; a->dia_nd = nd;
+    a->dia_min = 0; a->dia_max = 0;
+    for (int r = 0; r < nd; ++r) {
+        const int32_t off = dict[codes[order[r]]];
+        a->dia_off[r] = off;
+        a->dia_min = std::min(a->dia_min, off); a->dia_max = std::max(a->dia_max, off);
+    }
+    return KRYST_OK;
+}
+
 // ---------------------------------------------------------------- creation
 static int32_t upload_csr(kryst_csr_t a, const std::vector<int32_t>& rp, const std::vector<int32_t>& col, const double* val) {
     kryst_ctx_t ctx = a->ctx;
@@ -192,6 +328,7 @@ static int32_t upload_csr(kryst_csr_t a, const std::vector<int32_t>& rp, const s
     const double per_slice = a->nrows > 0 ? (double)a->nnz / (double)((a->nrows + 127) / 128) : 0.0;
     a->slots = per_slice <= 256.0 ? 2 : (per_slice <= 512.0 ? 4 : 7);
     KR_TRY(build_patterns(a, rp, col, val));
+    KR_TRY(build_dia(a));
     return KRYST_OK;
 }
 
@@ -553,6 +690,7 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("stencil7 generation failed"); rc = KRYST_ERR_HIP; break; }
         a->ntiles = ntiles_of(nloc);
         a->slots = 7;
+        if ((rc = build_dia(a)) != KRYST_OK) break;
         if (!dist) break;
         // analytic halo plan of a k-slab partition: one grid plane from each neighbour, sent in place
         HaloPlan& pl = a->plan;
@@ -615,7 +753,7 @@ int32_t kryst_csr_destroy(kryst_csr_t a) {
     (void)hipStreamSynchronize(a->ctx->s_main);
     (void)hipStreamSynchronize(a->ctx->s_comm);
     (void)hipFree(a->d_row_ptr); (void)hipFree(a->d_col); (void)hipFree(a->d_val); (void)hipFree(a->d_code); (void)hipFree(a->d_dict); (void)hipFree(a->d_code16); (void)hipFree(a->d_vdict);
-    (void)hipFree(a->d_pid); (void)hipFree(a->d_pmeta); (void)hipFree(a->d_poff); (void)hipFree(a->d_pval);
+    (void)hipFree(a->d_pid); (void)hipFree(a->d_pmeta); (void)hipFree(a->d_poff); (void)hipFree(a->d_pval); (void)hipFree(a->d_dia);
     (void)hipFree(a->d_tiles_interior); (void)hipFree(a->d_tiles_boundary);
     (void)hipFree(a->plan.d_send_idx); (void)hipFree(a->plan.d_sendbuf); (void)hipFree(a->plan.d_halo);
     delete a;

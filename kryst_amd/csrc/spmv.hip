@@ -41,6 +41,9 @@ struct SpmvArgs {
     int32_t nloc8;                                 // 8 * nloc
     int32_t tpw;                                   // pattern kernel: consecutive tile slots per workgroup
     int32_t amask;                                 // window start = k0 & ~amask (1: value pairs; 31: whole memory lines)
+    const double* dia; int64_t dia_stride; int32_t dia_nd; int32_t dia_min;    // CSR-DIA: value streams, diagonals, lowest offset
+    int64_t xsafe; int32_t cmax;                   // last safe start of a 16-byte pair in x's allocation; last valid local column
+    int32_t dia_off[KR_DIA_MAX];
 #ifdef KR_TUNING
     int32_t abl;                                   // timing-only ablation mask (tuning builds)
 #endif
@@ -579,6 +582,87 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {
     }
 }
 
+// CSR-DIA (spmv_dia_kernel): operators with a handful of well-filled diagonals -- every stencil on a structured grid, variable
+// coefficients included.  The values are stored as one stream per diagonal in natural row order (csr_create.hip: build_dia), an
+// absent entry carries a NaN payload no stored value may have, so there are NO row pointers, NO per-entry codes and no
+// dependent load: lane t (rows 2t, 2t+1) issues, per diagonal, one 16-byte nontemporal load of its two values and one 16-byte
+// load of x[2t + off], x[2t + 1 + off] -- all 2 D loads of a tile in flight at once -- and then folds the present entries in
+// diagonal (= stored, ascending column) order from 0.0 with separate mul and add: the reference's loop (sparse.rs:107-113), bit
+// for bit.  8 D + 16 bytes per row (7-point: 72; CSR-D8 83, plain CSR 104).  Pair loads of x are clamped at the top of x's
+// (padded) allocation -- only an absent entry can point there -- and tiles whose lowest diagonal would start before x[0], as well
+// as tiles with halo columns, take the per-element clamped path.
+// one batch of DB diagonals starting at d0 (EXACT: the operator has exactly DB diagonals, so every index is a compile-time constant
+// and the offsets are plain kernel arguments); FAST: 16-byte pair loads of x, else per-element clamped gathers
+template <bool HALO, int DB, bool EXACT, bool FAST>
+__device__ __forceinline__ void dia_batch(const SpmvArgs& a, int row, int d0, int nd, double& s0, double& s1) {
+    v2d v[DB], xx[DB];
+    const double* vrow = a.dia + row;
+#pragma unroll
+    for (int u = 0; u < DB; ++u) {
+        const int d = EXACT ? u : min(d0 + u, nd - 1);           // (a batch's tail re-reads the last diagonal; not used below)
+        v[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(vrow + (int64_t)d * a.dia_stride));
+        const int64_t c = (int64_t)row + a.dia_off[d];
+        if constexpr (FAST) {
+            xx[u] = *reinterpret_cast<const v2d*>(a.x + min(c, a.xsafe));
+        } else {
+            const int32_t c0 = (int32_t)min(max(c, (int64_t)0), (int64_t)a.cmax), c1 = (int32_t)min(max(c + 1, (int64_t)0), (int64_t)a.cmax);
+            xx[u].x = gather<HALO>(a, c0); xx[u].y = gather<HALO>(a, c1);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < DB; ++u) {
+        if (EXACT || d0 + u < nd) {
+            const double ta = s0 + v[u].x * xx[u].x, tb = s1 + v[u].y * xx[u].y;
+            s0 = ((unsigned long long)__double_as_longlong(v[u].x) != KR_DIA_ABSENT) ? ta : s0;
+            s1 = ((unsigned long long)__double_as_longlong(v[u].y) != KR_DIA_ABSENT) ? tb : s1;
+        }
+    }
+}
+
+template <int NQ, bool HALO, int DB, bool EXACT>
+__global__ __launch_bounds__(KR_T) void spmv_dia_kernel(const SpmvArgs a) {
+    if (a.done && *a.done) return;
+    __shared__ double red[(NQ > 0 ? NQ : 1) * (KR_T / 64)];
+    const int t = threadIdx.x;
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int nd = a.dia_nd;
+    for (int li = slot0; li < a.xcd_chunk; li += per) {
+        int ti;
+        if (a.swizzle) ti = xcd * a.xcd_chunk + li;
+        else ti = ((li / a.group) * 8 + xcd) * a.group + (li % a.group);
+        if (ti >= a.ntiles) { if (a.swizzle) break; else continue; }
+        const int q = a.tiles ? a.tiles[ti] : ti;
+        const int r0 = q * KR_TILE;
+        const int r1 = min(r0 + KR_TILE, a.nrows);
+        const int row = r0 + 2 * t;
+        double s0 = 0.0, s1 = 0.0;
+        if (!HALO && r0 + a.dia_min >= 0) {                            // uniform over the workgroup
+            for (int d0 = 0; d0 < (EXACT ? 1 : nd); d0 += DB) dia_batch<HALO, DB, EXACT, true>(a, row, d0, nd, s0, s1);
+        } else {
+            for (int d0 = 0; d0 < (EXACT ? 1 : nd); d0 += DB) dia_batch<HALO, DB, EXACT, false>(a, row, d0, nd, s0, s1);
+        }
+        if (row + 1 < r1) st2(a.y, row, s0, s1);
+        else if (row < r1) a.y[row] = s0;
+        if constexpr (NQ > 0) {
+            double acc[NQ];
+            const d2 d = ld2(a.dvec, row);
+            acc[0] = 0.0;
+            if (row < r1) acc[0] = acc[0] + d.a * s0;
+            if (row + 1 < r1) acc[0] = acc[0] + d.b * s1;
+            if constexpr (NQ > 1) {
+                acc[1] = 0.0;
+                if (row < r1) acc[1] = acc[1] + s0 * s0;
+                if (row + 1 < r1) acc[1] = acc[1] + s1 * s1;
+            }
+            block_reduce<NQ, KR_T / 64>(acc, red);
+            if (t == 0) {
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) a.partials[k * a.pstride + q] = acc[k];
+            }
+        }
+    }
+}
+
 __global__ void pack_kernel(const double* x, const int32_t* idx, double* out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = x[idx[i]];
@@ -662,6 +746,26 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
             case 2: hipLaunchKernelGGL((spmv_dict_kernel<2, HALO>), grid, block, 0, ctx->s_main, args); break;
             default: set_error("spmv: nq=%d", nq); return KRYST_ERR_ARG;
         }
+        KR_HIP(hipGetLastError());
+        return KRYST_OK;
+    }
+    if (a->d_dia && comp_level >= 1 && env_int("KRYST_SPMV_DIA", 1) != 0) {
+        args.dia = a->d_dia; args.dia_stride = a->dia_stride; args.dia_nd = a->dia_nd; args.dia_min = a->dia_min;
+        for (int d = 0; d < KR_DIA_MAX; ++d) args.dia_off[d] = a->dia_off[d];
+        args.xsafe = (a->xlen + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE - 2;      // vectors are allocated padded to a tile multiple + one tile (blas1.hip)
+        args.cmax = (int32_t)(HALO ? a->nrows + a->plan.total_recv - 1 : a->xlen - 1);
+        const int nd = a->dia_nd;
+#define KR_DIA(NQ_, DB_, EX_) hipLaunchKernelGGL((spmv_dia_kernel<NQ_, HALO, DB_, EX_>), grid, block, 0, ctx->s_main, args)
+#define KR_DIA_BY(NQ_) do { if (nd == 3) KR_DIA(NQ_, 3, true); else if (nd == 5) KR_DIA(NQ_, 5, true); else if (nd == 7) KR_DIA(NQ_, 7, true); \
+                            else if (nd == 9) KR_DIA(NQ_, 9, true); else if (nd < 7) KR_DIA(NQ_, 4, false); else KR_DIA(NQ_, 8, false); } while (0)
+        switch (nq) {
+            case 0: KR_DIA_BY(0); break;
+            case 1: KR_DIA_BY(1); break;
+            case 2: KR_DIA_BY(2); break;
+            default: set_error("spmv: nq=%d", nq); return KRYST_ERR_ARG;
+        }
+#undef KR_DIA_BY
+#undef KR_DIA
         KR_HIP(hipGetLastError());
         return KRYST_OK;
     }
@@ -767,16 +871,17 @@ int32_t kryst_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y) {
 }
 
 // which encoding kryst_spmv streams for this operator under the current KRYST_SPMV_COMPRESS setting:
-// 0 plain CSR (12 B/nnz), 1 CSR-D8 (9 B/nnz), 2 CSR-D16 (2 B/nnz), 3 CSR-P16 (2 B/row)
+// 0 plain CSR (12 B/nnz), 1 CSR-D8 (9 B/nnz), 2 CSR-D16 (2 B/nnz), 3 CSR-P16 (2 B/row), 4 CSR-DIA (8 B per diagonal and row)
 int32_t kryst_csr_encoding(kryst_csr_t a, int32_t* encoding, int32_t* patterns, int32_t* table_entries) {
     KR_ARG(a && encoding, "csr_encoding");
     const int lvl = env_int("KRYST_SPMV_COMPRESS", 3);
     int e = 0;
     if (a->d_pid && lvl >= 3) e = 3;
     else if (a->d_code16 && lvl >= 2) e = 2;
+    else if (a->d_dia && lvl >= 1 && env_int("KRYST_SPMV_DIA", 1) != 0) e = 4;
     else if (a->d_code && lvl >= 1) e = 1;
     *encoding = e;
-    if (patterns) *patterns = a->d_pid ? a->npat : 0;
+    if (patterns) *patterns = e == 4 ? a->dia_nd : (a->d_pid ? a->npat : 0);      // CSR-DIA: the number of diagonals
     if (table_entries) *table_entries = a->d_pid ? a->ntab : 0;
     return KRYST_OK;
 }

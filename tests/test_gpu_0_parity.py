@@ -126,6 +126,65 @@ def test_spmv_kernel_forms_bit_exact(ctx, kernel, compress, monkeypatch):
     assert st.iterations == res.iterations and np.array_equal(xx, res.x) and np.array_equal(np.array(s.residual_history), res.history)
 
 
+def test_spmv_diagonal_streams_form_bit_exact(ctx, monkeypatch):
+    """CSR-DIA (one value stream per diagonal, absent entries marked by a NaN payload): built whenever an operator has at most 16
+    well-filled diagonals (KRYST_SPMV_DIA=2: also beside the more compact D16 / P16 forms, which this test switches off).  Cases:
+    1-, 3-, 5-, 7-, 9-, 11- and 16-diagonal operators (the exact-count kernels and the batched one), boxes whose first tiles start
+    before x[0] and whose last reach past x's end, stored zeros, signed zeros, inf / NaN values AND inf / NaN in x next to absent
+    entries (an absent entry must contribute nothing, not 0 * x), empty rows, a stored value with the marker's own bits (the
+    operator must then NOT take this form), 17 diagonals and sparsely filled diagonals (not this form either)."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("KRYST_SPMV_DIA", "2"); monkeypatch.setenv("KRYST_SPMV_COMPRESS", "1")
+    rng = np.random.default_rng(44)
+
+    def banded(n, offs, keep=1.0, vals=None):
+        rows, cols, vs = [], [], []
+        for o in offs:
+            i = np.arange(max(0, -o), min(n, n - o))
+            m = rng.random(len(i)) < keep
+            rows.append(i[m]); cols.append(i[m] + o); vs.append(rng.standard_normal(int(m.sum())) if vals is None else np.full(int(m.sum()), vals))
+        m = sp.csr_matrix((np.concatenate(vs), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)); m.sort_indices()
+        return O.Csr(n, n, m.indptr, m.indices, m.data)
+
+    yes = [banded(1, [0]), banded(700, [0]), banded(2000, [-1, 0, 1]), banded(5000, [-70, -1, 0, 1, 70]), O.stencil7(21, "varcoef"), O.stencil7(33, "poisson"),
+           banded(3000, [-900, -30, -1, 0, 1, 30, 900], keep=0.93),                               # randomly missing couplings
+           banded(4099, [-1200, -35, -34, -1, 0, 1, 34, 35, 1200]), banded(2500, list(range(-5, 6))), banded(3333, list(range(-8, 8)))]
+    for a in yes:
+        d = to_dev(ctx, a)
+        assert d.encoding()[0] == "csr-dia", (a.nrows, a.nnz)
+        for trial in range(2):
+            x = rng.standard_normal(a.ncols)
+            if trial == 1 and a.ncols > 10:
+                x[rng.integers(0, a.ncols, 5)] = [np.inf, -np.inf, np.nan, 0.0, -0.0]             # next to absent entries at the box's faces
+            got, want = d.spmv(x), a.spmv(x)
+            ok = ~np.isnan(want)
+            assert np.array_equal(got, want, equal_nan=True) and np.array_equal(np.signbit(got[ok]), np.signbit(want[ok])), (a.nrows, a.nnz, trial)
+    # special values among the stored entries; an explicitly stored zero is an entry (0 * inf = NaN), an absent one is not
+    sv = banded(1500, [-40, -1, 0, 1, 40])
+    sv.vals[rng.integers(0, sv.nnz, 40)] = rng.choice([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324], 40)
+    d = to_dev(ctx, sv)
+    assert d.encoding()[0] == "csr-dia"
+    x = rng.standard_normal(1500); x[7] = np.inf; x[900] = np.nan
+    assert np.array_equal(d.spmv(x), sv.spmv(x), equal_nan=True)
+    # NOT this form: the marker's bit pattern among the values, 17 diagonals, thinly filled diagonals, an empty matrix
+    mk = banded(1000, [-1, 0, 1])
+    mk.vals[123] = np.frombuffer(np.uint64(0x7FF8D1A0D1A0D1A0).tobytes(), dtype=np.float64)[0]
+    for a in (mk, banded(3000, list(range(-8, 9))), banded(4000, [-1000, -10, 0, 10, 1000], keep=0.5), O.Csr(5, 5, [0, 0, 0, 0, 0, 0], [], [])):
+        d = to_dev(ctx, a)
+        assert d.encoding()[0] != "csr-dia", (a.nrows, a.nnz)
+        x = rng.standard_normal(a.ncols)
+        assert np.array_equal(d.spmv(x), a.spmv(x), equal_nan=True)
+    # fused inner products through a solver on the diagonal-streams form
+    ao = O.stencil7(24, "aniso"); a = K.CsrMatrix.stencil7(24, "aniso", ctx=ctx)
+    assert a.encoding()[0] == "csr-dia"
+    b = ao.spmv(np.ones(ao.nrows))
+    T, V, F = K.reduce_spec()
+    res = O.solve("bicgstab", ao, b, tol=1e-7 * np.linalg.norm(b), max_iters=200, rs=O.Reduce.tiled(T, V, F))
+    s = K.BiCgStabSolver(1e-7 * np.linalg.norm(b), 200); xx = np.zeros(ao.nrows)
+    st = s.solve(a, None, b, xx)
+    assert st.iterations == res.iterations and np.array_equal(xx, res.x) and np.array_equal(np.array(s.residual_history), res.history)
+
+
 @pytest.mark.parametrize("slots", ["2", "4", "7"])
 @pytest.mark.parametrize("nt,align", [("0", "0"), ("1", "0"), ("1", "1")])
 def test_spmv_plain_kernel_settings_bit_exact(ctx, slots, nt, align, monkeypatch):
@@ -214,18 +273,20 @@ def test_spmv_device_generator_matches_host(ctx):
 @pytest.mark.parametrize("N", [5, 21, 40])
 def test_variable_coefficient_operator_every_form_and_solver(ctx, rs, N, monkeypatch):
     """The variable-coefficient 7-point operator (kind "varcoef": no two rows alike, so neither the value dictionary nor the row
-    patterns apply): the device generator keeps CSR-D8 as its most compact form; plain CSR and CSR-D8 SpMV, CG, Jacobi-PCG and
+    patterns apply): its most compact form is CSR-DIA (seven value streams); CSR-DIA, CSR-D8 and plain CSR SpMV, CG, Jacobi-PCG and
     BiCGStab + true ILU(0) (device-side factorisation, wavefront solve without repeating coefficient chunks) give the oracle's bits."""
     ao = O.stencil7(N, "varcoef")
     a = K.CsrMatrix.stencil7(N, "varcoef", ctx=ctx)
-    assert a.encoding()[0] == "csr-d8"
+    assert a.encoding()[:2] == ("csr-dia", 7)
     x = O.splitmix64_uniform(0xC0FFEE, ao.ncols) - 0.5
     want = ao.spmv(x)
-    for comp in ("3", "1", "0"):
-        monkeypatch.setenv("KRYST_SPMV_COMPRESS", comp)
-        assert np.array_equal(a.spmv(x), want), comp
-        assert np.array_equal(to_dev(ctx, ao).spmv(x), want), comp             # host-built operator: same encodings found by kryst_csr_create
-    monkeypatch.delenv("KRYST_SPMV_COMPRESS")
+    for comp, dia, name in (("3", "1", "csr-dia"), ("1", "1", "csr-dia"), ("1", "0", "csr-d8"), ("0", "1", "csr")):
+        monkeypatch.setenv("KRYST_SPMV_COMPRESS", comp); monkeypatch.setenv("KRYST_SPMV_DIA", dia)
+        assert a.encoding()[0] == name
+        assert np.array_equal(a.spmv(x), want), (comp, dia)
+        h = to_dev(ctx, ao)                                                    # host-built operator: same encodings found by kryst_csr_create
+        assert h.encoding()[0] == name and np.array_equal(h.spmv(x), want), (comp, dia)
+    monkeypatch.delenv("KRYST_SPMV_COMPRESS"); monkeypatch.delenv("KRYST_SPMV_DIA")
     b = ao.spmv(np.ones(ao.nrows))
     atol = 1e-9 * float(np.linalg.norm(b))                                     # BiCGStab's tolerance is absolute (bicgstab.rs)
     for name, mk, pc_k, pc_o, kw in (("cg", lambda: K.CgSolver(1e-9, 400), None, None, dict(tol=1e-9, max_iters=400)),

@@ -22,6 +22,7 @@ def _build_shim():
 @pytest.mark.gpu
 @pytest.mark.parametrize("P,N,kind,hostgen", [(2, 12, "poisson", "0"), (3, 12, "convdiff", "0"), (2, 10, "aniso", "1"), (4, 16, "poisson", "1"),
                                                  (3, 2500, "random", "0"), (4, 1031, "random", "0"),
+                                                 (2, 12, "varcoef", "0"), (3, 10, "varcoef", "1"),     # CSR-DIA with halo diagonals (device generator / host path)
                                                  (2, 20, "aniso", "0+quad")])      # "+quad": every rank's block factor through the 16 x 16 wavefront kernel
 def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     from oracle import oracle as O
