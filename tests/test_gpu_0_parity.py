@@ -147,7 +147,7 @@ def test_spmv_diagonal_streams_form_bit_exact(ctx, monkeypatch):
         return O.Csr(n, n, m.indptr, m.indices, m.data)
 
     yes = [banded(1, [0]), banded(700, [0]), banded(2000, [-1, 0, 1]), banded(5000, [-70, -1, 0, 1, 70]), O.stencil7(21, "varcoef"), O.stencil7(33, "poisson"),
-           banded(3000, [-900, -30, -1, 0, 1, 30, 900], keep=0.93),                               # randomly missing couplings
+           banded(3000, [-300, -30, -1, 0, 1, 30, 300], keep=0.97),                               # randomly missing couplings
            banded(4099, [-1200, -35, -34, -1, 0, 1, 34, 35, 1200]), banded(2500, list(range(-5, 6))), banded(3333, list(range(-8, 8)))]
     for a in yes:
         d = to_dev(ctx, a)
@@ -621,6 +621,64 @@ def test_device_side_grid_setup_equals_host_setup(ctx, seed, monkeypatch):
     m = m.tocsr(); m.eliminate_zeros()
     m = m.tolil()
     m[1, 1] = 0.25                                                             # row 1: u_11 = 0.25 - (-1/4)(-1) = 0
+    m = m.tocsr(); m.sort_indices()
+    d = to_dev(ctx, O.Csr(n, n, m.indptr, m.indices, m.data))
+    for dev in ("1", "0"):
+        monkeypatch.setenv("KRYST_ILU_DEVICE_SETUP", dev)
+        with pytest.raises(K.KError) as e:
+            K.TrueIlu0().setup(d)
+        assert e.value.code == 5 and e.value.row == 1, dev
+
+
+def test_device_side_general_factorisation_equals_host_and_oracle(ctx, monkeypatch):
+    """True ILU(0) of operators that are NOT 7-point boxes is eliminated on the device too (ilu0_ikj_syncfree_kernel: one lane per row,
+    rows concurrent along the dependency graph, the host loop's operations in the host loop's order); KRYST_ILU_DEVICE_SETUP=0 keeps
+    the sequential host loop.  Both give the oracle's bits on random sparse operators (unsymmetric patterns, long and empty lower
+    parts, deep and shallow dependency graphs, a band matrix that only looks like a grid), name the same zero-pivot row, and a
+    starved poll budget falls back to the host loop without changing a bit."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(2024)
+
+    def rand_op(n, per_row, band=None):
+        rows = np.repeat(np.arange(n), per_row)
+        if band:
+            cols = np.clip(rows + rng.integers(-band, band + 1, len(rows)), 0, n - 1)
+        else:
+            cols = rng.integers(0, n, len(rows))
+        m = sp.csr_matrix((rng.uniform(-1.0, 1.0, len(rows)), (rows, cols)), shape=(n, n))
+        m.sum_duplicates()
+        m = m - sp.diags(m.diagonal()) + sp.diags(np.asarray(abs(m).sum(axis=1)).ravel() + 1.0 + rng.random(n))
+        m = m.tocsr(); m.sort_indices()
+        return O.Csr(n, n, m.indptr, m.indices, m.data)
+
+    n_w = 6 * 5 * 4
+    offs = [o for o in (-30, -6, -1, 0, 1, 6, 30)]
+    wrap = sp.diags([(-1.0 if o else 7.0) * np.ones(n_w - abs(o)) for o in offs], offs).tocsr(); wrap.sort_indices()
+    cases = [rand_op(50, 3), rand_op(3000, 6), rand_op(20000, 9, band=40), rand_op(7000, 25, band=300), rand_op(1500, 2),
+             O.Csr(n_w, n_w, wrap.indptr, wrap.indices, wrap.data), O.Csr.from_dense(O.tridiag(900, -1.0, 2.5, -0.5), keep_zeros=False)]
+    for a in cases:
+        d = to_dev(ctx, a)
+        ref = O.Pc.ilu0_true(a)
+        r = rng.standard_normal(a.nrows)
+        want = ref.apply(r)
+        for dev, budget in (("1", None), ("0", None), ("1", "1")):
+            monkeypatch.setenv("KRYST_ILU_DEVICE_SETUP", dev)
+            if budget:
+                monkeypatch.setenv("KRYST_ILU_SETUP_POLL_BUDGET", budget)                      # gives up at once -> host loop
+            else:
+                monkeypatch.delenv("KRYST_ILU_SETUP_POLL_BUDGET", raising=False)
+            assert np.array_equal(K.TrueIlu0().setup(d).apply(r), want), (a.nrows, a.nnz, dev, budget)
+    monkeypatch.delenv("KRYST_ILU_SETUP_POLL_BUDGET", raising=False)
+    # zero pivot: u_11 = 1 - 1 * 1 = 0 is met when row 2 eliminates with row 1; rows beyond it must not change which row is named
+    n = 40
+    m = sp.lil_matrix((n, n))
+    for i in range(n):
+        m[i, i] = 4.0
+        if i > 0:
+            m[i, i - 1] = 1.0
+        if i + 1 < n:
+            m[i, i + 1] = 1.0
+    m[0, 0] = 1.0; m[0, 1] = 1.0; m[1, 0] = 1.0; m[1, 1] = 1.0
     m = m.tocsr(); m.sort_indices()
     d = to_dev(ctx, O.Csr(n, n, m.indptr, m.indices, m.data))
     for dev in ("1", "0"):
