@@ -1040,12 +1040,13 @@ static int32_t grid_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Device-side IKJ factorisation of a GENERAL sparse operator (true ILU(0) on A's pattern; the pointwise kryst-compat / Ilup(0)
-// quotients need no elimination and stay parallel host loops).  Row i is eliminated by ONE lane, its lower entries in stored
-// order and each pivot row's entries in stored order -- the host loop below (and the oracle's), operation for operation, so the
-// factor is bit-identical -- and rows run concurrently as far as the dependency graph allows: a lane polls the "row c is final"
-// flag of the pivot row it needs next, eliminates with it when it is, and moves on; lanes never block each other (one poll per
-// round, like tri_syncfree_*), pivot rows have smaller indices and workgroups start in index order, so the lowest unfinished
-// workgroup only waits for finished ones.  A poll budget turns a scheduling surprise into a clean fallback to the host loop.
+// quotients need no elimination and stay parallel host loops).  ONE WAVE PER ROW: the row's entries sit in LDS, its lower entries
+// are taken in stored order, and for each the pivot row's entries are spread over the lanes -- lane t looks its column up in the
+// row and subtracts there (a pivot row's columns are distinct, so no two lanes touch one entry; each entry receives its updates in
+// pivot order: the host loop's operations in the host loop's order, bit for bit).  Rows run concurrently as far as the dependency
+// graph allows: the wave polls the "row c is final" flag of the pivot row it needs next.  Pivot rows have smaller indices and
+// workgroups start in index order, so the lowest unfinished workgroup only waits for finished ones; a poll budget turns a
+// scheduling surprise into a clean fallback to the host loop.  Rows longer than 64 entries: host loop.
 __global__ __launch_bounds__(256) void ilu0_dpos_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, int32_t n, int32_t* dpos, int32_t* rowdone) {
     const int32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1053,63 +1054,67 @@ __global__ __launch_bounds__(256) void ilu0_dpos_kernel(const int32_t* __restric
     for (int32_t k = rp[i]; k < rp[i + 1]; ++k) if (col[k] == i) d = k;
     dpos[i] = d; rowdone[i] = 0;
 }
-__global__ __launch_bounds__(256) void ilu0_ikj_syncfree_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, double* w,
-                                                                const int32_t* __restrict__ dpos, int32_t n, int32_t* rowdone,
-                                                                unsigned long long* first_bad, int32_t* stalled, int budget0) {
-    const int32_t i = blockIdx.x * 256 + threadIdx.x;
-    const bool active = i < n;
-    const int32_t kbeg = active ? rp[i] : 0, kend = active ? rp[i + 1] : 0;
-    int32_t k = kbeg;
-    bool fin = !active;
-    for (int budget = budget0; budget > 0; --budget) {
-        if (!fin) {
-            while (k < kend && col[k] >= n) ++k;                       // halo columns (another rank's rows) are not part of this block
-            if (k >= kend || col[k] >= i) {
-                __threadfence();                                       // this row's values before its flag (agent scope)
-                __hip_atomic_store(&rowdone[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                fin = true;
-            } else {
-                const int32_t c = col[k];
-                if (__hip_atomic_load(&rowdone[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                    __threadfence();
-                    const int32_t kd = dpos[c];
-                    const double pivot = kd >= 0 ? __hip_atomic_load(&w[kd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-                    if (kd < 0 || pivot == 0.0) {
-                        // the sequential loop stops at the first (row, entry) that meets a zero pivot and names the PIVOT row
-                        atomicMin(first_bad, ((unsigned long long)(unsigned)i << 32) | (unsigned)c);
-                        __threadfence();
-                        __hip_atomic_store(&rowdone[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nobody must wait for this row)
-                        fin = true;
-                    } else {
-                        const double lik = w[k] / pivot;
-                        w[k] = lik;
-                        for (int32_t kk = rp[c]; kk < rp[c + 1]; ++kk) {
-                            const int32_t j = col[kk];
-                            if (j <= c || j >= n) continue;
-                            for (int32_t p = kbeg; p < kend; ++p)
-                                if (col[p] == j) { w[p] = w[p] - lik * __hip_atomic_load(&w[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                        }
-                        ++k;
-                    }
-                }
+__global__ __launch_bounds__(256) void ilu0_ikj_wave_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, double* w,
+                                                            const int32_t* __restrict__ dpos, int32_t n, int32_t* rowdone,
+                                                            unsigned long long* first_bad, int32_t* stalled, int budget0) {
+    __shared__ int32_t lcol_all[4 * 64];
+    __shared__ double lw_all[4 * 64];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+    const int32_t i = blockIdx.x * 4 + wv;
+    if (i >= n) return;                                                    // (uniform over the wave; no workgroup barrier anywhere)
+    int32_t* const lcol = lcol_all + 64 * wv;
+    double* const lw = lw_all + 64 * wv;
+    const int32_t kbeg = rp[i], len = rp[i + 1] - kbeg;                    // len <= 64 (checked on the host)
+    lcol[l] = l < len ? col[kbeg + l] : 0x7fffffff;
+    lw[l] = l < len ? w[kbeg + l] : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = 0; e < len; ++e) {
+        const int32_t c = lcol[e];                                         // (the same word for every lane)
+        if (c >= n) continue;                                              // halo column (another rank's row): not part of this block
+        if (c >= i) break;
+        int budget = budget0;
+        while (__hip_atomic_load(&rowdone[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            if (--budget <= 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (budget <= 0) { if (l == 0) __hip_atomic_store(stalled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // the host loop takes over
+        __threadfence();
+        const int32_t kd = dpos[c];
+        const double pivot = kd >= 0 ? __hip_atomic_load(&w[kd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        if (kd < 0 || pivot == 0.0) {
+            // the sequential loop stops at the first (row, entry) that meets a zero pivot and names the PIVOT row
+            if (l == 0) atomicMin(first_bad, ((unsigned long long)(unsigned)i << 32) | (unsigned)c);
+            break;
+        }
+        const double lik = lw[e] / pivot;
+        __builtin_amdgcn_wave_barrier();                                   // (every lane has read lw[e] before lane 0 replaces it)
+        if (l == 0) lw[e] = lik;
+        const int32_t cb = rp[c], clen = rp[c + 1] - cb;
+        for (int32_t o = 0; o < clen; o += 64) {
+            const bool has = o + l < clen;
+            const int32_t j = has ? col[cb + o + l] : -1;
+            const double wc = has ? __hip_atomic_load(&w[cb + o + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            if (j > c && j < n) {
+                for (int p = 0; p < len; ++p)
+                    if (lcol[p] == j) { lw[p] = lw[p] - lik * wc; break; }
             }
         }
-        if (__all(fin)) return;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (!fin) {                                                        // out of patience: the host loop takes over
-        __hip_atomic_store(stalled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&rowdone[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (l < len) w[kbeg + l] = lw[l];
+    __threadfence();                                                       // this row's values before its flag (agent scope)
+    __builtin_amdgcn_wave_barrier();
+    if (l == 0) __hip_atomic_store(&rowdone[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (also after a failure: nobody must wait for this row)
 }
 
 // w <- the true ILU(0) factor values on A's pattern, computed on the device and copied to the host vector `w` (which holds A's
 // values on entry).  *used = false when the device path did not run to completion (the caller then runs the host loop).
-static int32_t ikj_on_device(kryst_csr_t a, std::vector<double>& w, bool* used, int64_t* bad_row) {
+static int32_t ikj_on_device(kryst_csr_t a, const std::vector<int64_t>& rp, std::vector<double>& w, bool* used, int64_t* bad_row) {
     *used = false; *bad_row = -1;
     kryst_ctx_t ctx = a->ctx;
     const int64_t n = a->nrows, nnz = a->nnz;
-    if (n == 0 || nnz == 0 || n >= (1ll << 31) || env_i("KRYST_ILU_DEVICE_SETUP", 1) == 0) return KRYST_OK;
+    if (n == 0 || nnz == 0 || n >= (1ll << 31) - 4 || env_i("KRYST_ILU_DEVICE_SETUP", 1) == 0) return KRYST_OK;
+    for (int64_t i = 0; i < n; ++i) if (rp[i + 1] - rp[i] > 64) return KRYST_OK;       // (a row must fit one wave's LDS slice)
     struct Tmp { double* w = nullptr; int32_t* dpos = nullptr; int32_t* done = nullptr; unsigned long long* bad = nullptr;
                  ~Tmp() { (void)hipFree(w); (void)hipFree(dpos); (void)hipFree(done); (void)hipFree(bad); } } t;
     if (hipMalloc(&t.w, sizeof(double) * (size_t)nnz) != hipSuccess || hipMalloc(&t.dpos, sizeof(int32_t) * (size_t)n) != hipSuccess ||
@@ -1119,8 +1124,8 @@ static int32_t ikj_on_device(kryst_csr_t a, std::vector<double>& w, bool* used, 
     KR_HIP(hipMemsetAsync(t.bad + 1, 0, 8, ctx->s_main));
     const unsigned g = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(ilu0_dpos_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, (int32_t)n, t.dpos, t.done);
-    hipLaunchKernelGGL(ilu0_ikj_syncfree_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dpos, (int32_t)n, t.done,
-                       t.bad, reinterpret_cast<int32_t*>(t.bad + 1), std::max(1, env_i("KRYST_ILU_SETUP_POLL_BUDGET", 1 << 24)));
+    hipLaunchKernelGGL(ilu0_ikj_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dpos, (int32_t)n, t.done,
+                       t.bad, reinterpret_cast<int32_t*>(t.bad + 1), std::max(1, env_i("KRYST_ILU_SETUP_POLL_BUDGET", 1 << 22)));
     KR_HIP(hipGetLastError());
     unsigned long long flags[2] = {0, 0};
     KR_HIP(hipMemcpyAsync(flags, t.bad, 16, hipMemcpyDeviceToHost, ctx->s_main));
@@ -1167,7 +1172,7 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
     bool on_device = false;
     if (mode == KRYST_ILU_TRUE_ILU0) {                // IKJ restricted to the pattern: on the device (one lane per row, rows concurrent
         int64_t bad = -1;                             // along the dependency graph), same operations in the same order as the loop below
-        KR_TRY(ikj_on_device(a, w, &on_device, &bad));
+        KR_TRY(ikj_on_device(a, rp, w, &on_device, &bad));
         if (on_device && bad >= 0) { set_error("ILU(0): zero pivot at row %lld", (long long)bad); set_error_row(bad); return KRYST_ZERO_PIVOT; }
         if (verbose && on_device) { fprintf(stderr, "[kryst ilu] device-side IKJ factorisation %.0f ms\n", ms_since(t_phase)); t_phase = now(); }
     }
@@ -1189,7 +1194,7 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
             }
             for (int64_t k = rp[i]; k < rp[i + 1]; ++k) if (col[k] < n) pos[col[k]] = -1;
         }
-    } else {
+    } else if (mode != KRYST_ILU_TRUE_ILU0) {
         // ilu.rs:76-80 / ilup.rs:104-111: l_ij = a_ij / a_jj for stored nonzeros below the diagonal; U = triu(A)
         std::atomic<long long> bad{-1};                                    // lowest row whose pivot is zero (the reference stops at the first)
         par_rows(n, [&](int64_t lo, int64_t hi) {

@@ -654,7 +654,7 @@ def test_device_side_general_factorisation_equals_host_and_oracle(ctx, monkeypat
     n_w = 6 * 5 * 4
     offs = [o for o in (-30, -6, -1, 0, 1, 6, 30)]
     wrap = sp.diags([(-1.0 if o else 7.0) * np.ones(n_w - abs(o)) for o in offs], offs).tocsr(); wrap.sort_indices()
-    cases = [rand_op(50, 3), rand_op(3000, 6), rand_op(20000, 9, band=40), rand_op(7000, 25, band=300), rand_op(1500, 2),
+    cases = [rand_op(50, 3), rand_op(3000, 6), rand_op(20000, 9, band=40), rand_op(7000, 25, band=300), rand_op(1500, 2), rand_op(600, 90),          # (rows longer than a wave: host loop)
              O.Csr(n_w, n_w, wrap.indptr, wrap.indices, wrap.data), O.Csr.from_dense(O.tridiag(900, -1.0, 2.5, -0.5), keep_zeros=False)]
     for a in cases:
         d = to_dev(ctx, a)
