@@ -1044,9 +1044,11 @@ static int32_t grid_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out) {
 // are taken in stored order, and for each the pivot row's entries are spread over the lanes -- lane t looks its column up in the
 // row and subtracts there (a pivot row's columns are distinct, so no two lanes touch one entry; each entry receives its updates in
 // pivot order: the host loop's operations in the host loop's order, bit for bit).  Rows run concurrently as far as the dependency
-// graph allows: the wave polls the "row c is final" flag of the pivot row it needs next.  Pivot rows have smaller indices and
-// workgroups start in index order, so the lowest unfinished workgroup only waits for finished ones; a poll budget turns a
-// scheduling surprise into a clean fallback to the host loop.  Rows longer than 64 entries: host loop.
+// graph allows: the wave polls the "row c is final" flag of the pivot row it needs next.  Waves take the rows in DEPENDENCY-LEVEL
+// order (levels of A's lower pattern, computed on the host from the row pointers and columns it has anyway: in natural order the
+// few thousand rows in flight are a thin slice of the graph, 100+ levels deep, and the launch crawls): a pivot row sits at a
+// smaller position, workgroups start in index order, so the lowest unfinished workgroup only waits for finished ones; a poll
+// budget turns a scheduling surprise into a clean fallback to the host loop.  Rows longer than 64 entries: host loop.
 __global__ __launch_bounds__(256) void ilu0_dpos_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, int32_t n, int32_t* dpos, int32_t* rowdone) {
     const int32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1055,13 +1057,14 @@ __global__ __launch_bounds__(256) void ilu0_dpos_kernel(const int32_t* __restric
     dpos[i] = d; rowdone[i] = 0;
 }
 __global__ __launch_bounds__(256) void ilu0_ikj_wave_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, double* w,
-                                                            const int32_t* __restrict__ dpos, int32_t n, int32_t* rowdone,
+                                                            const int32_t* __restrict__ dpos, const int32_t* __restrict__ order, int32_t n, int32_t* rowdone,
                                                             unsigned long long* first_bad, int32_t* stalled, int budget0) {
     __shared__ int32_t lcol_all[4 * 64];
     __shared__ double lw_all[4 * 64];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
-    const int32_t i = blockIdx.x * 4 + wv;
-    if (i >= n) return;                                                    // (uniform over the wave; no workgroup barrier anywhere)
+    const int32_t pos = blockIdx.x * 4 + wv;
+    if (pos >= n) return;                                                  // (uniform over the wave; no workgroup barrier anywhere)
+    const int32_t i = order[pos];                                          // rows in dependency-level order: a pivot row sits at a smaller position
     int32_t* const lcol = lcol_all + 64 * wv;
     double* const lw = lw_all + 64 * wv;
     const int32_t kbeg = rp[i], len = rp[i + 1] - kbeg;                    // len <= 64 (checked on the host)
@@ -1109,22 +1112,39 @@ __global__ __launch_bounds__(256) void ilu0_ikj_wave_kernel(const int32_t* __res
 
 // w <- the true ILU(0) factor values on A's pattern, computed on the device and copied to the host vector `w` (which holds A's
 // values on entry).  *used = false when the device path did not run to completion (the caller then runs the host loop).
-static int32_t ikj_on_device(kryst_csr_t a, const std::vector<int64_t>& rp, std::vector<double>& w, bool* used, int64_t* bad_row) {
+static int32_t ikj_on_device(kryst_csr_t a, const std::vector<int64_t>& rp, const std::vector<int32_t>& col, std::vector<double>& w, bool* used, int64_t* bad_row) {
     *used = false; *bad_row = -1;
     kryst_ctx_t ctx = a->ctx;
     const int64_t n = a->nrows, nnz = a->nnz;
     if (n == 0 || nnz == 0 || n >= (1ll << 31) - 4 || env_i("KRYST_ILU_DEVICE_SETUP", 1) == 0) return KRYST_OK;
     for (int64_t i = 0; i < n; ++i) if (rp[i + 1] - rp[i] > 64) return KRYST_OK;       // (a row must fit one wave's LDS slice)
-    struct Tmp { double* w = nullptr; int32_t* dpos = nullptr; int32_t* done = nullptr; unsigned long long* bad = nullptr;
-                 ~Tmp() { (void)hipFree(w); (void)hipFree(dpos); (void)hipFree(done); (void)hipFree(bad); } } t;
+    // dependency levels of the lower pattern (local columns below the diagonal), rows ordered by (level, row)
+    std::vector<int32_t> order((size_t)n);
+    {
+        std::vector<int32_t> lvl((size_t)n, 0), cnt;
+        int32_t nl = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            int32_t lv = 0;
+            for (int64_t k = rp[i]; k < rp[i + 1]; ++k) { const int32_t c = col[k]; if (c < i) lv = std::max(lv, lvl[c] + 1); }   // (halo columns are >= n > i)
+            lvl[i] = lv; nl = std::max(nl, lv + 1);
+        }
+        cnt.assign((size_t)nl + 1, 0);
+        for (int64_t i = 0; i < n; ++i) cnt[lvl[i] + 1]++;
+        for (int32_t q = 0; q < nl; ++q) cnt[q + 1] += cnt[q];
+        for (int64_t i = 0; i < n; ++i) order[cnt[lvl[i]]++] = (int32_t)i;
+    }
+    struct Tmp { double* w = nullptr; int32_t* dpos = nullptr; int32_t* done = nullptr; int32_t* order = nullptr; unsigned long long* bad = nullptr;
+                 ~Tmp() { (void)hipFree(w); (void)hipFree(dpos); (void)hipFree(done); (void)hipFree(order); (void)hipFree(bad); } } t;
     if (hipMalloc(&t.w, sizeof(double) * (size_t)nnz) != hipSuccess || hipMalloc(&t.dpos, sizeof(int32_t) * (size_t)n) != hipSuccess ||
-        hipMalloc(&t.done, sizeof(int32_t) * (size_t)n) != hipSuccess || hipMalloc(&t.bad, 16) != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }
+        hipMalloc(&t.done, sizeof(int32_t) * (size_t)n) != hipSuccess || hipMalloc(&t.order, sizeof(int32_t) * (size_t)n) != hipSuccess ||
+        hipMalloc(&t.bad, 16) != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }
+    KR_HIP(hipMemcpyAsync(t.order, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->s_main));
     KR_HIP(hipMemcpyAsync(t.w, a->d_val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, ctx->s_main));
     KR_HIP(hipMemsetAsync(t.bad, 0xff, 8, ctx->s_main));
     KR_HIP(hipMemsetAsync(t.bad + 1, 0, 8, ctx->s_main));
     const unsigned g = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(ilu0_dpos_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, (int32_t)n, t.dpos, t.done);
-    hipLaunchKernelGGL(ilu0_ikj_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dpos, (int32_t)n, t.done,
+    hipLaunchKernelGGL(ilu0_ikj_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dpos, t.order, (int32_t)n, t.done,
                        t.bad, reinterpret_cast<int32_t*>(t.bad + 1), std::max(1, env_i("KRYST_ILU_SETUP_POLL_BUDGET", 1 << 22)));
     KR_HIP(hipGetLastError());
     unsigned long long flags[2] = {0, 0};
@@ -1172,7 +1192,7 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
     bool on_device = false;
     if (mode == KRYST_ILU_TRUE_ILU0) {                // IKJ restricted to the pattern: on the device (one lane per row, rows concurrent
         int64_t bad = -1;                             // along the dependency graph), same operations in the same order as the loop below
-        KR_TRY(ikj_on_device(a, rp, w, &on_device, &bad));
+        KR_TRY(ikj_on_device(a, rp, col, w, &on_device, &bad));
         if (on_device && bad >= 0) { set_error("ILU(0): zero pivot at row %lld", (long long)bad); set_error_row(bad); return KRYST_ZERO_PIVOT; }
         if (verbose && on_device) { fprintf(stderr, "[kryst ilu] device-side IKJ factorisation %.0f ms\n", ms_since(t_phase)); t_phase = now(); }
     }
