@@ -210,14 +210,38 @@ __global__ __launch_bounds__(256) void tri_syncfree_csr_kernel(const TriArgs* ar
     int32_t k = 0, kend = 0; double s = 0.0, dg = 1.0;
     if (active) { k = ptr[p]; kend = ptr[p + 1]; s = in[p]; if (!FORWARD) dg = diag[p]; }
     bool done = !active;
+    // While a row waits it polls ONE entry: the dependency at the largest level-order position, i.e. of the deepest level -- the
+    // last one to be solved in all but rare cases (eight uncached loads per waiting lane and round slowed everybody down: 20 -> 40 ms
+    // on a 27-point factor).  Once that one is there, the batches below usually find everything ready.
+    int32_t gate_col = -1;
+    for (int32_t kk = k; kk < kend; ++kk) gate_col = max(gate_col, col[kk]);
+    bool open = gate_col < 0;
     for (int budget = 1 << 22; budget > 0; --budget) {
-        if (!done) {
-            while (k < kend) {
-                const double x = __hip_atomic_load(&out[col[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned long long)__double_as_longlong(x) == KR_TRI_SENTINEL) break;
-                s = s - val[k] * x;                                                        // stored order
-                ++k;
+        if (!done && !open) {
+            const double g = __hip_atomic_load(&out[gate_col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            open = (unsigned long long)__double_as_longlong(g) != KR_TRI_SENTINEL;
+        }
+        if (!done && open) {
+            // the next (up to) eight dependencies are asked for TOGETHER -- one uncached round trip (~1.5 us) for the batch instead
+            // of one per entry: a 27-point factor's 13 entries per row cost 15 us per dependency level when polled one by one --
+            // and the ready prefix is consumed in stored order
+            constexpr int B = 8;
+            double xv[B], vv[B];
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                const int32_t kk = min(k + u, kend - 1);
+                vv[u] = k < kend ? val[kk] : 0.0;
+                xv[u] = k < kend ? __hip_atomic_load(&out[col[kk]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
             }
+            bool prefix = true;
+            int adv = 0;
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                const bool ready = (unsigned long long)__double_as_longlong(xv[u]) != KR_TRI_SENTINEL;
+                prefix = prefix && k + u < kend && ready;
+                if (prefix) { s = s - vv[u] * xv[u]; ++adv; }                              // stored order
+            }
+            k += adv;
             if (k == kend) {
                 __hip_atomic_store(&out[p], FORWARD ? s : s / dg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 done = true;
@@ -1081,7 +1105,9 @@ __global__ __launch_bounds__(256) void ilu0_ikj_wave_kernel(const int32_t* __res
             __builtin_amdgcn_s_sleep(1);
         }
         if (budget <= 0) { if (l == 0) __hip_atomic_store(stalled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // the host loop takes over
-        __threadfence();
+        // (no acquire fence: everything another wave has written -- pivot and pivot row -- is read with agent-scope loads below;
+        // an agent-scope fence writes back / invalidates the whole L2 on this chip, and thirteen of them per row made the launch
+        // 190 ms instead of a few)
         const int32_t kd = dpos[c];
         const double pivot = kd >= 0 ? __hip_atomic_load(&w[kd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         if (kd < 0 || pivot == 0.0) {
@@ -1104,9 +1130,10 @@ __global__ __launch_bounds__(256) void ilu0_ikj_wave_kernel(const int32_t* __res
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (l < len) w[kbeg + l] = lw[l];
-    __threadfence();                                                       // this row's values before its flag (agent scope)
-    __builtin_amdgcn_wave_barrier();
+    // this row's values before its flag: write-through (agent-scope) stores, waited for, then the flag -- no L2-wide release fence
+    if (l < len) __hip_atomic_store(&w[kbeg + l], lw[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the stores have been acknowledged (a workgroup-scope release fence
+    __builtin_amdgcn_wave_barrier();                                       // does not wait for vector stores on this target: the flag overtook them)
     if (l == 0) __hip_atomic_store(&rowdone[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (also after a failure: nobody must wait for this row)
 }
 
@@ -1118,6 +1145,10 @@ static int32_t ikj_on_device(kryst_csr_t a, const std::vector<int64_t>& rp, cons
     const int64_t n = a->nrows, nnz = a->nnz;
     if (n == 0 || nnz == 0 || n >= (1ll << 31) - 4 || env_i("KRYST_ILU_DEVICE_SETUP", 1) == 0) return KRYST_OK;
     for (int64_t i = 0; i < n; ++i) if (rp[i + 1] - rp[i] > 64) return KRYST_OK;       // (a row must fit one wave's LDS slice)
+    const bool verbose = getenv("KRYST_ILU_VERBOSE") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = tnow();
+    auto lap = [&](const char* what) { if (verbose) { fprintf(stderr, "[kryst ilu]   ikj: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(tnow() - t0).count()); t0 = tnow(); } };
     // dependency levels of the lower pattern (local columns below the diagonal), rows ordered by (level, row)
     std::vector<int32_t> order((size_t)n);
     {
@@ -1133,6 +1164,7 @@ static int32_t ikj_on_device(kryst_csr_t a, const std::vector<int64_t>& rp, cons
         for (int32_t q = 0; q < nl; ++q) cnt[q + 1] += cnt[q];
         for (int64_t i = 0; i < n; ++i) order[cnt[lvl[i]]++] = (int32_t)i;
     }
+    lap("levels on the host");
     struct Tmp { double* w = nullptr; int32_t* dpos = nullptr; int32_t* done = nullptr; int32_t* order = nullptr; unsigned long long* bad = nullptr;
                  ~Tmp() { (void)hipFree(w); (void)hipFree(dpos); (void)hipFree(done); (void)hipFree(order); (void)hipFree(bad); } } t;
     if (hipMalloc(&t.w, sizeof(double) * (size_t)nnz) != hipSuccess || hipMalloc(&t.dpos, sizeof(int32_t) * (size_t)n) != hipSuccess ||
@@ -1150,10 +1182,12 @@ static int32_t ikj_on_device(kryst_csr_t a, const std::vector<int64_t>& rp, cons
     unsigned long long flags[2] = {0, 0};
     KR_HIP(hipMemcpyAsync(flags, t.bad, 16, hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
+    lap("allocations, uploads, kernels");
     if ((int32_t)flags[1] != 0) return KRYST_OK;                       // stalled: host loop
     if (flags[0] != ~0ull) { *bad_row = (int64_t)(flags[0] & 0xffffffffull); *used = true; return KRYST_OK; }
     KR_HIP(hipMemcpyAsync(w.data(), t.w, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
+    lap("factor values to the host");
     *used = true;
     return KRYST_OK;
 }
