@@ -73,6 +73,12 @@ int32_t kryst_ctx_synchronize(kryst_ctx_t ctx);                    /* hipStreamS
 int32_t kryst_ctx_rank(kryst_ctx_t ctx, int32_t* rank, int32_t* nranks);   /* Comm::rank / Comm::size */
 int32_t kryst_comm_barrier(kryst_ctx_t ctx);                       /* Comm::barrier, mpi_comm.rs:67 */
 int32_t kryst_comm_all_reduce(kryst_ctx_t ctx, double x, double* out);     /* Comm::all_reduce, mpi_comm.rs:116-121 */
+/* How the solvers' inner products cross the ranks (DistributedInnerProduct, core/wrappers.rs:134-156): mode 0 = RCCL all-gather +
+ * rank-ordered fold (default), 1 = hipIpc-mapped mailboxes written and polled by the kernel that finishes the local fold (one
+ * launch, no collective; the same bits).  COLLECTIVE over the context's ranks, no solve open.  Mode 1 returns KRYST_UNSUPPORTED --
+ * on every rank, which all stay on RCCL -- when a mailbox cannot be exported or mapped.  *active (may be NULL): mode in use.
+ * KRYST_SCALAR_REDUCE=ipc selects mode 1 at kryst_ctx_create_dist. */
+int32_t kryst_ctx_scalar_reduce(kryst_ctx_t ctx, int32_t mode, int32_t* active);
 /* measurement only: per-phase device time of the work enqueued between begin and end (hipEvents recorded on the compute stream
  * after each phase: time between two marks is charged to the later one).  ms[p] for p < kryst_phase_count(): "spmv" (tiles
  * without halo columns; single rank: the whole SpMV), "halo_wait" (compute stream waiting for the neighbour planes),

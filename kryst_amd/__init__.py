@@ -79,6 +79,15 @@ class Context:
         check(lib().kryst_comm_all_reduce(self.h, float(x), C.byref(out)))
         return out.value
 
+    def scalar_reduce(self, mode):
+        """'rccl' | 'ipc': how the solvers' inner products cross the ranks (kryst_ctx_scalar_reduce; collective).  Returns the mode in
+        use afterwards ('ipc' falls back to 'rccl' on every rank when a mailbox cannot be mapped)."""
+        active = C.c_int32(0)
+        rc = lib().kryst_ctx_scalar_reduce(self.h, {"rccl": 0, "ipc": 1}[mode], C.byref(active))
+        if rc not in (0, 6):
+            check(rc)
+        return "ipc" if active.value else "rccl"
+
     def synchronize(self):
         check(lib().kryst_ctx_synchronize(self.h))
 

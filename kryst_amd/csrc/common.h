@@ -94,6 +94,15 @@ struct kryst_ctx_s {
     // The scalar state of a solve (DevState, reduction results, progress record) lives in per-context scratch, so ONE solve
     // or stepping session may be open per context at a time: a second one is refused with KRYST_ERR_BUSY (kryst_hip.h).
     const void* active_ws = nullptr;
+    // Scalar all-reduce without a collective launch (dist.cpp: ipc_reduce_*): every rank owns a fine-grained mailbox that the
+    // others map through hipIpc; the kernel that finishes a rank's local fold stores its partials into every peer's mailbox
+    // (system-scope write-through stores, epoch stamp last), polls its own mailbox for the peers' stamps and folds in rank order --
+    // the same bits as the RCCL all-gather + ordered fold, one launch instead of two launches and a collective.
+    double* ipc_mine = nullptr;                  // 2 parities x nranks cells of 16 doubles: [parity][writer rank]{q0..q7, epoch, pad}
+    double** d_ipc_peers = nullptr;              // device array: peer p's mailbox as mapped into this process (own entry: ipc_mine)
+    std::vector<void*> ipc_opened;               // mappings to close
+    unsigned long long* d_ipc_epoch = nullptr;   // reductions completed so far (device)
+    bool ipc_on = false;                         // reduce_then uses the mailbox path
     kr::PhaseTimer* phase = nullptr;     // non-null while kryst_phase_timing is on
     int num_cu = 256;
 };
@@ -193,9 +202,9 @@ __device__ __forceinline__ void block_reduce_any(double (&v)[NQ], double* lds) {
 //            64-lane butterfly, serial fold over the 16 waves -> chunk value c;
 //   stage 2  (only when nchunks > 1) the workgroup that finishes LAST folds the chunk values: thread t folds chunks
 //            t, t+KR_F, ... in ascending order, butterfly, serial over waves.
-// The association tree depends only on ntiles, never on which workgroup happens to be last.  Hand-off: relaxed
-// agent-scope stores of the chunk values, agent release fence, ticket atomic; the last workgroup acquires and reads
-// them with agent-scope loads (cdna_hip_programming.md, Guideline 16).  Returns true in the workgroup that holds
+// The association tree depends only on ntiles, never on which workgroup happens to be last.  Hand-off: write-through
+// (agent-scope) stores of the chunk values, waited for, then the ticket atomic; the last workgroup reads them with
+// agent-scope loads (cdna_hip_programming.md, Guideline 16, without the L2-wide fences).  Returns true in the workgroup that holds
 // the final result (valid in every thread of it).
 template <int NQ>
 __device__ __forceinline__ bool fold2(const double* partials, int64_t stride, int64_t ntiles, double* chunks,
@@ -209,13 +218,15 @@ __device__ __forceinline__ bool fold2(const double* partials, int64_t stride, in
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) __hip_atomic_store(&chunks[q * cstride + blockIdx.x], out[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
+        // the chunk values are write-through (agent-scope) stores: once they have been acknowledged they are visible to the agent-scope
+        // loads of the last workgroup.  (An agent-scope FENCE writes back / invalidates the whole L2 on this chip -- measured in
+        // ilu.hip's factorisation kernel: 13 per row made a 14 ms launch 190 ms -- and is not needed on either side.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int t = atomicAdd(ticket, 1u);
         is_last = (t == gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
     if (!is_last) return false;
-    __threadfence();
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         double acc = 0.0;

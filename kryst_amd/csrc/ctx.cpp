@@ -89,6 +89,12 @@ int32_t kryst_ctx_create_dist(int32_t device_id, int32_t rank, int32_t nranks, c
     ctx->device = device_id; ctx->rank = rank; ctx->nranks = nranks;
     int32_t rc = ctx_init(ctx);
     if (rc == KRYST_OK) rc = comm_init(ctx, uid);
+    if (rc == KRYST_OK) {
+        // KRYST_SCALAR_REDUCE=ipc: the mailbox path from the start (all ranks read the same environment); failure to set it up is
+        // not an error -- the RCCL path stays
+        const char* e = getenv("KRYST_SCALAR_REDUCE");
+        if (e && strcmp(e, "ipc") == 0) { const int32_t r2 = ipc_reduce_setup(ctx); if (r2 != KRYST_OK && r2 != KRYST_UNSUPPORTED) rc = r2; }
+    }
     if (rc != KRYST_OK) { kryst_ctx_destroy(ctx); return rc; }      // frees whatever ctx_init / comm_init got as far as creating
     *out = ctx;
     return KRYST_OK;
@@ -140,6 +146,23 @@ int32_t kryst_comm_all_reduce(kryst_ctx_t ctx, double x, double* out) {
     for (int p = 1; p < ctx->nranks; ++p) total = total + ctx->h_pinned[p];   // rank order: same bits on every rank
     *out = total;
     return KRYST_OK;
+}
+
+// How the solvers' inner products cross the ranks: mode 0 = RCCL all-gather + rank-ordered fold (default), 1 = IPC mailboxes
+// (dist.cpp: one launch per inner product, no collective).  COLLECTIVE: every rank of the context calls it with the same mode.
+// KRYST_UNSUPPORTED (mode 1) when some rank cannot export / map a mailbox: every rank then stays on RCCL.  *active: the mode in use.
+int32_t kryst_ctx_scalar_reduce(kryst_ctx_t ctx, int32_t mode, int32_t* active) {
+    KR_ARG(ctx && (mode == 0 || mode == 1), "ctx_scalar_reduce");
+    KR_ARG(ctx->active_ws == nullptr, "ctx_scalar_reduce: a solve or stepping session is open on this context");
+    int32_t rc = KRYST_OK;
+    if (ctx->nranks > 1 || ctx->comm) {
+        KR_HIP(hipSetDevice(ctx->device));
+        KR_TRY(kryst_ctx_synchronize(ctx));
+        if (mode == 1) rc = ipc_reduce_setup(ctx);
+        else ctx->ipc_on = false;                 // (the mailboxes stay mapped: switching back costs nothing)
+    }
+    if (active) *active = ctx->ipc_on ? 1 : 0;
+    return rc;
 }
 
 int32_t kryst_comm_barrier(kryst_ctx_t ctx) {

@@ -72,6 +72,7 @@ int32_t comm_init(kryst_ctx_t ctx, const void* uid128) {
 }
 
 void comm_destroy(kryst_ctx_t ctx) {
+    ipc_reduce_destroy(ctx);
     if (ctx->comm) {
         if (ctx->comm->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm->comm);
         delete ctx->comm;
@@ -104,6 +105,80 @@ int32_t comm_exchange(kryst_ctx_t ctx, const void* send, const int64_t* send_cou
             KR_NCCL(g_rccl.Recv((char*)recv + 8 * recv_off[p], (size_t)recv_counts[p], dt, p, ctx->comm->comm, s));
     }
     KR_NCCL(g_rccl.GroupEnd());
+    return KRYST_OK;
+}
+
+// ---- scalar all-reduce through IPC-mapped mailboxes (replaces the two tiny RCCL all-gathers of a CG iteration: Comm::all_reduce,
+// src/parallel/mpi_comm.rs:116-121 / DistributedInnerProduct, src/core/wrappers.rs:134-156)
+void ipc_reduce_destroy(kryst_ctx_t ctx) {
+    for (void* p : ctx->ipc_opened) (void)hipIpcCloseMemHandle(p);
+    ctx->ipc_opened.clear();
+    (void)hipFree(ctx->ipc_mine); (void)hipFree(ctx->d_ipc_peers); (void)hipFree(ctx->d_ipc_epoch);
+    ctx->ipc_mine = nullptr; ctx->d_ipc_peers = nullptr; ctx->d_ipc_epoch = nullptr; ctx->ipc_on = false;
+    (void)hipGetLastError();
+}
+
+int32_t ipc_reduce_setup(kryst_ctx_t ctx) {
+    if (ctx->ipc_on) return KRYST_OK;
+    KR_ARG(ctx->comm, "ipc_reduce_setup: context has no communicator");
+    const int P = ctx->nranks, me = ctx->rank;
+    KR_ARG(P <= 64, "ipc_reduce_setup: at most 64 ranks (one lane per peer)");
+    const size_t cells = (size_t)2 * P * 16;
+    // phase 1 (local): mailbox in fine-grained device memory (coherent for the peers' system-scope stores), zeroed, and its IPC handle
+    int64_t ok_mine = 1;
+    hipIpcMemHandle_t hmine;
+    memset(&hmine, 0, sizeof hmine);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (hipExtMallocWithFlags((void**)&ctx->ipc_mine, sizeof(double) * cells, hipDeviceMallocFinegrained) != hipSuccess ||
+        hipMemsetAsync(ctx->ipc_mine, 0, sizeof(double) * cells, ctx->s_main) != hipSuccess ||
+        hipMalloc(&ctx->d_ipc_peers, sizeof(double*) * P) != hipSuccess || hipMalloc(&ctx->d_ipc_epoch, 8) != hipSuccess ||
+        hipMemsetAsync(ctx->d_ipc_epoch, 0, 8, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess ||
+        hipIpcGetMemHandle(&hmine, ctx->ipc_mine) != hipSuccess) { (void)hipGetLastError(); ok_mine = 0; }
+    // phase 2 (collective): all-gather {ok, handle} = 9 int64 per rank
+    int64_t send[9]; send[0] = ok_mine; memcpy(send + 1, &hmine, 64);
+    std::vector<int64_t> all((size_t)9 * P, 0);
+    int64_t *d_s = nullptr, *d_r = nullptr;
+    int32_t rc = KRYST_OK;
+    if (hipMalloc(&d_s, sizeof send) != hipSuccess || hipMalloc(&d_r, sizeof(int64_t) * 9 * P) != hipSuccess) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK && (hipMemcpyAsync(d_s, send, sizeof send, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK) rc = comm_all_gather_i64(ctx, d_s, d_r, 9, ctx->s_main);
+    if (rc == KRYST_OK && (hipMemcpyAsync(all.data(), d_r, sizeof(int64_t) * 9 * P, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess ||
+                           hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
+    (void)hipFree(d_s); (void)hipFree(d_r);
+    if (rc != KRYST_OK) { ipc_reduce_destroy(ctx); return rc; }      // (a failing collective fails on every rank)
+    // phase 3 (local): map the peers' mailboxes; phase 4 (collective): everybody mapped everybody?
+    int64_t ok_all = 1;
+    for (int p = 0; p < P; ++p) ok_all = ok_all && all[(size_t)9 * p] == 1;
+    std::vector<double*> peers((size_t)P, nullptr);
+    if (ok_all) {
+        for (int p = 0; p < P && ok_all; ++p) {
+            if (p == me) { peers[p] = ctx->ipc_mine; continue; }
+            hipIpcMemHandle_t h; memcpy(&h, &all[(size_t)9 * p + 1], 64);
+            void* ptr = nullptr;
+            if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok_all = 0; break; }
+            ctx->ipc_opened.push_back(ptr);
+            peers[p] = static_cast<double*>(ptr);
+        }
+        if (ok_all && (hipMemcpyAsync(ctx->d_ipc_peers, peers.data(), sizeof(double*) * P, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess ||
+                       hipStreamSynchronize(ctx->s_main) != hipSuccess)) ok_all = 0;
+    }
+    int64_t *d_s2 = nullptr, *d_r2 = nullptr;
+    std::vector<int64_t> all2((size_t)P, 0);
+    if (hipMalloc(&d_s2, 8) != hipSuccess || hipMalloc(&d_r2, sizeof(int64_t) * P) != hipSuccess) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK && (hipMemcpyAsync(d_s2, &ok_all, 8, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK) rc = comm_all_gather_i64(ctx, d_s2, d_r2, 1, ctx->s_main);
+    if (rc == KRYST_OK && (hipMemcpyAsync(all2.data(), d_r2, sizeof(int64_t) * P, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess ||
+                           hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
+    (void)hipFree(d_s2); (void)hipFree(d_r2);
+    bool everybody = rc == KRYST_OK;
+    for (int p = 0; p < P && everybody; ++p) everybody = all2[p] == 1;
+    if (!everybody) {
+        ipc_reduce_destroy(ctx);
+        if (rc != KRYST_OK) return rc;
+        set_error("ipc scalar all-reduce: a rank could not allocate, export or map a mailbox (hipIpc); the RCCL path stays in use");
+        return KRYST_UNSUPPORTED;
+    }
+    ctx->ipc_on = true;
     return KRYST_OK;
 }
 

@@ -17,6 +17,11 @@ int32_t comm_all_gather_i64(kryst_ctx_t ctx, const int64_t* send, int64_t* recv,
 int32_t comm_exchange(kryst_ctx_t ctx, const void* send, const int64_t* send_counts, const int64_t* send_off,
                       void* recv, const int64_t* recv_counts, const int64_t* recv_off, bool is_double, hipStream_t s);
 
+// Mailbox path of the scalar all-reduce (see kryst_ctx_s): collective over the context's ranks (one all-gather of the IPC
+// handles).  On success ctx->ipc_on is set on EVERY rank, or on none (the outcome is agreed through an all-gather).
+int32_t ipc_reduce_setup(kryst_ctx_t ctx);
+void    ipc_reduce_destroy(kryst_ctx_t ctx);
+
 // Halo plan of a row-partitioned operator (host side; also exported as kryst_host_halo_recv_plan)
 struct HaloPlan {
     int nranks = 1, rank = 0;

@@ -101,12 +101,66 @@ __global__ void rank_fold_logic_kernel(const double* gathered, int nranks, doubl
     logic.run(red_out);
 }
 
+// several ranks, mailbox path (kryst_ctx_s::ipc_*): local two-level fold, exchange and rank-ordered fold + logic in ONE launch.
+// The workgroup that ends up with the local result sends it (lane p -> rank p's mailbox cell [epoch parity][my rank]: the values
+// as system-scope write-through stores, waited for, then the epoch stamp), polls its own mailbox until rank p's stamp carries this
+// epoch, and folds the P cells in rank order (total = r0; total = total + r_p): the bits of the all-gather path.  Two cells per
+// writer (epoch parity) suffice: a rank can be at most one reduction ahead of the slowest one, because finishing reduction e needs
+// everybody's contribution to e.  A peer that never shows up (budget) ends the solve with KRYST_ERR_RCCL instead of a hung GPU.
+struct IpcView { double* mine; double* const* peers; unsigned long long* epoch; int me, P, budget; };
+template <int NQ, class L>
+__global__ __launch_bounds__(KR_F) void fold_ipc_logic_kernel(const double* partials, int64_t stride, int64_t ntiles,
+                                                              double* chunks, int64_t cstride, unsigned int* ticket,
+                                                              double* red_out, L logic, IpcView v) {
+    if (logic.c.st->done && !L::RUN_WHEN_DONE) return;      // the same decision on every rank (identical scalars): nobody sends, nobody waits
+    __shared__ double lds[NQ * (KR_F / 64)];
+    double val[NQ];
+    if (!fold2<NQ>(partials, stride, ntiles, chunks, cstride, ticket, val, lds)) return;
+    if (threadIdx.x >= 64) return;
+    const int p = threadIdx.x;
+    const unsigned long long e = *v.epoch + 1;
+    const int par = (int)(e & 1ull);
+    double* const dst = p < v.P ? v.peers[p] + (size_t)(par * v.P + v.me) * 16 : nullptr;
+    if (p < v.P) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) __hip_atomic_store(dst + q, val[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the values have been acknowledged before the stamp goes out
+    if (p < v.P) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + 8), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    bool ok = true;
+    if (p < v.P) {
+        const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(v.mine + (size_t)(par * v.P + p) * 16 + 8);
+        int b = v.budget;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+            if (--b <= 0) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    const bool all_ok = __all(ok);
+    if (p != 0) return;
+    *v.epoch = e;
+    if (!all_ok) { logic.c.finish(KRYST_ERR_RCCL); return; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double total = __hip_atomic_load(v.mine + (size_t)(par * v.P) * 16 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int r = 1; r < v.P; ++r) total = total + __hip_atomic_load(v.mine + (size_t)(par * v.P + r) * 16 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        red_out[q] = total;
+    }
+    logic.run(red_out);
+}
+
 template <int NQ, class L>
 inline int32_t reduce_then(kryst_ctx_t ctx, int64_t ntiles, double* d_red, const L& logic) {
     if (!use_collectives(ctx)) {
         KR_TRY(ensure_partials(ctx, ntiles > 0 ? ntiles : 1));
         hipLaunchKernelGGL((fold_logic_kernel<NQ, L>), dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main,
                            ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_red, logic);
+    } else if (ctx->ipc_on) {
+        KR_TRY(ensure_partials(ctx, ntiles > 0 ? ntiles : 1));
+        static const int budget = [] { const char* e = getenv("KRYST_IPC_POLL_BUDGET"); return e ? std::max(1, atoi(e)) : (1 << 26); }();
+        const IpcView v{ctx->ipc_mine, ctx->d_ipc_peers, ctx->d_ipc_epoch, ctx->rank, ctx->nranks, budget};
+        hipLaunchKernelGGL((fold_ipc_logic_kernel<NQ, L>), dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main,
+                           ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_red, logic, v);
     } else {
         // local two-level fold -> RCCL all-gather of NQ doubles per rank -> rank-ordered fold + logic in one launch
         double* local = ctx->d_gather + (size_t)ctx->nranks * KR_MAXQ;

@@ -116,6 +116,26 @@ def main():
     st = sess.end()
     out["sess_stats"] = np.array([st.iterations, float(st.converged), st.final_residual])
     out["sess_x"] = x.to_host()
+    # the mailbox path of the scalar all-reduce (kryst_ctx_scalar_reduce: hipIpc-mapped cells written and polled by the kernel that
+    # finishes the local fold): every solver again, bit for bit the results of the RCCL all-gather path above
+    stage(rank, "scalar_reduce ipc")
+    mode = ctx.scalar_reduce("ipc")
+    out["ipc_active"] = np.array([1 if mode == "ipc" else 0])
+    if mode == "ipc":
+        for name, s, pc in runs + extra:
+            stage(rank, "ipc solve " + name)
+            x = ctx.vec(nloc)
+            st = s.solve(a, pc, b, x)
+            assert np.array_equal(x.to_host(), out[name + "_x"]), ("ipc", name)
+            assert np.array_equal(np.array(s.residual_history), out[name + "_hist"]), ("ipc", name)
+            assert (st.iterations, float(st.converged), st.final_residual) == tuple(out[name + "_stats"]), ("ipc", name)
+        stage(rank, "ipc session")
+        x = ctx.vec(nloc)
+        with K.Session("cg", a, None, b, x, tol=0.0, max_iters=25) as sess:
+            sess.step(5); sess.step(20)
+            sess.end()
+        assert np.array_equal(x.to_host(), out["sess_x"]), "ipc session"
+        assert ctx.scalar_reduce("rccl") == "rccl"
     stage(rank, "barrier")
     ctx.barrier()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)

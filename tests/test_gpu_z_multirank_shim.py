@@ -46,6 +46,8 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     assert all(p.returncode == 0 for p in procs), "\n".join(
         f"---- rank {r}: exit code {p.returncode}, log tail ----\n{o[-3000:]}" for r, (p, o) in enumerate(zip(procs, outs)))
     R = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(P)]
+    # the worker repeated every solve on the IPC-mailbox path of the scalar all-reduce and compared it with the RCCL path itself
+    assert all(int(r["ipc_active"][0]) == 1 for r in R), "the hipIpc mailbox path could not be set up between the ranks of this box"
     T, V, F = K.reduce_spec()
     if kind == "random":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
