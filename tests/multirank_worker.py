@@ -124,6 +124,7 @@ def main():
     if mode == "ipc":
         for name, s, pc in runs + extra:
             stage(rank, "ipc solve " + name)
+            s.clear_history()                                   # (residual_history accumulates over solves, like the reference's Vec)
             x = ctx.vec(nloc)
             st = s.solve(a, pc, b, x)
             assert np.array_equal(x.to_host(), out[name + "_x"]), ("ipc", name)
