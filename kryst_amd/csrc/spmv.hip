@@ -128,7 +128,7 @@ __global__ __launch_bounds__(KR_T, MINW) void spmv_wave_kernel(const SpmvArgs a)
                 v[j] = stream_load<NT>(reinterpret_cast<const v2d*>(a.val + k));
             }
 #ifdef KR_TUNING
-            // timing-only ablations (tools/tune_abl.py; wrong results): 1 no x gathers, 2 no LDS products / row sums, 4 no y / dot
+            // timing-only ablations (round-2 study, profiles/r02/plain_csr_study/; wrong results): 1 no x gathers, 2 no LDS products / row sums, 4 no y / dot
             if (a.abl & 1) {
 #pragma unroll
                 for (int j = 0; j < SLOTS; ++j) { xa[j] = (double)c[j].x; xb[j] = (double)c[j].y; }
@@ -706,7 +706,7 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
     args.pid = a->d_pid; args.pmeta = a->d_pmeta; args.poff = a->d_poff; args.pval = a->d_pval; args.npat = a->npat; args.ntab = a->ntab;
     if (a->d_pid && comp_level >= 3 && a->xlen + (HALO ? a->plan.total_recv : 0) < (1ll << 28) && a->nrows < (1ll << 28)) {   // 32-bit byte offsets
         // a workgroup loads the tables once and walks one run of 8 consecutive tiles (next tile's ids prefetched); runs go
-        // round-robin over the XCDs.  Measured at 512^3 (tools/p16_tune5.sh, tools/p16_pmc.sh): 0.70 ms and 1.6 GB of reads
+        // round-robin over the XCDs.  Measured at 512^3 (round-2 sweeps and --pmc passes, profiles/r02/): 0.70 ms and 1.6 GB of reads
         // per launch, against 0.79 ms and 4.1 GB for a strided persistent grid whose fast workgroups run ahead.
         args.group = std::max(1, env_int("KRYST_SPMV_GROUP", 8));
         const int64_t pchunk = (chunk + args.group - 1) / args.group * args.group;      // an XCD's share is a whole number of runs
