@@ -204,7 +204,7 @@ def kernel_name(enc):
             "csr-dia": f"spmv_dia_kernel<1> (CSR-DIA: one 8-byte value stream per diagonal, {npat} diagonals; no row pointers, no column codes)"}[name]
 
 
-def roofline_of(enc, grid, nloc, nnz_loc, ms, world):
+def roofline_of(enc, grid, nloc, nnz_loc, ms, world, traffic_form=None):
     """The kernel that ran, priced at the bytes IT moves."""
     alg = spmv_bytes(nloc, nnz_loc)
     moved = {"csr": alg, "csr-d8": alg - 3 * nnz_loc, "csr-d16": alg - 10 * nnz_loc, "csr-p16": 2 * nloc + 16 * nloc,
@@ -216,7 +216,7 @@ def roofline_of(enc, grid, nloc, nnz_loc, ms, world):
            "ms_per_launch": ms, "traffic": None, "encoding": enc[0],
            "algorithmic_bytes": alg, "algorithmic_GBs": alg / (ms * 1e-3) / 1e9, "algorithmic_speedup": alg / moved}
     if world == 1:
-        tr = traffic_of(grid, "plain" if enc[0] == "csr" else "default")
+        tr = traffic_of(grid, traffic_form or ("plain" if enc[0] == "csr" else "default"))
         if tr:
             out["traffic"] = tr
             out["frac_traffic"] = tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -463,7 +463,7 @@ def other_configs(K, ctx, steps, warmup):
                 ms = a.bench_spmv(b, y, fused_dots=1, reps=20)
                 e = a.encoding()
             if form == "default":
-                blk.update(value=kv / dt, unit="iterations/s", steps=kv, ms_per_step=dt / kv * 1e3, roofline=roofline_of(e, grid, n, nnz, ms, 2))
+                blk.update(value=kv / dt, unit="iterations/s", steps=kv, ms_per_step=dt / kv * 1e3, roofline=roofline_of(e, grid, n, nnz, ms, 1, "varcoef"))
             else:
                 blk.update(value_plain_csr=kv / dt, ms_per_step_plain_csr=dt / kv * 1e3, roofline_csr=roofline_csr_of(grid, n, nnz, ms, 2))
             del x
