@@ -120,6 +120,8 @@ void ipc_reduce_destroy(kryst_ctx_t ctx) {
 
 int32_t ipc_reduce_setup(kryst_ctx_t ctx) {
     if (ctx->ipc_on) return KRYST_OK;
+    if (ctx->ipc_mine) { ctx->ipc_on = true; return KRYST_OK; }      // set up before and switched off: the mailboxes are still mapped on every rank,
+                                                                     // and every rank has counted the same epochs
     KR_ARG(ctx->comm, "ipc_reduce_setup: context has no communicator");
     const int P = ctx->nranks, me = ctx->rank;
     KR_ARG(P <= 64, "ipc_reduce_setup: at most 64 ranks (one lane per peer)");

@@ -34,7 +34,7 @@ def test_reduce_spec():
     assert T % 64 == 0 and F % 64 == 0 and V >= 1
 
 
-@pytest.mark.parametrize("kind", ["poisson", "aniso", "convdiff"])
+@pytest.mark.parametrize("kind", ["poisson", "aniso", "convdiff", "varcoef"])
 def test_host_stencil_matches_oracle_generator(kind):
     N = 6
     for k_lo, k_hi in ((0, N), (0, 2), (2, 5), (5, 6)):
@@ -43,6 +43,23 @@ def test_host_stencil_matches_oracle_generator(kind):
         assert np.array_equal(rp, ref.row_ptr) and np.array_equal(ci, ref.col_idx) and np.array_equal(va, ref.vals)
     n = N ** 3
     assert K.host_stencil7(N, kind)[0][-1] == 7 * n - 6 * N * N        # nnz = 7n - 6N^2
+
+
+def test_variable_coefficient_operator_is_a_symmetric_m_matrix():
+    """kind "varcoef" (DESIGN.md section 5): per-edge weights in [0.5, 1.5) from splitmix64, a_ij = a_ji = -w, diagonal = sum of the
+    six incident weights (1.0 for a neighbour outside the box): symmetric, weakly diagonally dominant, strictly at the faces, SPD;
+    every row differs from every other (nothing for a value dictionary or a row-pattern table to find)."""
+    import scipy.sparse as sp
+    N = 7
+    rp, ci, va = K.host_stencil7(N, "varcoef")
+    m = sp.csr_matrix((va, ci, rp), shape=(N ** 3, N ** 3))
+    assert abs(m - m.T).max() == 0.0
+    off = m - sp.diags(m.diagonal())
+    assert off.data.max() < -0.5 + 1e-15 and off.data.min() >= -1.5
+    slack = m.diagonal() - np.asarray(abs(off).sum(axis=1)).ravel()
+    assert slack.min() >= -1e-12 and slack.max() <= 3.0 + 1e-12 and (slack > 0.5).sum() == N ** 3 - (N - 2) ** 3
+    assert np.linalg.eigvalsh(m.toarray()).min() > 0.0
+    assert len(np.unique(va)) >= 4 * N ** 3 - 3 * N * N - 10                   # ~ one value per edge plus one per row
 
 
 def test_partition_rows_and_halo_plan():
