@@ -178,27 +178,10 @@ __global__ __launch_bounds__(256) void tri_syncfree_ell_kernel(const TriArgs* ar
     const unsigned want = (1u << len) - 1u;
     unsigned have = 0;
     bool done = !active;
-#ifndef KR_ELL_NO_GATE
-    // while it waits a row polls ONE entry -- the dependency at the largest level-order position (the deepest level: the last to be
-    // solved in all but rare cases) -- instead of all of them (see tri_syncfree_csr_kernel)
-    int gate_u = 0;
-#pragma unroll
-    for (int u = 1; u < ELLW; ++u) if (u < len && c[u] > c[gate_u]) gate_u = u;
-    bool open = len == 0;
-#else
-    bool open = true;
-#endif
+    // (all (<= 4) dependencies are polled every round: gating them on the deepest one, which pays for rows of 13 entries in
+    // tri_syncfree_csr_kernel, adds a dependent round trip here -- 256^3: 3.1 -> 4.2 ms)
     for (int budget = 1 << 22; budget > 0; --budget) {
-#ifndef KR_ELL_NO_GATE
-        if (!done && !open) {
-            int32_t gc = c[0];
-#pragma unroll
-            for (int u = 1; u < ELLW; ++u) gc = (u == gate_u) ? c[u] : gc;
-            const double g = __hip_atomic_load(&out[gc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            open = (unsigned long long)__double_as_longlong(g) != KR_TRI_SENTINEL;
-        }
-#endif
-        if (!done && open) {
+        if (!done) {
 #pragma unroll
             for (int u = 0; u < ELLW; ++u)
                 if (u < len && !((have >> u) & 1u)) {
