@@ -91,6 +91,16 @@ impl HipContext {
     pub fn barrier(&self) -> Result<(), KError> {
         check(unsafe { ffi::kryst_comm_barrier(self.raw()) })
     }
+    /// How the solvers' `DistributedInnerProduct` (core/wrappers.rs:134-156) crosses the ranks: `false` = RCCL all-gather +
+    /// rank-ordered fold (default), `true` = hipIpc mailboxes written and polled by the fold kernel (one launch, no collective,
+    /// the same bits).  Collective over the context's ranks.  Returns whether the mailbox path is in use afterwards (it is not
+    /// when some rank cannot export or map a mailbox: every rank then stays on RCCL).
+    pub fn scalar_reduce_ipc(&self, on: bool) -> Result<bool, KError> {
+        let mut active = 0i32;
+        let rc = unsafe { ffi::kryst_ctx_scalar_reduce(self.raw(), if on { 1 } else { 0 }, &mut active) };
+        if rc != 0 && rc != 6 { check(rc)?; }
+        Ok(active != 0)
+    }
     pub fn synchronize(&self) -> Result<(), KError> {
         check(unsafe { ffi::kryst_ctx_synchronize(self.raw()) })
     }

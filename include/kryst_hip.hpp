@@ -65,6 +65,14 @@ public:
     ~Context() { kryst_ctx_destroy(h_); }
     Context(const Context&) = delete; Context& operator=(const Context&) = delete;
     kryst_ctx_t handle() const { return h_; }
+    // DistributedInnerProduct (core/wrappers.rs:134-156) inside the solvers: false = RCCL all-gather + rank-ordered fold (default),
+    // true = hipIpc mailboxes (one launch, no collective, the same bits).  Collective.  Returns whether the mailbox path is in use.
+    bool scalar_reduce_ipc(bool on) {
+        int32_t active = 0;
+        const int32_t rc = kryst_ctx_scalar_reduce(h_, on ? 1 : 0, &active);
+        if (rc != KRYST_OK && rc != KRYST_UNSUPPORTED) check(rc);
+        return active != 0;
+    }
     static std::shared_ptr<Context> global() { static std::shared_ptr<Context> c = std::make_shared<Context>(0); return c; }
 private:
     kryst_ctx_t h_ = nullptr;
