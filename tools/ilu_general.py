@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""True ILU(0) on operators that are NOT 7-point boxes (the level-ordered path): setup time with the device-side IKJ factorisation
+"""ILU-family preconditioners on the level-ordered path: true ILU(0) on operators that are NOT 7-point boxes: setup time with the device-side IKJ factorisation
 and with the host loop (KRYST_ILU_DEVICE_SETUP=0), dependency levels, and the apply time of the sync-free triangular kernels
 (HIP events, kryst_bench_pc_apply).  One JSON line per operator.   usage: ilu_general.py [N27=96] [nrand=2000000]"""
 import json, os, sys, time
@@ -51,3 +51,20 @@ for name, m in ((f"27-point stencil, {N27}^3", stencil27(N27)), (f"random band (
             out["us_per_level"] = out["apply_ms"] * 1e3 / max(1, sum(info["levels"]))
         del pc
     print(json.dumps(out), flush=True)
+
+# Ilup(1) (fill-in: 13 entries per row on a 7-point operator) and Ilut(4, 1e-3) (magnitude-ordered rows) on 128^3
+os.environ["KRYST_ILU_DEVICE_SETUP"] = "1"
+for name, kind, mk in (("Ilup(1), 7-point Poisson 128^3", "poisson", lambda: K.Ilup(1)), ("Ilut(4, 1e-3), 7-point anisotropic 128^3", "aniso", lambda: K.Ilut(4, 1e-3))):
+    a = K.CsrMatrix.stencil7(128, kind, ctx=ctx)
+    n = a.nrows()
+    ctx.synchronize(); t0 = time.perf_counter()
+    pc = mk().setup(a)
+    ctx.synchronize()
+    out = {"operator": name, "rows": n, "setup_ms": (time.perf_counter() - t0) * 1e3}
+    r = ctx.vec(n).fill_splitmix(3); z = ctx.vec(n)
+    out["apply_ms"] = pc.bench_apply(r, z, 10)
+    info = pc.ilu_info()
+    out["form"] = info["form"]; out["levels_L_U"] = info["levels"]
+    out["us_per_level"] = out["apply_ms"] * 1e3 / max(1, sum(info["levels"]))
+    print(json.dumps(out), flush=True)
+    del pc
