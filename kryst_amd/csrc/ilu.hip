@@ -654,22 +654,26 @@ static int32_t build_factor(int64_t n, const FlatRows& ent, const std::vector<do
     if (pos_out) *pos_out = pos;
     const size_t nnz = ent.col.size();
     std::vector<int32_t> col(nnz); std::vector<double> val(nnz), dg((size_t)n);
-    size_t w = 0; int64_t maxlen = 0;
-    for (int64_t p = 0; p < n; ++p) {
-        const int32_t i = rowid[p];
-        for (int64_t k = ent.ptr[i]; k < ent.ptr[i + 1]; ++k) { col[w] = pos[ent.col[k]]; val[w] = ent.val[k]; ++w; }   // columns as level-order positions
-        ptr[p + 1] = (int32_t)w;
-        dg[p] = diag[i];
-        maxlen = std::max(maxlen, ent.len(i));
-    }
+    int64_t maxlen = 0;
+    for (int64_t p = 0; p < n; ++p) { const int64_t len = ent.len(rowid[p]); ptr[p + 1] = ptr[p] + (int32_t)len; maxlen = std::max(maxlen, len); }
+    par_rows(n, [&](int64_t lo, int64_t hi) {
+        for (int64_t p = lo; p < hi; ++p) {
+            const int32_t i = rowid[p];
+            size_t w = (size_t)ptr[p];
+            for (int64_t k = ent.ptr[i]; k < ent.ptr[i + 1]; ++k) { col[w] = pos[ent.col[k]]; val[w] = ent.val[k]; ++w; }   // columns as level-order positions
+            dg[p] = diag[i];
+        }
+    });
     F->npos = n;
     if (maxlen <= ELLW && n > 0) {
         std::vector<int32_t> ecol((size_t)ELLW * n, 0); std::vector<double> eval((size_t)ELLW * n, 0.0); std::vector<uint8_t> elen((size_t)n, 0);
-        for (int64_t p = 0; p < n; ++p) {
-            const int64_t len = ptr[p + 1] - ptr[p];
-            elen[p] = (uint8_t)len;
-            for (int64_t u = 0; u < len; ++u) { ecol[(size_t)u * n + p] = col[ptr[p] + u]; eval[(size_t)u * n + p] = val[ptr[p] + u]; }
-        }
+        par_rows(n, [&](int64_t lo, int64_t hi) {
+            for (int64_t p = lo; p < hi; ++p) {
+                const int64_t len = ptr[p + 1] - ptr[p];
+                elen[p] = (uint8_t)len;
+                for (int64_t u = 0; u < len; ++u) { ecol[(size_t)u * n + p] = col[ptr[p] + u]; eval[(size_t)u * n + p] = val[ptr[p] + u]; }
+            }
+        });
         KR_TRY(up(&F->d_ecol, ecol)); KR_TRY(up(&F->d_eval, eval)); KR_TRY(up(&F->d_elen, elen));
         F->ell = true;
     }

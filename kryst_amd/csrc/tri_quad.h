@@ -30,7 +30,8 @@
 namespace kr {
 
 // -DTQ_ABL=bits: TIMING-ONLY ablations (wrong results; never in the shipped library): 1 no result stores, 2 coefficients from four
-// cached chunks, 4 spins sleep 4x longer, 8 no west/south ring reads, 16 no lane exchange, 32 no ring write, 64 no stage read.
+// cached chunks, 4 spins sleep 4x longer, 8 no west/south ring reads, 16 no lane exchange, 32 no ring write, 64 no stage read,
+// 128 a poller stream counts as fully delivered once its first rows have arrived.
 #if defined(TQ_ABL) && (TQ_ABL & 4)
 #define TQ_NAP(n) __builtin_amdgcn_s_sleep(4 * (n))
 #else
@@ -454,6 +455,11 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             if (so < m) { ring[((t + so) % R) * 8 + 2 * piece] = p0.x; ring[((t + so) % R) * 8 + 2 * piece + 1] = p0.y; }
             if (so + 4 < m) { ring[((t + so + 4) % R) * 8 + 2 * piece] = p1.x; ring[((t + so + 4) % R) * 8 + 2 * piece + 1] = p1.y; }
             if (m > 0) { if (idx == 0) for (int z = 0; z < m; ++z) TQ_STEP_TRACE(tq_deliv, gI, t + z); t += m; if (idx == 0) tq_publish(avail, t); }
+#if defined(TQ_ABL) && (TQ_ABL & 128)
+            // timing only: once a stream's FIRST rows have arrived, everything counts as delivered (what the per-step coupling to the
+            // producers costs on top of the start-up hand-over)
+            if (t > 0 && t < T) { t = T; if (idx == 0) tq_publish(avail, T); }
+#endif
 #ifdef TQ_SLOWSTART
             if (stuck) { if (__ballot(t > 0) == 0) TQ_NAP(TQ_SLOWSTART); else TQ_NAP(1); --budget; }
 #else

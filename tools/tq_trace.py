@@ -12,7 +12,7 @@ a = K.CsrMatrix.stencil7(N, "aniso", ctx=ctx)
 pc = K.TrueIlu0().setup(a)
 n = a.nrows()
 r = ctx.vec(n).fill_splitmix(3); z = ctx.vec(n)
-for _ in range(3):
+for _ in range(int(os.environ.get('TQ_APPLIES', '3'))):
     K.check(K.lib().kryst_pc_apply(pc.h, r.h, z.h)) if False else None
     import ctypes
     from kryst_amd._ffi import lib as _l
