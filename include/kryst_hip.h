@@ -123,7 +123,7 @@ int32_t kryst_csr_destroy(kryst_csr_t a);
 int32_t kryst_csr_shape(kryst_csr_t a, int64_t* nrows_local, int64_t* ncols_global, int64_t* nnz_local);
 /* storage form kryst_spmv streams for this operator (all forms are lossless re-encodings made at creation beside the CSR arrays;
  * results are bit-identical): 0 plain CSR, 1 CSR-D8 (1-byte column-offset codes), 2 CSR-D16 (offset + value codes, 2 B per
- * entry), 3 CSR-P16 (one 16-bit row-pattern id per row), 4 CSR-DIA (one value stream per diagonal: operators with at most 16
+ * entry), 3 CSR-P16 (one 16-bit row-pattern id per row), 4 CSR-DIA (one value stream per diagonal: operators with at most 32
  * well-filled diagonals that have no D16 / P16 form, e.g. variable-coefficient stencils).  patterns / table_entries (may be NULL):
  * size of the P16 tables. */
 int32_t kryst_csr_encoding(kryst_csr_t a, int32_t* encoding, int32_t* patterns, int32_t* table_entries);

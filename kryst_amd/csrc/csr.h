@@ -2,6 +2,11 @@
 #pragma once
 #include "dist.h"
 
+namespace kr {
+constexpr int KR_DIA_MAX = 32;     // CSR-DIA: at most this many diagonals (27-point box stencils fit)
+constexpr unsigned long long KR_DIA_ABSENT = 0x7FF8D1A0D1A0D1A0ull;   // "no entry here": a quiet NaN whose payload no arithmetic produces
+}
+
 struct kryst_csr_s {
     kryst_ctx_t ctx = nullptr;
     int64_t nrows = 0;        // local rows
@@ -22,13 +27,13 @@ struct kryst_csr_s {
     double* d_pval = nullptr;       // table: value
     int32_t npat = 0, ntab = 0, pat_unroll = 8; bool pat_single = false;
     bool pat_diag3 = false;        // stencil generator: every row has its diagonal, at table position 3 of its base   // table entries padded per pattern to a multiple of pat_unroll
-    // CSR-DIA: operators with at most KR_DIA_MAX distinct (col - row) offsets that fill their diagonals (any stencil on a structured
+    // CSR-DIA: operators with at most KR_DIA_MAX = 32 distinct (col - row) offsets that fill their diagonals (any stencil on a structured
     // grid, variable coefficients included): the values as ONE stream per diagonal in natural row order, absent entries marked by
     // a NaN payload no stored value may carry -- no row pointers, no per-entry codes (8 D + 16 bytes per row with x and y)
     double* d_dia = nullptr;        // dia_nd streams of dia_stride doubles: d_dia[d * dia_stride + row]
     int64_t dia_stride = 0;
     int32_t dia_nd = 0;
-    int32_t dia_off[16] = {0};      // col - row of diagonal d (a halo slot's local column for the halo diagonals), in the rows' stored order
+    int32_t dia_off[kr::KR_DIA_MAX] = {0};      // col - row of diagonal d (a halo slot's local column for the halo diagonals), in the rows' stored order
     int32_t dia_min = 0, dia_max = 0;   // over the diagonals that address x itself
     int64_t ntiles = 0;
     int slots = 7;            // SpMV pair slots per lane (picked from the average nnz of a 128-row slice)
@@ -43,8 +48,6 @@ struct kryst_csr_s {
 
 namespace kr {
 
-constexpr int KR_DIA_MAX = 16;     // CSR-DIA: at most this many diagonals
-constexpr unsigned long long KR_DIA_ABSENT = 0x7FF8D1A0D1A0D1A0ull;   // "no entry here": a quiet NaN whose payload no arithmetic produces
 constexpr int KR_PMAX = 512;        // CSR-P16 limits: patterns and (padded) table entries held in LDS: 2 + 12 + 24 KiB at most
 constexpr int KR_TMAX = 2048;
 inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }

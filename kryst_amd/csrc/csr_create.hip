@@ -178,9 +178,9 @@ static int32_t build_dia(kryst_csr_t a) {
     if (want == 0 || !a->d_code || !a->d_dict || n == 0 || nnz == 0) return KRYST_OK;
     if (want < 2 && a->d_code16) return KRYST_OK;
     struct Scratch { unsigned* u = nullptr; uint8_t* b = nullptr; ~Scratch() { (void)hipFree(u); (void)hipFree(b); } } sc;
-    KR_HIP(hipMalloc(&sc.u, sizeof(unsigned) * 32)); KR_HIP(hipMalloc(&sc.b, 512));
-    KR_HIP(hipMemsetAsync(sc.u, 0, sizeof(unsigned) * 32, ctx->s_main));
-    unsigned* d_used = sc.u; unsigned* d_prec = sc.u + 8; unsigned* d_flags = sc.u + 24;
+    KR_HIP(hipMalloc(&sc.u, sizeof(unsigned) * (16 + KR_DIA_MAX))); KR_HIP(hipMalloc(&sc.b, 512));
+    KR_HIP(hipMemsetAsync(sc.u, 0, sizeof(unsigned) * (16 + KR_DIA_MAX), ctx->s_main));
+    unsigned* d_used = sc.u; unsigned* d_prec = sc.u + 8; unsigned* d_flags = sc.u + 8 + KR_DIA_MAX;
     const unsigned eg = (unsigned)std::min<int64_t>(4096, (nnz + 255) / 256), rg = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(dia_usage_kernel, dim3(eg), dim3(256), 0, ctx->s_main, a->d_code, nnz, d_used);
     KR_HIP(hipGetLastError());

@@ -127,12 +127,12 @@ def test_spmv_kernel_forms_bit_exact(ctx, kernel, compress, monkeypatch):
 
 
 def test_spmv_diagonal_streams_form_bit_exact(ctx, monkeypatch):
-    """CSR-DIA (one value stream per diagonal, absent entries marked by a NaN payload): built whenever an operator has at most 16
+    """CSR-DIA (one value stream per diagonal, absent entries marked by a NaN payload): built whenever an operator has at most 32
     well-filled diagonals (KRYST_SPMV_DIA=2: also beside the more compact D16 / P16 forms, which this test switches off).  Cases:
-    1-, 3-, 5-, 7-, 9-, 11- and 16-diagonal operators (the exact-count kernels and the batched one), boxes whose first tiles start
+    1-, 3-, 5-, 7-, 9-, 11-, 16-, 27- and 32-diagonal operators (the exact-count kernels and the batched one), boxes whose first tiles start
     before x[0] and whose last reach past x's end, stored zeros, signed zeros, inf / NaN values AND inf / NaN in x next to absent
     entries (an absent entry must contribute nothing, not 0 * x), empty rows, a stored value with the marker's own bits (the
-    operator must then NOT take this form), 17 diagonals and sparsely filled diagonals (not this form either)."""
+    operator must then NOT take this form), 33 diagonals and sparsely filled diagonals (not this form either)."""
     import scipy.sparse as sp
     monkeypatch.setenv("KRYST_SPMV_DIA", "2"); monkeypatch.setenv("KRYST_SPMV_COMPRESS", "1")
     rng = np.random.default_rng(44)
@@ -146,9 +146,16 @@ def test_spmv_diagonal_streams_form_bit_exact(ctx, monkeypatch):
         m = sp.csr_matrix((np.concatenate(vs), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)); m.sort_indices()
         return O.Csr(n, n, m.indptr, m.indices, m.data)
 
+    def box27(N):                                                                                     # 27-point operator on an N^3 box, random values
+        one = sp.diags([np.ones(N - 1), np.ones(N), np.ones(N - 1)], [-1, 0, 1])
+        m = sp.kron(one, sp.kron(one, one)).tocsr(); m.sort_indices()
+        m.data = rng.standard_normal(m.nnz)
+        return O.Csr(N ** 3, N ** 3, m.indptr, m.indices, m.data)
+
     yes = [banded(1, [0]), banded(700, [0]), banded(2000, [-1, 0, 1]), banded(5000, [-70, -1, 0, 1, 70]), O.stencil7(21, "varcoef"), O.stencil7(33, "poisson"),
            banded(3000, [-300, -30, -1, 0, 1, 30, 300], keep=0.97),                               # randomly missing couplings
-           banded(4099, [-1200, -35, -34, -1, 0, 1, 34, 35, 1200]), banded(2500, list(range(-5, 6))), banded(3333, list(range(-8, 8)))]
+           banded(4099, [-1200, -35, -34, -1, 0, 1, 34, 35, 1200]), banded(2500, list(range(-5, 6))), banded(3333, list(range(-8, 8))),
+           banded(6000, list(range(-13, 14))), banded(5000, list(range(-16, 16))), box27(14)]            # 27 and 32 diagonals; a 27-point box with random coefficients
     for a in yes:
         d = to_dev(ctx, a)
         assert d.encoding()[0] == "csr-dia", (a.nrows, a.nnz)
@@ -169,7 +176,7 @@ def test_spmv_diagonal_streams_form_bit_exact(ctx, monkeypatch):
     # NOT this form: the marker's bit pattern among the values, 17 diagonals, thinly filled diagonals, an empty matrix
     mk = banded(1000, [-1, 0, 1])
     mk.vals[123] = np.frombuffer(np.uint64(0x7FF8D1A0D1A0D1A0).tobytes(), dtype=np.float64)[0]
-    for a in (mk, banded(3000, list(range(-8, 9))), banded(4000, [-1000, -10, 0, 10, 1000], keep=0.5), O.Csr(5, 5, [0, 0, 0, 0, 0, 0], [], [])):
+    for a in (mk, banded(3000, list(range(-16, 17))), banded(4000, [-1000, -10, 0, 10, 1000], keep=0.5), O.Csr(5, 5, [0, 0, 0, 0, 0, 0], [], [])):
         d = to_dev(ctx, a)
         assert d.encoding()[0] != "csr-dia", (a.nrows, a.nnz)
         x = rng.standard_normal(a.ncols)
