@@ -155,7 +155,7 @@ def test_spmv_diagonal_streams_form_bit_exact(ctx, monkeypatch):
     yes = [banded(1, [0]), banded(700, [0]), banded(2000, [-1, 0, 1]), banded(5000, [-70, -1, 0, 1, 70]), O.stencil7(21, "varcoef"), O.stencil7(33, "poisson"),
            banded(3000, [-300, -30, -1, 0, 1, 30, 300], keep=0.97),                               # randomly missing couplings
            banded(4099, [-1200, -35, -34, -1, 0, 1, 34, 35, 1200]), banded(2500, list(range(-5, 6))), banded(3333, list(range(-8, 8))),
-           banded(6000, list(range(-13, 14))), banded(5000, list(range(-16, 16))), box27(14)]            # 27 and 32 diagonals; a 27-point box with random coefficients
+           banded(6000, list(range(-13, 14))), banded(5000, list(range(-16, 16))), box27(24)]            # 27 and 32 diagonals; a 27-point box with random coefficients
     for a in yes:
         d = to_dev(ctx, a)
         assert d.encoding()[0] == "csr-dia", (a.nrows, a.nnz)
