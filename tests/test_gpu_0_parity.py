@@ -696,6 +696,30 @@ def test_device_side_general_factorisation_equals_host_and_oracle(ctx, monkeypat
         assert e.value.code == 5 and e.value.row == 1, dev
 
 
+def test_measurement_hooks_describe_what_the_apply_runs(ctx, monkeypatch):
+    """kryst_pc_ilu_info / kryst_bench_pc_apply (bench.py prices the triangular solve with them): the form an ILU-family apply runs,
+    its chunk bookkeeping (a constant-coefficient box repeats most coefficient chunks, a variable-coefficient one none), dependency
+    levels of a level-ordered factor, and a timing loop that leaves the same z as a single apply."""
+    for kind, repeats in (("aniso", True), ("varcoef", False)):
+        a = K.CsrMatrix.stencil7(64, kind, ctx=ctx)
+        pc = K.TrueIlu0().setup(a)
+        info = pc.ilu_info()
+        assert info["form"].startswith("grid 16x16") and info["box"] == [64, 64, 64]
+        assert info["chunks"][0] == info["chunks"][1] == 16 * 4 * ((64 + 14 + 7) // 8) and info["bytes_per_chunk"] == [12288, 16384]
+        assert (min(info["chunks_not_requested"]) > 0) == repeats
+        r = ctx.vec(a.nrows()).fill_splitmix(5)
+        z1 = pc.apply(r).to_host()
+        z2 = ctx.vec(a.nrows())
+        assert pc.bench_apply(r, z2, 3) > 0.0 and np.array_equal(z2.to_host(), z1)
+    rng = np.random.default_rng(8)
+    d = rng.random((200, 200)) * (rng.random((200, 200)) < 0.05) + np.diag(4.0 + rng.random(200))
+    pc = K.TrueIlu0().setup(to_dev(ctx, O.Csr.from_dense(d, keep_zeros=False)))
+    info = pc.ilu_info()
+    assert info["form"] == "level-ordered" and min(info["levels"]) >= 1 and info["chunks"] == [0, 0]
+    with pytest.raises(K.KError):
+        K.Jacobi().setup(K.CsrMatrix.stencil7(8, "poisson", ctx=ctx)).ilu_info()
+
+
 def test_plane_kernels_bit_exact(ctx, monkeypatch):
     """KRYST_ILU_PLANES=1: the fallback of the wavefront solve on its own, ragged boxes included."""
     monkeypatch.setenv("KRYST_ILU_PLANES", "1")
