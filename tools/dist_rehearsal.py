@@ -20,7 +20,11 @@ ctx_d = K.Context(0, 0, 1, box[0])
 ctx_s = K.Context(0)
 N = 40
 out = {}
-for name, ctx in (("dist", ctx_d), ("single", ctx_s)):
+for name, ctx in (("dist", ctx_d), ("dist_ipc", ctx_d), ("single", ctx_s)):
+    if name == "dist_ipc":
+        # the mailbox path of the scalar all-reduce with the REAL RCCL underneath (the handle exchange is an RCCL all-gather; with
+        # one rank the kernel sends to and polls its own mailbox): every inner product in one launch, the same bits
+        assert ctx.scalar_reduce("ipc") == "ipc", "hipIpc mailbox set-up failed"
     a = K.CsrMatrix.stencil7(N, "poisson", ctx=ctx)
     n = a.nrows()
     b = a.spmv(ctx.vec(n).fill(1.0))
@@ -34,5 +38,6 @@ for name, ctx in (("dist", ctx_d), ("single", ctx_s)):
     ctx.barrier()
     assert ctx.all_reduce(2.5) == 2.5
 assert out["dist"] == out["single"], "forced-collective path differs from the plain path"
+assert out["dist_ipc"] == out["single"], "mailbox path of the scalar all-reduce differs from the plain path"
 print("dist rehearsal ok:", [(r[0], r[2]) for r in out["dist"]])
 dist.destroy_process_group()
