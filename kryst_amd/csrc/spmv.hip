@@ -876,7 +876,8 @@ int32_t kryst_csr_encoding(kryst_csr_t a, int32_t* encoding, int32_t* patterns, 
     KR_ARG(a && encoding, "csr_encoding");
     const int lvl = env_int("KRYST_SPMV_COMPRESS", 3);
     int e = 0;
-    if (a->d_pid && lvl >= 3) e = 3;
+    const bool p16_fits = a->xlen + a->plan.total_recv < (1ll << 28) && a->nrows < (1ll << 28);     // (32-bit byte offsets: launch_tiles)
+    if (a->d_pid && lvl >= 3 && p16_fits) e = 3;
     else if (a->d_code16 && lvl >= 2) e = 2;
     else if (a->d_dia && lvl >= 1 && env_int("KRYST_SPMV_DIA", 1) != 0) e = 4;
     else if (a->d_code && lvl >= 1) e = 1;

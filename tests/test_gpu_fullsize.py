@@ -268,3 +268,34 @@ def test_config4_jacobi_pcg_512_cubed_on_one_gpu(ctx):
     assert stc.converged and abs(stc.iterations - its) <= 60, (stc.iterations, its)
     K.axpy(-1.0, ones, x)
     assert K.norm(x) <= 1e-3 * np.sqrt(n)                                                      # x* = 1: error <= kappa * 1e-8
+
+
+@pytest.mark.gpu
+def test_sizes_at_the_index_limits(ctx, monkeypatch):
+    """648^3 = 272 M rows is beyond the CSR-P16 kernel's 32-bit byte offsets (2^28 rows): the operator must fall back to CSR-D16 and say
+    so, and every form must still give the exact row sums of the Poisson operator (A 1 = number of missing neighbours) and agree bit for
+    bit; 768^3 (3.2 G entries) exceeds the int32 entry indexing and must be refused with an argument error, not attempted."""
+    with pytest.raises(K.KError) as e:
+        K.CsrMatrix.stencil7(768, "poisson", ctx=ctx)
+    assert e.value.code == 102
+    M = 648
+    n = M ** 3
+    assert n > 1 << 28 and 7 * n - 6 * M * M < (1 << 31) - 16
+    monkeypatch.delenv("KRYST_SPMV_COMPRESS", raising=False)
+    a = K.CsrMatrix.stencil7(M, "poisson", ctx=ctx)
+    assert a.encoding()[0] == "csr-d16"
+    ones = ctx.vec(n).fill(1.0)
+    x = ctx.vec(n).fill_splitmix(0xC0FFEE)
+    ref = None
+    for comp in ("3", "1", "0"):
+        monkeypatch.setenv("KRYST_SPMV_COMPRESS", comp)
+        y = a.spmv(ones)
+        assert K.dot(y, ones) == float(6 * M * M)
+        assert K.dot(y, y) == float(6 * (M - 2) ** 2 + 4 * 12 * (M - 2) + 9 * 8)
+        z = a.spmv(x)
+        if ref is None:
+            ref = z
+        else:
+            d = ctx.vec(n); d.copy_from(z); K.axpy(-1.0, ref, d)
+            assert K.norm(d) == 0.0
+        del y
