@@ -277,6 +277,24 @@ def test_spmv_device_generator_matches_host(ctx):
         assert np.array_equal(hrp, ref.row_ptr) and np.array_equal(hci, ref.col_idx) and np.array_equal(hva, ref.vals)
 
 
+@pytest.mark.parametrize("N", [1, 2, 3, 8, 17, 40, 70])
+def test_spmv_on_generator_made_operators_bit_exact(ctx, rs, N):
+    """Operators written by the device generator (ids, codes and tables come from stencil7_gen_kernel, not from the host builder) run
+    the CSR-P16 kernel's generator instances (two gathers for x[row-1 .. row+2], the fused dot's p taken from the diagonal's gather):
+    the oracle's bits with and without the fused (p, Ap) partials, boxes smaller than a tile and several tiles large."""
+    for kind in ("poisson", "aniso", "convdiff"):
+        ao = O.stencil7(N, kind)
+        a = K.CsrMatrix.stencil7(N, kind, ctx=ctx)
+        assert a.encoding()[0] == "csr-p16"
+        x = O.splitmix64_uniform(0xC0FFEE + N, ao.ncols) - 0.5
+        assert np.array_equal(a.spmv(x), ao.spmv(x)), (kind, N)
+        b = ao.spmv(np.ones(ao.nrows))
+        ref = O.solve("cg", ao, b, tol=1e-10, max_iters=12, rs=rs)                 # the fused-dot instances (CENTER = 3)
+        s = K.CgSolver(1e-10, 12); xx = np.zeros(ao.nrows)
+        st = s.solve(a, None, b, xx)
+        assert st.iterations == ref.iterations and np.array_equal(xx, ref.x) and np.array_equal(np.array(s.residual_history), ref.history), (kind, N)
+
+
 @pytest.mark.parametrize("N", [5, 21, 40])
 def test_variable_coefficient_operator_every_form_and_solver(ctx, rs, N, monkeypatch):
     """The variable-coefficient 7-point operator (kind "varcoef": no two rows alike, so neither the value dictionary nor the row
