@@ -18,13 +18,14 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,N,kind,method", [(2, 8, "poisson", "cg"), (2, 8, "poisson", "pcg"),
-                                                  (3, 9, "aniso", "pcg"), (2, 6, "poisson", "pcg")])
+                                                  (3, 9, "aniso", "pcg"), (2, 6, "poisson", "pcg"),
+                                                  (8, 16, "poisson", "pcg")])        # BASELINE config 4's shape: Jacobi-PCG over 8 k-slabs
 def test_partitioned_cg_matches_oracle(world, N, kind, method):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="2")
+                   OMP_NUM_THREADS="2" if world <= 4 else "1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_cpu_worker.py"), str(N), kind, method],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -56,7 +57,7 @@ print("RDZV_OK")
 '''
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_socket_rendezvous_without_torch(world):
     """kryst_amd/launch.py: the no-torch launcher plumbing bench.py --launcher socket uses (unique id broadcast, barrier, max,
     gather), also when the first port of its range is already taken by somebody else."""
