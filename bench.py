@@ -298,14 +298,25 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters):
     if world > 1:
         reduce_info = {"path": "rccl", "value_rccl": steps / dt, "value_ipc": None, "ipc": "unavailable on this node (hipIpc export / mapping failed)"}
         if ctx.scalar_reduce("ipc") == "ipc":
-            dt_ipc, stats_ipc = timed_iterations()
-            same = group.allreduce_max(0.0 if stats_ipc.final_residual == stats.final_residual else 1.0) == 0.0
-            reduce_info.update(value_ipc=steps / dt_ipc, ipc="bit-identical residual" if same else "DIFFERENT residual: not used")
-            if same and dt_ipc < dt:
-                dt, stats = dt_ipc, stats_ipc
-                reduce_info["path"] = "ipc"
-            else:
+            try:
+                dt_ipc, stats_ipc = timed_iterations()
+                failed = 0.0
+            except Exception as e:                  # e.g. a peer's stamp never arrived (KRYST_ERR_RCCL after the poll budget)
+                dt_ipc, stats_ipc, failed = float("inf"), None, 1.0
+                reduce_info["ipc"] = f"failed: {e}"
+            if group.allreduce_max(failed) > 0.0:    # one rank's failure is everybody's: back to the all-gather path, on every rank
+                reduce_info.setdefault("ipc", "failed on another rank")
+                if not reduce_info["ipc"].startswith("failed"):
+                    reduce_info["ipc"] = "failed on another rank"
                 ctx.scalar_reduce("rccl")
+            else:
+                same = group.allreduce_max(0.0 if stats_ipc.final_residual == stats.final_residual else 1.0) == 0.0
+                reduce_info.update(value_ipc=steps / dt_ipc, ipc="bit-identical residual" if same else "DIFFERENT residual: not used")
+                if same and dt_ipc < dt:
+                    dt, stats = dt_ipc, stats_ipc
+                    reduce_info["path"] = "ipc"
+                else:
+                    ctx.scalar_reduce("rccl")
     enc = a.encoding()
     with env_override(KRYST_SPMV_COMPRESS="0"):
         dt_plain, stats_plain = timed_iterations()
