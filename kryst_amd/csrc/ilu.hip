@@ -1203,6 +1203,264 @@ static int32_t ikj_on_device(kryst_csr_t a, const std::vector<int64_t>& rp, cons
     return KRYST_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// GENERAL operators, everything on the device (round 3).  The host loops of kryst_pc_ilu0 download A, eliminate, split into L / U,
+// level-order both factors and upload them again; here the nnz-sized data never leave the GPU and the host only handles O(n)
+// bookkeeping (counting sorts of the rows by level, prefix sums of the row lengths):
+//   dpos / longest row -> factor values w (mode 2: dependency levels of the lower pattern, ilu0_ikj_wave_kernel; modes 0 / 1: the
+//   pointwise quotients) -> kept entries per row and the divisor -> dependency levels of L (forward) and U (backward), each a
+//   sync-free launch in which a row polls its dependencies' levels -> [host: rows by level, positions, row pointers] -> the factors
+//   written in level order straight from (A's pattern, w) -> finish_ilu_device.
+// Same kept entries, same stored order, same divisors as the host path: the apply is bit-identical (the tests run both).  Taken for
+// single-rank operators that are not candidate grid operators (more than 7 distinct offsets, or no offset dictionary at all) and
+// whose rows fit a wave (<= 64 entries); everything else, KRYST_ILU_DEVICE_SETUP=0 and any starved poll budget: the host path.
+__global__ __launch_bounds__(256) void gen_rowmax_kernel(const int32_t* __restrict__ rp, int32_t n, int32_t* maxlen) {
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    int32_t len = i < n ? rp[i + 1] - rp[i] : 0;
+    for (int off = 32; off >= 1; off >>= 1) len = max(len, __shfl_xor(len, off, 64));
+    if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(maxlen, len);
+}
+// modes 0 / 1 (ilu.rs:76-80, ilup.rs:104-111): l_ij = a_ij / a_jj for stored nonzeros below the diagonal, everything else as stored
+__global__ __launch_bounds__(256) void gen_pointwise_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                            const int32_t* __restrict__ dpos, int32_t n, int mode, double* w, unsigned long long* first_bad) {
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+        const int32_t j = col[k];
+        if (j < i && val[k] != 0.0) {
+            const double ujj = dpos[j] >= 0 ? val[dpos[j]] : 0.0;
+            if (mode == KRYST_ILU_ILUP0 && ujj == 0.0) { atomicMin(first_bad, ((unsigned long long)(unsigned)i << 32) | (unsigned)j); return; }   // ilup.rs:106-108
+            w[k] = val[k] / ujj;
+        }
+    }
+}
+// kept entries (`!= T::zero()` filters, local columns only) below / above the diagonal and the backward solve's divisor
+__global__ __launch_bounds__(256) void gen_classify_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ w,
+                                                           int32_t n, int divide, int32_t* nl, int32_t* nu, double* dg) {
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int32_t a = 0, b = 0; double d = 1.0;
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+        const int32_t j = col[k];
+        if (j >= n || w[k] == 0.0) continue;
+        if (j < i) ++a; else if (j > i) ++b; else if (divide) d = w[k];                  // ilup.rs:160-164 (missing diagonal: no divide)
+    }
+    nl[i] = a; nu[i] = b; dg[i] = d;
+}
+// dependency levels: level(i) = 1 + max level(j) over the row's dependencies (0 without any).  One lane per row in processing order
+// (FORWARD: ascending rows, dependencies j < i; backward: descending rows, dependencies i < j < n); a lane polls the levels it still
+// needs once per round (-1 = not known yet) and never blocks the other lanes of its wave.  KEPT: only entries with w != 0 count.
+template <bool FORWARD, bool KEPT>
+__global__ __launch_bounds__(256) void gen_level_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ w,
+                                                        int32_t n, int32_t* level, int32_t* stalled, int budget0) {
+    const int32_t tid = blockIdx.x * 256 + threadIdx.x;
+    const bool active = tid < n;
+    const int32_t i = FORWARD ? tid : n - 1 - tid;
+    int32_t k = active ? rp[i] : 0; const int32_t kend = active ? rp[i + 1] : 0;
+    int32_t lv = 0;
+    bool fin = !active;
+    for (int budget = budget0; budget > 0; --budget) {
+        if (!fin) {
+            while (k < kend) {
+                const int32_t j = col[k];
+                const bool dep = (FORWARD ? j < i : (j > i && j < n)) && (!KEPT || w[k] != 0.0);
+                if (dep) {
+                    const int32_t lj = __hip_atomic_load(&level[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lj < 0) break;
+                    lv = max(lv, lj + 1);
+                }
+                ++k;
+            }
+            if (k == kend) { __hip_atomic_store(&level[i], lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fin = true; }
+        }
+        if (__all(fin)) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (!fin) { __hip_atomic_store(stalled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&level[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
+// one factor in level order: position p holds row rowid[p]; its kept entries in stored order, columns as positions
+template <bool LOWER>
+__global__ __launch_bounds__(256) void gen_fill_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ w, int32_t n,
+                                                       const int32_t* __restrict__ rowid, const int32_t* __restrict__ pos, const int32_t* __restrict__ ptr,
+                                                       const double* __restrict__ dg, int32_t* out_col, double* out_val, double* out_diag,
+                                                       int32_t* ecol, double* eval, uint8_t* elen) {
+    const int32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int32_t i = rowid[p];
+    int32_t dst = ptr[p], u = 0;
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+        const int32_t j = col[k];
+        if (j >= n || w[k] == 0.0) continue;
+        if (LOWER ? j < i : j > i) {
+            out_col[dst] = pos[j]; out_val[dst] = w[k];
+            if (ecol && u < ELLW) { ecol[(int64_t)u * n + p] = pos[j]; eval[(int64_t)u * n + p] = w[k]; }
+            ++dst; ++u;
+        }
+    }
+    out_diag[p] = LOWER ? 1.0 : dg[i];
+    if (elen) elen[p] = (uint8_t)u;
+}
+__global__ __launch_bounds__(256) void gen_maplu_kernel(const int32_t* __restrict__ posL, const int32_t* __restrict__ posU, int32_t n, int32_t* mapLU) {
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) mapLU[posU[i]] = posL[i];
+}
+
+// rows ordered by (level, row); -> rowid, pos, number of levels, level offsets
+static void rows_by_level(const std::vector<int32_t>& lvl, std::vector<int32_t>& rowid, std::vector<int32_t>& pos, std::vector<int32_t>& lvl_off) {
+    const int64_t n = (int64_t)lvl.size();
+    int32_t nlv = 0;
+    for (int64_t i = 0; i < n; ++i) nlv = std::max(nlv, lvl[i] + 1);
+    lvl_off.assign((size_t)nlv + 1, 0);
+    for (int64_t i = 0; i < n; ++i) lvl_off[lvl[i] + 1]++;
+    for (int32_t q = 0; q < nlv; ++q) lvl_off[q + 1] += lvl_off[q];
+    std::vector<int32_t> cursor(lvl_off.begin(), lvl_off.end() - 1);
+    rowid.resize((size_t)n); pos.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) rowid[cursor[lvl[i]]++] = (int32_t)i;        // ascending row inside a level
+    for (int64_t p = 0; p < n; ++p) pos[rowid[p]] = (int32_t)p;
+}
+
+static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out) {
+    *out = nullptr;
+    kryst_ctx_t ctx = a->ctx;
+    const int64_t n64 = a->nrows, nnz = a->nnz;
+    if (a->dist || n64 == 0 || nnz == 0 || n64 >= (1ll << 31) - 4 || env_i("KRYST_ILU_DEVICE_SETUP", 1) == 0) return KRYST_OK;
+    const int32_t n = (int32_t)n64;
+    tl_setup_stream = ctx->s_main;
+    const bool verbose = getenv("KRYST_ILU_VERBOSE") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = tnow();
+    auto lap = [&](const char* what) { if (verbose) { fprintf(stderr, "[kryst ilu]   device setup: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(tnow() - t0).count()); t0 = tnow(); } };
+    if (a->d_code) {                         // a handful of offsets: a candidate grid operator -- the host path recognises those and takes the wavefront kernels
+        int32_t used[256]; int32_t* d_used = nullptr;
+        KR_HIP(hipMalloc(&d_used, sizeof used));
+        (void)hipMemsetAsync(d_used, 0, sizeof used, ctx->s_main);
+        hipLaunchKernelGGL(code_usage_kernel, dim3((unsigned)std::min<int64_t>(4096, (nnz + 255) / 256 + 1)), dim3(256), 0, ctx->s_main, a->d_code, nnz, d_used);
+        const hipError_t e1 = hipMemcpyAsync(used, d_used, sizeof used, hipMemcpyDeviceToHost, ctx->s_main), e2 = hipStreamSynchronize(ctx->s_main);
+        (void)hipFree(d_used);
+        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }
+        int cnt = 0;
+        for (int q = 0; q < 256; ++q) cnt += used[q] ? 1 : 0;
+        if (cnt <= 7) return KRYST_OK;
+    }
+    struct Tmp {
+        double *w = nullptr, *dg = nullptr; int32_t *dpos = nullptr, *done = nullptr, *order = nullptr, *lvl = nullptr, *lvl2 = nullptr, *nl = nullptr, *nu = nullptr;
+        int32_t *posL = nullptr, *posU = nullptr; unsigned long long* flags = nullptr;
+        ~Tmp() { for (void* q : {(void*)w, (void*)dg, (void*)dpos, (void*)done, (void*)order, (void*)lvl, (void*)lvl2, (void*)nl, (void*)nu, (void*)posL, (void*)posU, (void*)flags}) (void)hipFree(q); }
+    } t;
+    const size_t nb = sizeof(int32_t) * (size_t)n;
+    if (hipMalloc(&t.w, sizeof(double) * (size_t)nnz) != hipSuccess || hipMalloc(&t.dg, sizeof(double) * (size_t)n) != hipSuccess || hipMalloc(&t.dpos, nb) != hipSuccess ||
+        hipMalloc(&t.done, nb) != hipSuccess || hipMalloc(&t.order, nb) != hipSuccess || hipMalloc(&t.lvl, nb) != hipSuccess || hipMalloc(&t.lvl2, nb) != hipSuccess ||
+        hipMalloc(&t.nl, nb) != hipSuccess || hipMalloc(&t.nu, nb) != hipSuccess || hipMalloc(&t.posL, nb) != hipSuccess || hipMalloc(&t.posU, nb) != hipSuccess ||
+        hipMalloc(&t.flags, 64) != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }
+    const unsigned g = (unsigned)((n + 255) / 256);
+    const int budget = std::max(1, env_i("KRYST_ILU_SETUP_POLL_BUDGET", 1 << 22));
+    // flags: [0] first zero pivot (min), [1] stalled, [2] longest row
+    KR_HIP(hipMemsetAsync(t.flags, 0xff, 8, ctx->s_main));
+    KR_HIP(hipMemsetAsync(t.flags + 1, 0, 56, ctx->s_main));
+    int32_t* d_stalled = reinterpret_cast<int32_t*>(t.flags + 1); int32_t* d_maxlen = reinterpret_cast<int32_t*>(t.flags + 2);
+    KR_HIP(hipMemcpyAsync(t.w, a->d_val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, ctx->s_main));
+    hipLaunchKernelGGL(ilu0_dpos_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, n, t.dpos, t.done);
+    hipLaunchKernelGGL(gen_rowmax_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, n, d_maxlen);
+    unsigned long long hf[3];
+    KR_HIP(hipMemcpyAsync(hf, t.flags, sizeof hf, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    if ((int32_t)hf[2] > 64) return KRYST_OK;                               // a row must fit one wave's LDS slice
+    std::vector<int32_t> lvl((size_t)n), lvlU((size_t)n), rowid, pos, lvl_off;
+    // ---- factor values
+    if (mode == KRYST_ILU_TRUE_ILU0) {
+        KR_HIP(hipMemsetAsync(t.lvl, 0xff, nb, ctx->s_main));
+        hipLaunchKernelGGL((gen_level_kernel<true, false>), dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, n, t.lvl, d_stalled, budget);
+        KR_HIP(hipGetLastError());
+        KR_HIP(hipMemcpyAsync(lvl.data(), t.lvl, nb, hipMemcpyDeviceToHost, ctx->s_main));
+        KR_HIP(hipMemcpyAsync(hf, t.flags, sizeof hf, hipMemcpyDeviceToHost, ctx->s_main));
+        KR_HIP(hipStreamSynchronize(ctx->s_main));
+        if ((int32_t)hf[1] != 0) return KRYST_OK;
+        rows_by_level(lvl, rowid, pos, lvl_off);
+        lap("pattern levels");
+        KR_HIP(hipMemcpyAsync(t.order, rowid.data(), nb, hipMemcpyHostToDevice, ctx->s_main));
+        hipLaunchKernelGGL(ilu0_ikj_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dpos, t.order, n, t.done,
+                           t.flags, d_stalled, budget);
+    } else {
+        hipLaunchKernelGGL(gen_pointwise_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, a->d_val, t.dpos, n, mode, t.w, t.flags);
+    }
+    KR_HIP(hipGetLastError());
+    // ---- kept entries, divisors, levels of both factors
+    const int divide = mode != KRYST_ILU_KRYST_COMPAT ? 1 : 0;              // ilu.rs:115-119 never divides
+    hipLaunchKernelGGL(gen_classify_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, n, divide, t.nl, t.nu, t.dg);
+    KR_HIP(hipMemsetAsync(t.lvl, 0xff, nb, ctx->s_main));
+    KR_HIP(hipMemsetAsync(t.lvl2, 0xff, nb, ctx->s_main));
+    hipLaunchKernelGGL((gen_level_kernel<true, true>), dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, n, t.lvl, d_stalled, budget);
+    hipLaunchKernelGGL((gen_level_kernel<false, true>), dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, n, t.lvl2, d_stalled, budget);
+    KR_HIP(hipGetLastError());
+    std::vector<int32_t> nl((size_t)n), nu((size_t)n);
+    KR_HIP(hipMemcpyAsync(lvl.data(), t.lvl, nb, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipMemcpyAsync(lvlU.data(), t.lvl2, nb, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipMemcpyAsync(nl.data(), t.nl, nb, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipMemcpyAsync(nu.data(), t.nu, nb, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipMemcpyAsync(hf, t.flags, sizeof hf, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    if ((int32_t)hf[1] != 0) return KRYST_OK;                               // a starved poll budget somewhere: the host path
+    if (hf[0] != ~0ull) {
+        if (mode == KRYST_ILU_TRUE_ILU0) { const long long c = (long long)(hf[0] & 0xffffffffull); set_error("ILU(0): zero pivot at row %lld", c); set_error_row(c); return KRYST_ZERO_PIVOT; }
+        set_error("ILUP: zero diagonal in U at row %lld", (long long)(hf[0] & 0xffffffffull));
+        return KRYST_SOLVE_ERROR;
+    }
+    lap("factor values, kept entries, levels");
+    // ---- the preconditioner object and its two level-ordered factors
+    kryst_pc_t pc = new kryst_pc_s();
+    pc->ctx = ctx; pc->kind = KR_PC_ILU; pc->a = a; pc->n = n; pc->ilu_mode = mode; pc->divide_diag = divide;
+    IluData* D = new IluData();
+    D->n = n;
+    pc->d_work = reinterpret_cast<double*>(D);
+    int32_t rc = KRYST_OK;
+    std::vector<int32_t> ptr((size_t)n + 1);
+    for (int which = 0; which < 2 && rc == KRYST_OK; ++which) {
+        TriFactor* F = which == 0 ? &D->L : &D->U;
+        const std::vector<int32_t>& lv = which == 0 ? lvl : lvlU;
+        const std::vector<int32_t>& len = which == 0 ? nl : nu;
+        rows_by_level(lv, rowid, pos, F->lvl_off);
+        int32_t maxlen = 0;
+        ptr[0] = 0;
+        for (int32_t p = 0; p < n; ++p) { const int32_t L = len[rowid[p]]; ptr[(size_t)p + 1] = ptr[p] + L; maxlen = std::max(maxlen, L); }
+        const size_t fn = (size_t)ptr[n];
+        F->npos = n;
+        F->ell = maxlen <= ELLW;
+        const double rows_per_level = (double)n / (double)std::max<size_t>(1, F->lvl_off.size() - 1);
+        F->syncfree = env_i("KRYST_ILU_SYNCFREE", (F->ell || rows_per_level >= 512.0) ? 1 : 0) != 0;
+        int32_t* d_pos = which == 0 ? t.posL : t.posU;
+        rc = up(&F->d_row, rowid);
+        if (rc == KRYST_OK) rc = up(&F->d_ptr, ptr);
+        if (rc == KRYST_OK) rc = up(&F->d_lvl_off, F->lvl_off);
+        if (rc == KRYST_OK && (hipMalloc(&F->d_col, sizeof(int32_t) * (fn + 1)) != hipSuccess || hipMalloc(&F->d_val, sizeof(double) * (fn + 1)) != hipSuccess ||
+                               hipMalloc(&F->d_diag, sizeof(double) * ((size_t)n + 1)) != hipSuccess)) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (rc == KRYST_OK && F->ell) {
+            const size_t eb = (size_t)ELLW * n;
+            if (hipMalloc(&F->d_ecol, sizeof(int32_t) * (eb + 1)) != hipSuccess || hipMalloc(&F->d_eval, sizeof(double) * (eb + 1)) != hipSuccess ||
+                hipMalloc(&F->d_elen, (size_t)n + 1) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+            else if (hipMemsetAsync(F->d_ecol, 0, sizeof(int32_t) * (eb + 1), ctx->s_main) != hipSuccess ||
+                     hipMemsetAsync(F->d_eval, 0, sizeof(double) * (eb + 1), ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;      // padding slots: column 0, value 0
+        }
+        if (rc == KRYST_OK && hipMemcpyAsync(d_pos, pos.data(), nb, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
+        if (rc == KRYST_OK) {
+            if (which == 0) hipLaunchKernelGGL((gen_fill_kernel<true>), dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, n, F->d_row, d_pos, F->d_ptr, t.dg,
+                                               F->d_col, F->d_val, F->d_diag, F->ell ? F->d_ecol : nullptr, F->d_eval, F->ell ? F->d_elen : nullptr);
+            else hipLaunchKernelGGL((gen_fill_kernel<false>), dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, n, F->d_row, d_pos, F->d_ptr, t.dg,
+                                    F->d_col, F->d_val, F->d_diag, F->ell ? F->d_ecol : nullptr, F->d_eval, F->ell ? F->d_elen : nullptr);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("factor fill kernel failed"); rc = KRYST_ERR_HIP; }   // (pos lives in a host vector reused below)
+        }
+    }
+    if (rc == KRYST_OK && hipMalloc(&D->d_mapLU, nb + 4) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+    if (rc == KRYST_OK) {
+        hipLaunchKernelGGL(gen_maplu_kernel, dim3(g), dim3(256), 0, ctx->s_main, t.posL, t.posU, n, D->d_mapLU);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
+    }
+    lap("level-ordered factors");
+    if (rc == KRYST_OK) rc = finish_ilu_device(pc, D);
+    if (rc != KRYST_OK) { kryst_pc_destroy(pc); return rc; }
+    *out = pc;
+    return KRYST_OK;
+}
+
 static int32_t download_rows(kryst_csr_t a, std::vector<int64_t>& rp, std::vector<int32_t>& col, std::vector<double>& val) {
     rp.resize((size_t)a->nrows + 1); col.resize((size_t)a->nnz); val.resize((size_t)a->nnz);
     return kryst_csr_download(a, rp.data(), col.data(), val.data());
@@ -1217,6 +1475,8 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
     {   // grid operators are factored on the device (no download, no host loops)
         kryst_pc_t pc = nullptr;
         KR_TRY(grid_setup_on_device(a, mode, &pc));
+        if (pc) { *out = pc; return KRYST_OK; }
+        KR_TRY(general_setup_on_device(a, mode, &pc));      // general operators: factor values, levels and the level-ordered factors on the device
         if (pc) { *out = pc; return KRYST_OK; }
     }
     const int64_t n = a->nrows, nnz = a->nnz;
