@@ -1205,12 +1205,14 @@ static int32_t ikj_on_device(kryst_csr_t a, const std::vector<int64_t>& rp, cons
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // GENERAL operators, everything on the device (round 3).  The host loops of kryst_pc_ilu0 download A, eliminate, split into L / U,
-// level-order both factors and upload them again; here the nnz-sized data never leave the GPU and the host only handles O(n)
-// bookkeeping (counting sorts of the rows by level, prefix sums of the row lengths):
-//   dpos / longest row -> factor values w (mode 2: dependency levels of the lower pattern, ilu0_ikj_wave_kernel; modes 0 / 1: the
-//   pointwise quotients) -> kept entries per row and the divisor -> dependency levels of L (forward) and U (backward), each a
-//   sync-free launch in which a row polls its dependencies' levels -> [host: rows by level, positions, row pointers] -> the factors
-//   written in level order straight from (A's pattern, w) -> finish_ilu_device.
+// level-order both factors and upload them again; here the VALUES never leave the GPU: the host gets A's pattern (row pointers and
+// columns, 4 bytes per entry, once) and does the symbolic part -- dependency levels of the lower and the upper pattern, the rows by
+// level, positions, row pointers -- while the device does everything that touches a value:
+//   dpos / longest row -> factor values w (mode 2: ilu0_ikj_wave_kernel in the lower pattern's level order; modes 0 / 1: the pointwise
+//   quotients) -> kept entries per row and the divisor (checked against the pattern: an operator whose factor DROPS entries -- stored or
+//   computed zeros -- takes the host path) -> the factors written in level order straight from (A's pattern, w) -> finish_ilu_device.
+// (Levels computed on the device by a sync-free launch in natural row order were tried first: half a million waiting lanes polling
+// uncached flags made a 10 716-level band matrix take 1.07 s for what the host's two O(nnz) sweeps do in 40 ms.)
 // Same kept entries, same stored order, same divisors as the host path: the apply is bit-identical (the tests run both).  Taken for
 // single-rank operators that are not candidate grid operators (more than 7 distinct offsets, or no offset dictionary at all) and
 // whose rows fit a wave (<= 64 entries); everything else, KRYST_ILU_DEVICE_SETUP=0 and any starved poll budget: the host path.
@@ -1246,37 +1248,6 @@ __global__ __launch_bounds__(256) void gen_classify_kernel(const int32_t* __rest
         if (j < i) ++a; else if (j > i) ++b; else if (divide) d = w[k];                  // ilup.rs:160-164 (missing diagonal: no divide)
     }
     nl[i] = a; nu[i] = b; dg[i] = d;
-}
-// dependency levels: level(i) = 1 + max level(j) over the row's dependencies (0 without any).  One lane per row in processing order
-// (FORWARD: ascending rows, dependencies j < i; backward: descending rows, dependencies i < j < n); a lane polls the levels it still
-// needs once per round (-1 = not known yet) and never blocks the other lanes of its wave.  KEPT: only entries with w != 0 count.
-template <bool FORWARD, bool KEPT>
-__global__ __launch_bounds__(256) void gen_level_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ w,
-                                                        int32_t n, int32_t* level, int32_t* stalled, int budget0) {
-    const int32_t tid = blockIdx.x * 256 + threadIdx.x;
-    const bool active = tid < n;
-    const int32_t i = FORWARD ? tid : n - 1 - tid;
-    int32_t k = active ? rp[i] : 0; const int32_t kend = active ? rp[i + 1] : 0;
-    int32_t lv = 0;
-    bool fin = !active;
-    for (int budget = budget0; budget > 0; --budget) {
-        if (!fin) {
-            while (k < kend) {
-                const int32_t j = col[k];
-                const bool dep = (FORWARD ? j < i : (j > i && j < n)) && (!KEPT || w[k] != 0.0);
-                if (dep) {
-                    const int32_t lj = __hip_atomic_load(&level[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (lj < 0) break;
-                    lv = max(lv, lj + 1);
-                }
-                ++k;
-            }
-            if (k == kend) { __hip_atomic_store(&level[i], lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fin = true; }
-        }
-        if (__all(fin)) return;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    if (!fin) { __hip_atomic_store(stalled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&level[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 // one factor in level order: position p holds row rowid[p]; its kept entries in stored order, columns as positions
 template <bool LOWER>
@@ -1343,13 +1314,13 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         if (cnt <= 7) return KRYST_OK;
     }
     struct Tmp {
-        double *w = nullptr, *dg = nullptr; int32_t *dpos = nullptr, *done = nullptr, *order = nullptr, *lvl = nullptr, *lvl2 = nullptr, *nl = nullptr, *nu = nullptr;
+        double *w = nullptr, *dg = nullptr; int32_t *dpos = nullptr, *done = nullptr, *order = nullptr, *nl = nullptr, *nu = nullptr;
         int32_t *posL = nullptr, *posU = nullptr; unsigned long long* flags = nullptr;
-        ~Tmp() { for (void* q : {(void*)w, (void*)dg, (void*)dpos, (void*)done, (void*)order, (void*)lvl, (void*)lvl2, (void*)nl, (void*)nu, (void*)posL, (void*)posU, (void*)flags}) (void)hipFree(q); }
+        ~Tmp() { for (void* q : {(void*)w, (void*)dg, (void*)dpos, (void*)done, (void*)order, (void*)nl, (void*)nu, (void*)posL, (void*)posU, (void*)flags}) (void)hipFree(q); }
     } t;
     const size_t nb = sizeof(int32_t) * (size_t)n;
     if (hipMalloc(&t.w, sizeof(double) * (size_t)nnz) != hipSuccess || hipMalloc(&t.dg, sizeof(double) * (size_t)n) != hipSuccess || hipMalloc(&t.dpos, nb) != hipSuccess ||
-        hipMalloc(&t.done, nb) != hipSuccess || hipMalloc(&t.order, nb) != hipSuccess || hipMalloc(&t.lvl, nb) != hipSuccess || hipMalloc(&t.lvl2, nb) != hipSuccess ||
+        hipMalloc(&t.done, nb) != hipSuccess || hipMalloc(&t.order, nb) != hipSuccess ||
         hipMalloc(&t.nl, nb) != hipSuccess || hipMalloc(&t.nu, nb) != hipSuccess || hipMalloc(&t.posL, nb) != hipSuccess || hipMalloc(&t.posU, nb) != hipSuccess ||
         hipMalloc(&t.flags, 64) != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }
     const unsigned g = (unsigned)((n + 255) / 256);
@@ -1365,18 +1336,25 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
     KR_HIP(hipMemcpyAsync(hf, t.flags, sizeof hf, hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
     if ((int32_t)hf[2] > 64) return KRYST_OK;                               // a row must fit one wave's LDS slice
-    std::vector<int32_t> lvl((size_t)n), lvlU((size_t)n), rowid, pos, lvl_off;
+    // ---- the pattern on the host: levels of the lower / upper pattern, local entries per row
+    std::vector<int32_t> hrp((size_t)n + 1), hcol((size_t)nnz), lvl((size_t)n), lvlU((size_t)n), cntL((size_t)n), cntU((size_t)n), rowid, pos, lvl_off;
+    KR_HIP(hipMemcpyAsync(hrp.data(), a->d_row_ptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipMemcpyAsync(hcol.data(), a->d_col, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    for (int32_t i = 0; i < n; ++i) {
+        int32_t lv = 0, c = 0;
+        for (int32_t k = hrp[i]; k < hrp[i + 1]; ++k) { const int32_t j = hcol[k]; if (j < i) { lv = std::max(lv, lvl[j] + 1); ++c; } }
+        lvl[i] = lv; cntL[i] = c;
+    }
+    for (int32_t i = n - 1; i >= 0; --i) {
+        int32_t lv = 0, c = 0;
+        for (int32_t k = hrp[i]; k < hrp[i + 1]; ++k) { const int32_t j = hcol[k]; if (j > i && j < n) { lv = std::max(lv, lvlU[j] + 1); ++c; } }
+        lvlU[i] = lv; cntU[i] = c;
+    }
+    lap("pattern to the host, levels");
     // ---- factor values
     if (mode == KRYST_ILU_TRUE_ILU0) {
-        KR_HIP(hipMemsetAsync(t.lvl, 0xff, nb, ctx->s_main));
-        hipLaunchKernelGGL((gen_level_kernel<true, false>), dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, n, t.lvl, d_stalled, budget);
-        KR_HIP(hipGetLastError());
-        KR_HIP(hipMemcpyAsync(lvl.data(), t.lvl, nb, hipMemcpyDeviceToHost, ctx->s_main));
-        KR_HIP(hipMemcpyAsync(hf, t.flags, sizeof hf, hipMemcpyDeviceToHost, ctx->s_main));
-        KR_HIP(hipStreamSynchronize(ctx->s_main));
-        if ((int32_t)hf[1] != 0) return KRYST_OK;
         rows_by_level(lvl, rowid, pos, lvl_off);
-        lap("pattern levels");
         KR_HIP(hipMemcpyAsync(t.order, rowid.data(), nb, hipMemcpyHostToDevice, ctx->s_main));
         hipLaunchKernelGGL(ilu0_ikj_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dpos, t.order, n, t.done,
                            t.flags, d_stalled, budget);
@@ -1384,28 +1362,23 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         hipLaunchKernelGGL(gen_pointwise_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, a->d_val, t.dpos, n, mode, t.w, t.flags);
     }
     KR_HIP(hipGetLastError());
-    // ---- kept entries, divisors, levels of both factors
+    // ---- kept entries and divisors; a factor that drops entries does not have the pattern's levels: host path
     const int divide = mode != KRYST_ILU_KRYST_COMPAT ? 1 : 0;              // ilu.rs:115-119 never divides
     hipLaunchKernelGGL(gen_classify_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, n, divide, t.nl, t.nu, t.dg);
-    KR_HIP(hipMemsetAsync(t.lvl, 0xff, nb, ctx->s_main));
-    KR_HIP(hipMemsetAsync(t.lvl2, 0xff, nb, ctx->s_main));
-    hipLaunchKernelGGL((gen_level_kernel<true, true>), dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, n, t.lvl, d_stalled, budget);
-    hipLaunchKernelGGL((gen_level_kernel<false, true>), dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, n, t.lvl2, d_stalled, budget);
     KR_HIP(hipGetLastError());
     std::vector<int32_t> nl((size_t)n), nu((size_t)n);
-    KR_HIP(hipMemcpyAsync(lvl.data(), t.lvl, nb, hipMemcpyDeviceToHost, ctx->s_main));
-    KR_HIP(hipMemcpyAsync(lvlU.data(), t.lvl2, nb, hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipMemcpyAsync(nl.data(), t.nl, nb, hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipMemcpyAsync(nu.data(), t.nu, nb, hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipMemcpyAsync(hf, t.flags, sizeof hf, hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
-    if ((int32_t)hf[1] != 0) return KRYST_OK;                               // a starved poll budget somewhere: the host path
+    if ((int32_t)hf[1] != 0) return KRYST_OK;                               // a starved poll budget: the host path
     if (hf[0] != ~0ull) {
         if (mode == KRYST_ILU_TRUE_ILU0) { const long long c = (long long)(hf[0] & 0xffffffffull); set_error("ILU(0): zero pivot at row %lld", c); set_error_row(c); return KRYST_ZERO_PIVOT; }
         set_error("ILUP: zero diagonal in U at row %lld", (long long)(hf[0] & 0xffffffffull));
         return KRYST_SOLVE_ERROR;
     }
-    lap("factor values, kept entries, levels");
+    if (nl != cntL || nu != cntU) return KRYST_OK;
+    lap("factor values, kept entries");
     // ---- the preconditioner object and its two level-ordered factors
     kryst_pc_t pc = new kryst_pc_s();
     pc->ctx = ctx; pc->kind = KR_PC_ILU; pc->a = a; pc->n = n; pc->ilu_mode = mode; pc->divide_diag = divide;
