@@ -1301,7 +1301,8 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto t0 = tnow();
     auto lap = [&](const char* what) { if (verbose) { fprintf(stderr, "[kryst ilu]   device setup: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(tnow() - t0).count()); t0 = tnow(); } };
-    if (a->d_code) {                         // a handful of offsets: a candidate grid operator -- the host path recognises those and takes the wavefront kernels
+    if (a->d_code) {                         // a handful of offsets: a candidate grid operator (thin boxes, 2-D operators the device-side grid
+                                             // setup passed on) -- the host path recognises those and takes the wavefront kernels
         int32_t used[256]; int32_t* d_used = nullptr;
         KR_HIP(hipMalloc(&d_used, sizeof used));
         (void)hipMemsetAsync(d_used, 0, sizeof used, ctx->s_main);
@@ -1311,7 +1312,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }
         int cnt = 0;
         for (int q = 0; q < 256; ++q) cnt += used[q] ? 1 : 0;
-        if (cnt <= 7) return KRYST_OK;
+        if (cnt <= 7 && env_i("KRYST_ILU_GRID", 1) != 0) return KRYST_OK;      // (with the grid forms switched off nothing would recognise it anyway)
     }
     struct Tmp {
         double *w = nullptr, *dg = nullptr; int32_t *dpos = nullptr, *done = nullptr, *order = nullptr, *nl = nullptr, *nu = nullptr;
