@@ -1214,7 +1214,8 @@ static int32_t ikj_on_device(kryst_csr_t a, const std::vector<int64_t>& rp, cons
 // (Levels computed on the device by a sync-free launch in natural row order were tried first: half a million waiting lanes polling
 // uncached flags made a 10 716-level band matrix take 1.07 s for what the host's two O(nnz) sweeps do in 40 ms.)
 // Same kept entries, same stored order, same divisors as the host path: the apply is bit-identical (the tests run both).  Taken for
-// single-rank operators that are not candidate grid operators (more than 7 distinct offsets, or no offset dictionary at all) and
+// operators -- a rank's diagonal block included: halo columns (>= n) are skipped everywhere -- that are not candidate grid operators
+// (more than 7 distinct offsets, 9 for a distributed block; or no offset dictionary at all) and
 // whose rows fit a wave (<= 64 entries); everything else, KRYST_ILU_DEVICE_SETUP=0 and any starved poll budget: the host path.
 __global__ __launch_bounds__(256) void gen_rowmax_kernel(const int32_t* __restrict__ rp, int32_t n, int32_t* maxlen) {
     const int32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -1294,7 +1295,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
     *out = nullptr;
     kryst_ctx_t ctx = a->ctx;
     const int64_t n64 = a->nrows, nnz = a->nnz;
-    if (a->dist || n64 == 0 || nnz == 0 || n64 >= (1ll << 31) - 4 || env_i("KRYST_ILU_DEVICE_SETUP", 1) == 0) return KRYST_OK;
+    if (n64 == 0 || nnz == 0 || n64 >= (1ll << 31) - 4 || env_i("KRYST_ILU_DEVICE_SETUP", 1) == 0) return KRYST_OK;
     const int32_t n = (int32_t)n64;
     tl_setup_stream = ctx->s_main;
     const bool verbose = getenv("KRYST_ILU_VERBOSE") != nullptr;
@@ -1312,7 +1313,8 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }
         int cnt = 0;
         for (int q = 0; q < 256; ++q) cnt += used[q] ? 1 : 0;
-        if (cnt <= 7 && env_i("KRYST_ILU_GRID", 1) != 0) return KRYST_OK;      // (with the grid forms switched off nothing would recognise it anyway)
+        // (a row block of a distributed grid operator lists up to two halo offsets besides its seven)
+        if (cnt <= (a->dist ? 9 : 7) && env_i("KRYST_ILU_GRID", 1) != 0) return KRYST_OK;      // (with the grid forms switched off nothing would recognise it anyway)
     }
     struct Tmp {
         double *w = nullptr, *dg = nullptr; int32_t *dpos = nullptr, *done = nullptr, *order = nullptr, *nl = nullptr, *nu = nullptr;
