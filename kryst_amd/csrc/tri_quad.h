@@ -186,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     __shared__ int taken[4];                                               // chunks each solving wave has taken off the stage
     __shared__ int exported[4];                                            // producer steps each exporter stream has written to the edge buffers
     __shared__ int written[4];                                             // chunks of each solving wave's results the loader waves have stored to the caller's vector
-    __shared__ uint8_t skipf[4 * TQ_SKIPMAX];                              // per solving wave: chunk m needs no coefficient request (chunks past the end: 1)
+    __shared__ uint8_t skipf[4 * TQ_SKIPMAX];                              // per solving wave and chunk m, a 3-bit code: bit d = chunk m + d needs a coefficient request
     __shared__ int staged[2], quit, always, gate;                          // gate: the producers are under way (set by the poller)                                // chunks each loader wave has staged (quadrants 0-1 / 2-3)
     cgdouble* in = (cgdouble*)(in_ptr ? in_ptr : args->r);
     gdouble* out = (gdouble*)(out_ptr ? out_ptr : args->z);
@@ -211,7 +211,16 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     if (threadIdx.x == 0) { staged[0] = 0; staged[1] = 0; quit = 0; always = HUGE_STEPS; gate = (J == 0 && K == 0) ? 1 : 0; }
     for (int i = threadIdx.x; i < 4 * TQ_SKIPMAX; i += 512) {               // (before any hand-counted request is in flight)
         const int qq = i / TQ_SKIPMAX, m = i % TQ_SKIPMAX;
-        skipf[i] = m >= nch ? 1 : (Q.skip && nch + 3 <= TQ_SKIPMAX) ? Q.skip[((size_t)blk * 4 + qq) * nch + m] : 0;
+        // (one look-up per chunk answers all three questions the solving wave has about it and the two requests behind it: four
+        // separate flag reads, each a dependent LDS round trip on the wave's critical path, cost 8 % of a chunk)
+        const bool flags_on = Q.skip && nch + 3 <= TQ_SKIPMAX;
+        unsigned code = 0;
+        for (int d = 0; d < 3; ++d) {
+            const int md = m + d;
+            const bool need = md < nch && !(flags_on && Q.skip[((size_t)blk * 4 + qq) * nch + md] != 0);
+            code |= need ? (1u << d) : 0u;
+        }
+        skipf[i] = (uint8_t)code;
     }
     for (int i = threadIdx.x; i < 4 * R * 8; i += 512) pring[i] = 0.0;
     for (int i = threadIdx.x; i < 4 * YR * 64; i += 512) yring[i] = 0.0;
@@ -540,13 +549,17 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     // Chunk m needs a request unless its coefficients equal chunk m - 3's bit for bit: those sit in its buffer already (flags from
     // setup, tri_quad_dedup_kernel; chunks past the end count as "no request").
     const uint8_t* const my_skip = skipf + q * TQ_SKIPMAX;
-    // (m < nch explicitly: lines longer than the flag table -- Ni > 4 330 -- read its last entry, which then belongs to a real chunk)
-    auto needs = [&](int m) -> bool { return m < nch && my_skip[min(m, TQ_SKIPMAX - 1)] == 0; };
+    // code of chunk m: bit d set = chunk m + d needs a request.  Lines longer than the table (Ni > 4 330) run without repeat flags, so
+    // beyond the table the code is arithmetic (chunks past the end never need one).
+    auto code_of = [&](int m) -> unsigned {
+        if (m < TQ_SKIPMAX) return my_skip[m];
+        return (m < nch ? 1u : 0u) | (m + 1 < nch ? 2u : 0u) | (m + 2 < nch ? 4u : 0u);
+    };
     // before chunk m is computed: vector-memory operations younger than its request = the (up to) two later requests of 4 NA loads
     // each; the wave issues nothing else (its results are stored by the loader wave)
-    auto arrive = [&](Coef& cf, int m) __attribute__((always_inline)) {
-        if (!needs(m)) return;                                             // nothing was requested: the values are there (and were waited for then)
-        const int nf = (needs(m + 1) ? 1 : 0) + (needs(m + 2) ? 1 : 0);
+    auto arrive = [&](Coef& cf, unsigned code) __attribute__((always_inline)) {
+        if (!(code & 1u)) return;                                          // nothing was requested: the values are there (and were waited for then)
+        const int nf = (int)((code >> 1) & 1u) + (int)((code >> 2) & 1u);
         if (nf == 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 * NA) : "memory");
         else if (nf == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * NA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -679,15 +692,19 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     for (int budget = 1 << 24; tq_peek(&gate) == 0 && budget > 0; --budget) TQ_NAP(8);     // (see the loader)
     TQ_STAMP(0);
     fetch(c0, 0);                                                      // (chunks 0-2 always need their request)
-    if (needs(1)) fetch(c1, 1);
+    unsigned code_a = code_of(0);                                      // the code of a chunk is read one chunk ahead of its use
+    if (code_a & 2u) fetch(c1, 1);
 #pragma unroll 1
     for (int kc = 0; kc < nch; kc += 3) {
-        TQ_T0(tf0); if (needs(kc + 2)) fetch(c2, kc + 2); TQ_ACC(17, tf0);
-        TQ_T0(ta0); arrive(c0, kc); TQ_ACC(14, ta0); process(c0, kc);
-        TQ_T0(tf1); if (needs(kc + 3)) fetch(c0, kc + 3); TQ_ACC(17, tf1);
-        if (kc + 1 < nch) { TQ_T0(ta1); arrive(c1, kc + 1); TQ_ACC(14, ta1); process(c1, kc + 1); }
-        TQ_T0(tf2); if (needs(kc + 4)) fetch(c1, kc + 4); TQ_ACC(17, tf2);
-        if (kc + 2 < nch) { TQ_T0(ta2); arrive(c2, kc + 2); TQ_ACC(14, ta2); process(c2, kc + 2); }
+        TQ_T0(tf0); if (code_a & 4u) fetch(c2, kc + 2); TQ_ACC(17, tf0);
+        const unsigned code_b = code_of(kc + 1);
+        TQ_T0(ta0); arrive(c0, code_a); TQ_ACC(14, ta0); process(c0, kc);
+        TQ_T0(tf1); if (code_b & 4u) fetch(c0, kc + 3); TQ_ACC(17, tf1);
+        const unsigned code_c = code_of(kc + 2);
+        if (kc + 1 < nch) { TQ_T0(ta1); arrive(c1, code_b); TQ_ACC(14, ta1); process(c1, kc + 1); }
+        TQ_T0(tf2); if (code_c & 4u) fetch(c1, kc + 4); TQ_ACC(17, tf2);
+        code_a = code_of(kc + 3);
+        if (kc + 2 < nch) { TQ_T0(ta2); arrive(c2, code_c); TQ_ACC(14, ta2); process(c2, kc + 2); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (requests past the end: nothing of this wave's is in flight from here)
 #ifdef KR_TW_TRACE
