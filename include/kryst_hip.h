@@ -127,6 +127,10 @@ int32_t kryst_csr_shape(kryst_csr_t a, int64_t* nrows_local, int64_t* ncols_glob
  * well-filled diagonals that have no D16 / P16 form, e.g. variable-coefficient stencils).  patterns / table_entries (may be NULL):
  * size of the P16 tables. */
 int32_t kryst_csr_encoding(kryst_csr_t a, int32_t* encoding, int32_t* patterns, int32_t* table_entries);
+/* measurement hook: the order in which an operator's 512-row tiles are handed to the XCDs (plane-structured operators walk the
+ * plane segment by segment so that an XCD's L2 keeps its window of x; which rows a tile holds and every result bit are unchanged).
+ * info[0] rows per plane (0: natural order only), info[1], info[2] slots of the two orders, info[3] 1 if kryst_spmv uses it now */
+int32_t kryst_csr_tile_order(kryst_csr_t a, int64_t* info);
 int32_t kryst_csr_download(kryst_csr_t a, int64_t* row_ptr, int32_t* col_idx_local, double* vals);
 
 /* MatVec::matvec (src/core/traits.rs:4-7) == SparseMatrix::spmv (sparse.rs:56-67): y <- A x, y overwritten */

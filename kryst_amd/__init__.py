@@ -289,6 +289,12 @@ class CsrMatrix:
         check(lib().kryst_csr_encoding(self.h, C.byref(e), C.byref(p), C.byref(t)))
         return self.ENCODINGS[e.value], p.value, t.value
 
+    def tile_order(self):
+        """Measurement hook (kryst_csr_tile_order): {"plane_rows", "slots", "slots8", "in_use"} of the slab order of the tiles."""
+        info = (C.c_int64 * 4)()
+        check(lib().kryst_csr_tile_order(self.h, info))
+        return {"plane_rows": info[0], "slots": info[1], "slots8": info[2], "in_use": bool(info[3])}
+
     def bench_spmv(self, x, y, fused_dots=1, reps=50):
         """Average milliseconds per launch of the SpMV kernel (HIP events on the compute stream)."""
         ms = C.c_double()

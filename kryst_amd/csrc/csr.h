@@ -36,6 +36,9 @@ struct kryst_csr_s {
     int32_t dia_off[kr::KR_DIA_MAX] = {0};      // col - row of diagonal d (a halo slot's local column for the halo diagonals), in the rows' stored order
     int32_t dia_min = 0, dia_max = 0;   // over the diagonals that address x itself
     int64_t ntiles = 0;
+    // slab order of the tiles for plane-structured operators (csr_create.hip: build_tile_order), or nullptr: slot -> tile (-1: none);
+    // the first order_slots1 entries for runs of 1 slot per XCD, then order_slots8 entries for runs of 8
+    int32_t* d_tile_order = nullptr; int64_t order_slots1 = 0, order_slots8 = 0, order_plane = 0;   // order_plane: b, rows per plane
     int slots = 7;            // SpMV pair slots per lane (picked from the average nnz of a 128-row slice)
     // distributed
     bool dist = false;

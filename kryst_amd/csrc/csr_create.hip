@@ -8,6 +8,15 @@
 
 namespace kr {
 
+// host -> device on the context's compute stream, waited for: the compute stream is non-blocking, so nothing issued on the null
+// stream orders with it (DESIGN.md section 6, the round-2 fault)
+static int32_t h2d(kryst_ctx_t ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return KRYST_OK;
+    KR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    return KRYST_OK;
+}
+
 // CSR-P16: number the distinct rows (as sequences of (col - row, value bits)); give up as soon as the tables outgrow LDS
 static int32_t upload_patterns(kryst_csr_t a, const std::vector<uint16_t>& pid, const std::vector<uint32_t>& meta /* 2 words per pattern */,
                                const std::vector<int32_t>& poff, const std::vector<double>& pval) {
@@ -249,6 +258,60 @@ static int32_t build_dia(kryst_csr_t a) {
     return KRYST_OK;
 }
 
+// ---------------------------------------------------------------- tile order (plane-structured operators)
+// An operator whose entries sit near the main diagonal and near ONE far pair of diagonals +-b (every stencil on a structured grid:
+// b = one grid plane) re-reads x[row - b] and x[row + b] one and two planes after x[row] went by: in natural tile order an XCD's L2
+// has to hold 16 b bytes of x for that (4 MiB at 512^3 -- it does not), and because consecutive tiles go to different XCDs every
+// line of x is fetched by two or three of them.  The tiles are therefore handed out in SLAB order: the plane is cut into S = 8, 16, ...
+// segments of L rows (16 L bytes <= 1 MiB), XCD x walks segment x of plane 0, 1, 2, ... (then segment x + 7, ...), so that an XCD's
+// window of x is 2 L rows and only the segments' edges are shared.  Which rows a tile holds, the order inside a row and the order in
+// which the tile partials of the fused inner products are folded do not change: same bits.  order1 / order8: slot -> tile (or -1)
+// in the kernels' slot numbering for runs of 1 / 8 consecutive slots per XCD (spmv.hip: tile -> workgroup map).
+static int32_t build_tile_order(kryst_csr_t a) {
+    kryst_ctx_t ctx = a->ctx;
+    if (env_int("KRYST_SPMV_ORDER", 1) == 0 || !a->d_code || !a->d_dict || a->nnz == 0 || a->dist || a->ntiles < 64) return KRYST_OK;
+    struct Scratch { unsigned* u = nullptr; ~Scratch() { (void)hipFree(u); } } sc;
+    KR_HIP(hipMalloc(&sc.u, sizeof(unsigned) * 8));
+    KR_HIP(hipMemsetAsync(sc.u, 0, sizeof(unsigned) * 8, ctx->s_main));
+    hipLaunchKernelGGL(dia_usage_kernel, dim3((unsigned)std::min<int64_t>(4096, (a->nnz + 255) / 256)), dim3(256), 0, ctx->s_main, a->d_code, a->nnz, sc.u);
+    KR_HIP(hipGetLastError());
+    unsigned used[8]; int32_t dict[256];
+    KR_HIP(hipMemcpyAsync(used, sc.u, sizeof used, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipMemcpyAsync(dict, a->d_dict, sizeof dict, hipMemcpyDeviceToHost, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    int64_t b = 0;
+    for (int c = 0; c < 256; ++c) if ((used[c >> 5] >> (c & 31)) & 1u) b = std::max<int64_t>(b, std::llabs((long long)dict[c]));
+    if (b < env_int("KRYST_SPMV_ORDER_MIN_PLANE", 65536)) return KRYST_OK;          // 16 b bytes < 1 MiB: the window fits as it is
+    int64_t w = 0;                                                                      // how far an entry strays from 0 / +-b
+    for (int c = 0; c < 256; ++c) if ((used[c >> 5] >> (c & 31)) & 1u) {
+        const int64_t o = std::llabs((long long)dict[c]);
+        w = std::max(w, std::min(o, b - o));
+    }
+    const int64_t lmax = env_int("KRYST_SPMV_ORDER_SEG_ROWS", 65536);
+    const int64_t S = 8 * ((b + 8 * lmax - 1) / (8 * lmax));
+    const int64_t L = b / S;                                                            // (a tile belongs to the segment its first row falls into)
+    if (L < 4 * KR_TILE || 8 * w > L) return KRYST_OK;                                  // segments of a few tiles / mostly edge: not worth it
+    std::vector<int32_t> seq[8];
+    for (int64_t p = 0; p < S / 8; ++p)
+        for (int64_t q = 0; q < a->ntiles; ++q) {
+            const int64_t seg = std::min((q * KR_TILE) % b * S / b, S - 1);
+            if (seg / 8 == p) seq[(seg + p) % 8].push_back((int32_t)q);              // (+ p: segments of 4 and 5 tiles alternate; mix them)
+        }
+    size_t longest = 0;
+    for (int x = 0; x < 8; ++x) longest = std::max(longest, seq[x].size());
+    const size_t c1 = longest, c8 = (longest + 7) / 8 * 8;
+    std::vector<int32_t> order(8 * c1 + 8 * c8, -1);
+    for (int x = 0; x < 8; ++x)
+        for (size_t li = 0; li < seq[x].size(); ++li) {
+            order[li * 8 + x] = seq[x][li];
+            order[8 * c1 + ((li / 8) * 8 + x) * 8 + li % 8] = seq[x][li];
+        }
+    if (hipMalloc(&a->d_tile_order, sizeof(int32_t) * order.size()) != hipSuccess) { (void)hipGetLastError(); a->d_tile_order = nullptr; return KRYST_OK; }   // optional
+    KR_TRY(h2d(ctx, a->d_tile_order, order.data(), sizeof(int32_t) * order.size()));
+    a->order_slots1 = (int64_t)(8 * c1); a->order_slots8 = (int64_t)(8 * c8); a->order_plane = b;
+    return KRYST_OK;
+}
+
 // ---------------------------------------------------------------- creation
 static int32_t upload_csr(kryst_csr_t a, const std::vector<int32_t>& rp, const std::vector<int32_t>& col, const double* val) {
     kryst_ctx_t ctx = a->ctx;
@@ -329,6 +392,7 @@ static int32_t upload_csr(kryst_csr_t a, const std::vector<int32_t>& rp, const s
     a->slots = per_slice <= 256.0 ? 2 : (per_slice <= 512.0 ? 4 : 7);
     KR_TRY(build_patterns(a, rp, col, val));
     KR_TRY(build_dia(a));
+    KR_TRY(build_tile_order(a));
     return KRYST_OK;
 }
 
@@ -383,15 +447,6 @@ int32_t kryst_csr_create_i32(kryst_ctx_t ctx, int64_t nrows, int64_t ncols, cons
                              const double* vals, kryst_csr_t* out) {
     KR_ARG(ctx && ctx->nranks == 1, "csr_create needs a single-rank context (use kryst_csr_create_dist)");
     return create_local(ctx, nrows, ncols, row_ptr, col_idx, vals, out);
-}
-
-// host -> device on the context's compute stream, waited for: the compute stream is non-blocking, so nothing issued on the null
-// stream orders with it (DESIGN.md section 6, the round-2 fault)
-static int32_t h2d(kryst_ctx_t ctx, void* dst, const void* src, size_t bytes) {
-    if (bytes == 0) return KRYST_OK;
-    KR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->s_main));
-    KR_HIP(hipStreamSynchronize(ctx->s_main));
-    return KRYST_OK;
 }
 
 // Phase 1 of kryst_csr_create_dist: everything that involves this rank alone (validation, halo receive plan, local column
@@ -691,6 +746,7 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
         a->ntiles = ntiles_of(nloc);
         a->slots = 7;
         if ((rc = build_dia(a)) != KRYST_OK) break;
+        if ((rc = build_tile_order(a)) != KRYST_OK) break;
         if (!dist) break;
         // analytic halo plan of a k-slab partition: one grid plane from each neighbour, sent in place
         HaloPlan& pl = a->plan;
@@ -754,7 +810,7 @@ int32_t kryst_csr_destroy(kryst_csr_t a) {
     (void)hipStreamSynchronize(a->ctx->s_comm);
     (void)hipFree(a->d_row_ptr); (void)hipFree(a->d_col); (void)hipFree(a->d_val); (void)hipFree(a->d_code); (void)hipFree(a->d_dict); (void)hipFree(a->d_code16); (void)hipFree(a->d_vdict);
     (void)hipFree(a->d_pid); (void)hipFree(a->d_pmeta); (void)hipFree(a->d_poff); (void)hipFree(a->d_pval); (void)hipFree(a->d_dia);
-    (void)hipFree(a->d_tiles_interior); (void)hipFree(a->d_tiles_boundary);
+    (void)hipFree(a->d_tiles_interior); (void)hipFree(a->d_tiles_boundary); (void)hipFree(a->d_tile_order);
     (void)hipFree(a->plan.d_send_idx); (void)hipFree(a->plan.d_sendbuf); (void)hipFree(a->plan.d_halo);
     delete a;
     return KRYST_OK;

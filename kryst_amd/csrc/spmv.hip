@@ -102,6 +102,7 @@ __global__ __launch_bounds__(KR_T, MINW) void spmv_wave_kernel(const SpmvArgs a)
         else ti = ((li / a.group) * 8 + xcd) * a.group + (li % a.group);
         if (ti >= a.ntiles) { if (a.swizzle) break; else continue; }
         const int q = a.tiles ? a.tiles[ti] : ti;
+        if (q < 0) continue;                                    // an empty slot of the slab order
         const int r0 = q * KR_TILE;
         const int r1 = min(r0 + KR_TILE, a.nrows);
         const int wr0 = min(r0 + 128 * w, r1), wr1 = min(wr0 + 128, r1);
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(KR_T) void spmv_rows_kernel(const SpmvArgs a) {
         else ti = ((li / a.group) * 8 + xcd) * a.group + (li % a.group);
         if (ti >= a.ntiles) { if (a.swizzle) break; else continue; }
         const int q = a.tiles ? a.tiles[ti] : ti;
+        if (q < 0) continue;                                    // an empty slot of the slab order
         const int r0 = q * KR_TILE;
         const int r1 = min(r0 + KR_TILE, a.nrows);
         const int wr0 = min(r0 + 128 * w, r1), wr1 = min(wr0 + 128, r1);
@@ -352,6 +354,7 @@ __global__ __launch_bounds__(KR_T) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         else ti = ((li / a.group) * 8 + xcd) * a.group + (li % a.group);
         if (ti >= a.ntiles) { if (a.swizzle) break; else continue; }
         const int q = a.tiles ? a.tiles[ti] : ti;
+        if (q < 0) continue;                                    // an empty slot of the slab order
         const int r0 = q * KR_TILE;
         const int r1 = min(r0 + KR_TILE, a.nrows);
         const int wr0 = min(r0 + 128 * w, r1), wr1 = min(wr0 + 128, r1);
@@ -632,6 +635,7 @@ __global__ __launch_bounds__(KR_T) void spmv_dia_kernel(const SpmvArgs a) {
         else ti = ((li / a.group) * 8 + xcd) * a.group + (li % a.group);
         if (ti >= a.ntiles) { if (a.swizzle) break; else continue; }
         const int q = a.tiles ? a.tiles[ti] : ti;
+        if (q < 0) continue;                                    // an empty slot of the slab order
         const int r0 = q * KR_TILE;
         const int r1 = min(r0 + KR_TILE, a.nrows);
         const int row = r0 + 2 * t;
@@ -671,6 +675,27 @@ __global__ void pack_kernel(const double* x, const int32_t* idx, double* out, in
 // tuning knobs (read per launch so that one process can A/B them)
 static int spmv_blocks_per_cu() { return env_int("KRYST_SPMV_BLOCKS_PER_CU", 0); }
 
+// Which kernel a launch takes is decided from the forms the operator has and the KRYST_SPMV_* settings (read per launch).
+static bool takes_pattern_path(kryst_csr_t a, bool halo) {
+    return a->d_pid && env_int("KRYST_SPMV_COMPRESS", 3) >= 3 && a->xlen + (halo ? a->plan.total_recv : 0) < (1ll << 28) && a->nrows < (1ll << 28);
+}
+// slab order (csr_create.hip: build_tile_order) for a whole local operator.  KRYST_SPMV_ORDER: 1 (default) where it was measured
+// to pay -- the CSR-DIA kernel, and the plain kernel once two planes of x outgrow an XCD's L2 (in-process A/B, tools/spmv_ab.py,
+// profiles/r03/slab_order/: plain 512^3 +1.3-2.2 %, 448^3 -1.4 %, 384^3 -1.1 %, 256^3 -2.2 %; CSR-DIA 512^3 / 256^3 +0.4 / +1.9 %;
+// CSR-D8 -2.4 / -3.6 %, CSR-D16 -0.7 / -2.9 %, CSR-P16 -4.8 / -4.6 % -- although the x re-reads go away in every form: 17.3 -> 14.3 GB
+// per launch through the fabric for plain CSR at 512^3, 11.8 -> 9.7 GB for CSR-DIA); 2 every kernel; 0 never
+static bool uses_tile_order(kryst_csr_t a) {
+    if (!a->d_tile_order || a->dist) return false;
+    const int order_mode = env_int("KRYST_SPMV_ORDER", 1);
+    if (order_mode <= 0) return false;
+    if (order_mode >= 2) return true;
+    const int form_level = env_int("KRYST_SPMV_COMPRESS", 3);
+    if (takes_pattern_path(a, false) || (a->d_code16 && form_level >= 2)) return false;
+    if (a->d_dia && form_level >= 1 && env_int("KRYST_SPMV_DIA", 1) != 0) return true;
+    const bool plain_path = !(a->d_code && form_level != 0) && env_int("KRYST_SPMV_KERNEL", 2) != 3;
+    return plain_path && a->order_plane >= 262144;
+}
+
 template <bool HALO>
 static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, const double* dvec, const int* done,
                             const int32_t* tiles, int64_t ntiles) {
@@ -679,14 +704,24 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
     SpmvArgs args;
     args.row_ptr = a->d_row_ptr; args.col = a->d_col; args.val = a->d_val;
     args.x = x; args.halo = a->plan.d_halo; args.nloc = (int32_t)a->nrows;
+    const bool pattern_path = takes_pattern_path(a, HALO);
+    const bool ordered = !tiles && !HALO && ntiles == a->ntiles && uses_tile_order(a);
+    if (ordered) {
+        tiles = pattern_path ? a->d_tile_order + a->order_slots1 : a->d_tile_order;
+        ntiles = pattern_path ? a->order_slots8 : a->order_slots1;
+    }
     args.y = y; args.tiles = tiles; args.ntiles = (int32_t)ntiles; args.nrows = (int32_t)a->nrows;
     args.dvec = dvec; args.partials = ctx->d_partials; args.pstride = ctx->partials_cap; args.done = done;
     args.swizzle = env_int("KRYST_SPMV_SWIZZLE", 0);
-    args.amask = env_int("KRYST_SPMV_ALIGN", 0) ? 31 : 1;
+    // the plain kernel beyond the Infinity Cache: nontemporal matrix streams in windows that start on whole memory lines (in-process
+    // A/B, tools/spmv_ab.py, profiles/r03/slab_order/: 384^3 +0.8 %, 448^3 +1.6-2.0 %, 512^3 +1.1-2.1 %; nontemporal loads alone lose 1 %)
+    const bool beyond_cache = a->nrows * 8 > (256ll << 20);
+    args.amask = env_int("KRYST_SPMV_ALIGN", beyond_cache ? 1 : 0) ? 31 : 1;
 #ifdef KR_TUNING
     args.abl = env_int("KRYST_SPMV_ABL", 0);
 #endif
-    args.group = std::max(1, env_int("KRYST_SPMV_GROUP", 1));
+    args.group = ordered ? 1 : std::max(1, env_int("KRYST_SPMV_GROUP", 1));
+    if (ordered) args.swizzle = 0;
     int64_t chunk = (ntiles + 7) / 8;                       // tiles per XCD
     if (!args.swizzle) chunk = (chunk + args.group - 1) / args.group * args.group;   // a whole number of runs of `group` tiles
     args.xcd_chunk = (int32_t)chunk;
@@ -704,11 +739,11 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
     args.code = comp ? a->d_code : nullptr; args.dict = comp ? a->d_dict : nullptr;
     args.code16 = a->d_code16; args.vdict = a->d_vdict;
     args.pid = a->d_pid; args.pmeta = a->d_pmeta; args.poff = a->d_poff; args.pval = a->d_pval; args.npat = a->npat; args.ntab = a->ntab;
-    if (a->d_pid && comp_level >= 3 && a->xlen + (HALO ? a->plan.total_recv : 0) < (1ll << 28) && a->nrows < (1ll << 28)) {   // 32-bit byte offsets
+    if (pattern_path) {   // (32-bit byte offsets: xlen < 2^28)
         // a workgroup loads the tables once and walks one run of 8 consecutive tiles (next tile's ids prefetched); runs go
         // round-robin over the XCDs.  Measured at 512^3 (round-2 sweeps and --pmc passes, profiles/r02/): 0.70 ms and 1.6 GB of reads
         // per launch, against 0.79 ms and 4.1 GB for a strided persistent grid whose fast workgroups run ahead.
-        args.group = std::max(1, env_int("KRYST_SPMV_GROUP", 8));
+        args.group = ordered ? 8 : std::max(1, env_int("KRYST_SPMV_GROUP", 8));
         const int64_t pchunk = (chunk + args.group - 1) / args.group * args.group;      // an XCD's share is a whole number of runs
         args.xcd_chunk = (int32_t)pchunk;
         args.tpw = std::max(1, env_int("KRYST_SPMV_PATTERN_TPW", 8));
@@ -793,7 +828,7 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
         KR_HIP(hipGetLastError());
         return KRYST_OK;
     }
-    const bool nt = env_int("KRYST_SPMV_NT", 0) != 0;
+    const bool nt = env_int("KRYST_SPMV_NT", beyond_cache ? 1 : 0) != 0;
     // window size of the plain kernel: one window per 128-row slice (7 pair slots for a 7-point stencil's 896 entries) while the
     // vectors fit the 256 MiB Infinity Cache, 4 slots (74 registers, 6 waves per SIMD instead of 4) beyond it -- measured
     // (profiles/r02/plain_csr_study/README.md): 256^3 0.298 / 0.309 ms with 7 / 4 slots, 512^3 2.84 / 2.62 ms
@@ -884,6 +919,15 @@ int32_t kryst_csr_encoding(kryst_csr_t a, int32_t* encoding, int32_t* patterns, 
     *encoding = e;
     if (patterns) *patterns = e == 4 ? a->dia_nd : (a->d_pid ? a->npat : 0);      // CSR-DIA: the number of diagonals
     if (table_entries) *table_entries = a->d_pid ? a->ntab : 0;
+    return KRYST_OK;
+}
+
+// info[0]: rows per plane of the slab order (0: the operator has none), info[1] / info[2]: tile slots in the orders for runs of 1 / 8
+// slots per XCD, info[3]: 1 when kryst_spmv would use the order under the current settings
+int32_t kryst_csr_tile_order(kryst_csr_t a, int64_t* info) {
+    KR_ARG(a && info, "csr_tile_order");
+    info[0] = a->d_tile_order ? a->order_plane : 0; info[1] = a->order_slots1; info[2] = a->order_slots8;
+    info[3] = uses_tile_order(a) ? 1 : 0;
     return KRYST_OK;
 }
 

@@ -192,6 +192,66 @@ def test_spmv_diagonal_streams_form_bit_exact(ctx, monkeypatch):
     assert st.iterations == res.iterations and np.array_equal(xx, res.x) and np.array_equal(np.array(s.residual_history), res.history)
 
 
+@pytest.mark.parametrize("compress,dia", [("0", "0"), ("1", "0"), ("1", "2"), ("2", "0"), ("3", "0")])
+def test_spmv_slab_order_of_the_tiles_bit_exact(ctx, compress, dia, monkeypatch):
+    """The slab order of the tiles (csr_create.hip: build_tile_order -- plane-structured operators hand their tiles to the XCDs segment by
+    segment of the plane) changes which workgroup computes a tile, nothing else: y, the fused inner products and whole solves are bit
+    for bit those of the natural order and of the oracle, in every storage form (KRYST_SPMV_ORDER=2: all kernels), on cubes, on boxes
+    whose planes are not a whole number of tiles (uneven shares: empty slots), with two passes of segments, and on operators that must
+    NOT get an order (entries far from 0 and +-b; small planes).  The thresholds are lowered so that 10^5-row cases qualify."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("KRYST_SPMV_COMPRESS", compress); monkeypatch.setenv("KRYST_SPMV_DIA", dia)
+    monkeypatch.setenv("KRYST_SPMV_ORDER", "2"); monkeypatch.setenv("KRYST_SPMV_ORDER_MIN_PLANE", "8192")
+    rng = np.random.default_rng(77)
+
+    def box7(ni, nj, nk, values="random"):
+        e = lambda n: sp.diags([np.ones(n - 1), np.ones(n), np.ones(n - 1)], [-1, 0, 1])
+        pat = (sp.kron(sp.identity(nk), sp.kron(sp.identity(nj), e(ni))) + sp.kron(sp.identity(nk), sp.kron(e(nj), sp.identity(ni))) +
+               sp.kron(e(nk), sp.identity(nj * ni))).tocsr()
+        pat.sort_indices()
+        vals = rng.standard_normal(pat.nnz) if values == "random" else rng.choice([-1.0, 6.0, 0.5], pat.nnz)
+        return O.Csr(pat.shape[0], pat.shape[1], pat.indptr, pat.indices, vals)
+
+    cases = [(box7(150, 150, 9), True), (box7(128, 128, 7, "few"), True), (box7(100, 250, 6), True), (box7(40, 40, 40), False)]
+    for a, qualifies in cases:
+        monkeypatch.setenv("KRYST_SPMV_ORDER", "2")
+        d = to_dev(ctx, a)
+        info = d.tile_order()
+        assert (info["plane_rows"] > 0) == qualifies and info["in_use"] == qualifies, info
+        if qualifies:
+            ntiles = (a.nrows + 511) // 512
+            assert info["slots"] >= ntiles and info["slots8"] >= info["slots"] and info["slots"] % 8 == 0 and info["slots8"] % 64 == 0
+        x = rng.standard_normal(a.ncols)
+        want = a.spmv(x)
+        assert np.array_equal(d.spmv(x), want), (compress, dia, a.nrows)
+        monkeypatch.setenv("KRYST_SPMV_ORDER", "0")              # read per launch: the same operator in natural order
+        assert not d.tile_order()["in_use"]
+        assert np.array_equal(d.spmv(x), want)
+        monkeypatch.setenv("KRYST_SPMV_ORDER", "1")              # the default policy: CSR-DIA always, plain CSR from 262144-row planes, the coded forms never
+        assert d.tile_order()["in_use"] == (qualifies and d.encoding()[0] == "csr-dia")
+    # two passes of segments (16 segments of 2304 rows per plane of 192 x 192: an XCD walks segment x, then segment x + 8), the
+    # generator-made operator, fused inner products in a solve
+    monkeypatch.setenv("KRYST_SPMV_ORDER", "2"); monkeypatch.setenv("KRYST_SPMV_ORDER_SEG_ROWS", "2560")
+    N = 192
+    for kind in ("varcoef", "poisson"):
+        monkeypatch.setenv("KRYST_SPMV_ORDER", "2")              # (KRYST_SPMV_ORDER=0 at creation: no order is built)
+        a = K.CsrMatrix.stencil7(N, kind, ctx=ctx)
+        n = a.nrows()
+        assert a.tile_order()["plane_rows"] == N * N and n // 512 <= a.tile_order()["slots"] <= 1.03 * n / 512     # even shares
+        xs = rng.standard_normal(n)
+        monkeypatch.setenv("KRYST_SPMV_ORDER", "2"); y2 = a.spmv(xs)
+        monkeypatch.setenv("KRYST_SPMV_ORDER", "0"); y0 = a.spmv(xs)
+        assert np.array_equal(y2, y0)
+        b = a.spmv(np.ones(n))
+        out = []
+        for order in ("2", "0"):
+            monkeypatch.setenv("KRYST_SPMV_ORDER", order)
+            s = K.CgSolver(1e-9, 25); xx = np.zeros(n)
+            st = s.solve(a, None, b, xx)
+            out.append((st.iterations, tuple(s.residual_history), xx.tobytes()))
+        assert out[0] == out[1], kind
+
+
 @pytest.mark.parametrize("slots", ["2", "4", "7"])
 @pytest.mark.parametrize("nt,align", [("0", "0"), ("1", "0"), ("1", "1")])
 def test_spmv_plain_kernel_settings_bit_exact(ctx, slots, nt, align, monkeypatch):
