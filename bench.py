@@ -238,12 +238,18 @@ def roofline_csr_of(grid, nloc, nnz_loc, ms, world):
 
 def blas1_streams(K, ctx, n):
     """The two BLAS-1 kernel shapes of a CG iteration, timed live with HIP events on fresh vectors of this size
-    (kryst_bench_streams): algorithmic bytes = 48 n (x += a p, r -= a Ap, (r,r): 4 reads + 2 writes) and 24 n (p = r + b p)."""
+    (kryst_bench_streams): the residual pass r -= a Ap with the fused (r,r) (2 reads + 1 write: 24 n bytes) and the direction pass
+    x += a p, p = r + b p (3 reads + 2 writes: 40 n) -- the reference's x += alpha p (cg.rs:207-209) rides on the pass that reads p
+    anyway, so p is read once per iteration (64 n bytes per iteration instead of 72 n; KRYST_CG_DEFER_X=0: 48 n + 24 n)."""
     import ctypes as C
     from kryst_amd._ffi import lib, check
     stride = ((n + 511) // 512 * 512 + 512) * 8
     out = []
-    for kind, name, words in ((2, "ew_kernel<CgUpdate1> (x += alpha p, r -= alpha Ap, fused (r,r))", 6), (6, "ew_kernel<AypxDevOp> (p = r + beta p)", 3)):
+    if os.environ.get("KRYST_CG_DEFER_X", "1") == "0":
+        shapes = ((2, "ew_kernel<CgUpdate1> (x += alpha p, r -= alpha Ap, fused (r,r))", 6), (6, "ew_kernel<AypxDevOp> (p = r + beta p)", 3))
+    else:
+        shapes = ((7, "ew_kernel<CgResidualOp> (r -= alpha Ap, fused (r,r))", 3), (8, "ew_kernel<CgDirectionOp> (x += alpha p, p = r + beta p)", 5))
+    for kind, name, words in shapes:
         ms = C.c_double(0)
         check(lib().kryst_bench_streams(ctx.h, n, stride, kind, 20, C.byref(ms)))
         ach = words * 8 * n / (ms.value * 1e-3) / 1e9

@@ -143,7 +143,8 @@ int32_t kryst_spmv_host(kryst_csr_t a, const double* x, int64_t nx, double* y, i
 int32_t kryst_bench_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t fused_dots, int32_t reps, double* avg_ms);
 /* measurement only: average time of one pass of a BLAS-1 stream shape (kind 0: Gram-Schmidt link, 3 vectors; 1: eight batched
  * dots, 9 vectors; 2: CG x/r update, 4 vectors; 3-5: the same with forced nontemporal loads/stores; 6: CG direction update,
- * 2 vectors) over vectors of n doubles placed stride_bytes apart in one allocation */
+ * 2 vectors; 7: CG residual pass r -= a q with (r,r), 2 vectors; 8: CG direction pass with the deferred x update, 3 vectors)
+ * over vectors of n doubles placed stride_bytes apart in one allocation */
 int32_t kryst_bench_streams(kryst_ctx_t ctx, int64_t n, int64_t stride_bytes, int32_t kind, int32_t reps, double* avg_ms);
 
 /* ---- BLAS-1: InnerProduct for () (src/core/wrappers.rs:90-127) and the solvers' pointwise loops ---- */

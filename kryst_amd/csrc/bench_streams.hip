@@ -69,13 +69,33 @@ struct BenchAypxOp {                 // p = r + beta p                      -- 2
         st2(y, i, a.a + be * b.a, a.b + be * b.b);
     }
 };
+struct BenchCgResOp {                // r -= a q ; partial (r,r)            -- 2 reads, 1 write (CG's residual pass, x update deferred)
+    static constexpr int NQ = 1; static constexpr int BPC = 3;
+    double al; const double* ap; double* r;
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
+        const d2 aa = ld2(ap, i), rr = ld2(r, i);
+        const double r0 = rr.a - al * aa.a, r1 = rr.b - al * aa.b;
+        st2(r, i, r0, r1);
+        if (in0) acc[0] = acc[0] + r0 * r0;
+        if (in1) acc[0] = acc[0] + r1 * r1;
+    }
+};
+struct BenchCgDirOp {                // x += a p ; p = r + b p             -- 3 reads, 2 writes (CG's direction pass with the deferred x update)
+    static constexpr int NQ = 0;
+    double al, be; const double* r; double* p; double* x;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const d2 pp = ld2(p, i), xx = ld2(x, i), rr = ld2(r, i);
+        st2(x, i, xx.a + al * pp.a, xx.b + al * pp.b);
+        st2(p, i, rr.a + be * pp.a, rr.b + be * pp.b);
+    }
+};
 }  // namespace kr
 
 using namespace kr;
 
 extern "C" int32_t kryst_bench_streams(kryst_ctx_t ctx, int64_t n, int64_t stride_bytes, int32_t kind, int32_t reps, double* avg_ms) {
-    KR_ARG(ctx && avg_ms && n > 0 && reps >= 1 && kind >= 0 && kind <= 6, "bench_streams");
-    const int nvec = kind == 0 ? 3 : kind == 1 ? 9 : kind == 6 ? 2 : 4;
+    KR_ARG(ctx && avg_ms && n > 0 && reps >= 1 && kind >= 0 && kind <= 8, "bench_streams");
+    const int nvec = kind == 0 ? 3 : kind == 1 ? 9 : (kind == 6 || kind == 7) ? 2 : kind == 8 ? 3 : 4;
     const size_t vbytes = padded_bytes(n) + sizeof(double) * KR_TILE;
     KR_ARG(stride_bytes % 16 == 0 && (size_t)stride_bytes >= vbytes, "bench_streams: stride must be a multiple of 16 and hold a padded vector");
     KR_HIP(hipSetDevice(ctx->device));
@@ -89,6 +109,8 @@ extern "C" int32_t kryst_bench_streams(kryst_ctx_t ctx, int64_t n, int64_t strid
         if (kind == 0) return launch_ew(ctx, BenchLinkOp{0.5, v[1], v[2], v[0]}, n);
         if (kind == 1) { BenchDot8Op op; op.w = v[0]; for (int k = 0; k < 8; ++k) op.v[k] = v[k + 1]; return launch_ew(ctx, op, n); }
         if (kind == 6) return launch_ew(ctx, BenchAypxOp{0.5, v[0], v[1]}, n);
+        if (kind == 7) return launch_ew(ctx, BenchCgResOp{0.5, v[0], v[1]}, n);
+        if (kind == 8) return launch_ew(ctx, BenchCgDirOp{1e-3, 0.5, v[0], v[1], v[2]}, n);
         if (kind == 3) return launch_ew(ctx, BenchCgNtOp<true, true>{0.5, v[0], v[1], v[2], v[3]}, n);
         if (kind == 4) return launch_ew(ctx, BenchCgNtOp<false, true>{0.5, v[0], v[1], v[2], v[3]}, n);
         if (kind == 5) return launch_ew(ctx, BenchCgNtOp<true, false>{0.5, v[0], v[1], v[2], v[3]}, n);

@@ -35,6 +35,8 @@ struct DevState {
     int status;              // KRYST_* code
     int converged;           // SolveStats.converged
     int early;               // BiCGStab: s-norm exit pending its x update
+    long long xlast;         // CG / PCG with the deferred x update: the iteration that ended the solve AFTER the reference's x += alpha p
+                             // (its direction pass still has to add alpha p to x; iterations count from 1, 0 = none)
 };
 
 struct LogicCtx {

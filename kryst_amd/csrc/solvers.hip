@@ -66,6 +66,57 @@ struct CgUpdate0 {                   // no fused dot (PCG with a non-pointwise p
     }
 };
 
+// ---- the x update deferred to the direction pass.  The reference does x += alpha p (cg.rs:207-209, pcg.rs:175-177) right after alpha;
+// nothing reads x again before the solve returns, so here the update rides on the pass that reads p anyway (p = r + beta p, cg.rs:274-276):
+// p is read once per iteration instead of twice -- 8 instead of 9 vector passes for CG, 10 instead of 11 for Jacobi-PCG -- and every
+// element sees the reference's operations on the reference's operands: x_{k+1} = x_k + alpha_k p_k with p_k not yet overwritten.
+// An exit taken after the reference's x update (convergence, iteration cap, indefinite preconditioner) stamps its iteration into
+// st->xlast, and that iteration's direction pass still runs its x half (GateXPending); an exit before it (p.Ap <= 0) does not.
+// KRYST_CG_DEFER_X=0 keeps the eager form (also used for the Natural norm, the trust region and the objective target, which read p or x
+// inside the iteration).
+template <bool KEEP = false>
+struct CgResidualOp {                // r -= alpha Ap (cg.rs:210-212) ; partial r.r (:223)
+    static constexpr int NQ = 1; static constexpr int BPC = 3;       // 2 reads + 1 write + a fold per tile: 3 workgroups per CU (tools/stream_ab.py: 512^3 0.609 -> 0.533 ms, 256^3 0.077 -> 0.065)
+    const double* alpha; const double* ap; double* r;
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
+        const double al = *alpha;
+        const d2 aa = ld2(ap, i), rr = ld2(r, i);
+        const double r0 = rr.a - al * aa.a, r1 = rr.b - al * aa.b;
+        st2_sel<KEEP>(r, i, r0, r1);                                      // r is read again by the direction pass
+        if (in0) acc[0] = acc[0] + r0 * r0;
+        if (in1) acc[0] = acc[0] + r1 * r1;
+    }
+};
+struct CgResidual0Op {               // r -= alpha Ap, no fused dot (PCG with a non-pointwise preconditioner)
+    static constexpr int NQ = 0;
+    const double* alpha; const double* ap; double* r;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const double al = *alpha;
+        const d2 aa = ld2(ap, i), rr = ld2(r, i);
+        st2(r, i, rr.a - al * aa.a, rr.b - al * aa.b);
+    }
+};
+template <bool KEEP = false>
+struct CgDirectionOp {               // x += alpha p (cg.rs:207-209, deferred) ; p = z + beta p (cg.rs:274-276, pcg.rs:215-217; z = r for CG)
+    static constexpr int NQ = 0;
+    const DevState* st; const double* z; double* p; double* x;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const double al = st->alpha, be = st->beta;
+        const bool ended = st->done != 0;                                 // (uniform) the solve ended in this iteration: only x is still owed
+        const d2 pp = ld2(p, i), xx = ld2(x, i);
+        st2(x, i, xx.a + al * pp.a, xx.b + al * pp.b);
+        if (!ended) {
+            const d2 zz = ld2_sel<KEEP>(z, i);
+            st2(p, i, zz.a + be * pp.a, zz.b + be * pp.b);
+        }
+    }
+};
+struct GateXPending {                // runs while the solve is under way, and once more in the iteration that ended it after the x update
+    const DevState* st; long long it;
+    __device__ __forceinline__ bool skip() const { return st->done && st->xlast != it; }
+};
+inline bool cg_defer_x() { return env_int("KRYST_CG_DEFER_X", 1) != 0; }      // (read per iteration enqueue: a getenv, not on any critical path)
+
 struct CgInitLogic {                 // cg.rs:127-140
     static constexpr bool RUN_WHEN_DONE = false;
     LogicCtx c;
@@ -109,12 +160,13 @@ struct CgBetaLogic {                 // cg.rs:223-284
         }
         if (rsq_new / st->rsq < 0.0) {                                 // :254-259
             st->iterations = i; st->final_residual = res_norm; st->converged = 0;
+            st->xlast = i;                                             // (x += alpha p happened at :207)
             c.finish(KRYST_INDEFINITE_PRECONDITIONER);
             return;
         }
         c.push(res_norm);                                              // :260-263
         st->iter = i;
-        if (c.check(res_norm, st->res0, i)) { c.finish(KRYST_OK); return; }   // :264-269
+        if (c.check(res_norm, st->res0, i)) { st->xlast = i; c.finish(KRYST_OK); return; }   // :264-269
         st->beta = rsq_new / st->rsq;                                  // :270
         st->rsq = rsq_new;                                             // :284
     }
@@ -201,9 +253,16 @@ struct CgRun : SolverRun {
         KR_HIP(hipMemcpyAsync(pp, r, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));      // :126
         return reduce_then<1>(ctx, nt, ws.red, CgInitLogic{lc});
     }
-    int32_t iterate(int64_t) override {
+    int32_t iterate(int64_t it) override {
         KR_TRY(launch_spmv(a, pp, ap, 1, pp, done));                                              // :143-144 + (p,Ap) :164
         KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgAlphaLogic{lc})));
+        if (cg_defer_x() && !prm.has_radius && !prm.has_obj_target && prm.norm_type != 2) {       // x += alpha p rides on the direction pass
+            if (keep_in_cache(n)) KR_TRY(launch_ew(ctx, CgResidualOp<true>{&ws.st->alpha, ap, r}, n, done));
+            else KR_TRY(launch_ew(ctx, CgResidualOp<false>{&ws.st->alpha, ap, r}, n, done));      // :210-212 + (r,r) :223
+            KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgBetaLogic{lc})));
+            if (keep_in_cache(n)) return launch_ew_gated(ctx, CgDirectionOp<true>{ws.st, r, pp, xw}, n, GateXPending{ws.st, (long long)it});
+            return launch_ew_gated(ctx, CgDirectionOp<false>{ws.st, r, pp, xw}, n, GateXPending{ws.st, (long long)it});   // :207-209, :274-276
+        }
         if (prm.has_radius) {                                                                     // :177-202 (Steihaug-Toint)
             KR_TRY(launch_ew(ctx, DotPairOp{pp, pp, xw, xw}, n, done));
             KR_TRY((reduce_then<2>(ctx, nt, ws.red, CgRadiusLogic{lc, prm.radius})));
@@ -265,6 +324,30 @@ struct PcgUpdateOp {
     }
 };
 
+template <bool JACOBI, bool KEEP = false>
+struct PcgResidualOp {               // PcgUpdateOp without its x half (deferred to CgDirectionOp): 2-3 reads + 1-2 writes
+    static constexpr int NQ = 2; static constexpr int BPC = 3;
+    const double* alpha; const double* ap; double* r; double* z; const double* inv;
+    int norm_type;
+    __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
+        const double al = *alpha;
+        const d2 aa = ld2(ap, i), rr = ld2(r, i);
+        const double r0 = rr.a - al * aa.a, r1 = rr.b - al * aa.b;                   // pcg.rs:179-181
+        double z0 = r0, z1 = r1;
+        if constexpr (JACOBI) {
+            st2(r, i, r0, r1);
+            const d2 dv = ld2(inv, i);
+            z0 = dv.a * r0; z1 = dv.b * r1;                                          // jacobi.rs:84-86
+            st2_sel<KEEP>(z, i, z0, z1);                                             // z is read again by the direction pass
+        } else {
+            st2_sel<KEEP>(r, i, r0, r1);                                             // z == r
+        }
+        const bool zz = norm_type == 0;                                              // Preconditioned: (z,z); else (r,r)
+        if (in0) { acc[0] = acc[0] + r0 * z0; acc[1] = acc[1] + (zz ? z0 * z0 : r0 * r0); }
+        if (in1) { acc[0] = acc[0] + r1 * z1; acc[1] = acc[1] + (zz ? z1 * z1 : r1 * r1); }
+    }
+};
+
 struct PcgInitLogic {                // pcg.rs:133-146 ; red0 = (r,z), red1 = (z,z) | (r,r)
     static constexpr bool RUN_WHEN_DONE = false;
     LogicCtx c;
@@ -311,10 +394,11 @@ struct PcgBetaLogic {                // pcg.rs:188-218
         }
         c.push(res_norm);                                              // :196-199
         st->iter = i1;
-        if (c.check(res_norm, st->res0, i1)) { c.finish(KRYST_OK); return; }   // :200-205
+        if (c.check(res_norm, st->res0, i1)) { st->xlast = i1; c.finish(KRYST_OK); return; }   // :200-205 (x += alpha p happened at :175)
         const double beta = rz_new / st->rz;                           // :206
         if (beta < 0.0) {                                              // :208-213
             st->iterations = i1; st->final_residual = res_norm; st->converged = 0;
+            st->xlast = i1;
             c.finish(KRYST_INDEFINITE_PRECONDITIONER);
             return;
         }
@@ -343,10 +427,28 @@ struct PcgRun : SolverRun {
         KR_TRY(launch_ew(ctx, DotPairOp{r, z, nq_a, nq_a}, n, nullptr));
         return reduce_then<2>(ctx, nt, ws.red, PcgInitLogic{lc});
     }
-    int32_t iterate(int64_t) override {
+    int32_t iterate(int64_t it) override {
         const int nt_ = prm.norm_type;
         KR_TRY(launch_spmv(a, pp, ap, 1, pp, done));                                              // :149-160
         KR_TRY((reduce_then<1>(ctx, nt, ws.red, PcgAlphaLogic{lc})));
+        if (cg_defer_x()) {                                                                       // x += alpha p (:175-177) rides on the direction pass
+            const bool keep = keep_in_cache(n);
+            if (alias) {
+                if (keep) KR_TRY(launch_ew(ctx, PcgResidualOp<false, true>{&ws.st->alpha, ap, r, z, nullptr, nt_}, n, done));
+                else KR_TRY(launch_ew(ctx, PcgResidualOp<false, false>{&ws.st->alpha, ap, r, z, nullptr, nt_}, n, done));
+            } else if (jac) {
+                if (keep) KR_TRY(launch_ew(ctx, PcgResidualOp<true, true>{&ws.st->alpha, ap, r, z, pc->d_inv_diag, nt_}, n, done));
+                else KR_TRY(launch_ew(ctx, PcgResidualOp<true, false>{&ws.st->alpha, ap, r, z, pc->d_inv_diag, nt_}, n, done));
+            } else {
+                KR_TRY(launch_ew(ctx, CgResidual0Op{&ws.st->alpha, ap, r}, n, done));             // :179-181
+                KR_TRY(pc_apply_dev(pc, r, z, done));                                             // :183-187
+                const double* nq_a = (nt_ == 0) ? z : r;
+                KR_TRY(launch_ew(ctx, DotPairOp{r, z, nq_a, nq_a}, n, done));                     // :188-195
+            }
+            KR_TRY((reduce_then<2>(ctx, nt, ws.red, PcgBetaLogic{lc})));
+            if ((alias || jac) && keep) return launch_ew_gated(ctx, CgDirectionOp<true>{ws.st, z, pp, xw}, n, GateXPending{ws.st, (long long)it});
+            return launch_ew_gated(ctx, CgDirectionOp<false>{ws.st, z, pp, xw}, n, GateXPending{ws.st, (long long)it});   // :175-177, :215-217
+        }
         if (alias) {
             KR_TRY(launch_ew(ctx, PcgUpdateOp<false>{&ws.st->alpha, pp, ap, xw, r, z, nullptr, nt_}, n, done));
         } else if (jac) {

@@ -830,9 +830,12 @@ def _check_solver(res, stats, solver, x, exact=True):
         assert np.array_equal(x, res.x)
 
 
+@pytest.mark.parametrize("defer_x", ["1", "0"])
 @pytest.mark.parametrize("N", [4, 12, 24])
 @pytest.mark.parametrize("norm", [K.CgNormType.Unpreconditioned, K.CgNormType.Natural, K.CgNormType.NoNorm])
-def test_cg_bit_exact(ctx, rs, N, norm):
+def test_cg_bit_exact(ctx, rs, N, norm, defer_x, monkeypatch):
+    """defer_x: x += alpha p riding on the direction pass (the default; solvers.hip) or done where the reference does it -- same bits."""
+    monkeypatch.setenv("KRYST_CG_DEFER_X", defer_x)
     a = O.stencil7(N)
     b = a.spmv(np.ones(a.nrows))
     res = O.solve("cg", a, b, tol=1e-8, max_iters=400, norm_type=int(norm), rs=rs)
@@ -859,9 +862,11 @@ def test_cg_vs_serial_fold_reference(ctx):
     assert np.linalg.norm(x - res.x) / np.linalg.norm(res.x) < 1e-12
 
 
+@pytest.mark.parametrize("defer_x", ["1", "0"])
 @pytest.mark.parametrize("pcname", ["none", "identity", "jacobi"])
 @pytest.mark.parametrize("norm", [K.CgNormType.Preconditioned, K.CgNormType.Unpreconditioned, K.CgNormType.Natural])
-def test_pcg_bit_exact(ctx, rs, pcname, norm):
+def test_pcg_bit_exact(ctx, rs, pcname, norm, defer_x, monkeypatch):
+    monkeypatch.setenv("KRYST_CG_DEFER_X", defer_x)
     a = O.stencil7(14, "aniso")
     b = O.splitmix64_uniform(0x5EED, a.nrows)
     d = to_dev(ctx, a)
@@ -872,6 +877,41 @@ def test_pcg_bit_exact(ctx, rs, pcname, norm):
     x = np.zeros(a.nrows)
     st = s.solve(d, kpc, b, x)
     _check_solver(res, st, s, x)
+
+
+@pytest.mark.parametrize("defer_x", ["1", "0"])
+def test_deferred_x_update_on_every_exit_path(ctx, rs, defer_x, monkeypatch):
+    """x += alpha p travels with the direction pass (p is read once per iteration).  Every way out of CG / PCG must leave x as the
+    reference does: convergence, the iteration cap (1, 2, 7 iterations -- `converged` true, x includes the last alpha p), p.Ap <= 0
+    (x untouched by that iteration), a non-pointwise preconditioner (ILU: the unfused PCG path), a stepping session ended after k
+    iterations, and an initial guess."""
+    monkeypatch.setenv("KRYST_CG_DEFER_X", defer_x)
+    a = O.stencil7(9, "aniso"); d = to_dev(ctx, a)
+    b = O.splitmix64_uniform(0xD0E, a.nrows)
+    x0 = O.splitmix64_uniform(0xABC, a.nrows)
+    for cap in (1, 2, 7, 300):
+        for name, cls, opc, kpc in (("cg", K.CgSolver, None, None), ("pcg", K.PcgSolver, O.Pc.jacobi(a), K.Jacobi().setup(d)),
+                                    ("pcg", K.PcgSolver, O.Pc.ilu0_true(a), K.TrueIlu0().setup(d))):
+            res = O.solve(name, a, b, pc=opc, x0=x0, tol=1e-10, max_iters=cap, rs=rs)
+            s = cls(1e-10, cap); x = x0.copy()
+            st = s.solve(d, kpc, b, x)
+            _check_solver(res, st, s, x)
+    # p.Ap <= 0 in the second iteration: diag(1, -1, 2) from b = (1, 1, 1): x keeps the first iteration's update only
+    ind = O.Csr(3, 3, [0, 1, 2, 3], [0, 1, 2], [1.0, -1.0, 2.0]); bi = np.ones(3)
+    for name, cls in (("cg", K.CgSolver), ("pcg", K.PcgSolver)):
+        s = cls(1e-12, 10); x = np.zeros(3); xin = x.copy()
+        with pytest.raises(K.KError) as e:
+            s.solve(to_dev(ctx, ind), None, bi, x)
+        assert e.value.code == 3 and np.array_equal(x, xin)                  # IndefiniteMatrix; on Err the reference never writes x back
+    # a stepping session ended after k of 1000 allowed iterations: x holds exactly k updates
+    for method, opc, kpc in (("cg", None, None), ("pcg", O.Pc.jacobi(a), K.Jacobi().setup(d))):
+        for k in (1, 3, 6):
+            res = O.solve(method, a, b, pc=opc, tol=1e-30, max_iters=k, rs=rs)
+            xs, bs = K.DeviceVec(ctx, np.zeros(a.nrows)), K.DeviceVec(ctx, b)
+            sess = K.Session(method, d, kpc, bs, xs, tol=1e-30, max_iters=1000)
+            sess.step(k)
+            sess.end()
+            assert np.array_equal(xs.to_host(), res.x), (method, k)
 
 
 def test_pcg_with_chebyshev_extension_bit_exact(ctx, rs):
