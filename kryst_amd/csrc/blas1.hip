@@ -7,7 +7,7 @@ namespace kr {
 
 // ---------------------------------------------------------------- ops
 struct DotOp {                       // wrappers.rs:90-108: sum of x[i]*y[i]
-    static constexpr int NQ = 1; static constexpr int BPC = 4;
+    static constexpr int NQ = 1; static constexpr const char* TAG = "Dot"; static constexpr int BPC = 4;
     const double* x; const double* y;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         const d2 a = ld2(x, i), b = ld2(y, i);
@@ -16,7 +16,7 @@ struct DotOp {                       // wrappers.rs:90-108: sum of x[i]*y[i]
     }
 };
 struct AxpyOp {                      // y[i] = y[i] + alpha*x[i]   (cg.rs:207-209)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "Axpy";
     Coef alpha; const double* x; double* y;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double al = alpha.get();
@@ -25,7 +25,7 @@ struct AxpyOp {                      // y[i] = y[i] + alpha*x[i]   (cg.rs:207-20
     }
 };
 struct AypxOp {                      // y[i] = x[i] + beta*y[i]    (cg.rs:274-276)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "Aypx";
     Coef beta; const double* x; double* y;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double be = beta.get();
@@ -34,7 +34,7 @@ struct AypxOp {                      // y[i] = x[i] + beta*y[i]    (cg.rs:274-27
     }
 };
 struct SubOp {                       // out[i] = a[i] - b[i]       (cg.rs:123 `bi - ax`)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "Sub";
     const double* a; const double* b; double* out;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const d2 u = ld2(a, i), v = ld2(b, i);
@@ -42,14 +42,14 @@ struct SubOp {                       // out[i] = a[i] - b[i]       (cg.rs:123 `b
     }
 };
 struct FillOp {
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "Fill";
     double v; double* out;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&)[1]) const {
         st2(out, i, in0 ? v : 0.0, in1 ? v : 0.0);       // padding stays zero
     }
 };
 struct SplitmixOp {                  // SURVEY 8d synthetic data
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "Splitmix";
     uint64_t seed; int64_t goff; double* out;
     __device__ __forceinline__ static double gen(uint64_t seed, uint64_t idx) {
         uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;

@@ -12,7 +12,7 @@ namespace kr {
 
 // =================================================================== CGS
 struct CgsDirOp {                    // i == 1: u = r, p = u (cgs.rs:83-86); else u = r + beta q, p = u + beta (q + beta p) (:87-99)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "CgsDir";
     const DevState* st; int first; const double* r; const double* q; double* u; double* p;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const d2 rr = ld2(r, i);
@@ -25,7 +25,7 @@ struct CgsDirOp {                    // i == 1: u = r, p = u (cgs.rs:83-86); els
     }
 };
 struct CgsQxOp {                     // q = u - alpha v (:107-109) ; x += alpha (u + q) (:111-113) ; upq = u + q (:115-118)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "CgsQx";
     const DevState* st; const double* u; const double* v; double* q; double* x; double* upq;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double al = st->alpha;
@@ -38,7 +38,7 @@ struct CgsQxOp {                     // q = u - alpha v (:107-109) ; x += alpha 
     }
 };
 struct CgsROp {                      // r = r - alpha w (:121-123) ; partials (r,r) (:124) and (r_tld, r) (:133)
-    static constexpr int NQ = 2;
+    static constexpr int NQ = 2; static constexpr const char* TAG = "CgsR";
     const DevState* st; const double* w; const double* rt; double* r;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
         const double al = st->alpha;
@@ -121,7 +121,7 @@ struct TfState {                     // device, next to DevState
     int stop0;                       // the m = 0 substep returned: skip m = 1 (tfqmr.rs:191-196)
 };
 struct TfUqtOp {                     // u = r - alpha v (:131-133) ; q = u - alpha v (:136-139) ; t = u + q (:142-145)
-    static constexpr int NQ = 3;     // partials (u,u) [||r|| of a later early return, :117/:124], (q,q) (:160), (r_tld,u) (:204)
+    static constexpr int NQ = 3; static constexpr const char* TAG = "TfUqt";     // partials (u,u) [||r|| of a later early return, :117/:124], (q,q) (:160), (r_tld,u) (:204)
     const DevState* st; const double* r; const double* v; const double* rt; double* u; double* q; double* t;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[3]) const {
         const double al = st->alpha;
@@ -134,7 +134,7 @@ struct TfUqtOp {                     // u = r - alpha v (:131-133) ; q = u - alp
     }
 };
 struct TfResNormOp {                 // partial ||r - alpha A(u+q)||^2 (:149-152); the vector itself is dead (r = u at :203)
-    static constexpr int NQ = 1; static constexpr int BPC = 4;
+    static constexpr int NQ = 1; static constexpr const char* TAG = "TfResNorm"; static constexpr int BPC = 4;
     const DevState* st; const double* r; const double* au;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         const double al = st->alpha;
@@ -145,7 +145,7 @@ struct TfResNormOp {                 // partial ||r - alpha A(u+q)||^2 (:149-152
     }
 };
 struct TfXdyOp {                     // both substeps of :175-182, then y = u + beta (q + beta y) (:210)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "TfXdy";
     const DevState* st; const TfState* tf; const double* u; const double* q; double* d; double* x; double* y;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const d2 uu = ld2(u, i), dd = ld2(d, i), xx = ld2(x, i);

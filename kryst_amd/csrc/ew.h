@@ -11,6 +11,8 @@
 #pragma once
 #include "common.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace kr {
 
@@ -88,6 +90,10 @@ __global__ __launch_bounds__(KR_T) void ew_kernel(Op op, Gate gate, int64_t n, i
 // workgroups per CU of the capped grid: 2 for kernels that also write; read-only reductions declare BPC = 4
 template <class Op, class = void> struct ew_bpc { static constexpr int value = 2; };
 template <class Op> struct ew_bpc<Op, std::void_t<decltype(Op::BPC)>> { static constexpr int value = Op::BPC; };
+// tuning: an op that declares `static constexpr const char* TAG = "X"` can have its workgroups per CU set per launch through
+// KRYST_BPC_X (tools/solver_ab.py times whole solver iterations with the settings in turn, in one process)
+template <class Op, class = void> struct ew_tag { static const char* get() { return nullptr; } };
+template <class Op> struct ew_tag<Op, std::void_t<decltype(Op::TAG)>> { static const char* get() { return Op::TAG; } };
 
 // bpc <= 0: the kernel shape's default (KRYST_EW_BLOCKS_PER_CU overrides it)
 template <class Op, class Gate>
@@ -103,6 +109,11 @@ inline int32_t launch_ew_gated(kryst_ctx_t ctx, const Op& op, int64_t n, const G
     if (bpc <= 0) {
         const char* e_bpc = getenv("KRYST_EW_BLOCKS_PER_CU");        // tuning knob (read per launch)
         bpc = e_bpc ? atoi(e_bpc) : ew_bpc<Op>::value;
+    }
+    if (const char* tag = ew_tag<Op>::get()) {
+        char name[64];
+        snprintf(name, sizeof name, "KRYST_BPC_%s", tag);
+        if (const char* e_tag = getenv(name)) bpc = std::max(1, atoi(e_tag));
     }
     const int64_t grid = std::min<int64_t>(ntiles, (int64_t)ctx->num_cu * bpc);
     hipLaunchKernelGGL((ew_kernel<Op, Gate>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, gate, n, ntiles,

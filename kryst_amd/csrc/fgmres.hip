@@ -27,7 +27,7 @@ struct FgPtrs { FgState* fs; double* h; double* cs; double* sn; double* s; doubl
 // ---- vector ops
 template <int NB, bool KEEP>
 struct MultiDotOp {                  // partial (w, v_k), k = 0..NB-1  (:220-222 / :231-233)
-    static constexpr int NQ = NB;
+    static constexpr int NQ = NB; static constexpr const char* TAG = "MultiDot";
     const double* w; const double* v[NB];
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[NB]) const {
         const d2 ww = ld2_sel<KEEP>(w, i);     // w is read by every kernel of the sweep: cacheable when it fits; the basis streams past it
@@ -41,7 +41,7 @@ struct MultiDotOp {                  // partial (w, v_k), k = 0..NB-1  (:220-222
 };
 template <int NB, bool KEEP>
 struct MultiAxpyOp {                 // w = w - h_k v_k, k ascending (:223-228 / :234-236); partial (w,w) or (w,next) of the result
-    static constexpr int NQ = 1;
+    static constexpr int NQ = 1; static constexpr const char* TAG = "MultiAxpy"; static constexpr int BPC = 3;   // FGMRES(30) classical GS 256^3: 2 -> 3 workgroups per CU +1.4 %
     const double* h; const double* v[NB]; const double* next; double* w;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         d2 ww = ld2_sel<KEEP>(w, i);
@@ -60,7 +60,7 @@ struct MultiAxpyOp {                 // w = w - h_k v_k, k ascending (:223-228 /
 };
 template <bool KEEP>
 struct RefineLinkOp {                // if |corr| > 1e-10: w = w - corr v_i (:242-246); partial (w, next) or (w, w)
-    static constexpr int NQ = 1;
+    static constexpr int NQ = 1; static constexpr const char* TAG = "RefineLink";
     const FgState* fs; const double* vi; const double* next; double* w;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         d2 ww = ld2_sel<KEEP>(w, i);
@@ -77,7 +77,7 @@ struct RefineLinkOp {                // if |corr| > 1e-10: w = w - corr v_i (:24
     }
 };
 struct NextBasisOp {                 // v_{j+1} = w / h[j+1][j], or zeros on happy breakdown (:255-261)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "NextBasis";
     const FgState* fs; const double* w; double* out;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         if (fs->happy) { st2(out, i, 0.0, 0.0); return; }
@@ -87,7 +87,7 @@ struct NextBasisOp {                 // v_{j+1} = w / h[j+1][j], or zeros on hap
     }
 };
 struct ScaleByOp {                   // v_0 = r / beta (:167-169, :332-334)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "ScaleBy";
     const double* s; const double* in; double* out;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double d = *s;
@@ -96,7 +96,7 @@ struct ScaleByOp {                   // v_0 = r / beta (:167-169, :332-334)
     }
 };
 struct FgUpdateOp {                  // build_solution (:344-356): x += y[i] z_i, i ascending per element
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "FgUpdate";
     const FgState* fs; const double* y; double* const* z; double* x;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const int m = (int)fs->k;
@@ -121,7 +121,7 @@ struct GateFgCycle {
 template <class Op>
 static int32_t fg_launch(kryst_ctx_t ctx, const Op& op, int64_t n, const DevState* st, const FgState* fs, int bpc = 0) {
     static const int dflt = [] { const char* e = getenv("KRYST_FG_BLOCKS_PER_CU"); return e ? atoi(e) : 2; }();
-    return launch_ew_gated(ctx, op, n, GateFgCycle{st, fs}, bpc > 0 ? bpc : dflt);
+    return launch_ew_gated(ctx, op, n, GateFgCycle{st, fs}, bpc > 0 ? bpc : std::max(dflt, ew_bpc<Op>::value));
 }
 __global__ void fg_gate_kernel(const DevState* st, const FgState* fs, int* gate) { *gate = (st->done || fs->cyc_stop) ? 1 : 0; }
 

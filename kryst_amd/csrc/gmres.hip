@@ -24,7 +24,7 @@ struct GmPtrs { GmState* gs; double* h; double* g; double* cs; double* sn; doubl
 
 // ---- vector ops
 struct DivOp {                       // out = in / s      (gmres.rs:242,253,304 `ri / r0_norm`, `zi / h[j+1][j]`)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "Div";
     const double* s; const double* in; double* out;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double d = *s;
@@ -34,7 +34,7 @@ struct DivOp {                       // out = in / s      (gmres.rs:242,253,304 
 };
 template <bool KEEP>
 struct MgsLinkOp {                   // z = z - h*Bi (gmres.rs:85-87) ; partial z.Bnext (the next link's dot, :84/:91)
-    static constexpr int NQ = 1;         // bnext == nullptr: partial z.z of the UPDATED z (h[j+1][j] = ||z||, :97)
+    static constexpr int NQ = 1; static constexpr const char* TAG = "MgsLink";         // bnext == nullptr: partial z.z of the UPDATED z (h[j+1][j] = ||z||, :97)
     const double* h; const double* bi; const double* bnext; double* z;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         const double hv = *h;
@@ -50,7 +50,7 @@ struct MgsLinkOp {                   // z = z - h*Bi (gmres.rs:85-87) ; partial 
     }
 };
 struct GmUpdateOp {                  // x += sum_j y[j]*U[j], j ascending per element (gmres.rs:362-386)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "GmUpdate";
     const GmState* gs; const double* y; double* const* u; double* x;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const int m = gs->m;
@@ -72,10 +72,11 @@ struct GateCycle {
     const DevState* st; const GmState* gs;
     __device__ __forceinline__ bool skip() const { return st->done || gs->cyc_stop; }
 };
-// the Gram-Schmidt links (3 reads + 1 write + a reduction per tile) want 4 workgroups per CU: GMRES(30) 256^3 244 -> 309 it/s
+// the Gram-Schmidt links (3 reads + 1 write + a reduction per tile) want 6 workgroups per CU: GMRES(30) 256^3 244 -> 309 it/s with 4
+// (round 1), 347.7 -> 356.5 with 6 (round 3, tools/solver_ab.py: 2 / 3 / 4 / 5 / 6 / 8 per CU = 250 / 319 / 348 / 356 / 357 / 339 it/s)
 template <class Op>
 static int32_t launch_iter(kryst_ctx_t ctx, const Op& op, int64_t n, const DevState* st, const GmState* gs) {
-    static const int bpc = [] { const char* e = getenv("KRYST_GMRES_BLOCKS_PER_CU"); return e ? atoi(e) : 4; }();
+    static const int bpc = [] { const char* e = getenv("KRYST_GMRES_BLOCKS_PER_CU"); return e ? atoi(e) : 6; }();
     return launch_ew_gated(ctx, op, n, GateCycle{st, gs}, bpc);
 }
 // "gate" kernel: copies done||cyc_stop into one int so that launch_spmv / pc_apply_dev can use their `done` hook

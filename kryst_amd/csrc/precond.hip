@@ -22,7 +22,7 @@ __global__ void jacobi_setup_kernel(const int32_t* row_ptr, const int32_t* col, 
 }
 
 struct JacobiOp {                    // y[i] = inv_diag[i] * x[i]   (jacobi.rs:84-92)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "Jacobi";
     const double* inv; const double* x; double* y;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const d2 a = ld2(inv, i), b = ld2(x, i);
@@ -32,7 +32,7 @@ struct JacobiOp {                    // y[i] = inv_diag[i] * x[i]   (jacobi.rs:8
 
 // ---------------------------------------------------------------- Chebyshev filter
 struct Cheb1Op {                     // v1[i] = (v1[i] - c*v0[i]) / d            (chebyshev.rs:105-107)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "Cheb1";
     double c, d; const double* v0; double* v1;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const d2 a = ld2(v0, i), b = ld2(v1, i);
@@ -40,7 +40,7 @@ struct Cheb1Op {                     // v1[i] = (v1[i] - c*v0[i]) / d           
     }
 };
 struct Cheb2Op {                     // v2[i] = (2*(v2[i] - c*v1[i]) / d) - v0[i] (chebyshev.rs:121)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "Cheb2";
     double c, d; const double* v0; const double* v1; double* v2;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const d2 a = ld2(v0, i), b = ld2(v1, i), w = ld2(v2, i);
@@ -48,7 +48,7 @@ struct Cheb2Op {                     // v2[i] = (2*(v2[i] - c*v1[i]) / d) - v0[i
     }
 };
 struct Cheb2ScaleOp {                // the last recurrence step and z[i] = tau * v2[i] (chebyshev.rs:121 then :130-138) in one pass
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "Cheb2Scale";
     double c, d, tau; const double* v0; const double* v1; const double* v2; double* z;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const d2 a = ld2(v0, i), b = ld2(v1, i), w = ld2(v2, i);
@@ -57,7 +57,7 @@ struct Cheb2ScaleOp {                // the last recurrence step and z[i] = tau 
     }
 };
 struct ScaleOp {                     // z[i] = tau * v[i]                         (chebyshev.rs:130-138)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "Scale";
     double tau; const double* v; double* z;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const d2 a = ld2(v, i);

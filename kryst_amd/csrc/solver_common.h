@@ -286,7 +286,7 @@ inline int32_t run_ahead(kryst_ctx_t ctx, const kryst_params_t* p, Body body, Po
 }
 
 struct DotOneOp {
-    static constexpr int NQ = 1; static constexpr int BPC = 4;
+    static constexpr int NQ = 1; static constexpr const char* TAG = "DotOne"; static constexpr int BPC = 4;
     const double *a, *b;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         const d2 u = ld2(a, i), v = ld2(b, i);
@@ -296,7 +296,7 @@ struct DotOneOp {
 };
 // out = a - b, partial of out.out        (r = b - A x, `bi - ax`, cg.rs:123; ||r||^2 for the first dot)
 struct SubDotOp {
-    static constexpr int NQ = 1;
+    static constexpr int NQ = 1; static constexpr const char* TAG = "SubDot";
     const double *a, *b; double* out;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         const d2 u = ld2(a, i), v = ld2(b, i);

@@ -7,7 +7,7 @@ namespace kr {
 
 // =================================================================== shared vector ops
 struct DotPairOp {
-    static constexpr int NQ = 2;
+    static constexpr int NQ = 2; static constexpr const char* TAG = "DotPair";
     const double *a, *b, *c, *d;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
         const d2 u = ld2(a, i), v = ld2(b, i), w = ld2(c, i), z = ld2(d, i);
@@ -17,7 +17,7 @@ struct DotPairOp {
 };
 template <bool KEEP = false>
 struct AypxDevOp {                   // y = x + beta*y  (cg.rs:274-276, pcg.rs:215-217), beta on the device
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "AypxDev";
     const double* beta; const double* x; double* y;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double be = *beta;
@@ -30,7 +30,7 @@ struct AypxDevOp {                   // y = x + beta*y  (cg.rs:274-276, pcg.rs:2
 // x += alpha p ; r -= alpha Ap (cg.rs:207-212) ; partial r.r (cg.rs:223) [; partial r.p for the Natural norm, :227]
 template <bool KEEP = false>
 struct CgUpdate1 {
-    static constexpr int NQ = 1;
+    static constexpr int NQ = 1; static constexpr const char* TAG = "CgUpdate1";
     const double* alpha; const double* p; const double* ap; double* x; double* r;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         const double al = *alpha;
@@ -43,7 +43,7 @@ struct CgUpdate1 {
     }
 };
 struct CgUpdate2 {                   // + r.p (old p) for CgNormType::Natural
-    static constexpr int NQ = 2;
+    static constexpr int NQ = 2; static constexpr const char* TAG = "CgUpdate2";
     const double* alpha; const double* p; const double* ap; double* x; double* r;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
         const double al = *alpha;
@@ -56,7 +56,7 @@ struct CgUpdate2 {                   // + r.p (old p) for CgNormType::Natural
     }
 };
 struct CgUpdate0 {                   // no fused dot (PCG with a non-pointwise preconditioner)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "CgUpdate0";
     const double* alpha; const double* p; const double* ap; double* x; double* r;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double al = *alpha;
@@ -76,7 +76,7 @@ struct CgUpdate0 {                   // no fused dot (PCG with a non-pointwise p
 // inside the iteration).
 template <bool KEEP = false>
 struct CgResidualOp {                // r -= alpha Ap (cg.rs:210-212) ; partial r.r (:223)
-    static constexpr int NQ = 1; static constexpr int BPC = 3;       // 2 reads + 1 write + a fold per tile: 3 workgroups per CU (tools/stream_ab.py: 512^3 0.609 -> 0.533 ms, 256^3 0.077 -> 0.065)
+    static constexpr int NQ = 1; static constexpr const char* TAG = "CgResidual"; static constexpr int BPC = 3;       // 2 reads + 1 write + a fold per tile: 3 workgroups per CU (tools/stream_ab.py: 512^3 0.609 -> 0.533 ms, 256^3 0.077 -> 0.065)
     const double* alpha; const double* ap; double* r;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         const double al = *alpha;
@@ -88,7 +88,7 @@ struct CgResidualOp {                // r -= alpha Ap (cg.rs:210-212) ; partial 
     }
 };
 struct CgResidual0Op {               // r -= alpha Ap, no fused dot (PCG with a non-pointwise preconditioner)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "CgResidual0";
     const double* alpha; const double* ap; double* r;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double al = *alpha;
@@ -98,7 +98,7 @@ struct CgResidual0Op {               // r -= alpha Ap, no fused dot (PCG with a 
 };
 template <bool KEEP = false>
 struct CgDirectionOp {               // x += alpha p (cg.rs:207-209, deferred) ; p = z + beta p (cg.rs:274-276, pcg.rs:215-217; z = r for CG)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "CgDirection"; static constexpr int BPC = 3;   // inside CG: 2 -> 3 +4.4 % (256^3), +1.1 % (512^3); PCG +3.0 % / -0.7 %
     const DevState* st; const double* z; double* p; double* x;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double al = st->alpha, be = st->beta;
@@ -233,7 +233,7 @@ struct CgBetaStoredLogic {           // second half: cg.rs:254-284 on the stored
     }
 };
 struct AxpyIfOp {                    // x += alpha*p, only while st->early is raised (cg.rs:185-187 max_step update)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "AxpyIf";
     const DevState* st; const double* p; double* x;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double al = st->alpha;
@@ -303,7 +303,7 @@ int32_t cg_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
 //   x += alpha p ; r -= alpha Ap ; z = M^-1 r ; partial 0 = r.z ; partial 1 = norm quantity (z.z | r.r)
 template <bool JACOBI, bool KEEP = false>
 struct PcgUpdateOp {
-    static constexpr int NQ = 2; static constexpr int BPC = 3;       // 5 reads + 3 writes: 3 workgroups per CU measured best (+3 %)
+    static constexpr int NQ = 2; static constexpr const char* TAG = "PcgUpdate"; static constexpr int BPC = 3;       // 5 reads + 3 writes: 3 workgroups per CU measured best (+3 %)
     const double* alpha; const double* p; const double* ap; double* x; double* r; double* z; const double* inv;
     int norm_type;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
@@ -326,7 +326,7 @@ struct PcgUpdateOp {
 
 template <bool JACOBI, bool KEEP = false>
 struct PcgResidualOp {               // PcgUpdateOp without its x half (deferred to CgDirectionOp): 2-3 reads + 1-2 writes
-    static constexpr int NQ = 2; static constexpr int BPC = 3;
+    static constexpr int NQ = 2; static constexpr const char* TAG = "PcgResidual"; static constexpr int BPC = 3;
     const double* alpha; const double* ap; double* r; double* z; const double* inv;
     int norm_type;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
@@ -475,7 +475,7 @@ int32_t pcg_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
 // =================================================================== BiCGStab (src/solver/bicgstab.rs:69-293)
 template <bool KEEP = false>
 struct BicgPOp {                     // p = r + beta*(p - omega_prev*v)   (bicgstab.rs:134/140)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr const char* TAG = "BicgP";
     const DevState* st; const double* r; const double* v; double* p;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double be = st->beta, om = st->omega_prev;
@@ -484,7 +484,7 @@ struct BicgPOp {                     // p = r + beta*(p - omega_prev*v)   (bicgs
     }
 };
 struct BicgSOp {                     // s = r - alpha*v ; partial s.s     (bicgstab.rs:166-188)
-    static constexpr int NQ = 1;
+    static constexpr int NQ = 1; static constexpr const char* TAG = "BicgS"; static constexpr int BPC = 4;      // tools/solver_ab.py: 2 -> 4 workgroups per CU, BiCGStab +4.5 % (256^3), +2.0 % (512^3)
     const DevState* st; const double* r; const double* v; double* s;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         const double al = st->alpha;
@@ -499,7 +499,7 @@ struct BicgSOp {                     // s = r - alpha*v ; partial s.s     (bicgs
 // when the s-norm exit is pending (st->early): only x = x + alpha*p   (bicgstab.rs:191-202)
 template <bool KEEP = false>
 struct BicgXROp {
-    static constexpr int NQ = 2;
+    static constexpr int NQ = 2; static constexpr const char* TAG = "BicgXR"; static constexpr int BPC = 3;     // 2 -> 3: +5.2 % (256^3), +3.0 % (512^3)
     // p / sx: the directions x is updated with (M^-1 p, M^-1 s in the right-preconditioned extension); s: the true s
     const DevState* st; const double* p; const double* sx; const double* s; const double* t; const double* rhat; double* x; double* r;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
