@@ -81,7 +81,7 @@ struct BenchCgResOp {                // r -= a q ; partial (r,r)            -- 2
     }
 };
 struct BenchCgDirOp {                // x += a p ; p = r + b p             -- 3 reads, 2 writes (CG's direction pass with the deferred x update)
-    static constexpr int NQ = 0;
+    static constexpr int NQ = 0; static constexpr int BPC = 3;       // as CgDirectionOp (3 per CU is what pays INSIDE the iteration; alone, 2 is 10 % faster)
     double al, be; const double* r; double* p; double* x;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const d2 pp = ld2(p, i), xx = ld2(x, i), rr = ld2(r, i);
