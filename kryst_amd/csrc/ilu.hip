@@ -64,6 +64,7 @@ struct TriFactor {                  // one triangular factor in level order
     // on a row pointer -- one round trip less on a latency-bound kernel
     int32_t* d_ecol = nullptr; double* d_eval = nullptr; uint8_t* d_elen = nullptr; int64_t npos = 0; bool ell = false;
     bool syncfree = false;          // ELL factor solved by ONE sync-free launch (KRYST_ILU_SYNCFREE=0: one launch per level)
+    int held = 16;                  // entries of a row the CSR sync-free kernel holds in registers (8: no row is longer than that)
     std::vector<int32_t> lvl_off;   // host: position offsets per level
     int32_t* d_lvl_off = nullptr;
     void free_all() { (void)hipFree(d_ptr); (void)hipFree(d_col); (void)hipFree(d_val); (void)hipFree(d_row); (void)hipFree(d_diag); (void)hipFree(d_lvl_off);
@@ -201,8 +202,11 @@ __global__ __launch_bounds__(256) void tri_syncfree_ell_kernel(const TriArgs* ar
     if (!done) __hip_atomic_store(&out[p], __longlong_as_double(0x7FF8000000000000ll), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // budget exhausted
 }
 
-// the same for factors with longer rows (CSR in level order): a lane advances through its entries as far as they are ready
-template <bool FORWARD>
+// the same for factors with longer rows (CSR in level order): a lane advances through its entries as far as they are ready.
+// The row's first P entries (columns AND values) are in registers before the lane starts waiting: once its gate opens, what stands
+// between the row and its result is ONE uncached round trip for all of them -- with the entries fetched after the gate (round 2:
+// batches of eight, columns from L2, values a cold miss each) a 27-point factor's 13 entries per row cost 7.4 us per dependency level.
+template <bool FORWARD, int P>
 __global__ __launch_bounds__(256) void tri_syncfree_csr_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
                                                                const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
                                                                const double* __restrict__ val, const double* __restrict__ diag, int32_t npos) {
@@ -212,38 +216,63 @@ __global__ __launch_bounds__(256) void tri_syncfree_csr_kernel(const TriArgs* ar
     int32_t k = 0, kend = 0; double s = 0.0, dg = 1.0;
     if (active) { k = ptr[p]; kend = ptr[p + 1]; s = in[p]; if (!FORWARD) dg = diag[p]; }
     bool done = !active;
+    int32_t cc[P]; double vv[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+        const int32_t kk = min(k + u, kend - 1);
+        cc[u] = k < kend ? col[kk] : 0;
+        vv[u] = k < kend ? val[kk] : 0.0;
+    }
     // While a row waits it polls ONE entry: the dependency at the largest level-order position, i.e. of the deepest level -- the
     // last one to be solved in all but rare cases (eight uncached loads per waiting lane and round slowed everybody down: 20 -> 40 ms
-    // on a 27-point factor).  Once that one is there, the batches below usually find everything ready.
+    // on a 27-point factor).  Once that one is there, the batch below usually finds everything ready.
     int32_t gate_col = -1;
-    for (int32_t kk = k; kk < kend; ++kk) gate_col = max(gate_col, col[kk]);
+#pragma unroll
+    for (int u = 0; u < P; ++u) if (k + u < kend) gate_col = max(gate_col, cc[u]);
+    for (int32_t kk = k + P; kk < kend; ++kk) gate_col = max(gate_col, col[kk]);
     bool open = gate_col < 0;
+    bool first = true;
     for (int budget = 1 << 22; budget > 0; --budget) {
         if (!done && !open) {
             const double g = __hip_atomic_load(&out[gate_col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             open = (unsigned long long)__double_as_longlong(g) != KR_TRI_SENTINEL;
         }
         if (!done && open) {
-            // the next (up to) eight dependencies are asked for TOGETHER -- one uncached round trip (~1.5 us) for the batch instead
-            // of one per entry: a 27-point factor's 13 entries per row cost 15 us per dependency level when polled one by one --
-            // and the ready prefix is consumed in stored order
-            constexpr int B = 8;
-            double xv[B], vv[B];
+            if (first) {
+                // the register-held entries: asked for TOGETHER, the ready prefix consumed in stored order
+                first = false;
+                double xv[P];
 #pragma unroll
-            for (int u = 0; u < B; ++u) {
-                const int32_t kk = min(k + u, kend - 1);
-                vv[u] = k < kend ? val[kk] : 0.0;
-                xv[u] = k < kend ? __hip_atomic_load(&out[col[kk]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-            }
-            bool prefix = true;
-            int adv = 0;
+                for (int u = 0; u < P; ++u) xv[u] = k + u < kend ? __hip_atomic_load(&out[cc[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                bool prefix = true;
+                int adv = 0;
 #pragma unroll
-            for (int u = 0; u < B; ++u) {
-                const bool ready = (unsigned long long)__double_as_longlong(xv[u]) != KR_TRI_SENTINEL;
-                prefix = prefix && k + u < kend && ready;
-                if (prefix) { s = s - vv[u] * xv[u]; ++adv; }                              // stored order
+                for (int u = 0; u < P; ++u) {
+                    const bool ready = (unsigned long long)__double_as_longlong(xv[u]) != KR_TRI_SENTINEL;
+                    prefix = prefix && k + u < kend && ready;
+                    if (prefix) { s = s - vv[u] * xv[u]; ++adv; }                          // stored order
+                }
+                k += adv;
+            } else {
+                // what is left (a gate that opened before an earlier dependency, rows longer than P): batches of eight from memory
+                constexpr int B = 8;
+                double xv[B], wv[B];
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const int32_t kk = min(k + u, kend - 1);
+                    wv[u] = k < kend ? val[kk] : 0.0;
+                    xv[u] = k < kend ? __hip_atomic_load(&out[col[kk]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                }
+                bool prefix = true;
+                int adv = 0;
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const bool ready = (unsigned long long)__double_as_longlong(xv[u]) != KR_TRI_SENTINEL;
+                    prefix = prefix && k + u < kend && ready;
+                    if (prefix) { s = s - wv[u] * xv[u]; ++adv; }                          // stored order
+                }
+                k += adv;
             }
-            k += adv;
             if (k == kend) {
                 __hip_atomic_store(&out[p], FORWARD ? s : s / dg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 done = true;
@@ -448,7 +477,11 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
     if (F.syncfree && F.npos > 0) {
         const dim3 grid((unsigned)((F.npos + 255) / 256));
         if (F.ell) hipLaunchKernelGGL((tri_syncfree_ell_kernel<FORWARD>), grid, dim3(256), 0, s, d_args, in, out, F.view(), F.d_diag, (int32_t)F.npos);
-        else hipLaunchKernelGGL((tri_syncfree_csr_kernel<FORWARD>), grid, dim3(256), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val, F.d_diag,
+        // (Ilup(1) on a 7-point operator, 6 entries per row: 7.3 -> 5.9 ms per apply with 8 held, 6.3 with 16; a 27-point factor, 13 per
+        // row: 9.8 -> 9.4 with 8, 6.9 with 16)
+        else if (env_i("KRYST_ILU_CSR_HELD", F.held) <= 8) hipLaunchKernelGGL((tri_syncfree_csr_kernel<FORWARD, 8>), grid, dim3(256), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val, F.d_diag,
+                                (int32_t)F.npos);
+        else hipLaunchKernelGGL((tri_syncfree_csr_kernel<FORWARD, 16>), grid, dim3(256), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val, F.d_diag,
                                 (int32_t)F.npos);
         KR_HIP(hipGetLastError());
         return KRYST_OK;
@@ -683,6 +716,11 @@ static int32_t build_factor(int64_t n, const FlatRows& ent, const std::vector<do
     // 13.0 ms otherwise).  KRYST_ILU_SYNCFREE = 0 / 1 forces either form.
     const double rows_per_level = nl > 0 ? (double)n / (double)nl : 0.0;
     F->syncfree = env_i("KRYST_ILU_SYNCFREE", (F->ell || rows_per_level >= 512.0) ? 1 : 0) != 0;
+    {
+        int64_t longest = 0;
+        for (int64_t p = 0; p < n; ++p) longest = std::max<int64_t>(longest, ptr[p + 1] - ptr[p]);
+        F->held = longest <= 8 ? 8 : 16;
+    }
     KR_TRY(up(&F->d_ptr, ptr)); KR_TRY(up(&F->d_col, col)); KR_TRY(up(&F->d_val, val)); KR_TRY(up(&F->d_row, rowid));
     KR_TRY(up(&F->d_diag, dg)); KR_TRY(up(&F->d_lvl_off, F->lvl_off));
     return KRYST_OK;
@@ -1401,6 +1439,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         const size_t fn = (size_t)ptr[n];
         F->npos = n;
         F->ell = maxlen <= ELLW;
+        F->held = maxlen <= 8 ? 8 : 16;
         const double rows_per_level = (double)n / (double)std::max<size_t>(1, F->lvl_off.size() - 1);
         F->syncfree = env_i("KRYST_ILU_SYNCFREE", (F->ell || rows_per_level >= 512.0) ? 1 : 0) != 0;
         int32_t* d_pos = which == 0 ? t.posL : t.posU;
