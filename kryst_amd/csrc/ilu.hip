@@ -451,6 +451,69 @@ __global__ __launch_bounds__(1024) void tri_run_kernel(const TriArgs* args, cons
     }
 }
 
+// The same run, software-pipelined: a level of a narrow factor is three DEPENDENT round trips (row pointers -> entries -> solution
+// values) and a workgroup barrier, 3.4 us; only the last of the three depends on the level before.  Here the row pointers and the
+// right-hand side of level lv + 2 and the first H entries (columns and values) of the rows of level lv + 1 are requested BEFORE level lv
+// is computed, so that between two barriers there is one gather of solution values (this workgroup wrote them: L2 at worst), the
+// subtractions in stored order and the store.  Each thread owns up to two rows of a level (levels of at most 2 048 rows, 1 024
+// threads: the pipelined row is the thread's first one, a second one is done as in tri_run_kernel); rows longer than H continue from
+// memory.  The same operations in the same order as tri_run_kernel: same bits.
+template <bool FORWARD, int H>
+__global__ __launch_bounds__(1024) void tri_run_pipe_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
+                                                            const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                                                            const double* __restrict__ val, const double* __restrict__ diag,
+                                                            const int32_t* __restrict__ lvl_off, int32_t l0, int32_t l1) {
+    if (args->skip) return;
+    struct Head { int32_t p, k0, k1; double s, dg; };                      // a row's position (-1: none), entry range, right-hand side, divisor
+    struct Body { int32_t c[H]; double v[H]; };
+    auto head_of = [&](int32_t lv) -> Head {
+        Head h{-1, 0, 0, 0.0, 1.0};
+        if (lv < l1) {
+            const int32_t p = lvl_off[lv] + (int32_t)threadIdx.x;
+            if (p < lvl_off[lv + 1]) { h.p = p; h.k0 = ptr[p]; h.k1 = ptr[p + 1]; h.s = in[p]; if (!FORWARD) h.dg = diag[p]; }
+        }
+        return h;
+    };
+    auto body_of = [&](const Head& h) -> Body {
+        Body b;
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            const bool on = h.p >= 0 && h.k0 + u < h.k1;
+            b.c[u] = on ? col[h.k0 + u] : 0;
+            b.v[u] = on ? val[h.k0 + u] : 0.0;
+        }
+        return b;
+    };
+    Head hc = head_of(l0), hn = head_of(l0 + 1);
+    Body bc = body_of(hc);
+    for (int32_t lv = l0; lv < l1; ++lv) {
+        // vector loads return in order: the gather of THIS level is requested first, the look-ahead loads behind it, so that the
+        // subtractions wait for the gather alone (look-ahead first would put its cold misses back on the level's critical path)
+        double x[H];
+#pragma unroll
+        for (int u = 0; u < H; ++u) x[u] = out[bc.c[u]];                              // (slots past the row's end read position 0: valid, unused)
+        asm volatile("" ::: "memory");
+        const Body bn = body_of(hn);                                       // in flight while this level is computed
+        const Head hnn = head_of(lv + 2);
+        asm volatile("" ::: "memory");
+        if (hc.p >= 0) {
+            double s = hc.s;
+#pragma unroll
+            for (int u = 0; u < H; ++u) if (hc.k0 + u < hc.k1) s = s - bc.v[u] * x[u];    // stored order
+            for (int32_t k = hc.k0 + H; k < hc.k1; ++k) s = s - val[k] * out[col[k]];
+            out[hc.p] = FORWARD ? s : s / hc.dg;
+        }
+        // levels wider than the workgroup (up to 2 048 rows): the rest as in tri_run_kernel
+        for (int32_t p = lvl_off[lv] + (int32_t)threadIdx.x + (int32_t)blockDim.x; p < lvl_off[lv + 1]; p += blockDim.x) {
+            double s = in[p];
+            for (int32_t k = ptr[p]; k < ptr[p + 1]; ++k) s = s - val[k] * out[col[k]];
+            out[p] = FORWARD ? s : s / diag[p];
+        }
+        __syncthreads();
+        hc = hn; bc = bn; hn = hnn;
+    }
+}
+
 // runs in stream order before the level kernels, so it sees the solver's `done` flag as of this apply
 __global__ void tri_set_args(TriArgs* a, const double* r, double* z, const int* done) {
     a->r = r; a->z = z; a->skip = (done && *done) ? 1 : 0;
@@ -493,8 +556,12 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
         if (rows <= NARROW && !F.ell) {
             int l1 = lv + 1;
             while (l1 < nl && F.lvl_off[l1 + 1] - F.lvl_off[l1] <= NARROW) ++l1;
-            hipLaunchKernelGGL((tri_run_kernel<FORWARD>), dim3(1), dim3(1024), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
-                               F.d_diag, F.d_lvl_off, lv, l1);
+            if (env_i("KRYST_ILU_RUN_PIPE", 1) != 0)
+                hipLaunchKernelGGL((tri_run_pipe_kernel<FORWARD, 8>), dim3(1), dim3(1024), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
+                                   F.d_diag, F.d_lvl_off, lv, l1);
+            else
+                hipLaunchKernelGGL((tri_run_kernel<FORWARD>), dim3(1), dim3(1024), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
+                                   F.d_diag, F.d_lvl_off, lv, l1);
             lv = l1;
         } else {
             if (F.ell)
