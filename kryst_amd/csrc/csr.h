@@ -26,6 +26,8 @@ struct kryst_csr_s {
     int32_t* d_poff = nullptr;      // table: col - row
     double* d_pval = nullptr;       // table: value
     int32_t npat = 0, ntab = 0, pat_unroll = 8; bool pat_single = false;
+    int32_t pat_far_lo = 0, pat_far_hi = 0; bool pat_far_uniform = false;   // table positions 0 / 6 are the same offsets in every base (a whole box on one rank)
+    int32_t pat_stage_n = 0;       // > 0: every base is (far, -n, -1, 0, +1, +n, far) with one even n <= 1024 -- the near operands of a run of tiles can be staged in LDS (spmv_pattern_stage_kernel)
     bool pat_diag3 = false;        // stencil generator: every row has its diagonal, at table position 3 of its base   // table entries padded per pattern to a multiple of pat_unroll
     // CSR-DIA: operators with at most KR_DIA_MAX = 32 distinct (col - row) offsets that fill their diagonals (any stencil on a structured
     // grid, variable coefficients included): the values as ONE stream per diagonal in natural row order, absent entries marked by

@@ -40,6 +40,24 @@ static int32_t upload_patterns(kryst_csr_t a, const std::vector<uint16_t>& pid, 
         const size_t b = meta[p] & 0xffffu; const int len = (int)(meta[p] >> 16);
         a->pat_diag3 = len == 7 && poff[b + 2] == -1 && poff[b + 3] == 0 && poff[b + 4] == 1 && (meta[p + 1] & 8u);
     }
+    // ... and, beyond that, positions 1 and 5 are the columns row - n and row + n with ONE even n <= 1024 in every base (a box of
+    // lines of n points, whatever the far couplings at positions 0 and 6 are): spmv_pattern_stage_kernel
+    a->pat_stage_n = 0;
+    if (a->pat_diag3) {
+        int32_t nn = -1;
+        for (size_t p = 0; p + 1 < meta.size() && nn != 0; p += 2) {
+            const size_t b = meta[p] & 0xffffu;
+            const int32_t lo = poff[b + 1], hi = poff[b + 5];
+            if (lo >= 0 || hi != -lo || (nn > 0 && hi != nn)) nn = 0; else nn = hi;
+        }
+        if (nn >= 8 && nn <= 1024 && nn % 2 == 0) a->pat_stage_n = nn;
+        a->pat_far_uniform = a->pat_stage_n > 0;
+        for (size_t p = 0; p + 1 < meta.size() && a->pat_far_uniform; p += 2) {
+            const size_t b = meta[p] & 0xffffu;
+            if (p == 0) { a->pat_far_lo = poff[b]; a->pat_far_hi = poff[b + 6]; }
+            else a->pat_far_uniform = poff[b] == a->pat_far_lo && poff[b + 6] == a->pat_far_hi;
+        }
+    }
     return KRYST_OK;
 }
 static int32_t build_patterns(kryst_csr_t a, const std::vector<int32_t>& rp, const std::vector<int32_t>& col, const double* val) {
@@ -735,6 +753,8 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
             (void)hipMemcpyAsync(a->d_pval, pval.data(), sizeof(double) * pval.size(), hipMemcpyHostToDevice, ctx->s_main);
             (void)hipStreamSynchronize(ctx->s_main);
             a->npat = 256; a->ntab = (int32_t)poff.size(); a->pat_unroll = 7; a->pat_single = true; a->pat_diag3 = true;
+            a->pat_stage_n = (N >= 8 && N <= 1024 && N % 2 == 0) ? N : 0;
+            a->pat_far_uniform = a->pat_stage_n > 0 && !dist; a->pat_far_lo = (int32_t)-N2; a->pat_far_hi = (int32_t)N2;
             (void)hipMemsetAsync(a->d_pid, 0, sizeof(uint16_t) * (size_t)((nloc + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE), ctx->s_main);
         }
         (void)hipMemsetAsync(a->d_col + nnz, 0, sizeof(int32_t) * 8, ctx->s_main);

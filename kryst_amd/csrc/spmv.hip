@@ -585,6 +585,149 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {
     }
 }
 
+// CSR-P16 with the NEAR operands staged in LDS (spmv_pattern_stage_kernel).  spmv_pattern_kernel pays per vector-memory
+// instruction (six 16-byte gathers per tile and wave) and per tile a chain of dependent latencies (ids -> tables -> gathers -> store ->
+// fold).  For operators whose every base is (far, -n, -1, 0, +1, +n, far) with one even n <= 1024 (csr.h: pat_stage_n -- a box of lines
+// of n points; the generator-made operators and host-built ones alike) a workgroup takes a RUN of T consecutive tiles and
+//   * requests, together, the ids of all T tiles and the run's window of x -- x[r0 - n - 2 .. r0 + 512 T + n + 2), T + (2 n + 4) / 512
+//     coalesced 16-byte loads per lane instead of 4 T gathers -- and copies the tables; one barrier;
+//   * requests the far operands (table positions 0 and 6) of all T tiles together;
+//   * then computes tile after tile out of LDS: five aligned 16-byte LDS reads give x[row - n], x[row - 2 .. row + 3], x[row + n].
+// Two global round trips per RUN instead of a dependent chain per tile, 2 T + T + (2 n + 4) / 512 global loads instead of 6 T.
+// The arithmetic is spmv_pattern_kernel's: every row's entries in stored order, un-fused multiply and add, absent entries skipped by
+// a select -- the same bits.
+// UFAR: the far offsets (table positions 0 and 6) are the same in every base: the far operands are requested with everything else
+// (ONE round trip per run), with clamped addresses where a row has no such entry.
+template <int NQ, int T, bool CENTER, bool UFAR>
+__global__ __launch_bounds__(KR_T) void spmv_pattern_stage_kernel(const SpmvArgs a, const int32_t n, const int32_t far_lo, const int32_t far_hi) {
+    if (a.done && *a.done) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int XS = T * KR_TILE + 2 * n + 4;                                  // staged elements (even)
+    double* xs = reinterpret_cast<double*>(smem);
+    uint2* meta = reinterpret_cast<uint2*>(xs + XS);
+    double* pval = reinterpret_cast<double*>(meta + a.npat);
+    int32_t* poff = reinterpret_cast<int32_t*>(pval + a.ntab);
+    double* red = reinterpret_cast<double*>(smem + a.pat_red_off);
+    const int t = threadIdx.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q0 = (slot * 8 + xcd) * T;                                     // runs of T consecutive tiles round-robin over the XCDs
+    if (q0 >= a.ntiles) return;                                              // (uniform over the workgroup)
+    const int nt = min(T, a.ntiles - q0);
+    const int64_t r0 = (int64_t)q0 * KR_TILE;
+    // ---- round trip 1: ids of the run, the window of x, the tables
+    unsigned ids[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) ids[k] = k < nt ? *reinterpret_cast<const unsigned*>(a.pid + (size_t)(q0 + k) * KR_TILE + 2 * t) : 0u;
+    constexpr int NP = (T * KR_TILE + 2 * 1024 + 4 + 2 * KR_T - 1) / (2 * KR_T);   // pairs per lane at most (n <= 1024)
+    const int npairs = XS / 2;
+    const int64_t e0 = r0 - n - 2;                                           // element of x staged at xs[0] (even)
+    // the window goes STRAIGHT into LDS (global_load_lds_dwordx4, gfx950's LDS-DMA: destination = a wave-uniform base + 16 bytes per
+    // lane, which is exactly the window's layout): no staging registers, no LDS store instructions
+    const int wbase = __builtin_amdgcn_readfirstlane(t & ~63);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int pi = t + i * KR_T;
+        if (pi < npairs) {
+            const int64_t e = min(max(e0 + 2 * (int64_t)pi, (int64_t)0), a.xsafe);   // outside x: any valid pair (those operands are absent entries)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + e),
+                                             (__attribute__((address_space(3))) void*)(xs + 2 * (i * KR_T + wbase)), 16, 0, 0);
+        }
+    }
+    uint2 ma[T], mb[T]; v2d lo[T], hi[T]; d2 dv[T];
+    if constexpr (UFAR) {
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            const int64_t row = r0 + (int64_t)k * KR_TILE + 2 * t;
+            lo[k] = *reinterpret_cast<const v2d*>(a.x + min(max(row + far_lo, (int64_t)0), a.xsafe));
+            hi[k] = *reinterpret_cast<const v2d*>(a.x + min(max(row + far_hi, (int64_t)0), a.xsafe));
+            if constexpr (NQ > 0 && !CENTER) { dv[k].a = 0.0; dv[k].b = 0.0; if (k < nt) dv[k] = ld2(a.dvec, row); }
+        }
+    }
+    for (int i = t; i < a.npat; i += KR_T) meta[i] = reinterpret_cast<const uint2*>(a.pmeta)[i];
+    for (int i = t; i < a.ntab; i += KR_T) { poff[i] = a.poff[i]; pval[i] = a.pval[i]; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the window has landed (the compiler does not count LDS-DMA requests)
+    __syncthreads();
+    // ---- round trip 2 (!UFAR): the far operands of every tile of the run (and the fused dot's vector when it is not x itself)
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        const int64_t row = r0 + (int64_t)k * KR_TILE + 2 * t;
+        const bool va = k < nt && row < a.nrows, vb = k < nt && row + 1 < a.nrows;
+        ma[k] = va ? meta[ids[k] & 0xffffu] : make_uint2(0u, 0u);
+        mb[k] = vb ? meta[ids[k] >> 16] : make_uint2(0u, 0u);
+        if constexpr (UFAR) continue;
+        const int ba = ma[k].x & 0xffffu, bb = mb[k].x & 0xffffu;
+        lo[k].x = 0.0; lo[k].y = 0.0; hi[k].x = 0.0; hi[k].y = 0.0;
+        const bool a0 = ma[k].y & 1u, b0 = mb[k].y & 1u, a6 = (ma[k].y >> 6) & 1u, b6 = (mb[k].y >> 6) & 1u;
+#if defined(KR_STAGE_ABL) && (KR_STAGE_ABL & 2)
+        if (t == 12345) lo[k] = *reinterpret_cast<const v2d*>(a.x + row + poff[ba]);        // timing only: no far operands
+        if (t == 12345) hi[k] = *reinterpret_cast<const v2d*>(a.x + row + poff[ba + 6]);
+        continue;
+#endif
+        if (a0 && b0 && ba == bb) lo[k] = *reinterpret_cast<const v2d*>(a.x + row + poff[ba]);
+        else { if (a0) lo[k].x = a.x[row + poff[ba]]; if (b0) lo[k].y = a.x[row + 1 + poff[bb]]; }
+        if (a6 && b6 && ba == bb) hi[k] = *reinterpret_cast<const v2d*>(a.x + row + poff[ba + 6]);
+        else { if (a6) hi[k].x = a.x[row + poff[ba + 6]]; if (b6) hi[k].y = a.x[row + 1 + poff[bb + 6]]; }
+        if constexpr (NQ > 0 && !CENTER) { dv[k].a = 0.0; dv[k].b = 0.0; if (k < nt) dv[k] = ld2(a.dvec, row); }
+    }
+    // ---- tile after tile out of LDS
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        if (k >= nt) break;                                                  // (uniform)
+        const int64_t row = r0 + (int64_t)k * KR_TILE + 2 * t;
+        const bool va = row < a.nrows, vb = row + 1 < a.nrows;
+        const int j = k * KR_TILE + 2 * t + n + 2;                           // xs[j] = x[row]
+        const v2d A = *reinterpret_cast<const v2d*>(xs + j - 2), B = *reinterpret_cast<const v2d*>(xs + j), C = *reinterpret_cast<const v2d*>(xs + j + 2);
+        const v2d M = *reinterpret_cast<const v2d*>(xs + j - n), P = *reinterpret_cast<const v2d*>(xs + j + n);
+        v2d e[7];
+        e[0] = lo[k]; e[1] = M; e[2].x = A.y; e[2].y = B.x; e[3] = B; e[4].x = B.y; e[4].y = C.x; e[5] = P; e[6] = hi[k];
+        const double* tva = pval + (ma[k].x & 0xffffu); const double* tvb = pval + (mb[k].x & 0xffffu);
+        const unsigned ka = ma[k].y, kb = mb[k].y;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const double ta = s0 + tva[u] * e[u].x, tb = s1 + tvb[u] * e[u].y;
+            s0 = ((ka >> u) & 1u) ? ta : s0;
+            s1 = ((kb >> u) & 1u) ? tb : s1;
+        }
+#if defined(KR_STAGE_ABL) && (KR_STAGE_ABL & 1)
+        if (s0 == 1.23456789e-300) a.y[row] = s0;                           // timing only: no y traffic
+#else
+        if (vb) st2(a.y, row, s0, s1);
+        else if (va) a.y[row] = s0;
+#endif
+        if constexpr (NQ > 0) {
+            // the tile's partials in the library's order (thread: its two rows; wave: butterfly; workgroup: the four waves in
+            // turn) -- the cross-wave step of all T tiles of the run meets at ONE barrier below
+            double acc[NQ];
+            d2 d;
+            if constexpr (CENTER) { d.a = B.x; d.b = B.y; } else d = dv[k];
+            acc[0] = 0.0;
+            if (va) acc[0] = acc[0] + d.a * s0;
+            if (vb) acc[0] = acc[0] + d.b * s1;
+            if constexpr (NQ > 1) {
+                acc[1] = 0.0;
+                if (va) acc[1] = acc[1] + s0 * s0;
+                if (vb) acc[1] = acc[1] + s1 * s1;
+            }
+#pragma unroll
+            for (int kk = 0; kk < NQ; ++kk) {
+                const double wsum = wave_butterfly(acc[kk]);
+                if ((t & 63) == 0) red[(k * NQ + kk) * (KR_T / 64) + (t >> 6)] = wsum;
+            }
+        }
+    }
+    if constexpr (NQ > 0) {
+        __syncthreads();
+        if (t < nt * NQ) {                                                   // thread k * NQ + kk: tile q0 + k, quantity kk
+            const int k = t / NQ, kk = t % NQ;
+            double sum = red[t * (KR_T / 64)];
+#pragma unroll
+            for (int w2 = 1; w2 < KR_T / 64; ++w2) sum = sum + red[t * (KR_T / 64) + w2];
+            a.partials[kk * a.pstride + q0 + k] = sum;
+        }
+    }
+}
+
 // CSR-DIA (spmv_dia_kernel): operators with a handful of well-filled diagonals -- every stencil on a structured grid, variable
 // coefficients included.  The values are stored as one stream per diagonal in natural row order (csr_create.hip: build_dia), an
 // absent entry carries a NaN payload no stored value may have, so there are NO row pointers, NO per-entry codes and no
@@ -743,6 +886,32 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
         // a workgroup loads the tables once and walks one run of 8 consecutive tiles (next tile's ids prefetched); runs go
         // round-robin over the XCDs.  Measured at 512^3 (round-2 sweeps and --pmc passes, profiles/r02/): 0.70 ms and 1.6 GB of reads
         // per launch, against 0.79 ms and 4.1 GB for a strided persistent grid whose fast workgroups run ahead.
+        // the near operands staged in LDS, runs of T = 4 tiles per workgroup (natural tile order, no halo columns)
+        if (!HALO && !tiles && a->pat_stage_n > 0 && a->npat <= 512 && a->ntab <= 512 && env_int("KRYST_SPMV_STAGE", 1) != 0 &&
+            a->xlen + 2 * KR_TILE < (1ll << 31)) {
+            constexpr int T = 4;
+            const int32_t n_ = a->pat_stage_n;
+            const size_t xs_bytes = sizeof(double) * (size_t)(T * KR_TILE + 2 * n_ + 4);
+            const size_t tab = xs_bytes + (size_t)a->npat * 8 + (size_t)a->ntab * 12;
+            args.pat_red_off = (int32_t)((tab + 15) & ~(size_t)15);
+            const size_t lds_s = (size_t)args.pat_red_off + sizeof(double) * (size_t)T * (size_t)(nq > 0 ? nq : 1) * (KR_T / 64);
+            args.xsafe = (a->xlen + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE - 2;
+            const int64_t nruns = (ntiles + T - 1) / T;
+            const dim3 sgrid((unsigned)((nruns + 7) / 8 * 8));
+            const bool center = nq > 0 && dvec == x;
+            const bool ufar = a->pat_far_uniform && env_int("KRYST_SPMV_STAGE_UFAR", 1) != 0;
+#define KR_STG(NQ_, C_) do { if (ufar) hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, T, C_, true>), sgrid, block, lds_s, ctx->s_main, args, n_, a->pat_far_lo, a->pat_far_hi); \
+                             else hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, T, C_, false>), sgrid, block, lds_s, ctx->s_main, args, n_, 0, 0); } while (0)
+            switch (nq) {
+                case 0: KR_STG(0, false); break;
+                case 1: if (center) KR_STG(1, true); else KR_STG(1, false); break;
+                case 2: if (center) KR_STG(2, true); else KR_STG(2, false); break;
+                default: set_error("spmv: nq=%d", nq); return KRYST_ERR_ARG;
+            }
+#undef KR_STG
+            KR_HIP(hipGetLastError());
+            return KRYST_OK;
+        }
         args.group = ordered ? 8 : std::max(1, env_int("KRYST_SPMV_GROUP", 8));
         const int64_t pchunk = (chunk + args.group - 1) / args.group * args.group;      // an XCD's share is a whole number of runs
         args.xcd_chunk = (int32_t)pchunk;
