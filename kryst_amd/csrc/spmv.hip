@@ -610,38 +610,69 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_stage_kernel(const SpmvArgs
     double* red = reinterpret_cast<double*>(smem + a.pat_red_off);
     const int t = threadIdx.x;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int q0 = (slot * 8 + xcd) * T;                                     // runs of T consecutive tiles round-robin over the XCDs
+    const int G = a.group;                                                   // G consecutive runs per XCD (neighbouring runs share window edges)
+    const int q0 = (((slot / G) * 8 + xcd) * G + slot % G) * T;              // runs of T consecutive tiles, groups of G runs round-robin over the XCDs
     if (q0 >= a.ntiles) return;                                              // (uniform over the workgroup)
     const int nt = min(T, a.ntiles - q0);
-    const int64_t r0 = (int64_t)q0 * KR_TILE;
+    const int32_t r0 = q0 * KR_TILE;                                         // (the launch checks xlen + 2 tiles < 2^31: 32-bit element indices)
     // ---- round trip 1: ids of the run, the window of x, the tables
+    // The kernel is bound by VALU issue (a 64-lane instruction takes four cycles whatever it does; 770 of them per wave and run
+    // before this paragraph, 45 % selects and compares): indices are 32-bit, and a run that lies INSIDE x with its whole window and
+    // its far operands -- all but the first and last few of a box -- takes a path without a single clamp (uniform over the workgroup).
     unsigned ids[T];
 #pragma unroll
     for (int k = 0; k < T; ++k) ids[k] = k < nt ? *reinterpret_cast<const unsigned*>(a.pid + (size_t)(q0 + k) * KR_TILE + 2 * t) : 0u;
     constexpr int NP = (T * KR_TILE + 2 * 1024 + 4 + 2 * KR_T - 1) / (2 * KR_T);   // pairs per lane at most (n <= 1024)
     const int npairs = XS / 2;
-    const int64_t e0 = r0 - n - 2;                                           // element of x staged at xs[0] (even)
+    const int32_t e0 = r0 - n - 2;                                           // element of x staged at xs[0] (even)
+    const int32_t xsafe = (int32_t)a.xsafe;
+    const bool inside = e0 >= 0 && e0 + XS <= xsafe && (!UFAR || ((int64_t)r0 + far_lo >= 0 && (int64_t)r0 + T * KR_TILE + far_hi <= (int64_t)xsafe));
     // the window goes STRAIGHT into LDS (global_load_lds_dwordx4, gfx950's LDS-DMA: destination = a wave-uniform base + 16 bytes per
     // lane, which is exactly the window's layout): no staging registers, no LDS store instructions
     const int wbase = __builtin_amdgcn_readfirstlane(t & ~63);
+    uint2 ma[T], mb[T]; v2d lo[T], hi[T]; d2 dv[T];
+    if (inside) {
+        const double* xw = a.x + e0 + 2 * t;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int pi = t + i * KR_T;
-        if (pi < npairs) {
-            const int64_t e = min(max(e0 + 2 * (int64_t)pi, (int64_t)0), a.xsafe);   // outside x: any valid pair (those operands are absent entries)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + e),
-                                             (__attribute__((address_space(3))) void*)(xs + 2 * (i * KR_T + wbase)), 16, 0, 0);
+        for (int i = 0; i < NP; ++i) {
+            if (t + i * KR_T < npairs)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xw + 2 * i * KR_T),
+                                                 (__attribute__((address_space(3))) void*)(xs + 2 * (i * KR_T + wbase)), 16, 0, 0);
+        }
+        if constexpr (UFAR) {
+            const double* xl = a.x + (r0 + 2 * t) + far_lo; const double* xh = a.x + (r0 + 2 * t) + far_hi;
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+#if defined(KR_STAGE_ABL) && (KR_STAGE_ABL & 2)
+                lo[k].x = 1.0; lo[k].y = 2.0; hi[k].x = 3.0; hi[k].y = 4.0;  // timing only: no far operands
+#else
+                lo[k] = *reinterpret_cast<const v2d*>(xl + k * KR_TILE);
+                hi[k] = *reinterpret_cast<const v2d*>(xh + k * KR_TILE);
+#endif
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int pi = t + i * KR_T;
+            if (pi < npairs) {
+                const int32_t e = min(max(e0 + 2 * pi, 0), xsafe);             // outside x: any valid pair (those operands are absent entries)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + e),
+                                                 (__attribute__((address_space(3))) void*)(xs + 2 * (i * KR_T + wbase)), 16, 0, 0);
+            }
+        }
+        if constexpr (UFAR) {
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                const int64_t row = (int64_t)r0 + k * KR_TILE + 2 * t;
+                lo[k] = *reinterpret_cast<const v2d*>(a.x + min(max(row + far_lo, (int64_t)0), (int64_t)xsafe));
+                hi[k] = *reinterpret_cast<const v2d*>(a.x + min(max(row + far_hi, (int64_t)0), (int64_t)xsafe));
+            }
         }
     }
-    uint2 ma[T], mb[T]; v2d lo[T], hi[T]; d2 dv[T];
-    if constexpr (UFAR) {
+    if constexpr (UFAR && NQ > 0 && !CENTER) {
 #pragma unroll
-        for (int k = 0; k < T; ++k) {
-            const int64_t row = r0 + (int64_t)k * KR_TILE + 2 * t;
-            lo[k] = *reinterpret_cast<const v2d*>(a.x + min(max(row + far_lo, (int64_t)0), a.xsafe));
-            hi[k] = *reinterpret_cast<const v2d*>(a.x + min(max(row + far_hi, (int64_t)0), a.xsafe));
-            if constexpr (NQ > 0 && !CENTER) { dv[k].a = 0.0; dv[k].b = 0.0; if (k < nt) dv[k] = ld2(a.dvec, row); }
-        }
+        for (int k = 0; k < T; ++k) { dv[k].a = 0.0; dv[k].b = 0.0; if (k < nt) dv[k] = ld2(a.dvec, r0 + k * KR_TILE + 2 * t); }
     }
     for (int i = t; i < a.npat; i += KR_T) meta[i] = reinterpret_cast<const uint2*>(a.pmeta)[i];
     for (int i = t; i < a.ntab; i += KR_T) { poff[i] = a.poff[i]; pval[i] = a.pval[i]; }
@@ -650,7 +681,7 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_stage_kernel(const SpmvArgs
     // ---- round trip 2 (!UFAR): the far operands of every tile of the run (and the fused dot's vector when it is not x itself)
 #pragma unroll
     for (int k = 0; k < T; ++k) {
-        const int64_t row = r0 + (int64_t)k * KR_TILE + 2 * t;
+        const int32_t row = r0 + k * KR_TILE + 2 * t;
         const bool va = k < nt && row < a.nrows, vb = k < nt && row + 1 < a.nrows;
         ma[k] = va ? meta[ids[k] & 0xffffu] : make_uint2(0u, 0u);
         mb[k] = vb ? meta[ids[k] >> 16] : make_uint2(0u, 0u);
@@ -673,7 +704,7 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_stage_kernel(const SpmvArgs
 #pragma unroll
     for (int k = 0; k < T; ++k) {
         if (k >= nt) break;                                                  // (uniform)
-        const int64_t row = r0 + (int64_t)k * KR_TILE + 2 * t;
+        const int32_t row = r0 + k * KR_TILE + 2 * t;
         const bool va = row < a.nrows, vb = row + 1 < a.nrows;
         const int j = k * KR_TILE + 2 * t + n + 2;                           // xs[j] = x[row]
         const v2d A = *reinterpret_cast<const v2d*>(xs + j - 2), B = *reinterpret_cast<const v2d*>(xs + j), C = *reinterpret_cast<const v2d*>(xs + j + 2);
@@ -683,6 +714,8 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_stage_kernel(const SpmvArgs
         const double* tva = pval + (ma[k].x & 0xffffu); const double* tvb = pval + (mb[k].x & 0xffffu);
         const unsigned ka = ma[k].y, kb = mb[k].y;
         double s0 = 0.0, s1 = 0.0;
+        // (a scalar branch per entry for the entries every row of the wave has -- no select then -- was tried: 114 branches per run cost
+        // more than the selects they save, 0.59 -> 0.64 ms at 512^3)
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             const double ta = s0 + tva[u] * e[u].x, tb = s1 + tvb[u] * e[u].y;
@@ -889,7 +922,7 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
         // the near operands staged in LDS, runs of T = 4 tiles per workgroup (natural tile order, no halo columns)
         if (!HALO && !tiles && a->pat_stage_n > 0 && a->npat <= 512 && a->ntab <= 512 && env_int("KRYST_SPMV_STAGE", 1) != 0 &&
             a->xlen + 2 * KR_TILE < (1ll << 31)) {
-            constexpr int T = 4;
+            const int T = env_int("KRYST_SPMV_STAGE_T", 4) <= 2 ? 2 : 4;
             const int32_t n_ = a->pat_stage_n;
             const size_t xs_bytes = sizeof(double) * (size_t)(T * KR_TILE + 2 * n_ + 4);
             const size_t tab = xs_bytes + (size_t)a->npat * 8 + (size_t)a->ntab * 12;
@@ -897,11 +930,16 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
             const size_t lds_s = (size_t)args.pat_red_off + sizeof(double) * (size_t)T * (size_t)(nq > 0 ? nq : 1) * (KR_T / 64);
             args.xsafe = (a->xlen + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE - 2;
             const int64_t nruns = (ntiles + T - 1) / T;
-            const dim3 sgrid((unsigned)((nruns + 7) / 8 * 8));
+            // groups of 4 runs per XCD once the launch is well beyond one wave of workgroups (in-process A/B: 512^3 +1.2 %, 256^3 +-0,
+            // 192^3 +4 %, but 128^3 -19 %; 8: +1.3 / -4.5 % at 512^3 / 256^3; 32: -2 / -21 %)
+            args.group = std::max(1, env_int("KRYST_SPMV_STAGE_GROUP", nruns >= 2048 ? 4 : 1));
+            const int64_t per_xcd = ((nruns + 7) / 8 + args.group - 1) / args.group * args.group;      // slots per XCD: whole groups
+            const dim3 sgrid((unsigned)(per_xcd * 8));
             const bool center = nq > 0 && dvec == x;
             const bool ufar = a->pat_far_uniform && env_int("KRYST_SPMV_STAGE_UFAR", 1) != 0;
-#define KR_STG(NQ_, C_) do { if (ufar) hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, T, C_, true>), sgrid, block, lds_s, ctx->s_main, args, n_, a->pat_far_lo, a->pat_far_hi); \
-                             else hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, T, C_, false>), sgrid, block, lds_s, ctx->s_main, args, n_, 0, 0); } while (0)
+#define KR_STG(NQ_, C_) do { if (ufar && T == 2) hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, 2, C_, true>), sgrid, block, lds_s, ctx->s_main, args, n_, a->pat_far_lo, a->pat_far_hi); \
+                             else if (ufar) hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, 4, C_, true>), sgrid, block, lds_s, ctx->s_main, args, n_, a->pat_far_lo, a->pat_far_hi); \
+                             else hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, 4, C_, false>), sgrid, block, lds_s, ctx->s_main, args, n_, 0, 0); } while (0)
             switch (nq) {
                 case 0: KR_STG(0, false); break;
                 case 1: if (center) KR_STG(1, true); else KR_STG(1, false); break;
