@@ -94,6 +94,7 @@ extern "C" {
     pub fn kryst_csr_shape(a: Csr, nrows_local: *mut i64, ncols_global: *mut i64, nnz_local: *mut i64) -> i32;
     pub fn kryst_csr_encoding(a: Csr, encoding: *mut i32, patterns: *mut i32, table_entries: *mut i32) -> i32;
     pub fn kryst_csr_tile_order(a: Csr, info: *mut i64) -> i32;
+    pub fn kryst_csr_pattern_info(a: Csr, info: *mut i64) -> i32;
     pub fn kryst_csr_download(a: Csr, row_ptr: *mut i64, col_idx_local: *mut i32, vals: *mut f64) -> i32;
 
     pub fn kryst_spmv(a: Csr, x: Vecd, y: Vecd) -> i32;

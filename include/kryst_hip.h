@@ -131,6 +131,11 @@ int32_t kryst_csr_encoding(kryst_csr_t a, int32_t* encoding, int32_t* patterns, 
  * plane segment by segment so that an XCD's L2 keeps its window of x; which rows a tile holds and every result bit are unchanged).
  * info[0] rows per plane (0: natural order only), info[1], info[2] slots of the two orders, info[3] 1 if kryst_spmv uses it now */
 int32_t kryst_csr_tile_order(kryst_csr_t a, int64_t* info);
+/* measurement hook: the staged-window form of the CSR-P16 kernel (operators whose row patterns are (far, -n, -1, 0, +1, +n, far) with one
+ * even n <= 1024: the near operands of a run of tiles come out of an LDS window).  info[0] n (0: not this form), info[1] 1 if the far
+ * offsets are the same in every pattern, info[2] first tile of a rank's contiguous interior range (-1: none), info[3] 1 if kryst_spmv
+ * takes that kernel now */
+int32_t kryst_csr_pattern_info(kryst_csr_t a, int64_t* info);
 int32_t kryst_csr_download(kryst_csr_t a, int64_t* row_ptr, int32_t* col_idx_local, double* vals);
 
 /* MatVec::matvec (src/core/traits.rs:4-7) == SparseMatrix::spmv (sparse.rs:56-67): y <- A x, y overwritten */

@@ -295,6 +295,12 @@ class CsrMatrix:
         check(lib().kryst_csr_tile_order(self.h, info))
         return {"plane_rows": info[0], "slots": info[1], "slots8": info[2], "in_use": bool(info[3])}
 
+    def pattern_info(self):
+        """Measurement hook (kryst_csr_pattern_info): {"line", "uniform_far", "interior_first", "staged"} of the CSR-P16 form."""
+        info = (C.c_int64 * 4)()
+        check(lib().kryst_csr_pattern_info(self.h, info))
+        return {"line": info[0], "uniform_far": bool(info[1]), "interior_first": info[2], "staged": bool(info[3])}
+
     def bench_spmv(self, x, y, fused_dots=1, reps=50):
         """Average milliseconds per launch of the SpMV kernel (HIP events on the compute stream)."""
         ms = C.c_double()

@@ -73,6 +73,7 @@ SIGNATURES = {
     "kryst_spmv_host": (C.c_int32, [Handle, c_dp, C.c_int64, c_dp, C.c_int64]),
     "kryst_csr_encoding": (C.c_int32, [Handle, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "kryst_csr_tile_order": (C.c_int32, [Handle, C.POINTER(C.c_int64)]),
+    "kryst_csr_pattern_info": (C.c_int32, [Handle, C.POINTER(C.c_int64)]),
     "kryst_bench_spmv": (C.c_int32, [Handle, Handle, Handle, C.c_int32, C.c_int32, c_dp]),
     "kryst_bench_streams": (C.c_int32, [Handle, C.c_int64, C.c_int64, C.c_int32, C.c_int32, c_dp]),
     "kryst_dot": (C.c_int32, [Handle, Handle, c_dp]),

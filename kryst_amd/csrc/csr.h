@@ -26,6 +26,7 @@ struct kryst_csr_s {
     int32_t* d_poff = nullptr;      // table: col - row
     double* d_pval = nullptr;       // table: value
     int32_t npat = 0, ntab = 0, pat_unroll = 8; bool pat_single = false;
+    bool pat_far_interior = false;  // ... at least in the rows of interior tiles (generator-made distributed operator)
     int32_t pat_far_lo = 0, pat_far_hi = 0; bool pat_far_uniform = false;   // table positions 0 / 6 are the same offsets in every base (a whole box on one rank)
     int32_t pat_stage_n = 0;       // > 0: every base is (far, -n, -1, 0, +1, +n, far) with one even n <= 1024 -- the near operands of a run of tiles can be staged in LDS (spmv_pattern_stage_kernel)
     bool pat_diag3 = false;        // stencil generator: every row has its diagonal, at table position 3 of its base   // table entries padded per pattern to a multiple of pat_unroll
@@ -47,6 +48,7 @@ struct kryst_csr_s {
     std::vector<int64_t> row_offsets;
     kr::HaloPlan plan;
     int32_t* d_tiles_interior = nullptr; int64_t n_interior = 0;
+    int64_t interior_first = -1;    // >= 0: the interior tiles are the contiguous range [interior_first, interior_first + n_interior)
     int32_t* d_tiles_boundary = nullptr; int64_t n_boundary = 0;
     bool send_contiguous = false;   // every send list is a contiguous run of local rows (k-slab stencils)
 };

@@ -500,6 +500,7 @@ static int32_t create_dist_local(kryst_csr_t a, int64_t n_global, const int64_t*
     std::vector<int32_t> ti, tb;
     for (int64_t q = 0; q < ntiles; ++q) (tile_bnd[q] ? tb : ti).push_back((int32_t)q);
     a->n_interior = (int64_t)ti.size(); a->n_boundary = (int64_t)tb.size();
+    a->interior_first = (!ti.empty() && (int64_t)ti.back() - (int64_t)ti.front() + 1 == (int64_t)ti.size()) ? (int64_t)ti.front() : -1;
     KR_HIP(hipMalloc(&a->d_tiles_interior, sizeof(int32_t) * (ti.size() + 1)));
     KR_HIP(hipMalloc(&a->d_tiles_boundary, sizeof(int32_t) * (tb.size() + 1)));
     KR_TRY(h2d(ctx, a->d_tiles_interior, ti.data(), sizeof(int32_t) * ti.size()));
@@ -755,6 +756,7 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
             a->npat = 256; a->ntab = (int32_t)poff.size(); a->pat_unroll = 7; a->pat_single = true; a->pat_diag3 = true;
             a->pat_stage_n = (N >= 8 && N <= 1024 && N % 2 == 0) ? N : 0;
             a->pat_far_uniform = a->pat_stage_n > 0 && !dist; a->pat_far_lo = (int32_t)-N2; a->pat_far_hi = (int32_t)N2;
+            a->pat_far_interior = a->pat_stage_n > 0;                // rows of INTERIOR tiles (no halo columns) all have the far offsets -N^2 / +N^2
             (void)hipMemsetAsync(a->d_pid, 0, sizeof(uint16_t) * (size_t)((nloc + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE), ctx->s_main);
         }
         (void)hipMemsetAsync(a->d_col + nnz, 0, sizeof(int32_t) * 8, ctx->s_main);
@@ -785,6 +787,7 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
             (bnd ? tb : ti).push_back((int32_t)q);
         }
         a->n_interior = (int64_t)ti.size(); a->n_boundary = (int64_t)tb.size();
+        a->interior_first = (!ti.empty() && (int64_t)ti.back() - (int64_t)ti.front() + 1 == (int64_t)ti.size()) ? (int64_t)ti.front() : -1;
         if (hipMalloc(&a->d_tiles_interior, sizeof(int32_t) * (ti.size() + 1)) != hipSuccess ||
             hipMalloc(&a->d_tiles_boundary, sizeof(int32_t) * (tb.size() + 1)) != hipSuccess ||
             hipMalloc(&pl.d_halo, sizeof(double) * (size_t)(pl.total_recv + 2)) != hipSuccess) { set_error("hipMalloc failed (halo)"); rc = KRYST_ERR_HIP; break; }

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_kernel(const SpmvArgs a) {
 // UFAR: the far offsets (table positions 0 and 6) are the same in every base: the far operands are requested with everything else
 // (ONE round trip per run), with clamped addresses where a row has no such entry.
 template <int NQ, int T, bool CENTER, bool UFAR>
-__global__ __launch_bounds__(KR_T) void spmv_pattern_stage_kernel(const SpmvArgs a, const int32_t n, const int32_t far_lo, const int32_t far_hi) {
+__global__ __launch_bounds__(KR_T) void spmv_pattern_stage_kernel(const SpmvArgs a, const int32_t n, const int32_t far_lo, const int32_t far_hi, const int32_t tile0) {
     if (a.done && *a.done) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int XS = T * KR_TILE + 2 * n + 4;                                  // staged elements (even)
@@ -611,9 +611,12 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_stage_kernel(const SpmvArgs
     const int t = threadIdx.x;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int G = a.group;                                                   // G consecutive runs per XCD (neighbouring runs share window edges)
-    const int q0 = (((slot / G) * 8 + xcd) * G + slot % G) * T;              // runs of T consecutive tiles, groups of G runs round-robin over the XCDs
-    if (q0 >= a.ntiles) return;                                              // (uniform over the workgroup)
-    const int nt = min(T, a.ntiles - q0);
+    // runs of T consecutive tiles of the range [tile0, tile0 + ntiles) (the whole operator, or a rank's interior tiles), groups of G
+    // runs round-robin over the XCDs
+    const int qr = (((slot / G) * 8 + xcd) * G + slot % G) * T;
+    if (qr >= a.ntiles) return;                                              // (uniform over the workgroup)
+    const int nt = min(T, a.ntiles - qr);
+    const int q0 = tile0 + qr;
     const int32_t r0 = q0 * KR_TILE;                                         // (the launch checks xlen + 2 tiles < 2^31: 32-bit element indices)
     // ---- round trip 1: ids of the run, the window of x, the tables
     // The kernel is bound by VALU issue (a 64-lane instruction takes four cycles whatever it does; 770 of them per wave and run
@@ -715,7 +718,10 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_stage_kernel(const SpmvArgs
         const unsigned ka = ma[k].y, kb = mb[k].y;
         double s0 = 0.0, s1 = 0.0;
         // (a scalar branch per entry for the entries every row of the wave has -- no select then -- was tried: 114 branches per run cost
-        // more than the selects they save, 0.59 -> 0.64 ms at 512^3)
+        // more than the selects they save, 0.59 -> 0.64 ms at 512^3; so was hoisting the masks' compares and the table values out of
+        // the tile loop when a lane's ids repeat over the run, with the values as scalars when the wave has one base: 486 instead of 770
+        // VALU instructions per wave and run, and no faster -- 0.576-0.580 ms, the extra paths cost the kernel a wave per SIMD.
+        // rocprofv3 --pmc: VALU busy 47 %, LDS 15 %, 21 % of the wave cycles waiting for memory)
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             const double ta = s0 + tva[u] * e[u].x, tb = s1 + tvb[u] * e[u].y;
@@ -920,9 +926,12 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
         // round-robin over the XCDs.  Measured at 512^3 (round-2 sweeps and --pmc passes, profiles/r02/): 0.70 ms and 1.6 GB of reads
         // per launch, against 0.79 ms and 4.1 GB for a strided persistent grid whose fast workgroups run ahead.
         // the near operands staged in LDS, runs of T = 4 tiles per workgroup (natural tile order, no halo columns)
-        if (!HALO && !tiles && a->pat_stage_n > 0 && a->npat <= 512 && a->ntab <= 512 && env_int("KRYST_SPMV_STAGE", 1) != 0 &&
+        const bool whole = !tiles, interior = tiles && tiles == a->d_tiles_interior && a->interior_first >= 0 && ntiles == a->n_interior;
+        if (!HALO && (whole || interior) && a->pat_stage_n > 0 && a->npat <= 512 && a->ntab <= 512 && env_int("KRYST_SPMV_STAGE", 1) != 0 &&
             a->xlen + 2 * KR_TILE < (1ll << 31)) {
-            const int T = env_int("KRYST_SPMV_STAGE_T", 4) <= 2 ? 2 : 4;
+            const int32_t tile0 = interior ? (int32_t)a->interior_first : 0;
+            args.tiles = nullptr;
+            constexpr int T = 4;          // (runs of 2 tiles: 63 registers, 8 waves per SIMD, and 512^3 2 % slower / 256^3 3.5 % faster: not occupancy-bound)
             const int32_t n_ = a->pat_stage_n;
             const size_t xs_bytes = sizeof(double) * (size_t)(T * KR_TILE + 2 * n_ + 4);
             const size_t tab = xs_bytes + (size_t)a->npat * 8 + (size_t)a->ntab * 12;
@@ -936,10 +945,9 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
             const int64_t per_xcd = ((nruns + 7) / 8 + args.group - 1) / args.group * args.group;      // slots per XCD: whole groups
             const dim3 sgrid((unsigned)(per_xcd * 8));
             const bool center = nq > 0 && dvec == x;
-            const bool ufar = a->pat_far_uniform && env_int("KRYST_SPMV_STAGE_UFAR", 1) != 0;
-#define KR_STG(NQ_, C_) do { if (ufar && T == 2) hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, 2, C_, true>), sgrid, block, lds_s, ctx->s_main, args, n_, a->pat_far_lo, a->pat_far_hi); \
-                             else if (ufar) hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, 4, C_, true>), sgrid, block, lds_s, ctx->s_main, args, n_, a->pat_far_lo, a->pat_far_hi); \
-                             else hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, 4, C_, false>), sgrid, block, lds_s, ctx->s_main, args, n_, 0, 0); } while (0)
+            const bool ufar = (a->pat_far_uniform || (interior && a->pat_far_interior)) && env_int("KRYST_SPMV_STAGE_UFAR", 1) != 0;
+#define KR_STG(NQ_, C_) do { if (ufar) hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, T, C_, true>), sgrid, block, lds_s, ctx->s_main, args, n_, a->pat_far_lo, a->pat_far_hi, tile0); \
+                             else hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, T, C_, false>), sgrid, block, lds_s, ctx->s_main, args, n_, 0, 0, tile0); } while (0)
             switch (nq) {
                 case 0: KR_STG(0, false); break;
                 case 1: if (center) KR_STG(1, true); else KR_STG(1, false); break;
@@ -1135,6 +1143,17 @@ int32_t kryst_csr_tile_order(kryst_csr_t a, int64_t* info) {
     KR_ARG(a && info, "csr_tile_order");
     info[0] = a->d_tile_order ? a->order_plane : 0; info[1] = a->order_slots1; info[2] = a->order_slots8;
     info[3] = uses_tile_order(a) ? 1 : 0;
+    return KRYST_OK;
+}
+
+// info[0]: line length n of the staged-window form of the CSR-P16 kernel (0: the operator's bases are not (far, -n, -1, 0, +1, +n, far)),
+// info[1]: 1 when every base has the same far offsets (one round trip per run), info[2]: first tile of a rank's contiguous interior
+// range (-1: none), info[3]: 1 when kryst_spmv would take the staged-window kernel under the current settings
+int32_t kryst_csr_pattern_info(kryst_csr_t a, int64_t* info) {
+    KR_ARG(a && info, "csr_pattern_info");
+    info[0] = a->d_pid ? a->pat_stage_n : 0; info[1] = a->pat_far_uniform ? 1 : 0; info[2] = a->interior_first;
+    info[3] = (a->d_pid && a->pat_stage_n > 0 && takes_pattern_path(a, false) && a->npat <= 512 && a->ntab <= 512 && env_int("KRYST_SPMV_STAGE", 1) != 0 &&
+               a->xlen + 2 * KR_TILE < (1ll << 31) && (!a->dist || !use_collectives(a->ctx) || a->interior_first >= 0)) ? 1 : 0;
     return KRYST_OK;
 }
 

@@ -252,6 +252,61 @@ def test_spmv_slab_order_of_the_tiles_bit_exact(ctx, compress, dia, monkeypatch)
         assert out[0] == out[1], kind
 
 
+def test_spmv_pattern_kernel_with_staged_window_bit_exact(ctx, rs, monkeypatch):
+    """spmv_pattern_stage_kernel (CSR-P16 operators whose bases are (far, -n, -1, 0, +1, +n, far) with one even n <= 1024: the near
+    operands of a run of 4 tiles come out of an LDS window filled by LDS-DMA loads) against the oracle and against
+    spmv_pattern_kernel (KRYST_SPMV_STAGE=0), bit for bit: boxes with lines of 8 ... 1024 points, first / last runs whose window or
+    far operands reach outside x (clamped requests, masked operands), a last run of fewer than 4 tiles and a last tile of fewer than
+    512 rows, inf / NaN in x next to absent entries (an absent entry must contribute nothing), odd line lengths (NOT this kernel),
+    far offsets that differ between bases, the fused inner products of CG and BiCGStab, and the generator-made operator."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(123)
+
+    def box7(ni, nj, nk, vals=(6.0, -1.0, -1.5, -0.25)):
+        e = lambda n: sp.diags([np.ones(n - 1), np.ones(n - 1)], [-1, 1])
+        I = sp.identity
+        m = (vals[0] * I(ni * nj * nk) + vals[1] * sp.kron(I(nk), sp.kron(I(nj), e(ni))) + vals[2] * sp.kron(I(nk), sp.kron(e(nj), I(ni))) +
+             vals[3] * sp.kron(e(nk), I(nj * ni))).tocsr()
+        m.sort_indices()
+        return O.Csr(m.shape[0], m.shape[1], m.indptr, m.indices, m.data)
+
+    boxes = [(8, 9, 40), (34, 7, 33), (130, 12, 5), (1024, 3, 3), (40, 40, 40), (64, 64, 9), (9, 16, 16), (1026, 3, 3)]
+    for ni, nj, nk in boxes:
+        a = box7(ni, nj, nk)
+        d = to_dev(ctx, a)
+        assert d.encoding()[0] == "csr-p16", (ni, nj, nk)
+        monkeypatch.setenv("KRYST_SPMV_STAGE", "1")
+        info = d.pattern_info()
+        assert info["line"] == (ni if ni % 2 == 0 and 8 <= ni <= 1024 else 0) and info["staged"] == (info["line"] > 0) and info["uniform_far"] == (info["line"] > 0), info
+        for trial in range(2):
+            x = rng.standard_normal(a.ncols)
+            if trial == 1:
+                x[rng.integers(0, a.ncols, 6)] = [np.inf, -np.inf, np.nan, 0.0, -0.0, 1e308]
+                x[0] = np.nan; x[-1] = np.inf                                                      # next to the absent -1 / +1 entries of the corners
+            want = a.spmv(x)
+            out = []
+            for stage in ("1", "0"):
+                monkeypatch.setenv("KRYST_SPMV_STAGE", stage)
+                assert d.pattern_info()["staged"] == (stage == "1" and info["line"] > 0)
+                out.append(d.spmv(x))
+            ok = ~np.isnan(want)
+            assert np.array_equal(out[0], want, equal_nan=True) and np.array_equal(out[1], want, equal_nan=True), (ni, nj, nk, trial)
+            assert np.array_equal(np.signbit(out[0][ok]), np.signbit(want[ok]))
+    monkeypatch.delenv("KRYST_SPMV_STAGE")
+    # fused inner products: whole solves on a host-built box (one base, uniform far offsets) and on generator-made operators
+    a = box7(34, 20, 11); d = to_dev(ctx, a)
+    b = a.spmv(np.ones(a.nrows))
+    for name, cls, tol in (("cg", K.CgSolver, 1e-9), ("bicgstab", K.BiCgStabSolver, 1e-7 * np.linalg.norm(b))):
+        res = O.solve(name, a, b, tol=tol, max_iters=60, rs=rs)
+        s = cls(tol, 60); x = np.zeros(a.nrows)
+        st = s.solve(d, None, b, x)
+        _check_solver(res, st, s, x)
+    for N, kind in ((26, "aniso"), (64, "convdiff")):
+        ao = O.stencil7(N, kind); ag = K.CsrMatrix.stencil7(N, kind, ctx=ctx)
+        x = rng.standard_normal(ao.nrows)
+        assert np.array_equal(ag.spmv(x), ao.spmv(x)), (N, kind)
+
+
 @pytest.mark.parametrize("slots", ["2", "4", "7"])
 @pytest.mark.parametrize("nt,align", [("0", "0"), ("1", "0"), ("1", "1")])
 def test_spmv_plain_kernel_settings_bit_exact(ctx, slots, nt, align, monkeypatch):
