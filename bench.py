@@ -195,8 +195,11 @@ def traffic_of(grid, form):
         return None
 
 
-def kernel_name(enc):
+def kernel_name(enc, staged=False):
     name, npat, ntab = enc
+    if name == "csr-p16" and staged:
+        return (f"spmv_pattern_stage_kernel<1> (CSR-P16: one 16-bit row-pattern id per row; {npat} ids, {ntab} table entries; the near operands of "
+                "a run of 4 tiles out of an LDS window filled by LDS-DMA loads)")
     return {"csr": "spmv_wave_kernel<1> (plain CSR: 8 B value + 4 B column per entry)",
             "csr-d8": "spmv_rows_kernel<1> (CSR-D8: 8 B value + 1-byte column-offset code per entry)",
             "csr-d16": "spmv_dict_kernel<1> (CSR-D16: one 16-bit word per entry = offset code + value code)",
@@ -204,13 +207,13 @@ def kernel_name(enc):
             "csr-dia": f"spmv_dia_kernel<1> (CSR-DIA: one 8-byte value stream per diagonal, {npat} diagonals; no row pointers, no column codes)"}[name]
 
 
-def roofline_of(enc, grid, nloc, nnz_loc, ms, world, traffic_form=None):
+def roofline_of(enc, grid, nloc, nnz_loc, ms, world, traffic_form=None, staged=False):
     """The kernel that ran, priced at the bytes IT moves."""
     alg = spmv_bytes(nloc, nnz_loc)
     moved = {"csr": alg, "csr-d8": alg - 3 * nnz_loc, "csr-d16": alg - 10 * nnz_loc, "csr-p16": 2 * nloc + 16 * nloc,
              "csr-dia": 8 * enc[1] * nloc + 16 * nloc}[enc[0]]
     ach = moved / (ms * 1e-3) / 1e9
-    out = {"bound": "hbm", "kernel": kernel_name(enc) + ", fused (p,Ap) tile partials",
+    out = {"bound": "hbm", "kernel": kernel_name(enc, staged) + ", fused (p,Ap) tile partials",
            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
            "bytes_per_launch": moved, "bytes_model": "bytes this storage form streams: matrix description + x once + y once",
            "ms_per_launch": ms, "traffic": None, "encoding": enc[0],
@@ -364,7 +367,7 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters):
         collective_us = group.allreduce_max((time.perf_counter() - t0) / 100 * 1e6)
     nnz_loc = a.nnz
     return {"dt": dt, "dt_plain": dt_plain, "stats": stats, "enc": enc, "nloc": nloc, "nnz_loc": nnz_loc, "collective_us": collective_us, "reduce_info": reduce_info,
-            "roofline": roofline_of(enc, grid, nloc, nnz_loc, spmv_ms, world),
+            "roofline": roofline_of(enc, grid, nloc, nnz_loc, spmv_ms, world, staged=a.pattern_info()["staged"]),
             "roofline_csr": roofline_csr_of(grid, nloc, nnz_loc, plain_ms, world),
             "blas1": blas1_streams(K, ctx, nloc), "copy_gbs": copy_gbs, "phases": phases,
             "final_residual_plain": stats_plain.final_residual}
