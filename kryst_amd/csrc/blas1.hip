@@ -85,6 +85,11 @@ bool use_collectives(kryst_ctx_t ctx) {
     return force == 1 && ctx->comm != nullptr;
 }
 
+__global__ void chunk_arm_kernel(double* chunks, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) chunks[i] = __longlong_as_double((long long)KR_FOLD_UNSET);
+}
+
 int32_t ensure_partials(kryst_ctx_t ctx, int64_t ntiles) {
     if (ntiles <= ctx->partials_cap) return KRYST_OK;
     if (ctx->d_partials) { KR_HIP(hipStreamSynchronize(ctx->s_main)); KR_HIP(hipFree(ctx->d_partials)); ctx->d_partials = nullptr; }
@@ -94,6 +99,9 @@ int32_t ensure_partials(kryst_ctx_t ctx, int64_t ntiles) {
     if (ctx->d_chunks) { KR_HIP(hipFree(ctx->d_chunks)); ctx->d_chunks = nullptr; }
     ctx->chunks_cap = nchunks_of(cap) + 8;
     KR_HIP(hipMalloc(&ctx->d_chunks, sizeof(double) * (size_t)ctx->chunks_cap * KR_MAXQ));
+    // every cell "unset" (fold2): a NaN payload, written on the compute stream in front of the first fold
+    hipLaunchKernelGGL(chunk_arm_kernel, dim3((unsigned)((ctx->chunks_cap * KR_MAXQ + 255) / 256)), dim3(256), 0, ctx->s_main, ctx->d_chunks, ctx->chunks_cap * KR_MAXQ);
+    KR_HIP(hipGetLastError());
     return KRYST_OK;
 }
 
@@ -105,11 +113,11 @@ int32_t launch_dot_partials(kryst_ctx_t ctx, const double* x, const double* y, i
 int32_t launch_final_fold(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out) {
     KR_TRY(ensure_partials(ctx, ntiles > 0 ? ntiles : 1));
     switch (nq) {
-        case 1: hipLaunchKernelGGL(final_fold_kernel<1>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
-        case 2: hipLaunchKernelGGL(final_fold_kernel<2>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
-        case 3: hipLaunchKernelGGL(final_fold_kernel<3>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
-        case 4: hipLaunchKernelGGL(final_fold_kernel<4>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
-        case 8: hipLaunchKernelGGL(final_fold_kernel<8>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_out); break;
+        case 1: hipLaunchKernelGGL(final_fold_kernel<1>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_out); break;
+        case 2: hipLaunchKernelGGL(final_fold_kernel<2>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_out); break;
+        case 3: hipLaunchKernelGGL(final_fold_kernel<3>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_out); break;
+        case 4: hipLaunchKernelGGL(final_fold_kernel<4>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_out); break;
+        case 8: hipLaunchKernelGGL(final_fold_kernel<8>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_out); break;
         default: set_error("final fold: nq=%d", nq); return KRYST_ERR_ARG;
     }
     KR_HIP(hipGetLastError());

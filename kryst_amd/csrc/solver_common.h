@@ -156,13 +156,13 @@ inline int32_t reduce_then(kryst_ctx_t ctx, int64_t ntiles, double* d_red, const
     if (!use_collectives(ctx)) {
         KR_TRY(ensure_partials(ctx, ntiles > 0 ? ntiles : 1));
         hipLaunchKernelGGL((fold_logic_kernel<NQ, L>), dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main,
-                           ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_red, logic);
+                           ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_red, logic);
     } else if (ctx->ipc_on) {
         KR_TRY(ensure_partials(ctx, ntiles > 0 ? ntiles : 1));
         static const int budget = [] { const char* e = getenv("KRYST_IPC_POLL_BUDGET"); return e ? std::max(1, atoi(e)) : (1 << 26); }();
         const IpcView v{ctx->ipc_mine, ctx->d_ipc_peers, ctx->d_ipc_epoch, ctx->rank, ctx->nranks, budget};
         hipLaunchKernelGGL((fold_ipc_logic_kernel<NQ, L>), dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main,
-                           ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, ctx->d_ticket, d_red, logic, v);
+                           ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_red, logic, v);
     } else {
         // local two-level fold -> RCCL all-gather of NQ doubles per rank -> rank-ordered fold + logic in one launch
         double* local = ctx->d_gather + (size_t)ctx->nranks * KR_MAXQ;
