@@ -233,8 +233,10 @@ __device__ __forceinline__ bool fold2(const double* partials, int64_t stride, in
             double acc = 0.0;
             for (int64_t j = threadIdx.x; j < (int64_t)gridDim.x; j += KR_F) {
                 double v = __hip_atomic_load(&chunks[q * cstride + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (the other workgroups may still be waiting for a free slot behind another stream's kernel: patience of seconds, short naps
+                // first; a budget that runs out leaves the payload itself -- a NaN result, not a hung GPU)
                 for (int budget = 1 << 22; (unsigned long long)__double_as_longlong(v) == KR_FOLD_UNSET && budget > 0; --budget) {
-                    __builtin_amdgcn_s_sleep(1);                  // (a budget that runs out leaves the payload itself: a NaN result, not a hung GPU)
+                    if (budget > (1 << 22) - 4096) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(64);
                     v = __hip_atomic_load(&chunks[q * cstride + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 acc = acc + v;
