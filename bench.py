@@ -181,11 +181,64 @@ def cpu_baseline(grid, base256):
 
 
 # ---------------------------------------------------------------------------------------------------------------- GPU side
+_LIVE_TRAFFIC = {}
+LIVE_FORMS = {(512, "default"), (512, "plain")}          # measured in THIS run (about 7 s per pass); the other sizes / forms come from profiles/
+
+
+def live_traffic(grid, form):
+    """HBM bytes per SpMV launch measured in THIS run: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE -- separate runs, no
+    trace domains, as MI355X_MICROARCH.md prescribes) over tools/spmv_only.py in child processes; the read side is calibrated on the
+    ew_kernel<DotOp> launches of the same process, whose byte count is known (the counter under-reports wide coalesced reads on
+    gfx950).  None when rocprofv3 is missing, a pass fails or KRYST_BENCH_LIVE_TRAFFIC=0."""
+    key = (grid, form)
+    if key in _LIVE_TRAFFIC:
+        return _LIVE_TRAFFIC[key]
+    res = None
+    if os.environ.get("KRYST_BENCH_LIVE_TRAFFIC", "1") != "0" and key in LIVE_FORMS:
+        import collections, csv, glob, shutil, subprocess, tempfile
+        exe = shutil.which("rocprofv3")
+        tmp = tempfile.mkdtemp(prefix="kryst_pmc_", dir="/tmp") if exe else None
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            env.pop("KRYST_SPMV_COMPRESS", None)
+            if form == "plain":
+                env["KRYST_SPMV_COMPRESS"] = "0"
+            means = {}
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, counter)
+                r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                                    os.path.join(ROOT, "tools", "spmv_only.py"), str(grid), "5", "1", "varcoef" if form == "varcoef" else "poisson"],
+                                   cwd="/tmp", env=env, capture_output=True, timeout=90)
+                if r.returncode != 0:
+                    raise RuntimeError(f"rocprofv3 --pmc {counter} failed")
+                acc = collections.defaultdict(list)
+                for row in csv.DictReader(open(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0])):
+                    if row["Counter_Name"] == counter:
+                        acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+                means[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
+            spmv = [k for k in means["FETCH_SIZE"] if "spmv" in k and "<1," in k][0]
+            dotk = [k for k in means["FETCH_SIZE"] if "DotOp" in k][0]
+            cal = (2 * grid ** 3 * 8) / (means["FETCH_SIZE"][dotk] * 1024.0)
+            res = means["FETCH_SIZE"][spmv] * 1024.0 * cal + means["WRITE_SIZE"][spmv] * 1024.0
+        except Exception as e:
+            sys.stderr.write(f"bench.py: live traffic measurement ({grid}, {form}) skipped: {e}\n")
+            res = None
+            LIVE_FORMS.clear()                                  # one failed pass: no further attempts in this run (the committed profile remains)
+        finally:
+            if tmp:
+                shutil.rmtree(tmp, ignore_errors=True)
+    _LIVE_TRAFFIC[key] = res
+    return res
+
+
 def traffic_of(grid, form):
-    """HBM bytes per SpMV launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh, read side
-    calibrated on a kernel of known byte count as MI355X_MICROARCH.md prescribes) -- only when that measurement was made on
-    THIS source tree (same sha of kryst_amd/csrc + include), else None."""
+    """HBM bytes per SpMV launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: measured in this run for the headline forms
+    (live_traffic), else read from profiles/spmv_traffic.json (tools/profile_round.sh, the same passes) -- but only when that
+    measurement was made on THIS source tree (same sha of the files the SpMV kernels are built from), else None."""
     from kryst_amd._ffi import spmv_source_sha16
+    live = live_traffic(grid, form)
+    if live is not None:
+        return live
     try:
         e = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json")))[str(grid)][form]
         if e.get("source_sha16") != spmv_source_sha16():
@@ -219,9 +272,12 @@ def roofline_of(enc, grid, nloc, nnz_loc, ms, world, traffic_form=None, staged=F
            "ms_per_launch": ms, "traffic": None, "encoding": enc[0],
            "algorithmic_bytes": alg, "algorithmic_GBs": alg / (ms * 1e-3) / 1e9, "algorithmic_speedup": alg / moved}
     if world == 1:
-        tr = traffic_of(grid, traffic_form or ("plain" if enc[0] == "csr" else "default"))
+        tform = traffic_form or ("plain" if enc[0] == "csr" else "default")
+        tr = traffic_of(grid, tform)
         if tr:
             out["traffic"] = tr
+            out["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this command" if _LIVE_TRAFFIC.get((grid, tform))
+                                     else "profiles/spmv_traffic.json (same passes, same source sha)")
             out["frac_traffic"] = tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     return out
 
@@ -236,6 +292,8 @@ def roofline_csr_of(grid, nloc, nnz_loc, ms, world):
         tr = traffic_of(grid, "plain")
         if tr:
             out["traffic"] = tr
+            out["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this command" if _LIVE_TRAFFIC.get((grid, "plain"))
+                                     else "profiles/spmv_traffic.json (same passes, same source sha)")
     return out
 
 
