@@ -16,9 +16,11 @@ What the line holds (every `frac` is bytes the named kernel really moves / its H
   value             CG iterations/s with the operator in its default (most compact lossless) storage form
   value_plain_csr   the same K iterations with KRYST_SPMV_COMPRESS=0: the 12-bytes-per-entry CSR arrays are streamed, which is
                     what every matrix that is not a constant-coefficient stencil gets
-  roofline          the SpMV kernel of the timed loop (fused (p,Ap) partials): bytes it moves (model; PMC `traffic` beside it
-                    when profiles/spmv_traffic.json was measured on this very source tree), `algorithmic_*` = SURVEY 8(d)'s
-                    CSR bytes for comparison (a re-encoded operator moves fewer)
+  roofline          the SpMV kernel of the timed loop (fused (p,Ap) partials): bytes it moves (model; PMC `traffic` beside it --
+                    at N = 1 measured by this very command for the 512^3 forms, two rocprofv3 --pmc passes per form in child
+                    processes; otherwise from profiles/spmv_traffic.json when that was measured on this very source tree;
+                    `traffic_source` says which), `algorithmic_*` = SURVEY 8(d)'s CSR bytes for comparison (a re-encoded
+                    operator moves fewer)
   roofline_csr      the plain-CSR kernel on SURVEY 8(d)'s bytes: north_star's "% of HBM roofline on CSR SpMV"
   roofline_blas1    the two vector kernels of a CG iteration
   phase_ms          device time per iteration by phase (hipEvents between the phases, a separate short run), per rank
