@@ -58,8 +58,10 @@ constexpr int TQ_SKIPMAX = 544;    // chunks per line the flag table in LDS hold
 // round trip per publish on the solving wave's critical path -- and for vmcnt(0): every outstanding GLOBAL load and store of
 // the wave, i.e. an HBM round trip per step for a wave that keeps a chunk of coefficient loads in flight.
 __device__ __forceinline__ double tq_shr1(double v) {                      // lane l <- lane l - 1 within its row of 16 lanes (row_shr:1)
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xf, 0xf, false);
+    // (bound_ctrl: a lane without a source -- lane 0 of a row -- reads 0 instead of keeping `old`: no register to initialise; those lanes
+    // take the west operand anyway)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ void tq_publish(int* p, int v) {
@@ -616,6 +618,15 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
         if (kc == 0 && q == 0 && l == 0)                                   // this block is under way: the blocks behind it may start asking
             __hip_atomic_store(&flags[blk], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         TQ_T0(tsteps0);
+        // A lone wave issues an instruction every four cycles or so, whatever its kind: the step is priced in INSTRUCTIONS (50 of them,
+        // 97 with the chunk's overhead spread over its eight steps).  Addresses that the step used to derive from t -- ring slot, west /
+        // south operand -- are carried instead: a chunk starts on a multiple of 8 steps and the rings hold multiples of 8, so slots
+        // t0 .. t0 + 7 of the own ring, and t0 + 1 + off .. t0 + 7 + off of a source ring, never wrap inside a chunk.
+        double* const ring_t0 = my_ring + (t0 & (YR - 1)) * 64;
+        const double* const w_first = w_ptr + ((t0 + w_off) & w_mask) * w_stride;
+        const double* const s_first = s_ptr + ((t0 + s_off) & s_mask) * s_stride;
+        const double* w_next = w_ptr + ((t0 + 1 + w_off) & w_mask) * w_stride;
+        const double* s_next = s_ptr + ((t0 + 1 + s_off) & s_mask) * s_stride;
 #pragma unroll
         for (int u = 0; u < C; ++u) {
             const int t = t0 + u;
@@ -634,7 +645,9 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #if defined(TQ_ABL) && (TQ_ABL & 8)
             const double wv = 0.5, sv = 0.25;
 #else
-            const double wv = w_ptr[((t + w_off) & w_mask) * w_stride], sv = s_ptr[((t + s_off) & s_mask) * s_stride];
+            double wv, sv;
+            if (u == 0) { wv = *w_first; sv = *s_first; }
+            else { wv = *w_next; sv = *s_next; w_next += w_stride; s_next += s_stride; }
 #endif
 #if defined(TQ_ABL) && (TQ_ABL & 16)
             double yj = y, yk = y;
@@ -665,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
             }
             y = s;
 #if !(defined(TQ_ABL) && (TQ_ABL & 32))
-            my_ring[(t & (YR - 1)) * 64] = s;                              // all 64 rows of the step, one unmasked store;
+            ring_t0[u * 64] = s;                                           // all 64 rows of the step, one unmasked store;
 #endif
             if (l == 0) TQ_STEP_TRACE(tq_steps, q, t);
             tq_publish(&prog[q], t + 1);                                   // then the count (LDS executes a wave's operations in order); written by ALL lanes --
