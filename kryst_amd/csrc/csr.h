@@ -51,6 +51,7 @@ struct kryst_csr_s {
     int64_t interior_first = -1;    // >= 0: the interior tiles are the contiguous range [interior_first, interior_first + n_interior)
     int32_t* d_tiles_boundary = nullptr; int64_t n_boundary = 0;
     bool send_contiguous = false;   // every send list is a contiguous run of local rows (k-slab stencils)
+    const double* halo_started_for = nullptr;   // the halo exchange of this input vector is already in flight (halo_begin: a solver started it early)
 };
 
 namespace kr {
@@ -62,5 +63,11 @@ inline int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 // y <- A x on ctx->s_main.  nq = 0: plain.  nq = 1: also tile partials of sum d[i]*y[i] into partial array 0.
 // nq = 2: additionally sum y[i]*y[i] into partial array 1.  `done` (device flag) makes the launch a no-op when set.
 int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const double* dvec, const int* done);
+// Distributed operators: start the halo exchange of x NOW (everything enqueued on the compute stream so far is waited for, nothing
+// later) and remember it, so that the next launch_spmv(a, x, ...) does not start it again.  A solver calls it after the launch that
+// wrote the rows the neighbours need and before the launches that write the rest (send_contiguous operators only).
+int32_t halo_begin(kryst_csr_t a, const double* x);
+// the tile ranges [lo, hi) whose rows are sent to neighbours, merged and ascending (send_contiguous operators)
+void halo_send_tiles(kryst_csr_t a, std::vector<std::pair<int64_t, int64_t>>& ranges);
 
 }  // namespace kr

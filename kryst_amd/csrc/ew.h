@@ -67,11 +67,11 @@ struct GateDone {                    // `done` flag of the solve (nullptr: alway
 };
 
 template <class Op, class Gate>
-__global__ __launch_bounds__(KR_T) void ew_kernel(Op op, Gate gate, int64_t n, int64_t ntiles, double* partials, int64_t pstride) {
+__global__ __launch_bounds__(KR_T) void ew_kernel(Op op, Gate gate, int64_t n, int64_t tile_lo, int64_t ntiles, double* partials, int64_t pstride) {
     if (gate.skip()) return;
     constexpr int NQ = Op::NQ;
     __shared__ double lds[(NQ > 0 ? NQ : 1) * (KR_T / 64)];
-    for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
+    for (int64_t q = tile_lo + blockIdx.x; q < ntiles; q += gridDim.x) {          // tiles [tile_lo, ntiles): the whole vector, or a range of it
         const int64_t i = q * KR_TILE + (int64_t)threadIdx.x * KR_V;
         double acc[NQ > 0 ? NQ : 1];
 #pragma unroll
@@ -97,10 +97,12 @@ template <class Op> struct ew_tag<Op, std::void_t<decltype(Op::TAG)>> { static c
 
 // bpc <= 0: the kernel shape's default (KRYST_EW_BLOCKS_PER_CU overrides it)
 template <class Op, class Gate>
-inline int32_t launch_ew_gated(kryst_ctx_t ctx, const Op& op, int64_t n, const Gate& gate, int bpc = 0) {
-    const int64_t ntiles = ntiles_of(n);
-    if (ntiles == 0) return KRYST_OK;
-    if (Op::NQ > 0) KR_TRY(ensure_partials(ctx, ntiles));
+inline int32_t launch_ew_gated(kryst_ctx_t ctx, const Op& op, int64_t n, const Gate& gate, int bpc = 0, int64_t tile_lo = 0, int64_t tile_hi = -1) {
+    const int64_t all_tiles = ntiles_of(n);
+    if (tile_hi < 0 || tile_hi > all_tiles) tile_hi = all_tiles;             // [tile_lo, tile_hi): a launch over part of the vector (the partials keep their tile numbers)
+    const int64_t ntiles = tile_hi - tile_lo;
+    if (ntiles <= 0) return KRYST_OK;
+    if (Op::NQ > 0) KR_TRY(ensure_partials(ctx, all_tiles));
     // memory-bound streaming: cap the grid and stride the rest.  Measured on MI355X (tools/stream_bench.py, vectors of
     // 1 GiB, interleaved rounds): 2-3 workgroups per CU sustain 5.6-5.8 TB/s on mixed read/write streams, 8 per CU only
     // 4.7-4.9 TB/s (a narrower moving window keeps DRAM pages open); CG at 512^3: +4 %.  Pure read streams with a
@@ -116,7 +118,7 @@ inline int32_t launch_ew_gated(kryst_ctx_t ctx, const Op& op, int64_t n, const G
         if (const char* e_tag = getenv(name)) bpc = std::max(1, atoi(e_tag));
     }
     const int64_t grid = std::min<int64_t>(ntiles, (int64_t)ctx->num_cu * bpc);
-    hipLaunchKernelGGL((ew_kernel<Op, Gate>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, gate, n, ntiles,
+    hipLaunchKernelGGL((ew_kernel<Op, Gate>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, gate, n, tile_lo, tile_hi,
                        ctx->d_partials, ctx->partials_cap);
     KR_HIP(hipGetLastError());
     phase_mark(ctx, KR_PH_BLAS1);

@@ -269,6 +269,7 @@ int32_t fgmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, int32_t 
     KR_ARG(bv->ctx == ctx && xv->ctx == ctx, "solve: context mismatch");
     KR_ARG(a->nrows == a->xlen && bv->n == n && xv->n == n, "solve: size mismatch");
     KR_ARG(p->restart >= 1 && p->restart <= 4096, "fgmres: restart out of range (restart = 0 never terminates in the reference)");
+    a->halo_started_for = nullptr;            // (csr.h: an early halo start belongs to the CG / PCG solve that made it)
     KR_ARG(p->max_iters >= 0, "solve: max_iters < 0");
     KR_ARG(orthog == 0 || orthog == 1, "fgmres: orthog (0 Classical, 1 Modified)");
     KR_HIP(hipSetDevice(ctx->device));

@@ -204,6 +204,7 @@ int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
     KR_ARG(bv->ctx == ctx && xv->ctx == ctx, "solve: context mismatch");
     KR_ARG(a->nrows == a->xlen && bv->n == n && xv->n == n, "solve: size mismatch");
     KR_ARG(p->restart >= 1 && p->restart <= 4096, "gmres: restart out of range");
+    a->halo_started_for = nullptr;            // (csr.h: an early halo start belongs to the CG / PCG solve that made it)
     KR_ARG(p->max_iters >= 0, "solve: max_iters < 0");
     KR_HIP(hipSetDevice(ctx->device));
     kryst_pc_s pcl; kryst_pc_t pc = nullptr;

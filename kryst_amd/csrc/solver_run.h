@@ -51,11 +51,12 @@ struct SolverRun {
     SolverRun(kryst_vec_t b, kryst_vec_t x, const SolveIO& io_)
         : bv(b), xv(x), io(io_), prm(*io_.params), a(io_.a), ctx(io_.a->ctx), n(io_.a->nrows), nt(ntiles_of(io_.a->nrows)),
           ws(io_.a->ctx, io_.a->nrows) { io.params = &prm; }
-    virtual ~SolverRun() {}
+    virtual ~SolverRun() { if (a) a->halo_started_for = nullptr; }
     virtual int32_t begin() = 0;
     virtual int32_t iterate(int64_t i) = 0;
     int32_t common_begin(int64_t hist_entries, int work_vectors) {
         KR_HIP(hipSetDevice(ctx->device));
+        a->halo_started_for = nullptr;        // (an early halo start belongs to ONE solve: work vectors of later solves reuse the addresses)
         if (io.pc) { pcl = *io.pc; if (pcl.n < 0) pcl.n = n; pc = &pcl; }
         KR_TRY(ws.init(hist_entries));
         KR_TRY(ws.reserve(work_vectors + 1));
@@ -73,6 +74,7 @@ struct SolverRun {
     int32_t end() {
         KR_HIP(hipStreamSynchronize(ctx->s_comm));
         KR_HIP(hipStreamSynchronize(ctx->s_main));
+        a->halo_started_for = nullptr;
         const int32_t status = finish_solve(ws, io);
         if (status == KRYST_OK)                  // on Err the reference never reaches `*x = ...`
             KR_HIP(hipMemcpyAsync(xv->d, xw, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));

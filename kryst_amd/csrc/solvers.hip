@@ -115,6 +115,30 @@ struct GateXPending {                // runs while the solve is under way, and o
     const DevState* st; long long it;
     __device__ __forceinline__ bool skip() const { return st->done && st->xlast != it; }
 };
+// The direction pass on a distributed operator whose neighbours get contiguous runs of rows (k-slab partitions): the tiles that hold
+// those rows first, then the halo exchange of the new p is STARTED (spmv.hip: halo_begin), then the rest of the vector -- the planes
+// travel while the pass is still writing the interior, not only during the next SpMV's interior tiles (which the staged-window
+// kernel has made shorter than the exchange).  Same launches' worth of work, same bits.  KRYST_HALO_EARLY=0: one launch, exchange
+// started by the SpMV as before.
+template <class Op>
+inline int32_t launch_direction(kryst_ctx_t ctx, kryst_csr_t a, const Op& op, int64_t n, const DevState* st, long long it, const double* p_vec) {
+    const GateXPending gate{st, it};
+    if (a->dist && use_collectives(ctx) && a->send_contiguous && env_int("KRYST_HALO_EARLY", 1) != 0) {
+        std::vector<std::pair<int64_t, int64_t>> early;
+        halo_send_tiles(a, early);
+        int64_t covered = 0;
+        for (const auto& r : early) covered += r.second - r.first;
+        const int64_t all = ntiles_of(n);
+        if (!early.empty() && early.size() <= 4 && 2 * covered < all) {
+            for (const auto& r : early) KR_TRY(launch_ew_gated(ctx, op, n, gate, 0, r.first, std::min(r.second, all)));
+            KR_TRY(halo_begin(a, p_vec));
+            int64_t at = 0;
+            for (const auto& r : early) { KR_TRY(launch_ew_gated(ctx, op, n, gate, 0, at, std::min(r.first, all))); at = std::min(r.second, all); }
+            return launch_ew_gated(ctx, op, n, gate, 0, at, all);
+        }
+    }
+    return launch_ew_gated(ctx, op, n, gate);
+}
 inline bool cg_defer_x() { return env_int("KRYST_CG_DEFER_X", 1) != 0; }      // (read per iteration enqueue: a getenv, not on any critical path)
 
 struct CgInitLogic {                 // cg.rs:127-140
@@ -260,8 +284,8 @@ struct CgRun : SolverRun {
             if (keep_in_cache(n)) KR_TRY(launch_ew(ctx, CgResidualOp<true>{&ws.st->alpha, ap, r}, n, done));
             else KR_TRY(launch_ew(ctx, CgResidualOp<false>{&ws.st->alpha, ap, r}, n, done));      // :210-212 + (r,r) :223
             KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgBetaLogic{lc})));
-            if (keep_in_cache(n)) return launch_ew_gated(ctx, CgDirectionOp<true>{ws.st, r, pp, xw}, n, GateXPending{ws.st, (long long)it});
-            return launch_ew_gated(ctx, CgDirectionOp<false>{ws.st, r, pp, xw}, n, GateXPending{ws.st, (long long)it});   // :207-209, :274-276
+            if (keep_in_cache(n)) return launch_direction(ctx, a, CgDirectionOp<true>{ws.st, r, pp, xw}, n, ws.st, (long long)it, pp);
+            return launch_direction(ctx, a, CgDirectionOp<false>{ws.st, r, pp, xw}, n, ws.st, (long long)it, pp);   // :207-209, :274-276
         }
         if (prm.has_radius) {                                                                     // :177-202 (Steihaug-Toint)
             KR_TRY(launch_ew(ctx, DotPairOp{pp, pp, xw, xw}, n, done));
@@ -446,8 +470,8 @@ struct PcgRun : SolverRun {
                 KR_TRY(launch_ew(ctx, DotPairOp{r, z, nq_a, nq_a}, n, done));                     // :188-195
             }
             KR_TRY((reduce_then<2>(ctx, nt, ws.red, PcgBetaLogic{lc})));
-            if ((alias || jac) && keep) return launch_ew_gated(ctx, CgDirectionOp<true>{ws.st, z, pp, xw}, n, GateXPending{ws.st, (long long)it});
-            return launch_ew_gated(ctx, CgDirectionOp<false>{ws.st, z, pp, xw}, n, GateXPending{ws.st, (long long)it});   // :175-177, :215-217
+            if ((alias || jac) && keep) return launch_direction(ctx, a, CgDirectionOp<true>{ws.st, z, pp, xw}, n, ws.st, (long long)it, pp);
+            return launch_direction(ctx, a, CgDirectionOp<false>{ws.st, z, pp, xw}, n, ws.st, (long long)it, pp);   // :175-177, :215-217
         }
         if (alias) {
             KR_TRY(launch_ew(ctx, PcgUpdateOp<false>{&ws.st->alpha, pp, ap, xw, r, z, nullptr, nt_}, n, done));

@@ -1070,15 +1070,23 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
     return KRYST_OK;
 }
 
-int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const double* dvec, const int* done) {
-    kryst_ctx_t ctx = a->ctx;
-    if (nq > 0) KR_TRY(ensure_partials(ctx, a->ntiles));
-    if (!a->dist || !use_collectives(ctx)) {
-        const int32_t rc = launch_tiles<false>(a, x, y, nq, dvec, done, nullptr, a->ntiles);
-        phase_mark(ctx, KR_PH_SPMV);
-        return rc;
+void halo_send_tiles(kryst_csr_t a, std::vector<std::pair<int64_t, int64_t>>& ranges) {
+    ranges.clear();
+    if (!a->dist || !a->send_contiguous) return;
+    const HaloPlan& pl = a->plan;
+    for (size_t p = 0; p < pl.send_counts.size(); ++p)
+        if (pl.send_counts[p] > 0) ranges.emplace_back(pl.send_off[p] / KR_TILE, (pl.send_off[p] + pl.send_counts[p] + KR_TILE - 1) / KR_TILE);
+    std::sort(ranges.begin(), ranges.end());
+    std::vector<std::pair<int64_t, int64_t>> merged;
+    for (const auto& r : ranges) {
+        if (!merged.empty() && r.first <= merged.back().second) merged.back().second = std::max(merged.back().second, r.second);
+        else merged.push_back(r);
     }
-    // halo exchange on s_comm, overlapped with the interior tiles
+    ranges.swap(merged);
+}
+
+int32_t halo_begin(kryst_csr_t a, const double* x) {
+    kryst_ctx_t ctx = a->ctx;
     HaloPlan& pl = a->plan;
     KR_HIP(hipEventRecord(ctx->ev_x_ready, ctx->s_main));
     KR_HIP(hipStreamWaitEvent(ctx->s_comm, ctx->ev_x_ready, 0));
@@ -1095,6 +1103,21 @@ int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const dou
     KR_TRY(comm_exchange(ctx, sendbase, pl.send_counts.data(), pl.send_off.data(), pl.d_halo, pl.recv_counts.data(),
                          pl.recv_off.data(), true, ctx->s_comm));
     KR_HIP(hipEventRecord(ctx->ev_halo_done, ctx->s_comm));
+    a->halo_started_for = x;
+    return KRYST_OK;
+}
+
+int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const double* dvec, const int* done) {
+    kryst_ctx_t ctx = a->ctx;
+    if (nq > 0) KR_TRY(ensure_partials(ctx, a->ntiles));
+    if (!a->dist || !use_collectives(ctx)) {
+        const int32_t rc = launch_tiles<false>(a, x, y, nq, dvec, done, nullptr, a->ntiles);
+        phase_mark(ctx, KR_PH_SPMV);
+        return rc;
+    }
+    // halo exchange on s_comm (unless the solver has started it already), overlapped with the interior tiles
+    if (a->halo_started_for != x) KR_TRY(halo_begin(a, x));
+    a->halo_started_for = nullptr;
     KR_TRY(launch_tiles<false>(a, x, y, nq, dvec, done, a->d_tiles_interior, a->n_interior));   // interior tiles have no halo columns
     phase_mark(ctx, KR_PH_SPMV);
     KR_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_halo_done, 0));
