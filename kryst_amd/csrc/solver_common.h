@@ -19,7 +19,8 @@ namespace kr {
 // memory-side cache, and streamed otherwise (measured: r of CG kept, 128^3 +5 %, 256^3 +1 %, 512^3 -5 %; the Gram-Schmidt
 // links' z kept, 128^3 / 256^3 +8 %).  KRYST_KEEP_BYTES moves the threshold (0: never keep).
 inline bool keep_in_cache(int64_t n) {
-    static const long long lim = [] { const char* e = getenv("KRYST_KEEP_BYTES"); return e ? atoll(e) : (160ll << 20); }();
+    const char* e = getenv("KRYST_KEEP_BYTES");                       // (read per launch: tools/solver_ab.py)
+    const long long lim = e ? atoll(e) : (160ll << 20);
     return (long long)n * 8 <= lim;
 }
 
