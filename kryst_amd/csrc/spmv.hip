@@ -931,7 +931,8 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
             a->xlen + 2 * KR_TILE < (1ll << 31)) {
             const int32_t tile0 = interior ? (int32_t)a->interior_first : 0;
             args.tiles = nullptr;
-            constexpr int T = 4;          // (runs of 2 tiles: 63 registers, 8 waves per SIMD, and 512^3 2 % slower / 256^3 3.5 % faster: not occupancy-bound)
+            // runs of 4 tiles for large vectors, of 2 below half a gigabyte (63 registers, 8 waves per SIMD: 512^3 2 % slower, 256^3 3.5 % faster)
+            const int T = env_int("KRYST_SPMV_STAGE_T", a->nrows * 8 > (512ll << 20) ? 4 : 2) <= 2 ? 2 : 4;     // (in CG: 128^3 +1.2 %, 192^3 +2 %, 256^3 +0.6 %, 320^3 +1.3 % with 2)
             const int32_t n_ = a->pat_stage_n;
             const size_t xs_bytes = sizeof(double) * (size_t)(T * KR_TILE + 2 * n_ + 4);
             const size_t tab = xs_bytes + (size_t)a->npat * 8 + (size_t)a->ntab * 12;
@@ -946,8 +947,9 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
             const dim3 sgrid((unsigned)(per_xcd * 8));
             const bool center = nq > 0 && dvec == x;
             const bool ufar = (a->pat_far_uniform || (interior && a->pat_far_interior)) && env_int("KRYST_SPMV_STAGE_UFAR", 1) != 0;
-#define KR_STG(NQ_, C_) do { if (ufar) hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, T, C_, true>), sgrid, block, lds_s, ctx->s_main, args, n_, a->pat_far_lo, a->pat_far_hi, tile0); \
-                             else hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, T, C_, false>), sgrid, block, lds_s, ctx->s_main, args, n_, 0, 0, tile0); } while (0)
+#define KR_STG_T(NQ_, C_, T_) do { if (ufar) hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, T_, C_, true>), sgrid, block, lds_s, ctx->s_main, args, n_, a->pat_far_lo, a->pat_far_hi, tile0); \
+                                   else hipLaunchKernelGGL((spmv_pattern_stage_kernel<NQ_, T_, C_, false>), sgrid, block, lds_s, ctx->s_main, args, n_, 0, 0, tile0); } while (0)
+#define KR_STG(NQ_, C_) do { if (T == 2) KR_STG_T(NQ_, C_, 2); else KR_STG_T(NQ_, C_, 4); } while (0)
             switch (nq) {
                 case 0: KR_STG(0, false); break;
                 case 1: if (center) KR_STG(1, true); else KR_STG(1, false); break;
@@ -955,6 +957,7 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
                 default: set_error("spmv: nq=%d", nq); return KRYST_ERR_ARG;
             }
 #undef KR_STG
+#undef KR_STG_T
             KR_HIP(hipGetLastError());
             return KRYST_OK;
         }
