@@ -391,9 +391,11 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters):
         dt_plain, stats_plain = timed_iterations()
     # the dominant kernel, timed live with HIP events on the compute stream (kryst_bench_spmv), in both storage forms
     y = ctx.vec(nloc)
-    spmv_ms = a.bench_spmv(b, y, fused_dots=1, reps=50)
+    # (three averages of 20 / 10 back-to-back launches each, the median of the three: one disturbed batch -- seen once, a 7x outlier --
+    # must not become the roofline figure)
+    spmv_ms = sorted(a.bench_spmv(b, y, fused_dots=1, reps=20) for _ in range(3))[1]
     with env_override(KRYST_SPMV_COMPRESS="0"):
-        plain_ms = a.bench_spmv(b, y, fused_dots=1, reps=30)
+        plain_ms = sorted(a.bench_spmv(b, y, fused_dots=1, reps=10) for _ in range(3))[1]
     # context: the device-copy rate at this footprint (hipMemcpy D2D of one vector, read + write)
     y.copy_from(b); ctx.synchronize()
     ctx.timer_start()
