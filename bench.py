@@ -254,7 +254,7 @@ def kernel_name(enc, staged=False):
     name, npat, ntab = enc
     if name == "csr-p16" and staged:
         return (f"spmv_pattern_stage_kernel<1> (CSR-P16: one 16-bit row-pattern id per row; {npat} ids, {ntab} table entries; the near operands of "
-                "a run of 4 tiles out of an LDS window filled by LDS-DMA loads)")
+                "a run of 2 or 4 tiles out of an LDS window filled by LDS-DMA loads)")
     return {"csr": "spmv_wave_kernel<1> (plain CSR: 8 B value + 4 B column per entry)",
             "csr-d8": "spmv_rows_kernel<1> (CSR-D8: 8 B value + 1-byte column-offset code per entry)",
             "csr-d16": "spmv_dict_kernel<1> (CSR-D16: one 16-bit word per entry = offset code + value code)",
