@@ -651,7 +651,10 @@ int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done
     if (D->n == 0) return KRYST_OK;
     hipLaunchKernelGGL(tri_set_args, dim3(1), dim3(1), 0, ctx->s_main, D->d_args, r, z, done);
     KR_HIP(hipGetLastError());
-    static const int use_graph = getenv("KRYST_ILU_GRAPH") ? atoi(getenv("KRYST_ILU_GRAPH")) : 1;
+    // a hipGraph pays where an apply is MANY launches (one per dependency level / hyperplane); the wavefront and the sync-free forms are
+    // three to five launches, and launching them directly is 0.6 % (256^3) to 1.9 % (128^3) of a BiCGStab + ILU(0) iteration faster
+    const bool few_launches = !D->safe && env_i("KRYST_ILU_PLANES", 0) == 0 && ((D->GL.ok && D->GU.ok) || (D->L.syncfree && D->U.syncfree));
+    const int use_graph = env_i("KRYST_ILU_GRAPH", few_launches ? 0 : 1);        // (read per apply: tools/solver_ab.py)
     if (!D->exec && use_graph) {
         // capture the launch sequence once; the graph only refers to the device argument block
         hipGraph_t g = nullptr;
@@ -667,7 +670,7 @@ int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done
             }
         }
     }
-    if (D->exec) { KR_HIP(hipGraphLaunch(D->exec, ctx->s_main)); return KRYST_OK; }
+    if (D->exec && use_graph) { KR_HIP(hipGraphLaunch(D->exec, ctx->s_main)); return KRYST_OK; }
     return enqueue_apply(ctx->s_main, D);                             // eager fallback (same kernels)
 }
 
