@@ -99,6 +99,7 @@ struct IluData {
     double* d_rL = nullptr; double* d_y = nullptr; double* d_yU = nullptr; double* d_zU = nullptr;   // level-permuted work vectors
     int32_t* d_mapLU = nullptr;     // L-position of the row at U-position q
     int32_t* d_flags = nullptr;     // wavefront solve: "this block is under way", one per block and direction
+    int32_t direct_epoch = 0;       // number of the last directly launched apply (1 .. 2^30 - 1; its flag value has bit 30 set)
     int32_t* h_gave_up = nullptr;   // mapped host word the wavefront kernel raises when a poller runs out of patience (never cleared on the device)
     int32_t* d_gave_up = nullptr;   // its device address
     bool safe = false;              // the wavefront kernel gave up once: this preconditioner now uses the plane kernels (no inter-workgroup waits)
@@ -578,7 +579,7 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
 }
 
 // r -> rL (L level order) -> forward -> yL -> yU (U level order) -> backward -> zU -> z
-static int32_t enqueue_apply(hipStream_t s, IluData* D) {
+static int32_t enqueue_apply(hipStream_t s, IluData* D, const TriDirect* direct = nullptr) {
     const unsigned g = (unsigned)((D->n + 255) / 256);
     if (D->GL.ok && D->GU.ok) {
         // structured grid: r -> forward wavefront -> y (natural order) -> backward wavefront -> z; no permutations
@@ -607,8 +608,9 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
             const QuadView QA{A.Ni, A.Nj, A.Nk, A.nbj, A.nbk, A.nch, (const tw_v2*)A.d_blocked, A.d_edge_e, A.d_edge_n, A.d_skip};
             const QuadView QB{B.Ni, B.Nj, B.Nk, B.nbj, B.nbk, B.nch, (const tw_v2*)B.d_blocked, B.d_edge_e, B.d_edge_n, B.d_skip};
             // (no per-apply launch re-arms the edge buffers or the flags: tri_quad.h, poller / epoch)
-            hipLaunchKernelGGL((tri_quad_kernel<true>), dim3(nq), dim3(512), 0, s, D->d_args, (const double*)nullptr, D->d_y, QA, D->n, D->d_flags, D->d_flags + 2 * nb, D->d_gave_up, budget);
-            hipLaunchKernelGGL((tri_quad_kernel<false>), dim3(nq), dim3(512), 0, s, D->d_args, (const double*)D->d_y, (double*)nullptr, QB, D->n, D->d_flags + nb, D->d_flags + 2 * nb, D->d_gave_up, budget);
+            const TriDirect dir = direct ? *direct : TriDirect{nullptr, nullptr, nullptr, 0};
+            hipLaunchKernelGGL((tri_quad_kernel<true>), dim3(nq), dim3(512), 0, s, D->d_args, (const double*)nullptr, D->d_y, QA, D->n, D->d_flags, D->d_flags + 2 * nb, D->d_gave_up, budget, dir);
+            hipLaunchKernelGGL((tri_quad_kernel<false>), dim3(nq), dim3(512), 0, s, D->d_args, (const double*)D->d_y, (double*)nullptr, QB, D->n, D->d_flags + nb, D->d_flags + 2 * nb, D->d_gave_up, budget, dir);
             KR_HIP(hipGetLastError());
             return KRYST_OK;
         }
@@ -645,10 +647,23 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D) {
     return KRYST_OK;
 }
 
+// does an apply take the 16 x 16 wavefront kernels (the same tests as in enqueue_apply)?
+static bool takes_quad_form(const IluData* D) {
+    if (!(D->GL.ok && D->GU.ok) || D->safe || env_int("KRYST_ILU_PLANES", 0)) return false;
+    const unsigned nb = (unsigned)(((D->GL.Nj + 7) / 8) * ((D->GL.Nk + 7) / 8));
+    return env_int("KRYST_ILU_WAVE", default_wave_form(nb)) >= 2 && D->GL.d_blocked && D->GU.d_blocked;
+}
+
 int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done) {
     IluData* D = reinterpret_cast<IluData*>(pc->d_work);
     kryst_ctx_t ctx = pc->ctx;
     if (D->n == 0) return KRYST_OK;
+    if (takes_quad_form(D) && env_i("KRYST_ILU_GRAPH", 0) == 0 && env_i("KRYST_ILU_DIRECT_ARGS", 1) != 0) {
+        // launched directly: the caller's vectors, the `done` flag and the apply's number travel as kernel arguments (tri_quad.h: TriDirect)
+        D->direct_epoch = (D->direct_epoch & 0x3fffffff) + 1;
+        const TriDirect dir{r, z, done, (int32_t)(0x40000000u | (uint32_t)D->direct_epoch)};
+        return enqueue_apply(ctx->s_main, D, &dir);
+    }
     hipLaunchKernelGGL(tri_set_args, dim3(1), dim3(1), 0, ctx->s_main, D->d_args, r, z, done);
     KR_HIP(hipGetLastError());
     // a hipGraph pays where an apply is MANY launches (one per dependency level / hyperplane); the wavefront and the sync-free forms are

@@ -172,11 +172,15 @@ __global__ __launch_bounds__(256) void tri_quad_fill_kernel(double* edge_e, doub
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nflags; i += gridDim.x * 256) flags[i] = 0;
 }
 
+// An apply launched directly (not replayed from a graph) gets the caller's vectors, the solver's `done` flag and its number as KERNEL
+// ARGUMENTS (epoch != 0) instead of through the device argument block: no argument kernel, one kernel boundary less per apply.
+// Direct epochs live in [2^30, 2^31), the argument block's in [1, 2^30): the two never meet in a flag.
+struct TriDirect { const double* r; double* z; const int* done; int32_t epoch; };
 template <bool FORWARD>
 __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, QuadView Q, int64_t n,
-                                                          int32_t* flags, int32_t* abort_word, int32_t* gave_up, int poll_budget) {
-    if (args->skip) return;
-    const int32_t epoch = (int32_t)args->epoch;                            // this apply's number: the value of an "under way" flag (nothing resets the flags)
+                                                          int32_t* flags, int32_t* abort_word, int32_t* gave_up, int poll_budget, const TriDirect dir) {
+    if (dir.epoch != 0 ? (dir.done && *dir.done) : (args->skip != 0)) return;
+    const int32_t epoch = dir.epoch != 0 ? dir.epoch : (int32_t)args->epoch;   // this apply's number: the value of an "under way" flag (nothing resets the flags)
     constexpr int C = TQ_C, S = TQ_S, R = TQ_R;
     constexpr int NA = FORWARD ? 3 : 4;                                    // coefficient arrays per chunk
     constexpr int YR = TQ_YR;
@@ -190,8 +194,8 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     __shared__ int written[4];                                             // chunks of each solving wave's results the loader waves have stored to the caller's vector
     __shared__ uint8_t skipf[4 * TQ_SKIPMAX];                              // per solving wave and chunk m, a 3-bit code: bit d = chunk m + d needs a coefficient request
     __shared__ int staged[2], quit, always, gate;                          // gate: the producers are under way (set by the poller)                                // chunks each loader wave has staged (quadrants 0-1 / 2-3)
-    cgdouble* in = (cgdouble*)(in_ptr ? in_ptr : args->r);
-    gdouble* out = (gdouble*)(out_ptr ? out_ptr : args->z);
+    cgdouble* in = (cgdouble*)(in_ptr ? in_ptr : (dir.epoch != 0 ? dir.r : args->r));
+    gdouble* out = (gdouble*)(out_ptr ? out_ptr : (dir.epoch != 0 ? dir.z : args->z));
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // 0-3 solve, 4-5 load the right-hand side (128 lines each), 6 polls, 7 exports
     const int l = threadIdx.x & 63;
     int J, K;
