@@ -58,6 +58,8 @@ def spmv_bytes(n, nnz):
 class TorchGroup:
     """torch.distributed (gloo) as plumbing: ships the RCCL unique id, host barrier, max, gather."""
 
+    env_leader = True
+
     def __init__(self, rank, world):
         import torch.distributed as dist
         self.dist, self.rank, self.world = dist, rank, world
@@ -88,12 +90,68 @@ class TorchGroup:
 
 
 class SoloGroup:
-    rank, world = 0, 1
+    rank, world, env_leader = 0, 1, True
     def broadcast_bytes(self, payload): return payload
     def barrier(self): pass
     def allreduce_max(self, x): return x
     def gather(self, obj): return [obj]
     def close(self): pass
+
+
+class ThreadedGroup:
+    """Several ranks of ONE process, a host thread each (rehearsals on a one-GPU box, which admits at most 6 processes on its card: 8 ranks =
+    4 processes x 2 threads).  Every method is collective over ALL ranks: the threads of a process meet at a barrier, thread 0 talks to the
+    other processes through the inner group."""
+
+    class Shared:
+        def __init__(self, inner, per):
+            self.inner, self.per = inner, per
+            self.bar = threading.Barrier(per)
+            self.slots = [None] * per
+            self.result = None
+
+    def __init__(self, shared, t):
+        self.sh, self.t = shared, t
+        self.rank = shared.inner.rank * shared.per + t
+        self.world = shared.inner.world * shared.per
+        self.env_leader = t == 0
+
+    def _via_leader(self, value, combine_local, inner_call):
+        sh = self.sh
+        sh.slots[self.t] = value
+        sh.bar.wait()
+        if self.t == 0:
+            sh.result = inner_call(combine_local(list(sh.slots)))
+        sh.bar.wait()
+        out = sh.result
+        sh.bar.wait()
+        return out
+
+    def broadcast_bytes(self, payload):
+        return self._via_leader(payload, lambda v: v[0], self.sh.inner.broadcast_bytes)
+
+    def barrier(self):
+        self._via_leader(0, lambda v: 0, lambda _: self.sh.inner.barrier())
+
+    def allreduce_max(self, x):
+        return self._via_leader(float(x), max, self.sh.inner.allreduce_max)
+
+    def gather(self, obj):
+        return self._via_leader(obj, lambda v: v, lambda v: [o for part in self.sh.inner.gather(v) for o in part])
+
+    def close(self):
+        self._via_leader(0, lambda v: 0, lambda _: self.sh.inner.close())
+
+
+_T0 = time.time()
+_STAGE = {}
+
+
+def stage(rank, name):
+    """Flushed stage marker on stderr: when a run hangs or dies, the tail the driver keeps names the phase."""
+    _STAGE[rank] = name
+    sys.stderr.write(f"[bench rank {rank} +{time.time() - _T0:7.2f}s] {name}\n")
+    sys.stderr.flush()
 
 
 def make_group(kind, rank, world):
@@ -108,7 +166,9 @@ def make_group(kind, rank, world):
             kind = "socket"
     if kind == "socket":                                    # no torch anywhere: kryst_amd/launch.py (TCP rendezvous)
         from kryst_amd.launch import Rendezvous
-        return Rendezvous.from_env()
+        g = Rendezvous.from_env()
+        g.env_leader = True
+        return g
     return TorchGroup(rank, world)
 
 
@@ -133,9 +193,12 @@ def host_mem_available_gb():
         return 0.0
 
 
-def cpu_cg(grid, seconds):
+def cpu_cg(grid, seconds, ctx=None):
     """The oracle's CG (the CPU restatement of the reference path, OpenMP over rows / tiles like the reference's Rayon loops,
-    device-order dot) on the grid^3 Poisson system: as many iterations as fit in ~`seconds`.  -> dict."""
+    device-order dot) on the grid^3 Poisson system: as many iterations as fit in ~`seconds`.  -> dict.
+    With a device context the oracle's residual history -- which this leg computes anyway -- CHECKS the GPU at full size: the same
+    system solved by the library for the same number of iterations, histories compared entry by entry (`parity_at_size`; the oracle is
+    the checker, outside every timed region)."""
     import numpy as np
     import kryst_amd as K
     from oracle import oracle as O
@@ -154,7 +217,28 @@ def cpu_cg(grid, seconds):
     out = {"value": res.iterations / dt, "unit": "cg_iterations/s", "cores": cores, "kind": "port", "grid": grid, "extrapolated": False,
            "sample": f"{res.iterations} oracle CG iterations on the {grid}^3 Poisson system in {dt:.1f} s "
                      f"(OpenMP rows/tiles over {cores} threads, device-order dot; usize = int64 indices like the reference)"}
+    if ctx is not None:
+        try:
+            del a, rp, ci, va
+            ga = K.CsrMatrix.stencil7(grid, "poisson", ctx=ctx)
+            gb = ga.spmv(ctx.vec(ga.nrows()).fill(1.0))
+            same_b = bool(np.array_equal(gb.to_host(), b))
+            gs = K.CgSolver(0.0, iters)
+            gx = ctx.vec(ga.nrows())
+            gs.solve(ga, None, gb, gx)
+            gh, oh = np.array(gs.residual_history), np.array(res.history)
+            m = min(len(gh), len(oh))
+            dev = float(np.max(np.abs(gh[:m] - oh[:m])) / oh[0]) if m else None
+            out["parity_at_size"] = {"grid": grid, "solver": "cg (cg.rs:141-288), tol 0", "iterations_compared": int(m - 1), "history_entries": int(m),
+                                     "rhs_bit_identical": same_b, "bit_identical": bool(len(gh) == len(oh) and np.array_equal(gh, oh)),
+                                     "max_rel_dev": dev, "x_bit_identical": bool(np.array_equal(gx.to_host(), res.x)),
+                                     "checker": "oracle/kryst_oracle.c kro_cg in the library's dot order (KRO_REDUCE_TILED), " + str(cores) + " threads"}
+            del ga, gb, gx
+        except Exception as e:
+            out["parity_at_size"] = {"grid": grid, "error": f"{type(e).__name__}: {e}"}
     if grid <= 256:                                     # the bit-canonical single-thread figure beside it, a few iterations
+        rp, ci, va = K.host_stencil7(grid, "poisson")
+        a = O.Csr(grid ** 3, grid ** 3, rp, ci, va, check=False)
         O.set_threads(1)
         t0 = time.perf_counter(); r1 = O.solve("cg", a, b, tol=0.0, max_iters=4, rs=rs); dt1 = time.perf_counter() - t0
         O.set_threads(cores)
@@ -162,16 +246,16 @@ def cpu_cg(grid, seconds):
     return out
 
 
-def cpu_baseline(grid, base256):
+def cpu_baseline(grid, base256, ctx=None):
     """Measured AT the workload's size when the host has the memory for it (512^3: 24 GB of int64-indexed CSR + vectors),
     otherwise the 256^3 measurement scaled by the row count and marked as extrapolated."""
     try:
         if grid <= 256:
-            return base256 or cpu_cg(grid, 8.0)
+            return base256 or cpu_cg(grid, 8.0, ctx)
         need = 16.0 * 7 * grid ** 3 / 1e9 + 8 * 8.0 * grid ** 3 / 1e9 + 6.0
         if os.environ.get("KRYST_BENCH_CPU_FULL", "1") != "0" and host_mem_available_gb() > need:
-            return cpu_cg(grid, 10.0)
-        b = base256 or cpu_cg(256, 8.0)
+            return cpu_cg(grid, 10.0, ctx)
+        b = base256 or cpu_cg(256, 8.0, ctx)
         scale = (256 / grid) ** 3
         out = dict(b, value=b["value"] * scale, grid=grid, extrapolated=True)
         out["sample"] = b["sample"] + f"; scaled by {scale:.4f} = (256/{grid})^3 rows (host memory below {need:.0f} GB)"
@@ -196,12 +280,16 @@ def live_traffic(grid, form):
     if key in _LIVE_TRAFFIC:
         return _LIVE_TRAFFIC[key]
     res = None
-    if os.environ.get("KRYST_BENCH_LIVE_TRAFFIC", "1") != "0" and key in LIVE_FORMS:
+    # (never under an outer profiler: the children would inherit its preloaded tool library and the inner rocprofv3 would exec with the
+    # GPU already initialised -- ADVICE r03; tools/profile_round.sh also switches the live passes off)
+    profiled = any(k == "LD_PRELOAD" and "rocprof" in v or k.startswith(("ROCP_", "ROCPROF")) or k == "HSA_TOOLS_LIB" for k, v in os.environ.items())
+    if os.environ.get("KRYST_BENCH_LIVE_TRAFFIC", "1") != "0" and key in LIVE_FORMS and not profiled:
         import collections, csv, glob, shutil, subprocess, tempfile
         exe = shutil.which("rocprofv3")
         tmp = tempfile.mkdtemp(prefix="kryst_pmc_", dir="/tmp") if exe else None
         try:
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "HSA_TOOLS_LIB") and not k.startswith(("ROCP_", "ROCPROF"))}
+            env["TMPDIR"] = "/tmp"
             env.pop("KRYST_SPMV_COMPRESS", None)
             if form == "plain":
                 env["KRYST_SPMV_COMPRESS"] = "0"
@@ -272,6 +360,11 @@ def roofline_of(enc, grid, nloc, nnz_loc, ms, world, traffic_form=None, staged=F
            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
            "bytes_per_launch": moved, "bytes_model": "bytes this storage form streams: matrix description + x once + y once",
            "ms_per_launch": ms, "traffic": None, "encoding": enc[0],
+           "frac_of_streamed_bytes": ach / HBM_PEAK_GBS,
+           "frac_basis": "`frac` prices the launch at the bytes THIS storage form streams; SURVEY 8(d)'s plain-CSR bytes / time / peak is "
+                         "`frac_of_sec8d_bytes` (it exceeds 1 when the form streams fewer bytes than CSR does -- it is NOT a bandwidth fraction); the "
+                         "roofline fraction of the kernel that moves SURVEY 8(d)'s bytes is `roofline_csr.frac`",
+           "frac_of_sec8d_bytes": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "algorithmic_bytes": alg, "algorithmic_GBs": alg / (ms * 1e-3) / 1e9, "algorithmic_speedup": alg / moved}
     if world == 1:
         tform = traffic_form or ("plain" if enc[0] == "csr" else "default")
@@ -322,56 +415,84 @@ def blas1_streams(K, ctx, n):
 
 
 class env_override:
-    def __init__(self, **kv): self.kv, self.old = kv, {}
+    """Tuning knobs for a block of measurements.  The library reads them per entry point (per solve / session step inside a solver), so the
+    block must not overlap with another setting: with several rank threads in one process the leader sets the variables between two
+    barriers (nobody is inside the library then -- setenv must not race with a getenv)."""
+    def __init__(self, group=None, **kv): self.g, self.kv, self.old = group, kv, {}
+    def _sync(self):
+        if self.g is not None and isinstance(self.g, ThreadedGroup): self.g.barrier()
     def __enter__(self):
-        for k, v in self.kv.items():
-            self.old[k] = os.environ.get(k)
-            os.environ[k] = v
+        self._sync()
+        if self.g is None or self.g.env_leader:
+            for k, v in self.kv.items():
+                self.old[k] = os.environ.get(k)
+                os.environ[k] = v
+        self._sync()
     def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
+        self._sync()
+        if self.g is None or self.g.env_leader:
+            for k, v in self.old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+        self._sync()
 
 
-def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters):
+def stepped(K, ctx, group, method, a, pc, b, warmup, steps, batches=3):
+    """W warm-up iterations, then `batches` batches of exactly K iterations of one stepping session (tol = 0), each bracketed by device
+    synchronize + barrier on both sides, the maximum over ranks per batch; -> (median batch seconds, stats, all batch seconds).  One
+    disturbed batch must not become the headline."""
+    def barrier():
+        ctx.synchronize()
+        group.barrier()
+    x = ctx.vec(a.nrows())
+    with K.Session(method, a, pc, b, x, tol=0.0, max_iters=warmup + batches * steps) as sess:
+        sess.step(warmup)
+        dts = []
+        for _ in range(batches):
+            barrier()
+            t0 = time.perf_counter()
+            sess.step(steps)
+            barrier()
+            dts.append(group.allreduce_max(time.perf_counter() - t0))
+        stats = sess.end()
+    assert stats.iterations == warmup + batches * steps, stats
+    return sorted(dts)[len(dts) // 2], stats, dts
+
+
+def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3):
     """Everything measured on one grid size -> dict (the operator is built once; the plain-CSR figures re-run the same
-    iterations with KRYST_SPMV_COMPRESS=0, which the launcher reads per launch)."""
+    iterations with KRYST_SPMV_COMPRESS=0, which the library reads per session step)."""
     def barrier():
         ctx.synchronize()
         group.barrier()
 
-    world = group.world
+    import contextlib
+    settings = contextlib.ExitStack()                        # knobs the headline's winning form keeps for the rest of the measurements
+    world, rank = group.world, group.rank
+    stage(rank, f"create operator {grid}^3")
     a = K.CsrMatrix.stencil7(grid, "poisson", ctx=ctx)
     nloc = a.nrows()
     b = a.spmv(ctx.vec(nloc).fill(1.0))                      # b = A*1 (tests/preconditioner_integration.rs:25-31 convention)
     pc = K.Jacobi().setup(a) if solver == "pcg" else None
 
     def timed_iterations():
-        x = ctx.vec(nloc)
-        sess = K.Session(solver, a, pc, b, x, tol=0.0, max_iters=warmup + steps)
-        sess.step(warmup)
-        barrier()
-        t0 = time.perf_counter()
-        sess.step(steps)
-        barrier()
-        dt = group.allreduce_max(time.perf_counter() - t0)
-        stats = sess.end()
-        assert stats.iterations == warmup + steps, stats
-        return dt, stats
+        return stepped(K, ctx, group, solver, a, pc, b, warmup, steps, batches)
 
-    dt, stats = timed_iterations()
+    stage(rank, "warm-up + timed iterations")
+    dt, stats, dts = timed_iterations()
     # N > 1: the same K iterations with the inner products crossing the ranks through the hipIpc mailboxes instead of two RCCL
     # all-gathers per iteration (kryst_ctx_scalar_reduce).  The faster path that reproduces the other's residual BIT FOR BIT is the
     # headline; both figures are reported.  (Every rank takes the same decision: times are max-reduced, scalars are identical.)
     reduce_info = None
     if world > 1:
+        stage(rank, "mailbox setup + timed iterations (scalar all-reduce through hipIpc mailboxes)")
         reduce_info = {"path": "rccl", "value_rccl": steps / dt, "value_ipc": None, "ipc": "unavailable on this node (hipIpc export / mapping failed)"}
         if ctx.scalar_reduce("ipc") == "ipc":
             try:
-                dt_ipc, stats_ipc = timed_iterations()
+                dt_ipc, stats_ipc, dts_ipc = timed_iterations()
                 failed = 0.0
             except Exception as e:                  # e.g. a peer's stamp never arrived (KRYST_ERR_RCCL after the poll budget)
-                dt_ipc, stats_ipc, failed = float("inf"), None, 1.0
+                dt_ipc, stats_ipc, dts_ipc, failed = float("inf"), None, None, 1.0
                 reduce_info["ipc"] = f"failed: {e}"
             if group.allreduce_max(failed) > 0.0:    # one rank's failure is everybody's: back to the all-gather path, on every rank
                 reduce_info.setdefault("ipc", "failed on another rank")
@@ -382,31 +503,68 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters):
                 same = group.allreduce_max(0.0 if stats_ipc.final_residual == stats.final_residual else 1.0) == 0.0
                 reduce_info.update(value_ipc=steps / dt_ipc, ipc="bit-identical residual" if same else "DIFFERENT residual: not used")
                 if same and dt_ipc < dt:
-                    dt, stats = dt_ipc, stats_ipc
+                    dt, stats, dts = dt_ipc, stats_ipc, dts_ipc
                     reduce_info["path"] = "ipc"
                 else:
                     ctx.scalar_reduce("rccl")
-    # N > 1: the halo exchange of the new p started behind the direction pass's boundary tiles (the default) against started by the next
-    # SpMV (KRYST_HALO_EARLY=0): the same bits; the faster one is the headline, both figures are reported
+    # N > 1: the forms of the halo exchange (kryst_ctx_halo_mode and KRYST_HALO_EARLY): the same bits; the fastest one is the headline, every
+    # figure is reported
     if world > 1:
-        with env_override(KRYST_HALO_EARLY="0"):
-            dt_late, stats_late = timed_iterations()
+        stage(rank, "timed iterations (other halo forms)")
+        forms = {"early": steps / dt}
+        best = "early"
+        with env_override(group, KRYST_HALO_EARLY="0"):
+            dt_late, stats_late, dts_late = timed_iterations()
         same = group.allreduce_max(0.0 if stats_late.final_residual == stats.final_residual else 1.0) == 0.0
-        reduce_info.update(value_halo_early=steps / dt, value_halo_at_spmv=steps / dt_late, halo="early")
-        if same and dt_late < dt:
-            dt, stats = dt_late, stats_late
-            reduce_info["halo"] = "at the SpMV"
-            os.environ["KRYST_HALO_EARLY"] = "0"          # (the plain-CSR and phase runs below use the same setting)
+        forms["at_spmv"] = steps / dt_late
+        late_wins = same and dt_late < dt
+        if late_wins:
+            dt, stats, dts, best = dt_late, stats_late, dts_late, "at_spmv"
+        peer_note = None
+        if hasattr(ctx, "halo_mode"):
+            if ctx.halo_mode("peer") == "peer":
+                try:
+                    dt_p, stats_p, dts_p = timed_iterations()
+                    failed = 0.0
+                except Exception as e:
+                    dt_p, stats_p, dts_p, failed = float("inf"), None, None, 1.0
+                    peer_note = f"failed: {e}"
+                if group.allreduce_max(failed) > 0.0:
+                    peer_note = peer_note or "failed on another rank"
+                    ctx.halo_mode("rccl")
+                else:
+                    same_p = group.allreduce_max(0.0 if stats_p.final_residual == stats.final_residual else 1.0) == 0.0
+                    forms["peer_stores"] = steps / dt_p
+                    peer_note = "bit-identical residual" if same_p else "DIFFERENT residual: not used"
+                    if same_p and dt_p < dt:
+                        dt, stats, dts, best = dt_p, stats_p, dts_p, "peer_stores"
+                    else:
+                        ctx.halo_mode("rccl")
+            else:
+                peer_note = "unavailable on this node (hipIpc export / mapping of the halo buffers failed)"
+        reduce_info.update(value_halo_early=forms["early"], value_halo_at_spmv=forms["at_spmv"], value_halo_peer_stores=forms.get("peer_stores"),
+                           halo={"early": "early", "at_spmv": "at the SpMV", "peer_stores": "peer stores"}[best], peer_stores=peer_note)
+        if best == "at_spmv":                                  # (the plain-CSR and phase runs below use the headline's setting)
+            settings.enter_context(env_override(group, KRYST_HALO_EARLY="0"))
     enc = a.encoding()
-    with env_override(KRYST_SPMV_COMPRESS="0"):
-        dt_plain, stats_plain = timed_iterations()
+    stage(rank, "timed iterations (plain CSR)")
+    with env_override(group, KRYST_SPMV_COMPRESS="0"):
+        dt_plain, stats_plain, dts_plain = timed_iterations()
     # the dominant kernel, timed live with HIP events on the compute stream (kryst_bench_spmv), in both storage forms
+    stage(rank, "kernel timings")
     y = ctx.vec(nloc)
     # (three averages of 20 / 10 back-to-back launches each, the median of the three: one disturbed batch -- seen once, a 7x outlier --
     # must not become the roofline figure)
     spmv_ms = sorted(a.bench_spmv(b, y, fused_dots=1, reps=20) for _ in range(3))[1]
-    with env_override(KRYST_SPMV_COMPRESS="0"):
+    with env_override(group, KRYST_SPMV_COMPRESS="0"):
         plain_ms = sorted(a.bench_spmv(b, y, fused_dots=1, reps=10) for _ in range(3))[1]
+    # the plain kernel's traffic without its arithmetic on the same arrays, in the same process: what this mix of streams can reach here
+    skeleton_ms = None
+    if world == 1:
+        try:
+            skeleton_ms = sorted(a.bench_csr_skeleton(b, y, reps=10) for _ in range(3))[1]
+        except Exception as e:
+            sys.stderr.write(f"bench.py: stream skeleton skipped: {e}\n")
     # context: the device-copy rate at this footprint (hipMemcpy D2D of one vector, read + write)
     y.copy_from(b); ctx.synchronize()
     ctx.timer_start()
@@ -416,14 +574,15 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters):
     # where an iteration's device time goes (a separate short run with event marks between the phases)
     phases = None
     if phase_iters > 0:
+        stage(rank, "phase timing")
         x = ctx.vec(nloc)
-        sess = K.Session(solver, a, pc, b, x, tol=0.0, max_iters=phase_iters + 2)
-        sess.step(2)
-        barrier()
-        ctx.phase_timing_begin()
-        sess.step(phase_iters)
-        ph = ctx.phase_timing_end()
-        sess.end()
+        with K.Session(solver, a, pc, b, x, tol=0.0, max_iters=phase_iters + 2) as sess:
+            sess.step(2)
+            barrier()
+            ctx.phase_timing_begin()
+            sess.step(phase_iters)
+            ph = ctx.phase_timing_end()
+            sess.end()
         mine = {k: v / phase_iters for k, v in ph.items() if v > 0.0}
         mine["total"] = sum(mine.values())
         phases = group.gather(mine)
@@ -431,6 +590,7 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters):
     # first real multi-GPU run says how much of an iteration the two inner-product exchanges can be at most
     collective_us = None
     if world > 1:
+        stage(rank, "scalar all-reduce round trips")
         for _ in range(10):
             ctx.all_reduce(1.0)
         barrier()
@@ -439,9 +599,18 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters):
             ctx.all_reduce(1.0)
         collective_us = group.allreduce_max((time.perf_counter() - t0) / 100 * 1e6)
     nnz_loc = a.nnz
-    return {"dt": dt, "dt_plain": dt_plain, "stats": stats, "enc": enc, "nloc": nloc, "nnz_loc": nnz_loc, "collective_us": collective_us, "reduce_info": reduce_info,
+    roof_csr = roofline_csr_of(grid, nloc, nnz_loc, plain_ms, world)
+    if skeleton_ms:
+        alg = spmv_bytes(nloc, nnz_loc)
+        roof_csr["stream_skeleton"] = {
+            "kernel": "csr_skeleton_kernel (the CSR arrays streamed, x read once, y written once: SURVEY 8(d)'s bytes, no gathers / products / row sums / fold; "
+                      "same arrays, same process)", "ms_per_launch": skeleton_ms, "achieved": alg / (skeleton_ms * 1e-3) / 1e9, "unit": "GB/s",
+            "frac": alg / (skeleton_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_over_skeleton": plain_ms / skeleton_ms}
+    settings.close()
+    return {"dt": dt, "dts": dts, "dt_plain": dt_plain, "dts_plain": dts_plain, "stats": stats, "enc": enc, "nloc": nloc, "nnz_loc": nnz_loc,
+            "collective_us": collective_us, "reduce_info": reduce_info,
             "roofline": roofline_of(enc, grid, nloc, nnz_loc, spmv_ms, world, staged=a.pattern_info()["staged"]),
-            "roofline_csr": roofline_csr_of(grid, nloc, nnz_loc, plain_ms, world),
+            "roofline_csr": roof_csr,
             "blas1": blas1_streams(K, ctx, nloc), "copy_gbs": copy_gbs, "phases": phases,
             "final_residual_plain": stats_plain.final_residual}
 
@@ -494,6 +663,24 @@ def tri_roofline(pc, r, z, n, nnz, reps=20):
     return out
 
 
+ILU_SETUP_NOTE = ("ilu_setup_ms = the SECOND setup of the same operator in this process (steady state: the device-side factorisation and the blocked "
+                  "layout); ilu_setup_first_call_ms = the first one, which also pays for first-use work that is not the factorisation's: the code "
+                  "objects of the setup kernels are loaded and the large layout buffers are allocated and first touched (round 3's 72 / 255 / 519 ms "
+                  "at 512^3 were first calls at different points of a process's life)")
+
+
+def ilu_setup_times(K, ctx, a):
+    """(first-call seconds, steady-state seconds, preconditioner) of the true ILU(0) setup."""
+    ctx.synchronize(); t0 = time.perf_counter()
+    pc = K.TrueIlu0().setup(a)
+    ctx.synchronize(); t_first = time.perf_counter() - t0
+    del pc
+    ctx.synchronize(); t0 = time.perf_counter()
+    pc = K.TrueIlu0().setup(a)
+    ctx.synchronize(); t_second = time.perf_counter() - t0
+    return t_first, t_second, pc
+
+
 def other_configs(K, ctx, steps, warmup):
     """BASELINE configs 3, 5 (256^3, solved to their tolerance), config 4's workload on one GPU (512^3 Jacobi-PCG, stepped) and the
     variable-coefficient operator at 256^3 / 512^3.  N = 1 only."""
@@ -513,14 +700,13 @@ def other_configs(K, ctx, steps, warmup):
     # ---- config 5: right-preconditioned BiCGStab + true ILU(0) on 256^3 anisotropic Poisson, absolute tol 1e-8 ||b|| (bicgstab.rs:69-293)
     a = K.CsrMatrix.stencil7(256, "aniso", ctx=ctx); n = a.nrows()
     b = a.spmv(ctx.vec(n).fill(1.0)); bn = K.norm(b)
-    ctx.synchronize(); t0 = time.perf_counter()
-    pc = K.TrueIlu0().setup(a)
-    ctx.synchronize(); t_setup = time.perf_counter() - t0
+    t_first, t_setup, pc = ilu_setup_times(K, ctx, a)
     dt, st = timed_solve(K, ctx, lambda: K.BiCgStabRightPcSolver(1e-8 * bn, 3000), a, pc, b)
     z = ctx.vec(n)
     out["config5_bicgstab_ilu0_256"] = {
         "workload": "bicgstab_right_true_ilu0_aniso7_256^3", "value": st.iterations / dt, "unit": "iterations/s", "iterations": st.iterations,
-        "converged": bool(st.converged), "final_residual": st.final_residual, "solve_seconds": dt, "ilu_setup_ms": t_setup * 1e3,
+        "converged": bool(st.converged), "final_residual": st.final_residual, "solve_seconds": dt, "ilu_setup_ms": t_setup * 1e3, "ilu_setup_first_call_ms": t_first * 1e3,
+        "ilu_setup_note": ILU_SETUP_NOTE,
         "spmv_encoding": a.encoding()[0], "note": "the reference's BiCGStab ignores pc (bicgstab.rs:70); the preconditioned form is a labelled extension",
         "roofline": tri_roofline(pc, b, z, n, a.nnz)}
     del pc, a, b, z
@@ -529,16 +715,12 @@ def other_configs(K, ctx, steps, warmup):
     a = K.CsrMatrix.stencil7(512, "poisson", ctx=ctx); n = a.nrows()
     b = a.spmv(ctx.vec(n).fill(1.0))
     pc = K.Jacobi().setup(a)
-    x = ctx.vec(n)
-    with K.Session("pcg", a, pc, b, x, tol=0.0, max_iters=warmup + k4) as sess:
-        sess.step(warmup); ctx.synchronize(); t0 = time.perf_counter()
-        sess.step(k4); ctx.synchronize(); dt = time.perf_counter() - t0
-        st = sess.end()
+    dt, st, dts4 = stepped(K, ctx, SoloGroup(), "pcg", a, pc, b, warmup, k4)
     out["config4_jacobi_pcg_512"] = {
         "workload": "jacobi_pcg_poisson7_512^3 on one GPU (the 8-way partition is the --gpus 8 run)", "value": k4 / dt, "unit": "iterations/s", "steps": k4,
-        "ms_per_step": dt / k4 * 1e3, "final_residual": st.final_residual, "spmv_encoding": a.encoding()[0],
+        "ms_per_step": dt / k4 * 1e3, "batch_ms": [d * 1e3 for d in dts4], "final_residual": st.final_residual, "spmv_encoding": a.encoding()[0],
         "algorithmic_bytes_per_iteration": spmv_bytes(n, a.nnz) + 136 * n}
-    del pc, a, b, x
+    del pc, a, b
     # ---- variable coefficients: no row patterns, no value dictionary, no repeating coefficient chunks
     for grid in (256, 512):
         kv = min(steps, 100)
@@ -547,71 +729,35 @@ def other_configs(K, ctx, steps, warmup):
         enc = a.encoding()
         blk = {"workload": f"variable-coefficient 7-point diffusion operator, {grid}^3 (kind varcoef: per-edge weights from splitmix64)", "spmv_encoding": enc[0]}
         for form, env in (("default", {}), ("plain_csr", {"KRYST_SPMV_COMPRESS": "0"})):
-            with env_override(**env):
-                x = ctx.vec(n)
-                with K.Session("cg", a, None, b, x, tol=0.0, max_iters=warmup + kv) as sess:
-                    sess.step(warmup); ctx.synchronize(); t0 = time.perf_counter()
-                    sess.step(kv); ctx.synchronize(); dt = time.perf_counter() - t0
-                    sess.end()
-                ms = a.bench_spmv(b, y, fused_dots=1, reps=20)
+            with env_override(None, **env):
+                dt, _, _ = stepped(K, ctx, SoloGroup(), "cg", a, None, b, warmup, kv)
+                ms = sorted(a.bench_spmv(b, y, fused_dots=1, reps=10) for _ in range(3))[1]
                 e = a.encoding()
             if form == "default":
                 blk.update(value=kv / dt, unit="iterations/s", steps=kv, ms_per_step=dt / kv * 1e3, roofline=roofline_of(e, grid, n, nnz, ms, 1, "varcoef"))
             else:
                 blk.update(value_plain_csr=kv / dt, ms_per_step_plain_csr=dt / kv * 1e3, roofline_csr=roofline_csr_of(grid, n, nnz, ms, 2))
-            del x
-        ctx.synchronize(); t0 = time.perf_counter()
-        pc = K.TrueIlu0().setup(a)
-        ctx.synchronize(); blk["ilu_setup_ms"] = (time.perf_counter() - t0) * 1e3
+        t_first, t_setup, pc = ilu_setup_times(K, ctx, a)
+        blk.update(ilu_setup_ms=t_setup * 1e3, ilu_setup_first_call_ms=t_first * 1e3)
         blk["ilu_apply"] = tri_roofline(pc, b, y, n, nnz, reps=10)
         out[f"variable_coefficient_{grid}"] = blk
         del pc, a, b, y
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--grid", type=int, default=0, help="grid edge (default 512 for every N)")
-    ap.add_argument("--solver", default="cg", choices=["cg", "pcg"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-256", action="store_true", help="skip the config1_256 block (N = 1 measures BASELINE configs[1]'s 256^3 grid too)")
-    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs and the variable-coefficient blocks (N = 1)")
-    ap.add_argument("--phase-iters", type=int, default=20, help="iterations of the per-phase timing run (0: skip)")
-    ap.add_argument("--launcher", default="auto", choices=["auto", "torch", "socket"],
-                    help="N > 1 plumbing for the RCCL id / barrier: torch.distributed gloo (default) or kryst_amd/launch.py (no torch)")
-    args = ap.parse_args()
-
-    # a hung collective must not hang the node: give up loudly after 20 minutes
-    def _watchdog():
-        sys.stderr.write("bench.py: watchdog timeout (1200 s), aborting\n"); sys.stderr.flush(); os._exit(124)
-    wd = threading.Timer(1200.0, _watchdog); wd.daemon = True; wd.start()
-
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between processes on this driver
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    grid = args.grid or 512          # ONE fixed problem for every N (strong scaling, north_star): 512^3
-
-    group = make_group(args.launcher, rank, world)
+def rank_main(args, group, rank, world, dev, grid):
+    """One rank's whole run (the process's only one, or one of its rank threads)."""
     import kryst_amd as K
+    stage(rank, "comm init" if world > 1 else "context")
     if world > 1:
         uid = group.broadcast_bytes(K.Context.unique_id() if rank == 0 else None)
-        # KRYST_BENCH_DEVICE: rehearsal of the N > 1 flow on a one-GPU box (all ranks on one device, RCCL stand-in)
-        dev = int(os.environ.get("KRYST_BENCH_DEVICE", local_rank))
         ctx = K.Context(dev, rank, world, uid)
     else:
         ctx = K.Context(0)
 
     n = grid ** 3
     nnz = 7 * n - 6 * grid * grid
-    m = measure(K, ctx, group, grid, args.solver, args.warmup, args.steps, args.phase_iters)
+    m = measure(K, ctx, group, grid, args.solver, args.warmup, args.steps, args.phase_iters, args.batches)
     wl = "jacobi_pcg" if args.solver == "pcg" else "cg"
     out = {
         "metric": "cg_iterations_per_sec", "value": args.steps / m["dt"], "unit": "iterations/s",
@@ -619,7 +765,10 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{wl}_poisson7_{grid}^3", "grid": grid, "rows": n, "nnz": nnz, "partition": f"{world} k-slab(s)",
                    "rhs": "A*1", "x0": "0", "final_residual": m["stats"].final_residual, "spmv_encoding": m["enc"][0],
-                   "launcher": type(group).__name__},
+                   "launcher": type(group).__name__ if not isinstance(group, ThreadedGroup) else f"{type(group.sh.inner).__name__} x {group.sh.per} rank threads per process"},
+        "timing": {"batches": len(m["dts"]), "batch_ms": [d * 1e3 for d in m["dts"]], "batch_ms_plain_csr": [d * 1e3 for d in m["dts_plain"]],
+                   "rule": "W warm-up iterations, then `batches` batches of exactly K iterations of ONE stepping session, each bracketed by device synchronize + "
+                           "barrier on both sides, max over ranks per batch; value = K / the MEDIAN batch"},
         "value_plain_csr": args.steps / m["dt_plain"], "ms_per_step_plain_csr": m["dt_plain"] / args.steps * 1e3,
         "roofline": m["roofline"], "roofline_csr": m["roofline_csr"], "roofline_blas1": m["blas1"],
         "measured_copy_GBs": m["copy_gbs"],
@@ -629,27 +778,109 @@ def main():
     }
     base256 = None
     if world == 1 and grid != 256 and not args.no_256:
-        m2 = measure(K, ctx, group, 256, args.solver, args.warmup, args.steps, args.phase_iters)
+        m2 = measure(K, ctx, group, 256, args.solver, args.warmup, args.steps, args.phase_iters, args.batches)
         out["config1_256"] = {"workload": f"{wl}_poisson7_256^3", "value": args.steps / m2["dt"], "unit": "iterations/s",
-                              "ms_per_step": m2["dt"] / args.steps * 1e3, "value_plain_csr": args.steps / m2["dt_plain"],
+                              "ms_per_step": m2["dt"] / args.steps * 1e3, "batch_ms": [d * 1e3 for d in m2["dts"]], "value_plain_csr": args.steps / m2["dt_plain"],
                               "roofline": m2["roofline"], "roofline_csr": m2["roofline_csr"], "roofline_blas1": m2["blas1"],
                               "phase_ms": m2["phases"]}
         if not args.no_cpu_baseline:
+            stage(rank, "cpu baseline + full-size parity 256^3")
             try:
-                base256 = cpu_cg(256, 8.0)
+                base256 = cpu_cg(256, 8.0, ctx)
                 out["config1_256"]["cpu_baseline"] = base256
             except Exception as e:
                 out["config1_256"]["cpu_baseline"] = {"value": None, "unit": "cg_iterations/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if world == 1 and not args.no_configs:
+        stage(rank, "other BASELINE configs")
         try:
             out.update(other_configs(K, ctx, args.steps, args.warmup))
         except Exception as e:                              # the headline line must survive a failing side measurement
             out["other_configs_error"] = f"{type(e).__name__}: {e}"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(grid, base256)
+        stage(rank, f"cpu baseline + full-size parity {grid}^3")
+        out["cpu_baseline"] = cpu_baseline(grid, base256, ctx)
+        # the oracle iterations of the baseline double as the full-size parity check (north_star: residuals matching the CPU reference)
+        par = [b["parity_at_size"] for b in (out["cpu_baseline"], base256 or {}) if isinstance(b, dict) and "parity_at_size" in b]
+        if par:
+            out["parity_at_size"] = par
+    stage(rank, "gather / print")
     if rank == 0:
         print(json.dumps(out), flush=True)
     group.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batches", type=int, default=3, help="timed batches of --steps iterations each; the median batch is the headline")
+    ap.add_argument("--grid", type=int, default=0, help="grid edge (default 512 for every N)")
+    ap.add_argument("--solver", default="cg", choices=["cg", "pcg"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-256", action="store_true", help="skip the config1_256 block (N = 1 measures BASELINE configs[1]'s 256^3 grid too)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs and the variable-coefficient blocks (N = 1)")
+    ap.add_argument("--phase-iters", type=int, default=20, help="iterations of the per-phase timing run (0: skip)")
+    ap.add_argument("--launcher", default="auto", choices=["auto", "torch", "socket"],
+                    help="N > 1 plumbing for the RCCL id / barrier: torch.distributed gloo (default) or kryst_amd/launch.py (no torch)")
+    ap.add_argument("--ranks-per-process", type=int, default=1,
+                    help="REHEARSAL ONLY (one-GPU box, KRYST_BENCH_DEVICE): this many ranks per launched process, a host thread each -- 8 ranks as "
+                         "4 processes x 2, because a GPU box admits at most 6 processes on its card; --gpus then counts ranks")
+    args = ap.parse_args()
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between processes on this driver
+    procs = int(os.environ.get("WORLD_SIZE", "1"))
+    prank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    per = max(1, args.ranks_per_process)
+    world = procs * per
+
+    # A hung collective must not hang the node, and the driver must learn WHERE it hung: the watchdog fires BELOW the driver's own
+    # timeout (600 s in round 3) and names every local rank's last stage marker.
+    limit = float(os.environ.get("KRYST_BENCH_WATCHDOG_S", "280" if world > 1 else "560"))
+    def _watchdog():
+        where = "; ".join(f"rank {r}: {nm}" for r, nm in sorted(_STAGE.items())) or "before the first stage"
+        sys.stderr.write(f"bench.py: watchdog timeout ({limit:.0f} s) -- last stage markers: {where}\n"); sys.stderr.flush(); os._exit(124)
+    wd = threading.Timer(limit, _watchdog); wd.daemon = True; wd.start()
+
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    grid = args.grid or 512          # ONE fixed problem for every N (strong scaling, north_star): 512^3
+
+    stage(prank * per, f"rendezvous (process {prank} of {procs}, {per} rank(s) per process, LOCAL_RANK {local_rank})")
+    inner = make_group(args.launcher, prank, procs)
+    # KRYST_BENCH_DEVICE: rehearsal of the N > 1 flow on a one-GPU box (all ranks on one device, RCCL stand-in)
+    dev = int(os.environ.get("KRYST_BENCH_DEVICE", local_rank))
+    if world > 1:
+        from kryst_amd._ffi import device_count
+        ndev = device_count()
+        if dev >= ndev:                  # one rank per GPU: a rank without a device of its own must fail loudly, not share one silently
+            sys.stderr.write(f"bench.py: rank {prank} has LOCAL_RANK {local_rank} -> device {dev}, but this process sees {ndev} device(s) "
+                             "(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); one GPU per rank is required\n")
+            sys.stderr.flush()
+            os._exit(2)
+    if per == 1:
+        return rank_main(args, inner, prank, world, dev, grid)
+    shared = ThreadedGroup.Shared(inner, per)
+    failed = []
+
+    def guarded(t):
+        try:
+            rank_main(args, ThreadedGroup(shared, t), prank * per + t, world, dev, grid)
+        except BaseException:                       # noqa: BLE001  (a sibling thread would wait for this rank inside a collective for ever)
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            failed.append(t)
+            os._exit(3)
+
+    ts = [threading.Thread(target=guarded, args=(t,)) for t in range(per)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
 
 
 if __name__ == "__main__":

@@ -58,6 +58,7 @@ extern "C" {
     pub fn kryst_hip_last_error() -> *const c_char;
     pub fn kryst_hip_last_error_row() -> i64;
     pub fn kryst_hip_abi_version() -> i32;
+    pub fn kryst_device_count(count: *mut i32) -> i32;
     pub fn kryst_reduce_spec(t: *mut i32, v: *mut i32, f: *mut i32);
 
     pub fn kryst_ctx_create(device_id: i32, out: *mut Ctx) -> i32;
@@ -101,6 +102,7 @@ extern "C" {
     pub fn kryst_spmv_host(a: Csr, x: *const f64, nx: i64, y: *mut f64, ny: i64) -> i32;
     pub fn kryst_bench_spmv(a: Csr, x: Vecd, y: Vecd, fused_dots: i32, reps: i32, avg_ms: *mut f64) -> i32;
     pub fn kryst_bench_streams(ctx: Ctx, n: i64, stride_bytes: i64, kind: i32, reps: i32, avg_ms: *mut f64) -> i32;
+    pub fn kryst_bench_csr_skeleton(a: Csr, x: Vecd, y: Vecd, reps: i32, avg_ms: *mut f64) -> i32;
 
     pub fn kryst_dot(x: Vecd, y: Vecd, out: *mut f64) -> i32;
     pub fn kryst_norm(x: Vecd, out: *mut f64) -> i32;

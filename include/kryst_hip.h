@@ -62,6 +62,9 @@ int32_t     kryst_hip_abi_version(void);
 void        kryst_reduce_spec(int32_t* T, int32_t* V, int32_t* F);
 
 /* ---- context: one per GPU / per rank.  Replaces src/parallel (Comm trait, parallel/mod.rs:4-35) ---- */
+/* HIP devices this process sees (0 without a GPU): a launcher checks it before it hands LOCAL_RANK to kryst_ctx_create_dist -- one rank
+ * per GPU, as MpiComm::new gets one rank per process from mpirun (src/parallel/mpi_comm.rs:49-55) */
+int32_t kryst_device_count(int32_t* count);
 int32_t kryst_ctx_create(int32_t device_id, kryst_ctx_t* out);
 /* rank/nranks + 128-byte RCCL unique id (rank 0 makes it with kryst_comm_unique_id and ships it to the other
  * ranks by any side channel).  Replaces MpiComm::new (src/parallel/mpi_comm.rs:49-55). */
@@ -151,6 +154,10 @@ int32_t kryst_bench_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t fu
  * 2 vectors; 7: CG residual pass r -= a q with (r,r), 2 vectors; 8: CG direction pass with the deferred x update, 3 vectors)
  * over vectors of n doubles placed stride_bytes apart in one allocation */
 int32_t kryst_bench_streams(kryst_ctx_t ctx, int64_t n, int64_t stride_bytes, int32_t kind, int32_t reps, double* avg_ms);
+/* measurement only: the plain-CSR SpMV's TRAFFIC without its arithmetic on the operator's own CSR arrays -- row pointers, values and
+ * column indices streamed, x read once, y written once (SURVEY 8(d)'s bytes; y receives garbage): what this mix of five read streams and
+ * one written reaches on this HBM, for `roofline_csr`'s "fraction of what the mix can reach" (bench.py: stream_skeleton) */
+int32_t kryst_bench_csr_skeleton(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t reps, double* avg_ms);
 
 /* ---- BLAS-1: InnerProduct for () (src/core/wrappers.rs:90-127) and the solvers' pointwise loops ---- */
 int32_t kryst_dot(kryst_vec_t x, kryst_vec_t y, double* out);       /* wrappers.rs:90-108 */

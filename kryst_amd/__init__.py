@@ -307,6 +307,13 @@ class CsrMatrix:
         check(lib().kryst_bench_spmv(self.h, x.h, y.h, fused_dots, reps, C.byref(ms)))
         return ms.value
 
+    def bench_csr_skeleton(self, x, y, reps=10):
+        """Average milliseconds per launch of the plain-CSR kernel's traffic skeleton (the CSR arrays streamed, x read, y written -- no
+        arithmetic; y receives garbage)."""
+        ms = C.c_double()
+        check(lib().kryst_bench_csr_skeleton(self.h, x.h, y.h, reps, C.byref(ms)))
+        return ms.value
+
     matvec = spmv                                # MatVec::matvec (core/traits.rs:4-7)
     spmv_parallel = spmv                         # sparse.rs:103-114 (same arithmetic)
 

@@ -38,6 +38,7 @@ SIGNATURES = {
     "kryst_hip_last_error": (C.c_char_p, []),
     "kryst_hip_last_error_row": (C.c_int64, []),
     "kryst_hip_abi_version": (C.c_int32, []),
+    "kryst_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
     "kryst_reduce_spec": (None, [c_i32p, c_i32p, c_i32p]),
     "kryst_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(Handle)]),
     "kryst_comm_unique_id": (C.c_int32, [C.c_void_p]),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "kryst_csr_pattern_info": (C.c_int32, [Handle, C.POINTER(C.c_int64)]),
     "kryst_bench_spmv": (C.c_int32, [Handle, Handle, Handle, C.c_int32, C.c_int32, c_dp]),
     "kryst_bench_streams": (C.c_int32, [Handle, C.c_int64, C.c_int64, C.c_int32, C.c_int32, c_dp]),
+    "kryst_bench_csr_skeleton": (C.c_int32, [Handle, Handle, Handle, C.c_int32, c_dp]),
     "kryst_dot": (C.c_int32, [Handle, Handle, c_dp]),
     "kryst_norm": (C.c_int32, [Handle, c_dp]),
     "kryst_axpy": (C.c_int32, [C.c_double, Handle, Handle]),
@@ -178,3 +180,10 @@ def check(rc, stats=None):
     if rc != OK:
         msg = lib().kryst_hip_last_error()
         raise KError(rc, msg.decode() if msg else "", stats, lib().kryst_hip_last_error_row() if rc == 5 else None)
+
+
+def device_count():
+    """HIP devices this process sees (0 without a GPU)."""
+    c = C.c_int32(0)
+    check(lib().kryst_device_count(C.byref(c)))
+    return c.value

@@ -130,3 +130,74 @@ extern "C" int32_t kryst_bench_streams(kryst_ctx_t ctx, int64_t n, int64_t strid
     (void)hipFree(pool);
     return rc;
 }
+
+// ---- the plain-CSR SpMV's traffic WITHOUT its arithmetic (bench.py: `stream_skeleton`): per 512-row tile a workgroup reads the tile's row
+// pointers (8 bytes per lane; the stream bounds come out of them, as in spmv_wave_kernel), streams the tile's values (16 bytes per lane and
+// request) and column indices (8 bytes per lane and request), four requests of each in flight per wave, reads x once (16 bytes per lane) and
+// writes y once (16 bytes per lane, nontemporal) -- SURVEY 8(d)'s bytes, 12 nnz + 4 (n + 1) + 16 n, on the operator's OWN arrays (same
+// allocation, same placement), one tile per workgroup in index order.  No gathers, no products, no row sums, no fold: what a kernel with this
+// traffic mix reaches on this HBM, measured in the same process as the real kernel.  y receives garbage.
+namespace kr {
+typedef unsigned int sk_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int sk_u2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__global__ __launch_bounds__(KR_T) void csr_skeleton_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                            const double* __restrict__ x, double* __restrict__ y, int64_t n, int64_t ntiles) {
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    const int64_t q = blockIdx.x;
+    if (q >= ntiles) return;
+    const int64_t r0 = q * KR_TILE, r1 = r0 + KR_TILE < n ? r0 + KR_TILE : n;
+    const int64_t ri = r0 + 2 * t < n ? r0 + 2 * t : ((n - 1) & ~(int64_t)1);
+    const sk_u2 mine = *reinterpret_cast<const sk_u2*>(rp + ri);              // the lane's two row pointers (row_ptr holds n + 1 + 8 entries)
+    unsigned acc = mine.x ^ mine.y;
+    const int64_t k0 = (int64_t)rp[r0] & ~(int64_t)1, k1 = rp[r1];            // (uniform: scalar loads) the tile's entries, from an even index
+    const int64_t wq = (((k1 - k0 + 3) / 4) + 1) & ~(int64_t)1;              // a contiguous quarter per wave, an even number of entries
+    const int64_t e0 = k0 + w * wq, e1 = e0 + wq < k1 ? e0 + wq : k1;
+    for (int64_t off = e0; off < e1; off += 4 * 128) {
+        sk_u4 v[4]; sk_u2 c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t k = off + u * 128 + 2 * l;                          // (val / col carry 8 entries of padding: k + 1 <= nnz + 7)
+            v[u] = sk_u4{0u, 0u, 0u, 0u}; c[u] = sk_u2{0u, 0u};
+            if (k < e1) {
+                const sk_u4* pv = reinterpret_cast<const sk_u4*>(val + k);
+                const sk_u2* pc = reinterpret_cast<const sk_u2*>(col + k);
+                v[u] = NT ? __builtin_nontemporal_load(pv) : *pv;
+                c[u] = NT ? __builtin_nontemporal_load(pc) : *pc;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w ^ c[u].x ^ c[u].y;
+    }
+    const sk_u4 xv = *reinterpret_cast<const sk_u4*>(x + r0 + 2 * t);         // vectors are padded to whole tiles
+    acc ^= xv.x ^ xv.w;
+    sk_u4 yv; yv.x = acc; yv.y = (unsigned)t; yv.z = 0u; yv.w = 1u;
+    __builtin_nontemporal_store(yv, reinterpret_cast<sk_u4*>(y + r0 + 2 * t));
+}
+}  // namespace kr
+
+extern "C" int32_t kryst_bench_csr_skeleton(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t reps, double* avg_ms) {
+    KR_ARG(a && x && y && avg_ms && reps >= 1, "bench_csr_skeleton");
+    KR_ARG(x->n == a->xlen && y->n == a->nrows && a->nrows == a->xlen && !a->dist, "bench_csr_skeleton: a square single-rank operator and vectors of its size");
+    KR_ARG(a->nrows >= 1 && a->d_row_ptr && a->d_col && a->d_val, "bench_csr_skeleton: the operator keeps no CSR arrays");
+    kryst_ctx_t ctx = a->ctx;
+    KR_HIP(hipSetDevice(ctx->device));
+    const int64_t nt = ntiles_of(a->nrows);
+    const bool nontemporal = a->nrows * 8 > (256ll << 20);                       // as spmv_wave_kernel: matrix streams bypass the caches beyond the Infinity Cache
+    auto once = [&] {
+        if (nontemporal) hipLaunchKernelGGL((csr_skeleton_kernel<true>), dim3((unsigned)nt), dim3(KR_T), 0, ctx->s_main, a->d_row_ptr, a->d_col, a->d_val, x->d, y->d, a->nrows, nt);
+        else hipLaunchKernelGGL((csr_skeleton_kernel<false>), dim3((unsigned)nt), dim3(KR_T), 0, ctx->s_main, a->d_row_ptr, a->d_col, a->d_val, x->d, y->d, a->nrows, nt);
+    };
+    once();
+    KR_HIP(hipGetLastError());
+    (void)hipEventRecord(ctx->tm0, ctx->s_main);
+    for (int r = 0; r < reps; ++r) once();
+    (void)hipEventRecord(ctx->tm1, ctx->s_main);
+    (void)hipEventSynchronize(ctx->tm1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ctx->tm0, ctx->tm1);
+    *avg_ms = (double)ms / reps;
+    KR_HIP(hipGetLastError());
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    return KRYST_OK;
+}

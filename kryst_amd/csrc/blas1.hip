@@ -66,14 +66,27 @@ struct SplitmixOp {                  // SURVEY 8d synthetic data
 // ---------------------------------------------------------------- final fold
 template <int NQ>
 __global__ __launch_bounds__(KR_F) void final_fold_kernel(const double* partials, int64_t stride, int64_t ntiles,
-                                                          double* chunks, int64_t cstride, unsigned int* ticket, double* out) {
+                                                          double* chunks, int64_t cstride, unsigned int* ticket, unsigned int* err, double* out) {
     __shared__ double lds[NQ * (KR_F / 64)];
     double v[NQ];
-    if (!fold2<NQ>(partials, stride, ntiles, chunks, cstride, ticket, v, lds)) return;
+    const int f = fold2<NQ>(partials, stride, ntiles, chunks, cstride, ticket, err, v, lds);
+    if (!f) return;
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) out[q] = v[q];
+        for (int q = 0; q < NQ; ++q) out[q] = f == 2 ? __longlong_as_double(0x7FF8000000000000ll) : v[q];      // (gave up: *err is raised, the host asks fold_gave_up)
     }
+}
+
+bool fold_gave_up(kryst_ctx_t ctx) {
+    unsigned int w = 0;
+    if (hipMemcpyAsync(&w, fold_err(ctx), sizeof w, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (!w) return false;
+    (void)hipMemsetAsync(fold_err(ctx), 0, sizeof w, ctx->s_main);
+    (void)hipStreamSynchronize(ctx->s_main);
+    ctx->fold_poll_off = true;
+    set_error("an inner product's two-level fold gave up waiting for a workgroup of its own launch (GPU shared, time-sliced or serialised by a "
+              "profiler for seconds); the result was discarded and this context now uses the ticket hand-off");
+    return true;
 }
 
 // A one-rank communicator normally skips RCCL; KRYST_FORCE_COMM=1 keeps the collective path (used by the
@@ -113,11 +126,11 @@ int32_t launch_dot_partials(kryst_ctx_t ctx, const double* x, const double* y, i
 int32_t launch_final_fold(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out) {
     KR_TRY(ensure_partials(ctx, ntiles > 0 ? ntiles : 1));
     switch (nq) {
-        case 1: hipLaunchKernelGGL(final_fold_kernel<1>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_out); break;
-        case 2: hipLaunchKernelGGL(final_fold_kernel<2>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_out); break;
-        case 3: hipLaunchKernelGGL(final_fold_kernel<3>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_out); break;
-        case 4: hipLaunchKernelGGL(final_fold_kernel<4>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_out); break;
-        case 8: hipLaunchKernelGGL(final_fold_kernel<8>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_out); break;
+        case 1: hipLaunchKernelGGL(final_fold_kernel<1>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), fold_err(ctx), d_out); break;
+        case 2: hipLaunchKernelGGL(final_fold_kernel<2>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), fold_err(ctx), d_out); break;
+        case 3: hipLaunchKernelGGL(final_fold_kernel<3>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), fold_err(ctx), d_out); break;
+        case 4: hipLaunchKernelGGL(final_fold_kernel<4>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), fold_err(ctx), d_out); break;
+        case 8: hipLaunchKernelGGL(final_fold_kernel<8>, dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main, ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), fold_err(ctx), d_out); break;
         default: set_error("final fold: nq=%d", nq); return KRYST_ERR_ARG;
     }
     KR_HIP(hipGetLastError());
@@ -213,6 +226,7 @@ int32_t kryst_dot(kryst_vec_t x, kryst_vec_t y, double* out) {
         KR_HIP(hipMemcpyAsync(ctx->h_pinned, slot, sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
         KR_HIP(hipStreamSynchronize(ctx->s_main));
         *out = ctx->h_pinned[0];
+        if (*out != *out && fold_gave_up(ctx)) return KRYST_ERR_HIP;
         return KRYST_OK;
     }
     // several ranks: local fold -> all-gather of one double per rank -> the result goes to the host anyway, so the rank-ordered
@@ -227,6 +241,7 @@ int32_t kryst_dot(kryst_vec_t x, kryst_vec_t y, double* out) {
     double total = ctx->h_pinned[0];
     for (int p = 1; p < ctx->nranks; ++p) total = total + ctx->h_pinned[p];
     *out = total;
+    if (total != total && fold_gave_up(ctx)) return KRYST_ERR_HIP;
     return KRYST_OK;
 }
 

@@ -17,7 +17,38 @@
 #define KR_F 1024           // threads of the final fold
 #define KR_MAXQ 8           // at most 8 fused reductions per kernel (FGMRES batches its Gram-Schmidt dots by 8)
 
+#include <atomic>
+
 namespace kr {
+
+// ---- tuning knobs from the environment.  Outside a solve every read is a getenv (a test or tool sets a knob and calls an entry
+// point: it takes effect at once).  INSIDE a solver's enqueue loop (EnvFreeze: a one-shot solve, or one kryst_session_step call) a
+// knob is read once and then served from its call site's slot -- an iteration used to cost ~30 scans of environ on the host's enqueue
+// path, and getenv races with a setenv from another host thread.  The epoch is bumped whenever a freeze begins, so a
+// tool that changes a knob between two session steps (tools/solver_ab.py) still sees it.
+struct EnvSlot { std::atomic<uint32_t> epoch{0}; std::atomic<int> has{0}; std::atomic<long long> val{0}; };
+extern std::atomic<uint32_t> g_env_epoch;        // ctx.cpp
+extern thread_local int g_env_frozen;
+inline long long env_ll_cached(EnvSlot& s, const char* name, long long dflt) {
+    if (g_env_frozen > 0) {
+        const uint32_t e = g_env_epoch.load(std::memory_order_relaxed);
+        if (s.epoch.load(std::memory_order_acquire) == e) return s.has.load(std::memory_order_relaxed) ? s.val.load(std::memory_order_relaxed) : dflt;
+        const char* v = getenv(name);
+        s.has.store(v ? 1 : 0, std::memory_order_relaxed); s.val.store(v ? atoll(v) : 0, std::memory_order_relaxed);
+        s.epoch.store(e, std::memory_order_release);
+        return v ? atoll(v) : dflt;
+    }
+    const char* v = getenv(name);
+    return v ? atoll(v) : dflt;
+}
+struct EnvFreeze {                               // RAII around a solver's enqueue loop
+    EnvFreeze() { if (g_env_frozen++ == 0) g_env_epoch.fetch_add(1, std::memory_order_relaxed); }
+    ~EnvFreeze() { --g_env_frozen; }
+    EnvFreeze(const EnvFreeze&) = delete; EnvFreeze& operator=(const EnvFreeze&) = delete;
+};
+// one slot per call site (the name must be a literal or otherwise fixed for the site)
+#define env_int(name, dflt) ([&]() -> int { static kr::EnvSlot slot__; return (int)kr::env_ll_cached(slot__, (name), (long long)(dflt)); }())
+#define env_ll(name, dflt) ([&]() -> long long { static kr::EnvSlot slot__; return kr::env_ll_cached(slot__, (name), (long long)(dflt)); }())
 
 void set_error(const char* fmt, ...);
 void set_error_row(int64_t row);      // the row of a KRYST_ZERO_PIVOT (KError::ZeroPivot(row), src/error.rs:15-16)
@@ -82,7 +113,8 @@ struct kryst_ctx_s {
     // reduction scratch: KR_MAXQ arrays of tile partials, sized on demand
     double* d_partials = nullptr; int64_t partials_cap = 0;     // doubles per array
     double* d_chunks = nullptr; int64_t chunks_cap = 0;         // stage-1 results of the two-level fold
-    unsigned int* d_ticket = nullptr;
+    unsigned int* d_ticket = nullptr;   // [0]: ticket of the two-level fold, [8]: error word of its polling form (fold_err)
+    bool fold_poll_off = false;         // a polling hand-off timed out on this context: ticket form from now on
     double* d_scal = nullptr;        // small scalar arena (device), 4096 doubles
     double* d_gather = nullptr;      // nranks * KR_MAXQ doubles (all-gather target)
     kr::HostProgress* h_prog = nullptr; kr::HostProgress* d_prog = nullptr;   // mapped
@@ -212,40 +244,52 @@ __device__ __forceinline__ void block_reduce_any(double (&v)[NQ], double* lds) {
 // fold.  Two dependent round trips less than store -> acknowledge -> ticket atomic -> load (5.8 -> ~4 us per fold at 256^3, where an
 // iteration has two to thirty-one of them).  Both forms leave the cells armed, so they can alternate.
 #define KR_FOLD_UNSET 0x7FF8F01DF01DF01Dull
+// A polling hand-off whose patience runs out (seconds: the GPU is shared, time-sliced or serialised by a profiler) raises *err (it stays
+// raised) instead of folding the payload as if it were a value: the consumers end the solve with KRYST_ERR_HIP, and the host switches the
+// context to the ticket form, whose cells are written before they are read (a late store of the abandoned fold cannot be mistaken for a
+// value there).
 template <int NQ>
-__device__ __forceinline__ bool fold2(const double* partials, int64_t stride, int64_t ntiles, double* chunks,
-                                      int64_t cstride, unsigned int* ticket, double (&out)[NQ], double* lds) {
-    __shared__ int is_last;
+__device__ __forceinline__ int fold2(const double* partials, int64_t stride, int64_t ntiles, double* chunks,
+                                     int64_t cstride, unsigned int* ticket, unsigned int* err, double (&out)[NQ], double* lds) {
+    // returns 0 in a workgroup that does not hold the result, 1 in the one that does (valid in every thread), 2 there when the polling
+    // hand-off gave up (no result; *err is raised)
+    __shared__ int is_last, gave_up;
     const int64_t i = (int64_t)blockIdx.x * KR_F + threadIdx.x;
+    if (threadIdx.x == 0) gave_up = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) out[q] = (i < ntiles) ? partials[q * stride + i] : 0.0;
     block_reduce_any<NQ, KR_F / 64>(out, lds);
-    if (gridDim.x == 1) return true;
+    if (gridDim.x == 1) return 1;
     const double unset = __longlong_as_double((long long)KR_FOLD_UNSET);
     if (ticket == nullptr) {
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) __hip_atomic_store(&chunks[q * cstride + blockIdx.x], out[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (blockIdx.x != 0) return false;
+        if (blockIdx.x != 0) return 0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             double acc = 0.0;
             for (int64_t j = threadIdx.x; j < (int64_t)gridDim.x; j += KR_F) {
                 double v = __hip_atomic_load(&chunks[q * cstride + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // (the other workgroups may still be waiting for a free slot behind another stream's kernel: patience of seconds, short naps
-                // first; a budget that runs out leaves the payload itself -- a NaN result, not a hung GPU)
+                // first)
                 for (int budget = 1 << 22; (unsigned long long)__double_as_longlong(v) == KR_FOLD_UNSET && budget > 0; --budget) {
                     if (budget > (1 << 22) - 4096) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(64);
                     v = __hip_atomic_load(&chunks[q * cstride + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if ((unsigned long long)__double_as_longlong(v) == KR_FOLD_UNSET) {      // never delivered: no value, and nothing to arm again
+                    gave_up = 1;
+                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    continue;
                 }
                 acc = acc + v;
                 chunks[q * cstride + j] = unset;                  // armed again for the next (stream-ordered) fold
             }
             out[q] = acc;
         }
-        block_reduce_any<NQ, KR_F / 64>(out, lds);
-        return true;
+        block_reduce_any<NQ, KR_F / 64>(out, lds);               // (its barriers also order the gave_up stores in front of the read below)
+        return gave_up ? 2 : 1;
     }
     if (threadIdx.x == 0) {
 #pragma unroll
@@ -258,7 +302,7 @@ __device__ __forceinline__ bool fold2(const double* partials, int64_t stride, in
         is_last = (t == gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
-    if (!is_last) return false;
+    if (!is_last) return 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         double acc = 0.0;
@@ -270,16 +314,22 @@ __device__ __forceinline__ bool fold2(const double* partials, int64_t stride, in
     }
     block_reduce_any<NQ, KR_F / 64>(out, lds);
     if (threadIdx.x == 0) *ticket = 0u;            // ready for the next (stream-ordered) fold
-    return true;
+    return 1;
 }
 #endif
 
 // ---- launchers implemented in blas1.hip / spmv.hip / precond.hip (all enqueue on ctx->s_main) ----
 // the ticket of the two-level fold, or nullptr for the polling hand-off (fold2; KRYST_FOLD_POLL, read per launch)
-inline unsigned int* fold_ticket(kryst_ctx_t ctx) { const char* e = getenv("KRYST_FOLD_POLL"); return (e && atoi(e) == 0) ? ctx->d_ticket : nullptr; }
+// (after a polling hand-off has timed out once -- fold_err, below -- the context keeps the ticket form: its cells are written before they are read)
+inline unsigned int* fold_ticket(kryst_ctx_t ctx) { return (ctx->fold_poll_off || env_int("KRYST_FOLD_POLL", 1) == 0) ? ctx->d_ticket : nullptr; }
+// the error word of the polling hand-off: set by the device when workgroup 0's patience ran out (a time-sliced or profiled GPU)
+inline unsigned int* fold_err(kryst_ctx_t ctx) { return ctx->d_ticket + 8; }
 int32_t launch_dot_partials(kryst_ctx_t ctx, const double* x, const double* y, int64_t n, int slot);
 // local result of up to nq partial arrays -> d_out[0..nq) (device), single rank: the final value
 int32_t launch_final_fold(kryst_ctx_t ctx, int nq, int64_t ntiles, double* d_out);
+// reads and clears the polling hand-off's error word; when it was raised: sets the error text, switches the context to the ticket form
+// and returns true (blas1.hip)
+bool fold_gave_up(kryst_ctx_t ctx);
 int32_t vec_check2(kryst_vec_t a, kryst_vec_t b);
 bool use_collectives(kryst_ctx_t ctx);
 

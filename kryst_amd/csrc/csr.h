@@ -51,6 +51,8 @@ struct kryst_csr_s {
     int64_t interior_first = -1;    // >= 0: the interior tiles are the contiguous range [interior_first, interior_first + n_interior)
     int32_t* d_tiles_boundary = nullptr; int64_t n_boundary = 0;
     bool send_contiguous = false;   // every send list is a contiguous run of local rows (k-slab stencils)
+    bool halo_early_ok = false;     // ... on EVERY rank (agreed at creation): the solvers may start the exchange of a new direction vector
+                                    // behind the pass that writes it -- a per-iteration exchange that all ranks issue or none does
     const double* halo_started_for = nullptr;   // the halo exchange of this input vector is already in flight (halo_begin: a solver started it early)
 };
 
@@ -58,7 +60,6 @@ namespace kr {
 
 constexpr int KR_PMAX = 512;        // CSR-P16 limits: patterns and (padded) table entries held in LDS: 2 + 12 + 24 KiB at most
 constexpr int KR_TMAX = 2048;
-inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 // y <- A x on ctx->s_main.  nq = 0: plain.  nq = 1: also tile partials of sum d[i]*y[i] into partial array 0.
 // nq = 2: additionally sum y[i]*y[i] into partial array 1.  `done` (device flag) makes the launch a no-op when set.

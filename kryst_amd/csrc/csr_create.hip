@@ -565,12 +565,11 @@ static int32_t create_dist_exchange(kryst_csr_t a) {
 
 // All ranks learn whether any of them failed so far (one all-gather of the status words): 0 if none did, else this rank's own
 // code, or KRYST_ERR_ARG with a message naming the first failed rank.
-static int32_t agree_on_status(kryst_ctx_t ctx, int32_t rc_mine) {
+// one int64 from every rank (all[p] = rank p's word); collective
+static int32_t all_gather_word(kryst_ctx_t ctx, int64_t mine, std::vector<int64_t>& all) {
     const int P = ctx->nranks;
-    if (P == 1) return rc_mine;
+    all.assign((size_t)P, 0);
     int64_t *d_s = nullptr, *d_r = nullptr;
-    std::vector<int64_t> all((size_t)P, 0);
-    const int64_t mine = rc_mine;
     int32_t rc = KRYST_OK;
     if (hipMalloc(&d_s, sizeof(int64_t)) != hipSuccess || hipMalloc(&d_r, sizeof(int64_t) * P) != hipSuccess) rc = KRYST_ERR_HIP;
     if (rc == KRYST_OK) rc = h2d(ctx, d_s, &mine, sizeof(int64_t));
@@ -578,6 +577,14 @@ static int32_t agree_on_status(kryst_ctx_t ctx, int32_t rc_mine) {
     if (rc == KRYST_OK && (hipMemcpyAsync(all.data(), d_r, sizeof(int64_t) * P, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess ||
                            hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
     (void)hipFree(d_s); (void)hipFree(d_r);
+    return rc;
+}
+
+static int32_t agree_on_status(kryst_ctx_t ctx, int32_t rc_mine) {
+    const int P = ctx->nranks;
+    if (P == 1) return rc_mine;
+    std::vector<int64_t> all;
+    const int32_t rc = all_gather_word(ctx, rc_mine, all);
     if (rc != KRYST_OK) return rc_mine != KRYST_OK ? rc_mine : rc;
     if (rc_mine != KRYST_OK) return rc_mine;
     for (int p = 0; p < P; ++p)
@@ -601,6 +608,16 @@ int32_t kryst_csr_create_dist(kryst_ctx_t ctx, int64_t n_global, const int64_t* 
     }
     rc = agree_on_status(ctx, rc);
     if (rc == KRYST_OK) rc = agree_on_status(ctx, create_dist_exchange(a));
+    if (rc == KRYST_OK) {
+        // An exchange of the solvers' direction vector that is started early (solvers.hip: launch_direction) adds one exchange per
+        // iteration on the rank that starts it: EVERY rank must take that decision alike, so it is taken here, once, from what all ranks
+        // report (send lists that are contiguous runs on every rank), never from a rank's own tile counts.
+        std::vector<int64_t> all;
+        rc = ctx->nranks > 1 ? all_gather_word(ctx, a->send_contiguous ? 1 : 0, all) : KRYST_OK;
+        bool every = a->send_contiguous;
+        for (int64_t v : all) every = every && v == 1;
+        a->halo_early_ok = rc == KRYST_OK && every;
+    }
     if (rc != KRYST_OK) { if (a) kryst_csr_destroy(a); return rc; }
     *out = a;
     return KRYST_OK;
@@ -780,6 +797,7 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
         pl.total_recv = (has_lower ? N2 : 0) + (has_upper ? N2 : 0);
         pl.total_send = pl.total_recv;
         a->send_contiguous = true;                      // send_off = first local row of each run
+        a->halo_early_ok = true;                        // ... on every rank of a k-slab partition (analytic plan: nothing to agree on)
         std::vector<int32_t> ti, tb;
         for (int64_t q = 0; q < a->ntiles; ++q) {
             const int64_t r0 = q * KR_TILE, r1 = std::min<int64_t>(r0 + KR_TILE, nloc);

@@ -3,6 +3,8 @@
 #include <cstdarg>
 
 namespace kr {
+std::atomic<uint32_t> g_env_epoch{1};
+thread_local int g_env_frozen = 0;
 static thread_local char g_err[1024] = "";
 static thread_local int64_t g_err_row = -1;
 void set_error_row(int64_t row) { g_err_row = row; }
@@ -31,7 +33,10 @@ static int32_t ctx_init(kryst_ctx_t ctx) {
         set_error("no HIP device available: libkryst_hip has no CPU fallback");
         return KRYST_ERR_HIP;
     }
-    KR_ARG(ctx->device >= 0 && ctx->device < count, "device id out of range");
+    if (!(ctx->device >= 0 && ctx->device < count)) {
+        set_error("bad argument: device id %d out of range (this process sees %d HIP device(s))", ctx->device, count);
+        return KRYST_ERR_ARG;
+    }
     KR_HIP(hipSetDevice(ctx->device));
     hipDeviceProp_t prop;
     KR_HIP(hipGetDeviceProperties(&prop, ctx->device));
@@ -66,6 +71,14 @@ void kryst_reduce_spec(int32_t* T, int32_t* V, int32_t* F) {
     if (T) *T = KR_T;
     if (V) *V = KR_V;
     if (F) *F = KR_F;
+}
+
+int32_t kryst_device_count(int32_t* count) {
+    KR_ARG(count, "device_count: out");
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); c = 0; }
+    *count = c;
+    return KRYST_OK;
 }
 
 int32_t kryst_ctx_create(int32_t device_id, kryst_ctx_t* out) {

@@ -3,6 +3,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <algorithm>
+#include <mutex>
+#include <unistd.h>
 
 namespace kr {
 
@@ -22,7 +24,9 @@ static Rccl g_rccl;
 
 struct Comm { ncclComm_t comm = nullptr; };
 
+static std::mutex g_rccl_mutex;             // several ranks of one process (one host thread each) may create their contexts at once
 static int32_t rccl_load() {
+    const std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.lib) return KRYST_OK;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
@@ -118,52 +122,58 @@ void ipc_reduce_destroy(kryst_ctx_t ctx) {
     (void)hipGetLastError();
 }
 
-int32_t ipc_reduce_setup(kryst_ctx_t ctx) {
-    if (ctx->ipc_on) return KRYST_OK;
-    if (ctx->ipc_mine) { ctx->ipc_on = true; return KRYST_OK; }      // set up before and switched off: the mailboxes are still mapped on every rank,
-                                                                     // and every rank has counted the same epochs
-    KR_ARG(ctx->comm, "ipc_reduce_setup: context has no communicator");
+// Map one allocation of every rank into this process: `mine` (device memory of this rank, fine-grained when peers write it with
+// system-scope stores) is exported, the handles travel in one all-gather, and peers[p] receives rank p's allocation as THIS process
+// addresses it (own entry: mine).  A peer that lives in this very process (several ranks of one process, one host thread each) is
+// addressed directly -- hipIpcOpenMemHandle refuses a handle of its own process -- after peer access to its device has been enabled.
+// Collective; the outcome is agreed: KRYST_OK on every rank, or KRYST_UNSUPPORTED (nothing left mapped) on every rank.
+int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, std::vector<void*>& opened) {
+    KR_ARG(ctx->comm, "ipc_map_peers: context has no communicator");
     const int P = ctx->nranks, me = ctx->rank;
-    KR_ARG(P <= 64, "ipc_reduce_setup: at most 64 ranks (one lane per peer)");
-    const size_t cells = (size_t)2 * P * 16;
-    // phase 1 (local): mailbox in fine-grained device memory (coherent for the peers' system-scope stores), zeroed, and its IPC handle
-    int64_t ok_mine = 1;
+    constexpr int W = 12;                      // words per rank: ok, pid, device, address, handle[8]
+    int64_t send[W] = {0};
     hipIpcMemHandle_t hmine;
     memset(&hmine, 0, sizeof hmine);
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
-    if (hipExtMallocWithFlags((void**)&ctx->ipc_mine, sizeof(double) * cells, hipDeviceMallocFinegrained) != hipSuccess ||
-        hipMemsetAsync(ctx->ipc_mine, 0, sizeof(double) * cells, ctx->s_main) != hipSuccess ||
-        hipMalloc(&ctx->d_ipc_peers, sizeof(double*) * P) != hipSuccess || hipMalloc(&ctx->d_ipc_epoch, 8) != hipSuccess ||
-        hipMemsetAsync(ctx->d_ipc_epoch, 0, 8, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess ||
-        hipIpcGetMemHandle(&hmine, ctx->ipc_mine) != hipSuccess) { (void)hipGetLastError(); ok_mine = 0; }
-    // phase 2 (collective): all-gather {ok, handle} = 9 int64 per rank
-    int64_t send[9]; send[0] = ok_mine; memcpy(send + 1, &hmine, 64);
-    std::vector<int64_t> all((size_t)9 * P, 0);
+    int64_t ok_mine = mine != nullptr ? 1 : 0;
+    if (ok_mine && hipIpcGetMemHandle(&hmine, mine) != hipSuccess) { (void)hipGetLastError(); ok_mine = 0; }
+    send[0] = ok_mine; send[1] = (int64_t)getpid(); send[2] = ctx->device; send[3] = (int64_t)(uintptr_t)mine; memcpy(send + 4, &hmine, 64);
+    std::vector<int64_t> all((size_t)W * P, 0);
     int64_t *d_s = nullptr, *d_r = nullptr;
     int32_t rc = KRYST_OK;
-    if (hipMalloc(&d_s, sizeof send) != hipSuccess || hipMalloc(&d_r, sizeof(int64_t) * 9 * P) != hipSuccess) rc = KRYST_ERR_HIP;
+    if (hipMalloc(&d_s, sizeof send) != hipSuccess || hipMalloc(&d_r, sizeof(int64_t) * W * P) != hipSuccess) rc = KRYST_ERR_HIP;
     if (rc == KRYST_OK && (hipMemcpyAsync(d_s, send, sizeof send, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
-    if (rc == KRYST_OK) rc = comm_all_gather_i64(ctx, d_s, d_r, 9, ctx->s_main);
-    if (rc == KRYST_OK && (hipMemcpyAsync(all.data(), d_r, sizeof(int64_t) * 9 * P, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess ||
+    if (rc == KRYST_OK) rc = comm_all_gather_i64(ctx, d_s, d_r, W, ctx->s_main);
+    if (rc == KRYST_OK && (hipMemcpyAsync(all.data(), d_r, sizeof(int64_t) * W * P, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess ||
                            hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
     (void)hipFree(d_s); (void)hipFree(d_r);
-    if (rc != KRYST_OK) { ipc_reduce_destroy(ctx); return rc; }      // (a failing collective fails on every rank)
-    // phase 3 (local): map the peers' mailboxes; phase 4 (collective): everybody mapped everybody?
+    if (rc != KRYST_OK) return rc;                                   // (a failing collective fails on every rank)
     int64_t ok_all = 1;
-    for (int p = 0; p < P; ++p) ok_all = ok_all && all[(size_t)9 * p] == 1;
-    std::vector<double*> peers((size_t)P, nullptr);
-    if (ok_all) {
-        for (int p = 0; p < P && ok_all; ++p) {
-            if (p == me) { peers[p] = ctx->ipc_mine; continue; }
-            hipIpcMemHandle_t h; memcpy(&h, &all[(size_t)9 * p + 1], 64);
-            void* ptr = nullptr;
-            if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok_all = 0; break; }
-            ctx->ipc_opened.push_back(ptr);
-            peers[p] = static_cast<double*>(ptr);
+    for (int p = 0; p < P; ++p) ok_all = ok_all && all[(size_t)W * p] == 1;
+    peers.assign((size_t)P, nullptr);
+    const size_t opened_before = opened.size();
+    for (int p = 0; p < P && ok_all; ++p) {
+        const int64_t* w = &all[(size_t)W * p];
+        if (p == me) { peers[p] = mine; continue; }
+        if (w[1] == (int64_t)getpid()) {                             // a rank of this process: same address space
+            const int pdev = (int)w[2];
+            if (pdev != ctx->device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, ctx->device, pdev) != hipSuccess || !can) { (void)hipGetLastError(); ok_all = 0; break; }
+                const hipError_t e = hipDeviceEnablePeerAccess(pdev, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { ok_all = 0; }
+                (void)hipGetLastError();
+            }
+            peers[p] = reinterpret_cast<void*>((uintptr_t)w[3]);
+            continue;
         }
-        if (ok_all && (hipMemcpyAsync(ctx->d_ipc_peers, peers.data(), sizeof(double*) * P, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess ||
-                       hipStreamSynchronize(ctx->s_main) != hipSuccess)) ok_all = 0;
+        hipIpcMemHandle_t h; memcpy(&h, w + 4, 64);
+        void* ptr = nullptr;
+        if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok_all = 0; break; }
+        opened.push_back(ptr);
+        peers[p] = ptr;
     }
+    // everybody mapped everybody?
     int64_t *d_s2 = nullptr, *d_r2 = nullptr;
     std::vector<int64_t> all2((size_t)P, 0);
     if (hipMalloc(&d_s2, 8) != hipSuccess || hipMalloc(&d_r2, sizeof(int64_t) * P) != hipSuccess) rc = KRYST_ERR_HIP;
@@ -175,11 +185,38 @@ int32_t ipc_reduce_setup(kryst_ctx_t ctx) {
     bool everybody = rc == KRYST_OK;
     for (int p = 0; p < P && everybody; ++p) everybody = all2[p] == 1;
     if (!everybody) {
-        ipc_reduce_destroy(ctx);
+        while (opened.size() > opened_before) { (void)hipIpcCloseMemHandle(opened.back()); opened.pop_back(); }
+        (void)hipGetLastError();
+        peers.assign((size_t)P, nullptr);
         if (rc != KRYST_OK) return rc;
-        set_error("ipc scalar all-reduce: a rank could not allocate, export or map a mailbox (hipIpc); the RCCL path stays in use");
+        set_error("hipIpc: a rank could not allocate, export or map a peer's buffer; the RCCL path stays in use");
         return KRYST_UNSUPPORTED;
     }
+    return KRYST_OK;
+}
+
+int32_t ipc_reduce_setup(kryst_ctx_t ctx) {
+    if (ctx->ipc_on) return KRYST_OK;
+    if (ctx->ipc_mine) { ctx->ipc_on = true; return KRYST_OK; }      // set up before and switched off: the mailboxes are still mapped on every rank,
+                                                                     // and every rank has counted the same epochs
+    KR_ARG(ctx->comm, "ipc_reduce_setup: context has no communicator");
+    const int P = ctx->nranks;
+    KR_ARG(P <= 64, "ipc_reduce_setup: at most 64 ranks (one lane per peer)");
+    const size_t cells = (size_t)2 * P * 16;
+    // local: mailbox in fine-grained device memory (coherent for the peers' system-scope stores), zeroed; a rank that fails here still
+    // takes part in the collective mapping below, which then fails on every rank alike
+    if (hipExtMallocWithFlags((void**)&ctx->ipc_mine, sizeof(double) * cells, hipDeviceMallocFinegrained) != hipSuccess ||
+        hipMemsetAsync(ctx->ipc_mine, 0, sizeof(double) * cells, ctx->s_main) != hipSuccess ||
+        hipMalloc(&ctx->d_ipc_peers, sizeof(double*) * P) != hipSuccess || hipMalloc(&ctx->d_ipc_epoch, 8) != hipSuccess ||
+        hipMemsetAsync(ctx->d_ipc_epoch, 0, 8, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(ctx->ipc_mine); ctx->ipc_mine = nullptr;
+    }
+    std::vector<void*> peers;
+    int32_t rc = ipc_map_peers(ctx, ctx->ipc_mine, peers, ctx->ipc_opened);
+    if (rc == KRYST_OK && (hipMemcpyAsync(ctx->d_ipc_peers, peers.data(), sizeof(double*) * P, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess ||
+                           hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;      // (cannot fail on one rank alone in practice: an 8 P byte copy)
+    if (rc != KRYST_OK) { ipc_reduce_destroy(ctx); return rc; }
     ctx->ipc_on = true;
     return KRYST_OK;
 }

@@ -20,6 +20,9 @@ int32_t comm_exchange(kryst_ctx_t ctx, const void* send, const int64_t* send_cou
 // Mailbox path of the scalar all-reduce (see kryst_ctx_s): collective over the context's ranks (one all-gather of the IPC
 // handles).  On success ctx->ipc_on is set on EVERY rank, or on none (the outcome is agreed through an all-gather).
 int32_t ipc_reduce_setup(kryst_ctx_t ctx);
+// one allocation of every rank mapped into this process (hipIpc between processes, directly between ranks of one process); collective,
+// agreed outcome (KRYST_OK everywhere or KRYST_UNSUPPORTED everywhere); `opened` collects the mappings to close with hipIpcCloseMemHandle
+int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, std::vector<void*>& opened);
 void    ipc_reduce_destroy(kryst_ctx_t ctx);
 
 // Halo plan of a row-partitioned operator (host side; also exported as kryst_host_halo_recv_plan)

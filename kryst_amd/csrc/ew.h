@@ -108,14 +108,11 @@ inline int32_t launch_ew_gated(kryst_ctx_t ctx, const Op& op, int64_t n, const G
     // 4.7-4.9 TB/s (a narrower moving window keeps DRAM pages open); CG at 512^3: +4 %.  Pure read streams with a
     // reduction per tile (dots) are the exception: they need 4 per CU to overlap loads with the butterfly (rocprofv3,
     // 9 streams of 128 MiB: 420 us at 2 per CU, 250 us at 4).
-    if (bpc <= 0) {
-        const char* e_bpc = getenv("KRYST_EW_BLOCKS_PER_CU");        // tuning knob (read per launch)
-        bpc = e_bpc ? atoi(e_bpc) : ew_bpc<Op>::value;
-    }
+    if (bpc <= 0) bpc = env_int("KRYST_EW_BLOCKS_PER_CU", ew_bpc<Op>::value);      // tuning knobs: read per launch outside a solve, once per solve / session step inside
     if (const char* tag = ew_tag<Op>::get()) {
-        char name[64];
-        snprintf(name, sizeof name, "KRYST_BPC_%s", tag);
-        if (const char* e_tag = getenv(name)) bpc = std::max(1, atoi(e_tag));
+        static const std::string name = std::string("KRYST_BPC_") + tag;          // (one name, and one slot, per op type)
+        const int t = env_int(name.c_str(), 0);
+        if (t > 0) bpc = t;
     }
     const int64_t grid = std::min<int64_t>(ntiles, (int64_t)ctx->num_cu * bpc);
     hipLaunchKernelGGL((ew_kernel<Op, Gate>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, gate, n, tile_lo, tile_hi,

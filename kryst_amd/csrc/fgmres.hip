@@ -263,6 +263,7 @@ static int32_t axpy_batch(kryst_ctx_t ctx, int64_t n, const FgPtrs& P, const Dev
 }
 
 int32_t fgmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, int32_t orthog, double haptol, int32_t preallocate) {
+    const EnvFreeze knobs;                    // the tuning knobs are read once per solve, not per launch
     KR_ARG(io.a && io.params && bv && xv, "solve: null argument");
     const kryst_params_t* p = io.params;
     kryst_csr_t a = io.a; kryst_ctx_t ctx = a->ctx; const int64_t n = a->nrows, nt = ntiles_of(n);

@@ -198,6 +198,7 @@ static int32_t logic_only(kryst_ctx_t ctx, const double* red, const L& l) {
 }
 
 int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
+    const EnvFreeze knobs;                    // the tuning knobs are read once per solve, not per launch
     KR_ARG(io.a && io.params && bv && xv, "solve: null argument");
     const kryst_params_t* p = io.params;
     kryst_csr_t a = io.a; kryst_ctx_t ctx = a->ctx; const int64_t n = a->nrows, nt = ntiles_of(n);

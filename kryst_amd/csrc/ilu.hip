@@ -42,7 +42,6 @@ static void par_rows(int64_t n, F body) {
     }
     for (auto& t : th) t.join();
 }
-static int env_i(const char* nm, int d) { const char* e = getenv(nm); return e ? atoi(e) : d; }
 // wavefront kernel by number of 8 x 8 line blocks in the (j, k) plane: the 16 x 16 kernel from 32^3 up (table at its use)
 static int default_wave_form(unsigned nb8) { return nb8 >= 16 ? 2 : 1; }
 
@@ -543,7 +542,7 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
         if (F.ell) hipLaunchKernelGGL((tri_syncfree_ell_kernel<FORWARD>), grid, dim3(256), 0, s, d_args, in, out, F.view(), F.d_diag, (int32_t)F.npos);
         // (Ilup(1) on a 7-point operator, 6 entries per row: 7.3 -> 5.9 ms per apply with 8 held, 6.3 with 16; a 27-point factor, 13 per
         // row: 9.8 -> 9.4 with 8, 6.9 with 16)
-        else if (env_i("KRYST_ILU_CSR_HELD", F.held) <= 8) hipLaunchKernelGGL((tri_syncfree_csr_kernel<FORWARD, 8>), grid, dim3(256), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val, F.d_diag,
+        else if (env_int("KRYST_ILU_CSR_HELD", F.held) <= 8) hipLaunchKernelGGL((tri_syncfree_csr_kernel<FORWARD, 8>), grid, dim3(256), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val, F.d_diag,
                                 (int32_t)F.npos);
         else hipLaunchKernelGGL((tri_syncfree_csr_kernel<FORWARD, 16>), grid, dim3(256), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val, F.d_diag,
                                 (int32_t)F.npos);
@@ -557,7 +556,7 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
         if (rows <= NARROW && !F.ell) {
             int l1 = lv + 1;
             while (l1 < nl && F.lvl_off[l1 + 1] - F.lvl_off[l1] <= NARROW) ++l1;
-            if (env_i("KRYST_ILU_RUN_PIPE", 1) != 0)
+            if (env_int("KRYST_ILU_RUN_PIPE", 1) != 0)
                 hipLaunchKernelGGL((tri_run_pipe_kernel<FORWARD, 8>), dim3(1), dim3(1024), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
                                    F.d_diag, F.d_lvl_off, lv, l1);
             else
@@ -658,7 +657,7 @@ int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done
     IluData* D = reinterpret_cast<IluData*>(pc->d_work);
     kryst_ctx_t ctx = pc->ctx;
     if (D->n == 0) return KRYST_OK;
-    if (takes_quad_form(D) && env_i("KRYST_ILU_GRAPH", 0) == 0 && env_i("KRYST_ILU_DIRECT_ARGS", 1) != 0) {
+    if (takes_quad_form(D) && env_int("KRYST_ILU_GRAPH", 0) == 0 && env_int("KRYST_ILU_DIRECT_ARGS", 1) != 0) {
         // launched directly: the caller's vectors, the `done` flag and the apply's number travel as kernel arguments (tri_quad.h: TriDirect)
         D->direct_epoch = (D->direct_epoch & 0x3fffffff) + 1;
         const TriDirect dir{r, z, done, (int32_t)(0x40000000u | (uint32_t)D->direct_epoch)};
@@ -668,8 +667,8 @@ int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done
     KR_HIP(hipGetLastError());
     // a hipGraph pays where an apply is MANY launches (one per dependency level / hyperplane); the wavefront and the sync-free forms are
     // three to five launches, and launching them directly is 0.6 % (256^3) to 1.9 % (128^3) of a BiCGStab + ILU(0) iteration faster
-    const bool few_launches = !D->safe && env_i("KRYST_ILU_PLANES", 0) == 0 && ((D->GL.ok && D->GU.ok) || (D->L.syncfree && D->U.syncfree));
-    const int use_graph = env_i("KRYST_ILU_GRAPH", few_launches ? 0 : 1);        // (read per apply: tools/solver_ab.py)
+    const bool few_launches = !D->safe && env_int("KRYST_ILU_PLANES", 0) == 0 && ((D->GL.ok && D->GU.ok) || (D->L.syncfree && D->U.syncfree));
+    const int use_graph = env_int("KRYST_ILU_GRAPH", few_launches ? 0 : 1);        // (read per apply: tools/solver_ab.py)
     if (!D->exec && use_graph) {
         // capture the launch sequence once; the graph only refers to the device argument block
         hipGraph_t g = nullptr;
@@ -800,7 +799,7 @@ static int32_t build_factor(int64_t n, const FlatRows& ent, const std::vector<do
     // random band matrix with 10 716 levels of 187 rows: 127 -> 72 ms; a 27-point factor with 1 328 rows per level: 9.9 ms sync-free,
     // 13.0 ms otherwise).  KRYST_ILU_SYNCFREE = 0 / 1 forces either form.
     const double rows_per_level = nl > 0 ? (double)n / (double)nl : 0.0;
-    F->syncfree = env_i("KRYST_ILU_SYNCFREE", (F->ell || rows_per_level >= 512.0) ? 1 : 0) != 0;
+    F->syncfree = env_int("KRYST_ILU_SYNCFREE", (F->ell || rows_per_level >= 512.0) ? 1 : 0) != 0;
     {
         int64_t longest = 0;
         for (int64_t p = 0; p < n; ++p) longest = std::max<int64_t>(longest, ptr[p + 1] - ptr[p]);
@@ -813,7 +812,7 @@ static int32_t build_factor(int64_t n, const FlatRows& ent, const std::vector<do
 
 // Recognise a structured-grid factor and lay it out for tri_grid_kernel.  Not an error when it does not apply.
 static int32_t build_grid(int64_t n, const FlatRows& ent, const std::vector<double>& diag, bool forward, GridFactor* G) {
-    if (n < 2 || n >= (1ll << 31) || env_i("KRYST_ILU_GRID", 1) == 0) return KRYST_OK;
+    if (n < 2 || n >= (1ll << 31) || env_int("KRYST_ILU_GRID", 1) == 0) return KRYST_OK;
     int64_t offs[3] = {0, 0, 0}; int no = 0;                              // distinct |col - row|, at most three
     {
         std::atomic<bool> reject{false};
@@ -905,7 +904,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
         if (rc == KRYST_OK && (hipHostMalloc((void**)&D->h_gave_up, 64, hipHostMallocMapped) != hipSuccess ||
                                hipHostGetDevicePointer((void**)&D->d_gave_up, D->h_gave_up, 0) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = KRYST_ERR_HIP; }
         if (rc == KRYST_OK) *D->h_gave_up = 0;
-        if (rc == KRYST_OK && D->GL.Ni >= 2 && env_i("KRYST_ILU_WAVE", default_wave_form(nb)) >= 2) {
+        if (rc == KRYST_OK && D->GL.Ni >= 2 && env_int("KRYST_ILU_WAVE", default_wave_form(nb)) >= 2) {
             // blocked coefficient layout + edge buffers of the 16 x 16 kernel (tri_quad.h), one device pass per factor
             for (GridFactor* G : {&D->GL, &D->GU}) {
                 if (rc != KRYST_OK) break;
@@ -932,7 +931,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
                 // edge buffers armed once (sentinels; zeros past the last step): between applies the pollers re-arm what they consume
                 hipLaunchKernelGGL(tri_quad_fill_kernel, dim3(std::min<unsigned>(1024u, (unsigned)nq * 4u)), dim3(256), 0, ctx->s_main, G->d_edge_e, G->d_edge_n, (int)nq, G->nch, (int32_t*)nullptr, 0);
                 // which chunks repeat chunk - 3 bit for bit (their coefficients are in the solving wave's registers already)
-                if (env_i("KRYST_ILU_DEDUP", 1) && G->nch + 3 <= TQ_SKIPMAX) {
+                if (env_int("KRYST_ILU_DEDUP", 1) && G->nch + 3 <= TQ_SKIPMAX) {
                     if (hipMalloc(&G->d_skip, nq * 4 * (size_t)G->nch) != hipSuccess) { (void)hipGetLastError(); G->d_skip = nullptr; }      // (flags are optional)
                     else if (fwd) hipLaunchKernelGGL((tri_quad_dedup_kernel<3>), dim3(lg), dim3(256), 0, ctx->s_main, (const tw_v2*)G->d_blocked, G->nch, G->d_skip);
                     else hipLaunchKernelGGL((tri_quad_dedup_kernel<4>), dim3(lg), dim3(256), 0, ctx->s_main, (const tw_v2*)G->d_blocked, G->nch, G->d_skip);
@@ -1096,7 +1095,7 @@ static int32_t grid_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out) {
     *out = nullptr;
     kryst_ctx_t ctx = a->ctx;
     const int64_t n = a->nrows;
-    if (a->dist || !a->d_dict || !a->d_code || n < 27 || n >= (1ll << 31) || env_i("KRYST_ILU_GRID", 1) == 0 || env_i("KRYST_ILU_DEVICE_SETUP", 1) == 0)
+    if (a->dist || !a->d_dict || !a->d_code || n < 27 || n >= (1ll << 31) || env_int("KRYST_ILU_GRID", 1) == 0 || env_int("KRYST_ILU_DEVICE_SETUP", 1) == 0)
         return KRYST_OK;
     int32_t dict[256], used[256];
     {
@@ -1277,7 +1276,7 @@ static int32_t ikj_on_device(kryst_csr_t a, const std::vector<int64_t>& rp, cons
     *used = false; *bad_row = -1;
     kryst_ctx_t ctx = a->ctx;
     const int64_t n = a->nrows, nnz = a->nnz;
-    if (n == 0 || nnz == 0 || n >= (1ll << 31) - 4 || env_i("KRYST_ILU_DEVICE_SETUP", 1) == 0) return KRYST_OK;
+    if (n == 0 || nnz == 0 || n >= (1ll << 31) - 4 || env_int("KRYST_ILU_DEVICE_SETUP", 1) == 0) return KRYST_OK;
     for (int64_t i = 0; i < n; ++i) if (rp[i + 1] - rp[i] > 64) return KRYST_OK;       // (a row must fit one wave's LDS slice)
     const bool verbose = getenv("KRYST_ILU_VERBOSE") != nullptr;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
@@ -1311,7 +1310,7 @@ static int32_t ikj_on_device(kryst_csr_t a, const std::vector<int64_t>& rp, cons
     const unsigned g = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(ilu0_dpos_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, (int32_t)n, t.dpos, t.done);
     hipLaunchKernelGGL(ilu0_ikj_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dpos, t.order, (int32_t)n, t.done,
-                       t.bad, reinterpret_cast<int32_t*>(t.bad + 1), std::max(1, env_i("KRYST_ILU_SETUP_POLL_BUDGET", 1 << 22)));
+                       t.bad, reinterpret_cast<int32_t*>(t.bad + 1), std::max(1, env_int("KRYST_ILU_SETUP_POLL_BUDGET", 1 << 22)));
     KR_HIP(hipGetLastError());
     unsigned long long flags[2] = {0, 0};
     KR_HIP(hipMemcpyAsync(flags, t.bad, 16, hipMemcpyDeviceToHost, ctx->s_main));
@@ -1418,7 +1417,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
     *out = nullptr;
     kryst_ctx_t ctx = a->ctx;
     const int64_t n64 = a->nrows, nnz = a->nnz;
-    if (n64 == 0 || nnz == 0 || n64 >= (1ll << 31) - 4 || env_i("KRYST_ILU_DEVICE_SETUP", 1) == 0) return KRYST_OK;
+    if (n64 == 0 || nnz == 0 || n64 >= (1ll << 31) - 4 || env_int("KRYST_ILU_DEVICE_SETUP", 1) == 0) return KRYST_OK;
     const int32_t n = (int32_t)n64;
     tl_setup_stream = ctx->s_main;
     const bool verbose = getenv("KRYST_ILU_VERBOSE") != nullptr;
@@ -1437,7 +1436,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         int cnt = 0;
         for (int q = 0; q < 256; ++q) cnt += used[q] ? 1 : 0;
         // (a row block of a distributed grid operator lists up to two halo offsets besides its seven)
-        if (cnt <= (a->dist ? 9 : 7) && env_i("KRYST_ILU_GRID", 1) != 0) return KRYST_OK;      // (with the grid forms switched off nothing would recognise it anyway)
+        if (cnt <= (a->dist ? 9 : 7) && env_int("KRYST_ILU_GRID", 1) != 0) return KRYST_OK;      // (with the grid forms switched off nothing would recognise it anyway)
     }
     struct Tmp {
         double *w = nullptr, *dg = nullptr; int32_t *dpos = nullptr, *done = nullptr, *order = nullptr, *nl = nullptr, *nu = nullptr;
@@ -1450,7 +1449,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         hipMalloc(&t.nl, nb) != hipSuccess || hipMalloc(&t.nu, nb) != hipSuccess || hipMalloc(&t.posL, nb) != hipSuccess || hipMalloc(&t.posU, nb) != hipSuccess ||
         hipMalloc(&t.flags, 64) != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }
     const unsigned g = (unsigned)((n + 255) / 256);
-    const int budget = std::max(1, env_i("KRYST_ILU_SETUP_POLL_BUDGET", 1 << 22));
+    const int budget = std::max(1, env_int("KRYST_ILU_SETUP_POLL_BUDGET", 1 << 22));
     // flags: [0] first zero pivot (min), [1] stalled, [2] longest row
     KR_HIP(hipMemsetAsync(t.flags, 0xff, 8, ctx->s_main));
     KR_HIP(hipMemsetAsync(t.flags + 1, 0, 56, ctx->s_main));
@@ -1526,7 +1525,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         F->ell = maxlen <= ELLW;
         F->held = maxlen <= 8 ? 8 : 16;
         const double rows_per_level = (double)n / (double)std::max<size_t>(1, F->lvl_off.size() - 1);
-        F->syncfree = env_i("KRYST_ILU_SYNCFREE", (F->ell || rows_per_level >= 512.0) ? 1 : 0) != 0;
+        F->syncfree = env_int("KRYST_ILU_SYNCFREE", (F->ell || rows_per_level >= 512.0) ? 1 : 0) != 0;
         int32_t* d_pos = which == 0 ? t.posL : t.posU;
         rc = up(&F->d_row, rowid);
         if (rc == KRYST_OK) rc = up(&F->d_ptr, ptr);

@@ -19,8 +19,7 @@ namespace kr {
 // memory-side cache, and streamed otherwise (measured: r of CG kept, 128^3 +5 %, 256^3 +1 %, 512^3 -5 %; the Gram-Schmidt
 // links' z kept, 128^3 / 256^3 +8 %).  KRYST_KEEP_BYTES moves the threshold (0: never keep).
 inline bool keep_in_cache(int64_t n) {
-    const char* e = getenv("KRYST_KEEP_BYTES");                       // (read per launch: tools/solver_ab.py)
-    const long long lim = e ? atoll(e) : (160ll << 20);
+    const long long lim = env_ll("KRYST_KEEP_BYTES", 160ll << 20);   // (tools/solver_ab.py changes it between session steps)
     return (long long)n * 8 <= lim;
 }
 
@@ -73,13 +72,15 @@ __device__ __forceinline__ double dsqrt(double x) { return __builtin_sqrt(x); }
 // single rank: fold the tile partials and run the logic in one launch
 template <int NQ, class L>
 __global__ __launch_bounds__(KR_F) void fold_logic_kernel(const double* partials, int64_t stride, int64_t ntiles,
-                                                          double* chunks, int64_t cstride, unsigned int* ticket,
+                                                          double* chunks, int64_t cstride, unsigned int* ticket, unsigned int* err,
                                                           double* red_out, L logic) {
     if (logic.c.st->done && !L::RUN_WHEN_DONE) return;      // uniform over the grid: only the LAST workgroup ever sets done
     __shared__ double lds[NQ * (KR_F / 64)];
     double v[NQ];
-    if (!fold2<NQ>(partials, stride, ntiles, chunks, cstride, ticket, v, lds)) return;
+    const int f = fold2<NQ>(partials, stride, ntiles, chunks, cstride, ticket, err, v, lds);
+    if (!f) return;
     if (threadIdx.x == 0) {
+        if (f == 2) { logic.c.finish(KRYST_ERR_HIP); return; }      // the hand-off gave up: no value to act on (finish_solve explains)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) red_out[q] = v[q];
         logic.run(red_out);
@@ -92,9 +93,10 @@ __global__ void logic_kernel(const double* red, L logic) {
 }
 // several ranks: fold the all-gathered rank results in rank order (total = r0; total = total + r_p), then the logic
 template <int NQ, class L>
-__global__ void rank_fold_logic_kernel(const double* gathered, int nranks, double* red_out, L logic) {
+__global__ void rank_fold_logic_kernel(const double* gathered, int nranks, const unsigned int* err, double* red_out, L logic) {
     if (logic.c.st->done && !L::RUN_WHEN_DONE) return;
     if (threadIdx.x != 0) return;
+    if (*err) { logic.c.finish(KRYST_ERR_HIP); return; }       // this rank's local fold gave up (its NaN went to the peers)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         double total = gathered[q];
@@ -113,13 +115,18 @@ __global__ void rank_fold_logic_kernel(const double* gathered, int nranks, doubl
 struct IpcView { double* mine; double* const* peers; unsigned long long* epoch; int me, P, budget; };
 template <int NQ, class L>
 __global__ __launch_bounds__(KR_F) void fold_ipc_logic_kernel(const double* partials, int64_t stride, int64_t ntiles,
-                                                              double* chunks, int64_t cstride, unsigned int* ticket,
+                                                              double* chunks, int64_t cstride, unsigned int* ticket, unsigned int* err,
                                                               double* red_out, L logic, IpcView v) {
     if (logic.c.st->done && !L::RUN_WHEN_DONE) return;      // the same decision on every rank (identical scalars): nobody sends, nobody waits
     __shared__ double lds[NQ * (KR_F / 64)];
     double val[NQ];
-    if (!fold2<NQ>(partials, stride, ntiles, chunks, cstride, ticket, val, lds)) return;
+    const int f = fold2<NQ>(partials, stride, ntiles, chunks, cstride, ticket, err, val, lds);
+    if (!f) return;
     if (threadIdx.x >= 64) return;
+    if (f == 2) {                                                    // the local hand-off gave up: the peers still get their message (a NaN)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) val[q] = __longlong_as_double(0x7FF8000000000000ll);
+    }
     const int p = threadIdx.x;
     const unsigned long long e = *v.epoch + 1;
     const int par = (int)(e & 1ull);
@@ -143,6 +150,7 @@ __global__ __launch_bounds__(KR_F) void fold_ipc_logic_kernel(const double* part
     if (p != 0) return;
     *v.epoch = e;
     if (!all_ok) { logic.c.finish(KRYST_ERR_RCCL); return; }
+    if (f == 2) { logic.c.finish(KRYST_ERR_HIP); return; }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         double total = __hip_atomic_load(v.mine + (size_t)(par * v.P) * 16 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -157,19 +165,19 @@ inline int32_t reduce_then(kryst_ctx_t ctx, int64_t ntiles, double* d_red, const
     if (!use_collectives(ctx)) {
         KR_TRY(ensure_partials(ctx, ntiles > 0 ? ntiles : 1));
         hipLaunchKernelGGL((fold_logic_kernel<NQ, L>), dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main,
-                           ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_red, logic);
+                           ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), fold_err(ctx), d_red, logic);
     } else if (ctx->ipc_on) {
         KR_TRY(ensure_partials(ctx, ntiles > 0 ? ntiles : 1));
         static const int budget = [] { const char* e = getenv("KRYST_IPC_POLL_BUDGET"); return e ? std::max(1, atoi(e)) : (1 << 26); }();
         const IpcView v{ctx->ipc_mine, ctx->d_ipc_peers, ctx->d_ipc_epoch, ctx->rank, ctx->nranks, budget};
         hipLaunchKernelGGL((fold_ipc_logic_kernel<NQ, L>), dim3((unsigned)nchunks_of(ntiles)), dim3(KR_F), 0, ctx->s_main,
-                           ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), d_red, logic, v);
+                           ctx->d_partials, ctx->partials_cap, ntiles, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), fold_err(ctx), d_red, logic, v);
     } else {
         // local two-level fold -> RCCL all-gather of NQ doubles per rank -> rank-ordered fold + logic in one launch
         double* local = ctx->d_gather + (size_t)ctx->nranks * KR_MAXQ;
         KR_TRY(launch_final_fold(ctx, NQ, ntiles, local));
         KR_TRY(comm_all_gather(ctx, local, ctx->d_gather, NQ));
-        hipLaunchKernelGGL((rank_fold_logic_kernel<NQ, L>), dim3(1), dim3(64), 0, ctx->s_main, ctx->d_gather, ctx->nranks, d_red, logic);
+        hipLaunchKernelGGL((rank_fold_logic_kernel<NQ, L>), dim3(1), dim3(64), 0, ctx->s_main, ctx->d_gather, ctx->nranks, fold_err(ctx), d_red, logic);
     }
     KR_HIP(hipGetLastError());
     phase_mark(ctx, KR_PH_REDUCE);
@@ -343,9 +351,9 @@ inline int32_t finish_solve(Workspace& ws, const SolveIO& io) {
     for (int64_t k = 0; k < len && k < ws.hist_cap; ++k) {
         if (io.hist && k < io.hist_cap) io.hist[k] = ws.h_hist[k];
     }
-    (void)ctx;
     // a preconditioner apply abandoned by the device (pc.h: pc_health) voids the whole solve, whatever the recurrences made of it
     if (io.pc && pc_health(io.pc) != KRYST_OK) return KRYST_SOLVE_ERROR;
+    if (h.status == KRYST_ERR_HIP) fold_gave_up(ctx);             // (a status the device raised: the fold's polling hand-off ran out of patience)
     return h.status;
 }
 

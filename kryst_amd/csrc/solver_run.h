@@ -68,6 +68,7 @@ struct SolverRun {
         return KRYST_OK;
     }
     int32_t step(int64_t k) {                // enqueue k more iterations, no host synchronisation
+        const EnvFreeze knobs;               // the tuning knobs are read once per step call, not per launch
         for (int64_t j = 0; j < k && next_iter <= prm.max_iters; ++j, ++next_iter) KR_TRY(iterate(next_iter));
         return KRYST_OK;
     }
@@ -83,6 +84,7 @@ struct SolverRun {
         return status;
     }
     int32_t solve() {
+        const EnvFreeze knobs;               // the tuning knobs are read once per solve, not per launch
         KR_TRY(begin());
         KR_TRY(run_ahead(ctx, &prm, [&](int64_t i) -> int32_t { next_iter = i + 1; return iterate(i); }, [&] { mon.poll(); }));
         return end();

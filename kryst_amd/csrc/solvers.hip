@@ -123,7 +123,11 @@ struct GateXPending {                // runs while the solve is under way, and o
 template <class Op>
 inline int32_t launch_direction(kryst_ctx_t ctx, kryst_csr_t a, const Op& op, int64_t n, const DevState* st, long long it, const double* p_vec) {
     const GateXPending gate{st, it};
-    if (a->dist && use_collectives(ctx) && a->send_contiguous && env_int("KRYST_HALO_EARLY", 1) != 0) {
+    // The early start adds one exchange per iteration, so WHETHER it happens must not depend on anything a rank sees alone: it is
+    // a->halo_early_ok (agreed across ranks when the operator was created) and the environment (the same on every rank, like every
+    // other setting).  Whether this rank SPLITS its pass around the exchange is a local matter: a rank whose send ranges are most of
+    // its block runs the whole pass first and starts the exchange behind it -- the same number of exchanges either way.
+    if (a->dist && use_collectives(ctx) && a->halo_early_ok && env_int("KRYST_HALO_EARLY", 1) != 0) {
         std::vector<std::pair<int64_t, int64_t>> early;
         halo_send_tiles(a, early);
         int64_t covered = 0;
@@ -136,6 +140,8 @@ inline int32_t launch_direction(kryst_ctx_t ctx, kryst_csr_t a, const Op& op, in
             for (const auto& r : early) { KR_TRY(launch_ew_gated(ctx, op, n, gate, 0, at, std::min(r.first, all))); at = std::min(r.second, all); }
             return launch_ew_gated(ctx, op, n, gate, 0, at, all);
         }
+        KR_TRY(launch_ew_gated(ctx, op, n, gate));
+        return halo_begin(a, p_vec);
     }
     return launch_ew_gated(ctx, op, n, gate);
 }

@@ -33,9 +33,50 @@ def stage(rank, name):
     print(f"[rank {rank} +{time.time() - _T0:7.3f}s] {name}", flush=True)
 
 
+def mixed_system(N):
+    """The N^3 Poisson operator plus three symmetric couplings between row 0 and rows n-1, n-3, n-7: the last rank then sends a
+    NON-contiguous list to rank 0 while every other send list is a contiguous run -- ranks that disagree on `send_contiguous`
+    (the early halo start must be switched off on all of them alike).  Same on every rank and in the test."""
+    import scipy.sparse as sp
+    rp, ci, va = K.host_stencil7(N, "poisson")
+    n = N ** 3
+    m = sp.csr_matrix((va, ci, rp), shape=(n, n)).tolil()
+    for j, w in ((n - 1, -0.25), (n - 3, -0.5), (n - 7, -0.125)):
+        m[0, j] = w; m[j, 0] = w
+        m[0, 0] += abs(w); m[j, j] += abs(w)
+    m = m.tocsr(); m.sort_indices()
+    return m
+
+
 def main():
-    rank, P, outdir, N = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    ranks, P, outdir, N = [int(r) for r in sys.argv[1].split(",")], int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
     kind = sys.argv[5]
+    if len(ranks) == 1:
+        return run_rank(ranks[0], P, outdir, N, kind)
+    # several ranks of ONE process, a host thread each (a GPU box admits at most 6 processes on its card: 8 ranks = 4 x 2)
+    import threading
+    errs = []
+
+    def guarded(r):
+        try:
+            run_rank(r, P, outdir, N, kind)
+        except BaseException as e:                      # noqa: BLE001  (the process must exit non-zero, with the stage in its log)
+            import traceback
+            traceback.print_exc()
+            errs.append((r, e))
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(3)                                 # the sibling would otherwise wait for this rank inside a collective
+
+    ts = [threading.Thread(target=guarded, args=(r,)) for r in ranks]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        sys.exit(3)
+
+
+def run_rank(rank, P, outdir, N, kind):
     stage(rank, "start")
     idfile = os.path.join(outdir, "uid.bin")
     if rank == 0:
@@ -52,9 +93,10 @@ def main():
     stage(rank, "ctx_create_dist")
     ctx = K.Context(0, rank, P, uid)
     stage(rank, "operator")
-    if kind == "random":                              # general operator: N rows, halo entries from any rank
-        m = random_system(N)
-        offs = K.partition_rows(N, P, 1)
+    if kind in ("random", "mixed"):                   # general operator: halo entries from any rank / one non-contiguous send list
+        m = random_system(N) if kind == "random" else mixed_system(N)
+        N = m.shape[0]
+        offs = K.partition_rows(N, P, 1) if kind == "random" else K.partition_rows(N, P, round(N ** (2 / 3)))
         sub = m[int(offs[rank]):int(offs[rank + 1])].tocsr()
         sub.sort_indices()
         a = K.CsrMatrix.from_csr_dist(ctx, N, offs, sub.indptr, sub.indices, sub.data)

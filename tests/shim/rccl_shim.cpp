@@ -22,7 +22,7 @@
 #include <thread>
 
 namespace {
-constexpr int MAXR = 4;
+constexpr int MAXR = 8;                           // (ranks may also be threads of one process: all per-call state is thread_local)
 constexpr size_t SLOT = 4u << 20;                 // bytes per (src,dst) mailbox
 struct Board {
     std::atomic<int> arrived; std::atomic<int> generation;

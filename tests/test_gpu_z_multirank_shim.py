@@ -25,7 +25,13 @@ def _build_shim():
                                                  (2, 12, "varcoef", "0"), (3, 10, "varcoef", "1"),     # CSR-DIA with halo diagonals (device generator / host path)
                                                  (2, 20, "aniso", "0+quad"),       # "+quad": every rank's block factor through the 16 x 16 wavefront kernel
                                                  (4, 48, "poisson", "0+light"),    # config 4's shape at 48^3: 4 k-slabs of 54 tiles (interior AND boundary
-                                                 (3, 40, "varcoef", "0+light")])   # tiles, P16 / DIA with halo planes): CG, Jacobi-PCG, BiCGStab, session
+                                                 (3, 40, "varcoef", "0+light"),    # tiles, P16 / DIA with halo planes): CG, Jacobi-PCG, BiCGStab, session
+                                                 # ranks whose OWN tile counts would decide differently about the early halo start (edge ranks: one send
+                                                 # range, middle ranks: two) and send lists that are contiguous on some ranks only:
+                                                 (3, 18, "poisson", "0+light"), (4, 24, "poisson", "0+light"), (3, 12, "mixed", "0+light"),
+                                                 # EIGHT ranks -- config 4's partition -- as 4 processes x 2 rank threads (a GPU box admits at most 6
+                                                 # processes on its card): k-slabs of 4 planes of a 32^3 grid, and a general operator
+                                                 (8, 32, "poisson", "0+light+t2"), (8, 4000, "random", "0+light+t2")])
 def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     from oracle import oracle as O
     import kryst_amd as K
@@ -33,11 +39,17 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     env = dict(os.environ, KRYST_RCCL_LIB=SHIM, KRYST_STENCIL_HOST=hostgen.split("+")[0])
     if hostgen.endswith("+quad"):
         env["KRYST_ILU_WAVE"] = "2"
-    light = hostgen.endswith("+light")
+    flags = hostgen.split("+")[1:]
+    light = "light" in flags
     if light:
         env["KRYST_MR_LIGHT"] = "1"
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), str(r), str(P), str(tmp_path), str(N), kind],
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(P)]
+    per = 2 if "t2" in flags else 1                     # ranks per process (host threads)
+    if per > 1:
+        env["GPU_MAX_HW_QUEUES"] = "8"                  # every rank's two streams on hardware queues of their own: a kernel that polls for a peer
+                                                        # must never sit in front of that peer's kernels in one queue
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), ",".join(str(r) for r in range(r0, r0 + per)),
+                               str(P), str(tmp_path), str(N), kind],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r0 in range(0, P, per)]
     outs = []
     try:
         for p in procs:
@@ -54,12 +66,13 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     # the worker repeated every solve on the IPC-mailbox path of the scalar all-reduce and compared it with the RCCL path itself
     assert all(int(r["ipc_active"][0]) == 1 for r in R), "the hipIpc mailbox path could not be set up between the ranks of this box"
     T, V, F = K.reduce_spec()
-    if kind == "random":
+    if kind in ("random", "mixed"):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from multirank_worker import random_system
-        m0 = random_system(N)
-        offs = K.partition_rows(N, P, 1)
-        a = O.Csr(N, N, m0.indptr, m0.indices, m0.data)
+        from multirank_worker import random_system, mixed_system
+        m0 = random_system(N) if kind == "random" else mixed_system(N)
+        n0 = m0.shape[0]
+        offs = K.partition_rows(n0, P, 1) if kind == "random" else K.partition_rows(n0, P, N * N)
+        a = O.Csr(n0, n0, m0.indptr, m0.indices, m0.data)
     else:
         offs = K.partition_rows(N ** 3, P, N * N)
         a = O.stencil7(N, kind)
