@@ -521,8 +521,8 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3):
         if late_wins:
             dt, stats, dts, best = dt_late, stats_late, dts_late, "at_spmv"
         peer_note = None
-        if hasattr(ctx, "halo_mode"):
-            if ctx.halo_mode("peer") == "peer":
+        if hasattr(a, "halo_mode"):
+            if a.halo_mode("peer") == "peer":
                 try:
                     dt_p, stats_p, dts_p = timed_iterations()
                     failed = 0.0
@@ -531,7 +531,7 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3):
                     peer_note = f"failed: {e}"
                 if group.allreduce_max(failed) > 0.0:
                     peer_note = peer_note or "failed on another rank"
-                    ctx.halo_mode("rccl")
+                    a.halo_mode("rccl")
                 else:
                     same_p = group.allreduce_max(0.0 if stats_p.final_residual == stats.final_residual else 1.0) == 0.0
                     forms["peer_stores"] = steps / dt_p
@@ -539,7 +539,7 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3):
                     if same_p and dt_p < dt:
                         dt, stats, dts, best = dt_p, stats_p, dts_p, "peer_stores"
                     else:
-                        ctx.halo_mode("rccl")
+                        a.halo_mode("rccl")
             else:
                 peer_note = "unavailable on this node (hipIpc export / mapping of the halo buffers failed)"
         reduce_info.update(value_halo_early=forms["early"], value_halo_at_spmv=forms["at_spmv"], value_halo_peer_stores=forms.get("peer_stores"),

@@ -70,6 +70,7 @@ extern "C" {
     pub fn kryst_comm_barrier(ctx: Ctx) -> i32;
     pub fn kryst_comm_all_reduce(ctx: Ctx, x: f64, out: *mut f64) -> i32;
     pub fn kryst_ctx_scalar_reduce(ctx: Ctx, mode: i32, active: *mut i32) -> i32;
+    pub fn kryst_csr_halo_mode(a: Csr, mode: i32, active: *mut i32) -> i32;
     pub fn kryst_phase_timing_begin(ctx: Ctx) -> i32;
     pub fn kryst_phase_timing_end(ctx: Ctx, ms: *mut f64, count: i32) -> i32;
     pub fn kryst_phase_count() -> i32;

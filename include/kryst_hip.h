@@ -82,6 +82,13 @@ int32_t kryst_comm_all_reduce(kryst_ctx_t ctx, double x, double* out);     /* Co
  * on every rank, which all stay on RCCL -- when a mailbox cannot be exported or mapped.  *active (may be NULL): mode in use.
  * KRYST_SCALAR_REDUCE=ipc selects mode 1 at kryst_ctx_create_dist. */
 int32_t kryst_ctx_scalar_reduce(kryst_ctx_t ctx, int32_t mode, int32_t* active);
+/* How a row-partitioned operator's halo exchange travels (the neighbour exchange src/parallel/mpi_comm.rs:133-143 leaves as a TODO): mode 0 =
+ * grouped ncclSend / ncclRecv on the second stream (default), 1 = direct peer stores -- a push kernel writes the rows each neighbour needs
+ * straight into that neighbour's hipIpc-mapped landing buffer and stamps the exchange's epoch behind them, the receiver's compute stream
+ * polls its stamps in front of the boundary tiles: no collective launch, no pack kernel, no event between receive and compute stream.
+ * COLLECTIVE over the context's ranks, no solve open.  Mode 1 returns KRYST_UNSUPPORTED -- on every rank, which all stay on RCCL -- when a
+ * landing buffer cannot be exported or mapped or a neighbour relation is one-way.  The same bits either way.  *active (may be NULL): mode in use. */
+int32_t kryst_csr_halo_mode(kryst_csr_t a, int32_t mode, int32_t* active);
 /* measurement only: per-phase device time of the work enqueued between begin and end (hipEvents recorded on the compute stream
  * after each phase: time between two marks is charged to the later one).  ms[p] for p < kryst_phase_count(): "spmv" (tiles
  * without halo columns; single rank: the whole SpMV), "halo_wait" (compute stream waiting for the neighbour planes),

@@ -307,6 +307,15 @@ class CsrMatrix:
         check(lib().kryst_bench_spmv(self.h, x.h, y.h, fused_dots, reps, C.byref(ms)))
         return ms.value
 
+    def halo_mode(self, mode):
+        """'rccl' | 'peer': how this row-partitioned operator's halo exchange travels (kryst_csr_halo_mode; collective).  Returns the mode in
+        use: 'peer' falls back to 'rccl' on every rank when a landing buffer cannot be exported / mapped (KRYST_UNSUPPORTED)."""
+        active = C.c_int32(0)
+        rc = lib().kryst_csr_halo_mode(self.h, {"rccl": 0, "peer": 1}[mode], C.byref(active))
+        if rc not in (0, 6):                     # (6 = KRYST_UNSUPPORTED: the documented fallback)
+            check(rc)
+        return "peer" if active.value == 1 else "rccl"
+
     def bench_csr_skeleton(self, x, y, reps=10):
         """Average milliseconds per launch of the plain-CSR kernel's traffic skeleton (the CSR arrays streamed, x read, y written -- no
         arithmetic; y receives garbage)."""

@@ -78,11 +78,16 @@ __global__ __launch_bounds__(KR_F) void final_fold_kernel(const double* partials
 }
 
 bool fold_gave_up(kryst_ctx_t ctx) {
-    unsigned int w = 0;
-    if (hipMemcpyAsync(&w, fold_err(ctx), sizeof w, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (!w) return false;
+    unsigned int w[2] = {0, 0};          // [0]: a fold's polling hand-off, [1]: a halo pull (spmv.hip: halo_pull_kernel) ran out of patience
+    if (hipMemcpyAsync(w, fold_err(ctx), sizeof w, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (!w[0] && !w[1]) return false;
     (void)hipMemsetAsync(fold_err(ctx), 0, sizeof w, ctx->s_main);
     (void)hipStreamSynchronize(ctx->s_main);
+    if (w[1]) {
+        set_error("halo exchange by peer stores: a neighbour's epoch stamp never arrived (poll budget exhausted); the halo was poisoned with NaNs -- "
+                  "switch the operator back with kryst_csr_halo_mode(a, 0)");
+        return true;
+    }
     ctx->fold_poll_off = true;
     set_error("an inner product's two-level fold gave up waiting for a workgroup of its own launch (GPU shared, time-sliced or serialised by a "
               "profiler for seconds); the result was discarded and this context now uses the ticket hand-off");

@@ -53,6 +53,7 @@ struct kryst_csr_s {
     bool send_contiguous = false;   // every send list is a contiguous run of local rows (k-slab stencils)
     bool halo_early_ok = false;     // ... on EVERY rank (agreed at creation): the solvers may start the exchange of a new direction vector
                                     // behind the pass that writes it -- a per-iteration exchange that all ranks issue or none does
+    bool halo_pushed_inline = false;            // (peer stores) the push in flight was enqueued on the compute stream itself
     const double* halo_started_for = nullptr;   // the halo exchange of this input vector is already in flight (halo_begin: a solver started it early)
 };
 
@@ -68,6 +69,10 @@ int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const dou
 // later) and remember it, so that the next launch_spmv(a, x, ...) does not start it again.  A solver calls it after the launch that
 // wrote the rows the neighbours need and before the launches that write the rest (send_contiguous operators only).
 int32_t halo_begin(kryst_csr_t a, const double* x);
+// switch the operator's halo exchange to direct peer stores (collective; KRYST_UNSUPPORTED on every rank when a rank cannot map a peer's
+// landing buffer or a neighbour relation is one-way) / back to RCCL
+int32_t halo_peer_setup(kryst_csr_t a);
+void halo_peer_destroy(kryst_csr_t a);
 // the tile ranges [lo, hi) whose rows are sent to neighbours, merged and ascending (send_contiguous operators)
 void halo_send_tiles(kryst_csr_t a, std::vector<std::pair<int64_t, int64_t>>& ranges);
 

@@ -853,6 +853,7 @@ int32_t kryst_csr_destroy(kryst_csr_t a) {
     (void)hipFree(a->d_pid); (void)hipFree(a->d_pmeta); (void)hipFree(a->d_poff); (void)hipFree(a->d_pval); (void)hipFree(a->d_dia);
     (void)hipFree(a->d_tiles_interior); (void)hipFree(a->d_tiles_boundary); (void)hipFree(a->d_tile_order);
     (void)hipFree(a->plan.d_send_idx); (void)hipFree(a->plan.d_sendbuf); (void)hipFree(a->plan.d_halo);
+    halo_peer_destroy(a);
     delete a;
     return KRYST_OK;
 }

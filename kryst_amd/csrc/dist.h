@@ -25,6 +25,29 @@ int32_t ipc_reduce_setup(kryst_ctx_t ctx);
 int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, std::vector<void*>& opened);
 void    ipc_reduce_destroy(kryst_ctx_t ctx);
 
+// Halo exchange by direct peer stores ("direct peer writes over xGMI / IPC-mapped buffers"; replaces the neighbour exchange
+// the reference's MpiComm leaves as a TODO, src/parallel/mpi_comm.rs:133-143): every rank owns a LANDING buffer in fine-grained device
+// memory that its neighbours map (hipIpc; directly between ranks of one process) -- two parities x total_recv doubles, then one 16-byte
+// stamp cell per sender.  An exchange = one push kernel on the sender (the rows each neighbour needs, stored straight into that
+// neighbour's landing buffer [epoch parity] with system-scope write-through stores; the workgroup that finishes last writes the epoch
+// into the neighbours' stamp cells) and one pull kernel on the receiver's compute stream in front of the boundary tiles (polls its own
+// stamp cells for the epoch, copies landing[parity] into the plan's d_halo).  No ncclSend / ncclRecv, no pack kernel, no event between
+// the receive and the compute stream.  Two parities suffice when every neighbour relation is mutual (checked at set-up): a rank pushes
+// exchange e + 2 only after it has consumed its neighbours' e + 1, which they push after they have consumed e.
+struct HaloPushSeg { double* dst; unsigned long long* stamp; int64_t dst_stride; int64_t src; int64_t count; };   // dst: peer landing + my offset there;
+                                                                     // src: first local row (contiguous lists) or first entry of d_send_idx
+struct HaloPullSeg { const unsigned long long* stamp; int64_t off; int64_t count; };    // my stamp cell of that sender, its range in d_halo
+struct HaloPeer {
+    bool on = false;
+    double* landing = nullptr;           // fine-grained: 2 * stride doubles of data, then 2 doubles (one 16-byte cell) per rank
+    int64_t stride = 0;                  // doubles per parity (total_recv rounded up to a multiple of 2, at least 2)
+    std::vector<void*> opened;           // peer mappings to close
+    HaloPushSeg* d_push = nullptr; int npush = 0; int64_t push_max = 0;      // longest segment (grid size)
+    HaloPullSeg* d_pull = nullptr; int npull = 0; int64_t pull_max = 0;
+    unsigned int* d_ticket = nullptr;    // the push kernel's "last workgroup" counter
+    unsigned long long epoch = 0;        // exchanges issued on this operator so far (the same number on every rank)
+};
+
 // Halo plan of a row-partitioned operator (host side; also exported as kryst_host_halo_recv_plan)
 struct HaloPlan {
     int nranks = 1, rank = 0;
@@ -35,6 +58,7 @@ struct HaloPlan {
     int32_t* d_send_idx = nullptr;       // local rows to pack, total_send
     double*  d_sendbuf = nullptr;        // total_send
     double*  d_halo = nullptr;           // total_recv
+    HaloPeer peer;                       // the exchange by direct peer stores (off unless kryst_csr_halo_mode switched it on)
 };
 
 // recv side from the local rows (global column ids); returns the plan's recv_* fields

@@ -353,7 +353,8 @@ inline int32_t finish_solve(Workspace& ws, const SolveIO& io) {
     }
     // a preconditioner apply abandoned by the device (pc.h: pc_health) voids the whole solve, whatever the recurrences made of it
     if (io.pc && pc_health(io.pc) != KRYST_OK) return KRYST_SOLVE_ERROR;
-    if (h.status == KRYST_ERR_HIP) fold_gave_up(ctx);             // (a status the device raised: the fold's polling hand-off ran out of patience)
+    // a fold's polling hand-off (status raised by the device) or a halo pull (NaNs in the halo, no status) that ran out of patience
+    if ((h.status == KRYST_ERR_HIP || (ctx->nranks > 1 && io.a->plan.peer.on)) && fold_gave_up(ctx)) return h.status != KRYST_OK ? h.status : KRYST_ERR_RCCL;
     return h.status;
 }
 

@@ -1088,9 +1088,148 @@ void halo_send_tiles(kryst_csr_t a, std::vector<std::pair<int64_t, int64_t>>& ra
     ranges.swap(merged);
 }
 
+// ---- halo exchange by direct peer stores (dist.h: HaloPeer)
+// push: workgroup (bx, seg) stores its share of segment `seg` into the neighbour's landing buffer; the workgroup that finishes LAST (all
+// data stores of the launch acknowledged: write-through system-scope stores + s_waitcnt vmcnt(0) in front of the ticket) stamps the epoch
+// into every neighbour's cell -- the protocol of fold_ipc_logic_kernel (solver_common.h).
+__global__ __launch_bounds__(256) void halo_push_kernel(const double* __restrict__ x, const int32_t* __restrict__ send_idx, const HaloPushSeg* __restrict__ segs,
+                                                        int nsegs, int parity, unsigned long long epoch, unsigned int* ticket) {
+    const HaloPushSeg sg = segs[blockIdx.y];
+    double* dst = sg.dst + (size_t)parity * sg.dst_stride;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < sg.count; i += (int64_t)gridDim.x * 256) {
+        const double v = send_idx ? x[send_idx[sg.src + i]] : x[sg.src + i];
+        __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __shared__ int last;
+    __syncthreads();                                                  // every wave of the workgroup has had its stores acknowledged
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == gridDim.x * gridDim.y - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x < nsegs) __hip_atomic_store(segs[threadIdx.x].stamp, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next (stream-ordered) push
+}
+// pull: wait for the sender's stamp, then landing[parity] -> d_halo (uncached reads: the landing buffer is written by another agent).
+// A stamp that never comes (budget) poisons the halo with NaNs and raises the context's error word instead of hanging the GPU.
+__global__ __launch_bounds__(256) void halo_pull_kernel(const double* __restrict__ landing, double* __restrict__ halo, const HaloPullSeg* __restrict__ segs,
+                                                        unsigned long long epoch, int budget, unsigned int* err) {
+    const HaloPullSeg sg = segs[blockIdx.y];
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        int b = budget;
+        unsigned long long seen = __hip_atomic_load(sg.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        while (seen < epoch && --b > 0) { __builtin_amdgcn_s_sleep(2); seen = __hip_atomic_load(sg.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+        ok = seen >= epoch ? 1 : 0;
+        if (!ok) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const bool good = ok != 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < sg.count; i += (int64_t)gridDim.x * 256)
+        halo[sg.off + i] = good ? __hip_atomic_load(landing + sg.off + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __longlong_as_double(0x7FF8000000000000ll);
+}
+
+void halo_peer_destroy(kryst_csr_t a) {
+    HaloPeer& hp = a->plan.peer;
+    for (void* q : hp.opened) (void)hipIpcCloseMemHandle(q);
+    hp.opened.clear();
+    (void)hipFree(hp.landing); (void)hipFree(hp.d_push); (void)hipFree(hp.d_pull); (void)hipFree(hp.d_ticket);
+    hp.landing = nullptr; hp.d_push = nullptr; hp.d_pull = nullptr; hp.d_ticket = nullptr; hp.on = false;
+    (void)hipGetLastError();
+}
+
+int32_t halo_peer_setup(kryst_csr_t a) {
+    kryst_ctx_t ctx = a->ctx;
+    HaloPlan& pl = a->plan;
+    HaloPeer& hp = pl.peer;
+    if (hp.on) return KRYST_OK;
+    if (hp.landing) { hp.on = true; return KRYST_OK; }               // set up before and switched off: still mapped everywhere, epochs counted alike
+    KR_ARG(a->dist && ctx->comm, "halo_peer_setup: not a distributed operator");
+    const int P = ctx->nranks, me = ctx->rank;
+    KR_HIP(hipStreamSynchronize(ctx->s_comm));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    // local: landing buffer (zeroed: stamps start at epoch 0); a rank that fails here, or whose neighbour relations are not mutual, still
+    // takes part in the collectives below with a null buffer, which then fail on every rank alike
+    bool mutual = true;
+    for (int p = 0; p < P; ++p) mutual = mutual && ((pl.send_counts[p] > 0) == (pl.recv_counts[p] > 0));
+    hp.stride = std::max<int64_t>(2, (pl.total_recv + 1) & ~(int64_t)1);
+    const size_t bytes = sizeof(double) * (size_t)(2 * hp.stride + 2 * P);
+    if (!mutual || hipExtMallocWithFlags((void**)&hp.landing, bytes, hipDeviceMallocFinegrained) != hipSuccess ||
+        hipMemsetAsync(hp.landing, 0, bytes, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(hp.landing); hp.landing = nullptr;
+    }
+    std::vector<void*> peers;
+    int32_t rc = ipc_map_peers(ctx, hp.landing, peers, hp.opened);
+    if (rc != KRYST_OK) { halo_peer_destroy(a); return rc; }
+    // where my rows land in each neighbour's buffer: every rank's {stride, recv_off[0..P)} in one all-gather
+    std::vector<int64_t> mine((size_t)P + 1), all((size_t)(P + 1) * P, 0);
+    mine[0] = hp.stride;
+    for (int p = 0; p < P; ++p) mine[(size_t)p + 1] = pl.recv_off[p];
+    int64_t *d_s = nullptr, *d_r = nullptr;
+    if (hipMalloc(&d_s, sizeof(int64_t) * (P + 1)) != hipSuccess || hipMalloc(&d_r, sizeof(int64_t) * (size_t)(P + 1) * P) != hipSuccess) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK && (hipMemcpyAsync(d_s, mine.data(), sizeof(int64_t) * (P + 1), hipMemcpyHostToDevice, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK) rc = comm_all_gather_i64(ctx, d_s, d_r, P + 1, ctx->s_main);
+    if (rc == KRYST_OK && (hipMemcpyAsync(all.data(), d_r, sizeof(int64_t) * all.size(), hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
+    (void)hipFree(d_s); (void)hipFree(d_r);
+    if (rc != KRYST_OK) { halo_peer_destroy(a); return rc; }         // (a failing collective fails on every rank)
+    std::vector<HaloPushSeg> push; std::vector<HaloPullSeg> pull;
+    hp.push_max = hp.pull_max = 0;
+    // (send_off: for contiguous lists the first local row of the run, otherwise the list's first entry in d_send_idx -- csr_create.hip)
+    for (int p = 0; p < P; ++p) {
+        if (p != me && pl.send_counts[p] > 0) {
+            const int64_t pstride = all[(size_t)(P + 1) * p], poff = all[(size_t)(P + 1) * p + 1 + me];
+            double* base = static_cast<double*>(peers[p]);
+            push.push_back(HaloPushSeg{base + poff, reinterpret_cast<unsigned long long*>(base + 2 * pstride + 2 * me), pstride, pl.send_off[p], pl.send_counts[p]});
+            hp.push_max = std::max(hp.push_max, pl.send_counts[p]);
+        }
+        if (p != me && pl.recv_counts[p] > 0) {
+            pull.push_back(HaloPullSeg{reinterpret_cast<const unsigned long long*>(hp.landing + 2 * hp.stride + 2 * p), pl.recv_off[p], pl.recv_counts[p]});
+            hp.pull_max = std::max(hp.pull_max, pl.recv_counts[p]);
+        }
+    }
+    hp.npush = (int)push.size(); hp.npull = (int)pull.size();
+    if (hp.npush > 256) { halo_peer_destroy(a); set_error("halo by peer stores: more than 256 neighbours"); return KRYST_UNSUPPORTED; }   // (cannot differ... every rank has P - 1 at most)
+    KR_HIP(hipMalloc(&hp.d_push, sizeof(HaloPushSeg) * (push.size() + 1)));
+    KR_HIP(hipMalloc(&hp.d_pull, sizeof(HaloPullSeg) * (pull.size() + 1)));
+    KR_HIP(hipMalloc(&hp.d_ticket, 64));
+    KR_HIP(hipMemsetAsync(hp.d_ticket, 0, 64, ctx->s_main));
+    if (!push.empty()) KR_HIP(hipMemcpyAsync(hp.d_push, push.data(), sizeof(HaloPushSeg) * push.size(), hipMemcpyHostToDevice, ctx->s_main));
+    if (!pull.empty()) KR_HIP(hipMemcpyAsync(hp.d_pull, pull.data(), sizeof(HaloPullSeg) * pull.size(), hipMemcpyHostToDevice, ctx->s_main));
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    hp.on = true;
+    return KRYST_OK;
+}
+
+// messages up to this many bytes in total are pushed from the compute stream itself (no second stream, no event): below it the two
+// cross-stream dependencies cost more than the stores' time on the wire
+static int64_t halo_inline_bytes() { return env_ll("KRYST_HALO_INLINE_BYTES", 256 << 10); }
+
 int32_t halo_begin(kryst_csr_t a, const double* x) {
     kryst_ctx_t ctx = a->ctx;
     HaloPlan& pl = a->plan;
+    if (pl.peer.on) {
+        HaloPeer& hp = pl.peer;
+        ++hp.epoch;
+        const bool inl = pl.total_send * 8 <= halo_inline_bytes();
+        hipStream_t s = inl ? ctx->s_main : ctx->s_comm;
+        if (!inl) {
+            KR_HIP(hipEventRecord(ctx->ev_x_ready, ctx->s_main));
+            KR_HIP(hipStreamWaitEvent(ctx->s_comm, ctx->ev_x_ready, 0));
+        }
+        if (hp.npush > 0) {
+            const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(1, (hp.push_max + 1023) / 1024), 64);   // <= 64 workgroups per neighbour: the wire, not the CUs, bounds it
+            hipLaunchKernelGGL(halo_push_kernel, dim3(gx, (unsigned)hp.npush), dim3(256), 0, s, x, a->send_contiguous ? nullptr : pl.d_send_idx, hp.d_push, hp.npush,
+                               (int)(hp.epoch & 1ull), hp.epoch, hp.d_ticket);
+            KR_HIP(hipGetLastError());
+        }
+        if (!inl) KR_HIP(hipEventRecord(ctx->ev_halo_done, ctx->s_comm));
+        a->halo_pushed_inline = inl;
+        a->halo_started_for = x;
+        return KRYST_OK;
+    }
     KR_HIP(hipEventRecord(ctx->ev_x_ready, ctx->s_main));
     KR_HIP(hipStreamWaitEvent(ctx->s_comm, ctx->ev_x_ready, 0));
     const void* sendbase = pl.d_sendbuf;
@@ -1123,7 +1262,20 @@ int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const dou
     a->halo_started_for = nullptr;
     KR_TRY(launch_tiles<false>(a, x, y, nq, dvec, done, a->d_tiles_interior, a->n_interior));   // interior tiles have no halo columns
     phase_mark(ctx, KR_PH_SPMV);
-    KR_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_halo_done, 0));
+    if (a->plan.peer.on) {
+        HaloPeer& hp = a->plan.peer;
+        // (my own push has read x: only needed before x is overwritten, and long since true -- the one local dependency that is left)
+        if (!a->halo_pushed_inline) KR_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_halo_done, 0));
+        if (hp.npull > 0) {
+            static const int budget = [] { const char* e = getenv("KRYST_IPC_POLL_BUDGET"); return e ? std::max(1, atoi(e)) : (1 << 26); }();
+            const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(1, (hp.pull_max + 1023) / 1024), 256);
+            hipLaunchKernelGGL(halo_pull_kernel, dim3(gx, (unsigned)hp.npull), dim3(256), 0, ctx->s_main, hp.landing + (size_t)(hp.epoch & 1ull) * hp.stride,
+                               a->plan.d_halo, hp.d_pull, hp.epoch, budget, fold_err(ctx) + 1);
+            KR_HIP(hipGetLastError());
+        }
+    } else {
+        KR_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_halo_done, 0));
+    }
     phase_mark(ctx, KR_PH_HALO_WAIT);
     KR_TRY(launch_tiles<true>(a, x, y, nq, dvec, done, a->d_tiles_boundary, a->n_boundary));
     phase_mark(ctx, KR_PH_SPMV_BOUNDARY);
@@ -1135,6 +1287,26 @@ int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const dou
 using namespace kr;
 
 extern "C" {
+
+// How the operator's halo exchange travels: mode 0 = grouped ncclSend / ncclRecv on the second stream (default), 1 = direct peer stores
+// into hipIpc-mapped landing buffers (dist.h: HaloPeer).  COLLECTIVE: every rank calls it with the same mode.  KRYST_UNSUPPORTED (mode 1)
+// when some rank cannot export / map a landing buffer or a neighbour relation is one-way: every rank then stays on RCCL.  *active: the
+// mode in use.  The results are bit-identical either way (the same values land in the same halo slots).
+int32_t kryst_csr_halo_mode(kryst_csr_t a, int32_t mode, int32_t* active) {
+    KR_ARG(a && (mode == 0 || mode == 1), "csr_halo_mode");
+    KR_ARG(a->ctx->active_ws == nullptr, "csr_halo_mode: a solve or stepping session is open on this context");
+    int32_t rc = KRYST_OK;
+    if (a->dist && a->ctx->comm) {
+        KR_HIP(hipSetDevice(a->ctx->device));
+        KR_HIP(hipStreamSynchronize(a->ctx->s_comm));
+        KR_HIP(hipStreamSynchronize(a->ctx->s_main));
+        a->halo_started_for = nullptr;
+        if (mode == 1) rc = halo_peer_setup(a);
+        else a->plan.peer.on = false;            // (the landing buffers stay mapped: switching back costs nothing)
+    }
+    if (active) *active = a->plan.peer.on ? 1 : 0;
+    return rc;
+}
 
 int32_t kryst_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y) {
     KR_ARG(a && x && y, "spmv");

@@ -184,6 +184,42 @@ def run_rank(rank, P, outdir, N, kind):
             sess.end()
         assert np.array_equal(x.to_host(), out["sess_x"]), "ipc session"
         assert ctx.scalar_reduce("rccl") == "rccl"
+    # the halo exchange by direct peer stores (kryst_csr_halo_mode: push kernel into the neighbours' hipIpc-mapped landing buffers, epoch
+    # stamps, pull kernel in front of the boundary tiles): every solver again on the RCCL scalar path and once more with BOTH hipIpc paths
+    # together, bit for bit the results above
+    stage(rank, "halo_mode peer")
+    hmode = a.halo_mode("peer")
+    out["peer_active"] = np.array([1 if hmode == "peer" else 0])
+    if hmode == "peer":
+        b2 = a.spmv(ctx.vec(nloc).fill(1.0))
+        assert np.array_equal(b2.to_host(), out["b"]), "peer spmv"
+        for both in (False, True):
+            if both and ctx.scalar_reduce("ipc") != "ipc":
+                break
+            for name, s, pc in runs + extra:
+                stage(rank, ("peer+ipc solve " if both else "peer solve ") + name)
+                s.clear_history()
+                x = ctx.vec(nloc)
+                st = s.solve(a, pc, b, x)
+                assert np.array_equal(x.to_host(), out[name + "_x"]), ("peer", both, name)
+                assert np.array_equal(np.array(s.residual_history), out[name + "_hist"]), ("peer", both, name)
+                assert (st.iterations, float(st.converged), st.final_residual) == tuple(out[name + "_stats"]), ("peer", both, name)
+            stage(rank, "peer session")
+            x = ctx.vec(nloc)
+            with K.Session("cg", a, None, b, x, tol=0.0, max_iters=25) as sess:
+                sess.step(5); sess.step(20)
+                sess.end()
+            assert np.array_equal(x.to_host(), out["sess_x"]), ("peer session", both)
+        ctx.scalar_reduce("rccl")
+        # messages pushed from the second stream instead of the compute stream (the form large planes take)
+        os.environ["KRYST_HALO_INLINE_BYTES"] = "0"
+        stage(rank, "peer solve cg (push on the second stream)")
+        s = runs[0][1]; s.clear_history()
+        x = ctx.vec(nloc)
+        s.solve(a, None, b, x)
+        assert np.array_equal(x.to_host(), out["cg_x"]), "peer, second stream"
+        os.environ.pop("KRYST_HALO_INLINE_BYTES", None)
+        assert a.halo_mode("rccl") == "rccl"
     stage(rank, "barrier")
     ctx.barrier()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)

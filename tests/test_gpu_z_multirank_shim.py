@@ -65,6 +65,8 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     R = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(P)]
     # the worker repeated every solve on the IPC-mailbox path of the scalar all-reduce and compared it with the RCCL path itself
     assert all(int(r["ipc_active"][0]) == 1 for r in R), "the hipIpc mailbox path could not be set up between the ranks of this box"
+    # ... and with the halo exchange by direct peer stores (kryst_csr_halo_mode), alone and together with the mailboxes
+    assert all(int(r["peer_active"][0]) == 1 for r in R), "the peer-store halo exchange could not be set up between the ranks of this box"
     T, V, F = K.reduce_spec()
     if kind in ("random", "mixed"):
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -18,6 +18,9 @@ for i in range(inst):
     y = ctx.vec(n)
     b = 12 * a.nnz + 4 * (n + 1) + 16 * n
     t = [a.bench_spmv(x, y, fused_dots=1, reps=20) for _ in range(3)]
-    print(f"instance {i}: {min(t):.4f} .. {max(t):.4f} ms  {b / min(t) / 1e6 / 8000:.3f}", flush=True)
+    # the kernel's traffic skeleton on the SAME arrays (round 4): does the mix's own ceiling move with the allocation?
+    sk = [a.bench_csr_skeleton(x, y, reps=10) for _ in range(3)] if os.environ.get("KRYST_SPMV_COMPRESS") == "0" else [float("nan")]
+    print(f"instance {i}: {min(t):.4f} .. {max(t):.4f} ms  {b / min(t) / 1e6 / 8000:.3f}   skeleton {min(sk):.4f} .. {max(sk):.4f} ms  "
+          f"kernel / skeleton {min(t) / min(sk):.3f}", flush=True)
     del a, x, y
     pads.append(ctx.vec(1000003 * (i + 1)))          # shifts what the next instance gets
