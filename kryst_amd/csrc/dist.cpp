@@ -127,7 +127,11 @@ void ipc_reduce_destroy(kryst_ctx_t ctx) {
 // addresses it (own entry: mine).  A peer that lives in this very process (several ranks of one process, one host thread each) is
 // addressed directly -- hipIpcOpenMemHandle refuses a handle of its own process -- after peer access to its device has been enabled.
 // Collective; the outcome is agreed: KRYST_OK on every rank, or KRYST_UNSUPPORTED (nothing left mapped) on every rank.
-int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, std::vector<void*>& opened) {
+// same_device_siblings = false refuses ranks of this process that share this rank's DEVICE (a rehearsal set-up: several rank threads on
+// one GPU): for them a kernel of one rank that waits for a kernel the sibling's host thread has yet to enqueue can wait for ever, because
+// host calls of that thread which synchronise the device or stage through the runtime (hipFree, a copy to pageable memory) wait for the
+// waiting kernel first -- measured: tools/peer_debug.py, DESIGN.md section 6.
+int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, std::vector<void*>& opened, bool same_device_siblings) {
     KR_ARG(ctx->comm, "ipc_map_peers: context has no communicator");
     const int P = ctx->nranks, me = ctx->rank;
     constexpr int W = 12;                      // words per rank: ok, pid, device, address, handle[8]
@@ -157,6 +161,7 @@ int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, st
         if (p == me) { peers[p] = mine; continue; }
         if (w[1] == (int64_t)getpid()) {                             // a rank of this process: same address space
             const int pdev = (int)w[2];
+            if (pdev == ctx->device && !same_device_siblings) { ok_all = 0; break; }      // (the caller's kernels must not wait on a sibling that shares the device)
             if (pdev != ctx->device) {
                 int can = 0;
                 if (hipDeviceCanAccessPeer(&can, ctx->device, pdev) != hipSuccess || !can) { (void)hipGetLastError(); ok_all = 0; break; }
@@ -213,7 +218,8 @@ int32_t ipc_reduce_setup(kryst_ctx_t ctx) {
         (void)hipFree(ctx->ipc_mine); ctx->ipc_mine = nullptr;
     }
     std::vector<void*> peers;
-    int32_t rc = ipc_map_peers(ctx, ctx->ipc_mine, peers, ctx->ipc_opened);
+    // (the mailbox kernels of a solve are enqueued by every rank before any of them blocks: siblings on one device are fine here)
+    int32_t rc = ipc_map_peers(ctx, ctx->ipc_mine, peers, ctx->ipc_opened, true);
     if (rc == KRYST_OK && (hipMemcpyAsync(ctx->d_ipc_peers, peers.data(), sizeof(double*) * P, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess ||
                            hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;      // (cannot fail on one rank alone in practice: an 8 P byte copy)
     if (rc != KRYST_OK) { ipc_reduce_destroy(ctx); return rc; }

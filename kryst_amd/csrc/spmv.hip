@@ -1131,6 +1131,12 @@ __global__ __launch_bounds__(256) void halo_pull_kernel(const double* __restrict
         halo[sg.off + i] = good ? __hip_atomic_load(landing + sg.off + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __longlong_as_double(0x7FF8000000000000ll);
 }
 
+// the landing buffer's first state (data and stamps zero), written with the stores its later writers use
+__global__ void halo_landing_init_kernel(double* landing, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) __hip_atomic_store(landing + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 void halo_peer_destroy(kryst_csr_t a) {
     HaloPeer& hp = a->plan.peer;
     for (void* q : hp.opened) (void)hipIpcCloseMemHandle(q);
@@ -1156,13 +1162,15 @@ int32_t halo_peer_setup(kryst_csr_t a) {
     for (int p = 0; p < P; ++p) mutual = mutual && ((pl.send_counts[p] > 0) == (pl.recv_counts[p] > 0));
     hp.stride = std::max<int64_t>(2, (pl.total_recv + 1) & ~(int64_t)1);
     const size_t bytes = sizeof(double) * (size_t)(2 * hp.stride + 2 * P);
-    if (!mutual || hipExtMallocWithFlags((void**)&hp.landing, bytes, hipDeviceMallocFinegrained) != hipSuccess ||
-        hipMemsetAsync(hp.landing, 0, bytes, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipFree(hp.landing); hp.landing = nullptr;
+    if (!mutual || hipExtMallocWithFlags((void**)&hp.landing, bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); hp.landing = nullptr; }
+    if (hp.landing) {
+        const int64_t cnt = (int64_t)(bytes / sizeof(double));
+        hipLaunchKernelGGL(halo_landing_init_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->s_main, hp.landing, cnt);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(hp.landing); hp.landing = nullptr; }
     }
     std::vector<void*> peers;
-    int32_t rc = ipc_map_peers(ctx, hp.landing, peers, hp.opened);
+    // (a pull kernel waits for a push its neighbour's host thread enqueues LATER -- at its next exchange: rank threads that share one device are refused)
+    int32_t rc = ipc_map_peers(ctx, hp.landing, peers, hp.opened, false);
     if (rc != KRYST_OK) { halo_peer_destroy(a); return rc; }
     // where my rows land in each neighbour's buffer: every rank's {stride, recv_off[0..P)} in one all-gather
     std::vector<int64_t> mine((size_t)P + 1), all((size_t)(P + 1) * P, 0);
@@ -1191,6 +1199,12 @@ int32_t halo_peer_setup(kryst_csr_t a) {
         }
     }
     hp.npush = (int)push.size(); hp.npull = (int)pull.size();
+    if (env_int("KRYST_HALO_DEBUG", 0)) {
+        fprintf(stderr, "[kryst halo rank %d] landing %p stride %lld total_recv %lld\n", me, (void*)hp.landing, (long long)hp.stride, (long long)pl.total_recv);
+        for (int p = 0; p < P; ++p) fprintf(stderr, "[kryst halo rank %d]   peer %d -> %p\n", me, p, peers[p]);
+        for (auto& q : push) fprintf(stderr, "[kryst halo rank %d]   push dst %p stamp %p dst_stride %lld src %lld count %lld\n", me, (void*)q.dst, (void*)q.stamp, (long long)q.dst_stride, (long long)q.src, (long long)q.count);
+        for (auto& q : pull) fprintf(stderr, "[kryst halo rank %d]   pull stamp %p off %lld count %lld\n", me, (const void*)q.stamp, (long long)q.off, (long long)q.count);
+    }
     if (hp.npush > 256) { halo_peer_destroy(a); set_error("halo by peer stores: more than 256 neighbours"); return KRYST_UNSUPPORTED; }   // (cannot differ... every rank has P - 1 at most)
     KR_HIP(hipMalloc(&hp.d_push, sizeof(HaloPushSeg) * (push.size() + 1)));
     KR_HIP(hipMalloc(&hp.d_pull, sizeof(HaloPullSeg) * (pull.size() + 1)));

@@ -8,7 +8,7 @@ if ROOT not in sys.path:
 # Order of the -m gpu tier: the kernel-level HIP-vs-oracle parity suite first, then the solver / full-size files, and the tests
 # that start other processes (C++ mirror, RCCL with one rank, several ranks on one GPU) last -- so that `pytest -x` can never
 # again stop in a subprocess test before the parity suite has run ("What's weak" 2).
-_ORDER = ["test_gpu_0_parity", "test_golden", "test_gpu_cgs_tfqmr", "test_gpu_fgmres", "test_gpu_fullsize",
+_ORDER = ["test_gpu_0_parity", "test_golden", "test_gpu_cgs_tfqmr", "test_gpu_fgmres", "test_gpu_fullsize", "test_gpu_fullsize_oracle",
           "test_gpu_x_cpp_mirror", "test_gpu_y_dist_single", "test_gpu_z_multirank_shim", "test_gpu_z_bench_rehearsal"]
 
 

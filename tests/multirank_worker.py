@@ -26,6 +26,7 @@ def random_system(n):
 
 
 _T0 = time.time()
+THREADED = False
 
 
 def stage(rank, name):
@@ -55,6 +56,8 @@ def main():
         return run_rank(ranks[0], P, outdir, N, kind)
     # several ranks of ONE process, a host thread each (a GPU box admits at most 6 processes on its card: 8 ranks = 4 x 2)
     import threading
+    global THREADED
+    THREADED = True
     errs = []
 
     def guarded(r):
@@ -189,6 +192,8 @@ def run_rank(rank, P, outdir, N, kind):
     # together, bit for bit the results above
     stage(rank, "halo_mode peer")
     hmode = a.halo_mode("peer")
+    if THREADED:                 # rank threads that share one device are refused (dist.cpp: ipc_map_peers) -- on every rank alike
+        assert hmode == "rccl", hmode
     out["peer_active"] = np.array([1 if hmode == "peer" else 0])
     if hmode == "peer":
         b2 = a.spmv(ctx.vec(nloc).fill(1.0))
@@ -201,8 +206,14 @@ def run_rank(rank, P, outdir, N, kind):
                 s.clear_history()
                 x = ctx.vec(nloc)
                 st = s.solve(a, pc, b, x)
-                assert np.array_equal(x.to_host(), out[name + "_x"]), ("peer", both, name)
-                assert np.array_equal(np.array(s.residual_history), out[name + "_hist"]), ("peer", both, name)
+                xh, hh = x.to_host(), np.array(s.residual_history)
+                if not np.array_equal(xh, out[name + "_x"]) or not np.array_equal(hh, out[name + "_hist"]):      # say what differs before failing
+                    bad = np.flatnonzero(xh != out[name + "_x"])
+                    hb = np.flatnonzero(hh[:len(out[name + "_hist"])] != out[name + "_hist"][:len(hh)])
+                    print(f"[rank {rank}] PEER MISMATCH {name} both={both}: {len(bad)} of {len(xh)} x entries differ (first {bad[:4]}), history lengths "
+                          f"{len(hh)} / {len(out[name + '_hist'])}, first differing history entry {hb[:1]}", flush=True)
+                assert np.array_equal(xh, out[name + "_x"]), ("peer", both, name)
+                assert np.array_equal(hh, out[name + "_hist"]), ("peer", both, name)
                 assert (st.iterations, float(st.converged), st.final_residual) == tuple(out[name + "_stats"]), ("peer", both, name)
             stage(rank, "peer session")
             x = ctx.vec(nloc)

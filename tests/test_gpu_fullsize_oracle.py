@@ -1,0 +1,89 @@
+"""Full-size parity AGAINST THE ORACLE (VERDICT r03 "missing" 3): BASELINE.json's 256^3 configurations solved on the GPU and by the
+CPU restatement of the reference (oracle/kryst_oracle.c, 16 OpenMP threads for the pointwise loops; test infrastructure), whole residual
+histories compared -- bit for bit in the library's dot order, and within north_star's 1e-12 * ||r0|| of the reference's strict serial
+left fold (src/core/wrappers.rs:101-107).  The oracle is the checker; nothing here is timed."""
+import os
+
+import numpy as np
+import pytest
+
+import kryst_amd as K
+
+pytestmark = pytest.mark.gpu
+N = 256
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return K.Context(0)
+
+
+def _oracle_system(kind):
+    from oracle import oracle as O
+    O.set_threads(min(len(os.sched_getaffinity(0)), 16))
+    rp, ci, va = K.host_stencil7(N, kind)
+    a = O.Csr(N ** 3, N ** 3, rp, ci, va, check=False)
+    return O, a, a.spmv(np.ones(a.nrows))
+
+
+def _compare(name, gpu_hist, gpu_stats, gpu_x, ref_tiled, ref_serial, serial_tol):
+    h = np.array(gpu_hist)
+    # the library's association tree (kryst_reduce_spec): everything bit for bit
+    assert (gpu_stats.iterations, bool(gpu_stats.converged), gpu_stats.final_residual) == (ref_tiled.iterations, ref_tiled.converged, ref_tiled.final_residual), name
+    assert len(h) == len(ref_tiled.history) and np.array_equal(h, ref_tiled.history), name
+    assert np.array_equal(gpu_x, ref_tiled.x), name
+    # the reference's --no-default-features fold: same iteration count, history within the stated tolerance of ||r0||
+    assert ref_serial.iterations == gpu_stats.iterations, name
+    dev = float(np.max(np.abs(h - ref_serial.history)) / ref_serial.history[0])
+    print(f"[full-size parity] {name}: {gpu_stats.iterations} iterations, {len(h)} history entries bit-identical to the tiled-order oracle; "
+          f"max |history - serial-fold history| / ||r0|| = {dev:.3e} (bound {serial_tol:.0e})")
+    assert dev <= serial_tol, (name, dev)
+    return dev
+
+
+def test_config2_cg_256_cubed_full_history_equals_the_oracle(ctx):
+    """BASELINE config 2 as written: unpreconditioned CG on 256^3 Poisson, tol 1e-8, max 2000 (cg.rs:114-288) -- all ~580 iterations."""
+    O, a, b = _oracle_system("poisson")
+    T, V, F = K.reduce_spec()
+    ga = K.CsrMatrix.stencil7(N, "poisson", ctx=ctx)
+    gb = ga.spmv(ctx.vec(N ** 3).fill(1.0))
+    assert np.array_equal(gb.to_host(), b)
+    s = K.CgSolver(1e-8, 2000)
+    x = ctx.vec(N ** 3)
+    st = s.solve(ga, None, gb, x)
+    assert st.converged and st.iterations > 300
+    ref_t = O.solve("cg", a, b, tol=1e-8, max_iters=2000, rs=O.Reduce.tiled(T, V, F))
+    ref_s = O.solve("cg", a, b, tol=1e-8, max_iters=2000, rs=O.Reduce.serial())
+    _compare("config 2: CG 256^3 to 1e-8", s.residual_history, st, x.to_host(), ref_t, ref_s, 1e-12)
+
+
+def test_config4_jacobi_pcg_256_cubed_hundred_iterations_equal_the_oracle(ctx):
+    """Config 4's solver (Jacobi-PCG, pcg.rs:114-222) at the size ONE rank of the 8-way 512^3 partition holds: 100 iterations, tol 0."""
+    O, a, b = _oracle_system("poisson")
+    T, V, F = K.reduce_spec()
+    ga = K.CsrMatrix.stencil7(N, "poisson", ctx=ctx)
+    gb = ga.spmv(ctx.vec(N ** 3).fill(1.0))
+    s = K.PcgSolver(0.0, 100)
+    x = ctx.vec(N ** 3)
+    st = s.solve(ga, K.Jacobi().setup(ga), gb, x)
+    assert st.iterations == 100
+    ref_t = O.solve("pcg", a, b, pc=O.Pc.jacobi(a), tol=0.0, max_iters=100, rs=O.Reduce.tiled(T, V, F))
+    ref_s = O.solve("pcg", a, b, pc=O.Pc.jacobi(a), tol=0.0, max_iters=100, rs=O.Reduce.serial())
+    _compare("config 4's solver: Jacobi-PCG 256^3, 100 iterations", s.residual_history, st, x.to_host(), ref_t, ref_s, 1e-12)
+
+
+def test_config5_bicgstab_256_cubed_hundred_iterations_equal_the_oracle(ctx):
+    """Config 5's solver as the reference has it (BiCGStab, pc ignored, bicgstab.rs:69-293) on the 256^3 anisotropic operator: 100
+    iterations.  Bit-identical in the library's dot order; against the serial fold BiCGStab's recurrences amplify the association
+    rounding, so the bound is the 1e-9 * ||r0|| DESIGN section 2 states for it -- the measured deviation is printed."""
+    O, a, b = _oracle_system("aniso")
+    T, V, F = K.reduce_spec()
+    ga = K.CsrMatrix.stencil7(N, "aniso", ctx=ctx)
+    gb = ga.spmv(ctx.vec(N ** 3).fill(1.0))
+    assert np.array_equal(gb.to_host(), b)
+    s = K.BiCgStabSolver(0.0, 100)
+    x = ctx.vec(N ** 3)
+    st = s.solve(ga, None, gb, x)
+    ref_t = O.solve("bicgstab", a, b, tol=0.0, max_iters=100, rs=O.Reduce.tiled(T, V, F))
+    ref_s = O.solve("bicgstab", a, b, tol=0.0, max_iters=100, rs=O.Reduce.serial())
+    _compare("config 5's solver: BiCGStab 256^3 anisotropic, 100 iterations", s.residual_history, st, x.to_host(), ref_t, ref_s, 1e-9)
