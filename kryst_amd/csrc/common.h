@@ -128,9 +128,9 @@ struct kryst_ctx_s {
     const void* active_ws = nullptr;
     // Scalar all-reduce without a collective launch (dist.cpp: ipc_reduce_*): every rank owns a fine-grained mailbox that the
     // others map through hipIpc; the kernel that finishes a rank's local fold stores its partials into every peer's mailbox
-    // (system-scope write-through stores, epoch stamp last), polls its own mailbox for the peers' stamps and folds in rank order --
+    // (self-validating cells: each 8-byte word carries half a value and the epoch's tag), polls its own mailbox and folds in rank order --
     // the same bits as the RCCL all-gather + ordered fold, one launch instead of two launches and a collective.
-    double* ipc_mine = nullptr;                  // 2 parities x nranks cells of 16 doubles: [parity][writer rank]{q0..q7, epoch, pad}
+    double* ipc_mine = nullptr;                  // 2 parities x nranks cells of 16 words: [parity][writer rank]{(low half | tag), (high half | tag)} x 8 quantities (solver_common.h)
     double** d_ipc_peers = nullptr;              // device array: peer p's mailbox as mapped into this process (own entry: ipc_mine)
     std::vector<void*> ipc_opened;               // mappings to close
     unsigned long long* d_ipc_epoch = nullptr;   // reductions completed so far (device)

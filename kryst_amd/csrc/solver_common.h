@@ -107,11 +107,14 @@ __global__ void rank_fold_logic_kernel(const double* gathered, int nranks, const
 }
 
 // several ranks, mailbox path (kryst_ctx_s::ipc_*): local two-level fold, exchange and rank-ordered fold + logic in ONE launch.
-// The workgroup that ends up with the local result sends it (lane p -> rank p's mailbox cell [epoch parity][my rank]: the values
-// as system-scope write-through stores, waited for, then the epoch stamp), polls its own mailbox until rank p's stamp carries this
-// epoch, and folds the P cells in rank order (total = r0; total = total + r_p): the bits of the all-gather path.  Two cells per
-// writer (epoch parity) suffice: a rank can be at most one reduction ahead of the slowest one, because finishing reduction e needs
-// everybody's contribution to e.  A peer that never shows up (budget) ends the solve with KRYST_ERR_RCCL instead of a hung GPU.
+// The workgroup that ends up with the local result sends it -- lane p -> rank p's mailbox cell [epoch parity][my rank] -- polls its own
+// mailbox for rank p's message of this epoch, and folds the P values in rank order (total = r0; total = total + r_p): the bits of the
+// all-gather path.  Round 4: the cells are SELF-VALIDATING -- a value travels as two 8-byte words, (low half | tag) and (high half | tag),
+// tag = the epoch's low 31 bits with the top bit set, each word one system-scope store that is atomic on its own; the receiver takes a
+// value when both tags match.  No acknowledge wait between data and stamp, no stamp: one round trip less per inner product than the
+// round-3 form (values, s_waitcnt vmcnt(0), stamp).  Two cells per writer (epoch parity) suffice: a rank can be at most one reduction
+// ahead of the slowest one, because finishing reduction e needs everybody's contribution to e.  A peer that never shows up (budget) ends
+// the solve with KRYST_ERR_RCCL instead of a hung GPU.
 struct IpcView { double* mine; double* const* peers; unsigned long long* epoch; int me, P, budget; };
 template <int NQ, class L>
 __global__ __launch_bounds__(KR_F) void fold_ipc_logic_kernel(const double* partials, int64_t stride, int64_t ntiles,
@@ -130,33 +133,50 @@ __global__ __launch_bounds__(KR_F) void fold_ipc_logic_kernel(const double* part
     const int p = threadIdx.x;
     const unsigned long long e = *v.epoch + 1;
     const int par = (int)(e & 1ull);
-    double* const dst = p < v.P ? v.peers[p] + (size_t)(par * v.P + v.me) * 16 : nullptr;
+    const unsigned long long tag = ((e & 0x7fffffffull) | 0x80000000ull) << 32;
     if (p < v.P) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(v.peers[p] + (size_t)(par * v.P + v.me) * 16);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) __hip_atomic_store(dst + q, val[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int q = 0; q < NQ; ++q) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(val[q]);
+            __hip_atomic_store(dst + 2 * q, (bits & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dst + 2 * q + 1, (bits >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the values have been acknowledged before the stamp goes out
-    if (p < v.P) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + 8), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     bool ok = true;
+    double got[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) got[q] = 0.0;
     if (p < v.P) {
-        const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(v.mine + (size_t)(par * v.P + p) * 16 + 8);
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(v.mine + (size_t)(par * v.P + p) * 16);
         int b = v.budget;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
-            if (--b <= 0) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            unsigned long long w0 = __hip_atomic_load(src + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            unsigned long long w1 = __hip_atomic_load(src + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            while (((w0 ^ tag) >> 32) != 0ull || ((w1 ^ tag) >> 32) != 0ull) {
+                if (--b <= 0) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(2);
+                w0 = __hip_atomic_load(src + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                w1 = __hip_atomic_load(src + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            got[q] = __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
         }
     }
     const bool all_ok = __all(ok);
+    // rank-ordered fold: lane r holds rank r's values
+    double total[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        total[q] = __shfl(got[q], 0, 64);
+        for (int r = 1; r < v.P; ++r) total[q] = total[q] + __shfl(got[q], r, 64);
+    }
     if (p != 0) return;
     *v.epoch = e;
     if (!all_ok) { logic.c.finish(KRYST_ERR_RCCL); return; }
     if (f == 2) { logic.c.finish(KRYST_ERR_HIP); return; }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        double total = __hip_atomic_load(v.mine + (size_t)(par * v.P) * 16 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        for (int r = 1; r < v.P; ++r) total = total + __hip_atomic_load(v.mine + (size_t)(par * v.P + r) * 16 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        red_out[q] = total;
-    }
+    for (int q = 0; q < NQ; ++q) red_out[q] = total[q];
     logic.run(red_out);
 }
 

@@ -11,10 +11,14 @@ grid = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 uid = K.Context.unique_id()
 ctx_d = K.Context(0, 0, 1, uid)
 ctx_s = K.Context(0)
-for name, ctx, mode in (("single-GPU path", ctx_s, None), ("collective path, RCCL all-gather", ctx_d, "rccl"), ("collective path, hipIpc mailboxes", ctx_d, "ipc")):
+for name, ctx, mode, halo in (("single-GPU path", ctx_s, None, None), ("collective path, RCCL all-gather, RCCL halo", ctx_d, "rccl", "rccl"),
+                             ("collective path, hipIpc mailboxes, RCCL halo", ctx_d, "ipc", "rccl"),
+                             ("collective path, hipIpc mailboxes, halo by peer stores", ctx_d, "ipc", "peer")):
     if mode and ctx.scalar_reduce(mode) != mode:
         print(f"{name}: unavailable"); continue
     a = K.CsrMatrix.stencil7(grid, "poisson", ctx=ctx)
+    if halo and a.halo_mode(halo) != halo:
+        print(f"{name}: unavailable"); continue
     n = a.nrows()
     b = a.spmv(ctx.vec(n).fill(1.0))
     best = None

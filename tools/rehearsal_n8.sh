@@ -9,7 +9,7 @@ G=${1:-512}; K=${2:-20}
 cd /root/repo
 O=gpurun_out/rehearsal; mkdir -p $O
 export KRYST_RCCL_LIB=/root/repo/tests/shim/librccl_shim.so KRYST_BENCH_DEVICE=0 HSA_ENABLE_IPC_MODE_LEGACY=0 GPU_MAX_HW_QUEUES=8 KRYST_BENCH_WATCHDOG_S=900
-[ -f $KRYST_RCCL_LIB ] || /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -shared -x hip --offload-arch=gfx950 tests/shim/rccl_shim.cpp -o $KRYST_RCCL_LIB -I/opt/rocm/include -lrt || exit 1
+[ -f $KRYST_RCCL_LIB ] && [ ! tests/shim/rccl_shim.cpp -nt $KRYST_RCCL_LIB ] || /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -shared -x hip --offload-arch=gfx950 tests/shim/rccl_shim.cpp -o $KRYST_RCCL_LIB -I/opt/rocm/include -lrt || exit 1
 for L in torch socket; do
   timeout -k 10 1000 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port $((29600 + RANDOM % 300)) \
       bench.py --gpus 8 --solver pcg --steps $K --warmup 5 --grid $G --launcher $L --phase-iters 10 --ranks-per-process 2 \
