@@ -32,8 +32,9 @@ def _build_shim():
                                                  # EIGHT ranks -- config 4's partition -- as 4 processes x 2 rank threads (a GPU box admits at most 6
                                                  # processes on its card): k-slabs of 4 planes of a 32^3 grid, and a general operator
                                                  (8, 32, "poisson", "0+light+t2"), (8, 4000, "random", "0+light+t2"),
-                                                 # six PROCESSES (the most a GPU box admits): the peer-store halo exchange and the mailboxes between six ranks
-                                                 (6, 24, "poisson", "0+light"), (6, 3000, "random", "0+light")])
+                                                 # five PROCESSES (with the test runner itself six have the GPU open: the most a GPU box admits): the
+                                                 # peer-store halo exchange and the mailboxes between five ranks
+                                                 (5, 20, "poisson", "0+light"), (5, 3000, "random", "0+light")])
 def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     from oracle import oracle as O
     import kryst_amd as K
@@ -68,7 +69,7 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     # the worker repeated every solve on the IPC-mailbox path of the scalar all-reduce and compared it with the RCCL path itself
     assert all(int(r["ipc_active"][0]) == 1 for r in R), "the hipIpc mailbox path could not be set up between the ranks of this box"
     # ... and with the halo exchange by direct peer stores (kryst_csr_halo_mode), alone and together with the mailboxes
-    # (not between rank THREADS that share the device -- refused by design, see dist.cpp: ipc_map_peers -- the 6-rank case covers more ranks)
+    # (not between rank THREADS that share the device -- refused by design, see dist.cpp: ipc_map_peers -- the 5-process cases cover more ranks)
     assert all(int(r["peer_active"][0]) == (0 if per > 1 else 1) for r in R), "the peer-store halo exchange could not be set up between the ranks of this box"
     T, V, F = K.reduce_spec()
     if kind in ("random", "mixed"):
