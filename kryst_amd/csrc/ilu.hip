@@ -608,9 +608,8 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D, const TriDirect* direct 
             const QuadView QB{B.Ni, B.Nj, B.Nk, B.nbj, B.nbk, B.nch, (const tw_v2*)B.d_blocked, B.d_edge_e, B.d_edge_n, B.d_skip};
             // (no per-apply launch re-arms the edge buffers or the flags: tri_quad.h, poller / epoch)
             const TriDirect dir = direct ? *direct : TriDirect{nullptr, nullptr, nullptr, 0};
-            const int hyst = std::min(4, std::max(1, env_int("KRYST_ILU_HYST", 1)));      // tri_quad.h: steps a caught-up quadrant lets its sibling get ahead before it goes on
-            hipLaunchKernelGGL((tri_quad_kernel<true>), dim3(nq), dim3(512), 0, s, D->d_args, (const double*)nullptr, D->d_y, QA, D->n, D->d_flags, D->d_flags + 2 * nb, D->d_gave_up, budget, dir, hyst);
-            hipLaunchKernelGGL((tri_quad_kernel<false>), dim3(nq), dim3(512), 0, s, D->d_args, (const double*)D->d_y, (double*)nullptr, QB, D->n, D->d_flags + nb, D->d_flags + 2 * nb, D->d_gave_up, budget, dir, hyst);
+            hipLaunchKernelGGL((tri_quad_kernel<true>), dim3(nq), dim3(512), 0, s, D->d_args, (const double*)nullptr, D->d_y, QA, D->n, D->d_flags, D->d_flags + 2 * nb, D->d_gave_up, budget, dir);
+            hipLaunchKernelGGL((tri_quad_kernel<false>), dim3(nq), dim3(512), 0, s, D->d_args, (const double*)D->d_y, (double*)nullptr, QB, D->n, D->d_flags + nb, D->d_flags + 2 * nb, D->d_gave_up, budget, dir);
             KR_HIP(hipGetLastError());
             return KRYST_OK;
         }

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void tri_quad_fill_kernel(double* edge_e, doub
 struct TriDirect { const double* r; double* z; const int* done; int32_t epoch; };
 template <bool FORWARD>
 __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, QuadView Q, int64_t n,
-                                                          int32_t* flags, int32_t* abort_word, int32_t* gave_up, int poll_budget, const TriDirect dir, const int hyst) {
+                                                          int32_t* flags, int32_t* abort_word, int32_t* gave_up, int poll_budget, const TriDirect dir) {
     if (dir.epoch != 0 ? (dir.done && *dir.done) : (args->skip != 0)) return;
     const int32_t epoch = dir.epoch != 0 ? dir.epoch : (int32_t)args->epoch;   // this apply's number: the value of an "under way" flag (nothing resets the flags)
     constexpr int C = TQ_C, S = TQ_S, R = TQ_R;
@@ -527,7 +527,6 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
     const double* const s_ptr = s_sib ? yring + (q - 2) * YR * 64 + 56 + jl : pring + (2 + qj) * R * 8 + jl;
     const int w_off = w_sib ? 7 : 0, w_mask = w_sib ? YR - 1 : R - 1, w_stride = w_sib ? 64 : 8;
     const int s_off = s_sib ? 7 : 0, s_mask = s_sib ? YR - 1 : R - 1, s_stride = s_sib ? 64 : 8;
-    const int h_w = w_sib ? hyst : 1, h_s = s_sib ? hyst : 1;
     int* const w_cnt = w_sib ? &prog[q - 1] : w_poll ? &pavail[qk == 0 ? 0 : 1] : &always;
     int* const s_cnt = s_sib ? &prog[q - 2] : s_poll ? &pavail[2 + qj] : &always;
     // who reads this quadrant's ring (back-pressure): sibling quadrants and exporter streams
@@ -639,16 +638,10 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #ifdef KR_TW_TRACE
                 const long long tw0 = wall_clock64();
 #endif
-                // A quadrant that has caught up with a SIBLING would look the sibling's counter up again at every step -- an LDS round trip and a
-                // nap per step, 0.3-0.36 us instead of the free-running 0.15-0.22, so it falls behind its producer step by step.
-                // Round 4: once it has to wait, it waits until the sibling is `hyst` steps further (h_w / h_s: 1 for a poller stream, whose rows
-                // arrive in rounds anyway) and then runs that many steps without looking.  No deadlock: the sibling needs this wave to have
-                // TAKEN chunk (t + 7 + hyst) / 8 - 4 at most, and hyst <= 4 keeps that below the chunk this wave is in.
 #pragma unroll 1
                 for (int budget = 1 << 26; budget > 0; --budget) {
-                    const int sw = tq_peek(w_cnt) - w_off, ss = tq_peek(s_cnt) - s_off;
-                    seen = __builtin_amdgcn_readfirstlane(min(sw, ss));
-                    if (__builtin_amdgcn_readfirstlane((int)(t + h_w <= sw && t + h_s <= ss))) break;
+                    seen = __builtin_amdgcn_readfirstlane(min(tq_peek(w_cnt) - w_off, tq_peek(s_cnt) - s_off));
+                    if (t < seen) break;
                     TQ_NAP(1);
                 }
                 TQ_ACC(11, tw0);

@@ -22,7 +22,7 @@ for g in 256 512; do
   python3 $R/tools/pmc_traffic.py $O/pmc_f${g}_varcoef $O/pmc_w${g}_varcoef $g $O/spmv${g}_varcoef_traffic.json $O/spmv_traffic.json varcoef > /dev/null || exit 1
 done
 cp $O/spmv_traffic.json $R/profiles/spmv_traffic.json   # (on the GPU box only: copy gpurun_out/round/spmv_traffic.json into profiles/ after the call)
-timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_prof -o bench -- python3 $R/bench.py > $O/bench_prof.log 2>&1 || exit 1
+KRYST_BENCH_LIVE_TRAFFIC=0 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_prof -o bench -- python3 $R/bench.py > $O/bench_prof.log 2>&1 || exit 1
 python3 $R/tools/kernel_by_size.py $O/bench_prof $O/bench_default_kernel_by_size.csv || exit 1
 for g in 256 512; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ilu_prof_$g -o ilu -- python3 $R/tools/ilu_only.py $g 20 true > $O/ilu_$g.log 2>&1 || exit 1
