@@ -63,7 +63,18 @@ class TorchGroup:
     def __init__(self, rank, world):
         import torch.distributed as dist
         self.dist, self.rank, self.world = dist, rank, world
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."), from C++: the line the driver reads must be the only
+        # thing on rank 0's stdout, so file descriptor 1 points at stderr while the group is set up and warmed
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     def broadcast_bytes(self, payload):
         box = [payload if self.rank == 0 else None]
