@@ -676,8 +676,9 @@ def tri_roofline(pc, r, z, n, nnz, reps=20):
 
 ILU_SETUP_NOTE = ("ilu_setup_ms = the SECOND setup of the same operator in this process (steady state: the device-side factorisation and the blocked "
                   "layout); ilu_setup_first_call_ms = the first one, which also pays for first-use work that is not the factorisation's: the code "
-                  "objects of the setup kernels are loaded and the large layout buffers are allocated and first touched (round 3's 72 / 255 / 519 ms "
-                  "at 512^3 were first calls at different points of a process's life)")
+                  "objects of the setup kernels are loaded and ~22 GB (512^3) of device memory are allocated for the first time -- fresh VRAM costs whatever the "
+                  "driver's page clearing costs at that moment: 80 ms to 2.2 s measured for the same call (profiles/r04/ilu_setup_512.txt; round 3's "
+                  "72 / 255 / 519 ms at 512^3 were first calls at different points of a process's life)")
 
 
 def ilu_setup_times(K, ctx, a):

@@ -1119,7 +1119,9 @@ __global__ __launch_bounds__(256) void halo_pull_kernel(const double* __restrict
     const HaloPullSeg sg = segs[blockIdx.y];
     __shared__ int ok;
     if (threadIdx.x == 0) {
-        int b = budget;
+        // (a pull that has given up once on this context stays given up until the host has read the error word: the exchanges a solver has
+        // already enqueued behind it must not burn the budget again, one after the other)
+        int b = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 1 : budget;
         unsigned long long seen = __hip_atomic_load(sg.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         while (seen < epoch && --b > 0) { __builtin_amdgcn_s_sleep(2); seen = __hip_atomic_load(sg.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
         ok = seen >= epoch ? 1 : 0;
