@@ -1,4 +1,4 @@
-//! Raw `extern "C"` declarations of include/kryst_hip.h (ABI version 2), one to one.  Everything returns an `i32` status:
+//! Raw `extern "C"` declarations of include/kryst_hip.h (ABI version 4), one to one.  Everything returns an `i32` status:
 //! 0 OK, 1..6 = `KError` (src/error.rs:6-19), >= 100 runtime / argument errors (`kryst_hip_last_error()` has the text).
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_void};

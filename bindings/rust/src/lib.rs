@@ -136,6 +136,15 @@ impl HipCsrMatrix {
     pub fn context(&self) -> &HipContext {
         &self.ctx
     }
+    /// The halo exchange of a row-partitioned operator (the neighbour exchange `src/parallel/mpi_comm.rs:133-143` leaves as a TODO):
+    /// `false` = grouped ncclSend / ncclRecv (default), `true` = direct peer stores into hipIpc-mapped landing buffers (no collective
+    /// launch, the same bits).  Collective over the context's ranks.  Returns whether the peer-store path is in use afterwards.
+    pub fn halo_peer_stores(&self, on: bool) -> Result<bool, KError> {
+        let mut active = 0i32;
+        let rc = unsafe { ffi::kryst_csr_halo_mode(self.h, if on { 1 } else { 0 }, &mut active) };
+        if rc != 0 && rc != 6 { check(rc)?; }
+        Ok(active != 0)
+    }
     /// `SparseMatrix::spmv` (sparse.rs:56-67) on host slices.
     pub fn spmv(&self, x: &[f64], y: &mut [f64]) {
         assert_eq!(x.len(), self.ncols);                                  // sparse.rs:57

@@ -104,6 +104,15 @@ public:
         check(kryst_spmv_host(h_, x.data(), (int64_t)x.size(), y.data(), (int64_t)y.size()));
     }
     void matvec(const Vec& x, Vec& y) const override { spmv(x, y); }
+    // The halo exchange of a row-partitioned operator (the neighbour exchange src/parallel/mpi_comm.rs:133-143 leaves as a TODO): false =
+    // grouped ncclSend / ncclRecv (default), true = direct peer stores into hipIpc-mapped landing buffers (no collective launch, the same
+    // bits).  Collective.  Returns whether the peer-store path is in use (it is not when a rank cannot map a peer's buffer).
+    bool halo_peer_stores(bool on) {
+        int32_t active = 0;
+        const int32_t rc = kryst_csr_halo_mode(h_, on ? 1 : 0, &active);
+        if (rc != KRYST_OK && rc != KRYST_UNSUPPORTED) check(rc);
+        return active != 0;
+    }
     kryst_csr_t handle() const { return h_; }
     const std::shared_ptr<Context>& context() const { return ctx_; }
 private:

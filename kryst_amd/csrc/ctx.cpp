@@ -66,7 +66,7 @@ extern "C" {
 
 const char* kryst_hip_last_error(void) { return g_err; }
 int64_t kryst_hip_last_error_row(void) { return g_err_row; }
-int32_t kryst_hip_abi_version(void) { return 3; }
+int32_t kryst_hip_abi_version(void) { return 4; }
 void kryst_reduce_spec(int32_t* T, int32_t* V, int32_t* F) {
     if (T) *T = KR_T;
     if (V) *V = KR_V;
