@@ -546,6 +546,39 @@ def test_triangular_solve_forms_bit_exact(ctx, syncfree, monkeypatch):
             assert np.array_equal(pc.apply(r), ref.apply(r)), (syncfree, a.nrows)
 
 
+@pytest.mark.parametrize("pipe", ["1", "0"])
+def test_narrow_level_runs_of_a_deep_factor_bit_exact(ctx, pipe, monkeypatch):
+    """The one-workgroup run kernels for deep, narrow factors (tri_run_pipe_kernel / tri_run_kernel, KRYST_ILU_SYNCFREE=0) on a factor of
+    40 000 rows and a thousand levels: dependencies in the previous level and tens of thousands of positions back, rows longer than the eight
+    entries held in registers, a level wider than the workgroup (1 500 independent rows) -- the oracle's bits.  (Round 4 rebuilt the
+    pipelined kernel three ways against this test -- LDS window, lazily waited stores, counted look-ahead, a prefetching workgroup: all
+    bit-exact, none faster, DESIGN.md section 8 -- and kept the round-3 kernel.)"""
+    import scipy.sparse as sp
+    monkeypatch.setenv("KRYST_ILU_SYNCFREE", "0"); monkeypatch.setenv("KRYST_ILU_RUN_PIPE", pipe)
+    lead = pipe
+    rng = np.random.default_rng(2024)
+    n, free = 40000, 1500
+    rows = np.repeat(np.arange(free, n), 9)
+    near = rows + rng.integers(-300, 301, len(rows))
+    far = rng.integers(0, n, len(rows))                                   # one entry in ten couples to ANY row: dependencies far below the window
+    cols = np.clip(np.where(rng.random(len(rows)) < 0.1, far, near), 0, n - 1)
+    m = sp.csr_matrix((rng.uniform(-1.0, 1.0, len(rows)), (rows, cols)), shape=(n, n)); m.sum_duplicates()
+    dense_rows = rng.choice(np.arange(free, n), 50, replace=False)        # rows with ~30 entries: longer than the held eight
+    extra = sp.csr_matrix((rng.uniform(-1.0, 1.0, 50 * 24), (np.repeat(dense_rows, 24), np.clip(np.repeat(dense_rows, 24) + rng.integers(-2000, 2001, 50 * 24), 0, n - 1))), shape=(n, n))
+    m = (m + extra).tocsr(); m.sum_duplicates()
+    m = m - sp.diags(m.diagonal()) + sp.diags(np.asarray(abs(m).sum(axis=1)).ravel() + 1.0)
+    m = m.tocsr(); m.sort_indices(); m.eliminate_zeros()
+    a = O.Csr(n, n, m.indptr, m.indices, m.data)
+    d = to_dev(ctx, a)
+    for kpc, ofn in ((K.TrueIlu0(), O.Pc.ilu0_true), (K.Ilu0(), O.Pc.ilu0_compat)):
+        pc = kpc.setup(d); ref = ofn(a)
+        info = pc.ilu_info()
+        assert info["form"].startswith("level") and min(info["levels"]) > 200, info
+        for seed in (1, 2):
+            r = O.splitmix64_uniform(seed, n) - 0.5
+            assert np.array_equal(pc.apply(r), ref.apply(r)), (lead, seed)
+
+
 @pytest.mark.parametrize("grid_path", ["quad", "1", "wave0", "0"])
 def test_structured_grid_triangular_solve_bit_exact(ctx, grid_path, monkeypatch):
     """Factors of 7-point / 5-point operators on an Ni x Nj x Nk box are solved by the pipelined wavefront kernel
