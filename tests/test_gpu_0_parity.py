@@ -546,6 +546,22 @@ def test_triangular_solve_forms_bit_exact(ctx, syncfree, monkeypatch):
             assert np.array_equal(pc.apply(r), ref.apply(r)), (syncfree, a.nrows)
 
 
+def test_measurement_hooks_of_round_4_leave_the_operator_alone(ctx):
+    """kryst_bench_csr_skeleton streams the operator's own CSR arrays (bench.py: roofline_csr.stream_skeleton) and writes garbage into y only;
+    kryst_csr_halo_mode on an operator that is not row-partitioned is a no-op that reports the RCCL mode; kryst_device_count sees the GPU."""
+    a = O.stencil7(12, "varcoef")
+    d = to_dev(ctx, a)
+    x = ctx.vec(a.nrows).fill_splitmix(11)
+    before = d.spmv(x).to_host()
+    y = ctx.vec(a.nrows)
+    ms = d.bench_csr_skeleton(x, y, reps=3)
+    assert ms > 0.0
+    assert np.array_equal(d.spmv(x).to_host(), before) and np.array_equal(before, a.spmv(x.to_host()))
+    assert d.halo_mode("peer") == "rccl" and d.halo_mode("rccl") == "rccl"
+    from kryst_amd._ffi import device_count
+    assert device_count() >= 1
+
+
 @pytest.mark.parametrize("pipe", ["1", "0"])
 def test_narrow_level_runs_of_a_deep_factor_bit_exact(ctx, pipe, monkeypatch):
     """The one-workgroup run kernels for deep, narrow factors (tri_run_pipe_kernel / tri_run_kernel, KRYST_ILU_SYNCFREE=0) on a factor of
