@@ -1,6 +1,6 @@
 #!/bin/bash
-# Copy what tools/profile_round.sh left under gpurun_out/round into profiles/rNN (run here, after the gpurun call).  usage: collect_round.sh r03
-P=profiles/${1:-r03}; O=gpurun_out/round
+# Copy what tools/profile_round.sh left under gpurun_out/round into profiles/rNN (run here, after the gpurun call).  usage: collect_round.sh r04
+P=profiles/${1:-r04}; O=gpurun_out/round
 cp $O/bench_n1.json $O/bench_default_kernel_by_size.csv $O/configs_256.jsonl $O/ilu_general.jsonl $P/
 find $O/bench_prof -name "*kernel_stats.csv" -exec cp {} $P/bench_default_kernel_stats.csv \;
 for f in spmv256_default spmv256_plain spmv256_varcoef spmv512_default spmv512_plain spmv512_varcoef; do cp $O/${f}_traffic.json $P/; done
