@@ -1156,6 +1156,7 @@ int32_t halo_peer_setup(kryst_csr_t a) {
     if (hp.landing) { hp.on = true; return KRYST_OK; }               // set up before and switched off: still mapped everywhere, epochs counted alike
     KR_ARG(a->dist && ctx->comm, "halo_peer_setup: not a distributed operator");
     const int P = ctx->nranks, me = ctx->rank;
+    KR_ARG(P <= 257, "halo by peer stores: at most 256 neighbours (one stamping lane each)");      // (the same answer on every rank: P is)
     KR_HIP(hipStreamSynchronize(ctx->s_comm));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
     // local: landing buffer (zeroed: stamps start at epoch 0); a rank that fails here, or whose neighbour relations are not mutual, still
@@ -1164,7 +1165,13 @@ int32_t halo_peer_setup(kryst_csr_t a) {
     for (int p = 0; p < P; ++p) mutual = mutual && ((pl.send_counts[p] > 0) == (pl.recv_counts[p] > 0));
     hp.stride = std::max<int64_t>(2, (pl.total_recv + 1) & ~(int64_t)1);
     const size_t bytes = sizeof(double) * (size_t)(2 * hp.stride + 2 * P);
-    if (!mutual || hipExtMallocWithFlags((void**)&hp.landing, bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); hp.landing = nullptr; }
+    // (everything this rank allocates is allocated BEFORE the collectives: a rank that fails alone afterwards would leave the others switched on)
+    if (!mutual || hipMalloc(&hp.d_push, sizeof(HaloPushSeg) * ((size_t)P + 1)) != hipSuccess || hipMalloc(&hp.d_pull, sizeof(HaloPullSeg) * ((size_t)P + 1)) != hipSuccess ||
+        hipMalloc(&hp.d_ticket, 64) != hipSuccess || hipMemsetAsync(hp.d_ticket, 0, 64, ctx->s_main) != hipSuccess ||
+        hipExtMallocWithFlags((void**)&hp.landing, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(hp.landing); hp.landing = nullptr;
+    }
     if (hp.landing) {
         const int64_t cnt = (int64_t)(bytes / sizeof(double));
         hipLaunchKernelGGL(halo_landing_init_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->s_main, hp.landing, cnt);
@@ -1207,11 +1214,6 @@ int32_t halo_peer_setup(kryst_csr_t a) {
         for (auto& q : push) fprintf(stderr, "[kryst halo rank %d]   push dst %p stamp %p dst_stride %lld src %lld count %lld\n", me, (void*)q.dst, (void*)q.stamp, (long long)q.dst_stride, (long long)q.src, (long long)q.count);
         for (auto& q : pull) fprintf(stderr, "[kryst halo rank %d]   pull stamp %p off %lld count %lld\n", me, (const void*)q.stamp, (long long)q.off, (long long)q.count);
     }
-    if (hp.npush > 256) { halo_peer_destroy(a); set_error("halo by peer stores: more than 256 neighbours"); return KRYST_UNSUPPORTED; }   // (cannot differ... every rank has P - 1 at most)
-    KR_HIP(hipMalloc(&hp.d_push, sizeof(HaloPushSeg) * (push.size() + 1)));
-    KR_HIP(hipMalloc(&hp.d_pull, sizeof(HaloPullSeg) * (pull.size() + 1)));
-    KR_HIP(hipMalloc(&hp.d_ticket, 64));
-    KR_HIP(hipMemsetAsync(hp.d_ticket, 0, 64, ctx->s_main));
     if (!push.empty()) KR_HIP(hipMemcpyAsync(hp.d_push, push.data(), sizeof(HaloPushSeg) * push.size(), hipMemcpyHostToDevice, ctx->s_main));
     if (!pull.empty()) KR_HIP(hipMemcpyAsync(hp.d_pull, pull.data(), sizeof(HaloPullSeg) * pull.size(), hipMemcpyHostToDevice, ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));

@@ -2,7 +2,9 @@
 oracle/kryst_oracle.c) in plain Python floats (IEEE double, one rounding per operation, no FMA), dense like the reference's own
 tests: restarted GMRES with its None / Left / Right branches (src/solver/gmres.rs:216-402, helpers :65-105,:154-192), Ilu0's
 setup and apply (src/preconditioner/ilu.rs:59-122), Jacobi (jacobi.rs:53-95), the dense row loop (src/core/wrappers.rs:27-38)
-and the serial dot / norm folds (wrappers.rs:101-107,120-126).
+and the serial dot / norm folds (wrappers.rs:101-107,120-126); since round 4 also the three solvers the BASELINE configs run --
+CgSolver (cg.rs:114-288, every CgNormType and both Indefinite errors), PcgSolver (pcg.rs:114-222, mixed norms included) and
+BiCgStabSolver (bicgstab.rs:69-293, absolute tolerance, silent breakdown breaks) with Convergence::check (convergence.rs:18-34).
 
 The C oracle (serial-fold mode) must agree with it BIT FOR BIT -- iteration counts, converged flags, final residuals and every
 entry of x -- on the reference's own test systems (gmres.rs:438-528, tests/preconditioner_integration.rs:16-57,126-179) and on
@@ -216,6 +218,152 @@ def gmres(a, pc, side, b, x0, restart, tol, max_iters):     # gmres.rs:216-402
     return xk, iterations, final_residual, converged
 
 
+# ------------------------------------------------------------------------------------------------ cg.rs / pcg.rs / bicgstab.rs / convergence.rs
+# (round 4) The three solvers the BASELINE configs run, transcribed from the Rust source like GMRES above -- without looking at the C oracle.
+class Indefinite(Exception):
+    """KError::IndefiniteMatrix (code 3) / KError::IndefinitePreconditioner (code 4), src/error.rs:6-19."""
+    def __init__(self, code, stats):
+        super().__init__(code)
+        self.code, self.stats = code, stats
+
+
+def conv_check(tol, max_iters, res_norm, res0, i):  # convergence.rs:18-34
+    rel = res_norm / res0
+    converged = (rel <= tol) or (i >= max_iters)
+    return converged, (i, res_norm, converged)
+
+
+def cg(a, b, x0, tol, max_iters, norm_type="unpreconditioned"):      # cg.rs:114-288 (no radius, no obj_target: both default to None, :58-59)
+    n = len(b)
+    x = list(x0)
+    ax = matvec(a, x)
+    r = [bi - axi for axi, bi in zip(ax, b)]        # :120-125 `bi - ax`
+    p = list(r)                                     # :126
+    rsq = dot(r, r)                                 # :127
+    res0 = math.sqrt(rsq)                           # :128
+    stats = (0, res0, False)                        # :129
+    dp = {"preconditioned": dot(r, r), "unpreconditioned": dot(r, r), "natural": dot(r, p), "none": 0.0}[norm_type]   # :131-136
+    hist = [math.sqrt(dp)]                          # :140
+    for i in range(1, max_iters + 1):               # :141
+        ap = matvec(a, p)                           # :143-144
+        p_dot_ap = dot(p, ap)                       # :164 (single_reduction false by default; the fused form has the same order)
+        if p_dot_ap <= 0.0:                         # :168-174
+            raise Indefinite(3, (i, math.sqrt(dot(r, r)), False))
+        alpha = rsq / p_dot_ap                      # :175
+        x = [xj + alpha * pj for xj, pj in zip(x, p)]          # :217-219
+        r = [rj - alpha * apj for rj, apj in zip(r, ap)]       # :220-222
+        rsq_new = dot(r, r)                         # :223
+        if norm_type in ("preconditioned", "unpreconditioned"):
+            res_norm = math.sqrt(rsq_new)           # :225-226
+        elif norm_type == "natural":
+            res_norm = math.sqrt(abs(dot(r, p)))    # :227 (the OLD p)
+        else:
+            res_norm = 0.0
+        if rsq_new / rsq < 0.0:                     # :254-259
+            raise Indefinite(4, (i, res_norm, False))
+        hist.append(res_norm)                       # :263
+        stop, stats = conv_check(tol, max_iters, res_norm, res0, i)      # :264-265
+        if stop and stats[2]:                       # :266-269
+            return x, stats, hist
+        beta = rsq_new / rsq                        # :270
+        p = [rj + beta * pj for pj, rj in zip(p, r)]           # :280-282
+        rsq = rsq_new                               # :284
+    return x, stats, hist                           # :286-287
+
+
+def pcg(a, pc, b, x0, tol, max_iters, norm_type="unpreconditioned"):  # pcg.rs:114-222
+    x = list(x0)
+    ax = matvec(a, x)
+    r = [bi - axi for axi, bi in zip(ax, b)]        # :119-124
+    z = pc.apply(r) if pc is not None else list(r)  # :126-131
+    p = list(z)                                     # :132
+    rz = dot(r, z)                                  # :133
+    res0 = math.sqrt(abs(rz))                       # :134  (NOT the norm the loop tests with: mixed norms)
+    stats = (0, res0, False)
+    dp = {"preconditioned": dot(z, z), "unpreconditioned": dot(r, r), "natural": dot(r, z), "none": 0.0}[norm_type]      # :137-142
+    hist = [math.sqrt(dp)]                          # :146 (no abs at iteration 0)
+
+    def res_of(r_, z_):                             # :190-195 / :164-169
+        if norm_type == "preconditioned":
+            return math.sqrt(dot(z_, z_))
+        if norm_type == "unpreconditioned":
+            return math.sqrt(dot(r_, r_))
+        if norm_type == "natural":
+            return math.sqrt(abs(dot(r_, z_)))
+        return 0.0
+    for i in range(max_iters):                      # :147
+        ap = matvec(a, p)                           # :149-150
+        p_dot_ap = dot(p, ap)                       # :159
+        if p_dot_ap <= 0.0:                         # :162-172
+            raise Indefinite(3, (i + 1, res_of(r, z), False))
+        alpha = rz / p_dot_ap                       # :173
+        x = [xj + alpha * pj for xj, pj in zip(x, p)]          # :175-177
+        r = [rj - alpha * apj for rj, apj in zip(r, ap)]       # :179-181
+        z = pc.apply(r) if pc is not None else list(r)         # :183-187
+        rz_new = dot(r, z)                          # :188
+        res_norm = res_of(r, z)                     # :190-195
+        hist.append(res_norm)                       # :199
+        stop, stats = conv_check(tol, max_iters, res_norm, res0, i + 1)  # :200-201
+        if stop and stats[2]:                       # :202-205
+            return x, stats, hist
+        beta = rz_new / rz                          # :206
+        if beta < 0.0:                              # :208-213
+            raise Indefinite(4, (i + 1, res_norm, False))
+        p = [zj + beta * pj for pj, zj in zip(p, z)]           # :215-217
+        rz = rz_new                                 # :218
+    return x, stats, hist                           # :220-221
+
+
+def bicgstab(a, b, x0, tol, max_iters):             # bicgstab.rs:69-293 (pc ignored, :70; no residual history in the reference)
+    eps = 2.220446049250313e-16                     # T::epsilon()
+    x = list(x0)
+    ax = matvec(a, x)
+    r = [bi - axi for axi, bi in zip(ax, b)]        # :75-77
+    r_hat = list(r)                                 # :78
+    rho_prev = alpha = omega_prev = 1.0             # :79-81
+    v = [0.0] * len(b)                              # :82
+    p = list(r)                                     # :83
+    res0 = norm(r)                                  # :95
+    stats = (0, res0, False)                        # :97
+    hist = [res0]                                   # (the port records what the reference computes: res0, then r_norm / s_norm per iteration)
+    if res0 <= tol:                                 # :98-102 ABSOLUTE tolerance
+        return x, (0, res0, True), hist
+    for i in range(1, max_iters + 1):               # :103
+        rho = dot(r_hat, r)                         # :115
+        if abs(rho) < eps:                          # :117-119 `break`: the stats of the previous iteration stay
+            break
+        beta = 0.0 if i == 1 else (rho / rho_prev) * (alpha / omega_prev)      # :120-124
+        p = [rj + beta * (pj - omega_prev * vj) for pj, rj, vj in zip(p, r, v)]   # :139-141
+        v = matvec(a, p)                            # :144-146
+        alpha_den = dot(r_hat, v)                   # :159
+        if abs(alpha_den) < eps:                    # :161-163
+            break
+        alpha = rho / alpha_den                     # :164
+        s = [rj - alpha * vj for rj, vj in zip(r, v)]          # :174
+        s_norm = norm(s)                            # :187
+        if s_norm <= tol:                           # :189-206
+            x = [xj + alpha * pj for xj, pj in zip(x, p)]
+            hist.append(s_norm)
+            return x, (i, s_norm, True), hist
+        t = matvec(a, s)                            # :208-209
+        omega_num = dot(t, s)                       # :221
+        omega_den = dot(t, t)                       # :233
+        if abs(omega_den) < eps:                    # :235-237
+            break
+        omega = omega_num / omega_den               # :238
+        x = [xj + alpha * pj + omega * sj for xj, pj, sj in zip(x, p, s)]      # :251-253, evaluated left to right
+        r = [sj - omega * tj for sj, tj in zip(s, t)]          # :264
+        r_norm = norm(r)                            # :278
+        stats = (i, r_norm, r_norm <= tol)          # :280
+        hist.append(r_norm)
+        if r_norm <= tol:                           # :281-284
+            return x, stats, hist
+        if abs(omega) < eps:                        # :285-287
+            break
+        rho_prev, omega_prev = rho, omega           # :288-289
+    return x, stats, hist                           # :291-292
+
+
 # ------------------------------------------------------------------------------------------------ the comparison
 def dense_csr(a):
     return O.Csr.from_dense(np.array(a, dtype=np.float64))             # every entry stored: the dense row loop, zeros included
@@ -298,3 +446,103 @@ def test_reference_expectations_hold_for_the_transcription():
     x, its, _, conv = gmres(an, Ilu0(an), "left", bn, [0.0] * 10, 10, 1e-12, 100)
     rel = math.sqrt(sum((xi - 1.0) ** 2 for xi in x) / 10.0)
     assert conv and rel < 1e-10 and its == 20                            # two cycles: SURVEY 3.3
+
+
+# ------------------------------------------------------------------------------------------------ CG / PCG / BiCGStab against the C oracle
+def poisson3d_dense(N):
+    """The build's 7-point Poisson operator on an N^3 grid as a dense list of lists (the reference's solvers see dense rows)."""
+    n = N ** 3
+    a = [[0.0] * n for _ in range(n)]
+    for k in range(N):
+        for j in range(N):
+            for i in range(N):
+                r = i + N * (j + N * k)
+                a[r][r] = 6.0
+                for d, ok in ((-1, i > 0), (1, i < N - 1), (-N, j > 0), (N, j < N - 1), (-N * N, k > 0), (N * N, k < N - 1)):
+                    if ok:
+                        a[r][r + d] = -1.0
+    return a
+
+
+def _krylov_cases():
+    rng = np.random.default_rng(4242)
+    out = [("cg.rs 2x2", [[4.0, 1.0], [1.0, 3.0]], [1.0, 2.0], True),                                      # cg.rs:310-323
+           ("cg.rs 3x3", [[4.0, 1.0, 0.0], [1.0, 3.0, 1.0], [0.0, 1.0, 2.0]], [1.0, 2.0, 3.0], True),      # cg.rs:326-356
+           ("bicgstab.rs 3x3", [[4.0, 1.0, 0.0], [2.0, 3.0, 1.0], [0.0, 1.0, 2.0]], [1.0, 2.0, 3.0], False),
+           ("spd tridiag 10", tridiag(10, -1.0, 2.0, -1.0), matvec(tridiag(10, -1.0, 2.0, -1.0), [1.0] * 10), True),
+           ("nonsym tridiag 10", tridiag(10, -1.0, 2.0, 0.5), matvec(tridiag(10, -1.0, 2.0, 0.5), [1.0] * 10), False),
+           ("poisson 4^3", poisson3d_dense(4), matvec(poisson3d_dense(4), [1.0] * 64), True)]
+    for n in (6, 17, 40):                              # seeded dense systems: SPD (B^T B + I) and diagonally dominant unsymmetric
+        bm = rng.uniform(-1.0, 1.0, (n, n))
+        spd = (bm.T @ bm + np.eye(n)).tolist()
+        out.append((f"random spd {n}", spd, rng.uniform(-2.0, 2.0, n).tolist(), True))
+        m = rng.uniform(-1.0, 1.0, (n, n))
+        m[rng.random((n, n)) < 0.5] = 0.0
+        m += np.diag(np.abs(m).sum(axis=1) + 1.0)
+        out.append((f"random nonsym {n}", m.tolist(), rng.uniform(-2.0, 2.0, n).tolist(), False))
+    return out
+
+
+NORMS = {"preconditioned": O.NORM_PRECONDITIONED, "unpreconditioned": O.NORM_UNPRECONDITIONED, "natural": O.NORM_NATURAL, "none": O.NORM_NONE}
+
+
+def _same(ref, x, stats, hist, what):
+    assert (ref.iterations, ref.converged) == (stats[0], stats[2]), (what, ref, stats)
+    assert ref.final_residual == stats[1], (what, ref.final_residual, stats[1])
+    assert np.array_equal(ref.x, np.array(x)), (what, np.max(np.abs(ref.x - np.array(x))))
+    assert len(ref.history) == len(hist) and np.array_equal(ref.history, np.array(hist)), what
+
+
+@pytest.mark.parametrize("name,a,b,spd", _krylov_cases(), ids=[c[0] for c in _krylov_cases()])
+def test_cg_pcg_bicgstab_of_the_c_oracle_equal_the_independent_transcription_bitwise(name, a, b, spd):
+    """CgSolver (cg.rs:114-288, every CgNormType), PcgSolver (pcg.rs:114-222; no pc, Jacobi, Ilu0; every norm type) and BiCgStabSolver
+    (bicgstab.rs:69-293) of the C oracle in serial-fold mode against the transcription above: iteration counts, flags, final residual, the
+    whole residual history and every entry of x, bit for bit -- on the reference's own test systems, tridiagonal systems, the build's 4^3
+    Poisson operator and seeded dense systems, with tolerances that are met, iteration caps that bite (`converged = true` at the cap,
+    convergence.rs:25) and tol = 0."""
+    ao = dense_csr(a)
+    n = len(b)
+    x0 = [0.0] * n
+    for tol, cap in ((1e-10, 200), (1e-6, 3), (0.0, 7)):
+        if spd:
+            for nt in NORMS:
+                x, st, hist = cg(a, b, x0, tol, cap, nt)
+                _same(O.solve("cg", ao, np.array(b), tol=tol, max_iters=cap, norm_type=NORMS[nt], rs=O.SERIAL), x, st, hist, (name, "cg", nt, tol, cap))
+            for pcname, pc_py, pc_c in ((None, None, None), ("jacobi", Jacobi, O.Pc.jacobi), ("ilu0", Ilu0, O.Pc.ilu0_compat)):
+                for nt in NORMS:
+                    try:
+                        x, st, hist = pcg(a, pc_py(a) if pc_py else None, b, x0, tol, cap, nt)
+                        code = 0
+                    except Indefinite as e:                               # (Ilu0 as written is not symmetric: beta < 0 can happen)
+                        code, st = e.code, e.stats
+                    ref = O.solve("pcg", ao, np.array(b), pc=pc_c(ao) if pc_c else None, tol=tol, max_iters=cap, norm_type=NORMS[nt], rs=O.SERIAL,
+                                  raise_on_error=False)
+                    assert ref.code == code, (name, "pcg", pcname, nt, ref.code, code)
+                    if code == 0:
+                        _same(ref, x, st, hist, (name, "pcg", pcname, nt, tol, cap))
+                    else:
+                        assert (ref.iterations, ref.final_residual, ref.converged) == st, (name, "pcg", pcname, nt)
+        bn = norm(b)
+        x, st, hist = bicgstab(a, b, x0, tol * bn, cap)                    # ABSOLUTE tolerance (bicgstab.rs:98,189,281)
+        _same(O.solve("bicgstab", ao, np.array(b), tol=tol * bn, max_iters=cap, rs=O.SERIAL), x, st, hist, (name, "bicgstab", tol, cap))
+
+
+def test_indefinite_matrix_and_breakdown_paths_bitwise():
+    """cg.rs:168-174 / pcg.rs:162-172 (p.Ap <= 0 -> KError::IndefiniteMatrix with the stats of that iteration) and BiCGStab's silent
+    `break`s (bicgstab.rs:117-119: rho = 0 with r_hat orthogonal to r after one step of a rotation-like operator): same codes, same stats."""
+    a = [[1.0, 0.0, 0.0], [0.0, -2.0, 0.0], [0.0, 0.0, 3.0]]
+    b = [1.0, 1.0, 1.0]
+    ao = dense_csr(a)
+    for solver, method in ((lambda: cg(a, b, [0.0] * 3, 1e-10, 50), "cg"), (lambda: pcg(a, None, b, [0.0] * 3, 1e-10, 50), "pcg")):
+        try:
+            solver()
+            raised = None
+        except Indefinite as e:
+            raised = e
+        ref = O.solve(method, ao, np.array(b), tol=1e-10, max_iters=50, rs=O.SERIAL, raise_on_error=False)
+        assert raised is not None and ref.code == raised.code
+        assert (ref.iterations, ref.final_residual, ref.converged) == raised.stats, (method, ref, raised.stats)
+    rot = [[0.0, 1.0], [-1.0, 0.0]]                                        # A r is orthogonal to r: alpha_den = <r_hat, A r> = 0 at i = 1
+    br = [1.0, 0.0]
+    x, st, hist = bicgstab(rot, br, [0.0, 0.0], 1e-12, 20)
+    _same(O.solve("bicgstab", dense_csr(rot), np.array(br), tol=1e-12, max_iters=20, rs=O.SERIAL), x, st, hist, "bicgstab breakdown")
