@@ -4,7 +4,9 @@ tests: restarted GMRES with its None / Left / Right branches (src/solver/gmres.r
 setup and apply (src/preconditioner/ilu.rs:59-122), Jacobi (jacobi.rs:53-95), the dense row loop (src/core/wrappers.rs:27-38)
 and the serial dot / norm folds (wrappers.rs:101-107,120-126); since round 4 also the three solvers the BASELINE configs run --
 CgSolver (cg.rs:114-288, every CgNormType and both Indefinite errors), PcgSolver (pcg.rs:114-222, mixed norms included) and
-BiCgStabSolver (bicgstab.rs:69-293, absolute tolerance, silent breakdown breaks) with Convergence::check (convergence.rs:18-34).
+BiCgStabSolver (bicgstab.rs:69-293, absolute tolerance, silent breakdown breaks) with Convergence::check (convergence.rs:18-34), the
+section-8f solvers FgmresSolver::solve_flex (fgmres.rs:114-340), CgsSolver (cgs.rs:58-135) and TfqmrSolver as written
+(tfqmr.rs:64-221), and apply_chebyshev (chebyshev.rs:83-159), Ilup::new(p) (ilup.rs:77-167) and Ilut (ilut.rs:80-150).
 
 The C oracle (serial-fold mode) must agree with it BIT FOR BIT -- iteration counts, converged flags, final residuals and every
 entry of x -- on the reference's own test systems (gmres.rs:438-528, tests/preconditioner_integration.rs:16-57,126-179) and on
@@ -546,3 +548,364 @@ def test_indefinite_matrix_and_breakdown_paths_bitwise():
     br = [1.0, 0.0]
     x, st, hist = bicgstab(rot, br, [0.0, 0.0], 1e-12, 20)
     _same(O.solve("bicgstab", dense_csr(rot), np.array(br), tol=1e-12, max_iters=20, rs=O.SERIAL), x, st, hist, "bicgstab breakdown")
+
+
+# ------------------------------------------------------------------------------------------------ chebyshev.rs / ilup.rs / ilut.rs
+def chebyshev_t(m, x):                              # chebyshev.rs:143-159
+    if m == 0:
+        return 1.0
+    if m == 1:
+        return x
+    t0, t1 = 1.0, x
+    for _ in range(2, m + 1):
+        t2 = 2.0 * x * t1 - t0
+        t0, t1 = t1, t2
+    return t1
+
+
+def apply_chebyshev(a, r, alpha, beta, m):          # chebyshev.rs:83-140
+    if abs(beta - alpha) < 2.220446049250313e-16:   # :88-92
+        return list(r)
+    v0 = list(r)
+    c = (beta + alpha) / 2.0                        # :99
+    d = (beta - alpha) / 2.0                        # :100
+    tau = 1.0 / chebyshev_t(m, (0.0 - c) / d)       # :102
+    v1 = matvec(a, v0)                              # :104
+    v1 = [(v1[i] - c * v0[i]) / d for i in range(len(r))]      # :105-107
+    if m == 0:                                      # :108-111 (after the wasted matvec)
+        return v0
+    if m == 1:                                      # :112-116: v1 UNSCALED by tau
+        return v1
+    for _k in range(2, m + 1):                      # :118-125
+        v2 = matvec(a, v1)
+        v2 = [(2.0 * (v2[i] - c * v1[i]) / d) - v0[i] for i in range(len(r))]
+        v0, v1 = v1, v2
+    return [tau * x for x in v1]                    # :127-139
+
+
+class Ilup:                                         # ilup.rs:77-167, dense work arrays exactly as written
+    def __init__(self, a, fill):
+        n = len(a)
+        UMAX = 2 ** 64 - 1
+        level = [[0 if a[i][j] != 0.0 else UMAX for j in range(n)] for i in range(n)]      # :84-91
+        w = [list(row) for row in a]                # :93-98
+        self.l = [([], []) for _ in range(n)]
+        self.u = [([], []) for _ in range(n)]
+        for i in range(n):                          # :100
+            for j in range(i):                      # :102
+                if w[i][j] != 0.0 and level[i][j] <= fill:          # :103
+                    u_jj = w[j][j]
+                    if u_jj == 0.0:
+                        raise ZeroDivisionError(j)  # :106-108 KError::SolveError
+                    lij = w[i][j] / u_jj            # :109
+                    self.l[i][0].append(j); self.l[i][1].append(lij)
+                    for k in range(j + 1, n):       # :113
+                        if w[j][k] != 0.0:
+                            new_level = min(UMAX, min(UMAX, level[i][j] + level[j][k]) + 1)      # saturating adds :115
+                            if new_level <= fill:
+                                w[i][k] = w[i][k] - lij * w[j][k]               # :117-118
+                                level[i][k] = min(level[i][k], new_level)       # :119
+            for k in range(i, n):                   # :126-131
+                if w[i][k] != 0.0 and level[i][k] <= fill:
+                    self.u[i][0].append(k); self.u[i][1].append(w[i][k])
+
+    def apply(self, r):                             # :138-167 (shared with Ilut, ilut.rs:121-150)
+        return tri_apply(self.l, self.u, r)
+
+
+def tri_apply(l, u, r):
+    n = len(r)
+    y = [0.0] * n
+    for i in range(n):
+        s = r[i]
+        for j, v in zip(*l[i]):
+            s = s - v * y[j]
+        y[i] = s
+    z = [0.0] * n
+    for i in reversed(range(n)):
+        s = y[i]
+        for j, v in zip(*u[i]):
+            if j > i:
+                s = s - v * z[j]
+        z[i] = s / u[i][1][u[i][0].index(i)] if i in u[i][0] else s
+    return z
+
+
+class Ilut:                                         # ilut.rs:80-117: no elimination at all -- drop, keep the `fill` largest, split
+    def __init__(self, a, fill, droptol):
+        n = len(a)
+        self.l, self.u = [], []
+        for i in range(n):
+            row = [(j, a[i][j]) for j in range(n) if a[i][j] != 0.0]           # :88-94
+            row = [(j, v) for j, v in row if abs(v) >= droptol]                # :96
+            if len(row) > fill:                                                # :98-101 (sort_by is stable; descending magnitude)
+                row = sorted(row, key=lambda e: -abs(e[1]))[:fill]
+            self.l.append(([j for j, _ in row if j < i], [v for j, v in row if j < i]))
+            self.u.append(([j for j, _ in row if j >= i], [v for j, v in row if j >= i]))
+
+    def apply(self, r):
+        return tri_apply(self.l, self.u, r)
+
+
+def test_chebyshev_ilup_ilut_of_the_c_oracle_equal_the_independent_transcription_bitwise():
+    """apply_chebyshev (chebyshev.rs:83-159: degenerate interval, m = 0 after a wasted matvec, m = 1 unscaled, m >= 2 scaled by tau),
+    Ilup::new(p) (ilup.rs:77-167: level-of-fill bookkeeping with saturating adds, fill 0 .. 3) and Ilut::new(fill, droptol)
+    (ilut.rs:80-150: no elimination, stable magnitude sort) of the C oracle against the transcriptions above, bit for bit."""
+    rng = np.random.default_rng(99)
+    mats = [tridiag(10, -1.0, 2.0, 0.5), A4, poisson3d_dense(3)]
+    for n in (8, 14):
+        m = rng.uniform(-1.0, 1.0, (n, n))
+        m[rng.random((n, n)) < 0.6] = 0.0
+        m += np.diag(np.abs(m).sum(axis=1) + 1.0)
+        mats.append(m.tolist())
+    for a in mats:
+        ao = dense_csr(a)
+        n = len(a)
+        r = rng.standard_normal(n).tolist()
+        for m_deg in (0, 1, 2, 3, 6):
+            for lo, hi in ((0.5, 7.5), (1.0, 1.0)):
+                assert np.array_equal(O.apply_chebyshev(ao, np.array(r), lo, hi, m_deg), np.array(apply_chebyshev(a, r, lo, hi, m_deg))), (n, m_deg, lo, hi)
+            assert O.chebyshev_t(m_deg, -1.37) == chebyshev_t(m_deg, -1.37)
+        sparse = O.Csr.from_dense(np.array(a, dtype=np.float64), keep_zeros=False)
+        for fill in (0, 1, 2, 3):
+            assert np.array_equal(O.Pc.ilup(sparse, fill).apply(np.array(r)), np.array(Ilup(a, fill).apply(r))), (n, "ilup", fill)
+        for fill, droptol in ((2, 0.0), (4, 1e-3), (3, 0.3), (100, 0.0)):
+            assert np.array_equal(O.Pc.ilut(sparse, fill, droptol).apply(np.array(r)), np.array(Ilut(a, fill, droptol).apply(r))), (n, "ilut", fill, droptol)
+
+
+# ------------------------------------------------------------------------------------------------ cgs.rs / tfqmr.rs
+def cgs(a, b, x0, tol, max_iters):                  # cgs.rs:58-135 (pc ignored, :59)
+    eps = 2.220446049250313e-16
+    n = len(b)
+    x = list(x0)
+    ax = matvec(a, x)
+    r = [bi - axi for bi, axi in zip(b, ax)]        # :64-69
+    r_tld = list(r)                                 # :70
+    p = list(r)                                     # :71
+    q = [0.0] * n                                   # :72
+    u = [0.0] * n                                   # :73
+    rho = dot(r_tld, r)                             # :74
+    rho_old = 0.0
+    res0 = norm(r)                                  # :76
+    stats = (0, res0, False)
+    hist = []                                       # (the port records res_norm per iteration; nothing at iteration 0)
+    for i in range(1, max_iters + 1):               # :78
+        if abs(rho) < eps:                          # :80-82
+            break
+        if i == 1:                                  # :83-86
+            u = list(r)
+            p = list(u)
+        else:
+            beta = rho / rho_old                    # :88
+            q_old, p_old = list(q), list(p)
+            u = [rj + beta * qo for rj, qo in zip(r, q_old)]                       # :93-95
+            p = [uj + beta * (qo + beta * po) for uj, qo, po in zip(u, q_old, p_old)]   # :97-99
+        v = matvec(a, p)                            # :102-104
+        alpha = rho / dot(r_tld, v)                 # :106
+        q = [uj - alpha * vj for uj, vj in zip(u, v)]          # :108-110
+        x = [xj + alpha * (uj + qj) for xj, uj, qj in zip(x, u, q)]    # :112-114  `*xj += alpha * (u + q)`
+        upq = [uj + qj for uj, qj in zip(u, q)]     # :116-119
+        w = matvec(a, upq)                          # :120-121
+        r = [rj - alpha * wj for rj, wj in zip(r, w)]          # :122-124
+        res_norm = norm(r)                          # :125
+        hist.append(res_norm)
+        stop, stats = conv_check(tol, max_iters, res_norm, res0, i)    # :127-128
+        if stop and stats[2]:                       # :129-132
+            return x, stats, hist
+        rho_old = rho                               # :133
+        rho = dot(r_tld, r)                         # :134
+    return x, stats, hist
+
+
+def tfqmr(a, b, tol, max_iters):                    # tfqmr.rs:64-221, as written (x0 is discarded, :72; the reference's only test of it is #[ignore])
+    n = len(b)
+    x = [0.0] * n                                   # :72
+    r = list(b)                                     # :75
+    r_tld = list(r)                                 # :77
+    rho = dot(r, r_tld)                             # :80
+    if rho == 0.0:                                  # :81-83
+        return x, (0, norm(r), True), []
+    w = list(r); y = list(r)                        # :96-97  (w is never read again)
+    u = [0.0] * n; d = [0.0] * n                    # :98-99
+    psi_old = eta_old = 0.0                         # :100-101
+    tau = norm(r)                                   # :102
+    res0 = tau                                      # :103
+    stats = (0, res0, False)                        # :104
+    hist = []
+    if tau == 0.0:                                  # :105-107
+        return x, (0, 0.0, True), hist
+    dpold = tau                                     # :109
+    for k in range(1, max_iters + 1):               # :110
+        v = matvec(a, y)                            # :112-114
+        sigma = dot(r_tld, v)                       # :117
+        if sigma == 0.0 or not math.isfinite(sigma):        # :118-123
+            return x, (k, norm(r), False), hist
+        alpha = rho / sigma                         # :124
+        if alpha == 0.0 or not math.isfinite(alpha):        # :125-130
+            return x, (k, norm(r), False), hist
+        u = [ri - alpha * vi for ri, vi in zip(r, v)]       # :133-135
+        q = [ui - alpha * vi for ui, vi in zip(u, v)]       # :138-141
+        t = [ui + qi for ui, qi in zip(u, q)]       # :144-147
+        au = matvec(a, t)                           # :148-149
+        r = [ri - alpha * aui for ri, aui in zip(r, au)]    # :151-153
+        dp = norm(r)                                # :154
+        tau_m0 = math.sqrt(dp * dpold)              # :155
+        tau_local = tau_m0                          # :156
+        for m in range(2):                          # :158
+            if m == 0:
+                norm_u_m, tau_for_m, u_m = dp, tau_m0, u            # :159-161,:164
+            else:
+                norm_u_m, tau_for_m, u_m = norm(q), tau_local, q    # :162-164
+            psi = norm_u_m / tau_for_m              # :167
+            c_m = 1.0 / math.sqrt(1.0 + psi * psi)  # :168
+            eta = c_m * c_m * alpha                 # :169
+            cf = 0.0 if (alpha == 0.0 or k == 1) else psi_old * psi_old * eta_old / alpha      # :172-176
+            d = [umi + cf * di for umi, di in zip(u_m, d)]          # :177-179
+            x = [xi + eta * di for xi, di in zip(x, d)]             # :182-184
+            dpest = math.sqrt(float(2 * k + m + 2)) * tau_for_m      # :187
+            stop, stats = conv_check(tol, max_iters, dpest, res0, k)     # :188-189
+            hist.append(dpest)
+            psi_old, eta_old = psi, eta             # :190-191
+            tau_local = tau_for_m * psi * c_m       # :192
+            if stop:                                # :193-198
+                return x, (k, dpest, True), hist
+        r = list(u)                                 # :205
+        rho_new = dot(r_tld, r)                     # :206
+        beta = rho_new / rho                        # :207
+        rho = rho_new                               # :208
+        y = [ui + beta * (qi + beta * yi) for ui, qi, yi in zip(u, q, y)]       # :212
+        dpold = dp                                  # :214
+    return x, (max_iters, norm(r), stats[2]), hist   # :217-219 (converged keeps the last check's value)
+
+
+@pytest.mark.parametrize("name,a,b,spd", _krylov_cases(), ids=[c[0] for c in _krylov_cases()])
+def test_cgs_tfqmr_of_the_c_oracle_equal_the_independent_transcription_bitwise(name, a, b, spd):
+    """CgsSolver (cgs.rs:58-135) and TfqmrSolver exactly as written (tfqmr.rs:64-221) of the C oracle, serial-fold mode, against the
+    transcriptions above: stats, residual estimates and x bit for bit."""
+    ao = dense_csr(a)
+    n = len(b)
+    for tol, cap in ((1e-10, 60), (1e-4, 3), (0.0, 6)):
+        x, st, hist = cgs(a, b, [0.0] * n, tol, cap)
+        _same(O.solve("cgs", ao, np.array(b), tol=tol, max_iters=cap, rs=O.SERIAL), x, st, hist, (name, "cgs", tol, cap))
+        x, st, hist = tfqmr(a, b, tol, cap)
+        _same(O.solve("tfqmr", ao, np.array(b), tol=tol, max_iters=cap, rs=O.SERIAL), x, st, hist, (name, "tfqmr", tol, cap))
+
+
+# ------------------------------------------------------------------------------------------------ fgmres.rs
+def fgmres(a, pc, b, x0, tol, max_iters, restart, orthog="classical", haptol=1e-12, preallocate=False):     # fgmres.rs:114-340
+    n = len(b)
+    x = list(x0)
+    tmp = matvec(a, x)
+    r = [ri - ai for ri, ai in zip(b, tmp)]         # :133-138
+    beta = norm(r)                                  # :139
+    if beta == 0.0:                                 # :140-142
+        return x, (0, 0.0, True), []
+    nb = max_iters if preallocate else restart      # :144-165 (sizes only matter through `m` below)
+    v = [None] * (nb + 1 + 16)
+    z = [None] * (nb + 16)
+    h = [[0.0] * max(nb, restart) for _ in range(nb + 1 + 16)]
+    cs = [0.0] * (nb + 16); sn = [0.0] * (nb + 16)
+    sv = [0.0] * (nb + 1 + 16)
+    sv[0] = beta                                    # :166
+    v[0] = [ri / beta for ri in r]                  # :167-169
+    total = 0
+    res_norm_outer = beta                           # :171 (never updated: the stats' final_residual at :339)
+    stats = (0, res_norm_outer, False)
+    hist = []
+    while total < max_iters:                        # :175
+        m = min(max_iters, restart) if preallocate else min(restart, max_iters - total)      # :202
+        converged = False
+        steps = m
+        for j in range(m):                          # :206
+            z[j] = list(v[j])                       # :208
+            if pc is not None:
+                z[j] = pc.apply(v[j])               # :209-211
+            w = matvec(a, z[j])                     # :213-214
+            hcol = [0.0] * (j + 2)
+            for i in range(j + 1):                  # :219-221 / :229-231: ALL dots first (classical in both arms)
+                hcol[i] = dot(w, v[i])
+            for i in range(j + 1):                  # :222-226 / :232-236
+                w = [wi - hcol[i] * vi for wi, vi in zip(w, v[i])]
+            if orthog == "modified":                # :238-245
+                for i in range(j + 1):
+                    corr = dot(w, v[i])
+                    if abs(corr) > 1e-10:
+                        w = [wi - corr * vi for wi, vi in zip(w, v[i])]
+            h[j + 1][j] = norm(w)                   # :248
+            for i in range(j + 1):
+                h[i][j] = hcol[i]                   # :249
+            hapbnd = haptol * abs(sv[j])            # :251
+            if not (abs(h[j + 1][j]) < hapbnd):     # :252-259
+                wn = h[j + 1][j]
+                v[j + 1] = [wi / wn for wi in w]
+            else:
+                v[j + 1] = [0.0] * n
+            for i in range(j):                      # :261-265
+                temp = cs[i] * h[i][j] + sn[i] * h[i + 1][j]
+                h[i + 1][j] = -sn[i] * h[i][j] + cs[i] * h[i + 1][j]
+                h[i][j] = temp
+            h1, h2 = h[j][j], h[j + 1][j]           # :267-276
+            denom = math.sqrt(h1 * h1 + h2 * h2)
+            c, s_ = (1.0, 0.0) if denom == 0.0 else (h1 / denom, h2 / denom)
+            cs[j], sn[j] = c, s_
+            temp = c * sv[j] + s_ * sv[j + 1]       # :279-281
+            sv[j + 1] = -s_ * sv[j] + c * sv[j + 1]
+            sv[j] = temp
+            h[j][j] = c * h[j][j] + s_ * h[j + 1][j]    # :282-283
+            h[j + 1][j] = 0.0
+            res_norm = abs(sv[j + 1])               # :284
+            total += 1                              # :285
+            hist.append(res_norm)                   # :290
+            stop, stats = conv_check(tol, max_iters, res_norm, sv[0], total)     # :291 (against the ROTATED s[0])
+            if stop:                                # :293-299
+                stats = (total, res_norm, stats[2])
+                steps = j + 1
+                converged = True
+                break
+        k = steps                                   # :302-311: no pivot guard
+        y = [0.0] * k
+        for i in reversed(range(k)):
+            acc = sv[i]
+            for l in range(i + 1, k):
+                acc = acc - h[i][l] * y[l]
+            y[i] = acc / h[i][i]
+        for i, yi in enumerate(y):                  # :349-353
+            x = [xi + yi * zi for xi, zi in zip(x, z[i])]
+        tmp = matvec(a, x)                          # :314-319
+        r_new = [ri - ai for ri, ai in zip(b, tmp)]
+        rn = norm(r_new)                            # :320
+        if rn < tol or converged:                   # :321-326  (ABSOLUTE tol for the true residual)
+            stats = (total, rn, True)
+            break
+        beta = rn                                   # :328-331
+        v[0] = [ri / beta for ri in r_new]
+        sv = [0.0] * (restart + 1 + 16)             # :332-334
+        sv[0] = beta
+    return x, (total, res_norm_outer, stats[2]), hist       # :339-340
+
+
+class FixedJacobi:                                  # a FlexiblePreconditioner that happens not to change (preconditioner/mod.rs:16-19)
+    def __init__(self, a):
+        self.inv = [1.0 / a[i][i] for i in range(len(a))]
+
+    def apply(self, x):
+        return [d * xi for d, xi in zip(self.inv, x)]
+
+
+@pytest.mark.parametrize("name,a,b,spd", _krylov_cases(), ids=[c[0] for c in _krylov_cases()])
+def test_fgmres_of_the_c_oracle_equals_the_independent_transcription_bitwise(name, a, b, spd):
+    """FgmresSolver::solve_flex (fgmres.rs:114-340) of the C oracle in serial-fold mode against the transcription above: classical and
+    modified orthogonalisation, restarts that bite, preallocate, with and without a (Jacobi) flexible preconditioner; the quirks are the
+    reference's (convergence against the rotated s[0], the INITIAL residual as final_residual, no pivot guard)."""
+    ao = dense_csr(a)
+    n = len(b)
+    for pc_py, pc_c in ((None, None), (FixedJacobi(a), O.Pc.jacobi(ao))):
+        for orth, oc in (("classical", 0), ("modified", 1)):
+            for tol, cap, restart, pre in ((1e-10, 60, 5, False), (1e-6, 7, 3, False), (1e-9, 12, 4, True)):
+                x, st, hist = fgmres(a, pc_py, b, [0.0] * n, tol, cap, restart, orth, 1e-12, pre)
+                ref = O.solve("fgmres", ao, np.array(b), pc=pc_c, tol=tol, max_iters=cap, restart=restart, orthog=oc, haptol=1e-12, preallocate=pre,
+                              rs=O.SERIAL, raise_on_error=False)
+                if not all(math.isfinite(v_) for v_ in x):              # (a happy breakdown without convergence ends in NaNs in the reference too)
+                    assert not np.all(np.isfinite(ref.x)), (name, orth, tol, cap, restart, pre)
+                    continue
+                _same(ref, x, st, hist, (name, "fgmres", orth, tol, cap, restart, pre, pc_py is not None))
