@@ -909,3 +909,26 @@ def test_fgmres_of_the_c_oracle_equals_the_independent_transcription_bitwise(nam
                     assert not np.all(np.isfinite(ref.x)), (name, orth, tol, cap, restart, pre)
                     continue
                 _same(ref, x, st, hist, (name, "fgmres", orth, tol, cap, restart, pre, pc_py is not None))
+
+
+def test_approx_inverse_apply_bitwise():
+    """ApproxInv::apply (approxinv.rs:268-298): y_i = sum over the row's stored (j, m_ij) in stored order of m_ij * x_j, from 0.0 --
+    here with rows whose entries are NOT in ascending column order (inv_rows keeps whatever order setup produced)."""
+    rng = np.random.default_rng(3)
+    n = 9
+    rows = []
+    for i in range(n):
+        cols = rng.permutation(n)[: rng.integers(0, 6)].tolist()
+        rows.append([(int(j), float(rng.uniform(-2.0, 2.0))) for j in cols])
+    x = rng.standard_normal(n).tolist()
+    y = []
+    for row in rows:
+        acc = 0.0
+        for j, mij in row:
+            acc = acc + mij * x[j]
+        y.append(acc)
+    ptr = np.cumsum([0] + [len(r) for r in rows])
+    col = np.array([j for r in rows for j, _ in r], dtype=np.int64)
+    val = np.array([v for r in rows for _, v in r])
+    m = O.Csr(n, n, ptr, col, val, check=False)                            # stored order kept: unsorted columns are the point
+    assert np.array_equal(O.Pc.approx_inverse(m).apply(np.array(x)), np.array(y))
