@@ -378,7 +378,8 @@ class _Pc:
         """What an ILU-family apply runs and streams (kryst_pc_ilu_info) -> dict."""
         v = np.zeros(13, dtype=np.int64)
         check(lib().kryst_pc_ilu_info(self.h, v.ctypes.data_as(_ffi.c_i64p), 13))
-        form = ("level-ordered", "grid 8x8 (tri_wave_kernel)", "grid 16x16 (tri_quad_kernel)", "grid planes (tri_plane_kernel)")[int(v[0])]
+        form = ("level-ordered", "grid 8x8 (tri_wave_kernel)", "grid 16x16 (tri_quad_kernel)", "grid planes (tri_plane_kernel)",
+                "box planes (tri_box_plane_kernel)", "box wavefront (tri_box_kernel)")[int(v[0])]
         return {"form": form, "box": [int(v[1]), int(v[2]), int(v[3])], "levels": [int(v[4]), int(v[5])], "chunks": [int(v[6]), int(v[7])],
                 "chunks_not_requested": [int(v[8]), int(v[9])], "bytes_per_chunk": [int(v[10]), int(v[11])]}
 

@@ -91,9 +91,25 @@ struct GridFactor {
 };
 struct GridView { int32_t Ni, Nj, Nk; const double* c1; const double* c2; const double* c3; const double* diag; };
 
+// Box-stencil form of one factor (round 4): every kept entry of row (i, j, k) of an Ni x Nj x Nk box couples it to (i + di, j + dj, k + dk)
+// with |di|, |dj|, |dk| <= 1 -- strictly lower (L) or strictly upper (U) in natural ordering: any ILU-family factor of a stencil inside the
+// 3 x 3 x 3 cube (27-point, 19-point, 9-point 2-D, ...) that is not a 7-point factor (those take GridFactor).  Thirteen coefficient streams
+// in natural row order, stream a = the a-th offset in ASCENDING COLUMN order (the order the reference subtracts in): L: (dk, dj, di) =
+// (-1,-1,-1), (-1,-1,0), ... (0,0,-1), i.e. a = 9 (dk + 1) + 3 (dj + 1) + (di + 1); U: (0,0,1), (0,1,-1), ... (1,1,1), a = that code - 14.
+// 0.0 = no such entry (zero entries are never stored).
+struct BoxFactor {
+    bool ok = false;
+    int32_t Ni = 0, Nj = 0, Nk = 0;
+    double* d_c = nullptr;          // 13 n doubles: d_c[a n + row]
+    double* d_diag = nullptr;       // divisor (backward factor only)
+    void free_all() { (void)hipFree(d_c); (void)hipFree(d_diag); d_c = nullptr; d_diag = nullptr; }
+};
+struct BoxView { int32_t Ni, Nj, Nk; int64_t n; const double* c; const double* diag; };
+
 struct IluData {
     TriFactor L, U;
     GridFactor GL, GU;
+    BoxFactor BL, BU;
     TriArgs* d_args = nullptr;
     double* d_rL = nullptr; double* d_y = nullptr; double* d_yU = nullptr; double* d_zU = nullptr;   // level-permuted work vectors
     int32_t* d_mapLU = nullptr;     // L-position of the row at U-position q
@@ -433,6 +449,33 @@ __global__ __launch_bounds__(256) void tri_plane_kernel(const TriArgs* args, con
     out[row] = s;
 }
 
+// Box-stencil factor, one launch per hyperplane i + 2 j + 4 k = h (schedule coordinates; mirrored for the backward solve): every lower
+// offset (dk, dj, di) of the 3 x 3 x 3 cube has di + 2 dj + 4 dk <= -1 -- the closest are (0, -1, +1) and (-1, +1, +1) -- so the rows of a
+// plane only need rows of earlier planes.  Ni + 2 Nj + 4 Nk - 6 launches per factor (replayed as a hipGraph): the barrier-free form of the
+// box solve, and the one a preconditioner falls back to.  Stored (ascending column) order, absent entries skipped: the reference's bits.
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void tri_box_plane_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, BoxView B, int h) {
+    if (args->skip) return;
+    const double* in = in_ptr ? in_ptr : args->r;
+    double* out = out_ptr ? out_ptr : args->z;
+    const int jk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (jk >= B.Nj * B.Nk) return;
+    const int jj = jk % B.Nj, kk = jk / B.Nj, ii = h - 2 * jj - 4 * kk;
+    if (ii < 0 || ii >= B.Ni) return;
+    const int i = FORWARD ? ii : B.Ni - 1 - ii, j = FORWARD ? jj : B.Nj - 1 - jj, k = FORWARD ? kk : B.Nk - 1 - kk;
+    const int64_t s1 = B.Ni, s2 = (int64_t)B.Ni * B.Nj;
+    const int64_t row = i + s1 * j + s2 * k;
+    double s = in[row];
+#pragma unroll
+    for (int a = 0; a < 13; ++a) {
+        const int code = FORWARD ? a : a + 14;                             // 9 (dk + 1) + 3 (dj + 1) + (di + 1)
+        const int dk = code / 9 - 1, dj = (code / 3) % 3 - 1, di = code % 3 - 1;
+        const double c = B.c[(int64_t)a * B.n + row];
+        if (c != 0.0) s = s - c * out[row + di + s1 * dj + s2 * dk];
+    }
+    out[row] = FORWARD ? s : s / B.diag[row];
+}
+
 // a run of consecutive NARROW levels [l0, l1) in one workgroup (CSR fallback for factors that do not fit the ELL form)
 template <bool FORWARD>
 __global__ __launch_bounds__(1024) void tri_run_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
@@ -580,6 +623,19 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
 // r -> rL (L level order) -> forward -> yL -> yU (U level order) -> backward -> zU -> z
 static int32_t enqueue_apply(hipStream_t s, IluData* D, const TriDirect* direct = nullptr) {
     const unsigned g = (unsigned)((D->n + 255) / 256);
+    if (D->BL.ok && D->BU.ok) {
+        // box stencil: r -> forward -> y (natural order) -> backward -> z; one launch per hyperplane i + 2 j + 4 k
+        const BoxFactor& A = D->BL; const BoxFactor& B = D->BU;
+        const BoxView VA{A.Ni, A.Nj, A.Nk, D->n, A.d_c, nullptr}, VB{B.Ni, B.Nj, B.Nk, D->n, B.d_c, B.d_diag};
+        const int nlev = (A.Ni - 1) + 2 * (A.Nj - 1) + 4 * (A.Nk - 1) + 1;
+        const unsigned pg = (unsigned)(((int64_t)A.Nj * A.Nk + 255) / 256);
+        for (int lv = 0; lv < nlev; ++lv)
+            hipLaunchKernelGGL((tri_box_plane_kernel<true>), dim3(pg), dim3(256), 0, s, D->d_args, (const double*)nullptr, D->d_y, VA, lv);
+        for (int lv = 0; lv < nlev; ++lv)
+            hipLaunchKernelGGL((tri_box_plane_kernel<false>), dim3(pg), dim3(256), 0, s, D->d_args, (const double*)D->d_y, (double*)nullptr, VB, lv);
+        KR_HIP(hipGetLastError());
+        return KRYST_OK;
+    }
     if (D->GL.ok && D->GU.ok) {
         // structured grid: r -> forward wavefront -> y (natural order) -> backward wavefront -> z; no permutations
         const GridFactor& A = D->GL; const GridFactor& B = D->GU;
@@ -718,7 +774,7 @@ void ilu_free(kryst_pc_t pc) {
     if (D->h_gave_up) (void)hipHostFree(D->h_gave_up);
     if (D->exec) (void)hipGraphExecDestroy(D->exec);
     if (D->graph) (void)hipGraphDestroy(D->graph);
-    D->L.free_all(); D->U.free_all(); D->GL.free_all(); D->GU.free_all(); (void)hipFree(D->d_args); (void)hipFree(D->d_flags); (void)hipFree(D->d_y); (void)hipFree(D->d_rL); (void)hipFree(D->d_yU); (void)hipFree(D->d_zU); (void)hipFree(D->d_mapLU);
+    D->L.free_all(); D->U.free_all(); D->GL.free_all(); D->GU.free_all(); D->BL.free_all(); D->BU.free_all(); (void)hipFree(D->d_args); (void)hipFree(D->d_flags); (void)hipFree(D->d_y); (void)hipFree(D->d_rL); (void)hipFree(D->d_yU); (void)hipFree(D->d_zU); (void)hipFree(D->d_mapLU);
     delete D;
     pc->d_work = nullptr;
 }
@@ -865,6 +921,90 @@ static int32_t build_grid(int64_t n, const FlatRows& ent, const std::vector<doub
     return KRYST_OK;
 }
 
+// Which box makes every offset of `offs` (col - row values, any sign) a step inside the 3 x 3 x 3 cube?  offset = di + Ni dj + Ni Nj dk with
+// |d| <= 1.  Candidates for Ni (and for Ni Nj) are the offsets' magnitudes and their neighbours; the smallest consistent pair wins (any
+// consistent pair gives a correct solve: the per-entry range checks of build_box make the decomposition unique for every row).
+static bool box_decompose(int64_t o, int64_t s1, int64_t s2, int& dk, int& dj, int& di) {
+    // o = di + s1 dj + s2 dk: take dk, dj as the nearest multiples
+    const int64_t ao = o < 0 ? -o : o;
+    for (int k = -1; k <= 1; ++k)
+        for (int j = -1; j <= 1; ++j) {
+            const int64_t rest = o - s2 * k - s1 * j;
+            if (rest >= -1 && rest <= 1) { dk = k; dj = j; di = (int)rest; (void)ao; return true; }
+        }
+    return false;
+}
+static bool box_dims_from_offsets(const std::vector<int64_t>& offs, int64_t n, int64_t* Ni_out, int64_t* Nj_out) {
+    std::vector<int64_t> mags;
+    for (int64_t o : offs) { const int64_t m = o < 0 ? -o : o; if (m > 0) mags.push_back(m); }
+    std::sort(mags.begin(), mags.end()); mags.erase(std::unique(mags.begin(), mags.end()), mags.end());
+    if (mags.empty() || mags.size() > 13) return false;
+    std::vector<int64_t> cand;
+    for (int64_t m : mags) for (int64_t c : {m - 1, m, m + 1}) if (c >= 3 && c <= n) cand.push_back(c);      // lines of at least 3 rows: +1 and -1 steps are distinct from +-Ni -+ 1
+    cand.push_back(n);
+    std::sort(cand.begin(), cand.end()); cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+    for (int64_t s1 : cand) {
+        if (n % s1 != 0) continue;
+        for (int64_t s2 : cand) {
+            if (s2 <= s1 || s2 % s1 != 0 || n % s2 != 0 || s2 / s1 < 3) continue;      // (at least 3 lines per plane, or one plane: s2 == n)
+            bool all = true;
+            for (int64_t o : offs) { int dk, dj, di; if (o != 0 && !box_decompose(o, s1, s2, dk, dj, di)) { all = false; break; } if (o != 0 && s2 == n && dk != 0) { all = false; break; } }
+            if (all) { *Ni_out = s1; *Nj_out = s2 / s1; return true; }
+        }
+    }
+    return false;
+}
+
+// Recognise a box-stencil factor and lay it out as 13 natural-order coefficient streams.  Not an error when it does not apply.
+static int32_t build_box(int64_t n, const FlatRows& ent, const std::vector<double>& diag, bool forward, BoxFactor* B) {
+    if (n < 27 || n >= (1ll << 31) || env_int("KRYST_ILU_BOX", 0) == 0) return KRYST_OK;
+    // distinct offsets (at most 13), rows in ascending column order, strictly lower / upper
+    std::vector<int64_t> offs;
+    {
+        std::atomic<bool> reject{false};
+        std::mutex mu;
+        par_rows(n, [&](int64_t lo, int64_t hi) {
+            std::vector<int64_t> mine;
+            for (int64_t i = lo; i < hi && !reject.load(std::memory_order_relaxed); ++i)
+                for (int64_t k = ent.ptr[i]; k < ent.ptr[i + 1]; ++k) {
+                    const int64_t o = (int64_t)ent.col[k] - i;
+                    if ((forward && o >= 0) || (!forward && o <= 0)) { reject = true; return; }
+                    if (k > ent.ptr[i] && ent.col[k] <= ent.col[k - 1]) { reject = true; return; }   // the kernels subtract in ascending column order
+                    if (std::find(mine.begin(), mine.end(), o) == mine.end()) { if (mine.size() == 13) { reject = true; return; } mine.push_back(o); }
+                }
+            std::lock_guard<std::mutex> g(mu);
+            for (int64_t o : mine) if (std::find(offs.begin(), offs.end(), o) == offs.end()) offs.push_back(o);
+        });
+        if (reject || offs.empty() || offs.size() > 13) return KRYST_OK;
+    }
+    int64_t Ni = 0, Nj = 0;
+    if (!box_dims_from_offsets(offs, n, &Ni, &Nj)) return KRYST_OK;
+    const int64_t s1 = Ni, s2 = Ni * Nj, Nk = n / s2;
+    std::vector<double> c((size_t)13 * (size_t)n, 0.0);
+    {
+        std::atomic<bool> reject{false};
+        par_rows(n, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) {
+                const int64_t ii = i % Ni, jx = (i / Ni) % Nj, kx = i / s2;
+                for (int64_t k = ent.ptr[i]; k < ent.ptr[i + 1]; ++k) {
+                    int dk, dj, di;
+                    if (!box_decompose((int64_t)ent.col[k] - i, s1, s2, dk, dj, di)) { reject = true; return; }
+                    // the neighbour must exist in the box (an entry that wraps around a line or plane end is not a box coupling)
+                    if (ii + di < 0 || ii + di >= Ni || jx + dj < 0 || jx + dj >= Nj || kx + dk < 0 || kx + dk >= Nk) { reject = true; return; }
+                    const int code = 9 * (dk + 1) + 3 * (dj + 1) + (di + 1);
+                    if (forward ? code >= 13 : code <= 13) { reject = true; return; }
+                    c[(size_t)(forward ? code : code - 14) * (size_t)n + (size_t)i] = ent.val[k];
+                }
+            }
+        });
+        if (reject) return KRYST_OK;
+    }
+    KR_TRY(up(&B->d_c, c));
+    if (!forward) KR_TRY(up(&B->d_diag, diag));
+    B->Ni = (int32_t)Ni; B->Nj = (int32_t)Nj; B->Nk = (int32_t)Nk; B->ok = true;
+    return KRYST_OK;
+}
+
 }  // namespace kr
 
 using namespace kr;
@@ -889,7 +1029,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
     if (hipMalloc(&D->d_args, sizeof(TriArgs)) != hipSuccess || zero_dev(D->d_args, sizeof(TriArgs), ctx->s_main) != KRYST_OK) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
     if (rc == KRYST_OK) {
         const size_t bytes = sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
-        const bool grid = D->GL.ok && D->GU.ok;                            // the wavefront solve works in place: one intermediate vector
+        const bool grid = (D->GL.ok && D->GU.ok) || (D->BL.ok && D->BU.ok);   // the wavefront / box solves work in place: one intermediate vector
         for (double** pp : {&D->d_y, &D->d_rL, &D->d_yU, &D->d_zU}) {
             if (rc != KRYST_OK) break;
             if (grid && pp != &D->d_y) continue;
@@ -970,6 +1110,12 @@ static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRow
     if (D->GL.ok && D->GU.ok && (D->GL.Ni != D->GU.Ni || D->GL.Nj != D->GU.Nj)) D->GL.ok = false;
     if (rc == KRYST_OK && !(D->GL.ok && D->GU.ok)) {
         D->GL.free_all(); D->GU.free_all(); D->GL = GridFactor(); D->GU = GridFactor();
+        // box stencils wider than 7 points (round 4): natural-order streams, hyperplane / wavefront kernels, no level machinery
+        rc = build_box(n, le, ones, true, &D->BL);
+        if (rc == KRYST_OK && D->BL.ok) rc = build_box(n, ue, dg, false, &D->BU);
+        if (!(D->BL.ok && D->BU.ok && D->BL.Ni == D->BU.Ni && D->BL.Nj == D->BU.Nj)) { D->BL.free_all(); D->BU.free_all(); D->BL = BoxFactor(); D->BU = BoxFactor(); }
+    }
+    if (rc == KRYST_OK && !(D->GL.ok && D->GU.ok) && !(D->BL.ok && D->BU.ok)) {
         std::vector<int32_t> posL, posU;
         rc = build_factor(n, le, ones, true, &D->L, &posL);
         if (rc == KRYST_OK) rc = build_factor(n, ue, dg, false, &D->U, &posU);
@@ -1437,6 +1583,19 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         for (int q = 0; q < 256; ++q) cnt += used[q] ? 1 : 0;
         // (a row block of a distributed grid operator lists up to two halo offsets besides its seven)
         if (cnt <= (a->dist ? 9 : 7) && env_int("KRYST_ILU_GRID", 1) != 0) return KRYST_OK;      // (with the grid forms switched off nothing would recognise it anyway)
+        // a box stencil inside the 3 x 3 x 3 cube (up to 27 offsets that decompose for one Ni, Nj): the host path lays its factors out as
+        // natural-order streams for the box kernels (round 4)
+        if (!a->dist && cnt <= 27 && env_int("KRYST_ILU_BOX", 0) != 0) {
+            int32_t dict[256];
+            if (hipMemcpyAsync(dict, a->d_dict, sizeof dict, hipMemcpyDeviceToHost, ctx->s_main) == hipSuccess && hipStreamSynchronize(ctx->s_main) == hipSuccess) {
+                std::vector<int64_t> offs;
+                for (int q = 0; q < 256; ++q) if (used[q]) offs.push_back(dict[q]);
+                int64_t bi = 0, bj = 0;
+                std::vector<int64_t> lower, upper;
+                for (int64_t o : offs) { if (o < 0) lower.push_back(o); else if (o > 0) upper.push_back(o); }
+                if (lower.size() <= 13 && upper.size() <= 13 && box_dims_from_offsets(offs, n64, &bi, &bj)) return KRYST_OK;
+            } else (void)hipGetLastError();
+        }
     }
     struct Tmp {
         double *w = nullptr, *dg = nullptr; int32_t *dpos = nullptr, *done = nullptr, *order = nullptr, *nl = nullptr, *nu = nullptr;
@@ -1781,7 +1940,8 @@ extern "C" int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kr
 
 // What an ILU-family preconditioner's apply runs and streams (bench.py prices the triangular solve with it):
 //   info[0] form: 0 level-ordered factors (sync-free / level kernels), 1 structured grid, 8 x 8 lines per workgroup, 2 structured
-//           grid, 16 x 16 lines per workgroup (tri_quad.h), 3 structured grid after a give-up (plane kernels)
+//           grid, 16 x 16 lines per workgroup (tri_quad.h), 3 structured grid after a give-up (plane kernels), 4 box stencil inside the
+//           3 x 3 x 3 cube, one launch per hyperplane i + 2 j + 4 k (info[4], info[5]: hyperplanes per factor)
 //   info[1..3] Ni, Nj, Nk (grid forms)          info[4], info[5] dependency levels of L, U (level-ordered forms)
 //   info[6], info[7] coefficient chunks (per block quadrant) of the forward / backward factor; info[8], info[9] how many of them
 //           repeat chunk - 3 bit for bit and are not requested; info[10], info[11] bytes per chunk request (forward, backward)
@@ -1792,6 +1952,12 @@ extern "C" int32_t kryst_pc_ilu_info(kryst_pc_t pc, int64_t* info, int32_t count
     IluData* D = reinterpret_cast<IluData*>(pc->d_work);
     kryst_ctx_t ctx = pc->ctx;
     for (int i = 0; i < count; ++i) info[i] = 0;
+    if (D->BL.ok && D->BU.ok) {                                            // box stencil (round 4): 4 = one launch per hyperplane i + 2 j + 4 k
+        info[0] = 4;
+        info[1] = D->BL.Ni; info[2] = D->BL.Nj; info[3] = D->BL.Nk;
+        info[4] = info[5] = (D->BL.Ni - 1) + 2 * (D->BL.Nj - 1) + 4 * (D->BL.Nk - 1) + 1;
+        return KRYST_OK;
+    }
     if (!(D->GL.ok && D->GU.ok)) {
         info[0] = 0;
         info[4] = D->L.lvl_off.empty() ? 0 : (int64_t)D->L.lvl_off.size() - 1;

@@ -636,6 +636,62 @@ def test_structured_grid_triangular_solve_bit_exact(ctx, grid_path, monkeypatch)
                 assert np.array_equal(pc.apply(r), ref.apply(r)), (grid_path, a.nrows)
 
 
+def _box_operator(rng, Ni, Nj, Nk, keep, drop=0.0, unsym=True):
+    """A stencil operator inside the 3 x 3 x 3 cube on an Ni x Nj x Nk box, natural ordering: `keep(dk, dj, di)` selects the couplings (27-point: all),
+    a fraction `drop` of the couplings is removed at random, the values are random (unsymmetric), the diagonal dominates."""
+    import scipy.sparse as sp
+    n = Ni * Nj * Nk
+    idx = np.arange(n)
+    i, j, k = idx % Ni, (idx // Ni) % Nj, idx // (Ni * Nj)
+    rows, cols, vals = [], [], []
+    for dk in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            for di in (-1, 0, 1):
+                if (dk, dj, di) == (0, 0, 0) or not keep(dk, dj, di):
+                    continue
+                ok = (i + di >= 0) & (i + di < Ni) & (j + dj >= 0) & (j + dj < Nj) & (k + dk >= 0) & (k + dk < Nk)
+                if drop > 0.0:
+                    ok &= rng.random(n) >= drop
+                r = idx[ok]
+                rows.append(r); cols.append(r + di + Ni * dj + Ni * Nj * dk)
+                vals.append(-rng.uniform(0.2, 1.0, len(r)) if unsym else -np.ones(len(r)))
+    m = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    m = (m + sp.diags(np.asarray(abs(m).sum(axis=1)).ravel() + 1.0)).tocsr()
+    m.sort_indices()
+    return O.Csr(n, n, m.indptr, m.indices, m.data)
+
+
+@pytest.mark.parametrize("form", ["box", "levels"])
+def test_box_stencil_triangular_solve_bit_exact(ctx, form, monkeypatch):
+    """Factors of operators inside the 3 x 3 x 3 cube that are NOT 7-point operators (27-point, 19-point, 2-D 9-point, boxes with randomly
+    missing couplings) are laid out as 13 natural-order coefficient streams per factor and solved by the box kernels (KRYST_ILU_BOX=1,
+    default; round 4) -- hyperplanes i + 2 j + 4 k -- instead of the level-ordered forms: the oracle's bits either way, for true ILU(0),
+    Ilu0 as written and Ilup(0), on boxes of any shape; a band matrix that wraps around line ends is not a box operator."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("KRYST_ILU_BOX", "1" if form == "box" else "0")
+    rng = np.random.default_rng(27)
+    all27 = lambda dk, dj, di: True
+    p19 = lambda dk, dj, di: abs(dk) + abs(dj) + abs(di) <= 2
+    p9_2d = lambda dk, dj, di: dk == 0
+    cases = [(_box_operator(rng, 5, 4, 3, all27), True), (_box_operator(rng, 9, 8, 8, all27), True), (_box_operator(rng, 17, 9, 10, all27), True),
+             (_box_operator(rng, 12, 11, 7, p19), True), (_box_operator(rng, 40, 25, 1, p9_2d), True), (_box_operator(rng, 3, 3, 3, all27), True),
+             (_box_operator(rng, 10, 9, 9, all27, drop=0.3), True), (_box_operator(rng, 33, 5, 6, all27, drop=0.05), True)]
+    # wrap-around bands with the offsets of a 6 x 5 x 4 box: entries cross line ends -> level-ordered forms
+    n = 6 * 5 * 4
+    offs = sorted({di + 6 * dj + 30 * dk for dk in (-1, 0, 1) for dj in (-1, 0, 1) for di in (-1, 0, 1)})
+    m = sp.diags([(-0.03 if o else 5.0) * np.ones(n - abs(o)) for o in offs], offs).tocsr(); m.sort_indices()
+    cases.append((O.Csr(n, n, m.indptr, m.indices, m.data), False))
+    for a, is_box in cases:
+        d = to_dev(ctx, a)
+        for kpc, ofn in ((K.TrueIlu0(), O.Pc.ilu0_true), (K.Ilu0(), O.Pc.ilu0_compat), (K.Ilup(0), O.Pc.ilup0)):
+            pc = kpc.setup(d); ref = ofn(a)
+            info = pc.ilu_info()
+            assert info["form"].startswith("box") == (is_box and form == "box"), (form, a.nrows, info)
+            for _ in range(2):
+                r = rng.standard_normal(a.nrows)
+                assert np.array_equal(pc.apply(r), ref.apply(r)), (form, a.nrows)
+
+
 def test_lines_longer_than_the_chunk_flag_table(ctx, monkeypatch):
     """A box whose lines have more 8-step chunks than the 16 x 16 kernel's flag table holds (TQ_SKIPMAX = 544 chunks, Ni > ~4 330):
     the kernel runs without repeat flags and must not request coefficient chunks past the line's end (needs(m) read
