@@ -45,6 +45,8 @@ static void par_rows(int64_t n, F body) {
 // wavefront kernel by number of 8 x 8 line blocks in the (j, k) plane: the 16 x 16 kernel from 32^3 up (table at its use)
 static int default_wave_form(unsigned nb8) { return nb8 >= 16 ? 2 : 1; }
 
+#define KR_ILU_BOX_DEFAULT 0         // KRYST_ILU_BOX: 0 box-stencil factors take the level-ordered forms, 1 hyperplane launches, 2 pipelined wavefront (tri_box.h)
+
 struct TriArgs {                    // device-resident argument block, rewritten before every apply (graph-friendly):
     const double* r; double* z; long long skip;   // one scalar load gives a level kernel everything it needs
     long long epoch;                              // number of this apply (tri_quad.h: the value of its "under way" flags)
@@ -117,6 +119,7 @@ struct IluData {
     int32_t direct_epoch = 0;       // number of the last directly launched apply (1 .. 2^30 - 1; its flag value has bit 30 set)
     int32_t* h_gave_up = nullptr;   // mapped host word the wavefront kernel raises when a poller runs out of patience (never cleared on the device)
     int32_t* d_gave_up = nullptr;   // its device address
+    bool box_wave_ready = false;    // box factor: flags, give-up word and the kernels' LDS size are set up for tri_box_kernel
     bool safe = false;              // the wavefront kernel gave up once: this preconditioner now uses the plane kernels (no inter-workgroup waits)
     bool fell_back = false;         // ... and the switch happened since the last pc_fell_back() query
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
@@ -409,6 +412,7 @@ __global__ __launch_bounds__(64) void tri_grid_kernel(const TriArgs* args, const
 }  // namespace kr
 #include "tri_wave.h"
 #include "tri_quad.h"
+#include "tri_box.h"
 namespace kr {
 
 __global__ __launch_bounds__(256) void tri_fill_kernel(const TriArgs* args, double* dst_ptr, int64_t n, int32_t* flags = nullptr, int32_t nflags = 0) {
@@ -620,13 +624,32 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
     return KRYST_OK;
 }
 
+// does a box-stencil factor take the pipelined wavefront kernels (KRYST_ILU_BOX: 0 no box form at all, 1 hyperplane launches, 2 wavefront)?
+static bool box_takes_wavefront(const IluData* D) {
+    return D->BL.ok && D->BU.ok && D->box_wave_ready && !D->safe && env_int("KRYST_ILU_PLANES", 0) == 0 && env_int("KRYST_ILU_BOX", KR_ILU_BOX_DEFAULT) >= 2;
+}
+
 // r -> rL (L level order) -> forward -> yL -> yU (U level order) -> backward -> zU -> z
 static int32_t enqueue_apply(hipStream_t s, IluData* D, const TriDirect* direct = nullptr) {
     const unsigned g = (unsigned)((D->n + 255) / 256);
     if (D->BL.ok && D->BU.ok) {
-        // box stencil: r -> forward -> y (natural order) -> backward -> z; one launch per hyperplane i + 2 j + 4 k
+        // box stencil: r -> forward -> y (natural order) -> backward -> z
         const BoxFactor& A = D->BL; const BoxFactor& B = D->BU;
         const BoxView VA{A.Ni, A.Nj, A.Nk, D->n, A.d_c, nullptr}, VB{B.Ni, B.Nj, B.Nk, D->n, B.d_c, B.d_diag};
+        if (box_takes_wavefront(D)) {
+            // pipelined wavefront over parallelograms of 8 x 8 lines (tri_box.h); the abort word behind the 2 nb flags stays set once raised
+            const unsigned nb = (unsigned)(tb_nbj(A.Nj) * tb_nbk(A.Nk));
+            const int budget = std::max(1, env_int("KRYST_ILU_POLL_BUDGET", 1 << 22));
+            hipLaunchKernelGGL((tri_box_fill_kernel<true>), dim3(nb), dim3(256), 0, s, D->d_args, D->d_y, VA, D->d_flags, (int32_t)(2 * nb));
+            hipLaunchKernelGGL((tri_box_kernel<true>), dim3(nb), dim3(256), tb_lds_bytes<true>(), s, D->d_args, (const double*)nullptr, D->d_y, VA, D->d_flags,
+                               D->d_flags + 2 * nb, D->d_gave_up, budget);
+            hipLaunchKernelGGL((tri_box_fill_kernel<false>), dim3(nb), dim3(256), 0, s, D->d_args, (double*)nullptr, VB, (int32_t*)nullptr, 0);
+            hipLaunchKernelGGL((tri_box_kernel<false>), dim3(nb), dim3(256), tb_lds_bytes<false>(), s, D->d_args, (const double*)D->d_y, (double*)nullptr, VB, D->d_flags + nb,
+                               D->d_flags + 2 * nb, D->d_gave_up, budget);
+            KR_HIP(hipGetLastError());
+            return KRYST_OK;
+        }
+        // one launch per hyperplane i + 2 j + 4 k (KRYST_ILU_BOX=1, KRYST_ILU_PLANES=1, or after a give-up)
         const int nlev = (A.Ni - 1) + 2 * (A.Nj - 1) + 4 * (A.Nk - 1) + 1;
         const unsigned pg = (unsigned)(((int64_t)A.Nj * A.Nk + 255) / 256);
         for (int lv = 0; lv < nlev; ++lv)
@@ -723,7 +746,7 @@ int32_t ilu_apply_dev(kryst_pc_t pc, const double* r, double* z, const int* done
     KR_HIP(hipGetLastError());
     // a hipGraph pays where an apply is MANY launches (one per dependency level / hyperplane); the wavefront and the sync-free forms are
     // three to five launches, and launching them directly is 0.6 % (256^3) to 1.9 % (128^3) of a BiCGStab + ILU(0) iteration faster
-    const bool few_launches = !D->safe && env_int("KRYST_ILU_PLANES", 0) == 0 && ((D->GL.ok && D->GU.ok) || (D->L.syncfree && D->U.syncfree));
+    const bool few_launches = (!D->safe && env_int("KRYST_ILU_PLANES", 0) == 0 && ((D->GL.ok && D->GU.ok) || (D->L.syncfree && D->U.syncfree))) || box_takes_wavefront(D);
     const int use_graph = env_int("KRYST_ILU_GRAPH", few_launches ? 0 : 1);        // (read per apply: tools/solver_ab.py)
     if (!D->exec && use_graph) {
         // capture the launch sequence once; the graph only refers to the device argument block
@@ -765,7 +788,7 @@ bool ilu_fell_back(kryst_pc_t pc) {
 }
 bool ilu_is_wavefront(kryst_pc_t pc) {
     IluData* D = reinterpret_cast<IluData*>(pc->d_work);
-    return D && D->GL.ok && D->GU.ok && !D->safe;
+    return D && ((D->GL.ok && D->GU.ok && !D->safe) || box_takes_wavefront(D));
 }
 
 void ilu_free(kryst_pc_t pc) {
@@ -957,7 +980,7 @@ static bool box_dims_from_offsets(const std::vector<int64_t>& offs, int64_t n, i
 
 // Recognise a box-stencil factor and lay it out as 13 natural-order coefficient streams.  Not an error when it does not apply.
 static int32_t build_box(int64_t n, const FlatRows& ent, const std::vector<double>& diag, bool forward, BoxFactor* B) {
-    if (n < 27 || n >= (1ll << 31) || env_int("KRYST_ILU_BOX", 0) == 0) return KRYST_OK;
+    if (n < 27 || n >= (1ll << 31) || env_int("KRYST_ILU_BOX", KR_ILU_BOX_DEFAULT) == 0) return KRYST_OK;
     // distinct offsets (at most 13), rows in ascending column order, strictly lower / upper
     std::vector<int64_t> offs;
     {
@@ -1037,6 +1060,19 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
             else if (hipMemsetAsync(*pp, 0, bytes, ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
         }
         if (rc == KRYST_OK && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
+    }
+    if (rc == KRYST_OK && D->BL.ok && D->BU.ok && D->BL.Ni >= 2) {
+        const size_t nb = (size_t)tb_nbj(D->BL.Nj) * (size_t)tb_nbk(D->BL.Nk);
+        if (hipMalloc(&D->d_flags, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess || zero_dev(D->d_flags, sizeof(int32_t) * (2 * nb + 1), ctx->s_main) != KRYST_OK) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (rc == KRYST_OK && (hipHostMalloc((void**)&D->h_gave_up, 64, hipHostMallocMapped) != hipSuccess ||
+                               hipHostGetDevicePointer((void**)&D->d_gave_up, D->h_gave_up, 0) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (rc == KRYST_OK) {
+            *D->h_gave_up = 0;
+            // 70 / 73 KiB of LDS per workgroup (two per CU): more than the 64 KiB a kernel gets without asking
+            D->box_wave_ready = hipFuncSetAttribute((const void*)tri_box_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<true>()) == hipSuccess &&
+                                hipFuncSetAttribute((const void*)tri_box_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<false>()) == hipSuccess;
+            (void)hipGetLastError();
+        }
     }
     if (rc == KRYST_OK && D->GL.ok && D->GU.ok) {
         const size_t nb = (size_t)((D->GL.Nj + 7) / 8) * (size_t)((D->GL.Nk + 7) / 8);
@@ -1585,7 +1621,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         if (cnt <= (a->dist ? 9 : 7) && env_int("KRYST_ILU_GRID", 1) != 0) return KRYST_OK;      // (with the grid forms switched off nothing would recognise it anyway)
         // a box stencil inside the 3 x 3 x 3 cube (up to 27 offsets that decompose for one Ni, Nj): the host path lays its factors out as
         // natural-order streams for the box kernels (round 4)
-        if (!a->dist && cnt <= 27 && env_int("KRYST_ILU_BOX", 0) != 0) {
+        if (!a->dist && cnt <= 27 && env_int("KRYST_ILU_BOX", KR_ILU_BOX_DEFAULT) != 0) {
             int32_t dict[256];
             if (hipMemcpyAsync(dict, a->d_dict, sizeof dict, hipMemcpyDeviceToHost, ctx->s_main) == hipSuccess && hipStreamSynchronize(ctx->s_main) == hipSuccess) {
                 std::vector<int64_t> offs;
@@ -1953,7 +1989,7 @@ extern "C" int32_t kryst_pc_ilu_info(kryst_pc_t pc, int64_t* info, int32_t count
     kryst_ctx_t ctx = pc->ctx;
     for (int i = 0; i < count; ++i) info[i] = 0;
     if (D->BL.ok && D->BU.ok) {                                            // box stencil (round 4): 4 = one launch per hyperplane i + 2 j + 4 k
-        info[0] = 4;
+        info[0] = box_takes_wavefront(D) ? 5 : 4;                          // 5 = pipelined wavefront over parallelograms of 8 x 8 lines (tri_box.h)
         info[1] = D->BL.Ni; info[2] = D->BL.Nj; info[3] = D->BL.Nk;
         info[4] = info[5] = (D->BL.Ni - 1) + 2 * (D->BL.Nj - 1) + 4 * (D->BL.Nk - 1) + 1;
         return KRYST_OK;

@@ -661,21 +661,22 @@ def _box_operator(rng, Ni, Nj, Nk, keep, drop=0.0, unsym=True):
     return O.Csr(n, n, m.indptr, m.indices, m.data)
 
 
-@pytest.mark.parametrize("form", ["box", "levels"])
+@pytest.mark.parametrize("form", ["wave", "box", "levels"])
 def test_box_stencil_triangular_solve_bit_exact(ctx, form, monkeypatch):
     """Factors of operators inside the 3 x 3 x 3 cube that are NOT 7-point operators (27-point, 19-point, 2-D 9-point, boxes with randomly
     missing couplings) are laid out as 13 natural-order coefficient streams per factor and solved by the box kernels (KRYST_ILU_BOX=1,
     default; round 4) -- hyperplanes i + 2 j + 4 k -- instead of the level-ordered forms: the oracle's bits either way, for true ILU(0),
     Ilu0 as written and Ilup(0), on boxes of any shape; a band matrix that wraps around line ends is not a box operator."""
     import scipy.sparse as sp
-    monkeypatch.setenv("KRYST_ILU_BOX", "1" if form == "box" else "0")
+    monkeypatch.setenv("KRYST_ILU_BOX", {"wave": "2", "box": "1", "levels": "0"}[form])
     rng = np.random.default_rng(27)
     all27 = lambda dk, dj, di: True
     p19 = lambda dk, dj, di: abs(dk) + abs(dj) + abs(di) <= 2
     p9_2d = lambda dk, dj, di: dk == 0
     cases = [(_box_operator(rng, 5, 4, 3, all27), True), (_box_operator(rng, 9, 8, 8, all27), True), (_box_operator(rng, 17, 9, 10, all27), True),
              (_box_operator(rng, 12, 11, 7, p19), True), (_box_operator(rng, 40, 25, 1, p9_2d), True), (_box_operator(rng, 3, 3, 3, all27), True),
-             (_box_operator(rng, 10, 9, 9, all27, drop=0.3), True), (_box_operator(rng, 33, 5, 6, all27, drop=0.05), True)]
+             (_box_operator(rng, 10, 9, 9, all27, drop=0.3), True), (_box_operator(rng, 33, 5, 6, all27, drop=0.05), True),
+             (_box_operator(rng, 41, 30, 19, all27), True), (_box_operator(rng, 7, 26, 17, p19, drop=0.1), True)]
     # wrap-around bands with the offsets of a 6 x 5 x 4 box: entries cross line ends -> level-ordered forms
     n = 6 * 5 * 4
     offs = sorted({di + 6 * dj + 30 * dk for dk in (-1, 0, 1) for dj in (-1, 0, 1) for di in (-1, 0, 1)})
@@ -686,10 +687,13 @@ def test_box_stencil_triangular_solve_bit_exact(ctx, form, monkeypatch):
         for kpc, ofn in ((K.TrueIlu0(), O.Pc.ilu0_true), (K.Ilu0(), O.Pc.ilu0_compat), (K.Ilup(0), O.Pc.ilup0)):
             pc = kpc.setup(d); ref = ofn(a)
             info = pc.ilu_info()
-            assert info["form"].startswith("box") == (is_box and form == "box"), (form, a.nrows, info)
+            assert info["form"].startswith("box") == (is_box and form != "levels"), (form, a.nrows, info)
+            if is_box and form != "levels":
+                assert info["form"].startswith("box wavefront") == (form == "wave"), (form, info)
             for _ in range(2):
                 r = rng.standard_normal(a.nrows)
                 assert np.array_equal(pc.apply(r), ref.apply(r)), (form, a.nrows)
+            assert pc.ilu_info()["form"] == info["form"], (form, a.nrows, "the wavefront solve gave up and fell back")
 
 
 def test_lines_longer_than_the_chunk_flag_table(ctx, monkeypatch):
