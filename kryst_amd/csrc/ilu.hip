@@ -45,7 +45,7 @@ static void par_rows(int64_t n, F body) {
 // wavefront kernel by number of 8 x 8 line blocks in the (j, k) plane: the 16 x 16 kernel from 32^3 up (table at its use)
 static int default_wave_form(unsigned nb8) { return nb8 >= 16 ? 2 : 1; }
 
-#define KR_ILU_BOX_DEFAULT 0         // KRYST_ILU_BOX: 0 box-stencil factors take the level-ordered forms, 1 hyperplane launches, 2 pipelined wavefront (tri_box.h)
+#define KR_ILU_BOX_DEFAULT 2         // KRYST_ILU_BOX: 0 box-stencil factors take the level-ordered forms, 1 hyperplane launches, 2 pipelined wavefront (tri_box.h)
 
 struct TriArgs {                    // device-resident argument block, rewritten before every apply (graph-friendly):
     const double* r; double* z; long long skip;   // one scalar load gives a level kernel everything it needs
@@ -1555,6 +1555,28 @@ __global__ __launch_bounds__(256) void gen_classify_kernel(const int32_t* __rest
     nl[i] = a; nu[i] = b; dg[i] = d;
 }
 // one factor in level order: position p holds row rowid[p]; its kept entries in stored order, columns as positions
+// Box-stencil factors straight from the factor values on A's pattern (round 4): stream a of row i = the entry whose column is the
+// (dk, dj, di) neighbour of (i, j, k) in the Ni x Nj x Nk box -- BoxFactor's layout; `bad` is raised by an entry that is no such neighbour
+// (it wraps around a line or plane end), a halo column, or a row whose columns do not ascend.  Zero values stay +0.0 = no entry.
+__global__ __launch_bounds__(256) void gen_box_fill_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ w, const double* __restrict__ dg,
+                                                           int32_t n, int32_t Ni, int32_t Nj, int32_t Nk, double* cl, double* cu, double* diag, int32_t* bad) {
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t ii = i % Ni, jj = (i / Ni) % Nj, kk = i / (Ni * Nj);
+    int32_t prev = -1;
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+        const int32_t j = col[k];
+        if (j >= n || j <= prev) { *bad = 1; return; }
+        prev = j;
+        if (j == i || w[k] == 0.0) continue;
+        const int di = j % Ni - ii, dj = (j / Ni) % Nj - jj, dk = j / (Ni * Nj) - kk;
+        if (di < -1 || di > 1 || dj < -1 || dj > 1 || dk < -1 || dk > 1) { *bad = 1; return; }
+        const int code = 9 * (dk + 1) + 3 * (dj + 1) + (di + 1);
+        if (j < i) cl[(int64_t)code * n + i] = w[k]; else cu[(int64_t)(code - 14) * n + i] = w[k];
+    }
+    diag[i] = dg[i];
+}
+
 template <bool LOWER>
 __global__ __launch_bounds__(256) void gen_fill_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ w, int32_t n,
                                                        const int32_t* __restrict__ rowid, const int32_t* __restrict__ pos, const int32_t* __restrict__ ptr,
@@ -1601,6 +1623,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
     const int64_t n64 = a->nrows, nnz = a->nnz;
     if (n64 == 0 || nnz == 0 || n64 >= (1ll << 31) - 4 || env_int("KRYST_ILU_DEVICE_SETUP", 1) == 0) return KRYST_OK;
     const int32_t n = (int32_t)n64;
+    int64_t box_ni = 0, box_nj = 0;                                         // > 0: the operator's offsets are those of a box stencil on lines of box_ni rows, box_nj lines per plane
     tl_setup_stream = ctx->s_main;
     const bool verbose = getenv("KRYST_ILU_VERBOSE") != nullptr;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
@@ -1629,7 +1652,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
                 int64_t bi = 0, bj = 0;
                 std::vector<int64_t> lower, upper;
                 for (int64_t o : offs) { if (o < 0) lower.push_back(o); else if (o > 0) upper.push_back(o); }
-                if (lower.size() <= 13 && upper.size() <= 13 && box_dims_from_offsets(offs, n64, &bi, &bj)) return KRYST_OK;
+                if (lower.size() <= 13 && upper.size() <= 13 && box_dims_from_offsets(offs, n64, &bi, &bj) && n64 >= 27) { box_ni = bi; box_nj = bj; }
             } else (void)hipGetLastError();
         }
     }
@@ -1697,15 +1720,40 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         set_error("ILUP: zero diagonal in U at row %lld", (long long)(hf[0] & 0xffffffffull));
         return KRYST_SOLVE_ERROR;
     }
-    if (nl != cntL || nu != cntU) return KRYST_OK;
     lap("factor values, kept entries");
-    // ---- the preconditioner object and its two level-ordered factors
     kryst_pc_t pc = new kryst_pc_s();
     pc->ctx = ctx; pc->kind = KR_PC_ILU; pc->a = a; pc->n = n; pc->ilu_mode = mode; pc->divide_diag = divide;
     IluData* D = new IluData();
     D->n = n;
     pc->d_work = reinterpret_cast<double*>(D);
     int32_t rc = KRYST_OK;
+    if (box_ni > 0) {
+        // ---- box stencil: 13 natural-order coefficient streams per factor, written by one kernel (no level machinery at all)
+        const size_t cb = sizeof(double) * (size_t)13 * (size_t)n;
+        int32_t* d_bad = reinterpret_cast<int32_t*>(t.flags + 3);
+        int32_t bad = 1;
+        if (hipMalloc(&D->BL.d_c, cb) != hipSuccess || hipMalloc(&D->BU.d_c, cb) != hipSuccess || hipMalloc(&D->BU.d_diag, sizeof(double) * (size_t)n) != hipSuccess) {
+            (void)hipGetLastError();
+        } else if (hipMemsetAsync(D->BL.d_c, 0, cb, ctx->s_main) == hipSuccess && hipMemsetAsync(D->BU.d_c, 0, cb, ctx->s_main) == hipSuccess) {
+            const int32_t Ni = (int32_t)box_ni, Nj = (int32_t)box_nj, Nk = (int32_t)(n64 / (box_ni * box_nj));
+            hipLaunchKernelGGL(gen_box_fill_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dg, n, Ni, Nj, Nk, D->BL.d_c, D->BU.d_c, D->BU.d_diag, d_bad);
+            if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->s_main) == hipSuccess &&
+                hipStreamSynchronize(ctx->s_main) == hipSuccess && bad == 0) {
+                for (BoxFactor* F : {&D->BL, &D->BU}) { F->Ni = Ni; F->Nj = Nj; F->Nk = Nk; F->ok = true; }
+            }
+        }
+        (void)hipGetLastError();
+        if (D->BL.ok && D->BU.ok) {
+            lap("box-stencil streams");
+            rc = finish_ilu_device(pc, D);
+            if (rc != KRYST_OK) { kryst_pc_destroy(pc); return rc; }
+            *out = pc;
+            return KRYST_OK;
+        }
+        D->BL.free_all(); D->BU.free_all(); D->BL = BoxFactor(); D->BU = BoxFactor();       // not a box operator after all: the level-ordered forms
+    }
+    if (nl != cntL || nu != cntU) { kryst_pc_destroy(pc); return KRYST_OK; }
+    // ---- the two level-ordered factors
     std::vector<int32_t> ptr((size_t)n + 1);
     for (int which = 0; which < 2 && rc == KRYST_OK; ++which) {
         TriFactor* F = which == 0 ? &D->L : &D->U;
