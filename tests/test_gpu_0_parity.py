@@ -636,7 +636,7 @@ def test_structured_grid_triangular_solve_bit_exact(ctx, grid_path, monkeypatch)
                 assert np.array_equal(pc.apply(r), ref.apply(r)), (grid_path, a.nrows)
 
 
-def _box_operator(rng, Ni, Nj, Nk, keep, drop=0.0, unsym=True):
+def _box_operator(rng, Ni, Nj, Nk, keep, drop=0.0, unsym=True, zeros=0.0):
     """A stencil operator inside the 3 x 3 x 3 cube on an Ni x Nj x Nk box, natural ordering: `keep(dk, dj, di)` selects the couplings (27-point: all),
     a fraction `drop` of the couplings is removed at random, the values are random (unsymmetric), the diagonal dominates."""
     import scipy.sparse as sp
@@ -654,10 +654,16 @@ def _box_operator(rng, Ni, Nj, Nk, keep, drop=0.0, unsym=True):
                     ok &= rng.random(n) >= drop
                 r = idx[ok]
                 rows.append(r); cols.append(r + di + Ni * dj + Ni * Nj * dk)
-                vals.append(-rng.uniform(0.2, 1.0, len(r)) if unsym else -np.ones(len(r)))
-    m = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
-    m = (m + sp.diags(np.asarray(abs(m).sum(axis=1)).ravel() + 1.0)).tocsr()
+                v = -rng.uniform(0.2, 1.0, len(r)) if unsym else -np.ones(len(r))
+                if zeros > 0.0:
+                    v[rng.random(len(v)) < zeros] = 0.0                    # stored zeros: part of the pattern, never kept in a factor
+                vals.append(v)
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    dsum = np.ones(n)
+    np.add.at(dsum, rows, np.abs(vals))
+    m = sp.coo_matrix((np.concatenate([vals, dsum]), (np.concatenate([rows, idx]), np.concatenate([cols, idx]))), shape=(n, n)).tocsr()
     m.sort_indices()
+    assert zeros == 0.0 or (m.data == 0.0).any()                           # the zeros are stored
     return O.Csr(n, n, m.indptr, m.indices, m.data)
 
 
@@ -676,17 +682,23 @@ def test_box_stencil_triangular_solve_bit_exact(ctx, form, monkeypatch):
     cases = [(_box_operator(rng, 5, 4, 3, all27), True), (_box_operator(rng, 9, 8, 8, all27), True), (_box_operator(rng, 17, 9, 10, all27), True),
              (_box_operator(rng, 12, 11, 7, p19), True), (_box_operator(rng, 40, 25, 1, p9_2d), True), (_box_operator(rng, 3, 3, 3, all27), True),
              (_box_operator(rng, 10, 9, 9, all27, drop=0.3), True), (_box_operator(rng, 33, 5, 6, all27, drop=0.05), True),
-             (_box_operator(rng, 41, 30, 19, all27), True), (_box_operator(rng, 7, 26, 17, p19, drop=0.1), True)]
+             (_box_operator(rng, 41, 30, 19, all27), True), (_box_operator(rng, 7, 26, 17, p19, drop=0.1), True),
+             (_box_operator(rng, 13, 12, 11, all27, drop=0.1, zeros=0.1), True)]
     # wrap-around bands with the offsets of a 6 x 5 x 4 box: entries cross line ends -> level-ordered forms
     n = 6 * 5 * 4
     offs = sorted({di + 6 * dj + 30 * dk for dk in (-1, 0, 1) for dj in (-1, 0, 1) for di in (-1, 0, 1)})
     m = sp.diags([(-0.03 if o else 5.0) * np.ones(n - abs(o)) for o in offs], offs).tocsr(); m.sort_indices()
     cases.append((O.Csr(n, n, m.indptr, m.indices, m.data), False))
-    for a, is_box in cases:
+    for case, (a, is_box) in enumerate(cases):
         d = to_dev(ctx, a)
-        for kpc, ofn in ((K.TrueIlu0(), O.Pc.ilu0_true), (K.Ilu0(), O.Pc.ilu0_compat), (K.Ilup(0), O.Pc.ilup0)):
+        # streams written on the device from the factor values (gen_box_fill_kernel) / by the host path (build_box)
+        monkeypatch.setenv("KRYST_ILU_DEVICE_SETUP", "0" if case % 2 else "1")
+        for kpc, ofn in ((K.TrueIlu0(), O.Pc.ilu0_true), (K.Ilu0(), O.Pc.ilu0_compat), (K.Ilup(0), O.Pc.ilup0), (K.Ilup(1), lambda m: O.Pc.ilup(m, 1))):
             pc = kpc.setup(d); ref = ofn(a)
             info = pc.ilu_info()
+            if isinstance(kpc, K.Ilup) and kpc.fill == 1:                  # fill entries leave the 3 x 3 x 3 cube
+                assert np.array_equal(pc.apply(np.ones(a.nrows)), ref.apply(np.ones(a.nrows)))
+                continue
             assert info["form"].startswith("box") == (is_box and form != "levels"), (form, a.nrows, info)
             if is_box and form != "levels":
                 assert info["form"].startswith("box wavefront") == (form == "wave"), (form, info)
@@ -822,6 +834,29 @@ def test_wavefront_give_up_path_falls_back_to_plane_kernels(ctx, rs, wave, monke
     with pytest.raises(K.KError) as e:
         sess.end()
     assert e.value.code == 2
+
+
+def test_box_wavefront_give_up_path_falls_back_to_hyperplane_launches(ctx, rs, monkeypatch):
+    """tri_box.h's pollers wait for neighbour blocks like tri_wave.h's: with a poll budget of one empty poll every block gives up; the host
+    notices, repeats the apply with one launch per hyperplane i + 2 j + 4 k and stays there -- the oracle's bits throughout."""
+    monkeypatch.setenv("KRYST_ILU_POLL_BUDGET", "1")
+    monkeypatch.setenv("KRYST_ILU_BOX", "2")
+    rng = np.random.default_rng(5)
+    ao = _box_operator(rng, 20, 18, 17, lambda dk, dj, di: True)
+    a = to_dev(ctx, ao)
+    r = rng.standard_normal(ao.nrows)
+    pc = K.TrueIlu0().setup(a); ref = O.Pc.ilu0_true(ao)
+    assert pc.ilu_info()["form"].startswith("box wavefront")
+    assert np.array_equal(pc.apply(r), ref.apply(r))              # gives up, repeated with the hyperplane kernels
+    assert pc.ilu_info()["form"].startswith("box planes")
+    assert np.array_equal(pc.apply(2.0 * r), ref.apply(2.0 * r))
+    b = ao.spmv(np.ones(ao.nrows))
+    pc = K.TrueIlu0().setup(a)                                      # a fresh preconditioner: the give-up happens inside the solve
+    res = O.solve("gmres", ao, b, pc=O.Pc.ilu0_true(ao), tol=1e-10, max_iters=100, restart=10, side=O.SIDE_RIGHT, rs=rs)
+    g = K.GmresSolver(10, 1e-10, 100); g.preconditioning = K.Preconditioning.Right; x = np.zeros(ao.nrows)
+    st = g.solve(a, pc, b, x)
+    assert st.iterations == res.iterations and np.array_equal(x, res.x)
+    assert pc.ilu_info()["form"].startswith("box planes")
 
 
 @pytest.mark.parametrize("seed", [1, 2])
