@@ -20,6 +20,12 @@
 #include "pc.h"
 #include <chrono>
 #include <thread>
+#include <sched.h>
+#include <sys/mman.h>
+#include <cstdlib>
+#include <new>
+#include <pthread.h>
+#include <memory>
 #include <mutex>
 #include <atomic>
 #include "ew.h"
@@ -42,6 +48,33 @@ static void par_rows(int64_t n, F body) {
     }
     for (auto& t : th) t.join();
 }
+// Host arrays of the setup paths (hundreds of MB on a 128^3 operator): elements are NOT value-initialised (a std::vector zeroes what the
+// next loop overwrites, on one thread), and blocks of 4 MiB and more are 2 MiB-aligned with a huge-page hint -- first-touch page faults
+// and the unmapping at the end were a quarter of the Ilup(1) setup (round 4).
+template <class T>
+struct HostAlloc {
+    using value_type = T;
+    HostAlloc() = default;
+    template <class U> HostAlloc(const HostAlloc<U>&) {}
+    T* allocate(size_t cnt) {
+        const size_t bytes = cnt * sizeof(T);
+        void* q = nullptr;
+        if (bytes >= ((size_t)1 << 22)) {
+            const size_t big = (size_t)1 << 21;
+            if (posix_memalign(&q, big, (bytes + big - 1) / big * big) != 0) throw std::bad_alloc();
+            (void)madvise(q, (bytes + big - 1) / big * big, MADV_HUGEPAGE);
+        } else if (!(q = std::malloc(std::max<size_t>(bytes, 1)))) throw std::bad_alloc();
+        return static_cast<T*>(q);
+    }
+    void deallocate(T* q, size_t) { std::free(q); }
+    template <class U, class... A> void construct(U* q, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)q) U; else ::new ((void*)q) U(std::forward<A>(a)...);
+    }
+    template <class U> bool operator==(const HostAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const HostAlloc<U>&) const { return false; }
+};
+template <class T> using hvec = std::vector<T, HostAlloc<T>>;
+
 // wavefront kernel by number of 8 x 8 line blocks in the (j, k) plane: the 16 x 16 kernel from 32^3 up (table at its use)
 static int default_wave_form(unsigned nb8) { return nb8 >= 16 ? 2 : 1; }
 
@@ -812,8 +845,8 @@ static int32_t zero_dev(void* dst, size_t bytes, hipStream_t s) {
     KR_HIP(hipStreamSynchronize(s));
     return KRYST_OK;
 }
-template <class T>
-static int32_t up(T** dst, const std::vector<T>& v) {
+template <class T, class A>
+static int32_t up(T** dst, const std::vector<T, A>& v) {
     KR_HIP(hipMalloc(dst, sizeof(T) * (v.size() + 1)));
     KR_HIP(hipMemsetAsync(*dst, 0, sizeof(T) * (v.size() + 1), tl_setup_stream));
     if (!v.empty()) KR_HIP(hipMemcpyAsync(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, tl_setup_stream));
@@ -824,12 +857,12 @@ static int32_t up(T** dst, const std::vector<T>& v) {
 
 // kept entries of a triangular factor, row by row in STORED order (flat CSR: a vector per row costs 2n heap blocks)
 struct FlatRows {
-    std::vector<int64_t> ptr; std::vector<int32_t> col; std::vector<double> val;
+    hvec<int64_t> ptr; hvec<int32_t> col; hvec<double> val;
     int64_t len(int64_t i) const { return ptr[(size_t)i + 1] - ptr[(size_t)i]; }
 };
 
 // level order of one factor
-static int32_t build_factor(int64_t n, const FlatRows& ent, const std::vector<double>& diag, bool forward, TriFactor* F,
+static int32_t build_factor(int64_t n, const FlatRows& ent, const hvec<double>& diag, bool forward, TriFactor* F,
                             std::vector<int32_t>* pos_out) {
     std::vector<int32_t> lvl((size_t)n, 0);
     int32_t nl = 0;
@@ -890,7 +923,7 @@ static int32_t build_factor(int64_t n, const FlatRows& ent, const std::vector<do
 }
 
 // Recognise a structured-grid factor and lay it out for tri_grid_kernel.  Not an error when it does not apply.
-static int32_t build_grid(int64_t n, const FlatRows& ent, const std::vector<double>& diag, bool forward, GridFactor* G) {
+static int32_t build_grid(int64_t n, const FlatRows& ent, const hvec<double>& diag, bool forward, GridFactor* G) {
     if (n < 2 || n >= (1ll << 31) || env_int("KRYST_ILU_GRID", 1) == 0) return KRYST_OK;
     int64_t offs[3] = {0, 0, 0}; int no = 0;                              // distinct |col - row|, at most three
     {
@@ -978,8 +1011,26 @@ static bool box_dims_from_offsets(const std::vector<int64_t>& offs, int64_t n, i
     return false;
 }
 
+// one factor's kept entries (host FlatRows, uploaded) -> its 13 coefficient streams; `bad` is raised by an entry that is not a neighbour
+// inside the box (it wraps around a line or plane end) or lies on the wrong side of the diagonal
+__global__ __launch_bounds__(256) void box_rows_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val, int32_t n,
+                                                            int32_t Ni, int32_t Nj, int32_t Nk, int forward, double* c, int32_t* bad) {
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t ii = i % Ni, jj = (i / Ni) % Nj, kk = i / (Ni * Nj);
+    for (int64_t k = ptr[i]; k < ptr[i + 1]; ++k) {
+        const int32_t j = col[k];
+        if (j < 0 || j >= n) { *bad = 1; return; }
+        const int di = j % Ni - ii, dj = (j / Ni) % Nj - jj, dk = j / (Ni * Nj) - kk;
+        if (di < -1 || di > 1 || dj < -1 || dj > 1 || dk < -1 || dk > 1 || kk + dk >= Nk) { *bad = 1; return; }
+        const int code = 9 * (dk + 1) + 3 * (dj + 1) + (di + 1);
+        if (forward ? code >= 13 : code <= 13) { *bad = 1; return; }
+        c[(int64_t)(forward ? code : code - 14) * n + i] = val[k];
+    }
+}
+
 // Recognise a box-stencil factor and lay it out as 13 natural-order coefficient streams.  Not an error when it does not apply.
-static int32_t build_box(int64_t n, const FlatRows& ent, const std::vector<double>& diag, bool forward, BoxFactor* B) {
+static int32_t build_box(int64_t n, const FlatRows& ent, const hvec<double>& diag, bool forward, BoxFactor* B) {
     if (n < 27 || n >= (1ll << 31) || env_int("KRYST_ILU_BOX", KR_ILU_BOX_DEFAULT) == 0) return KRYST_OK;
     // distinct offsets (at most 13), rows in ascending column order, strictly lower / upper
     std::vector<int64_t> offs;
@@ -1002,27 +1053,26 @@ static int32_t build_box(int64_t n, const FlatRows& ent, const std::vector<doubl
     }
     int64_t Ni = 0, Nj = 0;
     if (!box_dims_from_offsets(offs, n, &Ni, &Nj)) return KRYST_OK;
-    const int64_t s1 = Ni, s2 = Ni * Nj, Nk = n / s2;
-    std::vector<double> c((size_t)13 * (size_t)n, 0.0);
-    {
-        std::atomic<bool> reject{false};
-        par_rows(n, [&](int64_t lo, int64_t hi) {
-            for (int64_t i = lo; i < hi; ++i) {
-                const int64_t ii = i % Ni, jx = (i / Ni) % Nj, kx = i / s2;
-                for (int64_t k = ent.ptr[i]; k < ent.ptr[i + 1]; ++k) {
-                    int dk, dj, di;
-                    if (!box_decompose((int64_t)ent.col[k] - i, s1, s2, dk, dj, di)) { reject = true; return; }
-                    // the neighbour must exist in the box (an entry that wraps around a line or plane end is not a box coupling)
-                    if (ii + di < 0 || ii + di >= Ni || jx + dj < 0 || jx + dj >= Nj || kx + dk < 0 || kx + dk >= Nk) { reject = true; return; }
-                    const int code = 9 * (dk + 1) + 3 * (dj + 1) + (di + 1);
-                    if (forward ? code >= 13 : code <= 13) { reject = true; return; }
-                    c[(size_t)(forward ? code : code - 14) * (size_t)n + (size_t)i] = ent.val[k];
-                }
-            }
-        });
-        if (reject) return KRYST_OK;
+    const int64_t Nk = n / (Ni * Nj);
+    // the streams are written on the device from the uploaded rows (round 4: the host used to fill 13 n doubles per factor and send those)
+    hipStream_t st = tl_setup_stream;
+    int64_t* d_ptr = nullptr; int32_t* d_col = nullptr; double* d_val = nullptr; int32_t* d_bad = nullptr;
+    const size_t cb = sizeof(double) * (size_t)13 * (size_t)n, ne = (size_t)ent.ptr[(size_t)n];
+    int32_t bad = 1;
+    bool ok = hipMalloc(&d_ptr, sizeof(int64_t) * ((size_t)n + 1)) == hipSuccess && hipMalloc(&d_col, sizeof(int32_t) * (ne + 1)) == hipSuccess &&
+              hipMalloc(&d_val, sizeof(double) * (ne + 1)) == hipSuccess && hipMalloc(&d_bad, 64) == hipSuccess && hipMalloc(&B->d_c, cb) == hipSuccess;
+    ok = ok && hipMemsetAsync(B->d_c, 0, cb, st) == hipSuccess && hipMemsetAsync(d_bad, 0, 64, st) == hipSuccess &&
+         hipMemcpyAsync(d_ptr, ent.ptr.data(), sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, st) == hipSuccess &&
+         hipMemcpyAsync(d_col, ent.col.data(), sizeof(int32_t) * ne, hipMemcpyHostToDevice, st) == hipSuccess &&
+         hipMemcpyAsync(d_val, ent.val.data(), sizeof(double) * ne, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(box_rows_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_ptr, d_col, d_val, (int32_t)n, (int32_t)Ni, (int32_t)Nj, (int32_t)Nk,
+                           forward ? 1 : 0, B->d_c, d_bad);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
     }
-    KR_TRY(up(&B->d_c, c));
+    (void)hipFree(d_ptr); (void)hipFree(d_col); (void)hipFree(d_val); (void)hipFree(d_bad);
+    if (!ok) { (void)hipGetLastError(); B->free_all(); set_error("box-stencil factor: device allocation or copy failed"); return KRYST_ERR_HIP; }
+    if (bad != 0) { B->free_all(); return KRYST_OK; }
     if (!forward) KR_TRY(up(&B->d_diag, diag));
     B->Ni = (int32_t)Ni; B->Nj = (int32_t)Nj; B->Nk = (int32_t)Nk; B->ok = true;
     return KRYST_OK;
@@ -1122,7 +1172,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
         }
     }
     if (getenv("KRYST_ILU_VERBOSE"))
-        fprintf(stderr, "[kryst ilu] n=%lld %s; levels L/U=%zu/%zu\n", (long long)n, D->GL.ok ? "structured grid (wavefront kernel)" : "level-ordered",
+        fprintf(stderr, "[kryst ilu] n=%lld %s; levels L/U=%zu/%zu\n", (long long)n, D->GL.ok ? "structured grid (wavefront kernel)" : D->BL.ok ? "box stencil (13 streams per factor)" : "level-ordered",
                 D->L.lvl_off.empty() ? (size_t)0 : D->L.lvl_off.size() - 1, D->U.lvl_off.empty() ? (size_t)0 : D->U.lvl_off.size() - 1);
     return rc;
 }
@@ -1130,11 +1180,11 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
 // shared tail of every host-side ILU-family setup: recognise a structured grid or level-order both factors, then hand out the
 // preconditioner object
 static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRows& le, const FlatRows& ue,
-                             const std::vector<double>& dg, kryst_pc_t* out) {
+                             const hvec<double>& dg, kryst_pc_t* out) {
     kryst_ctx_t ctx = a->ctx;
     tl_setup_stream = ctx->s_main;
     const int64_t n = a->nrows;
-    std::vector<double> ones((size_t)n, 1.0);
+    hvec<double> ones((size_t)n, 1.0);
     kryst_pc_t pc = new kryst_pc_s();
     pc->ctx = ctx; pc->kind = KR_PC_ILU; pc->a = a; pc->n = n; pc->ilu_mode = mode; pc->divide_diag = divide;
     IluData* D = new IluData();
@@ -1803,7 +1853,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
     return KRYST_OK;
 }
 
-static int32_t download_rows(kryst_csr_t a, std::vector<int64_t>& rp, std::vector<int32_t>& col, std::vector<double>& val) {
+static int32_t download_rows(kryst_csr_t a, hvec<int64_t>& rp, hvec<int32_t>& col, hvec<double>& val) {
     rp.resize((size_t)a->nrows + 1); col.resize((size_t)a->nnz); val.resize((size_t)a->nnz);
     return kryst_csr_download(a, rp.data(), col.data(), val.data());
 }
@@ -1892,7 +1942,7 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
     const bool divide = mode != KRYST_ILU_KRYST_COMPAT;                    // ilu.rs:115-119 never divides
     FlatRows le, ue;
     le.ptr.assign((size_t)n + 1, 0); ue.ptr.assign((size_t)n + 1, 0);
-    std::vector<double> dg((size_t)n, 1.0);
+    hvec<double> dg((size_t)n, 1.0);
     par_rows(n, [&](int64_t lo, int64_t hi) {                              // count, prefix, then fill (stored order = ascending column)
         for (int64_t i = lo; i < hi; ++i) {
             int64_t nl = 0, nu = 0;
@@ -1926,84 +1976,243 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
 
 // Ilup::new(fill).setup(a) exactly as written (src/preconditioner/ilup.rs:77-134), on sparse rows instead of the reference's
 // dense n x n `level` / `a_work` arrays: an entry that the dense code never touches is (0.0, usize::MAX) here too.
+// Ilup(p >= 1), ilup.rs:77-167: IKJ elimination with level-of-fill bookkeeping; whether an entry takes part depends on its VALUE too
+// (`!= 0.0` tests at :106, :117, :129), so pattern and values are computed together, row by row.  Row i only needs the finished rows j < i
+// that appear in its working row (original entries and fill): rows are dealt out to the host's cores in small blocks, round-robin,
+// every thread walks its blocks in ascending order and waits on the block's "finished" flag before it uses another thread's pivot row (round 4;
+// one thread did all of it before: 300 ms of the 620 ms Ilup(1) setup at 128^3).  The lowest unfinished row never waits for an
+// unfinished one, so somebody always makes progress.  The same operations on the same operands in the same order as the one-thread
+// loop: same bits.
+namespace kr {
+// releases big host arrays off the caller's thread; at most one release in flight, joined before the next and when the library goes
+struct Janitor {
+    std::thread th; std::mutex mu;
+    ~Janitor() { if (th.joinable()) th.join(); }
+    template <class F> void run(F&& f) { std::lock_guard<std::mutex> g(mu); if (th.joinable()) th.join(); th = std::thread(std::forward<F>(f)); }
+};
+static Janitor g_janitor;
+struct IlupU { int32_t c; double v; uint64_t lev; };                       // a nonzero a_work[j][k], k > j, of a finished row
+struct IlupE { int32_t c; double v; };                                     // a kept entry of L or U
+template <class T>
+struct Arena {                                                             // append-only; what has been handed out never moves (other threads read it)
+    std::vector<hvec<T>> chunks; size_t used = 0, cap = 0;                 // (8 MiB chunks: huge pages, HostAlloc)
+    // room for `cnt` elements with its pages already mapped: a thread that takes page faults (or maps a new chunk) in the middle of the row
+    // pipeline holds up every thread behind it
+    void reserve_mapped(size_t cnt) {
+        cap = std::max<size_t>(cnt, ((size_t)8 << 20) / sizeof(T)); chunks.emplace_back(); chunks.back().resize(cap); used = 0;
+        char* q = reinterpret_cast<char*>(chunks.back().data()); const size_t bytes = cap * sizeof(T);
+#ifdef MADV_POPULATE_WRITE
+        if (madvise(reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(q) + 4095) & ~(uintptr_t)4095), bytes > 8192 ? (bytes - 4096) & ~(size_t)4095 : 0, MADV_POPULATE_WRITE) == 0) return;
+#endif
+        for (size_t x = 0; x < bytes; x += 4096) q[x] = 0;
+    }
+    T* take(size_t cnt) {
+        if (used + cnt > cap) { cap = std::max<size_t>(cnt, ((size_t)8 << 20) / sizeof(T)); chunks.emplace_back(); chunks.back().resize(cap); used = 0; }
+        T* p = chunks.back().data() + used; used += cnt; return p;
+    }
+};
+}  // namespace kr
+
+static int32_t ilup_setup(kryst_csr_t a, int32_t fill, kryst_pc_t* out);
 extern "C" int32_t kryst_pc_ilup(kryst_csr_t a, int32_t fill, kryst_pc_t* out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int32_t rc = ilup_setup(a, fill, out);
+    if (getenv("KRYST_ILU_VERBOSE")) fprintf(stderr, "[kryst ilup] all of it, host arrays freed: %.0f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return rc;
+}
+static int32_t ilup_setup(kryst_csr_t a, int32_t fill, kryst_pc_t* out) {
     KR_ARG(a && out && fill >= 0, "pc_ilup");
     KR_ARG(a->nrows == a->xlen, "pc_ilup: square operator required");
     if (fill == 0) return kryst_pc_ilu0(a, KRYST_ILU_ILUP0, out);
     KR_HIP(hipSetDevice(a->ctx->device));
     const int64_t n = a->nrows;
-    std::vector<int64_t> rp; std::vector<int32_t> col; std::vector<double> val;
+    const bool verbose = getenv("KRYST_ILU_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_phase = now();
+    auto lap = [&](const char* what) { if (verbose) { fprintf(stderr, "[kryst ilup] %s %.0f ms\n", what, std::chrono::duration<double, std::milli>(now() - t_phase).count()); t_phase = now(); } };
+    hvec<int64_t> rp; hvec<int32_t> col; hvec<double> val;
     KR_TRY(download_rows(a, rp, col, val));
-    // The row under elimination is a small SORTED array (a_work[i][*] / level[i][*] where the dense code ever touches them), finished
-    // rows' upper parts and the kept factor entries are appended to flat arrays: no per-row containers (round 2 used a std::map per
-    // row and 6 n small vectors: 1.6 s for Ilup(1) on 128^3).  Iterating the sorted array by index while inserting fill entries BEHIND
-    // the cursor visits exactly the columns `for j in 0..i` would (an inserted column is > j).
+    lap("download");
     const uint64_t UMAX = ~0ull;
     struct WEnt { int32_t c; double v; uint64_t lev; };
-    std::vector<int64_t> uptr((size_t)n + 1, 0);           // every nonzero a_work[j][k], k > j, of a finished row j: [uptr[j], uptr[j+1])
-    std::vector<int32_t> ucol; std::vector<double> uval; std::vector<uint64_t> ulev;
-    std::vector<double> udiag((size_t)n, 0.0);             // a_work[j][j] of a finished row
-    FlatRows le, ue;
-    le.ptr.assign((size_t)n + 1, 0); ue.ptr.assign((size_t)n + 1, 0);
-    std::vector<double> dg((size_t)n, 1.0);
-    std::vector<WEnt> W;
-    for (int64_t i = 0; i < n; ++i) {
-        W.clear();
-        for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
-            if (col[k] < n) W.push_back(WEnt{col[k], val[k], val[k] != 0.0 ? 0ull : UMAX});   // ilup.rs:88-101 (halo columns dropped)
-        std::sort(W.begin(), W.end(), [](const WEnt& x, const WEnt& y) { return x.c < y.c; });   // (a block's local numbering is ascending already)
-        for (size_t p = 0; p < W.size() && W[p].c < i; ++p) {                              // :104 `for j in 0..i`
-            const int32_t j = W[p].c;
-            const double ejv = W[p].v; const uint64_t ejl = W[p].lev;
-            if (!(ejv != 0.0 && ejl <= (uint64_t)fill)) continue;                          // :106
-            const double u_jj = udiag[j];
-            if (u_jj == 0.0) { set_error("ILUP: zero diagonal in U at row %d", j); return KRYST_SOLVE_ERROR; }   // :108-110
-            const double lij = ejv / u_jj;                                                 // :112
-            le.col.push_back(j); le.val.push_back(lij);
-            size_t q = p + 1;                                                              // both lists ascend: one merge pass per pivot row
-            for (int64_t t = uptr[j]; t < uptr[j + 1]; ++t) {                              // :116 `for k in (j+1)..n`
-                uint64_t nl = ejl;                                                         // saturating adds (:118)
-                nl = (nl > UMAX - ulev[t]) ? UMAX : nl + ulev[t];
-                nl = (nl == UMAX) ? UMAX : nl + 1;
-                if (nl <= (uint64_t)fill) {
-                    const int32_t k = ucol[t];
-                    while (q < W.size() && W[q].c < k) ++q;
-                    if (q == W.size() || W[q].c != k) W.insert(W.begin() + (std::ptrdiff_t)q, WEnt{k, 0.0, UMAX});
-                    W[q].v = W[q].v - lij * uval[t];                                       // :121
-                    if (nl < W[q].lev) W[q].lev = nl;                                      // :122
+    struct RowOut { const IlupU* u = nullptr; const IlupE* l = nullptr; const IlupE* k = nullptr; int32_t nu = 0, nl = 0, nk = 0; };
+    hvec<RowOut> rows((size_t)n);                                          // finished rows: upper part (for later rows), kept L and U entries
+    hvec<double> udiag((size_t)n), dg((size_t)n);                          // a_work[j][j] of a finished row; the kept diagonal
+    par_rows(n, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) { rows[(size_t)i] = RowOut(); udiag[(size_t)i] = 0.0; dg[(size_t)i] = 1.0; } });
+    std::atomic<long long> bad_row{-1};                                    // lowest row i whose elimination met a zero u_jj ...
+    std::vector<long long> bad_col;                                        // ... and that j, per thread
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned T = (unsigned)std::max(1, std::min<int>((int)hw, env_int("KRYST_ILUP_THREADS", n < 4096 ? 1 : (int)hw)));
+    // Blocks of 1 024 rows: on a grid with lines of 128 rows that is 8 lines, and row i's pivot rows i - 1, i - Ni (+ 1), i - Ni Nj (+ 1, + Ni)
+    // are the thread's own except along the block's first line -- a pivot row finished by another core costs a few cache-line
+    // transfers (0.2 - 1 us each on the two-socket hosts of the GPU boxes; blocks of 8 rows, tried first, were 3 x SLOWER than one thread).
+    // A thread publishes its finished rows 16 at a time (and before it waits itself): one flag byte per row, so a consumer walking a
+    // line behind its producer takes the flags' cache line once per batch, not once per row.
+    const int64_t B = std::max(1, env_int("KRYST_ILUP_BLOCK", 1024)), nblocks = (n + B - 1) / B;
+    std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[(size_t)n + 64]);
+    par_rows(n, [&](int64_t lo, int64_t hi) { for (int64_t r = lo; r < hi; ++r) done[(size_t)r].store(0, std::memory_order_relaxed); });
+    bad_col.assign(T, -1);
+    std::vector<double> waited(T, 0.0), busy(T, 0.0); std::vector<long long> waits(T, 0);   // (KRYST_ILU_VERBOSE: where a thread's time went)
+    std::vector<long long> bad_at(T, -1);
+    std::vector<Arena<IlupU>> arena_u(T); std::vector<Arena<IlupE>> arena_l(T), arena_k(T);   // (alive until the gather below)
+    std::atomic<unsigned> warm{0};
+    auto worker = [&](unsigned tid) {
+        const auto tw0 = std::chrono::steady_clock::now();
+        struct Stop { const std::chrono::steady_clock::time_point t0; double* out; ~Stop() { *out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } stop{tw0, &busy[tid]};
+        Arena<IlupU>& au = arena_u[tid]; Arena<IlupE>& al = arena_l[tid]; Arena<IlupE>& ak = arena_k[tid];
+        std::vector<WEnt> W; std::vector<IlupE> L, Kp; std::vector<IlupU> U;
+        W.reserve(256); L.reserve(256); Kp.reserve(256); U.reserve(256);
+        // every thread's first block waits for the one before it, so a slow start (a core waking up, the first pages of its arenas) would be paid
+        // T times in a row: touch the first chunk of each arena, then start together
+        if (T > 1) {
+            // (an estimate of this thread's share: (fill + 1) times the operator's entries above / below the diagonal, and a tenth on top;
+            // a thread that runs out continues in 8 MiB chunks)
+            const size_t share = (size_t)((double)(rp[(size_t)n] - n) * 0.5 * (double)(fill + 1) * 1.1 / (double)T) + 4096;
+            au.reserve_mapped(share); al.reserve_mapped(share); ak.reserve_mapped(share);
+            warm.fetch_add(1);
+            for (unsigned spin = 0; warm.load(std::memory_order_acquire) < T; ++spin) if ((spin & 1023) == 1023) std::this_thread::yield();
+        }
+        for (int64_t b = tid; b < nblocks; b += T) {
+            const bool trace = verbose && getenv("KRYST_ILUP_TRACE") && b < 6 * (int64_t)T && (tid < 3 || tid == T - 1);
+            const double tb0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count(), wb0 = waited[tid];
+            int64_t published = b * B;                                      // rows [b B, published) of this block carry their flag
+            auto publish = [&](int64_t upto) { for (; published < upto; ++published) done[(size_t)published].store(1, std::memory_order_release); };
+            for (int64_t i = b * B; i < std::min(n, (b + 1) * B); ++i) {
+                { const long long br = bad_row.load(std::memory_order_relaxed); if (br >= 0 && br < i) return; }   // the reference stopped before this row
+                W.clear(); L.clear(); Kp.clear(); U.clear();
+                for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
+                    if (col[k] < n) W.push_back(WEnt{col[k], val[k], val[k] != 0.0 ? 0ull : UMAX});   // ilup.rs:88-101 (halo columns dropped)
+                std::sort(W.begin(), W.end(), [](const WEnt& x, const WEnt& y) { return x.c < y.c; });   // (a block's local numbering is ascending already)
+                // The working row is a small SORTED array; iterating it by index while inserting fill entries BEHIND the cursor visits
+                // exactly the columns `for j in 0..i` would (an inserted column is > j).
+                for (size_t p = 0; p < W.size() && W[p].c < i; ++p) {                              // :104 `for j in 0..i`
+                    const int32_t j = W[p].c;
+                    const double ejv = W[p].v; const uint64_t ejl = W[p].lev;
+                    if (!(ejv != 0.0 && ejl <= (uint64_t)fill)) continue;                          // :106
+                    if (j < b * B && done[(size_t)j].load(std::memory_order_acquire) == 0) {      // row j is somebody else's and still under way
+                        publish(i);                                                                // (nobody waits for what this thread has finished)
+                        const auto w0 = std::chrono::steady_clock::now();
+                        ++waits[tid];
+                        for (unsigned spin = 0; done[(size_t)j].load(std::memory_order_acquire) == 0; ++spin) {
+                            const long long br = bad_row.load(std::memory_order_relaxed);
+                            if (br >= 0 && br < i) return;
+                            if ((spin & 1023) == 1023) std::this_thread::yield();
+                        }
+                        waited[tid] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+                    }
+                    const double u_jj = udiag[(size_t)j];
+                    if (u_jj == 0.0) {                                                             // :108-110
+                        long long cur = bad_row.load();
+                        while ((cur < 0 || i < cur) && !bad_row.compare_exchange_weak(cur, (long long)i)) {}
+                        if (bad_at[tid] < 0 || i < bad_at[tid]) { bad_at[tid] = i; bad_col[tid] = j; }
+                        return;
+                    }
+                    const double lij = ejv / u_jj;                                                 // :112
+                    L.push_back(IlupE{j, lij});
+                    size_t q = p + 1;                                                              // both lists ascend: one merge pass per pivot row
+                    const IlupU* uj = rows[(size_t)j].u;
+                    for (int32_t t = 0; t < rows[(size_t)j].nu; ++t) {                             // :116 `for k in (j+1)..n`
+                        uint64_t nl = ejl;                                                         // saturating adds (:118)
+                        nl = (nl > UMAX - uj[t].lev) ? UMAX : nl + uj[t].lev;
+                        nl = (nl == UMAX) ? UMAX : nl + 1;
+                        if (nl <= (uint64_t)fill) {
+                            const int32_t k = uj[t].c;
+                            while (q < W.size() && W[q].c < k) ++q;
+                            if (q == W.size() || W[q].c != k) W.insert(W.begin() + (std::ptrdiff_t)q, WEnt{k, 0.0, UMAX});
+                            W[q].v = W[q].v - lij * uj[t].v;                                       // :121
+                            if (nl < W[q].lev) W[q].lev = nl;                                      // :122
+                        }
+                    }
                 }
+                for (const WEnt& e : W) {
+                    if (e.c < i) continue;
+                    if (e.c == i) udiag[(size_t)i] = e.v;
+                    if (e.v != 0.0 && e.lev <= (uint64_t)fill) {                                   // :129-134
+                        if (e.c == i) dg[(size_t)i] = e.v;
+                        else Kp.push_back(IlupE{e.c, e.v});
+                    }
+                    if (e.c > i && e.v != 0.0) U.push_back(IlupU{e.c, e.v, e.lev});
+                }
+                RowOut& r = rows[(size_t)i];
+                r.nu = (int32_t)U.size(); r.nl = (int32_t)L.size(); r.nk = (int32_t)Kp.size();
+                if (r.nu) { IlupU* d = au.take(U.size()); std::copy(U.begin(), U.end(), d); r.u = d; }
+                if (r.nl) { auto* d = al.take(L.size()); std::copy(L.begin(), L.end(), d); r.l = d; }
+                if (r.nk) { auto* d = ak.take(Kp.size()); std::copy(Kp.begin(), Kp.end(), d); r.k = d; }
+                if (((i + 1) & 15) == 0) publish(i + 1);
             }
+            publish(std::min(n, (b + 1) * B));
+            if (trace) fprintf(stderr, "[kryst ilup]     thread %u block %lld: %.3f .. %.3f ms, waited %.3f\n", tid, (long long)b, tb0,
+                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count(), waited[tid] - wb0);
         }
-        le.ptr[(size_t)i + 1] = (int64_t)le.col.size();
-        for (const WEnt& e : W) {
-            if (e.c < i) continue;
-            if (e.c == i) udiag[i] = e.v;
-            if (e.v != 0.0 && e.lev <= (uint64_t)fill) {                                   // :129-134
-                if (e.c == i) dg[i] = e.v;
-                else { ue.col.push_back(e.c); ue.val.push_back(e.v); }
+    };
+    FlatRows le, ue;
+    {
+        // the workers exchange finished rows through the caches: keep them on neighbouring cores (one group of 16 consecutive CPU numbers
+        // around the caller's: one socket, two L3 domains on the GPU boxes' hosts) -- KRYST_ILUP_CPU_GROUP=0 leaves the placement to the OS
+        const int group = env_int("KRYST_ILUP_CPU_GROUP", 16);
+        const int cpu0 = sched_getcpu();
+        auto placed = [&](unsigned t) {
+            if (group > 0 && cpu0 >= 0 && T > 1) {
+                cpu_set_t set; CPU_ZERO(&set);
+                const int base = cpu0 / group * group;
+                for (int c = base; c < base + group && c < CPU_SETSIZE; ++c) CPU_SET(c, &set);
+                (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);     // (refused: the OS places the thread)
             }
-            if (e.c > i && e.v != 0.0) { ucol.push_back(e.c); uval.push_back(e.v); ulev.push_back(e.lev); }
+            worker(t);
+        };
+        if (T == 1) worker(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < T; ++t) th.emplace_back(placed, t);
+            for (auto& t : th) t.join();
         }
-        ue.ptr[(size_t)i + 1] = (int64_t)ue.col.size();
-        uptr[(size_t)i + 1] = (int64_t)ucol.size();
     }
-    return finish_ilu_pc(a, 10 + fill, true, le, ue, dg, out);
+    if (bad_row.load() >= 0) {
+        const long long i = bad_row.load();
+        long long j = -1;
+        for (unsigned t = 0; t < T; ++t) if (bad_at[t] == i) j = bad_col[t];
+        set_error("ILUP: zero diagonal in U at row %lld", j);
+        return KRYST_SOLVE_ERROR;
+    }
+    lap("elimination");
+    if (verbose) for (unsigned t = 0; t < T; ++t) fprintf(stderr, "[kryst ilup]   thread %u: %.0f ms, of which %.0f ms in %lld waits for another thread's rows\n", t, busy[t], waited[t], waits[t]);
+    le.ptr.assign((size_t)n + 1, 0); ue.ptr.assign((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) { le.ptr[(size_t)i + 1] = le.ptr[(size_t)i] + rows[(size_t)i].nl; ue.ptr[(size_t)i + 1] = ue.ptr[(size_t)i] + rows[(size_t)i].nk; }
+    le.col.resize((size_t)le.ptr[(size_t)n]); le.val.resize(le.col.size()); ue.col.resize((size_t)ue.ptr[(size_t)n]); ue.val.resize(ue.col.size());
+    par_rows(n, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const RowOut& r = rows[(size_t)i];
+            for (int32_t t = 0; t < r.nl; ++t) { le.col[(size_t)le.ptr[(size_t)i] + t] = r.l[t].c; le.val[(size_t)le.ptr[(size_t)i] + t] = r.l[t].v; }
+            for (int32_t t = 0; t < r.nk; ++t) { ue.col[(size_t)ue.ptr[(size_t)i] + t] = r.k[t].c; ue.val[(size_t)ue.ptr[(size_t)i] + t] = r.k[t].v; }
+        }
+    });
+    lap("kept entries gathered");
+    const int32_t rc = finish_ilu_pc(a, 10 + fill, true, le, ue, dg, out);
+    lap("device structures");
+    // ~1 GB of host arrays at 128^3: unmapping them takes 60-70 ms, which the caller need not wait for
+    struct Bundle { std::vector<Arena<IlupU>> u; std::vector<Arena<IlupE>> l, k; hvec<RowOut> rows; FlatRows le, ue; hvec<int64_t> rp; hvec<int32_t> col; hvec<double> val; };
+    auto bundle = std::make_shared<Bundle>();
+    bundle->u.swap(arena_u); bundle->l.swap(arena_l); bundle->k.swap(arena_k); bundle->rows.swap(rows);
+    bundle->le.ptr.swap(le.ptr); bundle->le.col.swap(le.col); bundle->le.val.swap(le.val); bundle->ue.ptr.swap(ue.ptr); bundle->ue.col.swap(ue.col); bundle->ue.val.swap(ue.val);
+    bundle->rp.swap(rp); bundle->col.swap(col); bundle->val.swap(val);
+    g_janitor.run([bundle]() mutable { bundle.reset(); });
+    lap("host arrays handed to the janitor thread");
+    return rc;
 }
 
-// Ilut::new(fill, droptol).setup(a) exactly as written (src/preconditioner/ilut.rs:80-117): no elimination; drop by
-// magnitude, keep the `fill` largest (stable descending sort), split at the diagonal.  Entries keep their STORED order
-// (descending magnitude after a truncation), which is the order the apply subtracts them in (ilut.rs:129-141).
 extern "C" int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kryst_pc_t* out) {
     KR_ARG(a && out && fill >= 0, "pc_ilut");
     KR_ARG(a->nrows == a->xlen, "pc_ilut: square operator required");
     KR_HIP(hipSetDevice(a->ctx->device));
     const int64_t n = a->nrows;
-    std::vector<int64_t> rp; std::vector<int32_t> col; std::vector<double> val;
+    hvec<int64_t> rp; hvec<int32_t> col; hvec<double> val;
     KR_TRY(download_rows(a, rp, col, val));
-    RowLists le((size_t)n), ue((size_t)n);
-    std::vector<double> dg((size_t)n, 1.0);
-    std::vector<std::pair<int32_t, double>> row;
-    for (int64_t i = 0; i < n; ++i) {
+    // rows are independent (ilut.rs:80-150 eliminates nothing): counted and written by the host's cores, straight into flat arrays
+    hvec<double> dg((size_t)n);
+    par_rows(n, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) dg[(size_t)i] = 1.0; });
+    FlatRows le, ue;
+    le.ptr.assign((size_t)n + 1, 0); ue.ptr.assign((size_t)n + 1, 0);
+    auto kept_row = [&](int64_t i, std::vector<std::pair<int32_t, double>>& row) {
         row.clear();
         for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
             if (col[k] < n && val[k] != 0.0 && std::fabs(val[k]) >= droptol) row.push_back({col[k], val[k]});     // :88-95
@@ -2012,14 +2221,32 @@ extern "C" int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kr
                 return std::fabs(x.second) > std::fabs(y.second); });
             row.resize((size_t)fill);
         }
-        bool have_d = false;
-        for (auto& e : row) {                                                                                    // :104-112
-            if (e.first < i) le[i].push_back(e);
-            else if (e.first > i) ue[i].push_back(e);
-            else if (!have_d) { dg[i] = e.second; have_d = true; }                                               // :143-144
+    };
+    par_rows(n, [&](int64_t lo, int64_t hi) {
+        std::vector<std::pair<int32_t, double>> row;
+        for (int64_t i = lo; i < hi; ++i) {
+            kept_row(i, row);
+            int64_t nl = 0, nu = 0;
+            for (auto& e : row) { if (e.first < i) ++nl; else if (e.first > i) ++nu; }
+            le.ptr[(size_t)i + 1] = nl; ue.ptr[(size_t)i + 1] = nu;
         }
-    }
-    return finish_ilu_pc(a, 100, true, flatten(le), flatten(ue), dg, out);
+    });
+    for (int64_t i = 0; i < n; ++i) { le.ptr[(size_t)i + 1] += le.ptr[(size_t)i]; ue.ptr[(size_t)i + 1] += ue.ptr[(size_t)i]; }
+    le.col.resize((size_t)le.ptr[(size_t)n]); le.val.resize(le.col.size()); ue.col.resize((size_t)ue.ptr[(size_t)n]); ue.val.resize(ue.col.size());
+    par_rows(n, [&](int64_t lo, int64_t hi) {
+        std::vector<std::pair<int32_t, double>> row;
+        for (int64_t i = lo; i < hi; ++i) {
+            kept_row(i, row);
+            int64_t pl = le.ptr[(size_t)i], pu = ue.ptr[(size_t)i];
+            bool have_d = false;
+            for (auto& e : row) {                                                                                // :104-112
+                if (e.first < i) { le.col[(size_t)pl] = e.first; le.val[(size_t)pl] = e.second; ++pl; }
+                else if (e.first > i) { ue.col[(size_t)pu] = e.first; ue.val[(size_t)pu] = e.second; ++pu; }
+                else if (!have_d) { dg[(size_t)i] = e.second; have_d = true; }                                   // :143-144
+            }
+        }
+    });
+    return finish_ilu_pc(a, 100, true, le, ue, dg, out);
 }
 
 // What an ILU-family preconditioner's apply runs and streams (bench.py prices the triangular solve with it):
