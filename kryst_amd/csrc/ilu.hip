@@ -544,6 +544,7 @@ __global__ __launch_bounds__(1024) void tri_run_pipe_kernel(const TriArgs* args,
                                                             const double* __restrict__ val, const double* __restrict__ diag,
                                                             const int32_t* __restrict__ lvl_off, int32_t l0, int32_t l1) {
     if (args->skip) return;
+
     struct Head { int32_t p, k0, k1; double s, dg; };                      // a row's position (-1: none), entry range, right-hand side, divisor
     struct Body { int32_t c[H]; double v[H]; };
     auto head_of = [&](int32_t lv) -> Head {
@@ -636,8 +637,16 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
         if (rows <= NARROW && !F.ell) {
             int l1 = lv + 1;
             while (l1 < nl && F.lvl_off[l1 + 1] - F.lvl_off[l1] <= NARROW) ++l1;
+            // Threads: what a level costs is the instructions every wave of the workgroup issues for it, needed or not -- the random band
+            // matrix of tools/band_apply.py (187 rows per level): 46.1 ms per apply with 1 024 threads, 39.2 with 512, 34.4 with 256, 35.8 with 320,
+            // 79.5 with 128 (only a thread's first row of a level is pipelined).  Hence 5/4 of the run's mean level width, 256 at least.
+            // (Not the branches around its predicated look-ahead loads: with every load unconditional -- clamped indices, straight-line code,
+            // half the instructions -- the same apply took 38.7 ms, and 38.2 with the last 8 192 solution values in an LDS ring:
+            // profiles/r04/narrow_level_kernel_experiments.txt.)
+            const int mean_rows = (int)((F.lvl_off[l1] - F.lvl_off[lv]) / std::max(1, l1 - lv));
+            const unsigned run_threads = (unsigned)std::min(1024, std::max(64, env_int("KRYST_ILU_RUN_THREADS", std::max(256, (mean_rows * 5 / 4 + 63) / 64 * 64)) / 64 * 64));
             if (env_int("KRYST_ILU_RUN_PIPE", 1) != 0)
-                hipLaunchKernelGGL((tri_run_pipe_kernel<FORWARD, 8>), dim3(1), dim3(1024), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
+                hipLaunchKernelGGL((tri_run_pipe_kernel<FORWARD, 8>), dim3(1), dim3(run_threads), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
                                    F.d_diag, F.d_lvl_off, lv, l1);
             else
                 hipLaunchKernelGGL((tri_run_kernel<FORWARD>), dim3(1), dim3(1024), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
