@@ -754,6 +754,46 @@ def other_configs(K, ctx, steps, warmup):
         blk["ilu_apply"] = tri_roofline(pc, b, y, n, nnz, reps=10)
         out[f"variable_coefficient_{grid}"] = blk
         del pc, a, b, y
+    try:
+        out["general_ilu"] = general_ilu(K, ctx)
+    except Exception as e:                                  # (scipy missing, out of memory ...: the headline does not depend on it)
+        out["general_ilu"] = {"skipped": repr(e)}
+    return out
+
+
+def general_ilu(K, ctx):
+    """SURVEY 8 row f-2, operators that are NOT 7-point boxes: true ILU(0) of a 27-point stencil on 96^3 (box-stencil wavefront solve,
+    tri_box.h) and Ilup(1) of the 7-point Poisson operator on 128^3 (row-pipelined host elimination; its 13-entry factors take the same
+    kernels).  Setup = the second setup of the same operator in this process; apply = HIP events around 10 applies."""
+    import numpy as np
+    import scipy.sparse as sp
+    out = {}
+    N = 96
+    one = sp.diags([np.ones(N - 1), np.ones(N), np.ones(N - 1)], [-1, 0, 1])
+    m = (sp.identity(N ** 3) * 28.0 - sp.kron(one, sp.kron(one, one))).tocsr()
+    m.sort_indices()
+    n = m.shape[0]
+    a = K.CsrMatrix.from_csr(n, n, m.indptr, m.indices, m.data, ctx=ctx)
+    del m
+    for name, a_, mk in (("true_ilu0_27pt_96", a, lambda: K.TrueIlu0()), ("ilup1_poisson7_128", None, lambda: K.Ilup(1))):
+        if a_ is None:
+            a_ = K.CsrMatrix.stencil7(128, "poisson", ctx=ctx)
+        n = a_.nrows()
+        mk().setup(a_)
+        ctx.synchronize(); t0 = time.perf_counter()
+        pc = mk().setup(a_)
+        ctx.synchronize(); setup_ms = (time.perf_counter() - t0) * 1e3
+        r = ctx.vec(n).fill_splitmix(3); z = ctx.vec(n)
+        ms = min(pc.bench_apply(r, z, 10) for _ in range(2))
+        info = pc.ilu_info()
+        blk = {"rows": n, "nnz": int(a_.nnz), "setup_ms": setup_ms, "apply_ms": ms, "form": info["form"]}
+        if info["form"].startswith("box"):
+            moved = (26 * 8 + 8 + 32) * n                    # 13 coefficient streams per factor + the divisor + r, y read and y, z written
+            blk.update(bytes_moved=moved, bytes_model="26 coefficient streams + divisor + 32 n (r, y read; y, z written)",
+                       achieved=moved / (ms * 1e-3) / 1e9, unit="GB/s", peak=HBM_PEAK_GBS, frac=moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       hyperplanes=info["levels"][0], us_per_hyperplane=ms * 1e3 / max(1, 2 * info["levels"][0]))
+        out[name] = blk
+        del pc, r, z, a_
     return out
 
 

@@ -320,7 +320,9 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
             for (int a = 0; a < 13; ++a) {
                 const double cf = q.v[1 + a][u];
                 double x = dep[FORWARD ? a : 12 - a];
-                x = cf != 0.0 ? x : 0.0;                                  // absent entry (coefficient +0.0): operand +0.0, s unchanged
+                // absent entry (coefficient +0.0): the operand's high word cleared -> zero or a positive subnormal, the product is +0.0 and s
+                // unchanged, whatever the operand was (one select instead of tri_wave.h's two)
+                x = __hiloint2double(cf != 0.0 ? __double2hiint(x) : 0, __double2loint(x));
                 s = s - cf * x;
             }
             if (!FORWARD) s = s / q.v[NA - 1][u];
