@@ -137,6 +137,8 @@ struct BoxFactor {
     int32_t Ni = 0, Nj = 0, Nk = 0;
     double* d_c = nullptr;          // 13 n doubles: d_c[a n + row]
     double* d_diag = nullptr;       // divisor (backward factor only)
+    uint32_t present = 0x1fff;      // streams with at least one entry
+    bool regular = false;           // every present stream has an entry wherever the neighbour row exists in the box (tri_box.h: REGULAR)
     void free_all() { (void)hipFree(d_c); (void)hipFree(d_diag); d_c = nullptr; d_diag = nullptr; }
 };
 struct BoxView { int32_t Ni, Nj, Nk; int64_t n; const double* c; const double* diag; };
@@ -683,11 +685,16 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D, const TriDirect* direct 
             const unsigned nb = (unsigned)(tb_nbj(A.Nj) * tb_nbk(A.Nk));
             const int budget = std::max(1, env_int("KRYST_ILU_POLL_BUDGET", 1 << 22));
             hipLaunchKernelGGL((tri_box_fill_kernel<true>), dim3(nb), dim3(256), 0, s, D->d_args, D->d_y, VA, D->d_flags, (int32_t)(2 * nb));
-            hipLaunchKernelGGL((tri_box_kernel<true>), dim3(nb), dim3(256), tb_lds_bytes<true>(), s, D->d_args, (const double*)nullptr, D->d_y, VA, D->d_flags,
-                               D->d_flags + 2 * nb, D->d_gave_up, budget);
+            const bool reg = A.regular && B.regular && env_int("KRYST_ILU_BOX_REGULAR", 1) != 0;
+            if (reg) hipLaunchKernelGGL((tri_box_kernel<true, true>), dim3(nb), dim3(256), tb_lds_bytes<true>(), s, D->d_args, (const double*)nullptr, D->d_y, VA, D->d_flags,
+                               D->d_flags + 2 * nb, D->d_gave_up, budget, A.present);
+            else hipLaunchKernelGGL((tri_box_kernel<true, false>), dim3(nb), dim3(256), tb_lds_bytes<true>(), s, D->d_args, (const double*)nullptr, D->d_y, VA, D->d_flags,
+                               D->d_flags + 2 * nb, D->d_gave_up, budget, A.present);
             hipLaunchKernelGGL((tri_box_fill_kernel<false>), dim3(nb), dim3(256), 0, s, D->d_args, (double*)nullptr, VB, (int32_t*)nullptr, 0);
-            hipLaunchKernelGGL((tri_box_kernel<false>), dim3(nb), dim3(256), tb_lds_bytes<false>(), s, D->d_args, (const double*)D->d_y, (double*)nullptr, VB, D->d_flags + nb,
-                               D->d_flags + 2 * nb, D->d_gave_up, budget);
+            if (reg) hipLaunchKernelGGL((tri_box_kernel<false, true>), dim3(nb), dim3(256), tb_lds_bytes<false>(), s, D->d_args, (const double*)D->d_y, (double*)nullptr, VB, D->d_flags + nb,
+                               D->d_flags + 2 * nb, D->d_gave_up, budget, B.present);
+            else hipLaunchKernelGGL((tri_box_kernel<false, false>), dim3(nb), dim3(256), tb_lds_bytes<false>(), s, D->d_args, (const double*)D->d_y, (double*)nullptr, VB, D->d_flags + nb,
+                               D->d_flags + 2 * nb, D->d_gave_up, budget, B.present);
             KR_HIP(hipGetLastError());
             return KRYST_OK;
         }
@@ -1020,22 +1027,40 @@ static bool box_dims_from_offsets(const std::vector<int64_t>& offs, int64_t n, i
     return false;
 }
 
+// entries per stream -> which streams a factor has, and whether each of those has an entry wherever the neighbour row exists in the box
+static void box_classify(const unsigned long long cnt[13], bool forward, int64_t Ni, int64_t Nj, int64_t Nk, BoxFactor* B) {
+    B->present = 0; B->regular = true;
+    for (int a = 0; a < 13; ++a) {
+        const int code = forward ? a : a + 14, dk = code / 9 - 1, dj = (code / 3) % 3 - 1, di = code % 3 - 1;
+        const int64_t expect = std::max<int64_t>(0, Ni - std::abs(di)) * std::max<int64_t>(0, Nj - std::abs(dj)) * std::max<int64_t>(0, Nk - std::abs(dk));
+        if (cnt[a] != 0) B->present |= 1u << a;
+        if (cnt[a] != 0 && (int64_t)cnt[a] != expect) B->regular = false;
+    }
+}
+
 // one factor's kept entries (host FlatRows, uploaded) -> its 13 coefficient streams; `bad` is raised by an entry that is not a neighbour
 // inside the box (it wraps around a line or plane end) or lies on the wrong side of the diagonal
 __global__ __launch_bounds__(256) void box_rows_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val, int32_t n,
-                                                            int32_t Ni, int32_t Nj, int32_t Nk, int forward, double* c, int32_t* bad) {
+                                                            int32_t Ni, int32_t Nj, int32_t Nk, int forward, double* c, int32_t* bad, unsigned long long* counts) {
+    __shared__ unsigned int cnt[13];
+    if (threadIdx.x < 13) cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int32_t ii = i % Ni, jj = (i / Ni) % Nj, kk = i / (Ni * Nj);
-    for (int64_t k = ptr[i]; k < ptr[i + 1]; ++k) {
-        const int32_t j = col[k];
-        if (j < 0 || j >= n) { *bad = 1; return; }
-        const int di = j % Ni - ii, dj = (j / Ni) % Nj - jj, dk = j / (Ni * Nj) - kk;
-        if (di < -1 || di > 1 || dj < -1 || dj > 1 || dk < -1 || dk > 1 || kk + dk >= Nk) { *bad = 1; return; }
-        const int code = 9 * (dk + 1) + 3 * (dj + 1) + (di + 1);
-        if (forward ? code >= 13 : code <= 13) { *bad = 1; return; }
-        c[(int64_t)(forward ? code : code - 14) * n + i] = val[k];
+    if (i < n) {
+        const int32_t ii = i % Ni, jj = (i / Ni) % Nj, kk = i / (Ni * Nj);
+        for (int64_t k = ptr[i]; k < ptr[i + 1]; ++k) {
+            const int32_t j = col[k];
+            if (j < 0 || j >= n) { *bad = 1; break; }
+            const int di = j % Ni - ii, dj = (j / Ni) % Nj - jj, dk = j / (Ni * Nj) - kk;
+            if (di < -1 || di > 1 || dj < -1 || dj > 1 || dk < -1 || dk > 1 || kk + dk >= Nk) { *bad = 1; break; }
+            const int code = 9 * (dk + 1) + 3 * (dj + 1) + (di + 1);
+            if (forward ? code >= 13 : code <= 13) { *bad = 1; break; }
+            c[(int64_t)(forward ? code : code - 14) * n + i] = val[k];
+            atomicAdd(&cnt[forward ? code : code - 14], 1u);
+        }
     }
+    __syncthreads();
+    if (threadIdx.x < 13 && cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
 }
 
 // Recognise a box-stencil factor and lay it out as 13 natural-order coefficient streams.  Not an error when it does not apply.
@@ -1069,20 +1094,23 @@ static int32_t build_box(int64_t n, const FlatRows& ent, const hvec<double>& dia
     const size_t cb = sizeof(double) * (size_t)13 * (size_t)n, ne = (size_t)ent.ptr[(size_t)n];
     int32_t bad = 1;
     bool ok = hipMalloc(&d_ptr, sizeof(int64_t) * ((size_t)n + 1)) == hipSuccess && hipMalloc(&d_col, sizeof(int32_t) * (ne + 1)) == hipSuccess &&
-              hipMalloc(&d_val, sizeof(double) * (ne + 1)) == hipSuccess && hipMalloc(&d_bad, 64) == hipSuccess && hipMalloc(&B->d_c, cb) == hipSuccess;
-    ok = ok && hipMemsetAsync(B->d_c, 0, cb, st) == hipSuccess && hipMemsetAsync(d_bad, 0, 64, st) == hipSuccess &&
+              hipMalloc(&d_val, sizeof(double) * (ne + 1)) == hipSuccess && hipMalloc(&d_bad, 128) == hipSuccess && hipMalloc(&B->d_c, cb) == hipSuccess;
+    unsigned long long hostw[16];                                           // [0]: "not a box factor", [1..13]: entries per stream
+    ok = ok && hipMemsetAsync(B->d_c, 0, cb, st) == hipSuccess && hipMemsetAsync(d_bad, 0, 128, st) == hipSuccess &&
          hipMemcpyAsync(d_ptr, ent.ptr.data(), sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, st) == hipSuccess &&
          hipMemcpyAsync(d_col, ent.col.data(), sizeof(int32_t) * ne, hipMemcpyHostToDevice, st) == hipSuccess &&
          hipMemcpyAsync(d_val, ent.val.data(), sizeof(double) * ne, hipMemcpyHostToDevice, st) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(box_rows_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_ptr, d_col, d_val, (int32_t)n, (int32_t)Ni, (int32_t)Nj, (int32_t)Nk,
-                           forward ? 1 : 0, B->d_c, d_bad);
-        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+                           forward ? 1 : 0, B->d_c, d_bad, reinterpret_cast<unsigned long long*>(d_bad) + 1);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(hostw, d_bad, 128, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+        if (ok) bad = (int32_t)(hostw[0] & 0xffffffffull);
     }
     (void)hipFree(d_ptr); (void)hipFree(d_col); (void)hipFree(d_val); (void)hipFree(d_bad);
     if (!ok) { (void)hipGetLastError(); B->free_all(); set_error("box-stencil factor: device allocation or copy failed"); return KRYST_ERR_HIP; }
     if (bad != 0) { B->free_all(); return KRYST_OK; }
     if (!forward) KR_TRY(up(&B->d_diag, diag));
+    box_classify(hostw + 1, forward, Ni, Nj, Nk, B);
     B->Ni = (int32_t)Ni; B->Nj = (int32_t)Nj; B->Nk = (int32_t)Nk; B->ok = true;
     return KRYST_OK;
 }
@@ -1128,8 +1156,10 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
         if (rc == KRYST_OK) {
             *D->h_gave_up = 0;
             // 70 / 73 KiB of LDS per workgroup (two per CU): more than the 64 KiB a kernel gets without asking
-            D->box_wave_ready = hipFuncSetAttribute((const void*)tri_box_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<true>()) == hipSuccess &&
-                                hipFuncSetAttribute((const void*)tri_box_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<false>()) == hipSuccess;
+            D->box_wave_ready = hipFuncSetAttribute((const void*)tri_box_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<true>()) == hipSuccess &&
+                                hipFuncSetAttribute((const void*)tri_box_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<false>()) == hipSuccess &&
+                                hipFuncSetAttribute((const void*)tri_box_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<true>()) == hipSuccess &&
+                                hipFuncSetAttribute((const void*)tri_box_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<false>()) == hipSuccess;
             (void)hipGetLastError();
         }
     }
@@ -1180,9 +1210,11 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
             }
         }
     }
-    if (getenv("KRYST_ILU_VERBOSE"))
+    if (getenv("KRYST_ILU_VERBOSE")) {
+        if (D->BL.ok) { fprintf(stderr, "[kryst ilu] box streams: L present %#x regular %d, U present %#x regular %d\n", D->BL.present, (int)D->BL.regular, D->BU.present, (int)D->BU.regular); }
         fprintf(stderr, "[kryst ilu] n=%lld %s; levels L/U=%zu/%zu\n", (long long)n, D->GL.ok ? "structured grid (wavefront kernel)" : D->BL.ok ? "box stencil (13 streams per factor)" : "level-ordered",
                 D->L.lvl_off.empty() ? (size_t)0 : D->L.lvl_off.size() - 1, D->U.lvl_off.empty() ? (size_t)0 : D->U.lvl_off.size() - 1);
+    }
     return rc;
 }
 
@@ -1618,22 +1650,30 @@ __global__ __launch_bounds__(256) void gen_classify_kernel(const int32_t* __rest
 // (dk, dj, di) neighbour of (i, j, k) in the Ni x Nj x Nk box -- BoxFactor's layout; `bad` is raised by an entry that is no such neighbour
 // (it wraps around a line or plane end), a halo column, or a row whose columns do not ascend.  Zero values stay +0.0 = no entry.
 __global__ __launch_bounds__(256) void gen_box_fill_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ w, const double* __restrict__ dg,
-                                                           int32_t n, int32_t Ni, int32_t Nj, int32_t Nk, double* cl, double* cu, double* diag, int32_t* bad) {
+                                                           int32_t n, int32_t Ni, int32_t Nj, int32_t Nk, double* cl, double* cu, double* diag, int32_t* bad,
+                                                           unsigned long long* counts) {           // counts[0..12]: entries per L stream, [13..25]: per U stream
+    __shared__ unsigned int cnt[26];
+    if (threadIdx.x < 26) cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int32_t ii = i % Ni, jj = (i / Ni) % Nj, kk = i / (Ni * Nj);
-    int32_t prev = -1;
-    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
-        const int32_t j = col[k];
-        if (j >= n || j <= prev) { *bad = 1; return; }
-        prev = j;
-        if (j == i || w[k] == 0.0) continue;
-        const int di = j % Ni - ii, dj = (j / Ni) % Nj - jj, dk = j / (Ni * Nj) - kk;
-        if (di < -1 || di > 1 || dj < -1 || dj > 1 || dk < -1 || dk > 1) { *bad = 1; return; }
-        const int code = 9 * (dk + 1) + 3 * (dj + 1) + (di + 1);
-        if (j < i) cl[(int64_t)code * n + i] = w[k]; else cu[(int64_t)(code - 14) * n + i] = w[k];
+    if (i < n) {
+        const int32_t ii = i % Ni, jj = (i / Ni) % Nj, kk = i / (Ni * Nj);
+        int32_t prev = -1;
+        for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+            const int32_t j = col[k];
+            if (j >= n || j <= prev) { *bad = 1; break; }
+            prev = j;
+            if (j == i || w[k] == 0.0) continue;
+            const int di = j % Ni - ii, dj = (j / Ni) % Nj - jj, dk = j / (Ni * Nj) - kk;
+            if (di < -1 || di > 1 || dj < -1 || dj > 1 || dk < -1 || dk > 1) { *bad = 1; break; }
+            const int code = 9 * (dk + 1) + 3 * (dj + 1) + (di + 1);
+            if (j < i) { cl[(int64_t)code * n + i] = w[k]; atomicAdd(&cnt[code], 1u); }
+            else { cu[(int64_t)(code - 14) * n + i] = w[k]; atomicAdd(&cnt[13 + code - 14], 1u); }
+        }
+        diag[i] = dg[i];
     }
-    diag[i] = dg[i];
+    __syncthreads();
+    if (threadIdx.x < 26 && cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
 }
 
 template <bool LOWER>
@@ -1790,17 +1830,23 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         // ---- box stencil: 13 natural-order coefficient streams per factor, written by one kernel (no level machinery at all)
         const size_t cb = sizeof(double) * (size_t)13 * (size_t)n;
         int32_t* d_bad = reinterpret_cast<int32_t*>(t.flags + 3);
+        unsigned long long* d_counts = nullptr; unsigned long long counts[26];
         int32_t bad = 1;
         if (hipMalloc(&D->BL.d_c, cb) != hipSuccess || hipMalloc(&D->BU.d_c, cb) != hipSuccess || hipMalloc(&D->BU.d_diag, sizeof(double) * (size_t)n) != hipSuccess) {
             (void)hipGetLastError();
-        } else if (hipMemsetAsync(D->BL.d_c, 0, cb, ctx->s_main) == hipSuccess && hipMemsetAsync(D->BU.d_c, 0, cb, ctx->s_main) == hipSuccess) {
+        } else if (hipMalloc(&d_counts, sizeof counts) == hipSuccess && hipMemsetAsync(d_counts, 0, sizeof counts, ctx->s_main) == hipSuccess &&
+                   hipMemsetAsync(D->BL.d_c, 0, cb, ctx->s_main) == hipSuccess && hipMemsetAsync(D->BU.d_c, 0, cb, ctx->s_main) == hipSuccess) {
             const int32_t Ni = (int32_t)box_ni, Nj = (int32_t)box_nj, Nk = (int32_t)(n64 / (box_ni * box_nj));
-            hipLaunchKernelGGL(gen_box_fill_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dg, n, Ni, Nj, Nk, D->BL.d_c, D->BU.d_c, D->BU.d_diag, d_bad);
+            hipLaunchKernelGGL(gen_box_fill_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dg, n, Ni, Nj, Nk, D->BL.d_c, D->BU.d_c, D->BU.d_diag, d_bad,
+                               d_counts);
             if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->s_main) == hipSuccess &&
+                hipMemcpyAsync(counts, d_counts, sizeof counts, hipMemcpyDeviceToHost, ctx->s_main) == hipSuccess &&
                 hipStreamSynchronize(ctx->s_main) == hipSuccess && bad == 0) {
                 for (BoxFactor* F : {&D->BL, &D->BU}) { F->Ni = Ni; F->Nj = Nj; F->Nk = Nk; F->ok = true; }
+                box_classify(counts, true, Ni, Nj, Nk, &D->BL); box_classify(counts + 13, false, Ni, Nj, Nk, &D->BU);
             }
         }
+        (void)hipFree(d_counts);
         (void)hipGetLastError();
         if (D->BL.ok && D->BU.ok) {
             lap("box-stencil streams");

@@ -63,9 +63,14 @@ __global__ __launch_bounds__(256) void tri_box_fill_kernel(const TriArgs* args, 
     }
 }
 
-template <bool FORWARD>
+// REGULAR: every stream of the factor is either absent altogether (`present` bit clear: the term is skipped) or has an entry wherever the
+// neighbour row exists in the box -- the factors of a full 27- or 19-point stencil, Ilup(1) of a 7-point operator, ...  Then an absent entry's
+// operand is always a row OUTSIDE the box, and those are +0.0 by construction here (the poller hands +0.0 for rows outside a line, a lane
+// outside its line publishes +0.0): +0.0 x +0.0 = +0.0 leaves s unchanged bit for bit, so the 13 compare + select pairs of the general form
+// are not needed.  A factor with entries missing in the interior (dropped couplings, values that cancelled to zero) takes REGULAR = false.
+template <bool FORWARD, bool REGULAR>
 __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, BoxView B, int32_t* flags, int32_t* abort_word,
-                                                      int32_t* gave_up, int poll_budget) {
+                                                      int32_t* gave_up, int poll_budget, uint32_t present) {
     if (args->skip) return;
     constexpr int C = TB_C, NA = tb_arrays<FORWARD>(), S = TB_S, R = TB_R, RS = TB_RS;
     constexpr int LPL = C / 2;                                            // loader, fast path: lanes per line and chunk (16-byte pieces) = passes
@@ -103,6 +108,9 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
         // are rows of the lines next to it in memory: loaded, staged and never used.  Only a piece outside the ARRAY (first / last
         // lines of the box) sends the whole chunk down the element-wise path.
         const int a0 = wave == 1 ? 0 : NA1, cnt = wave == 1 ? NA1 : NA - NA1;
+        // arrays this wave moves: the right-hand side, the divisor, and the streams the factor HAS (what bounds a step is the bytes one CU can
+        // pull per microsecond -- 15 arrays x 64 lines x 8 bytes per step: 0.38 us at ~20 GB/s -- so a stream without entries is not streamed)
+        auto wanted = [&](int a) { const int g = a0 + a; return a < cnt && (g == 0 || g == 14 || ((present >> (g - 1)) & 1u)); };
         int* const staged = wave == 1 ? staged1 : staged2;
         struct Buf { tw_v2 d[NA1][C / 2]; };
         const int g = l / LPL, c = l % LPL;
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
                     const uint32_t off = (uint32_t)(8 * lo);
 #pragma unroll
                     for (int a = 0; a < NA1; ++a)
-                        if (a < cnt) q.d[a][r] = *(cg_v2*)tw_at(arr(a0 + a), off, 0);
+                        if (wanted(a)) q.d[a][r] = *(cg_v2*)tw_at(arr(a0 + a), off, 0);
                 }
             } else {
 #pragma unroll
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
                     const int64_t rb = min(max(base + (FORWARD ? 1 : -1) * (int64_t)(t0 + 2 * h + 1 - skew), (int64_t)0), n - 1);
 #pragma unroll
                     for (int a = 0; a < NA1; ++a)
-                        if (a < cnt) { cgdouble* p = arr(a0 + a); q.d[a][h] = tw_v2{p[ra], p[rb]}; }
+                        if (wanted(a)) { cgdouble* p = arr(a0 + a); q.d[a][h] = tw_v2{p[ra], p[rb]}; }
                 }
             }
         };
@@ -154,14 +162,14 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
                 const int h = FORWARD ? c : C / 2 - 1 - c;                // the piece's step pair (the backward solve walks rows downwards)
 #pragma unroll
                 for (int a = 0; a < NA1; ++a)
-                    if (a < cnt)
+                    if (wanted(a))
 #pragma unroll
                         for (int r = 0; r < LPL; ++r)
                             dst[((a0 + a) * (C / 2) + h) * 64 + LPP * r + g] = FORWARD ? q.d[a][r] : tw_v2{q.d[a][r].y, q.d[a][r].x};
             } else {
 #pragma unroll
                 for (int a = 0; a < NA1; ++a)
-                    if (a < cnt)
+                    if (wanted(a))
 #pragma unroll
                         for (int h = 0; h < C / 2; ++h) dst[((a0 + a) * (C / 2) + h) * 64 + l] = q.d[a][h];
             }
@@ -288,9 +296,11 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
         for (int budget = 1 << 24; (tw_lds_load(staged1) <= kc || tw_lds_load(staged2) <= kc) && budget > 0; --budget) __builtin_amdgcn_s_sleep(1);
         const tw_v2* src = stage + (size_t)(kc % S) * NA * (C / 2) * 64 + l;
 #pragma unroll
-        for (int a = 0; a < NA; ++a)
+        for (int a = 0; a < NA; ++a) {
+            if (a >= 1 && a <= 13 && !((present >> (a - 1)) & 1u)) continue;           // (not staged: the factor has no such stream)
 #pragma unroll
             for (int h = 0; h < C / 2; ++h) { const tw_v2 x = src[(a * (C / 2) + h) * 64]; q.v[a][2 * h] = x.x; q.v[a][2 * h + 1] = x.y; }
+        }
         tw_lds_store(taken, kc + 1);                                      // (release: the reads above are complete)
     };
     Chunk q;
@@ -318,14 +328,16 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
             double s = q.v[0][u];
 #pragma unroll
             for (int a = 0; a < 13; ++a) {
+                if (present != 0x1fffu && !((present >> a) & 1u)) continue;       // (uniform: a stream the factor does not have, not staged either)
                 const double cf = q.v[1 + a][u];
                 double x = dep[FORWARD ? a : 12 - a];
-                // absent entry (coefficient +0.0): the operand's high word cleared -> zero or a positive subnormal, the product is +0.0 and s
-                // unchanged, whatever the operand was (one select instead of tri_wave.h's two)
-                x = __hiloint2double(cf != 0.0 ? __double2hiint(x) : 0, __double2loint(x));
+                // general form, absent entry (coefficient +0.0): the operand's high word cleared -> zero or a positive subnormal, the product is
+                // +0.0 and s unchanged, whatever the operand was (one select instead of tri_wave.h's two)
+                if (!REGULAR) x = __hiloint2double(cf != 0.0 ? __double2hiint(x) : 0, __double2loint(x));
                 s = s - cf * x;
             }
             if (!FORWARD) s = s / q.v[NA - 1][u];
+            if (REGULAR) s = act ? s : 0.0;                               // a row outside the box: +0.0 for whoever reads it
             if (act) {
                 gdouble* dst = out + (base + (FORWARD ? ii : -ii));
                 if (edge) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
