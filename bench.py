@@ -788,8 +788,10 @@ def general_ilu(K, ctx):
         info = pc.ilu_info()
         blk = {"rows": n, "nnz": int(a_.nnz), "setup_ms": setup_ms, "apply_ms": ms, "form": info["form"]}
         if info["form"].startswith("box"):
-            moved = (26 * 8 + 8 + 32) * n                    # 13 coefficient streams per factor + the divisor + r, y read and y, z written
-            blk.update(bytes_moved=moved, bytes_model="26 coefficient streams + divisor + 32 n (r, y read; y, z written)",
+            ns = sum(info["streams"])                        # coefficient streams the two factors have (of 13 each): only those are streamed
+            moved = (ns * 8 + 8 + 32) * n
+            blk.update(bytes_moved=moved, streams=info["streams"], regular=info["regular"],
+                       bytes_model=f"{ns} coefficient streams + divisor + 32 n (r, y read; y, z written)",
                        achieved=moved / (ms * 1e-3) / 1e9, unit="GB/s", peak=HBM_PEAK_GBS, frac=moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        hyperplanes=info["levels"][0], us_per_hyperplane=ms * 1e3 / max(1, 2 * info["levels"][0]))
         out[name] = blk

@@ -380,6 +380,9 @@ class _Pc:
         check(lib().kryst_pc_ilu_info(self.h, v.ctypes.data_as(_ffi.c_i64p), 13))
         form = ("level-ordered", "grid 8x8 (tri_wave_kernel)", "grid 16x16 (tri_quad_kernel)", "grid planes (tri_plane_kernel)",
                 "box planes (tri_box_plane_kernel)", "box wavefront (tri_box_kernel)")[int(v[0])]
+        if form.startswith("box"):          # info[6..8]: coefficient streams L / U have (of 13 each), both factors "regular" (tri_box.h)
+            return {"form": form, "box": [int(v[1]), int(v[2]), int(v[3])], "levels": [int(v[4]), int(v[5])], "streams": [int(v[6]), int(v[7])],
+                    "regular": bool(v[8]), "chunks": [0, 0], "chunks_not_requested": [0, 0], "bytes_per_chunk": [0, 0]}
         return {"form": form, "box": [int(v[1]), int(v[2]), int(v[3])], "levels": [int(v[4]), int(v[5])], "chunks": [int(v[6]), int(v[7])],
                 "chunks_not_requested": [int(v[8]), int(v[9])], "bytes_per_chunk": [int(v[10]), int(v[11])]}
 

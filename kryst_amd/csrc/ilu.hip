@@ -2309,6 +2309,7 @@ extern "C" int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kr
 //           grid, 16 x 16 lines per workgroup (tri_quad.h), 3 structured grid after a give-up (plane kernels), 4 box stencil inside the
 //           3 x 3 x 3 cube, one launch per hyperplane i + 2 j + 4 k (info[4], info[5]: hyperplanes per factor)
 //   info[1..3] Ni, Nj, Nk (grid forms)          info[4], info[5] dependency levels of L, U (level-ordered forms)
+//   box forms (4, 5): info[6], info[7] coefficient streams L / U have (of 13), info[8] 1 when both factors are "regular" (tri_box.h)
 //   info[6], info[7] coefficient chunks (per block quadrant) of the forward / backward factor; info[8], info[9] how many of them
 //           repeat chunk - 3 bit for bit and are not requested; info[10], info[11] bytes per chunk request (forward, backward)
 //   info[12] stored entries of L + U (level-ordered forms)
@@ -2322,6 +2323,8 @@ extern "C" int32_t kryst_pc_ilu_info(kryst_pc_t pc, int64_t* info, int32_t count
         info[0] = box_takes_wavefront(D) ? 5 : 4;                          // 5 = pipelined wavefront over parallelograms of 8 x 8 lines (tri_box.h)
         info[1] = D->BL.Ni; info[2] = D->BL.Nj; info[3] = D->BL.Nk;
         info[4] = info[5] = (D->BL.Ni - 1) + 2 * (D->BL.Nj - 1) + 4 * (D->BL.Nk - 1) + 1;
+        info[6] = __builtin_popcount(D->BL.present); info[7] = __builtin_popcount(D->BU.present);   // coefficient streams the factors have (of 13 each)
+        info[8] = (D->BL.regular && D->BU.regular) ? 1 : 0;                                          // tri_box.h: REGULAR
         return KRYST_OK;
     }
     if (!(D->GL.ok && D->GU.ok)) {
