@@ -91,6 +91,10 @@ class Context:
     def synchronize(self):
         check(lib().kryst_ctx_synchronize(self.h))
 
+    def poison_lds(self):
+        """Test hook: NaNs into every compute unit's LDS (a kernel must not depend on what LDS held before it started)."""
+        check(lib().kryst_bench_poison_lds(self.h))
+
     def timer_start(self):
         check(lib().kryst_ctx_timer_start(self.h))
 

@@ -176,6 +176,26 @@ __global__ __launch_bounds__(KR_T) void csr_skeleton_kernel(const int32_t* __res
 }
 }  // namespace kr
 
+namespace kr {
+__global__ __launch_bounds__(256) void poison_lds_kernel(int words) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long poison_smem[];
+    for (int i = threadIdx.x; i < words; i += blockDim.x) poison_smem[i] = 0x7ff8badc0ffee000ull + (unsigned)i;
+    __syncthreads();
+    if (poison_smem[(threadIdx.x * 31) % words] == 1) __builtin_trap();       // (keeps the stores)
+}
+}  // namespace kr
+
+extern "C" int32_t kryst_bench_poison_lds(kryst_ctx_t ctx) {
+    KR_ARG(ctx, "bench_poison_lds");
+    KR_HIP(hipSetDevice(ctx->device));
+    const int bytes = 152 * 1024;                                               // (160 KiB per CU: one such workgroup per CU at a time)
+    KR_HIP(hipFuncSetAttribute((const void*)kr::poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    for (int pass = 0; pass < 2; ++pass) hipLaunchKernelGGL(kr::poison_lds_kernel, dim3(2048), dim3(256), bytes, ctx->s_main, bytes / 8);
+    KR_HIP(hipGetLastError());
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    return KRYST_OK;
+}
+
 extern "C" int32_t kryst_bench_csr_skeleton(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t reps, double* avg_ms) {
     KR_ARG(a && x && y && avg_ms && reps >= 1, "bench_csr_skeleton");
     KR_ARG(x->n == a->xlen && y->n == a->nrows && a->nrows == a->xlen && !a->dist, "bench_csr_skeleton: a square single-rank operator and vectors of its size");

@@ -99,7 +99,11 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
     auto line_exists = [&](int jj, int kk) { return jj >= 0 && jj < B.Nj && kk >= 0 && kk < B.Nk; };
     const int nsteps = B.Ni + 29, nch = (nsteps + C - 1) / C, T = nch * C;
     if (threadIdx.x < 8) ctr[threadIdx.x] = 0;
-    __syncthreads();                                                      // the only barrier: counters are zero before anybody looks
+    // The ring starts as +0.0: a lane with skew s asks for rows -s+1 .. -1 of its external lines during its first steps, rows the poller never
+    // delivers (it starts at row 0).  Their coefficients are +0.0, but a REGULAR factor multiplies without a select, and whatever the LDS
+    // held before -- a NaN, on one GPU box in five -- would end up in s.
+    for (int x = threadIdx.x; x < R * RS; x += blockDim.x) ring[x] = 0.0;
+    __syncthreads();                                                      // the only barrier: counters and ring are zero before anybody looks
     int* const staged1 = &ctr[0]; int* const staged2 = &ctr[1]; int* const taken = &ctr[2]; int* const pub = &ctr[3]; int* const quit = &ctr[4];
 
     if (wave == 1 || wave == 2) {
