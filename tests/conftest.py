@@ -25,7 +25,7 @@ def pytest_collection_modifyitems(session, config, items):
 
 # LDS is not cleared between kernels, and what an earlier process left there differs from GPU box to GPU box: a kernel that reads LDS it has
 # not written is right on one box and wrong on the next (round 4: tri_box.h's ring, found by a test that failed on one box in five).
-# Every -m gpu test therefore starts with NaNs in every compute unit's LDS (kryst_bench_poison_lds).
+# Every -m gpu test therefore starts with NaNs in every compute unit's LDS (kryst_bench_poison_lds) and in 4 GB of just-freed device memory.
 import pytest
 
 _poison_ctx = None
@@ -39,4 +39,8 @@ def _nans_in_lds_before_every_gpu_test(request):
         if _poison_ctx is None:
             _poison_ctx = K.Context(0)
         _poison_ctx.poison_lds()
+        # ... and NaNs in the device memory the test is about to be handed (hipMalloc does not clear either)
+        junk = [_poison_ctx.vec(1 << 28).fill(float("nan")) for _ in range(2)]
+        _poison_ctx.synchronize()
+        del junk
     yield
