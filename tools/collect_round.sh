@@ -7,3 +7,4 @@ for f in spmv256_default spmv256_plain spmv256_varcoef spmv512_default spmv512_p
 cp $O/spmv_traffic.json profiles/spmv_traffic.json
 find $O/ilu_prof_256 -name "*kernel_stats.csv" -exec cp {} $P/ilu_apply256_kernel_stats.csv \;
 find $O/ilu_prof_512 -name "*kernel_stats.csv" -exec cp {} $P/ilu_apply512_kernel_stats.csv \;
+find $O/box_prof_96 -name "*kernel_stats.csv" -exec cp {} $P/box_apply96_kernel_stats.csv \;

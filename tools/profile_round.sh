@@ -27,6 +27,7 @@ python3 $R/tools/kernel_by_size.py $O/bench_prof $O/bench_default_kernel_by_size
 for g in 256 512; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ilu_prof_$g -o ilu -- python3 $R/tools/ilu_only.py $g 20 true > $O/ilu_$g.log 2>&1 || exit 1
 done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/box_prof_96 -o box -- python3 $R/tools/box_only.py 96 20 > $O/box_96.log 2>&1 || exit 1
 cd $R
 timeout -k 10 900 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err || exit 1
 timeout -k 10 900 python3 tools/bench_configs.py 256 64 > $O/configs_256.jsonl 2> $O/configs.err || exit 1
