@@ -686,15 +686,17 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D, const TriDirect* direct 
             const int budget = std::max(1, env_int("KRYST_ILU_POLL_BUDGET", 1 << 22));
             hipLaunchKernelGGL((tri_box_fill_kernel<true>), dim3(nb), dim3(256), 0, s, D->d_args, D->d_y, VA, D->d_flags, (int32_t)(2 * nb));
             const bool reg = A.regular && B.regular && env_int("KRYST_ILU_BOX_REGULAR", 1) != 0;
-            if (reg) hipLaunchKernelGGL((tri_box_kernel<true, true>), dim3(nb), dim3(256), tb_lds_bytes<true>(), s, D->d_args, (const double*)nullptr, D->d_y, VA, D->d_flags,
-                               D->d_flags + 2 * nb, D->d_gave_up, budget, A.present);
-            else hipLaunchKernelGGL((tri_box_kernel<true, false>), dim3(nb), dim3(256), tb_lds_bytes<true>(), s, D->d_args, (const double*)nullptr, D->d_y, VA, D->d_flags,
-                               D->d_flags + 2 * nb, D->d_gave_up, budget, A.present);
+            const bool all = A.present == 0x1fffu && B.present == 0x1fffu;
+            auto launch = [&](auto fwd, const BoxView& V, const double* in, double* out, int32_t* fl, uint32_t present) {
+                constexpr bool F = decltype(fwd)::value;
+                const size_t lds = tb_lds_bytes<F>();
+#define KR_BOX_LAUNCH(R, AL) hipLaunchKernelGGL((tri_box_kernel<F, R, AL>), dim3(nb), dim3(256), lds, s, D->d_args, in, out, V, fl, D->d_flags + 2 * nb, D->d_gave_up, budget, present)
+                if (reg && all) KR_BOX_LAUNCH(true, true); else if (reg) KR_BOX_LAUNCH(true, false); else if (all) KR_BOX_LAUNCH(false, true); else KR_BOX_LAUNCH(false, false);
+#undef KR_BOX_LAUNCH
+            };
+            launch(std::true_type(), VA, (const double*)nullptr, D->d_y, D->d_flags, A.present);
             hipLaunchKernelGGL((tri_box_fill_kernel<false>), dim3(nb), dim3(256), 0, s, D->d_args, (double*)nullptr, VB, (int32_t*)nullptr, 0);
-            if (reg) hipLaunchKernelGGL((tri_box_kernel<false, true>), dim3(nb), dim3(256), tb_lds_bytes<false>(), s, D->d_args, (const double*)D->d_y, (double*)nullptr, VB, D->d_flags + nb,
-                               D->d_flags + 2 * nb, D->d_gave_up, budget, B.present);
-            else hipLaunchKernelGGL((tri_box_kernel<false, false>), dim3(nb), dim3(256), tb_lds_bytes<false>(), s, D->d_args, (const double*)D->d_y, (double*)nullptr, VB, D->d_flags + nb,
-                               D->d_flags + 2 * nb, D->d_gave_up, budget, B.present);
+            launch(std::false_type(), VB, (const double*)D->d_y, (double*)nullptr, D->d_flags + nb, B.present);
             KR_HIP(hipGetLastError());
             return KRYST_OK;
         }
@@ -1156,10 +1158,12 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
         if (rc == KRYST_OK) {
             *D->h_gave_up = 0;
             // 70 / 73 KiB of LDS per workgroup (two per CU): more than the 64 KiB a kernel gets without asking
-            D->box_wave_ready = hipFuncSetAttribute((const void*)tri_box_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<true>()) == hipSuccess &&
-                                hipFuncSetAttribute((const void*)tri_box_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<false>()) == hipSuccess &&
-                                hipFuncSetAttribute((const void*)tri_box_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<true>()) == hipSuccess &&
-                                hipFuncSetAttribute((const void*)tri_box_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<false>()) == hipSuccess;
+            bool ok = true;
+#define KR_BOX_ATTR(F, R, AL) ok = ok && hipFuncSetAttribute((const void*)tri_box_kernel<F, R, AL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<F>()) == hipSuccess
+            KR_BOX_ATTR(true, true, true); KR_BOX_ATTR(true, true, false); KR_BOX_ATTR(true, false, true); KR_BOX_ATTR(true, false, false);
+            KR_BOX_ATTR(false, true, true); KR_BOX_ATTR(false, true, false); KR_BOX_ATTR(false, false, true); KR_BOX_ATTR(false, false, false);
+#undef KR_BOX_ATTR
+            D->box_wave_ready = ok;
             (void)hipGetLastError();
         }
     }

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256) void tri_box_fill_kernel(const TriArgs* args, 
 // operand is always a row OUTSIDE the box, and those are +0.0 by construction here (the poller hands +0.0 for rows outside a line, a lane
 // outside its line publishes +0.0): +0.0 x +0.0 = +0.0 leaves s unchanged bit for bit, so the 13 compare + select pairs of the general form
 // are not needed.  A factor with entries missing in the interior (dropped couplings, values that cancelled to zero) takes REGULAR = false.
-template <bool FORWARD, bool REGULAR>
+// ALL: the factor has all 13 streams (`present` == 0x1fff): no per-stream tests anywhere ("skip this term" costs two selects per term ON the
+// dependent chain of s, present or not: 0.39 -> 0.32 us per step without them).
+template <bool FORWARD, bool REGULAR, bool ALL>
 __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, BoxView B, int32_t* flags, int32_t* abort_word,
                                                       int32_t* gave_up, int poll_budget, uint32_t present) {
     if (args->skip) return;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
         const int a0 = wave == 1 ? 0 : NA1, cnt = wave == 1 ? NA1 : NA - NA1;
         // arrays this wave moves: the right-hand side, the divisor, and the streams the factor HAS (what bounds a step is the bytes one CU can
         // pull per microsecond -- 15 arrays x 64 lines x 8 bytes per step: 0.38 us at ~20 GB/s -- so a stream without entries is not streamed)
-        auto wanted = [&](int a) { const int g = a0 + a; return a < cnt && (g == 0 || g == 14 || ((present >> (g - 1)) & 1u)); };
+        auto wanted = [&](int a) { const int g = a0 + a; return a < cnt && (ALL || g == 0 || g == 14 || ((present >> (g - 1)) & 1u)); };
         int* const staged = wave == 1 ? staged1 : staged2;
         struct Buf { tw_v2 d[NA1][C / 2]; };
         const int g = l / LPL, c = l % LPL;
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
         const tw_v2* src = stage + (size_t)(kc % S) * NA * (C / 2) * 64 + l;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            if (a >= 1 && a <= 13 && !((present >> (a - 1)) & 1u)) continue;           // (not staged: the factor has no such stream)
+            if (!ALL && a >= 1 && a <= 13 && !((present >> (a - 1)) & 1u)) continue;   // (not staged: the factor has no such stream)
 #pragma unroll
             for (int h = 0; h < C / 2; ++h) { const tw_v2 x = src[(a * (C / 2) + h) * 64]; q.v[a][2 * h] = x.x; q.v[a][2 * h + 1] = x.y; }
         }
@@ -332,7 +334,9 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
             double s = q.v[0][u];
 #pragma unroll
             for (int a = 0; a < 13; ++a) {
-                if (present != 0x1fffu && !((present >> a) & 1u)) continue;       // (uniform: a stream the factor does not have, not staged either)
+                // (uniform: a stream the factor does not have is not staged either.  The compiler turns the skip into two selects per term; forced
+                // to be a branch it was slower -- Ilup(1) of the 7-point operator on 128^3, 6 of 13 streams: 0.96 ms with selects, 1.12 with branches)
+                if (!ALL && !((present >> a) & 1u)) continue;
                 const double cf = q.v[1 + a][u];
                 double x = dep[FORWARD ? a : 12 - a];
                 // general form, absent entry (coefficient +0.0): the operand's high word cleared -> zero or a positive subnormal, the product is
