@@ -135,13 +135,17 @@ struct GridView { int32_t Ni, Nj, Nk; const double* c1; const double* c2; const 
 struct BoxFactor {
     bool ok = false;
     int32_t Ni = 0, Nj = 0, Nk = 0;
-    double* d_c = nullptr;          // 13 n doubles: d_c[a n + row]
+    double* d_c = nullptr;          // 13 streams, box_stream_stride(n) doubles apart: d_c[a stride + row]
     double* d_diag = nullptr;       // divisor (backward factor only)
     uint32_t present = 0x1fff;      // streams with at least one entry
     bool regular = false;           // every present stream has an entry wherever the neighbour row exists in the box (tri_box.h: REGULAR)
     void free_all() { (void)hipFree(d_c); (void)hipFree(d_diag); d_c = nullptr; d_diag = nullptr; }
 };
-struct BoxView { int32_t Ni, Nj, Nk; int64_t n; const double* c; const double* diag; };
+struct BoxView { int32_t Ni, Nj, Nk; int64_t n; const double* c; const double* diag; int64_t cs; };   // cs: doubles from one stream to the next
+// Streams are NOT n doubles apart: with n = 128^3 that is 16 MiB, and the 13 coefficients of a row would sit in the same HBM channel and bank
+// (measured: 27-point 128^3 apply 1.75 ms where the hop / step model says 1.0).  n rounded up to 64 rows plus 72 rows: consecutive streams are
+// 576 bytes apart modulo any power of two from 1 KiB up.
+static inline int64_t box_stream_stride(int64_t n) { return (n + 63) / 64 * 64 + 72; }
 
 struct IluData {
     TriFactor L, U;
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(256) void tri_box_plane_kernel(const TriArgs* args,
     for (int a = 0; a < 13; ++a) {
         const int code = FORWARD ? a : a + 14;                             // 9 (dk + 1) + 3 (dj + 1) + (di + 1)
         const int dk = code / 9 - 1, dj = (code / 3) % 3 - 1, di = code % 3 - 1;
-        const double c = B.c[(int64_t)a * B.n + row];
+        const double c = B.c[(int64_t)a * B.cs + row];
         if (c != 0.0) s = s - c * out[row + di + s1 * dj + s2 * dk];
     }
     out[row] = FORWARD ? s : s / B.diag[row];
@@ -679,7 +683,7 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D, const TriDirect* direct 
     if (D->BL.ok && D->BU.ok) {
         // box stencil: r -> forward -> y (natural order) -> backward -> z
         const BoxFactor& A = D->BL; const BoxFactor& B = D->BU;
-        const BoxView VA{A.Ni, A.Nj, A.Nk, D->n, A.d_c, nullptr}, VB{B.Ni, B.Nj, B.Nk, D->n, B.d_c, B.d_diag};
+        const BoxView VA{A.Ni, A.Nj, A.Nk, D->n, A.d_c, nullptr, box_stream_stride(D->n)}, VB{B.Ni, B.Nj, B.Nk, D->n, B.d_c, B.d_diag, box_stream_stride(D->n)};
         if (box_takes_wavefront(D)) {
             // pipelined wavefront over parallelograms of 8 x 8 lines (tri_box.h); the abort word behind the 2 nb flags stays set once raised
             const unsigned nb = (unsigned)(tb_nbj(A.Nj) * tb_nbk(A.Nk));
@@ -1043,7 +1047,7 @@ static void box_classify(const unsigned long long cnt[13], bool forward, int64_t
 // one factor's kept entries (host FlatRows, uploaded) -> its 13 coefficient streams; `bad` is raised by an entry that is not a neighbour
 // inside the box (it wraps around a line or plane end) or lies on the wrong side of the diagonal
 __global__ __launch_bounds__(256) void box_rows_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val, int32_t n,
-                                                            int32_t Ni, int32_t Nj, int32_t Nk, int forward, double* c, int32_t* bad, unsigned long long* counts) {
+                                                            int32_t Ni, int32_t Nj, int32_t Nk, int forward, double* c, int64_t cs, int32_t* bad, unsigned long long* counts) {
     __shared__ unsigned int cnt[13];
     if (threadIdx.x < 13) cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -1057,7 +1061,7 @@ __global__ __launch_bounds__(256) void box_rows_fill_kernel(const int64_t* __res
             if (di < -1 || di > 1 || dj < -1 || dj > 1 || dk < -1 || dk > 1 || kk + dk >= Nk) { *bad = 1; break; }
             const int code = 9 * (dk + 1) + 3 * (dj + 1) + (di + 1);
             if (forward ? code >= 13 : code <= 13) { *bad = 1; break; }
-            c[(int64_t)(forward ? code : code - 14) * n + i] = val[k];
+            c[(int64_t)(forward ? code : code - 14) * cs + i] = val[k];
             atomicAdd(&cnt[forward ? code : code - 14], 1u);
         }
     }
@@ -1093,7 +1097,7 @@ static int32_t build_box(int64_t n, const FlatRows& ent, const hvec<double>& dia
     // the streams are written on the device from the uploaded rows (round 4: the host used to fill 13 n doubles per factor and send those)
     hipStream_t st = tl_setup_stream;
     int64_t* d_ptr = nullptr; int32_t* d_col = nullptr; double* d_val = nullptr; int32_t* d_bad = nullptr;
-    const size_t cb = sizeof(double) * (size_t)13 * (size_t)n, ne = (size_t)ent.ptr[(size_t)n];
+    const size_t cb = sizeof(double) * (size_t)13 * (size_t)box_stream_stride(n), ne = (size_t)ent.ptr[(size_t)n];
     int32_t bad = 1;
     bool ok = hipMalloc(&d_ptr, sizeof(int64_t) * ((size_t)n + 1)) == hipSuccess && hipMalloc(&d_col, sizeof(int32_t) * (ne + 1)) == hipSuccess &&
               hipMalloc(&d_val, sizeof(double) * (ne + 1)) == hipSuccess && hipMalloc(&d_bad, 128) == hipSuccess && hipMalloc(&B->d_c, cb) == hipSuccess;
@@ -1104,7 +1108,7 @@ static int32_t build_box(int64_t n, const FlatRows& ent, const hvec<double>& dia
          hipMemcpyAsync(d_val, ent.val.data(), sizeof(double) * ne, hipMemcpyHostToDevice, st) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(box_rows_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_ptr, d_col, d_val, (int32_t)n, (int32_t)Ni, (int32_t)Nj, (int32_t)Nk,
-                           forward ? 1 : 0, B->d_c, d_bad, reinterpret_cast<unsigned long long*>(d_bad) + 1);
+                           forward ? 1 : 0, B->d_c, box_stream_stride(n), d_bad, reinterpret_cast<unsigned long long*>(d_bad) + 1);
         ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(hostw, d_bad, 128, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
         if (ok) bad = (int32_t)(hostw[0] & 0xffffffffull);
     }
@@ -1654,7 +1658,7 @@ __global__ __launch_bounds__(256) void gen_classify_kernel(const int32_t* __rest
 // (dk, dj, di) neighbour of (i, j, k) in the Ni x Nj x Nk box -- BoxFactor's layout; `bad` is raised by an entry that is no such neighbour
 // (it wraps around a line or plane end), a halo column, or a row whose columns do not ascend.  Zero values stay +0.0 = no entry.
 __global__ __launch_bounds__(256) void gen_box_fill_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ w, const double* __restrict__ dg,
-                                                           int32_t n, int32_t Ni, int32_t Nj, int32_t Nk, double* cl, double* cu, double* diag, int32_t* bad,
+                                                           int32_t n, int32_t Ni, int32_t Nj, int32_t Nk, double* cl, double* cu, int64_t cs, double* diag, int32_t* bad,
                                                            unsigned long long* counts) {           // counts[0..12]: entries per L stream, [13..25]: per U stream
     __shared__ unsigned int cnt[26];
     if (threadIdx.x < 26) cnt[threadIdx.x] = 0;
@@ -1671,8 +1675,8 @@ __global__ __launch_bounds__(256) void gen_box_fill_kernel(const int32_t* __rest
             const int di = j % Ni - ii, dj = (j / Ni) % Nj - jj, dk = j / (Ni * Nj) - kk;
             if (di < -1 || di > 1 || dj < -1 || dj > 1 || dk < -1 || dk > 1) { *bad = 1; break; }
             const int code = 9 * (dk + 1) + 3 * (dj + 1) + (di + 1);
-            if (j < i) { cl[(int64_t)code * n + i] = w[k]; atomicAdd(&cnt[code], 1u); }
-            else { cu[(int64_t)(code - 14) * n + i] = w[k]; atomicAdd(&cnt[13 + code - 14], 1u); }
+            if (j < i) { cl[(int64_t)code * cs + i] = w[k]; atomicAdd(&cnt[code], 1u); }
+            else { cu[(int64_t)(code - 14) * cs + i] = w[k]; atomicAdd(&cnt[13 + code - 14], 1u); }
         }
         diag[i] = dg[i];
     }
@@ -1832,7 +1836,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
     int32_t rc = KRYST_OK;
     if (box_ni > 0) {
         // ---- box stencil: 13 natural-order coefficient streams per factor, written by one kernel (no level machinery at all)
-        const size_t cb = sizeof(double) * (size_t)13 * (size_t)n;
+        const size_t cb = sizeof(double) * (size_t)13 * (size_t)box_stream_stride(n);
         int32_t* d_bad = reinterpret_cast<int32_t*>(t.flags + 3);
         unsigned long long* d_counts = nullptr; unsigned long long counts[26];
         int32_t bad = 1;
@@ -1841,7 +1845,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         } else if (hipMalloc(&d_counts, sizeof counts) == hipSuccess && hipMemsetAsync(d_counts, 0, sizeof counts, ctx->s_main) == hipSuccess &&
                    hipMemsetAsync(D->BL.d_c, 0, cb, ctx->s_main) == hipSuccess && hipMemsetAsync(D->BU.d_c, 0, cb, ctx->s_main) == hipSuccess) {
             const int32_t Ni = (int32_t)box_ni, Nj = (int32_t)box_nj, Nk = (int32_t)(n64 / (box_ni * box_nj));
-            hipLaunchKernelGGL(gen_box_fill_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dg, n, Ni, Nj, Nk, D->BL.d_c, D->BU.d_c, D->BU.d_diag, d_bad,
+            hipLaunchKernelGGL(gen_box_fill_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dg, n, Ni, Nj, Nk, D->BL.d_c, D->BU.d_c, box_stream_stride(n), D->BU.d_diag, d_bad,
                                d_counts);
             if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->s_main) == hipSuccess &&
                 hipMemcpyAsync(counts, d_counts, sizeof counts, hipMemcpyDeviceToHost, ctx->s_main) == hipSuccess &&

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
     gdouble* out = (gdouble*)(out_ptr ? out_ptr : args->z);
     cgdouble* cbase = (cgdouble*)B.c; cgdouble* dgp = (cgdouble*)B.diag;
     const int64_t n = B.n;
-    auto arr = [&](int a) -> cgdouble* { return a == 0 ? in : a <= 13 ? cbase + (int64_t)(a - 1) * n : dgp; };
+    auto arr = [&](int a) -> cgdouble* { return a == 0 ? in : a <= 13 ? cbase + (int64_t)(a - 1) * B.cs : dgp; };
     const int wave = threadIdx.x >> 6;                                    // 0 solves, 1 and 2 load, 3 polls
     const int l = threadIdx.x & 63;
     const int nbj = tb_nbj(B.Nj), nbk = tb_nbk(B.Nk);
