@@ -137,11 +137,12 @@ struct BoxFactor {
     int32_t Ni = 0, Nj = 0, Nk = 0;
     double* d_c = nullptr;          // 13 streams, box_stream_stride(n) doubles apart: d_c[a stride + row]
     double* d_diag = nullptr;       // divisor (backward factor only)
+    void* d_cb = nullptr;           // blocked copy for tri_box_kernel: [block][chunk][stream (, divisor)][step pair][lane] (tri_box_layout_kernel)
     uint32_t present = 0x1fff;      // streams with at least one entry
     bool regular = false;           // every present stream has an entry wherever the neighbour row exists in the box (tri_box.h: REGULAR)
-    void free_all() { (void)hipFree(d_c); (void)hipFree(d_diag); d_c = nullptr; d_diag = nullptr; }
+    void free_all() { (void)hipFree(d_c); (void)hipFree(d_diag); (void)hipFree(d_cb); d_c = nullptr; d_diag = nullptr; d_cb = nullptr; }
 };
-struct BoxView { int32_t Ni, Nj, Nk; int64_t n; const double* c; const double* diag; int64_t cs; };   // cs: doubles from one stream to the next
+struct BoxView { int32_t Ni, Nj, Nk; int64_t n; const double* c; const double* diag; int64_t cs; const void* cb; };   // cs: doubles from one stream to the next; cb: blocked copy (tri_box.h)
 // Streams are NOT n doubles apart: with n = 128^3 that is 16 MiB, and the 13 coefficients of a row would sit in the same HBM channel and bank
 // (measured: 27-point 128^3 apply 1.75 ms where the hop / step model says 1.0).  n rounded up to 64 rows plus 72 rows: consecutive streams are
 // 576 bytes apart modulo any power of two from 1 KiB up.
@@ -683,7 +684,7 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D, const TriDirect* direct 
     if (D->BL.ok && D->BU.ok) {
         // box stencil: r -> forward -> y (natural order) -> backward -> z
         const BoxFactor& A = D->BL; const BoxFactor& B = D->BU;
-        const BoxView VA{A.Ni, A.Nj, A.Nk, D->n, A.d_c, nullptr, box_stream_stride(D->n)}, VB{B.Ni, B.Nj, B.Nk, D->n, B.d_c, B.d_diag, box_stream_stride(D->n)};
+        const BoxView VA{A.Ni, A.Nj, A.Nk, D->n, A.d_c, nullptr, box_stream_stride(D->n), A.d_cb}, VB{B.Ni, B.Nj, B.Nk, D->n, B.d_c, B.d_diag, box_stream_stride(D->n), B.d_cb};
         if (box_takes_wavefront(D)) {
             // pipelined wavefront over parallelograms of 8 x 8 lines (tri_box.h); the abort word behind the 2 nb flags stays set once raised
             const unsigned nb = (unsigned)(tb_nbj(A.Nj) * tb_nbk(A.Nk));
@@ -1159,6 +1160,20 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
         if (hipMalloc(&D->d_flags, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess || zero_dev(D->d_flags, sizeof(int32_t) * (2 * nb + 1), ctx->s_main) != KRYST_OK) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
         if (rc == KRYST_OK && (hipHostMalloc((void**)&D->h_gave_up, 64, hipHostMallocMapped) != hipSuccess ||
                                hipHostGetDevicePointer((void**)&D->d_gave_up, D->h_gave_up, 0) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (rc == KRYST_OK && env_int("KRYST_ILU_BOX", KR_ILU_BOX_DEFAULT) >= 2) {
+            // blocked copies of both factors for the wavefront kernels' loaders, one device pass each
+            const size_t nch = (size_t)(D->BL.Ni + 29 + TB_C - 1) / TB_C;
+            const size_t el = (size_t)(TB_C / 2) * 64 * 16;
+            const BoxView VA{D->BL.Ni, D->BL.Nj, D->BL.Nk, D->n, D->BL.d_c, nullptr, box_stream_stride(D->n), nullptr};
+            const BoxView VB{D->BU.Ni, D->BU.Nj, D->BU.Nk, D->n, D->BU.d_c, D->BU.d_diag, box_stream_stride(D->n), nullptr};
+            if (hipMalloc(&D->BL.d_cb, nb * nch * 13 * el) != hipSuccess || hipMalloc(&D->BU.d_cb, nb * nch * 14 * el) != hipSuccess) {
+                (void)hipGetLastError(); (void)hipFree(D->BL.d_cb); (void)hipFree(D->BU.d_cb); D->BL.d_cb = D->BU.d_cb = nullptr;     // (no room: the hyperplane kernels)
+            } else {
+                hipLaunchKernelGGL((tri_box_layout_kernel<true>), dim3((unsigned)(nb * nch)), dim3(256), 0, ctx->s_main, VA, (tw_v2*)D->BL.d_cb);
+                hipLaunchKernelGGL((tri_box_layout_kernel<false>), dim3((unsigned)(nb * nch)), dim3(256), 0, ctx->s_main, VB, (tw_v2*)D->BU.d_cb);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("box layout kernel failed"); rc = KRYST_ERR_HIP; }
+            }
+        }
         if (rc == KRYST_OK) {
             *D->h_gave_up = 0;
             // 70 / 73 KiB of LDS per workgroup (two per CU): more than the 64 KiB a kernel gets without asking
@@ -1167,7 +1182,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
             KR_BOX_ATTR(true, true, true); KR_BOX_ATTR(true, true, false); KR_BOX_ATTR(true, false, true); KR_BOX_ATTR(true, false, false);
             KR_BOX_ATTR(false, true, true); KR_BOX_ATTR(false, true, false); KR_BOX_ATTR(false, false, true); KR_BOX_ATTR(false, false, false);
 #undef KR_BOX_ATTR
-            D->box_wave_ready = ok;
+            D->box_wave_ready = ok && D->BL.d_cb && D->BU.d_cb;
             (void)hipGetLastError();
         }
     }

@@ -63,6 +63,35 @@ __global__ __launch_bounds__(256) void tri_box_fill_kernel(const TriArgs* args, 
     }
 }
 
+// BLOCKED COPY of a factor's coefficients (and divisor): [block][chunk][stream][step pair][lane] sixteen-byte elements -- exactly what a loader
+// wave puts into the LDS stage, in that order, zeros (divisor: 1) where a lane is outside its line.  From the natural-order streams a loader's
+// 64 lanes fetch 32 pieces of 32 bytes from 32 different memory lines per instruction, and whether the other 96 bytes of each line are
+// still in L2 when the next three chunks want them depends on how many blocks are active: the loads were 29 % of the 96^3 apply and 49 % of the
+// 128^3 one (profiles/r04/box_step_ablations.txt).  From the blocked copy an instruction reads 1 KB of consecutive bytes, each byte once.
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void tri_box_layout_kernel(BoxView B, tw_v2* cb) {
+    constexpr int C = TB_C, NAc = FORWARD ? 13 : 14;
+    const int nbj = tb_nbj(B.Nj);
+    const int nch = (B.Ni + 29 + C - 1) / C;
+    const int blk = blockIdx.x / nch, kc = blockIdx.x % nch, J = blk % nbj, K = blk / nbj;
+    for (int idx = threadIdx.x; idx < NAc * (C / 2) * 64; idx += 256) {
+        const int lane = idx & 63, h = (idx >> 6) % (C / 2), a = idx / (64 * (C / 2));
+        const int jl = lane & 7, kl = lane >> 3, jj = 8 * J + jl - kl, kk = 8 * K + kl, skew = 2 * (jl + kl) + 1;
+        const bool ok = jj >= 0 && jj < B.Nj && kk < B.Nk;
+        const int j = FORWARD ? jj : B.Nj - 1 - jj, k = FORWARD ? kk : B.Nk - 1 - kk;
+        const int64_t base = ok ? ((int64_t)k * B.Nj + j) * B.Ni + (FORWARD ? 0 : B.Ni - 1) : 0;
+        double v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ii = kc * C + 2 * h + e - skew;
+            const bool valid = ok && ii >= 0 && ii < B.Ni;
+            const int64_t row = base + (FORWARD ? ii : -ii);
+            v[e] = valid ? (a < 13 ? B.c[(int64_t)a * B.cs + row] : B.diag[row]) : (a < 13 ? 0.0 : 1.0);
+        }
+        cb[(size_t)blockIdx.x * (NAc * (C / 2) * 64) + idx] = tw_v2{v[0], v[1]};
+    }
+}
+
 // REGULAR: every stream of the factor is either absent altogether (`present` bit clear: the term is skipped) or has an entry wherever the
 // neighbour row exists in the box -- the factors of a full 27- or 19-point stencil, Ilup(1) of a 7-point operator, ...  Then an absent entry's
 // operand is always a row OUTSIDE the box, and those are +0.0 by construction here (the poller hands +0.0 for rows outside a line, a lane
@@ -84,9 +113,7 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
     int* const ctr = (int*)(ring + R * RS);                               // staged (loader 1), staged (loader 2), taken, published, "the poller gave up"
     cgdouble* in = (cgdouble*)(in_ptr ? in_ptr : args->r);
     gdouble* out = (gdouble*)(out_ptr ? out_ptr : args->z);
-    cgdouble* cbase = (cgdouble*)B.c; cgdouble* dgp = (cgdouble*)B.diag;
     const int64_t n = B.n;
-    auto arr = [&](int a) -> cgdouble* { return a == 0 ? in : a <= 13 ? cbase + (int64_t)(a - 1) * B.cs : dgp; };
     const int wave = threadIdx.x >> 6;                                    // 0 solves, 1 and 2 load, 3 polls
     const int l = threadIdx.x & 63;
     const int nbj = tb_nbj(B.Nj), nbk = tb_nbk(B.Nk);
@@ -140,44 +167,50 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
             }
             return __all(ok);
         };
+        // coefficients and divisor: the blocked copy (tri_box_layout_kernel), element (stream, step pair, lane) of this block's chunk
+        constexpr int NAc = FORWARD ? 13 : 14;
+        cg_v2* const cb_blk = (cg_v2*)B.cb + (size_t)blk * nch * (NAc * (C / 2) * 64) + l;
         auto fetch = [&](Buf& q, int t0) {
+            cg_v2* const cbk = cb_blk + (size_t)(t0 / C) * (NAc * (C / 2) * 64);
+#pragma unroll
+            for (int a = 0; a < NA1; ++a)
+                if (a0 + a >= 1 && wanted(a))
+#pragma unroll
+                    for (int h = 0; h < C / 2; ++h) q.d[a][h] = cbk[((a0 + a - 1) * (C / 2) + h) * 64];
+            if (a0 != 0) return;
+            // the right-hand side (array 0) changes with every apply: from the vector itself, as before
             if (is_fast(t0)) {
 #pragma unroll
                 for (int r = 0; r < LPL; ++r) {
                     const int64_t lo = lok[r] ? row0[r] + (FORWARD ? t0 + 2 * c : -(t0 + C - 1) + 2 * c) : 0;
-                    const uint32_t off = (uint32_t)(8 * lo);
-#pragma unroll
-                    for (int a = 0; a < NA1; ++a)
-                        if (wanted(a)) q.d[a][r] = *(cg_v2*)tw_at(arr(a0 + a), off, 0);
+                    q.d[0][r] = *(cg_v2*)tw_at(in, (uint32_t)(8 * lo), 0);
                 }
             } else {
 #pragma unroll
                 for (int h = 0; h < C / 2; ++h) {
                     const int64_t ra = min(max(base + (FORWARD ? 1 : -1) * (int64_t)(t0 + 2 * h - skew), (int64_t)0), n - 1);
                     const int64_t rb = min(max(base + (FORWARD ? 1 : -1) * (int64_t)(t0 + 2 * h + 1 - skew), (int64_t)0), n - 1);
-#pragma unroll
-                    for (int a = 0; a < NA1; ++a)
-                        if (wanted(a)) { cgdouble* p = arr(a0 + a); q.d[a][h] = tw_v2{p[ra], p[rb]}; }
+                    q.d[0][h] = tw_v2{in[ra], in[rb]};
                 }
             }
         };
         auto publish = [&](const Buf& q, int kc) {
             for (int budget = 1 << 24; kc - tw_lds_load(taken) >= S && budget > 0; --budget) __builtin_amdgcn_s_sleep(2);   // slot still in use
             tw_v2* dst = stage + (size_t)(kc % S) * NA * (C / 2) * 64;
-            if (is_fast(kc * C)) {
-                const int h = FORWARD ? c : C / 2 - 1 - c;                // the piece's step pair (the backward solve walks rows downwards)
 #pragma unroll
-                for (int a = 0; a < NA1; ++a)
-                    if (wanted(a))
+            for (int a = 0; a < NA1; ++a)
+                if (a0 + a >= 1 && wanted(a))
 #pragma unroll
-                        for (int r = 0; r < LPL; ++r)
-                            dst[((a0 + a) * (C / 2) + h) * 64 + LPP * r + g] = FORWARD ? q.d[a][r] : tw_v2{q.d[a][r].y, q.d[a][r].x};
-            } else {
+                    for (int h = 0; h < C / 2; ++h) dst[((a0 + a) * (C / 2) + h) * 64 + l] = q.d[a][h];
+            if (a0 == 0) {
+                if (is_fast(kc * C)) {
+                    const int h = FORWARD ? c : C / 2 - 1 - c;            // the piece's step pair (the backward solve walks rows downwards)
 #pragma unroll
-                for (int a = 0; a < NA1; ++a)
-                    if (wanted(a))
+                    for (int r = 0; r < LPL; ++r) dst[h * 64 + LPP * r + g] = FORWARD ? q.d[0][r] : tw_v2{q.d[0][r].y, q.d[0][r].x};
+                } else {
 #pragma unroll
-                        for (int h = 0; h < C / 2; ++h) dst[((a0 + a) * (C / 2) + h) * 64 + l] = q.d[a][h];
+                    for (int h = 0; h < C / 2; ++h) dst[h * 64 + l] = q.d[0][h];
+                }
             }
             tw_lds_store(staged, kc + 1);
         };
