@@ -794,6 +794,13 @@ def general_ilu(K, ctx):
                        bytes_model=f"{ns} coefficient streams + divisor + 32 n (r, y read; y, z written)",
                        achieved=moved / (ms * 1e-3) / 1e9, unit="GB/s", peak=HBM_PEAK_GBS, frac=moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        hyperplanes=info["levels"][0], us_per_hyperplane=ms * 1e3 / max(1, 2 * info["levels"][0]))
+        if name == "true_ilu0_27pt_96":
+            # the preconditioner inside a solve: right-preconditioned BiCGStab to 1e-10 ||b|| (bicgstab.rs:69-293 + the labelled right-pc extension)
+            b = a_.spmv(ctx.vec(n).fill(1.0)); bn = K.norm(b)
+            dt, st = timed_solve(K, ctx, lambda: K.BiCgStabRightPcSolver(1e-10 * bn, 500), a_, pc, b)
+            blk["bicgstab_right_pc"] = {"iterations": st.iterations, "converged": bool(st.converged), "final_residual": st.final_residual, "solve_seconds": dt,
+                                        "iterations_per_s": st.iterations / dt, "spmv_encoding": a_.encoding()[0]}
+            del b
         out[name] = blk
         del pc, r, z, a_
     return out
