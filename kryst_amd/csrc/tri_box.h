@@ -10,8 +10,11 @@
 // (the neighbour finished it 1, 1, 3 and 5 steps ago: it hands over its value of that age) and keeps the two rows before it in
 // registers.  25 lines of other blocks feed the lanes on the parallelogram's left and lower sides: a poller wave reads them (NaN
 // sentinel = not written yet) into an LDS ring indexed by ROW, since up to three lanes with different skews read the same line.  Two
-// loader waves stream the right-hand side, the 13 coefficient streams and the divisor two chunks ahead into a two-slot LDS stage (the
-// solving wave copies a chunk into registers at once, which frees the slot).  No barriers after the first; every wait has a budget.
+// loader waves stream the right-hand side (from the vector) and the 13 coefficient streams and the divisor (from a BLOCKED copy laid out
+// exactly like the LDS stage: tri_box_layout_kernel) two chunks ahead into a two-slot LDS stage (the solving wave copies a chunk into
+// registers at once, which frees the slot).  No barriers after the first; every wait has a budget.  Specialisations: REGULAR (no
+// absent-entry selects), ALL (the factor has all 13 streams: no per-stream tests); a stream a factor does not have is neither staged nor
+// subtracted.
 //
 // Subtraction order: the stored (ascending column) order of the row -- forward: schedule offsets (-1,-1,-1) ... (0,0,-1) = streams 0..12;
 // backward: stream a is the schedule offset with code 12 - a.  Absent entries select a +0.0 operand (tri_wave.h).  Same bits as the
