@@ -360,25 +360,43 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
-            // row ii + 1 of the four neighbour lines
+            // row ii + 1 of the four neighbour lines: asked for here, looked at after the products that do not need them
             double r1 = tw_bperm(i1, yh0), r2 = tw_bperm(i2, yh0), r3 = tw_bperm(i3, yh2), r4 = tw_bperm(i4, yh4);
             const double* rr = ring + ((ii + 1) & (R - 1)) * RS;
             const double x1 = rr[c1], x2 = rr[c2], x3 = rr[c3], x4 = rr[c4];
+            // one term of the row: coefficient of stream a times its operand (general form, absent entry -- coefficient +0.0: the operand's
+            // high word cleared -> zero or a positive subnormal, the product is +0.0 and s unchanged, whatever the operand was)
+            auto product = [&](int a, double x) -> double {
+                const double cf = q.v[1 + a][u];
+                if (!REGULAR) x = __hiloint2double(cf != 0.0 ? __double2hiint(x) : 0, __double2loint(x));
+                return cf * x;
+            };
+            // operands by schedule offset code 9 (dk + 1) + 3 (dj + 1) + (di + 1); codes 2, 5, 8, 11 arrive this step
+            const double old_dep[13] = {p4b, p4a, 0.0, p3b, p3a, 0.0, p2b, p2a, 0.0, p1b, p1a, 0.0, yh0};
+            double pr[13];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 13; ++a) {                                // the nine products of operands this lane already holds
+                const int code = FORWARD ? a : 12 - a;
+                if (code != 2 && code != 5 && code != 8 && code != 11) pr[a] = product(a, old_dep[code]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             r1 = e1 >= 0 ? x1 : r1; r2 = e2 >= 0 ? x2 : r2; r3 = e3 >= 0 ? x3 : r3; r4 = e4 >= 0 ? x4 : r4;
-            // operands by schedule offset code 9 (dk + 1) + 3 (dj + 1) + (di + 1)
-            const double dep[13] = {p4b, p4a, r4, p3b, p3a, r3, p2b, p2a, r2, p1b, p1a, r1, yh0};
+#pragma unroll
+            for (int a = 0; a < 13; ++a) {                                // the four that wait for the arrivals
+                const int code = FORWARD ? a : 12 - a;
+                if (code == 2) pr[a] = product(a, r4);
+                if (code == 5) pr[a] = product(a, r3);
+                if (code == 8) pr[a] = product(a, r2);
+                if (code == 11) pr[a] = product(a, r1);
+            }
             double s = q.v[0][u];
 #pragma unroll
-            for (int a = 0; a < 13; ++a) {
+            for (int a = 0; a < 13; ++a) {                                // subtracted in the stored order
                 // (uniform: a stream the factor does not have is not staged either.  The compiler turns the skip into two selects per term; forced
                 // to be a branch it was slower -- Ilup(1) of the 7-point operator on 128^3, 6 of 13 streams: 0.96 ms with selects, 1.12 with branches)
                 if (!ALL && !((present >> a) & 1u)) continue;
-                const double cf = q.v[1 + a][u];
-                double x = dep[FORWARD ? a : 12 - a];
-                // general form, absent entry (coefficient +0.0): the operand's high word cleared -> zero or a positive subnormal, the product is
-                // +0.0 and s unchanged, whatever the operand was (one select instead of tri_wave.h's two)
-                if (!REGULAR) x = __hiloint2double(cf != 0.0 ? __double2hiint(x) : 0, __double2loint(x));
-                s = s - cf * x;
+                s = s - pr[a];
             }
             if (!FORWARD) s = s / q.v[NA - 1][u];
             if (REGULAR) s = act ? s : 0.0;                               // a row outside the box: +0.0 for whoever reads it
