@@ -102,7 +102,9 @@ __global__ __launch_bounds__(256) void tri_box_layout_kernel(BoxView B, tw_v2* c
 // are not needed.  A factor with entries missing in the interior (dropped couplings, values that cancelled to zero) takes REGULAR = false.
 // ALL: the factor has all 13 streams (`present` == 0x1fff): no per-stream tests anywhere ("skip this term" costs two selects per term ON the
 // dependent chain of s, present or not: 0.39 -> 0.32 us per step without them).
-template <bool FORWARD, bool REGULAR, bool ALL>
+// MASK: the factor's streams when known at compile time -- 0x1fff (ALL), the two patterns Ilup(1) makes of a 7-point operator (lower 0x1cb0,
+// upper 0x01a7) -- or 0: the launch's `present` decides at run time (selects).
+template <bool FORWARD, bool REGULAR, uint32_t MASK>
 __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, BoxView B, int32_t* flags, int32_t* abort_word,
                                                       int32_t* gave_up, int poll_budget, uint32_t present) {
     if (args->skip) return;
@@ -117,6 +119,8 @@ __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const
     cgdouble* in = (cgdouble*)(in_ptr ? in_ptr : args->r);
     gdouble* out = (gdouble*)(out_ptr ? out_ptr : args->z);
     const int64_t n = B.n;
+    constexpr bool ALL = MASK == 0x1fffu;
+    if (MASK != 0) present = MASK;                                        // (compile-time streams: every test on `present` folds away)
     const int wave = threadIdx.x >> 6;                                    // 0 solves, 1 and 2 load, 3 polls
     const int l = threadIdx.x & 63;
     const int nbj = tb_nbj(B.Nj), nbk = tb_nbk(B.Nk);
