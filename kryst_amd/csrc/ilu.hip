@@ -691,14 +691,16 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D, const TriDirect* direct 
             const int budget = std::max(1, env_int("KRYST_ILU_POLL_BUDGET", 1 << 22));
             hipLaunchKernelGGL((tri_box_fill_kernel<true>), dim3(nb), dim3(256), 0, s, D->d_args, D->d_y, VA, D->d_flags, (int32_t)(2 * nb));
             const bool reg = A.regular && B.regular && env_int("KRYST_ILU_BOX_REGULAR", 1) != 0;
-            // streams known at compile time: all 13, or Ilup(1)'s pattern on a 7-point operator (lower 0x1cb0 / upper 0x01a7); otherwise run-time tests
+            // streams known at compile time: all 13 (27-point), a 19-point stencil's (lower 0x1eba / upper 0x0baf), Ilup(1)'s on a 7-point operator
+            // (0x1cb0 / 0x01a7); any other set: run-time tests
             auto launch = [&](auto fwd, const BoxView& V, const double* in, double* out, int32_t* fl, uint32_t present) {
                 constexpr bool F = decltype(fwd)::value;
-                constexpr uint32_t FILL1 = F ? 0x1cb0u : 0x01a7u;
+                constexpr uint32_t FILL1 = F ? 0x1cb0u : 0x01a7u, P19 = F ? 0x1ebau : 0x0bafu;
                 const size_t lds = tb_lds_bytes<F>();
 #define KR_BOX_LAUNCH(R, M) hipLaunchKernelGGL((tri_box_kernel<F, R, M>), dim3(nb), dim3(256), lds, s, D->d_args, in, out, V, fl, D->d_flags + 2 * nb, D->d_gave_up, budget, present)
                 if (present == 0x1fffu) { if (reg) KR_BOX_LAUNCH(true, 0x1fffu); else KR_BOX_LAUNCH(false, 0x1fffu); }
                 else if (present == FILL1) { if (reg) KR_BOX_LAUNCH(true, FILL1); else KR_BOX_LAUNCH(false, FILL1); }
+                else if (present == P19) { if (reg) KR_BOX_LAUNCH(true, P19); else KR_BOX_LAUNCH(false, P19); }
                 else { if (reg) KR_BOX_LAUNCH(true, 0u); else KR_BOX_LAUNCH(false, 0u); }
 #undef KR_BOX_LAUNCH
             };
@@ -1182,6 +1184,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
             // 70 / 73 KiB of LDS per workgroup (two per CU): more than the 64 KiB a kernel gets without asking
             bool ok = true;
 #define KR_BOX_ATTR(F, R, M) ok = ok && hipFuncSetAttribute((const void*)tri_box_kernel<F, R, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb_lds_bytes<F>()) == hipSuccess
+            KR_BOX_ATTR(true, true, 0x1ebau); KR_BOX_ATTR(true, false, 0x1ebau); KR_BOX_ATTR(false, true, 0x0bafu); KR_BOX_ATTR(false, false, 0x0bafu);
             KR_BOX_ATTR(true, true, 0x1fffu); KR_BOX_ATTR(true, true, 0x1cb0u); KR_BOX_ATTR(true, true, 0u); KR_BOX_ATTR(true, false, 0x1fffu); KR_BOX_ATTR(true, false, 0x1cb0u); KR_BOX_ATTR(true, false, 0u);
             KR_BOX_ATTR(false, true, 0x1fffu); KR_BOX_ATTR(false, true, 0x01a7u); KR_BOX_ATTR(false, true, 0u); KR_BOX_ATTR(false, false, 0x1fffu); KR_BOX_ATTR(false, false, 0x01a7u); KR_BOX_ATTR(false, false, 0u);
 #undef KR_BOX_ATTR

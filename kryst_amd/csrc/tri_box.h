@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void tri_box_layout_kernel(BoxView B, tw_v2* c
 // are not needed.  A factor with entries missing in the interior (dropped couplings, values that cancelled to zero) takes REGULAR = false.
 // ALL: the factor has all 13 streams (`present` == 0x1fff): no per-stream tests anywhere ("skip this term" costs two selects per term ON the
 // dependent chain of s, present or not: 0.39 -> 0.32 us per step without them).
-// MASK: the factor's streams when known at compile time -- 0x1fff (ALL), the two patterns Ilup(1) makes of a 7-point operator (lower 0x1cb0,
-// upper 0x01a7) -- or 0: the launch's `present` decides at run time (selects).
+// MASK: the factor's streams when known at compile time -- 0x1fff (ALL), a 19-point stencil's (lower 0x1eba, upper 0x0baf), the two patterns
+// Ilup(1) makes of a 7-point operator (0x1cb0, 0x01a7) -- or 0: the launch's `present` decides at run time (selects).
 template <bool FORWARD, bool REGULAR, uint32_t MASK>
 __global__ __launch_bounds__(256) void tri_box_kernel(const TriArgs* args, const double* in_ptr, double* out_ptr, BoxView B, int32_t* flags, int32_t* abort_word,
                                                       int32_t* gave_up, int poll_budget, uint32_t present) {

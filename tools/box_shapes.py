@@ -11,7 +11,25 @@ shapes = [tuple(int(v) for v in s.split("x")) for s in (sys.argv[1] if len(sys.a
 ctx = K.Context(0)
 
 
+P19 = len(sys.argv) > 2 and sys.argv[2] == "19"      # second argument "19": the 19-point stencil (no corner couplings)
+
+
 def stencil27(Ni, Nj, Nk):
+    if P19:
+        n = Ni * Nj * Nk
+        idx = np.arange(n); i, j, k = idx % Ni, (idx // Ni) % Nj, idx // (Ni * Nj)
+        rows, cols = [idx], [idx]
+        for dk in (-1, 0, 1):
+            for dj in (-1, 0, 1):
+                for di in (-1, 0, 1):
+                    if (dk, dj, di) == (0, 0, 0) or abs(dk) + abs(dj) + abs(di) > 2:
+                        continue
+                    ok = (i + di >= 0) & (i + di < Ni) & (j + dj >= 0) & (j + dj < Nj) & (k + dk >= 0) & (k + dk < Nk)
+                    rows.append(idx[ok]); cols.append(idx[ok] + di + Ni * dj + Ni * Nj * dk)
+        rows, cols = np.concatenate(rows), np.concatenate(cols)
+        m = sp.csr_matrix((np.where(rows == cols, 20.0, -1.0), (rows, cols)), shape=(n, n))
+        m.sort_indices()
+        return m
     t = lambda N: sp.diags([np.ones(N - 1), np.ones(N), np.ones(N - 1)], [-1, 0, 1]) if N > 1 else sp.identity(1)
     full = sp.kron(t(Nk), sp.kron(t(Nj), t(Ni))).tocsr()
     m = (sp.identity(Ni * Nj * Nk) * 28.0 - full).tocsr()
