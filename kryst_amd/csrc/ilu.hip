@@ -1675,6 +1675,31 @@ __global__ __launch_bounds__(256) void gen_classify_kernel(const int32_t* __rest
     nl[i] = a; nu[i] = b; dg[i] = d;
 }
 // one factor in level order: position p holds row rowid[p]; its kept entries in stored order, columns as positions
+// Is every off-diagonal entry of a (candidate) box operator the coupling to a neighbour inside the 3 x 3 x 3 cube of an Ni x Nj x Nk box, columns
+// ascending?  Then the hyperplanes i + 2 j + 4 k are a valid elimination order (every lower entry lies on an earlier plane), and the set-up
+// needs neither the pattern on the host nor its level sweeps: box_plane_hist_kernel / box_plane_order_kernel sort the rows by plane on the device.
+__global__ __launch_bounds__(256) void box_check_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, int32_t n, int32_t Ni, int32_t Nj, int32_t* bad) {
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t ii = i % Ni, jj = (i / Ni) % Nj, kk = i / (Ni * Nj);
+    int32_t prev = -1;
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+        const int32_t j = col[k];
+        if (j >= n || j <= prev) { *bad = 1; return; }
+        prev = j;
+        const int di = j % Ni - ii, dj = (j / Ni) % Nj - jj, dk = j / (Ni * Nj) - kk;
+        if (di < -1 || di > 1 || dj < -1 || dj > 1 || dk < -1 || dk > 1) { *bad = 1; return; }
+    }
+}
+__global__ __launch_bounds__(256) void box_plane_hist_kernel(int32_t n, int32_t Ni, int32_t Nj, int32_t* hist) {
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&hist[i % Ni + 2 * ((i / Ni) % Nj) + 4 * (i / (Ni * Nj))], 1);
+}
+__global__ __launch_bounds__(256) void box_plane_order_kernel(int32_t n, int32_t Ni, int32_t Nj, int32_t* cursor, int32_t* order) {
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) order[atomicAdd(&cursor[i % Ni + 2 * ((i / Ni) % Nj) + 4 * (i / (Ni * Nj))], 1)] = i;
+}
+
 // Box-stencil factors straight from the factor values on A's pattern (round 4): stream a of row i = the entry whose column is the
 // (dk, dj, di) neighbour of (i, j, k) in the Ni x Nj x Nk box -- BoxFactor's layout; `bad` is raised by an entry that is no such neighbour
 // (it wraps around a line or plane end), a halo column, or a row whose columns do not ascend.  Zero values stay +0.0 = no entry.
@@ -1807,8 +1832,37 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
     KR_HIP(hipMemcpyAsync(hf, t.flags, sizeof hf, hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
     if ((int32_t)hf[2] > 64) return KRYST_OK;                               // a row must fit one wave's LDS slice
+    // ---- a box operator whose every entry is a neighbour inside the cube: rows sorted by hyperplane on the device, no pattern on the host
+    bool plane_order = false;
+    if (box_ni > 0) {
+        const int32_t Ni = (int32_t)box_ni, Nj = (int32_t)box_nj, Nk = (int32_t)(n64 / (box_ni * box_nj));
+        const int32_t H = Ni + 2 * Nj + 4 * Nk;
+        int32_t* d_hist = nullptr; int32_t bad = 1;
+        int32_t* d_bad = reinterpret_cast<int32_t*>(t.flags + 4);
+        std::vector<int32_t> hist((size_t)H + 1, 0);
+        if (hipMalloc(&d_hist, sizeof(int32_t) * ((size_t)H + 1)) == hipSuccess && hipMemsetAsync(d_hist, 0, sizeof(int32_t) * ((size_t)H + 1), ctx->s_main) == hipSuccess) {
+            hipLaunchKernelGGL(box_check_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, n, Ni, Nj, d_bad);
+            hipLaunchKernelGGL(box_plane_hist_kernel, dim3(g), dim3(256), 0, ctx->s_main, n, Ni, Nj, d_hist);
+            if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->s_main) == hipSuccess &&
+                hipMemcpyAsync(hist.data(), d_hist, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, ctx->s_main) == hipSuccess &&
+                hipStreamSynchronize(ctx->s_main) == hipSuccess && bad == 0) {
+                int32_t run = 0;
+                for (int32_t h = 0; h < H; ++h) { const int32_t c = hist[(size_t)h]; hist[(size_t)h] = run; run += c; }      // exclusive scan: the planes' first positions
+                if (run == n && hipMemcpyAsync(d_hist, hist.data(), sizeof(int32_t) * (size_t)H, hipMemcpyHostToDevice, ctx->s_main) == hipSuccess) {
+                    hipLaunchKernelGGL(box_plane_order_kernel, dim3(g), dim3(256), 0, ctx->s_main, n, Ni, Nj, d_hist, t.order);
+                    plane_order = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->s_main) == hipSuccess;
+                }
+            }
+        }
+        (void)hipGetLastError();
+        (void)hipFree(d_hist);
+        if (!plane_order) box_ni = 0;                                         // not (provably) a box operator: the general path below
+        else lap("box operator checked, rows sorted by hyperplane");
+    }
     // ---- the pattern on the host: levels of the lower / upper pattern, local entries per row
-    std::vector<int32_t> hrp((size_t)n + 1), hcol((size_t)nnz), lvl((size_t)n), lvlU((size_t)n), cntL((size_t)n), cntU((size_t)n), rowid, pos, lvl_off;
+    std::vector<int32_t> hrp, hcol, lvl, lvlU, cntL, cntU, rowid, pos, lvl_off;
+    if (!plane_order) {
+    hrp.resize((size_t)n + 1); hcol.resize((size_t)nnz); lvl.resize((size_t)n); lvlU.resize((size_t)n); cntL.resize((size_t)n); cntU.resize((size_t)n);
     KR_HIP(hipMemcpyAsync(hrp.data(), a->d_row_ptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipMemcpyAsync(hcol.data(), a->d_col, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
@@ -1823,10 +1877,13 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         lvlU[i] = lv; cntU[i] = c;
     }
     lap("pattern to the host, levels");
+    }
     // ---- factor values
     if (mode == KRYST_ILU_TRUE_ILU0) {
-        rows_by_level(lvl, rowid, pos, lvl_off);
-        KR_HIP(hipMemcpyAsync(t.order, rowid.data(), nb, hipMemcpyHostToDevice, ctx->s_main));
+        if (!plane_order) {
+            rows_by_level(lvl, rowid, pos, lvl_off);
+            KR_HIP(hipMemcpyAsync(t.order, rowid.data(), nb, hipMemcpyHostToDevice, ctx->s_main));
+        }
         hipLaunchKernelGGL(ilu0_ikj_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dpos, t.order, n, t.done,
                            t.flags, d_stalled, budget);
     } else {
@@ -1885,6 +1942,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
             return KRYST_OK;
         }
         D->BL.free_all(); D->BU.free_all(); D->BL = BoxFactor(); D->BU = BoxFactor();       // not a box operator after all: the level-ordered forms
+        if (plane_order) { kryst_pc_destroy(pc); return KRYST_OK; }                           // (no pattern on the host to level-order from: the host path)
     }
     if (nl != cntL || nu != cntU) { kryst_pc_destroy(pc); return KRYST_OK; }
     // ---- the two level-ordered factors
