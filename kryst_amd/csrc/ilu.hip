@@ -2185,12 +2185,12 @@ static int32_t ilup_setup(kryst_csr_t a, int32_t fill, kryst_pc_t* out) {
     std::vector<long long> bad_col;                                        // ... and that j, per thread
     const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     const unsigned T = (unsigned)std::max(1, std::min<int>((int)hw, env_int("KRYST_ILUP_THREADS", n < 4096 ? 1 : (int)hw)));
-    // Blocks of 1 024 rows: on a grid with lines of 128 rows that is 8 lines, and row i's pivot rows i - 1, i - Ni (+ 1), i - Ni Nj (+ 1, + Ni)
+    // Blocks of 2 048 rows (measured at 128^3, 16 threads: 512 rows 197 ms, 1 024 110, 2 048 89, 4 096 90): on a grid with lines of 128 rows that is 16 lines, and row i's pivot rows i - 1, i - Ni (+ 1), i - Ni Nj (+ 1, + Ni)
     // are the thread's own except along the block's first line -- a pivot row finished by another core costs a few cache-line
     // transfers (0.2 - 1 us each on the two-socket hosts of the GPU boxes; blocks of 8 rows, tried first, were 3 x SLOWER than one thread).
     // A thread publishes its finished rows 16 at a time (and before it waits itself): one flag byte per row, so a consumer walking a
     // line behind its producer takes the flags' cache line once per batch, not once per row.
-    const int64_t B = std::max(1, env_int("KRYST_ILUP_BLOCK", 1024)), nblocks = (n + B - 1) / B;
+    const int64_t B = std::max(1, env_int("KRYST_ILUP_BLOCK", 2048)), nblocks = (n + B - 1) / B;
     std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[(size_t)n + 64]);
     par_rows(n, [&](int64_t lo, int64_t hi) { for (int64_t r = lo; r < hi; ++r) done[(size_t)r].store(0, std::memory_order_relaxed); });
     bad_col.assign(T, -1);
