@@ -1876,15 +1876,20 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
     KR_HIP(hipMemcpyAsync(hrp.data(), a->d_row_ptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipMemcpyAsync(hcol.data(), a->d_col, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
-    for (int32_t i = 0; i < n; ++i) {
-        int32_t lv = 0, c = 0;
-        for (int32_t k = hrp[i]; k < hrp[i + 1]; ++k) { const int32_t j = hcol[k]; if (j < i) { lv = std::max(lv, lvl[j] + 1); ++c; } }
-        lvl[i] = lv; cntL[i] = c;
-    }
-    for (int32_t i = n - 1; i >= 0; --i) {
-        int32_t lv = 0, c = 0;
-        for (int32_t k = hrp[i]; k < hrp[i + 1]; ++k) { const int32_t j = hcol[k]; if (j > i && j < n) { lv = std::max(lv, lvlU[j] + 1); ++c; } }
-        lvlU[i] = lv; cntU[i] = c;
+    {   // the two sweeps do not touch each other's arrays: side by side
+        std::thread upper([&] {
+            for (int32_t i = n - 1; i >= 0; --i) {
+                int32_t lv = 0, c = 0;
+                for (int32_t k = hrp[i]; k < hrp[i + 1]; ++k) { const int32_t j = hcol[k]; if (j > i && j < n) { lv = std::max(lv, lvlU[j] + 1); ++c; } }
+                lvlU[i] = lv; cntU[i] = c;
+            }
+        });
+        for (int32_t i = 0; i < n; ++i) {
+            int32_t lv = 0, c = 0;
+            for (int32_t k = hrp[i]; k < hrp[i + 1]; ++k) { const int32_t j = hcol[k]; if (j < i) { lv = std::max(lv, lvl[j] + 1); ++c; } }
+            lvl[i] = lv; cntL[i] = c;
+        }
+        upper.join();
     }
     lap("pattern to the host, levels");
     }
