@@ -1510,6 +1510,28 @@ def test_ilup_level_of_fill_bit_exact(ctx, rs, fill):
     _check_solver(res, s.solve(dev, K.Ilup(fill).setup(dev), b, x), s, x)
 
 
+@pytest.mark.parametrize("threads,block", [(4, 8), (16, 32), (3, 1), (16, 2048)])
+def test_ilup_row_pipeline_over_host_threads_bit_exact(ctx, threads, block, monkeypatch):
+    """Ilup(p >= 1) is eliminated by a pipeline of host threads (round 4: rows dealt out in blocks, a thread waits on a per-row flag before it uses
+    another thread's pivot row).  Small operators take one thread by default; here the pipeline is forced onto them with blocks of 1 .. 32 rows,
+    so that nearly every pivot row is another thread's -- against the oracle's dense algorithm (ilup.rs:77-167) bit for bit, fill 1 .. 3, on
+    stencils, a random sparse matrix and one with stored zeros and cancellations; and at 40^3 the 16-thread result against the one-thread one."""
+    monkeypatch.setenv("KRYST_ILUP_THREADS", str(threads))
+    monkeypatch.setenv("KRYST_ILUP_BLOCK", str(block))
+    rng = np.random.default_rng(77)
+    d = rng.random((90, 90)) * (rng.random((90, 90)) < 0.1) + np.diag(4.0 + rng.random(90))
+    z = np.array(O.stencil7(5, "poisson").to_dense()); z[z == -1.0] = np.where(rng.random((z == -1.0).sum()) < 0.3, 0.0, -1.0)   # zeros: entries that never take part
+    for a in (O.stencil7(9, "convdiff"), O.stencil7(8, "poisson"), O.Csr.from_dense(d, keep_zeros=False), O.Csr.from_dense(z, keep_zeros=False)):
+        for fill in (1, 2, 3):
+            r = rng.standard_normal(a.nrows)
+            assert np.array_equal(K.Ilup(fill).setup(to_dev(ctx, a)).apply(r), O.Pc.ilup(a, fill).apply(r)), (threads, block, fill, a.nrows)
+    big = K.CsrMatrix.stencil7(40, "aniso", ctx=ctx)
+    r = np.random.default_rng(3).standard_normal(big.nrows())
+    got = K.Ilup(1).setup(big).apply(r)
+    monkeypatch.setenv("KRYST_ILUP_THREADS", "1")
+    assert np.array_equal(got, K.Ilup(1).setup(big).apply(r)), (threads, block)
+
+
 @pytest.mark.parametrize("fill,droptol", [(7, 1e-12), (3, 1e-12), (4, 0.6), (1, 0.0), (0, 0.0)])
 def test_ilut_bit_exact(ctx, rs, fill, droptol):
     """Ilut::new(fill, droptol) (ilut.rs:80-150): rows truncated to the `fill` largest entries keep their sorted
