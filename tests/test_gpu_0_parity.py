@@ -1542,6 +1542,10 @@ def test_ilut_bit_exact(ctx, rs, fill, droptol):
         r = rng.standard_normal(a.nrows)
         z = K.Ilut(fill, droptol).setup(to_dev(ctx, a)).apply(r)
         assert np.array_equal(z, O.Pc.ilut(a, fill, droptol).apply(r)), (fill, droptol, a.nrows)
+    if fill == 4:                                                   # 110 592 rows: the set-up's row loops run on all host cores (round 4)
+        big = O.stencil7(48, "aniso")
+        r = rng.standard_normal(big.nrows)
+        assert np.array_equal(K.Ilut(fill, 1e-3).setup(to_dev(ctx, big)).apply(r), O.Pc.ilut(big, fill, 1e-3).apply(r))
     # reference tests ilut.rs:185-211
     ident = to_dev(ctx, O.Csr.from_dense([[1.0, 0.0], [0.0, 1.0]]))
     assert np.array_equal(K.Ilut(2, 1e-12).setup(ident).apply(np.array([2.0, 3.0])), [2.0, 3.0])
