@@ -1,5 +1,8 @@
 // RCCL binding + halo planning.  Compiled with hipcc (host code only).
 #include "dist.h"
+#include <map>
+#include <array>
+#include <mutex>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <algorithm>
@@ -115,11 +118,40 @@ int32_t comm_exchange(kryst_ctx_t ctx, const void* send, const int64_t* send_cou
 // ---- scalar all-reduce through IPC-mapped mailboxes (replaces the two tiny RCCL all-gathers of a CG iteration: Comm::all_reduce,
 // src/parallel/mpi_comm.rs:116-121 / DistributedInnerProduct, src/core/wrappers.rs:134-156)
 void ipc_reduce_destroy(kryst_ctx_t ctx) {
-    for (void* p : ctx->ipc_opened) (void)hipIpcCloseMemHandle(p);
+    for (void* p : ctx->ipc_opened) ipc_close_shared(p);
     ctx->ipc_opened.clear();
     (void)hipFree(ctx->ipc_mine); (void)hipFree(ctx->d_ipc_peers); (void)hipFree(ctx->d_ipc_epoch);
     ctx->ipc_mine = nullptr; ctx->d_ipc_peers = nullptr; ctx->d_ipc_epoch = nullptr; ctx->ipc_on = false;
     (void)hipGetLastError();
+}
+
+// hipIpcOpenMemHandle / hipIpcCloseMemHandle, once per handle and PROCESS: two ranks of one process (rank threads) both want their common
+// peers' buffers, and a second open of a handle the process already holds -- or two opens of it at the same moment -- is not something the
+// runtime promises to survive (seen on one box in four: the mailbox set-up of the 4 x 2 rehearsal fell back to RCCL now and then).  The
+// mappings are shared and counted; the last close unmaps.
+namespace {
+struct IpcShared { void* ptr; int refs; };
+std::mutex g_ipc_mu;
+std::map<std::array<char, 68>, IpcShared> g_ipc_open;               // key: the handle and the device it was opened on
+}  // namespace
+hipError_t ipc_open_shared(void** ptr, const hipIpcMemHandle_t& h) {
+    std::array<char, 68> key; memcpy(key.data(), &h, 64);
+    int dev = -1; (void)hipGetDevice(&dev); memcpy(key.data() + 64, &dev, 4);
+    std::lock_guard<std::mutex> g(g_ipc_mu);
+    auto it = g_ipc_open.find(key);
+    if (it != g_ipc_open.end()) { ++it->second.refs; *ptr = it->second.ptr; return hipSuccess; }
+    const hipError_t e = hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) g_ipc_open.emplace(key, IpcShared{*ptr, 1});
+    return e;
+}
+void ipc_close_shared(void* ptr) {
+    std::lock_guard<std::mutex> g(g_ipc_mu);
+    for (auto it = g_ipc_open.begin(); it != g_ipc_open.end(); ++it)
+        if (it->second.ptr == ptr) {
+            if (--it->second.refs == 0) { (void)hipIpcCloseMemHandle(ptr); g_ipc_open.erase(it); }
+            return;
+        }
+    (void)hipIpcCloseMemHandle(ptr);                                  // (not one of ours)
 }
 
 // Map one allocation of every rank into this process: `mine` (device memory of this rank, fine-grained when peers write it with
@@ -140,7 +172,9 @@ int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, st
     memset(&hmine, 0, sizeof hmine);
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
     int64_t ok_mine = mine != nullptr ? 1 : 0;
-    if (ok_mine && hipIpcGetMemHandle(&hmine, mine) != hipSuccess) { (void)hipGetLastError(); ok_mine = 0; }
+    const char* why = "";
+    if (!ok_mine) why = "no buffer to export";
+    if (ok_mine) { const hipError_t e = hipIpcGetMemHandle(&hmine, mine); if (e != hipSuccess) { (void)hipGetLastError(); ok_mine = 0; why = hipGetErrorString(e); set_error("hipIpcGetMemHandle: %s", why); } }
     send[0] = ok_mine; send[1] = (int64_t)getpid(); send[2] = ctx->device; send[3] = (int64_t)(uintptr_t)mine; memcpy(send + 4, &hmine, 64);
     std::vector<int64_t> all((size_t)W * P, 0);
     int64_t *d_s = nullptr, *d_r = nullptr;
@@ -153,7 +187,7 @@ int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, st
     (void)hipFree(d_s); (void)hipFree(d_r);
     if (rc != KRYST_OK) return rc;                                   // (a failing collective fails on every rank)
     int64_t ok_all = 1;
-    for (int p = 0; p < P; ++p) ok_all = ok_all && all[(size_t)W * p] == 1;
+    for (int p = 0; p < P; ++p) { if (all[(size_t)W * p] != 1 && getenv("KRYST_IPC_DEBUG")) fprintf(stderr, "[kryst] rank %d: rank %d could not export its buffer\n", me, p); ok_all = ok_all && all[(size_t)W * p] == 1; }
     peers.assign((size_t)P, nullptr);
     const size_t opened_before = opened.size();
     for (int p = 0; p < P && ok_all; ++p) {
@@ -174,7 +208,7 @@ int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, st
         }
         hipIpcMemHandle_t h; memcpy(&h, w + 4, 64);
         void* ptr = nullptr;
-        if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok_all = 0; break; }
+        { const hipError_t e = ipc_open_shared(&ptr, h); if (e != hipSuccess) { (void)hipGetLastError(); ok_all = 0; fprintf(stderr, "[kryst] rank %d: hipIpcOpenMemHandle of rank %d's buffer: %s\n", me, p, hipGetErrorString(e)); break; } }
         opened.push_back(ptr);
         peers[p] = ptr;
     }
@@ -190,7 +224,7 @@ int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, st
     bool everybody = rc == KRYST_OK;
     for (int p = 0; p < P && everybody; ++p) everybody = all2[p] == 1;
     if (!everybody) {
-        while (opened.size() > opened_before) { (void)hipIpcCloseMemHandle(opened.back()); opened.pop_back(); }
+        while (opened.size() > opened_before) { ipc_close_shared(opened.back()); opened.pop_back(); }
         (void)hipGetLastError();
         peers.assign((size_t)P, nullptr);
         if (rc != KRYST_OK) return rc;
@@ -210,7 +244,9 @@ int32_t ipc_reduce_setup(kryst_ctx_t ctx) {
     const size_t cells = (size_t)2 * P * 16;
     // local: mailbox in fine-grained device memory (coherent for the peers' system-scope stores), zeroed; a rank that fails here still
     // takes part in the collective mapping below, which then fails on every rank alike
-    if (hipExtMallocWithFlags((void**)&ctx->ipc_mine, sizeof(double) * cells, hipDeviceMallocFinegrained) != hipSuccess ||
+    // (2 MiB although 2 KB would do: small allocations of one process are carved out of one underlying buffer, and a peer that opens the handles of
+    // two such pieces -- the mailboxes of two rank threads of one process -- gets "invalid device pointer" for the second, now and then)
+    if (hipExtMallocWithFlags((void**)&ctx->ipc_mine, std::max<size_t>(sizeof(double) * cells, (size_t)2 << 20), hipDeviceMallocFinegrained) != hipSuccess ||
         hipMemsetAsync(ctx->ipc_mine, 0, sizeof(double) * cells, ctx->s_main) != hipSuccess ||
         hipMalloc(&ctx->d_ipc_peers, sizeof(double*) * P) != hipSuccess || hipMalloc(&ctx->d_ipc_epoch, 8) != hipSuccess ||
         hipMemsetAsync(ctx->d_ipc_epoch, 0, 8, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) {

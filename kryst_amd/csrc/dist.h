@@ -22,6 +22,7 @@ int32_t comm_exchange(kryst_ctx_t ctx, const void* send, const int64_t* send_cou
 int32_t ipc_reduce_setup(kryst_ctx_t ctx);
 // one allocation of every rank mapped into this process (hipIpc between processes, directly between ranks of one process); collective,
 // agreed outcome (KRYST_OK everywhere or KRYST_UNSUPPORTED everywhere); `opened` collects the mappings to close with hipIpcCloseMemHandle
+void ipc_close_shared(void* ptr);                       // closes a mapping ipc_map_peers opened (shared between the ranks of a process, counted)
 int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, std::vector<void*>& opened, bool same_device_siblings);
 void    ipc_reduce_destroy(kryst_ctx_t ctx);
 

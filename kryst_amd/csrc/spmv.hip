@@ -1141,7 +1141,7 @@ __global__ void halo_landing_init_kernel(double* landing, int64_t count) {
 
 void halo_peer_destroy(kryst_csr_t a) {
     HaloPeer& hp = a->plan.peer;
-    for (void* q : hp.opened) (void)hipIpcCloseMemHandle(q);
+    for (void* q : hp.opened) ipc_close_shared(q);
     hp.opened.clear();
     (void)hipFree(hp.landing); (void)hipFree(hp.d_push); (void)hipFree(hp.d_pull); (void)hipFree(hp.d_ticket);
     hp.landing = nullptr; hp.d_push = nullptr; hp.d_pull = nullptr; hp.d_ticket = nullptr; hp.on = false;
@@ -1168,7 +1168,7 @@ int32_t halo_peer_setup(kryst_csr_t a) {
     // (everything this rank allocates is allocated BEFORE the collectives: a rank that fails alone afterwards would leave the others switched on)
     if (!mutual || hipMalloc(&hp.d_push, sizeof(HaloPushSeg) * ((size_t)P + 1)) != hipSuccess || hipMalloc(&hp.d_pull, sizeof(HaloPullSeg) * ((size_t)P + 1)) != hipSuccess ||
         hipMalloc(&hp.d_ticket, 64) != hipSuccess || hipMemsetAsync(hp.d_ticket, 0, 64, ctx->s_main) != hipSuccess ||
-        hipExtMallocWithFlags((void**)&hp.landing, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        hipExtMallocWithFlags((void**)&hp.landing, std::max<size_t>(bytes, (size_t)2 << 20), hipDeviceMallocFinegrained) != hipSuccess) {   // (an allocation of its own: dist.cpp, ipc_reduce_setup)
         (void)hipGetLastError();
         (void)hipFree(hp.landing); hp.landing = nullptr;
     }

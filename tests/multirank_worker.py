@@ -171,6 +171,9 @@ def run_rank(rank, P, outdir, N, kind):
     stage(rank, "scalar_reduce ipc")
     mode = ctx.scalar_reduce("ipc")
     out["ipc_active"] = np.array([1 if mode == "ipc" else 0])
+    if mode != "ipc":
+        from kryst_amd._ffi import lib as _lib
+        print(f"[rank {rank}] scalar_reduce('ipc') fell back to {mode}: {_lib().kryst_hip_last_error().decode()}", flush=True)
     if mode == "ipc":
         for name, s, pc in runs + extra:
             stage(rank, "ipc solve " + name)

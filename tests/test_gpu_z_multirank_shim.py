@@ -67,7 +67,8 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
         f"---- rank {r}: exit code {p.returncode}, log tail ----\n{o[-3000:]}" for r, (p, o) in enumerate(zip(procs, outs)))
     R = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(P)]
     # the worker repeated every solve on the IPC-mailbox path of the scalar all-reduce and compared it with the RCCL path itself
-    assert all(int(r["ipc_active"][0]) == 1 for r in R), "the hipIpc mailbox path could not be set up between the ranks of this box"
+    assert all(int(r["ipc_active"][0]) == 1 for r in R), "the hipIpc mailbox path could not be set up between the ranks of this box:\n" + "\n".join(
+        line for o in outs for line in o.splitlines() if "fell back" in line or "[kryst]" in line)
     # ... and with the halo exchange by direct peer stores (kryst_csr_halo_mode), alone and together with the mailboxes
     # (not between rank THREADS that share the device -- refused by design, see dist.cpp: ipc_map_peers -- the 5-process cases cover more ranks)
     assert all(int(r["peer_active"][0]) == (0 if per > 1 else 1) for r in R), "the peer-store halo exchange could not be set up between the ranks of this box"
