@@ -51,22 +51,51 @@ static void par_rows(int64_t n, F body) {
 // Host arrays of the setup paths (hundreds of MB on a 128^3 operator): elements are NOT value-initialised (a std::vector zeroes what the
 // next loop overwrites, on one thread), and blocks of 4 MiB and more are 2 MiB-aligned with a huge-page hint -- first-touch page faults
 // and the unmapping at the end were a quarter of the Ilup(1) setup (round 4).
+// Big blocks are not given back to the OS but kept (KRYST_HOST_POOL_MB, default 2048; 0: off) for the next set-up: mapping and unmapping ~1 GB per
+// Ilup set-up at 128^3 was a third of its time, and the unmapping of one set-up got in the way of the page faults of the next.
+struct HostPool {
+    std::mutex mu; std::vector<std::pair<void*, size_t>> blocks; size_t held = 0;
+    ~HostPool() { for (auto& b : blocks) std::free(b.first); }
+    void* take(size_t bytes) {
+        std::lock_guard<std::mutex> g(mu);
+        size_t best = blocks.size();
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (blocks[i].second >= bytes && blocks[i].second <= 2 * bytes && (best == blocks.size() || blocks[i].second < blocks[best].second)) best = i;
+        if (best == blocks.size()) return nullptr;
+        void* q = blocks[best].first; held -= blocks[best].second;
+        blocks[best] = blocks.back(); blocks.pop_back();
+        return q;
+    }
+    bool give(void* q, size_t bytes) {
+        const size_t limit = (size_t)std::max(0ll, env_ll("KRYST_HOST_POOL_MB", 2048)) << 20;
+        std::lock_guard<std::mutex> g(mu);
+        if (held + bytes > limit) return false;
+        blocks.emplace_back(q, bytes); held += bytes;
+        return true;
+    }
+};
+static HostPool g_host_pool;
 template <class T>
 struct HostAlloc {
     using value_type = T;
     HostAlloc() = default;
     template <class U> HostAlloc(const HostAlloc<U>&) {}
+    static size_t rounded(size_t bytes) { const size_t big = (size_t)1 << 21; return (bytes + big - 1) / big * big; }
     T* allocate(size_t cnt) {
         const size_t bytes = cnt * sizeof(T);
         void* q = nullptr;
         if (bytes >= ((size_t)1 << 22)) {
-            const size_t big = (size_t)1 << 21;
-            if (posix_memalign(&q, big, (bytes + big - 1) / big * big) != 0) throw std::bad_alloc();
-            (void)madvise(q, (bytes + big - 1) / big * big, MADV_HUGEPAGE);
+            if ((q = g_host_pool.take(rounded(bytes)))) return static_cast<T*>(q);
+            if (posix_memalign(&q, (size_t)1 << 21, rounded(bytes)) != 0) throw std::bad_alloc();
+            (void)madvise(q, rounded(bytes), MADV_HUGEPAGE);
         } else if (!(q = std::malloc(std::max<size_t>(bytes, 1)))) throw std::bad_alloc();
         return static_cast<T*>(q);
     }
-    void deallocate(T* q, size_t) { std::free(q); }
+    void deallocate(T* q, size_t cnt) {
+        const size_t bytes = cnt * sizeof(T);
+        if (bytes >= ((size_t)1 << 22) && g_host_pool.give(q, rounded(bytes))) return;
+        std::free(q);
+    }
     template <class U, class... A> void construct(U* q, A&&... a) {
         if constexpr (sizeof...(A) == 0) ::new ((void*)q) U; else ::new ((void*)q) U(std::forward<A>(a)...);
     }
