@@ -1302,8 +1302,16 @@ static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRow
     }
     if (rc == KRYST_OK && !(D->GL.ok && D->GU.ok) && !(D->BL.ok && D->BU.ok)) {
         std::vector<int32_t> posL, posU;
+        // the two factors' level orders are independent: side by side (each has its own host arrays; the uploads share the context's stream)
+        int32_t rc_u = KRYST_OK;
+        std::thread upper([&] {
+            (void)hipSetDevice(ctx->device);
+            tl_setup_stream = ctx->s_main;
+            rc_u = build_factor(n, ue, dg, false, &D->U, &posU);
+        });
         rc = build_factor(n, le, ones, true, &D->L, &posL);
-        if (rc == KRYST_OK) rc = build_factor(n, ue, dg, false, &D->U, &posU);
+        upper.join();
+        if (rc == KRYST_OK) rc = rc_u;
         if (rc == KRYST_OK) {
             std::vector<int32_t> mapLU((size_t)n);
             for (int64_t i = 0; i < n; ++i) mapLU[posU[i]] = posL[i];
