@@ -939,7 +939,7 @@ static int32_t build_factor(int64_t n, const FlatRows& ent, const hvec<double>& 
     for (int64_t p = 0; p < n; ++p) pos[rowid[p]] = (int32_t)p;
     if (pos_out) *pos_out = pos;
     const size_t nnz = ent.col.size();
-    std::vector<int32_t> col(nnz); std::vector<double> val(nnz), dg((size_t)n);
+    hvec<int32_t> col(nnz); hvec<double> val(nnz), dg((size_t)n);          // (every element is written below: not value-initialised)
     int64_t maxlen = 0;
     for (int64_t p = 0; p < n; ++p) { const int64_t len = ent.len(rowid[p]); ptr[p + 1] = ptr[p] + (int32_t)len; maxlen = std::max(maxlen, len); }
     par_rows(n, [&](int64_t lo, int64_t hi) {
@@ -952,12 +952,14 @@ static int32_t build_factor(int64_t n, const FlatRows& ent, const hvec<double>& 
     });
     F->npos = n;
     if (maxlen <= ELLW && n > 0) {
-        std::vector<int32_t> ecol((size_t)ELLW * n, 0); std::vector<double> eval((size_t)ELLW * n, 0.0); std::vector<uint8_t> elen((size_t)n, 0);
+        hvec<int32_t> ecol((size_t)ELLW * n); hvec<double> eval((size_t)ELLW * n); hvec<uint8_t> elen((size_t)n);
         par_rows(n, [&](int64_t lo, int64_t hi) {
             for (int64_t p = lo; p < hi; ++p) {
                 const int64_t len = ptr[p + 1] - ptr[p];
                 elen[p] = (uint8_t)len;
-                for (int64_t u = 0; u < len; ++u) { ecol[(size_t)u * n + p] = col[ptr[p] + u]; eval[(size_t)u * n + p] = val[ptr[p] + u]; }
+                for (int64_t u = 0; u < ELLW; ++u) {                     // (padding slots: column 0, value 0)
+                    ecol[(size_t)u * n + p] = u < len ? col[ptr[p] + u] : 0; eval[(size_t)u * n + p] = u < len ? val[ptr[p] + u] : 0.0;
+                }
             }
         });
         KR_TRY(up(&F->d_ecol, ecol)); KR_TRY(up(&F->d_eval, eval)); KR_TRY(up(&F->d_elen, elen));
