@@ -1909,7 +1909,8 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         else lap("box operator checked, rows sorted by hyperplane");
     }
     // ---- the pattern on the host: levels of the lower / upper pattern, local entries per row
-    std::vector<int32_t> hrp, hcol, lvl, lvlU, cntL, cntU, rowid, pos, lvl_off;
+    hvec<int32_t> hrp, hcol;                                               // (copied into: not value-initialised)
+    std::vector<int32_t> lvl, lvlU, cntL, cntU, rowid, pos, lvl_off;
     if (!plane_order) {
     hrp.resize((size_t)n + 1); hcol.resize((size_t)nnz); lvl.resize((size_t)n); lvlU.resize((size_t)n); cntL.resize((size_t)n); cntU.resize((size_t)n);
     KR_HIP(hipMemcpyAsync(hrp.data(), a->d_row_ptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, ctx->s_main));
