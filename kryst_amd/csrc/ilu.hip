@@ -103,6 +103,7 @@ struct HostAlloc {
     template <class U> bool operator!=(const HostAlloc<U>&) const { return false; }
 };
 template <class T> using hvec = std::vector<T, HostAlloc<T>>;
+void janitor_wait();        // (defined with the janitor thread below) what the previous set-up released is in the pool after this
 
 // wavefront kernel by number of 8 x 8 line blocks in the (j, k) plane: the 16 x 16 kernel from 32^3 up (table at its use)
 static int default_wave_form(unsigned nb8) { return nb8 >= 16 ? 2 : 1; }
@@ -1912,6 +1913,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
     hvec<int32_t> hrp, hcol;                                               // (copied into: not value-initialised)
     std::vector<int32_t> lvl, lvlU, cntL, cntU, rowid, pos, lvl_off;
     if (!plane_order) {
+    janitor_wait();
     hrp.resize((size_t)n + 1); hcol.resize((size_t)nnz); lvl.resize((size_t)n); lvlU.resize((size_t)n); cntL.resize((size_t)n); cntU.resize((size_t)n);
     KR_HIP(hipMemcpyAsync(hrp.data(), a->d_row_ptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, ctx->s_main));
     KR_HIP(hipMemcpyAsync(hcol.data(), a->d_col, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->s_main));
@@ -2051,6 +2053,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
 }
 
 static int32_t download_rows(kryst_csr_t a, hvec<int64_t>& rp, hvec<int32_t>& col, hvec<double>& val) {
+    kr::janitor_wait();
     rp.resize((size_t)a->nrows + 1); col.resize((size_t)a->nnz); val.resize((size_t)a->nnz);
     return kryst_csr_download(a, rp.data(), col.data(), val.data());
 }
@@ -2186,8 +2189,12 @@ struct Janitor {
     std::thread th; std::mutex mu;
     ~Janitor() { if (th.joinable()) th.join(); }
     template <class F> void run(F&& f) { std::lock_guard<std::mutex> g(mu); if (th.joinable()) th.join(); th = std::thread(std::forward<F>(f)); }
+    // a set-up about to take big host arrays: what the previous one released should be in the pool by then (a back-to-back second set-up
+    // that overtook the janitor took fresh pages instead -- download 43-74 ms instead of 4-6)
+    void wait() { std::lock_guard<std::mutex> g(mu); if (th.joinable()) th.join(); }
 };
 static Janitor g_janitor;
+void janitor_wait() { g_janitor.wait(); }
 struct IlupU { int32_t c; double v; uint64_t lev; };                       // a nonzero a_work[j][k], k > j, of a finished row
 struct IlupE { int32_t c; double v; };                                     // a kept entry of L or U
 template <class T>

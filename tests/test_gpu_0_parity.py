@@ -392,6 +392,24 @@ def test_spmv_device_generator_matches_host(ctx):
         assert np.array_equal(hrp, ref.row_ptr) and np.array_equal(hci, ref.col_idx) and np.array_equal(hva, ref.vals)
 
 
+def test_operator_download_of_a_large_operator_returns_what_was_uploaded(ctx):
+    """kryst_csr_download at a size where the copies are tens of megabytes (the set-up paths of Ilup / Ilut / the host ILU(0) loop start
+    with it): row pointers widened from the device's int32, columns and values byte for byte, empty rows included."""
+    threads = 0
+    rng = np.random.default_rng(77 + threads)
+    n = 1_300_003                                                                   # row pointers: 5.2 MB = one full piece + a ragged one
+    i = np.arange(n, dtype=np.int64)
+    cols = np.sort((i[:, None] * 3 + np.array([0, 1001, 20011, 300007])[None, :]) % n, axis=1)
+    keep = np.arange(4)[None, :] < (i % 5)[:, None]                                 # 0 .. 4 entries per row
+    ci = cols[keep].astype(np.int32); row_ptr = np.concatenate(([0], np.cumsum(keep.sum(axis=1))))
+    va = rng.standard_normal(len(ci))
+    assert len(ci) * 12 > 16 << 20
+    d = K.CsrMatrix.from_csr(n, n, row_ptr, ci, va, ctx=ctx)
+    rp, gc, gv = d.download()
+    assert rp.dtype == np.int64 and np.array_equal(rp, row_ptr) and np.array_equal(gc, ci)
+    assert np.array_equal(gv.view(np.uint64), va.view(np.uint64))
+
+
 @pytest.mark.parametrize("N", [1, 2, 3, 8, 17, 40, 70])
 def test_spmv_on_generator_made_operators_bit_exact(ctx, rs, N):
     """Operators written by the device generator (ids, codes and tables come from stencil7_gen_kernel, not from the host builder) run
