@@ -128,6 +128,8 @@ struct TriFactor {                  // one triangular factor in level order
     // on a row pointer -- one round trip less on a latency-bound kernel
     int32_t* d_ecol = nullptr; double* d_eval = nullptr; uint8_t* d_elen = nullptr; int64_t npos = 0; bool ell = false;
     bool syncfree = false;          // ELL factor solved by ONE sync-free launch (KRYST_ILU_SYNCFREE=0: one launch per level)
+    int32_t last_entry = -1;        // index of the factor's last stored entry (tri_run_free_kernel clamps its look-ahead to it)
+    bool free_runs = false;         // runs of narrow levels take tri_run_free_kernel (its 128 KiB of LDS were granted at set-up): the vector starts as sentinels
     int held = 16;                  // entries of a row the CSR sync-free kernel holds in registers (8: no row is longer than that)
     std::vector<int32_t> lvl_off;   // host: position offsets per level
     int32_t* d_lvl_off = nullptr;
@@ -632,6 +634,162 @@ __global__ __launch_bounds__(1024) void tri_run_pipe_kernel(const TriArgs* args,
     }
 }
 
+// The same run WITHOUT barriers (round 4, late): one workgroup, its waves take the run's positions in chunks of 64, round-robin, and a lane
+// waits for the rows ITS row needs instead of for the whole level.  A solved value is published twice: to the solution vector (agent-scope
+// store; the vector starts as sentinels, perm_kernel) and to an LDS ring of the last TRF_RING positions as two self-validating 8-byte words
+// (32 bits of the value | the position's tag): a reader that finds both tags takes the value from LDS (~0.1 us instead of an L2 round trip), one
+// that finds a LATER tag -- the slot has been reused -- or whose dependency lies before the run polls the vector instead.  Products are formed
+// when an operand arrives, the subtractions run in stored order: tri_run_kernel's bits.  Progress: the lowest unsolved position's row needs only
+// solved rows, and the wave that owns its chunk has finished all its earlier chunks (all positions below), so it is polling that chunk now;
+// every wave of the one workgroup is resident.  The look-ahead is the pipe kernel's: the next chunk's entries and the one after's row pointers
+// are requested before this chunk starts to wait.  A poll budget turns a logic error into NaNs instead of a hung GPU.
+#define TRF_RING 8192
+template <bool FORWARD, int H>
+__global__ __launch_bounds__(1024) void tri_run_free_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
+                                                            const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                                                            const double* __restrict__ val, const double* __restrict__ diag,
+                                                            int32_t P0, int32_t P1, int32_t kmax, int tune) {
+    if (args->skip) return;
+    extern __shared__ unsigned long long trf_ring[];                     // [TRF_RING][2]
+    for (int x = threadIdx.x; x < 2 * TRF_RING; x += blockDim.x) trf_ring[x] = 0ull;      // tag 0: never written (LDS is not cleared between kernels)
+    __syncthreads();
+    const int W = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int32_t nchunk = (P1 - P0 + 63) >> 6;
+
+    struct Head { int32_t p, k0, k1; double s, dg; };
+    struct Body { int32_t c[H]; double v[H]; };
+    // every load of the look-ahead is issued by every lane (clamped indices): the waits can then be COUNTED (s_waitcnt vmcnt(n)) and the
+    // gathers of step (1) below do not wait for the look-ahead behind them
+    auto head_of = [&](int32_t ch) -> Head {
+        Head h;
+        const int32_t p = P0 + (ch << 6) + lane, pc = p < P1 ? p : P1 - 1;
+        h.k0 = ptr[pc]; h.k1 = ptr[pc + 1]; h.s = in[pc]; h.dg = FORWARD ? 1.0 : diag[pc];
+        h.p = p < P1 ? p : -1;
+        if (p >= P1) h.k1 = h.k0;
+        return h;
+    };
+    auto body_of = [&](const Head& h) -> Body {
+        Body b;
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            const int32_t k = h.k0 + u < kmax ? h.k0 + u : kmax;
+            b.c[u] = col[k]; b.v[u] = val[k];
+        }
+        return b;
+    };
+    // one look at a dependency: true and its value when it has been solved.  `far` (kept per operand by the caller): take it from the vector
+    auto look = [&](int32_t d, bool& far, double& xv) -> bool {
+        if (!far) {
+            const uint32_t slot = (uint32_t)(d - P0) & (TRF_RING - 1), e = (uint32_t)(d - P0) + 1u;
+            const unsigned long long a = __hip_atomic_load(&trf_ring[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long b = __hip_atomic_load(&trf_ring[2 * slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t ta = (uint32_t)(a >> 32), tb = (uint32_t)(b >> 32);
+            if (ta == e && tb == e) { xv = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32))); return true; }
+            if (ta > e || tb > e) far = true;                              // the slot belongs to a later position now
+            return false;
+        }
+        xv = __hip_atomic_load(&out[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (unsigned long long)__double_as_longlong(xv) != KR_TRI_SENTINEL;
+    };
+    const unsigned long long* ring = trf_ring;
+    Head hc = head_of(w), hn = head_of(w + W);
+    Body bc = body_of(hc);
+    for (int32_t ch = w; ch < nchunk; ch += W) {
+        const int len = hc.k1 - hc.k0, nh = len < H ? len : H;
+        // (1) operands from before the run or more than a ring back: gathered from the vector NOW, ahead of the look-ahead loads (vector loads
+        //     return in order: a gather issued later would wait for the next chunk's cold misses); every lane issues all H loads, the ones
+        //     it has no use for at one common address
+        unsigned farm = 0;
+        double t[H];
+#pragma unroll
+        for (int u = 0; u < H; ++u) if (u < nh && (bc.c[u] < P0 || hc.p - bc.c[u] >= TRF_RING)) farm |= 1u << u;
+#pragma unroll
+        for (int u = 0; u < H; ++u) t[u] = __hip_atomic_load(&out[((farm >> u) & 1u) ? bc.c[u] : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::: "memory");
+        // (2) the look-ahead: in flight while this chunk waits and computes
+        const Body bn = body_of(hn);
+        const Head hnn = head_of(ch + 2 * W);
+        asm volatile("" ::: "memory");
+        // (3) one look at every near operand, all reads issued together
+        unsigned have = 0;
+        {
+            unsigned long long ra[H], rb[H];
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                const uint32_t slot = (uint32_t)(bc.c[u] - P0) & (TRF_RING - 1);
+                ra[u] = __hip_atomic_load(&ring[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                rb[u] = __hip_atomic_load(&ring[2 * slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                const uint32_t e = (uint32_t)(bc.c[u] - P0) + 1u, ta = (uint32_t)(ra[u] >> 32), tb = (uint32_t)(rb[u] >> 32);
+                const bool near = u < nh && !((farm >> u) & 1u);
+                const double xl = __longlong_as_double((long long)((ra[u] & 0xffffffffull) | (rb[u] << 32)));
+                const bool far = (farm >> u) & 1u;
+                const bool got = far ? (unsigned long long)__double_as_longlong(t[u]) != KR_TRI_SENTINEL : (near && ta == e && tb == e);
+                t[u] = bc.v[u] * (far ? t[u] : xl);                        // (a product nobody uses when !got)
+                if (got) have |= 1u << u;
+                if (near && (ta > e || tb > e)) farm |= 1u << u;           // the slot belongs to a later position: from the vector
+            }
+        }
+        double s = hc.s;
+        int cons = 0;
+        bool done = hc.p < 0;
+        int32_t cd = 0; double cv = 0.0; bool cfar = false;
+        auto advance = [&]() {
+#pragma unroll
+            for (int u = 0; u < H; ++u) if (cons == u && ((have >> u) & 1u)) { s = s - t[u]; cons = u + 1; }      // stored order
+            if (cons < nh) {
+#pragma unroll
+                for (int u = 0; u < H; ++u) if (cons == u) { cd = bc.c[u]; cv = bc.v[u]; }
+                cfar = (farm >> cons) & 1u;
+            } else if (cons < len) {                                       // a row longer than H: its later entries one at a time, from memory
+                cd = col[hc.k0 + cons]; cv = val[hc.k0 + cons];
+                cfar = cd < P0 || hc.p - cd >= TRF_RING;
+            }
+        };
+        if (!done) advance();
+        int budget = 1 << 22, idle = 0;
+        for (;;) {
+            bool moved = false;
+            if (!done) {
+                if (cons < len) {
+                    double xv = 0.0;
+                    bool got = look(cd, cfar, xv);
+                    if (got) { s = s - cv * xv; ++cons; advance(); moved = true; }
+                }
+                if (cons == len) {
+                    const double res = FORWARD ? s : s / hc.dg;
+                    __hip_atomic_store(&out[hc.p], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(res), tag = (unsigned long long)((uint32_t)(hc.p - P0) + 1u) << 32;
+                    const uint32_t slot = (uint32_t)(hc.p - P0) & (TRF_RING - 1);
+                    __hip_atomic_store(&trf_ring[2 * slot], (bits & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&trf_ring[2 * slot + 1], (bits >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    done = true; moved = true;
+                }
+            }
+            if (__all(done)) break;
+            if (--budget <= 0) {                                           // a logic error: NaNs, not a hung GPU
+                if (!done) {
+                    __hip_atomic_store(&out[hc.p], __longlong_as_double(0x7FF8000000000000ll), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long tag = (unsigned long long)((uint32_t)(hc.p - P0) + 1u) << 32; const uint32_t slot = (uint32_t)(hc.p - P0) & (TRF_RING - 1);
+                    __hip_atomic_store(&trf_ring[2 * slot], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&trf_ring[2 * slot + 1], 0x7FF80000ull | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                break;
+            }
+            // a wave that makes progress is at the front: it gets the SIMD ahead of the waves that only look; those back off
+            if (__any(moved)) { if (idle && (tune & 256)) __builtin_amdgcn_s_setprio(3); idle = 0; }
+            else {
+                if (!idle && (tune & 256)) __builtin_amdgcn_s_setprio(0);
+                if (idle < (tune & 255)) ++idle;
+                for (int q = 0; q < idle; ++q) __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        hc = hn; bc = bn; hn = hnn;
+    }
+}
+
 // runs in stream order before the level kernels, so it sees the solver's `done` flag as of this apply
 __global__ void tri_set_args(TriArgs* a, const double* r, double* z, const int* done) {
     a->r = r; a->z = z; a->skip = (done && *done) ? 1 : 0;
@@ -649,6 +807,15 @@ __global__ __launch_bounds__(256) void perm_kernel(const TriArgs* args, double* 
     else if (MODE == 1) dst[p] = src[map[p]];
     else args->z[map[p]] = src[p];
     if (fill) fill[p] = __longlong_as_double((long long)KR_TRI_SENTINEL);     // "not yet solved" marks for the sync-free kernel
+}
+
+// KRYST_ILU_RUN_FREE (default 1): runs of narrow levels without barriers; needs 128 KiB of LDS, twice what a kernel gets without asking
+static bool grant_free_runs() {
+    if (env_int("KRYST_ILU_RUN_FREE", 1) == 0) return false;
+    const bool ok = hipFuncSetAttribute((const void*)tri_run_free_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, TRF_RING * 16) == hipSuccess &&
+                    hipFuncSetAttribute((const void*)tri_run_free_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, TRF_RING * 16) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    return ok;
 }
 
 static const int NARROW = 2048;     // levels with at most this many rows are folded into one-workgroup runs (CSR fallback)
@@ -682,7 +849,13 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
             // profiles/r04/narrow_level_kernel_experiments.txt.)
             const int mean_rows = (int)((F.lvl_off[l1] - F.lvl_off[lv]) / std::max(1, l1 - lv));
             const unsigned run_threads = (unsigned)std::min(1024, std::max(64, env_int("KRYST_ILU_RUN_THREADS", std::max(256, (mean_rows * 5 / 4 + 63) / 64 * 64)) / 64 * 64));
-            if (env_int("KRYST_ILU_RUN_PIPE", 1) != 0)
+            if (F.free_runs) {
+                // (waves: a power of two, so that the positions that share a ring slot belong to ONE wave and are solved in order)
+                const int fw = env_int("KRYST_ILU_FREE_WAVES", 16);
+                const unsigned waves = fw >= 16 ? 16u : fw >= 8 ? 8u : fw >= 4 ? 4u : fw >= 2 ? 2u : 1u;
+                hipLaunchKernelGGL((tri_run_free_kernel<FORWARD, 8>), dim3(1), dim3(64 * waves), (size_t)TRF_RING * 16, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
+                                   F.d_diag, F.lvl_off[lv], F.lvl_off[l1], F.last_entry, env_int("KRYST_ILU_FREE_TUNE", 1));
+            } else if (env_int("KRYST_ILU_RUN_PIPE", 1) != 0)
                 hipLaunchKernelGGL((tri_run_pipe_kernel<FORWARD, 8>), dim3(1), dim3(run_threads), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
                                    F.d_diag, F.d_lvl_off, lv, l1);
             else
@@ -803,11 +976,11 @@ static int32_t enqueue_apply(hipStream_t s, IluData* D, const TriDirect* direct 
         return KRYST_OK;
     }
     hipLaunchKernelGGL((perm_kernel<0>), dim3(g), dim3(256), 0, s, D->d_args, D->d_rL, (const double*)nullptr, D->L.d_row, D->n,
-                       D->L.syncfree ? D->d_y : (double*)nullptr);
+                       (D->L.syncfree || D->L.free_runs) ? D->d_y : (double*)nullptr);
     KR_HIP(hipGetLastError());
     KR_TRY(enqueue_factor<true>(s, D->L, D->d_args, D->d_rL, D->d_y));
     hipLaunchKernelGGL((perm_kernel<1>), dim3(g), dim3(256), 0, s, D->d_args, D->d_yU, (const double*)D->d_y, D->d_mapLU, D->n,
-                       D->U.syncfree ? D->d_zU : (double*)nullptr);
+                       (D->U.syncfree || D->U.free_runs) ? D->d_zU : (double*)nullptr);
     KR_HIP(hipGetLastError());
     KR_TRY(enqueue_factor<false>(s, D->U, D->d_args, D->d_yU, D->d_zU));
     hipLaunchKernelGGL((perm_kernel<2>), dim3(g), dim3(256), 0, s, D->d_args, (double*)nullptr, (const double*)D->d_zU, D->U.d_row, D->n,
@@ -972,6 +1145,8 @@ static int32_t build_factor(int64_t n, const FlatRows& ent, const hvec<double>& 
     // 13.0 ms otherwise).  KRYST_ILU_SYNCFREE = 0 / 1 forces either form.
     const double rows_per_level = nl > 0 ? (double)n / (double)nl : 0.0;
     F->syncfree = env_int("KRYST_ILU_SYNCFREE", (F->ell || rows_per_level >= 512.0) ? 1 : 0) != 0;
+    F->last_entry = (int32_t)ptr[n] - 1;
+    F->free_runs = !F->syncfree && !F->ell && ptr[n] > 0 && grant_free_runs();
     {
         int64_t longest = 0;
         for (int64_t p = 0; p < n; ++p) longest = std::max<int64_t>(longest, ptr[p + 1] - ptr[p]);
@@ -2018,6 +2193,8 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         F->held = maxlen <= 8 ? 8 : 16;
         const double rows_per_level = (double)n / (double)std::max<size_t>(1, F->lvl_off.size() - 1);
         F->syncfree = env_int("KRYST_ILU_SYNCFREE", (F->ell || rows_per_level >= 512.0) ? 1 : 0) != 0;
+        F->last_entry = (int32_t)fn - 1;
+        F->free_runs = !F->syncfree && !F->ell && fn > 0 && grant_free_runs();
         int32_t* d_pos = which == 0 ? t.posL : t.posU;
         rc = up(&F->d_row, rowid);
         if (rc == KRYST_OK) rc = up(&F->d_ptr, ptr);

@@ -580,16 +580,20 @@ def test_measurement_hooks_of_round_4_leave_the_operator_alone(ctx):
     assert device_count() >= 1
 
 
-@pytest.mark.parametrize("pipe", ["1", "0"])
+@pytest.mark.parametrize("pipe", ["free16", "free4", "free1", "1", "0"])
 def test_narrow_level_runs_of_a_deep_factor_bit_exact(ctx, pipe, monkeypatch):
-    """The one-workgroup run kernels for deep, narrow factors (tri_run_pipe_kernel / tri_run_kernel, KRYST_ILU_SYNCFREE=0) on a factor of
+    """The one-workgroup run kernels for deep, narrow factors (tri_run_free_kernel with 16 / 4 / 1 waves -- no barriers, values handed over
+    through an LDS ring of the last 8 192 positions, older ones polled in the vector --, tri_run_pipe_kernel / tri_run_kernel, KRYST_ILU_SYNCFREE=0) on a factor of
     40 000 rows and a thousand levels: dependencies in the previous level and tens of thousands of positions back, rows longer than the eight
     entries held in registers, a level wider than the workgroup (1 500 independent rows) -- the oracle's bits.  (Round 4 rebuilt the
     pipelined kernel three ways against this test -- LDS window, lazily waited stores, counted look-ahead, a prefetching workgroup: all
     bit-exact, none faster, DESIGN.md section 8 -- and kept the round-3 kernel.)"""
     import scipy.sparse as sp
-    monkeypatch.setenv("KRYST_ILU_SYNCFREE", "0"); monkeypatch.setenv("KRYST_ILU_RUN_PIPE", pipe)
-    lead = pipe
+    monkeypatch.setenv("KRYST_ILU_SYNCFREE", "0")
+    if pipe.startswith("free"):
+        monkeypatch.setenv("KRYST_ILU_RUN_FREE", "1"); monkeypatch.setenv("KRYST_ILU_FREE_WAVES", pipe[4:])
+    else:
+        monkeypatch.setenv("KRYST_ILU_RUN_FREE", "0"); monkeypatch.setenv("KRYST_ILU_RUN_PIPE", pipe)
     rng = np.random.default_rng(2024)
     n, free = 40000, 1500
     rows = np.repeat(np.arange(free, n), 9)
@@ -610,7 +614,7 @@ def test_narrow_level_runs_of_a_deep_factor_bit_exact(ctx, pipe, monkeypatch):
         assert info["form"].startswith("level") and min(info["levels"]) > 200, info
         for seed in (1, 2):
             r = O.splitmix64_uniform(seed, n) - 0.5
-            assert np.array_equal(pc.apply(r), ref.apply(r)), (lead, seed)
+            assert np.array_equal(pc.apply(r), ref.apply(r)), (pipe, seed)
 
 
 @pytest.mark.parametrize("grid_path", ["quad", "1", "wave0", "0"])
