@@ -637,29 +637,41 @@ __global__ __launch_bounds__(1024) void tri_run_pipe_kernel(const TriArgs* args,
 // The same run WITHOUT barriers (round 4, late): one workgroup, its waves take the run's positions in chunks of 64, round-robin, and a lane
 // waits for the rows ITS row needs instead of for the whole level.  A solved value is published twice: to the solution vector (agent-scope
 // store; the vector starts as sentinels, perm_kernel) and to an LDS ring of the last TRF_RING positions as two self-validating 8-byte words
-// (32 bits of the value | the position's tag): a reader that finds both tags takes the value from LDS (~0.1 us instead of an L2 round trip), one
-// that finds a LATER tag -- the slot has been reused -- or whose dependency lies before the run polls the vector instead.  Products are formed
-// when an operand arrives, the subtractions run in stored order: tri_run_kernel's bits.  Progress: the lowest unsolved position's row needs only
-// solved rows, and the wave that owns its chunk has finished all its earlier chunks (all positions below), so it is polling that chunk now;
-// every wave of the one workgroup is resident.  The look-ahead is the pipe kernel's: the next chunk's entries and the one after's row pointers
-// are requested before this chunk starts to wait.  A poll budget turns a logic error into NaNs instead of a hung GPU.
-#define TRF_RING 8192
+// (32 bits of the value | the position's tag).  A lane first polls ONE word pair -- that of its operand at the largest position, the last to be
+// solved in all but rare cases -- and once that gate is open reads all its operands in one batch (eight pairs in flight); if every tag is the
+// expected one it subtracts in stored order and publishes, otherwise it looks again at the next pass.  Passes are batched over the lanes of a
+// wave (a pass costs the wave the same whether one lane or all take it) and have no branch per operand: EVERY operand is an LDS word pair with
+// an expected tag -- an absent entry reads a constant pair (value +0.0, coefficient set to 0.0: s - 0.0 * 0.0 == s bit for bit), an operand
+// from before the run, more than a ring back, or whose ring slot has been reused (a LATER tag) is gathered from the vector into a pair private
+// to the lane (at the chunk's start, ahead of the look-ahead loads: vector loads return in order; polled there in the rare case that it was not
+// solved yet).  tri_run_kernel's operations in tri_run_kernel's order.  Progress: the lowest unsolved position's row needs only solved rows, and
+// the wave that owns its chunk has finished all its earlier chunks (all positions below), so it is on that chunk now; every wave of the one
+// workgroup is resident.  Positions that share a ring slot belong to one wave (TRF_RING / 64 is a multiple of the wave count) and are solved in
+// order.  The look-ahead is the pipe kernel's.  A poll budget turns a logic error into NaNs instead of a hung GPU.
+#define TRF_RING 4096
+#define TRF_THREADS 512
+#define TRF_LDS_BYTES (TRF_RING * 16 + TRF_THREADS * 8 * 16 + 16)
 template <bool FORWARD, int H>
-__global__ __launch_bounds__(1024) void tri_run_free_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
-                                                            const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
-                                                            const double* __restrict__ val, const double* __restrict__ diag,
-                                                            int32_t P0, int32_t P1, int32_t kmax, int tune) {
+__global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
+                                                                   const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                                                                   const double* __restrict__ val, const double* __restrict__ diag,
+                                                                   int32_t P0, int32_t P1, int32_t kmax, int tune) {
+    static_assert(H == 8, "eight private pairs per lane");
     if (args->skip) return;
-    extern __shared__ unsigned long long trf_ring[];                     // [TRF_RING][2]
-    for (int x = threadIdx.x; x < 2 * TRF_RING; x += blockDim.x) trf_ring[x] = 0ull;      // tag 0: never written (LDS is not cleared between kernels)
+    extern __shared__ unsigned long long trf_lds[];                      // [TRF_RING][2] ring, [TRF_THREADS][8][2] private pairs, [2] the constant pair
+    constexpr uint32_t PRIV = TRF_RING * 2, CONSTP = PRIV + TRF_THREADS * 16;      // (in words)
+    constexpr uint32_t TAG_PRIV = 0xFFFFFFFEu, TAG_CONST = 0xFFFFFFFFu;
+    for (int x = threadIdx.x; x < (int)CONSTP; x += blockDim.x) trf_lds[x] = 0ull;         // tag 0: never written (LDS is not cleared between kernels)
+    if (threadIdx.x == 0) { trf_lds[CONSTP] = (unsigned long long)TAG_CONST << 32; trf_lds[CONSTP + 1] = (unsigned long long)TAG_CONST << 32; }
     __syncthreads();
     const int W = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t nchunk = (P1 - P0 + 63) >> 6;
+    const int batch = tune & 255;
 
     struct Head { int32_t p, k0, k1; double s, dg; };
     struct Body { int32_t c[H]; double v[H]; };
-    // every load of the look-ahead is issued by every lane (clamped indices): the waits can then be COUNTED (s_waitcnt vmcnt(n)) and the
-    // gathers of step (1) below do not wait for the look-ahead behind them
+    struct Stage { int32_t c[8]; double v[8]; };                           // a chunk's entries as they lie in memory: entry kb + 64 q + lane in slot q
+    // every load of the look-ahead is issued by every lane (clamped indices): the waits can then be COUNTED (s_waitcnt vmcnt(n))
     auto head_of = [&](int32_t ch) -> Head {
         Head h;
         const int32_t p = P0 + (ch << 6) + lane, pc = p < P1 ? p : P1 - 1;
@@ -668,125 +680,183 @@ __global__ __launch_bounds__(1024) void tri_run_free_kernel(const TriArgs* args,
         if (p >= P1) h.k1 = h.k0;
         return h;
     };
-    auto body_of = [&](const Head& h) -> Body {
-        Body b;
+    // The entries of 64 consecutive rows are consecutive in memory: the wave loads them as they lie (512 of them, 16 fully coalesced loads) and
+    // deals them out to the rows through LDS.  (With each lane loading ITS row's entries -- the pipe kernel's way -- every cache line is asked
+    // for by eight different instructions: 650 L1 accesses per chunk, the L1 busy or stalled on pending lines for 60 % of the run; PMC, round 4.)
+    auto stage_of = [&](const Head& h, Stage& st) {
+        const int32_t kb = __builtin_amdgcn_readfirstlane(h.k0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int32_t k = kb + 64 * q + lane < kmax ? kb + 64 * q + lane : kmax;
+            st.c[q] = col[k]; st.v[q] = val[k];
+        }
+    };
+    double* const stage_v = reinterpret_cast<double*>(&trf_lds[PRIV + (uint32_t)w * 1024u]);       // this wave's 8 KiB: 512 values, 512 columns; the
+    int32_t* const stage_c = reinterpret_cast<int32_t*>(stage_v + 512);                             // lanes' private pairs once the rows are dealt out
+    auto deal = [&](const Head& h, const Stage& st, Body& b) -> int {      // returns how many of the row's first H entries were staged
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { stage_v[64 * q + lane] = st.v[q]; stage_c[64 * q + lane] = st.c[q]; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int32_t off = h.k0 - __builtin_amdgcn_readfirstlane(h.k0);
+        const int len = h.k1 - h.k0;
+        int n = 0;
 #pragma unroll
         for (int u = 0; u < H; ++u) {
-            const int32_t k = h.k0 + u < kmax ? h.k0 + u : kmax;
-            b.c[u] = col[k]; b.v[u] = val[k];
+            const int32_t idx = off + u < 511 ? off + u : 511;
+            const bool here = u < len && off + u < 512;
+            const int32_t c = stage_c[idx]; const double v = stage_v[idx];
+            b.c[u] = here ? c : 0; b.v[u] = here ? v : 0.0;
+            n += here ? 1 : 0;
         }
-        return b;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        return n;
     };
-    // one look at a dependency: true and its value when it has been solved.  `far` (kept per operand by the caller): take it from the vector
-    auto look = [&](int32_t d, bool& far, double& xv) -> bool {
-        if (!far) {
-            const uint32_t slot = (uint32_t)(d - P0) & (TRF_RING - 1), e = (uint32_t)(d - P0) + 1u;
-            const unsigned long long a = __hip_atomic_load(&trf_ring[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const unsigned long long b = __hip_atomic_load(&trf_ring[2 * slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint32_t ta = (uint32_t)(a >> 32), tb = (uint32_t)(b >> 32);
-            if (ta == e && tb == e) { xv = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32))); return true; }
-            if (ta > e || tb > e) far = true;                              // the slot belongs to a later position now
-            return false;
-        }
-        xv = __hip_atomic_load(&out[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return (unsigned long long)__double_as_longlong(xv) != KR_TRI_SENTINEL;
+    auto pair_at = [&](uint32_t word, unsigned long long& a, unsigned long long& b) {
+        a = __hip_atomic_load(&trf_lds[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        b = __hip_atomic_load(&trf_lds[word + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    const unsigned long long* ring = trf_ring;
-    Head hc = head_of(w), hn = head_of(w + W);
-    Body bc = body_of(hc);
-    for (int32_t ch = w; ch < nchunk; ch += W) {
-        const int len = hc.k1 - hc.k0, nh = len < H ? len : H;
-        // (1) operands from before the run or more than a ring back: gathered from the vector NOW, ahead of the look-ahead loads (vector loads
-        //     return in order: a gather issued later would wait for the next chunk's cold misses); every lane issues all H loads, the ones
-        //     it has no use for at one common address
-        unsigned farm = 0;
-        double t[H];
+    auto put_pair = [&](uint32_t word, double x, uint32_t tag) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(x), t = (unsigned long long)tag << 32;
+        __hip_atomic_store(&trf_lds[word], (bits & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&trf_lds[word + 1], (bits >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto publish = [&](int32_t p, double res) {
+        __hip_atomic_store(&out[p], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        put_pair(((uint32_t)(p - P0) & (TRF_RING - 1)) * 2, res, (uint32_t)(p - P0) + 1u);
+    };
+    auto solved = [](double x) { return (unsigned long long)__double_as_longlong(x) != KR_TRI_SENTINEL; };
+    // one chunk: (hc, bc) are here, hn is the next chunk's head; bn and hnn are requested on the way
+    auto chunk = [&](const Head& hc, const Head& hn, Stage& st, Head& hnn, int32_t ch) {
+        Body bc;
+        const int len = hc.k1 - hc.k0, nh = deal(hc, st, bc);
+        // every operand as (word offset of its pair, expected tag); bit u of `vecm`: operand u comes from the vector, of `vpend`: ... and is not there yet
+        uint32_t word[H], etag[H];
+        unsigned vecm = 0, vpend = 0;
+        int32_t gpos = -1;
 #pragma unroll
-        for (int u = 0; u < H; ++u) if (u < nh && (bc.c[u] < P0 || hc.p - bc.c[u] >= TRF_RING)) farm |= 1u << u;
-#pragma unroll
-        for (int u = 0; u < H; ++u) t[u] = __hip_atomic_load(&out[((farm >> u) & 1u) ? bc.c[u] : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::: "memory");
-        // (2) the look-ahead: in flight while this chunk waits and computes
-        const Body bn = body_of(hn);
-        const Head hnn = head_of(ch + 2 * W);
-        asm volatile("" ::: "memory");
-        // (3) one look at every near operand, all reads issued together
-        unsigned have = 0;
-        {
-            unsigned long long ra[H], rb[H];
-#pragma unroll
-            for (int u = 0; u < H; ++u) {
-                const uint32_t slot = (uint32_t)(bc.c[u] - P0) & (TRF_RING - 1);
-                ra[u] = __hip_atomic_load(&ring[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                rb[u] = __hip_atomic_load(&ring[2 * slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-#pragma unroll
-            for (int u = 0; u < H; ++u) {
-                const uint32_t e = (uint32_t)(bc.c[u] - P0) + 1u, ta = (uint32_t)(ra[u] >> 32), tb = (uint32_t)(rb[u] >> 32);
-                const bool near = u < nh && !((farm >> u) & 1u);
-                const double xl = __longlong_as_double((long long)((ra[u] & 0xffffffffull) | (rb[u] << 32)));
-                const bool far = (farm >> u) & 1u;
-                const bool got = far ? (unsigned long long)__double_as_longlong(t[u]) != KR_TRI_SENTINEL : (near && ta == e && tb == e);
-                t[u] = bc.v[u] * (far ? t[u] : xl);                        // (a product nobody uses when !got)
-                if (got) have |= 1u << u;
-                if (near && (ta > e || tb > e)) farm |= 1u << u;           // the slot belongs to a later position: from the vector
-            }
+        for (int u = 0; u < H; ++u) {
+            const int32_t c = bc.c[u];
+            const bool here = u < nh, near = here && c >= P0 && hc.p - c < TRF_RING;
+            word[u] = near ? ((uint32_t)(c - P0) & (TRF_RING - 1)) * 2 : here ? PRIV + (threadIdx.x * 8 + u) * 2 : CONSTP;
+            etag[u] = near ? (uint32_t)(c - P0) + 1u : here ? TAG_PRIV : TAG_CONST;
+            if (!here) bc.v[u] = 0.0;
+            if (here && !near) vecm |= 1u << u;
+            if (near) gpos = c > gpos ? c : gpos;
         }
+        if (__any(vecm != 0)) {                                            // gathers from the vector, BEFORE the look-ahead is requested
+#pragma unroll
+            for (int u = 0; u < H; ++u)
+                if (__any((vecm >> u) & 1u)) {
+                    const bool mine = (vecm >> u) & 1u;
+                    const double x = __hip_atomic_load(&out[mine ? bc.c[u] : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (mine) { const bool ok = solved(x); put_pair(word[u], x, ok ? TAG_PRIV : 0u); if (!ok) vpend |= 1u << u; }
+                }
+        }
+        asm volatile("" ::: "memory");
+        stage_of(hn, st);                                                  // the look-ahead: in flight while this chunk waits and computes
+        hnn = head_of(ch + 2 * W);
+        asm volatile("" ::: "memory");
+        bool done = hc.p < 0, wait = !done && gpos >= 0, headdone = false;
         double s = hc.s;
-        int cons = 0;
-        bool done = hc.p < 0;
-        int32_t cd = 0; double cv = 0.0; bool cfar = false;
-        auto advance = [&]() {
+        int cons = 0, fails = 0;
+        const uint32_t gword = ((uint32_t)(gpos - P0) & (TRF_RING - 1)) * 2, ge = (uint32_t)(gpos - P0) + 1u;
+        int budget = 1 << 22, since = 0, idle = 0;
+        // FAST: no vector-memory load inside the loop -- the common case.  (With one anywhere in the loop body the compiler has to wait for ALL
+        // outstanding loads, the look-ahead included, at the top of every iteration: the loaded registers may be the ones a poll writes.)
+        // A lane that needs the vector or has a row longer than H raises `rare`, and the chunk is finished by the general form of the loop.
+        auto run = [&](auto fast_tag) -> bool {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            for (;;) {
+                bool moved = false, rare = false;
+                if (wait) {                                                // the gate: one word pair (a LATER tag opens it too: the pass sorts that out)
+                    unsigned long long a, b; pair_at(gword, a, b);
+                    const uint32_t ta = (uint32_t)(a >> 32), tb = (uint32_t)(b >> 32);
+                    if ((ta < tb ? ta : tb) >= ge) wait = false;
+                }
+                const bool open = !wait && !done;
+                ++since;
+                if (__any(open) && (!__any(wait) || since >= batch)) {
+                    since = 0;
+                    if (open && !headdone) {
+                        unsigned long long ra[H], rb[H];
 #pragma unroll
-            for (int u = 0; u < H; ++u) if (cons == u && ((have >> u) & 1u)) { s = s - t[u]; cons = u + 1; }      // stored order
-            if (cons < nh) {
+                        for (int u = 0; u < H; ++u) pair_at(word[u], ra[u], rb[u]);
+                        uint32_t bad = 0;                                  // (no branch per operand)
 #pragma unroll
-                for (int u = 0; u < H; ++u) if (cons == u) { cd = bc.c[u]; cv = bc.v[u]; }
-                cfar = (farm >> cons) & 1u;
-            } else if (cons < len) {                                       // a row longer than H: its later entries one at a time, from memory
-                cd = col[hc.k0 + cons]; cv = val[hc.k0 + cons];
-                cfar = cd < P0 || hc.p - cd >= TRF_RING;
+                        for (int u = 0; u < H; ++u) bad |= ((uint32_t)(ra[u] >> 32) ^ etag[u]) | ((uint32_t)(rb[u] >> 32) ^ etag[u]);
+                        if (bad == 0) {
+#pragma unroll
+                            for (int u = 0; u < H; ++u) {                  // stored order (absent: s - 0.0 * 0.0)
+                                const double t = bc.v[u] * __longlong_as_double((long long)((ra[u] & 0xffffffffull) | (rb[u] << 32)));
+                                s = s - t;
+                            }
+                            headdone = true; cons = nh;
+                        } else if (++fails >= 3) {
+                            // rare: a ring slot that belongs to a later position now, or an operand that was not in the vector when gathered
+                            if constexpr (FAST) rare = true;
+                            else {
+#pragma unroll
+                                for (int u = 0; u < H; ++u) {
+                                    const bool over = etag[u] < TAG_PRIV && ((uint32_t)(ra[u] >> 32) > etag[u] || (uint32_t)(rb[u] >> 32) > etag[u]);
+                                    if (over) { word[u] = PRIV + (threadIdx.x * 8 + u) * 2; etag[u] = TAG_PRIV; put_pair(word[u], 0.0, 0u); vecm |= 1u << u; vpend |= 1u << u; }
+                                    if ((vpend >> u) & 1u) {
+                                        const double x = __hip_atomic_load(&out[bc.c[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        if (solved(x)) { put_pair(word[u], x, TAG_PRIV); vpend &= ~(1u << u); }
+                                    }
+                                }
+                            }
+                        }
+                        moved = true;
+                    }
+                    if (open && headdone && cons < len) {
+                        // a row longer than H: its later entries from memory, a few per pass and never waiting inside the pass (the row it waits
+                        // for may belong to a lane of this wave)
+                        if constexpr (FAST) rare = true;
+                        else {
+                            for (int q = 0; q < 4 && cons < len; ++q) {
+                                const int32_t d = col[hc.k0 + cons]; const double vv = val[hc.k0 + cons];
+                                double xv = 0.0; bool got = false;
+                                if (d >= P0 && hc.p - d < TRF_RING) {
+                                    unsigned long long a, b; pair_at(((uint32_t)(d - P0) & (TRF_RING - 1)) * 2, a, b);
+                                    const uint32_t e = (uint32_t)(d - P0) + 1u;
+                                    if ((uint32_t)(a >> 32) == e && (uint32_t)(b >> 32) == e) { xv = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32))); got = true; }
+                                }
+                                if (!got) { xv = __hip_atomic_load(&out[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); got = solved(xv); }
+                                if (!got) break;
+                                s = s - vv * xv; ++cons; moved = true;
+                            }
+                        }
+                    }
+                    if (open && headdone && cons >= len) {
+                        publish(hc.p, FORWARD ? s : s / hc.dg);
+                        done = true; moved = true;
+                    }
+                }
+                if (__all(done)) return true;
+                if (FAST && __any(rare)) return false;
+                if (--budget <= 0) {                                       // a logic error: NaNs, not a hung GPU
+                    if (!done) publish(hc.p, __longlong_as_double(0x7FF8000000000000ll));
+                    return true;
+                }
+                // a wave that makes progress is at the front: it gets the SIMD ahead of the waves that only look; those back off
+                if (__any(moved)) { if (idle && (tune & 256)) __builtin_amdgcn_s_setprio(3); idle = 0; }
+                else {
+                    if (!idle && (tune & 256)) __builtin_amdgcn_s_setprio(0);
+                    if (idle < ((tune >> 9) & 15)) ++idle;
+                    for (int q = 0; q < idle; ++q) __builtin_amdgcn_s_sleep(1);
+                }
             }
         };
-        if (!done) advance();
-        int budget = 1 << 22, idle = 0;
-        for (;;) {
-            bool moved = false;
-            if (!done) {
-                if (cons < len) {
-                    double xv = 0.0;
-                    bool got = look(cd, cfar, xv);
-                    if (got) { s = s - cv * xv; ++cons; advance(); moved = true; }
-                }
-                if (cons == len) {
-                    const double res = FORWARD ? s : s / hc.dg;
-                    __hip_atomic_store(&out[hc.p], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long bits = (unsigned long long)__double_as_longlong(res), tag = (unsigned long long)((uint32_t)(hc.p - P0) + 1u) << 32;
-                    const uint32_t slot = (uint32_t)(hc.p - P0) & (TRF_RING - 1);
-                    __hip_atomic_store(&trf_ring[2 * slot], (bits & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_store(&trf_ring[2 * slot + 1], (bits >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    done = true; moved = true;
-                }
-            }
-            if (__all(done)) break;
-            if (--budget <= 0) {                                           // a logic error: NaNs, not a hung GPU
-                if (!done) {
-                    __hip_atomic_store(&out[hc.p], __longlong_as_double(0x7FF8000000000000ll), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long tag = (unsigned long long)((uint32_t)(hc.p - P0) + 1u) << 32; const uint32_t slot = (uint32_t)(hc.p - P0) & (TRF_RING - 1);
-                    __hip_atomic_store(&trf_ring[2 * slot], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_store(&trf_ring[2 * slot + 1], 0x7FF80000ull | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                break;
-            }
-            // a wave that makes progress is at the front: it gets the SIMD ahead of the waves that only look; those back off
-            if (__any(moved)) { if (idle && (tune & 256)) __builtin_amdgcn_s_setprio(3); idle = 0; }
-            else {
-                if (!idle && (tune & 256)) __builtin_amdgcn_s_setprio(0);
-                if (idle < (tune & 255)) ++idle;
-                for (int q = 0; q < idle; ++q) __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        hc = hn; bc = bn; hn = hnn;
+        if (!run(std::true_type{})) run(std::false_type{});
+    };
+    Head hc = head_of(w), hn = head_of(w + W), hnn;
+    Stage st;
+    stage_of(hc, st);
+    for (int32_t ch = w; ch < nchunk; ch += W) {
+        chunk(hc, hn, st, hnn, ch);
+        hc = hn; hn = hnn;
     }
 }
 
@@ -812,8 +882,8 @@ __global__ __launch_bounds__(256) void perm_kernel(const TriArgs* args, double* 
 // KRYST_ILU_RUN_FREE (default 1): runs of narrow levels without barriers; needs 128 KiB of LDS, twice what a kernel gets without asking
 static bool grant_free_runs() {
     if (env_int("KRYST_ILU_RUN_FREE", 1) == 0) return false;
-    const bool ok = hipFuncSetAttribute((const void*)tri_run_free_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, TRF_RING * 16) == hipSuccess &&
-                    hipFuncSetAttribute((const void*)tri_run_free_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, TRF_RING * 16) == hipSuccess;
+    const bool ok = hipFuncSetAttribute((const void*)tri_run_free_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, TRF_LDS_BYTES) == hipSuccess &&
+                    hipFuncSetAttribute((const void*)tri_run_free_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, TRF_LDS_BYTES) == hipSuccess;
     if (!ok) (void)hipGetLastError();
     return ok;
 }
@@ -851,10 +921,10 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
             const unsigned run_threads = (unsigned)std::min(1024, std::max(64, env_int("KRYST_ILU_RUN_THREADS", std::max(256, (mean_rows * 5 / 4 + 63) / 64 * 64)) / 64 * 64));
             if (F.free_runs) {
                 // (waves: a power of two, so that the positions that share a ring slot belong to ONE wave and are solved in order)
-                const int fw = env_int("KRYST_ILU_FREE_WAVES", 16);
-                const unsigned waves = fw >= 16 ? 16u : fw >= 8 ? 8u : fw >= 4 ? 4u : fw >= 2 ? 2u : 1u;
-                hipLaunchKernelGGL((tri_run_free_kernel<FORWARD, 8>), dim3(1), dim3(64 * waves), (size_t)TRF_RING * 16, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
-                                   F.d_diag, F.lvl_off[lv], F.lvl_off[l1], F.last_entry, env_int("KRYST_ILU_FREE_TUNE", 1));
+                const int fw = env_int("KRYST_ILU_FREE_WAVES", 8);
+                const unsigned waves = fw >= 8 ? 8u : fw >= 4 ? 4u : fw >= 2 ? 2u : 1u;
+                hipLaunchKernelGGL((tri_run_free_kernel<FORWARD, 8>), dim3(1), dim3(64 * waves), (size_t)TRF_LDS_BYTES, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
+                                   F.d_diag, F.lvl_off[lv], F.lvl_off[l1], F.last_entry, env_int("KRYST_ILU_FREE_TUNE", 1 | (1 << 9)));
             } else if (env_int("KRYST_ILU_RUN_PIPE", 1) != 0)
                 hipLaunchKernelGGL((tri_run_pipe_kernel<FORWARD, 8>), dim3(1), dim3(run_threads), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
                                    F.d_diag, F.d_lvl_off, lv, l1);

@@ -580,10 +580,10 @@ def test_measurement_hooks_of_round_4_leave_the_operator_alone(ctx):
     assert device_count() >= 1
 
 
-@pytest.mark.parametrize("pipe", ["free16", "free4", "free1", "1", "0"])
+@pytest.mark.parametrize("pipe", ["free8", "free4", "free1", "1", "0"])
 def test_narrow_level_runs_of_a_deep_factor_bit_exact(ctx, pipe, monkeypatch):
     """The one-workgroup run kernels for deep, narrow factors (tri_run_free_kernel with 16 / 4 / 1 waves -- no barriers, values handed over
-    through an LDS ring of the last 8 192 positions, older ones polled in the vector --, tri_run_pipe_kernel / tri_run_kernel, KRYST_ILU_SYNCFREE=0) on a factor of
+    through an LDS ring of the last 4 096 positions, older ones gathered from the vector --, tri_run_pipe_kernel / tri_run_kernel, KRYST_ILU_SYNCFREE=0) on a factor of
     40 000 rows and a thousand levels: dependencies in the previous level and tens of thousands of positions back, rows longer than the eight
     entries held in registers, a level wider than the workgroup (1 500 independent rows) -- the oracle's bits.  (Round 4 rebuilt the
     pipelined kernel three ways against this test -- LDS window, lazily waited stores, counted look-ahead, a prefetching workgroup: all
