@@ -580,7 +580,7 @@ def test_measurement_hooks_of_round_4_leave_the_operator_alone(ctx):
     assert device_count() >= 1
 
 
-@pytest.mark.parametrize("pipe", ["free8", "free4", "free1", "1", "0"])
+@pytest.mark.parametrize("pipe", ["free8", "free4", "free1", "free8-wide-first-level", "1", "0"])
 def test_narrow_level_runs_of_a_deep_factor_bit_exact(ctx, pipe, monkeypatch):
     """The one-workgroup run kernels for deep, narrow factors (tri_run_free_kernel with 16 / 4 / 1 waves -- no barriers, values handed over
     through an LDS ring of the last 4 096 positions, older ones gathered from the vector --, tri_run_pipe_kernel / tri_run_kernel, KRYST_ILU_SYNCFREE=0) on a factor of
@@ -590,12 +590,13 @@ def test_narrow_level_runs_of_a_deep_factor_bit_exact(ctx, pipe, monkeypatch):
     bit-exact, none faster, DESIGN.md section 8 -- and kept the round-3 kernel.)"""
     import scipy.sparse as sp
     monkeypatch.setenv("KRYST_ILU_SYNCFREE", "0")
+    wide = pipe.endswith("-wide-first-level")           # 3 000 independent rows: a level kernel of its own, the run starts behind it (operands "before the run")
     if pipe.startswith("free"):
-        monkeypatch.setenv("KRYST_ILU_RUN_FREE", "1"); monkeypatch.setenv("KRYST_ILU_FREE_WAVES", pipe[4:])
+        monkeypatch.setenv("KRYST_ILU_RUN_FREE", "1"); monkeypatch.setenv("KRYST_ILU_FREE_WAVES", pipe[4])
     else:
         monkeypatch.setenv("KRYST_ILU_RUN_FREE", "0"); monkeypatch.setenv("KRYST_ILU_RUN_PIPE", pipe)
     rng = np.random.default_rng(2024)
-    n, free = 40000, 1500
+    n, free = 40000, (3000 if wide else 1500)
     rows = np.repeat(np.arange(free, n), 9)
     near = rows + rng.integers(-300, 301, len(rows))
     far = rng.integers(0, n, len(rows))                                   # one entry in ten couples to ANY row: dependencies far below the window
