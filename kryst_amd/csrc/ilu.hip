@@ -667,6 +667,9 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
     const int W = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t nchunk = (P1 - P0 + 63) >> 6;
     const int batch = tune & 255;
+    // an operand counts as "in the ring" when no wave can have reused its slot yet in the ordinary course of things: the most advanced wave is
+    // W chunks ahead of the least advanced one (further only if its rows need none of the rows in between; the tags catch that)
+    const int32_t reach = TRF_RING - 64 * (W + 1);
 
     struct Head { int32_t p, k0, k1; double s, dg; };
     struct Body { int32_t c[H]; double v[H]; };
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
 #pragma unroll
         for (int u = 0; u < H; ++u) {
             const int32_t c = bc.c[u];
-            const bool here = u < nh, near = here && c >= P0 && hc.p - c < TRF_RING;
+            const bool here = u < nh, near = here && c >= P0 && hc.p - c < reach;
             word[u] = near ? ((uint32_t)(c - P0) & (TRF_RING - 1)) * 2 : here ? PRIV + (threadIdx.x * 8 + u) * 2 : CONSTP;
             etag[u] = near ? (uint32_t)(c - P0) + 1u : here ? TAG_PRIV : TAG_CONST;
             if (!here) bc.v[u] = 0.0;
@@ -849,7 +852,49 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
                 }
             }
         };
-        if (!run(std::true_type{})) run(std::false_type{});
+        // LEAN: the loop a chunk normally lives in -- every unsolved lane whose gate is open looks at all its operands every turn (no batching, no
+        // bookkeeping per lane: a lone wave issues an instruction every ~4.5 cycles, so the turn's LENGTH is the hop's latency).  It leaves to the
+        // loops above when a lane has a row longer than H or an operand that was not in the vector, or when a ring slot has been
+        // reused under a reader (looked for every 16th turn without progress).
+        auto lean = [&]() -> bool {
+            if (tune & 8192) return false;
+            if (__any(!done && (len > nh || vpend != 0))) return false;
+            bool stuck = false;
+            for (int quiet = 0;;) {
+                bool got = false;
+                if (wait && (tune & 16384)) wait = false;
+                if (wait) {                                                // the gate: one word pair (waves that are early keep the LDS free)
+                    unsigned long long a, b; pair_at(gword, a, b);
+                    const uint32_t ta = (uint32_t)(a >> 32), tb = (uint32_t)(b >> 32);
+                    if ((ta < tb ? ta : tb) >= ge) wait = false;
+                }
+                if (!done && !wait) {
+                    unsigned long long ra[H], rb[H];
+#pragma unroll
+                    for (int u = 0; u < H; ++u) pair_at(word[u], ra[u], rb[u]);
+                    uint32_t bad = 0;
+#pragma unroll
+                    for (int u = 0; u < H; ++u) bad |= ((uint32_t)(ra[u] >> 32) ^ etag[u]) | ((uint32_t)(rb[u] >> 32) ^ etag[u]);
+                    if (bad == 0) {
+#pragma unroll
+                        for (int u = 0; u < H; ++u) {                      // stored order (absent: s - 0.0 * 0.0)
+                            const double t = bc.v[u] * __longlong_as_double((long long)((ra[u] & 0xffffffffull) | (rb[u] << 32)));
+                            s = s - t;
+                        }
+                        publish(hc.p, FORWARD ? s : s / hc.dg);
+                        done = true; got = true;
+                    } else if ((quiet & 15) == 15) {                       // now and then: has one of my ring slots been reused under me?
+#pragma unroll
+                        for (int u = 0; u < H; ++u)
+                            stuck = stuck || (etag[u] < TAG_PRIV && ((uint32_t)(ra[u] >> 32) > etag[u] || (uint32_t)(rb[u] >> 32) > etag[u]));
+                    }
+                }
+                if (__all(done)) return true;
+                if (__any(got)) quiet = 0;
+                else { if (++quiet > 4096 || __any(stuck)) return false; __builtin_amdgcn_s_sleep(1); }
+            }
+        };
+        if (!lean()) if (!run(std::true_type{})) run(std::false_type{});
     };
     Head hc = head_of(w), hn = head_of(w + W), hnn;
     Stage st;
@@ -921,10 +966,12 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
             const unsigned run_threads = (unsigned)std::min(1024, std::max(64, env_int("KRYST_ILU_RUN_THREADS", std::max(256, (mean_rows * 5 / 4 + 63) / 64 * 64)) / 64 * 64));
             if (F.free_runs) {
                 // (waves: a power of two, so that the positions that share a ring slot belong to ONE wave and are solved in order)
-                const int fw = env_int("KRYST_ILU_FREE_WAVES", 8);
+                // (8 waves where a level fills a wave; 4 on narrower levels, where the waves that only wait cost the one that works:
+                // 22 rows per level 0.50 us per level against 0.53, 3 rows 0.42 against 0.44; 187 rows: 30.4 ms with 8, 42.6 with 4)
+                const int fw = env_int("KRYST_ILU_FREE_WAVES", mean_rows >= 64 ? 8 : 4);
                 const unsigned waves = fw >= 8 ? 8u : fw >= 4 ? 4u : fw >= 2 ? 2u : 1u;
                 hipLaunchKernelGGL((tri_run_free_kernel<FORWARD, 8>), dim3(1), dim3(64 * waves), (size_t)TRF_LDS_BYTES, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
-                                   F.d_diag, F.lvl_off[lv], F.lvl_off[l1], F.last_entry, env_int("KRYST_ILU_FREE_TUNE", 1 | (1 << 9)));
+                                   F.d_diag, F.lvl_off[lv], F.lvl_off[l1], F.last_entry, env_int("KRYST_ILU_FREE_TUNE", 1 | (1 << 9) | 16384));
             } else if (env_int("KRYST_ILU_RUN_PIPE", 1) != 0)
                 hipLaunchKernelGGL((tri_run_pipe_kernel<FORWARD, 8>), dim3(1), dim3(run_threads), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
                                    F.d_diag, F.d_lvl_off, lv, l1);
