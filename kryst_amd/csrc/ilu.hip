@@ -637,17 +637,19 @@ __global__ __launch_bounds__(1024) void tri_run_pipe_kernel(const TriArgs* args,
 // The same run WITHOUT barriers (round 4, late): one workgroup, its waves take the run's positions in chunks of 64, round-robin, and a lane
 // waits for the rows ITS row needs instead of for the whole level.  A solved value is published twice: to the solution vector (agent-scope
 // store; the vector starts as sentinels, perm_kernel) and to an LDS ring of the last TRF_RING positions as two self-validating 8-byte words
-// (32 bits of the value | the position's tag).  A lane first polls ONE word pair -- that of its operand at the largest position, the last to be
-// solved in all but rare cases -- and once that gate is open reads all its operands in one batch (eight pairs in flight); if every tag is the
-// expected one it subtracts in stored order and publishes, otherwise it looks again at the next pass.  Passes are batched over the lanes of a
-// wave (a pass costs the wave the same whether one lane or all take it) and have no branch per operand: EVERY operand is an LDS word pair with
-// an expected tag -- an absent entry reads a constant pair (value +0.0, coefficient set to 0.0: s - 0.0 * 0.0 == s bit for bit), an operand
-// from before the run, more than a ring back, or whose ring slot has been reused (a LATER tag) is gathered from the vector into a pair private
-// to the lane (at the chunk's start, ahead of the look-ahead loads: vector loads return in order; polled there in the rare case that it was not
-// solved yet).  tri_run_kernel's operations in tri_run_kernel's order.  Progress: the lowest unsolved position's row needs only solved rows, and
-// the wave that owns its chunk has finished all its earlier chunks (all positions below), so it is on that chunk now; every wave of the one
-// workgroup is resident.  Positions that share a ring slot belong to one wave (TRF_RING / 64 is a multiple of the wave count) and are solved in
-// order.  The look-ahead is the pipe kernel's.  A poll budget turns a logic error into NaNs instead of a hung GPU.
+// (32 bits of the value | the position's tag).  EVERY operand of a row is an LDS word pair with an expected tag: a ring slot for a row of this
+// run that no wave can have overtaken yet, a constant pair for an absent entry (value +0.0, coefficient set to 0.0: s - 0.0 * 0.0 == s bit for
+// bit), a pair private to the lane for an operand from before the run or further back -- gathered from the vector at the chunk's start, ahead
+// of the look-ahead loads (vector loads return in order).  So a turn of the loop has no branch per operand: read the eight pairs, compare the
+// sixteen tags, and if all agree subtract in stored order and publish.  Three forms of that loop, tried in this order per chunk: LEAN (every
+// unsolved lane looks every turn; ~120 instructions, and a lone wave issues one per ~4.5 cycles, so that is the latency of a dependent hop),
+// GATED (a lane first polls the pair of its operand at the largest position; passes batched over the wave's lanes) and GENERAL (vector loads
+// allowed: rows longer than H, operands not yet in the vector, ring slots reused under a reader -- a LATER tag).  tri_run_kernel's operations
+// in tri_run_kernel's order.  Progress: the lowest unsolved position's row needs only solved rows, and the wave that owns its chunk has finished
+// all its earlier chunks (all positions below), so it is on that chunk now; every wave of the one workgroup is resident.  Positions that share
+// a ring slot belong to one wave (TRF_RING / 64 is a multiple of the wave count) and are solved in order.  The look-ahead: a chunk's entries are
+// requested one chunk ahead, as they lie in memory (16 coalesced loads), and dealt out to the rows through LDS.  A poll budget turns a logic
+// error into NaNs instead of a hung GPU.
 #define TRF_RING 4096
 #define TRF_THREADS 512
 #define TRF_LDS_BYTES (TRF_RING * 16 + TRF_THREADS * 8 * 16 + 16)
