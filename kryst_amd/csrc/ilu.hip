@@ -955,7 +955,7 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
     int lv = 0;
     while (lv < nl) {
         const int rows = F.lvl_off[lv + 1] - F.lvl_off[lv];
-        if (rows <= NARROW && !F.ell) {
+        if (rows <= NARROW && (!F.ell || F.free_runs)) {
             int l1 = lv + 1;
             while (l1 < nl && F.lvl_off[l1 + 1] - F.lvl_off[l1] <= NARROW) ++l1;
             // Threads: what a level costs is the instructions every wave of the workgroup issues for it, needed or not -- the random band
@@ -1263,9 +1263,11 @@ static int32_t build_factor(int64_t n, const FlatRows& ent, const hvec<double>& 
     // random band matrix with 10 716 levels of 187 rows: 127 -> 72 ms; a 27-point factor with 1 328 rows per level: 9.9 ms sync-free,
     // 13.0 ms otherwise).  KRYST_ILU_SYNCFREE = 0 / 1 forces either form.
     const double rows_per_level = nl > 0 ? (double)n / (double)nl : 0.0;
-    F->syncfree = env_int("KRYST_ILU_SYNCFREE", (F->ell || rows_per_level >= 512.0) ? 1 : 0) != 0;
+    // (round 4: an ELL factor with FEWER than 256 rows per level takes the one-workgroup barrier-free run kernel as well -- 0.45-1.4 us per level
+    // there against the sync-free kernel's two fabric trips, 2 us, whatever the width)
+    F->syncfree = env_int("KRYST_ILU_SYNCFREE", ((F->ell && (rows_per_level >= 256.0 || env_int("KRYST_ILU_RUN_FREE", 1) == 0)) || rows_per_level >= 512.0) ? 1 : 0) != 0;
     F->last_entry = (int32_t)ptr[n] - 1;
-    F->free_runs = !F->syncfree && !F->ell && ptr[n] > 0 && grant_free_runs();
+    F->free_runs = !F->syncfree && ptr[n] > 0 && grant_free_runs();
     {
         int64_t longest = 0;
         for (int64_t p = 0; p < n; ++p) longest = std::max<int64_t>(longest, ptr[p + 1] - ptr[p]);
@@ -2311,9 +2313,9 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         F->ell = maxlen <= ELLW;
         F->held = maxlen <= 8 ? 8 : 16;
         const double rows_per_level = (double)n / (double)std::max<size_t>(1, F->lvl_off.size() - 1);
-        F->syncfree = env_int("KRYST_ILU_SYNCFREE", (F->ell || rows_per_level >= 512.0) ? 1 : 0) != 0;
+        F->syncfree = env_int("KRYST_ILU_SYNCFREE", ((F->ell && (rows_per_level >= 256.0 || env_int("KRYST_ILU_RUN_FREE", 1) == 0)) || rows_per_level >= 512.0) ? 1 : 0) != 0;
         F->last_entry = (int32_t)fn - 1;
-        F->free_runs = !F->syncfree && !F->ell && fn > 0 && grant_free_runs();
+        F->free_runs = !F->syncfree && fn > 0 && grant_free_runs();
         int32_t* d_pos = which == 0 ? t.posL : t.posU;
         rc = up(&F->d_row, rowid);
         if (rc == KRYST_OK) rc = up(&F->d_ptr, ptr);
