@@ -679,8 +679,12 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
     // every load of the look-ahead is issued by every lane (clamped indices): the waits can then be COUNTED (s_waitcnt vmcnt(n))
     auto head_of = [&](int32_t ch) -> Head {
         Head h;
-        const int32_t p = P0 + (ch << 6) + lane, pc = p < P1 ? p : P1 - 1;
-        h.k0 = ptr[pc]; h.k1 = ptr[pc + 1]; h.s = in[pc]; h.dg = FORWARD ? 1.0 : diag[pc];
+        const int32_t p = P0 + (ch << 6) + lane;
+        const uint32_t pc = (uint32_t)(p < P1 ? p : P1 - 1);
+        const int32_t* pp = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(ptr) + pc * 4u);
+        h.k0 = pp[0]; h.k1 = pp[1];
+        h.s = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(in) + pc * 8u);
+        h.dg = FORWARD ? 1.0 : *reinterpret_cast<const double*>(reinterpret_cast<const char*>(diag) + pc * 8u);
         h.p = p < P1 ? p : -1;
         if (p >= P1) h.k1 = h.k0;
         return h;
@@ -691,9 +695,10 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
     auto stage_of = [&](const Head& h, Stage& st) {
         const int32_t kb = __builtin_amdgcn_readfirstlane(h.k0);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int32_t k = kb + 64 * q + lane < kmax ? kb + 64 * q + lane : kmax;
-            st.c[q] = col[k]; st.v[q] = val[k];
+        for (int q = 0; q < 8; ++q) {                                       // (32-bit byte offsets from the uniform base: one address instruction per load)
+            const uint32_t k = (uint32_t)(kb + 64 * q + lane < kmax ? kb + 64 * q + lane : kmax);
+            st.c[q] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(col) + k * 4u);
+            st.v[q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(val) + k * 8u);
         }
     };
     double* const stage_v = reinterpret_cast<double*>(&trf_lds[PRIV + (uint32_t)w * 1024u]);       // this wave's 8 KiB: 512 values, 512 columns; the
@@ -746,7 +751,6 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
             const bool here = u < nh, near = here && c >= P0 && hc.p - c < reach;
             word[u] = near ? ((uint32_t)(c - P0) & (TRF_RING - 1)) * 2 : here ? PRIV + (threadIdx.x * 8 + u) * 2 : CONSTP;
             etag[u] = near ? (uint32_t)(c - P0) + 1u : here ? TAG_PRIV : TAG_CONST;
-            if (!here) bc.v[u] = 0.0;
             if (here && !near) vecm |= 1u << u;
             if (near) gpos = c > gpos ? c : gpos;
         }
