@@ -128,12 +128,18 @@ struct TriFactor {                  // one triangular factor in level order
     // on a row pointer -- one round trip less on a latency-bound kernel
     int32_t* d_ecol = nullptr; double* d_eval = nullptr; uint8_t* d_elen = nullptr; int64_t npos = 0; bool ell = false;
     bool syncfree = false;          // ELL factor solved by ONE sync-free launch (KRYST_ILU_SYNCFREE=0: one launch per level)
+    // operand streams of tri_run_free_kernel, built at set-up: per chunk of 64 level-order positions of a narrow run, [operand 0..7][lane] -- a
+    // descriptor (> 0: the ring tag of an operand of this run that lies within reach, < 0: 0x80000000 | position of an operand to be gathered
+    // from the vector, 0: no such entry) and the coefficient; what a lane needs lies where a coalesced load puts it, and nothing is classified per apply
+    int32_t* d_fdesc = nullptr; double* d_fval = nullptr;
+    std::vector<int32_t> run_cbase; // first chunk of every narrow run in the streams, in the order enqueue_factor meets them
     int32_t last_entry = -1;        // index of the factor's last stored entry (tri_run_free_kernel clamps its look-ahead to it)
     bool free_runs = false;         // runs of narrow levels take tri_run_free_kernel (its 128 KiB of LDS were granted at set-up): the vector starts as sentinels
     int held = 16;                  // entries of a row the CSR sync-free kernel holds in registers (8: no row is longer than that)
     std::vector<int32_t> lvl_off;   // host: position offsets per level
     int32_t* d_lvl_off = nullptr;
     void free_all() { (void)hipFree(d_ptr); (void)hipFree(d_col); (void)hipFree(d_val); (void)hipFree(d_row); (void)hipFree(d_diag); (void)hipFree(d_lvl_off);
+                      (void)hipFree(d_fdesc); (void)hipFree(d_fval);
                       (void)hipFree(d_ecol); (void)hipFree(d_eval); (void)hipFree(d_elen); }
     EllView view() const { return EllView{d_ecol, d_eval, d_elen, npos}; }
 };
@@ -657,7 +663,8 @@ template <bool FORWARD, int H>
 __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
                                                                    const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
                                                                    const double* __restrict__ val, const double* __restrict__ diag,
-                                                                   int32_t P0, int32_t P1, int32_t kmax, int tune) {
+                                                                   const int32_t* __restrict__ fdesc, const double* __restrict__ fval, int32_t cbase,
+                                                                   int32_t P0, int32_t P1, int tune) {
     static_assert(H == 8, "eight private pairs per lane");
     if (args->skip) return;
     extern __shared__ unsigned long long trf_lds[];                      // [TRF_RING][2] ring, [TRF_THREADS][8][2] private pairs, [2] the constant pair
@@ -669,13 +676,9 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
     const int W = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t nchunk = (P1 - P0 + 63) >> 6;
     const int batch = tune & 255;
-    // an operand counts as "in the ring" when no wave can have reused its slot yet in the ordinary course of things: the most advanced wave is
-    // W chunks ahead of the least advanced one (further only if its rows need none of the rows in between; the tags catch that)
-    const int32_t reach = TRF_RING - 64 * (W + 1);
 
     struct Head { int32_t p, k0, k1; double s, dg; };
-    struct Body { int32_t c[H]; double v[H]; };
-    struct Stage { int32_t c[8]; double v[8]; };                           // a chunk's entries as they lie in memory: entry kb + 64 q + lane in slot q
+    struct Stage { int32_t d[H]; double v[H]; };                           // a chunk's operand streams: descriptor and coefficient of operand u of this lane's row
     // every load of the look-ahead is issued by every lane (clamped indices): the waits can then be COUNTED (s_waitcnt vmcnt(n))
     auto head_of = [&](int32_t ch) -> Head {
         Head h;
@@ -689,39 +692,16 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
         if (p >= P1) h.k1 = h.k0;
         return h;
     };
-    // The entries of 64 consecutive rows are consecutive in memory: the wave loads them as they lie (512 of them, 16 fully coalesced loads) and
-    // deals them out to the rows through LDS.  (With each lane loading ITS row's entries -- the pipe kernel's way -- every cache line is asked
-    // for by eight different instructions: 650 L1 accesses per chunk, the L1 busy or stalled on pending lines for 60 % of the run; PMC, round 4.)
-    auto stage_of = [&](const Head& h, Stage& st) {
-        const int32_t kb = __builtin_amdgcn_readfirstlane(h.k0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {                                       // (32-bit byte offsets from the uniform base: one address instruction per load)
-            const uint32_t k = (uint32_t)(kb + 64 * q + lane < kmax ? kb + 64 * q + lane : kmax);
-            st.c[q] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(col) + k * 4u);
-            st.v[q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(val) + k * 8u);
-        }
-    };
-    double* const stage_v = reinterpret_cast<double*>(&trf_lds[PRIV + (uint32_t)w * 1024u]);       // this wave's 8 KiB: 512 values, 512 columns; the
-    int32_t* const stage_c = reinterpret_cast<int32_t*>(stage_v + 512);                             // lanes' private pairs once the rows are dealt out
-    auto deal = [&](const Head& h, const Stage& st, Body& b) -> int {      // returns how many of the row's first H entries were staged
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { stage_v[64 * q + lane] = st.v[q]; stage_c[64 * q + lane] = st.c[q]; }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        const int32_t off = h.k0 - __builtin_amdgcn_readfirstlane(h.k0);
-        const int len = h.k1 - h.k0;
-        int n = 0;
+    // 16 fully coalesced loads (32-bit byte offsets from the uniform base: one address instruction per load).  (With each lane loading ITS row's
+    // entries from the CSR arrays -- the pipe kernel's way -- every cache line is asked for by eight different instructions: 650 L1 accesses per
+    // chunk, the L1 busy or stalled on pending lines for 60 % of the run; PMC, round 4.)
+    auto stage_of = [&](int32_t ch, Stage& st) {
+        const uint32_t base = (uint32_t)(cbase + (ch < nchunk ? ch : nchunk - 1)) * (uint32_t)(H * 64) + (uint32_t)lane;
 #pragma unroll
         for (int u = 0; u < H; ++u) {
-            const int32_t idx = off + u < 511 ? off + u : 511;
-            const bool here = u < len && off + u < 512;
-            const int32_t c = stage_c[idx]; const double v = stage_v[idx];
-            b.c[u] = here ? c : 0; b.v[u] = here ? v : 0.0;
-            n += here ? 1 : 0;
+            st.d[u] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(fdesc) + (base + 64u * u) * 4u);
+            st.v[u] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(fval) + (base + 64u * u) * 8u);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        return n;
     };
     auto pair_at = [&](uint32_t word, unsigned long long& a, unsigned long long& b) {
         a = __hip_atomic_load(&trf_lds[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -737,36 +717,39 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
         put_pair(((uint32_t)(p - P0) & (TRF_RING - 1)) * 2, res, (uint32_t)(p - P0) + 1u);
     };
     auto solved = [](double x) { return (unsigned long long)__double_as_longlong(x) != KR_TRI_SENTINEL; };
-    // one chunk: (hc, bc) are here, hn is the next chunk's head; bn and hnn are requested on the way
-    auto chunk = [&](const Head& hc, const Head& hn, Stage& st, Head& hnn, int32_t ch) {
-        Body bc;
-        const int len = hc.k1 - hc.k0, nh = deal(hc, st, bc);
+    // one chunk: its head hc and its operand streams bc are here; the next chunk's streams (into st) and the head after that are requested on the way
+    auto chunk = [&](const Head& hc, const Stage& bc, Stage& st, Head& hnn, int32_t ch) {
+        const int len = hc.k1 - hc.k0, nh = len < H ? len : H;
         // every operand as (word offset of its pair, expected tag); bit u of `vecm`: operand u comes from the vector, of `vpend`: ... and is not there yet
         uint32_t word[H], etag[H];
         unsigned vecm = 0, vpend = 0;
         int32_t gpos = -1;
+        auto pos_of = [&](int u) -> int32_t { return bc.d[u] > 0 ? P0 + bc.d[u] - 1 : (int32_t)((uint32_t)bc.d[u] & 0x7fffffffu); };
 #pragma unroll
         for (int u = 0; u < H; ++u) {
-            const int32_t c = bc.c[u];
-            const bool here = u < nh, near = here && c >= P0 && hc.p - c < reach;
-            word[u] = near ? ((uint32_t)(c - P0) & (TRF_RING - 1)) * 2 : here ? PRIV + (threadIdx.x * 8 + u) * 2 : CONSTP;
-            etag[u] = near ? (uint32_t)(c - P0) + 1u : here ? TAG_PRIV : TAG_CONST;
-            if (here && !near) vecm |= 1u << u;
-            if (near) gpos = c > gpos ? c : gpos;
+            const int32_t d = hc.p >= 0 ? bc.d[u] : 0;
+            const bool near = d > 0, vec = d < 0;
+            word[u] = near ? ((uint32_t)(d - 1) & (TRF_RING - 1)) * 2 : vec ? PRIV + (threadIdx.x * 8 + u) * 2 : CONSTP;
+            etag[u] = near ? (uint32_t)d : vec ? TAG_PRIV : TAG_CONST;
+            if (vec) vecm |= 1u << u;
+            if (near) gpos = d > gpos ? d : gpos;
         }
-        if (__any(vecm != 0)) {                                            // gathers from the vector, BEFORE the look-ahead is requested
+        if (gpos >= 0) gpos += P0 - 1;
+        // gathers from the vector: requested BEFORE the look-ahead (vector loads return in order), by every lane for every operand (lanes without
+        // such an operand at one common address) so that the wait below can be COUNTED and covers the gathers alone -- waited for in per-operand
+        // branches they cost a chunk two or three L2 round trips one after the other
+        double xg[H];
 #pragma unroll
-            for (int u = 0; u < H; ++u)
-                if (__any((vecm >> u) & 1u)) {
-                    const bool mine = (vecm >> u) & 1u;
-                    const double x = __hip_atomic_load(&out[mine ? bc.c[u] : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (mine) { const bool ok = solved(x); put_pair(word[u], x, ok ? TAG_PRIV : 0u); if (!ok) vpend |= 1u << u; }
-                }
-        }
+        for (int u = 0; u < H; ++u) xg[u] = __hip_atomic_load(&out[((vecm >> u) & 1u) ? pos_of(u) : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("" ::: "memory");
-        stage_of(hn, st);                                                  // the look-ahead: in flight while this chunk waits and computes
+        stage_of(ch + W, st);                                              // the look-ahead: in flight while this chunk waits and computes
         hnn = head_of(ch + 2 * W);
         asm volatile("" ::: "memory");
+        if (__any(vecm != 0)) {
+#pragma unroll
+            for (int u = 0; u < H; ++u)
+                if ((vecm >> u) & 1u) { const bool ok = solved(xg[u]); put_pair(word[u], xg[u], ok ? TAG_PRIV : 0u); if (!ok) vpend |= 1u << u; }
+        }
         bool done = hc.p < 0, wait = !done && gpos >= 0, headdone = false;
         double s = hc.s;
         int cons = 0, fails = 0;
@@ -811,7 +794,7 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
                                     const bool over = etag[u] < TAG_PRIV && ((uint32_t)(ra[u] >> 32) > etag[u] || (uint32_t)(rb[u] >> 32) > etag[u]);
                                     if (over) { word[u] = PRIV + (threadIdx.x * 8 + u) * 2; etag[u] = TAG_PRIV; put_pair(word[u], 0.0, 0u); vecm |= 1u << u; vpend |= 1u << u; }
                                     if ((vpend >> u) & 1u) {
-                                        const double x = __hip_atomic_load(&out[bc.c[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        const double x = __hip_atomic_load(&out[pos_of(u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         if (solved(x)) { put_pair(word[u], x, TAG_PRIV); vpend &= ~(1u << u); }
                                     }
                                 }
@@ -903,11 +886,33 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
         if (!lean()) if (!run(std::true_type{})) run(std::false_type{});
     };
     Head hc = head_of(w), hn = head_of(w + W), hnn;
-    Stage st;
-    stage_of(hc, st);
-    for (int32_t ch = w; ch < nchunk; ch += W) {
-        chunk(hc, hn, st, hnn, ch);
+    Stage s0, s1;
+    stage_of(w, s0);
+    for (int32_t ch = w; ch < nchunk; ch += 2 * W) {
+        chunk(hc, s0, s1, hnn, ch);
+        if (ch + W >= nchunk) break;
         hc = hn; hn = hnn;
+        chunk(hc, s1, s0, hnn, ch + W);
+        hc = hn; hn = hnn;
+    }
+}
+
+// the operand streams of one narrow run (see TriFactor): one thread per row slot of its chunks
+__global__ __launch_bounds__(256) void trf_stream_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                         int32_t P0, int32_t P1, int32_t reach, int32_t cbase, int32_t* fdesc, double* fval) {
+    const int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (((P1 - P0 + 63) >> 6) << 6)) return;
+    const int32_t p = P0 + slot;
+    const size_t base = (size_t)(cbase + (slot >> 6)) * 512 + (size_t)(slot & 63);
+    int32_t k0 = 0, k1 = 0;
+    if (p < P1) { k0 = ptr[p]; k1 = ptr[p + 1]; }
+    for (int u = 0; u < 8; ++u) {
+        int32_t d = 0; double v = 0.0;
+        if (k0 + u < k1) {
+            const int32_t c = col[k0 + u]; v = val[k0 + u];
+            d = (c >= P0 && p - c < reach) ? c - P0 + 1 : (int32_t)(0x80000000u | (uint32_t)c);
+        }
+        fdesc[base + 64 * (size_t)u] = d; fval[base + 64 * (size_t)u] = v;
     }
 }
 
@@ -941,6 +946,45 @@ static bool grant_free_runs() {
 
 static const int NARROW = 2048;     // levels with at most this many rows are folded into one-workgroup runs (CSR fallback)
 
+// The operand streams of every narrow run of a factor that takes tri_run_free_kernel (F->free_runs), in the order enqueue_factor meets the runs.
+// 6 KiB per chunk of 64 rows.  Not enough memory, or offsets past 32 bits: the factor keeps the barrier kernel (free_runs = false).
+static int32_t build_free_streams(TriFactor* F, hipStream_t st) {
+    if (!F->free_runs) return KRYST_OK;
+    const int nl = (int)F->lvl_off.size() - 1;
+    std::vector<std::pair<int32_t, int32_t>> runs;
+    size_t chunks = 0;
+    for (int lv = 0; lv < nl;) {
+        if (F->lvl_off[lv + 1] - F->lvl_off[lv] <= NARROW) {
+            int l1 = lv + 1;
+            while (l1 < nl && F->lvl_off[l1 + 1] - F->lvl_off[l1] <= NARROW) ++l1;
+            runs.emplace_back(F->lvl_off[lv], F->lvl_off[l1]);
+            F->run_cbase.push_back((int32_t)chunks);
+            chunks += (size_t)(F->lvl_off[l1] - F->lvl_off[lv] + 63) / 64;
+            lv = l1;
+        } else ++lv;
+    }
+    if (chunks == 0 || chunks * 512 * 8 >= ((size_t)1 << 32) ||
+        hipMalloc(&F->d_fdesc, chunks * 512 * sizeof(int32_t)) != hipSuccess || hipMalloc(&F->d_fval, chunks * 512 * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(F->d_fdesc); (void)hipFree(F->d_fval); F->d_fdesc = nullptr; F->d_fval = nullptr; F->run_cbase.clear();
+        F->free_runs = false;
+        if (F->ell) F->syncfree = true;                    // (an ELL factor's other form)
+        return KRYST_OK;
+    }
+    // an operand counts as "in the ring" when no wave can have reused its slot yet in the ordinary course of things: the most advanced wave is
+    // W <= 8 chunks ahead of the least advanced one (further only if its rows need none of the rows in between; the tags catch that)
+    const int32_t reach = TRF_RING - 64 * (8 + 1);
+    for (size_t r = 0; r < runs.size(); ++r) {
+        const int32_t slots = (runs[r].second - runs[r].first + 63) / 64 * 64;
+        hipLaunchKernelGGL(trf_stream_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, F->d_ptr, F->d_col, F->d_val, runs[r].first, runs[r].second,
+                           reach, F->run_cbase[r], F->d_fdesc, F->d_fval);
+    }
+    KR_HIP(hipGetLastError());
+    KR_HIP(hipStreamSynchronize(st));
+    return KRYST_OK;
+}
+
+
 template <bool FORWARD>
 static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* d_args, const double* in, double* out) {
     if (F.syncfree && F.npos > 0) {
@@ -957,6 +1001,7 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
     }
     const int nl = (int)F.lvl_off.size() - 1;
     int lv = 0;
+    size_t run_index = 0;
     while (lv < nl) {
         const int rows = F.lvl_off[lv + 1] - F.lvl_off[lv];
         if (rows <= NARROW && (!F.ell || F.free_runs)) {
@@ -977,7 +1022,8 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
                 const int fw = env_int("KRYST_ILU_FREE_WAVES", mean_rows >= 64 ? 8 : 4);
                 const unsigned waves = fw >= 8 ? 8u : fw >= 4 ? 4u : fw >= 2 ? 2u : 1u;
                 hipLaunchKernelGGL((tri_run_free_kernel<FORWARD, 8>), dim3(1), dim3(64 * waves), (size_t)TRF_LDS_BYTES, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
-                                   F.d_diag, F.lvl_off[lv], F.lvl_off[l1], F.last_entry, env_int("KRYST_ILU_FREE_TUNE", 1 | (1 << 9) | 16384));
+                                   F.d_diag, F.d_fdesc, F.d_fval, F.run_cbase[run_index++], F.lvl_off[lv], F.lvl_off[l1],
+                                   env_int("KRYST_ILU_FREE_TUNE", 1 | (1 << 9) | 16384));
             } else if (env_int("KRYST_ILU_RUN_PIPE", 1) != 0)
                 hipLaunchKernelGGL((tri_run_pipe_kernel<FORWARD, 8>), dim3(1), dim3(run_threads), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
                                    F.d_diag, F.d_lvl_off, lv, l1);
@@ -1279,6 +1325,7 @@ static int32_t build_factor(int64_t n, const FlatRows& ent, const hvec<double>& 
     }
     KR_TRY(up(&F->d_ptr, ptr)); KR_TRY(up(&F->d_col, col)); KR_TRY(up(&F->d_val, val)); KR_TRY(up(&F->d_row, rowid));
     KR_TRY(up(&F->d_diag, dg)); KR_TRY(up(&F->d_lvl_off, F->lvl_off));
+    KR_TRY(build_free_streams(F, tl_setup_stream));
     return KRYST_OK;
 }
 
@@ -2340,6 +2387,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
             else hipLaunchKernelGGL((gen_fill_kernel<false>), dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, n, F->d_row, d_pos, F->d_ptr, t.dg,
                                     F->d_col, F->d_val, F->d_diag, F->ell ? F->d_ecol : nullptr, F->d_eval, F->ell ? F->d_elen : nullptr);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("factor fill kernel failed"); rc = KRYST_ERR_HIP; }   // (pos lives in a host vector reused below)
+            if (rc == KRYST_OK) rc = build_free_streams(F, ctx->s_main);
         }
     }
     if (rc == KRYST_OK && hipMalloc(&D->d_mapLU, nb + 4) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
