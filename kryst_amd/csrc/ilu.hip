@@ -653,9 +653,9 @@ __global__ __launch_bounds__(1024) void tri_run_pipe_kernel(const TriArgs* args,
 // allowed: rows longer than H, operands not yet in the vector, ring slots reused under a reader -- a LATER tag).  tri_run_kernel's operations
 // in tri_run_kernel's order.  Progress: the lowest unsolved position's row needs only solved rows, and the wave that owns its chunk has finished
 // all its earlier chunks (all positions below), so it is on that chunk now; every wave of the one workgroup is resident.  Positions that share
-// a ring slot belong to one wave (TRF_RING / 64 is a multiple of the wave count) and are solved in order.  The look-ahead: a chunk's entries are
-// requested one chunk ahead, as they lie in memory (16 coalesced loads), and dealt out to the rows through LDS.  A poll budget turns a logic
-// error into NaNs instead of a hung GPU.
+// a ring slot belong to one wave (TRF_RING / 64 is a multiple of the wave count) and are solved in order.  The look-ahead: a chunk's operand
+// streams (descriptor and coefficient per operand and lane, laid out at set-up: trf_stream_kernel) are requested one chunk ahead with 16 coalesced
+// loads.  A poll budget turns a logic error into NaNs instead of a hung GPU.
 #define TRF_RING 4096
 #define TRF_THREADS 512
 #define TRF_LDS_BYTES (TRF_RING * 16 + TRF_THREADS * 8 * 16 + 16)
