@@ -718,7 +718,7 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
     };
     auto solved = [](double x) { return (unsigned long long)__double_as_longlong(x) != KR_TRI_SENTINEL; };
     // one chunk: its head hc and its operand streams bc are here; the next chunk's streams (into st) and the head after that are requested on the way
-    auto chunk = [&](const Head& hc, const Stage& bc, Stage& st, Head& hnn, int32_t ch) {
+    auto chunk = [&](const Head& hc, const Stage& bc, const Stage& nx, Stage& st, Head& hnn, int32_t ch, double (&xg)[H]) {
         const int len = hc.k1 - hc.k0, nh = len < H ? len : H;
         // every operand as (word offset of its pair, expected tag); bit u of `vecm`: operand u comes from the vector, of `vpend`: ... and is not there yet
         uint32_t word[H], etag[H];
@@ -735,21 +735,23 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
             if (near) gpos = d > gpos ? d : gpos;
         }
         if (gpos >= 0) gpos += P0 - 1;
-        // gathers from the vector: requested BEFORE the look-ahead (vector loads return in order), by every lane for every operand (lanes without
-        // such an operand at one common address) so that the wait below can be COUNTED and covers the gathers alone -- waited for in per-operand
-        // branches they cost a chunk two or three L2 round trips one after the other
-        double xg[H];
-#pragma unroll
-        for (int u = 0; u < H; ++u) xg[u] = __hip_atomic_load(&out[((vecm >> u) & 1u) ? pos_of(u) : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::: "memory");
-        stage_of(ch + W, st);                                              // the look-ahead: in flight while this chunk waits and computes
-        hnn = head_of(ch + 2 * W);
-        asm volatile("" ::: "memory");
+        // Gathers from the vector.  They are requested ONE CHUNK AHEAD (the next chunk's descriptors are here by now; an operand that far back has
+        // long been solved -- if not, the pair stays invalid and the general loop polls the vector), by every lane for every operand (lanes without
+        // such an operand at one common address) and in front of the look-ahead, so that every wait is a COUNTED one.  (Waited for in per-operand
+        // branches at the chunk's start they were two or three L2 round trips one after the other: 30 -> 23 ms; a chunk ahead: no wait at all.)
         if (__any(vecm != 0)) {
 #pragma unroll
             for (int u = 0; u < H; ++u)
                 if ((vecm >> u) & 1u) { const bool ok = solved(xg[u]); put_pair(word[u], xg[u], ok ? TAG_PRIV : 0u); if (!ok) vpend |= 1u << u; }
         }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < H; ++u)
+            xg[u] = __hip_atomic_load(&out[nx.d[u] < 0 ? (int32_t)((uint32_t)nx.d[u] & 0x7fffffffu) : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::: "memory");
+        stage_of(ch + 2 * W, st);                                          // the look-ahead: in flight while this chunk and the next wait and compute
+        hnn = head_of(ch + 2 * W);
+        asm volatile("" ::: "memory");
         bool done = hc.p < 0, wait = !done && gpos >= 0, headdone = false;
         double s = hc.s;
         int cons = 0, fails = 0;
@@ -886,13 +888,21 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
         if (!lean()) if (!run(std::true_type{})) run(std::false_type{});
     };
     Head hc = head_of(w), hn = head_of(w + W), hnn;
-    Stage s0, s1;
-    stage_of(w, s0);
-    for (int32_t ch = w; ch < nchunk; ch += 2 * W) {
-        chunk(hc, s0, s1, hnn, ch);
+    Stage sa, sb, sc;
+    double xg[H];
+    stage_of(w, sa);
+#pragma unroll
+    for (int u = 0; u < H; ++u)
+        xg[u] = __hip_atomic_load(&out[sa.d[u] < 0 ? (int32_t)((uint32_t)sa.d[u] & 0x7fffffffu) : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stage_of(w + W, sb);
+    for (int32_t ch = w; ch < nchunk; ch += 3 * W) {
+        chunk(hc, sa, sb, sc, hnn, ch, xg);
         if (ch + W >= nchunk) break;
         hc = hn; hn = hnn;
-        chunk(hc, s1, s0, hnn, ch + W);
+        chunk(hc, sb, sc, sa, hnn, ch + W, xg);
+        if (ch + 2 * W >= nchunk) break;
+        hc = hn; hn = hnn;
+        chunk(hc, sc, sa, sb, hnn, ch + 2 * W, xg);
         hc = hn; hn = hnn;
     }
 }
