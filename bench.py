@@ -764,7 +764,8 @@ def other_configs(K, ctx, steps, warmup):
 def general_ilu(K, ctx):
     """SURVEY 8 row f-2, operators that are NOT 7-point boxes: true ILU(0) of a 27-point stencil on 96^3 (box-stencil wavefront solve,
     tri_box.h) and Ilup(1) of the 7-point Poisson operator on 128^3 (row-pipelined host elimination; its 13-entry factors take the same
-    kernels).  Setup = the second setup of the same operator in this process; apply = HIP events around 10 applies."""
+    kernels), and true ILU(0) of a random band matrix of 2 M rows (deep, narrow dependency levels).  Setup = the second setup of the same operator in
+    this process; apply = HIP events around 10 (5) applies."""
     import numpy as np
     import scipy.sparse as sp
     out = {}
@@ -802,6 +803,31 @@ def general_ilu(K, ctx):
                                         "iterations_per_s": st.iterations / dt, "spmv_encoding": a_.encoding()[0]}
             del b
         out[name] = blk
+        del pc, r, z, a_
+    if os.environ.get("KRYST_BENCH_RANDOM_BAND", "1") != "0":
+        # true ILU(0) of the random band matrix of tools/band_apply.py (2 M rows, 9 per row, |i - j| <= 2000: 10 716 dependency
+        # levels of ~187 rows per factor) -- level-ordered factors, their narrow levels solved by the one-workgroup barrier-free kernel (tri_run_free_kernel)
+        NR = 2000000
+        rng = np.random.default_rng(1)
+        rows = np.repeat(np.arange(NR), 9)
+        cols = np.clip(rows + rng.integers(-2000, 2001, len(rows)), 0, NR - 1)
+        m = sp.csr_matrix((rng.uniform(-1.0, 1.0, len(rows)), (rows, cols)), shape=(NR, NR))
+        del rows, cols
+        m.sum_duplicates()
+        m = m - sp.diags(m.diagonal()) + sp.diags(np.asarray(abs(m).sum(axis=1)).ravel() + 1.0)
+        m = m.tocsr(); m.sort_indices()
+        a_ = K.CsrMatrix.from_csr(NR, NR, m.indptr, m.indices, m.data, ctx=ctx)
+        nnz = int(m.nnz)
+        del m
+        K.TrueIlu0().setup(a_)
+        ctx.synchronize(); t0 = time.perf_counter()
+        pc = K.TrueIlu0().setup(a_)
+        ctx.synchronize(); setup_ms = (time.perf_counter() - t0) * 1e3
+        r = ctx.vec(NR).fill_splitmix(3); z = ctx.vec(NR)
+        ms = min(pc.bench_apply(r, z, 5) for _ in range(2))
+        info = pc.ilu_info()
+        out["true_ilu0_random_band_2m"] = {"rows": NR, "nnz": nnz, "setup_ms": setup_ms, "apply_ms": ms, "form": info["form"], "levels_L_U": info["levels"],
+                                           "us_per_level": ms * 1e3 / max(1, sum(info["levels"]))}
         del pc, r, z, a_
     return out
 
