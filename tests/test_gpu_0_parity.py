@@ -580,7 +580,7 @@ def test_measurement_hooks_of_round_4_leave_the_operator_alone(ctx):
     assert device_count() >= 1
 
 
-@pytest.mark.parametrize("pipe", ["free8", "free4", "free1", "free8-wide-first-level", "1", "0"])
+@pytest.mark.parametrize("pipe", ["free8", "free4", "free1", "free8-wide-first-level", "free8-wide-level-in-the-middle", "1", "0"])
 def test_narrow_level_runs_of_a_deep_factor_bit_exact(ctx, pipe, monkeypatch):
     """The one-workgroup run kernels for deep, narrow factors (tri_run_free_kernel with 16 / 4 / 1 waves -- no barriers, values handed over
     through an LDS ring of the last 4 096 positions, older ones gathered from the vector --, tri_run_pipe_kernel / tri_run_kernel, KRYST_ILU_SYNCFREE=0) on a factor of
@@ -601,9 +601,16 @@ def test_narrow_level_runs_of_a_deep_factor_bit_exact(ctx, pipe, monkeypatch):
     near = rows + rng.integers(-300, 301, len(rows))
     far = rng.integers(0, n, len(rows))                                   # one entry in ten couples to ANY row: dependencies far below the window
     cols = np.clip(np.where(rng.random(len(rows)) < 0.1, far, near), 0, n - 1)
-    m = sp.csr_matrix((rng.uniform(-1.0, 1.0, len(rows)), (rows, cols)), shape=(n, n)); m.sum_duplicates()
-    dense_rows = rng.choice(np.arange(free, n), 50, replace=False)        # rows with ~30 entries: longer than the held eight
-    extra = sp.csr_matrix((rng.uniform(-1.0, 1.0, 50 * 24), (np.repeat(dense_rows, 24), np.clip(np.repeat(dense_rows, 24) + rng.integers(-2000, 2001, 50 * 24), 0, n - 1))), shape=(n, n))
+    vals = rng.uniform(-1.0, 1.0, len(rows))
+    chain = n
+    if pipe.endswith("-wide-level-in-the-middle"):
+        # 2 500 more rows that all hang on ONE row half way down the chain: a level of > 2 048 rows between two runs of narrow levels
+        # (a level kernel of its own; the second run's first chunks take their operands "from before the run")
+        rows = np.concatenate([rows, np.arange(n, n + 2500)]); cols = np.concatenate([cols, np.full(2500, 20000)]); vals = np.concatenate([vals, rng.uniform(-1.0, 1.0, 2500)])
+        n += 2500
+    m = sp.csr_matrix((vals, (rows, cols)), shape=(n, n)); m.sum_duplicates()
+    dense_rows = rng.choice(np.arange(free, chain), 50, replace=False)    # rows with ~30 entries: longer than the held eight
+    extra = sp.csr_matrix((rng.uniform(-1.0, 1.0, 50 * 24), (np.repeat(dense_rows, 24), np.clip(np.repeat(dense_rows, 24) + rng.integers(-2000, 2001, 50 * 24), 0, chain - 1))), shape=(n, n))
     m = (m + extra).tocsr(); m.sum_duplicates()
     m = m - sp.diags(m.diagonal()) + sp.diags(np.asarray(abs(m).sum(axis=1)).ravel() + 1.0)
     m = m.tocsr(); m.sort_indices(); m.eliminate_zeros()
