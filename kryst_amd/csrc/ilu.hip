@@ -946,8 +946,12 @@ __global__ __launch_bounds__(256) void perm_kernel(const TriArgs* args, double* 
 }
 
 // KRYST_ILU_RUN_FREE (default 1): runs of narrow levels without barriers; needs 128 KiB of LDS, twice what a kernel gets without asking
-static bool grant_free_runs() {
+// `long_rows`: the share of the factor's rows with more than the eight entries the kernel's lean loop holds -- such a row sends its whole chunk
+// to the general loop (entries from memory, one at a time), and with many of them the barrier kernel is the faster one (1 M rows, 14 entries per
+// row of A, 21 % long rows: 49 ms against 32; 9 per row, 0.2 %: 11.4 against 14.6).  KRYST_ILU_RUN_FREE=2 takes the kernel regardless.
+static bool grant_free_runs(double long_rows) {
     if (env_int("KRYST_ILU_RUN_FREE", 1) == 0) return false;
+    if (long_rows > 0.01 * (double)env_int("KRYST_ILU_FREE_LONG_PCT", 2) && env_int("KRYST_ILU_RUN_FREE", 1) < 2) return false;
     const bool ok = hipFuncSetAttribute((const void*)tri_run_free_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, TRF_LDS_BYTES) == hipSuccess &&
                     hipFuncSetAttribute((const void*)tri_run_free_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, TRF_LDS_BYTES) == hipSuccess;
     if (!ok) (void)hipGetLastError();
@@ -1327,11 +1331,11 @@ static int32_t build_factor(int64_t n, const FlatRows& ent, const hvec<double>& 
     // there against the sync-free kernel's two fabric trips, 2 us, whatever the width)
     F->syncfree = env_int("KRYST_ILU_SYNCFREE", ((F->ell && (rows_per_level >= 256.0 || env_int("KRYST_ILU_RUN_FREE", 1) == 0)) || rows_per_level >= 512.0) ? 1 : 0) != 0;
     F->last_entry = (int32_t)ptr[n] - 1;
-    F->free_runs = !F->syncfree && ptr[n] > 0 && grant_free_runs();
     {
-        int64_t longest = 0;
-        for (int64_t p = 0; p < n; ++p) longest = std::max<int64_t>(longest, ptr[p + 1] - ptr[p]);
+        int64_t longest = 0, nlong = 0;
+        for (int64_t p = 0; p < n; ++p) { longest = std::max<int64_t>(longest, ptr[p + 1] - ptr[p]); nlong += ptr[p + 1] - ptr[p] > 8; }
         F->held = longest <= 8 ? 8 : 16;
+        F->free_runs = !F->syncfree && ptr[n] > 0 && grant_free_runs(n > 0 ? (double)nlong / (double)n : 0.0);
     }
     KR_TRY(up(&F->d_ptr, ptr)); KR_TRY(up(&F->d_col, col)); KR_TRY(up(&F->d_val, val)); KR_TRY(up(&F->d_row, rowid));
     KR_TRY(up(&F->d_diag, dg)); KR_TRY(up(&F->d_lvl_off, F->lvl_off));
@@ -2368,7 +2372,8 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         rows_by_level(lv, rowid, pos, F->lvl_off);
         int32_t maxlen = 0;
         ptr[0] = 0;
-        for (int32_t p = 0; p < n; ++p) { const int32_t L = len[rowid[p]]; ptr[(size_t)p + 1] = ptr[p] + L; maxlen = std::max(maxlen, L); }
+        int64_t nlong = 0;
+        for (int32_t p = 0; p < n; ++p) { const int32_t L = len[rowid[p]]; ptr[(size_t)p + 1] = ptr[p] + L; maxlen = std::max(maxlen, L); nlong += L > 8; }
         const size_t fn = (size_t)ptr[n];
         F->npos = n;
         F->ell = maxlen <= ELLW;
@@ -2376,7 +2381,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         const double rows_per_level = (double)n / (double)std::max<size_t>(1, F->lvl_off.size() - 1);
         F->syncfree = env_int("KRYST_ILU_SYNCFREE", ((F->ell && (rows_per_level >= 256.0 || env_int("KRYST_ILU_RUN_FREE", 1) == 0)) || rows_per_level >= 512.0) ? 1 : 0) != 0;
         F->last_entry = (int32_t)fn - 1;
-        F->free_runs = !F->syncfree && fn > 0 && grant_free_runs();
+        F->free_runs = !F->syncfree && fn > 0 && grant_free_runs(n > 0 ? (double)nlong / (double)n : 0.0);
         int32_t* d_pos = which == 0 ? t.posL : t.posU;
         rc = up(&F->d_row, rowid);
         if (rc == KRYST_OK) rc = up(&F->d_ptr, ptr);
