@@ -131,15 +131,16 @@ struct TriFactor {                  // one triangular factor in level order
     // operand streams of tri_run_free_kernel, built at set-up: per chunk of 64 level-order positions of a narrow run, [operand 0..7][lane] -- a
     // descriptor (> 0: the ring tag of an operand of this run that lies within reach, < 0: 0x80000000 | position of an operand to be gathered
     // from the vector, 0: no such entry) and the coefficient; what a lane needs lies where a coalesced load puts it, and nothing is classified per apply
-    int32_t* d_fdesc = nullptr; double* d_fval = nullptr;
+    int32_t* d_fdesc = nullptr; double* d_fval = nullptr; int32_t* d_fpos = nullptr; int32_t* d_vreal = nullptr;   // (+ the operand's position in the vector; per virtual row its row and first / last flags)
     std::vector<int32_t> run_cbase; // first chunk of every narrow run in the streams, in the order enqueue_factor meets them
+    std::vector<int32_t> run_nvirt; // virtual rows of every narrow run (a row of more than eight entries is a chain of them)
     int32_t last_entry = -1;        // index of the factor's last stored entry (tri_run_free_kernel clamps its look-ahead to it)
     bool free_runs = false;         // runs of narrow levels take tri_run_free_kernel (its 128 KiB of LDS were granted at set-up): the vector starts as sentinels
     int held = 16;                  // entries of a row the CSR sync-free kernel holds in registers (8: no row is longer than that)
     std::vector<int32_t> lvl_off;   // host: position offsets per level
     int32_t* d_lvl_off = nullptr;
     void free_all() { (void)hipFree(d_ptr); (void)hipFree(d_col); (void)hipFree(d_val); (void)hipFree(d_row); (void)hipFree(d_diag); (void)hipFree(d_lvl_off);
-                      (void)hipFree(d_fdesc); (void)hipFree(d_fval);
+                      (void)hipFree(d_fdesc); (void)hipFree(d_fval); (void)hipFree(d_fpos); (void)hipFree(d_vreal);
                       (void)hipFree(d_ecol); (void)hipFree(d_eval); (void)hipFree(d_elen); }
     EllView view() const { return EllView{d_ecol, d_eval, d_elen, npos}; }
 };
@@ -661,10 +662,12 @@ __global__ __launch_bounds__(1024) void tri_run_pipe_kernel(const TriArgs* args,
 #define TRF_LDS_BYTES (TRF_RING * 16 + TRF_THREADS * 8 * 16 + 16)
 template <bool FORWARD, int H>
 __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
-                                                                   const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
-                                                                   const double* __restrict__ val, const double* __restrict__ diag,
-                                                                   const int32_t* __restrict__ fdesc, const double* __restrict__ fval, int32_t cbase,
-                                                                   int32_t P0, int32_t P1, int tune) {
+                                                                   const double* __restrict__ diag, const int32_t* __restrict__ vreal,
+                                                                   const int32_t* __restrict__ fdesc, const double* __restrict__ fval,
+                                                                   const int32_t* __restrict__ fpos, int32_t cbase, int32_t NV, int tune) {
+    // Positions are VIRTUAL rows of this run, 0 .. NV: a row of at most eight entries is one virtual row; a longer one is a chain of them -- the
+    // first with eight operands, each further one with the partial sum of the one before as operand 0 (taken over, not subtracted) and seven
+    // more -- and only the last of a chain divides and stores to the vector.  Same subtractions in the same order (trf_stream_kernel).
     static_assert(H == 8, "eight private pairs per lane");
     if (args->skip) return;
     extern __shared__ unsigned long long trf_lds[];                      // [TRF_RING][2] ring, [TRF_THREADS][8][2] private pairs, [2] the constant pair
@@ -674,22 +677,23 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
     if (threadIdx.x == 0) { trf_lds[CONSTP] = (unsigned long long)TAG_CONST << 32; trf_lds[CONSTP + 1] = (unsigned long long)TAG_CONST << 32; }
     __syncthreads();
     const int W = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int32_t nchunk = (P1 - P0 + 63) >> 6;
+    const int32_t nchunk = (NV + 63) >> 6;
     const int batch = tune & 255;
 
-    struct Head { int32_t p, k0, k1; double s, dg; };
+    struct Head { int32_t p, vp; bool first, last; double s, dg; };       // p: the row's position in the vector (-1: no row), vp: virtual position
     struct Stage { int32_t d[H]; double v[H]; };                           // a chunk's operand streams: descriptor and coefficient of operand u of this lane's row
     // every load of the look-ahead is issued by every lane (clamped indices): the waits can then be COUNTED (s_waitcnt vmcnt(n))
     auto head_of = [&](int32_t ch) -> Head {
         Head h;
-        const int32_t p = P0 + (ch << 6) + lane;
-        const uint32_t pc = (uint32_t)(p < P1 ? p : P1 - 1);
-        const int32_t* pp = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(ptr) + pc * 4u);
-        h.k0 = pp[0]; h.k1 = pp[1];
+        const int32_t cc = ch < nchunk ? ch : nchunk - 1;
+        const int32_t vr = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(vreal) + ((uint32_t)(cbase + cc) * 64u + (uint32_t)lane) * 4u);
+        const bool valid = ch < nchunk && vr != 0;
+        const uint32_t pc = valid ? (uint32_t)(vr & 0x1FFFFFFF) - 1u : 0u;
         h.s = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(in) + pc * 8u);
         h.dg = FORWARD ? 1.0 : *reinterpret_cast<const double*>(reinterpret_cast<const char*>(diag) + pc * 8u);
-        h.p = p < P1 ? p : -1;
-        if (p >= P1) h.k1 = h.k0;
+        h.p = valid ? (int32_t)pc : -1;
+        h.vp = (ch << 6) + lane;
+        h.first = (vr >> 30) & 1; h.last = (vr >> 29) & 1;
         return h;
     };
     // 16 fully coalesced loads (32-bit byte offsets from the uniform base: one address instruction per load).  (With each lane loading ITS row's
@@ -712,19 +716,24 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
         __hip_atomic_store(&trf_lds[word], (bits & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&trf_lds[word + 1], (bits >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    auto publish = [&](int32_t p, double res) {
-        __hip_atomic_store(&out[p], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        put_pair(((uint32_t)(p - P0) & (TRF_RING - 1)) * 2, res, (uint32_t)(p - P0) + 1u);
+    auto publish = [&](const Head& h, double res) {                        // (a partial sum only to the ring: its one reader is the next virtual row)
+        if (h.last) __hip_atomic_store(&out[h.p], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        put_pair(((uint32_t)h.vp & (TRF_RING - 1)) * 2, res, (uint32_t)h.vp + 1u);
     };
     auto solved = [](double x) { return (unsigned long long)__double_as_longlong(x) != KR_TRI_SENTINEL; };
     // one chunk: its head hc and its operand streams bc are here; the next chunk's streams (into st) and the head after that are requested on the way
     auto chunk = [&](const Head& hc, const Stage& bc, const Stage& nx, Stage& st, Head& hnn, int32_t ch, double (&xg)[H]) {
-        const int len = hc.k1 - hc.k0, nh = len < H ? len : H;
+        const int len = H, nh = H;                                         // (rows longer than H are chains of virtual rows: nothing is left over)
         // every operand as (word offset of its pair, expected tag); bit u of `vecm`: operand u comes from the vector, of `vpend`: ... and is not there yet
         uint32_t word[H], etag[H];
         unsigned vecm = 0, vpend = 0;
-        int32_t gpos = -1;
-        auto pos_of = [&](int u) -> int32_t { return bc.d[u] > 0 ? P0 + bc.d[u] - 1 : (int32_t)((uint32_t)bc.d[u] & 0x7fffffffu); };
+        int32_t gpos = -1;                                                 // (the largest ring tag among the operands)
+        // the operand's position in the vector: in its descriptor, or -- for a ring operand, asked for only when its slot has been reused -- in the
+        // third stream
+        auto pos_of = [&](int u) -> int32_t {
+            if (bc.d[u] < 0) return (int32_t)((uint32_t)bc.d[u] & 0x7fffffffu);
+            return fpos[((size_t)(cbase + ch) * H + u) * 64 + lane];
+        };
 #pragma unroll
         for (int u = 0; u < H; ++u) {
             const int32_t d = hc.p >= 0 ? bc.d[u] : 0;
@@ -734,7 +743,6 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
             if (vec) vecm |= 1u << u;
             if (near) gpos = d > gpos ? d : gpos;
         }
-        if (gpos >= 0) gpos += P0 - 1;
         // Gathers from the vector.  They are requested ONE CHUNK AHEAD (the next chunk's descriptors are here by now; an operand that far back has
         // long been solved -- if not, the pair stays invalid and the general loop polls the vector), by every lane for every operand (lanes without
         // such an operand at one common address) and in front of the look-ahead, so that every wait is a COUNTED one.  (Waited for in per-operand
@@ -752,10 +760,10 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
         stage_of(ch + 2 * W, st);                                          // the look-ahead: in flight while this chunk and the next wait and compute
         hnn = head_of(ch + 2 * W);
         asm volatile("" ::: "memory");
-        bool done = hc.p < 0, wait = !done && gpos >= 0, headdone = false;
+        bool done = hc.p < 0, wait = !done && gpos > 0, headdone = false;
         double s = hc.s;
         int cons = 0, fails = 0;
-        const uint32_t gword = ((uint32_t)(gpos - P0) & (TRF_RING - 1)) * 2, ge = (uint32_t)(gpos - P0) + 1u;
+        const uint32_t gword = ((uint32_t)(gpos - 1) & (TRF_RING - 1)) * 2, ge = (uint32_t)gpos;
         int budget = 1 << 22, since = 0, idle = 0;
         // FAST: no vector-memory load inside the loop -- the common case.  (With one anywhere in the loop body the compiler has to wait for ALL
         // outstanding loads, the look-ahead included, at the top of every iteration: the loaded registers may be the ones a poll writes.)
@@ -782,9 +790,10 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
                         for (int u = 0; u < H; ++u) bad |= ((uint32_t)(ra[u] >> 32) ^ etag[u]) | ((uint32_t)(rb[u] >> 32) ^ etag[u]);
                         if (bad == 0) {
 #pragma unroll
-                            for (int u = 0; u < H; ++u) {                  // stored order (absent: s - 0.0 * 0.0)
-                                const double t = bc.v[u] * __longlong_as_double((long long)((ra[u] & 0xffffffffull) | (rb[u] << 32)));
-                                s = s - t;
+                            for (int u = 0; u < H; ++u) {                  // stored order (absent: s - 0.0 * 0.0); operand 0 of a chain's later rows IS s
+                                const double x = __longlong_as_double((long long)((ra[u] & 0xffffffffull) | (rb[u] << 32)));
+                                const double t = bc.v[u] * x;
+                                s = (u == 0 && !hc.first) ? x : s - t;
                             }
                             headdone = true; cons = nh;
                         } else if (++fails >= 3) {
@@ -804,34 +813,15 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
                         }
                         moved = true;
                     }
-                    if (open && headdone && cons < len) {
-                        // a row longer than H: its later entries from memory, a few per pass and never waiting inside the pass (the row it waits
-                        // for may belong to a lane of this wave)
-                        if constexpr (FAST) rare = true;
-                        else {
-                            for (int q = 0; q < 4 && cons < len; ++q) {
-                                const int32_t d = col[hc.k0 + cons]; const double vv = val[hc.k0 + cons];
-                                double xv = 0.0; bool got = false;
-                                if (d >= P0 && hc.p - d < TRF_RING) {
-                                    unsigned long long a, b; pair_at(((uint32_t)(d - P0) & (TRF_RING - 1)) * 2, a, b);
-                                    const uint32_t e = (uint32_t)(d - P0) + 1u;
-                                    if ((uint32_t)(a >> 32) == e && (uint32_t)(b >> 32) == e) { xv = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32))); got = true; }
-                                }
-                                if (!got) { xv = __hip_atomic_load(&out[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); got = solved(xv); }
-                                if (!got) break;
-                                s = s - vv * xv; ++cons; moved = true;
-                            }
-                        }
-                    }
                     if (open && headdone && cons >= len) {
-                        publish(hc.p, FORWARD ? s : s / hc.dg);
+                        publish(hc, (FORWARD || !hc.last) ? s : s / hc.dg);
                         done = true; moved = true;
                     }
                 }
                 if (__all(done)) return true;
                 if (FAST && __any(rare)) return false;
                 if (--budget <= 0) {                                       // a logic error: NaNs, not a hung GPU
-                    if (!done) publish(hc.p, __longlong_as_double(0x7FF8000000000000ll));
+                    if (!done) publish(hc, __longlong_as_double(0x7FF8000000000000ll));
                     return true;
                 }
                 // a wave that makes progress is at the front: it gets the SIMD ahead of the waves that only look; those back off
@@ -849,7 +839,7 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
         // reused under a reader (looked for every 16th turn without progress).
         auto lean = [&]() -> bool {
             if (tune & 8192) return false;
-            if (__any(!done && (len > nh || vpend != 0))) return false;
+            if (__any(!done && vpend != 0)) return false;
             bool stuck = false;
             for (int quiet = 0;;) {
                 bool got = false;
@@ -868,11 +858,12 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
                     for (int u = 0; u < H; ++u) bad |= ((uint32_t)(ra[u] >> 32) ^ etag[u]) | ((uint32_t)(rb[u] >> 32) ^ etag[u]);
                     if (bad == 0) {
 #pragma unroll
-                        for (int u = 0; u < H; ++u) {                      // stored order (absent: s - 0.0 * 0.0)
-                            const double t = bc.v[u] * __longlong_as_double((long long)((ra[u] & 0xffffffffull) | (rb[u] << 32)));
-                            s = s - t;
+                        for (int u = 0; u < H; ++u) {                      // stored order (absent: s - 0.0 * 0.0); operand 0 of a chain's later rows IS s
+                            const double x = __longlong_as_double((long long)((ra[u] & 0xffffffffull) | (rb[u] << 32)));
+                            const double t = bc.v[u] * x;
+                            s = (u == 0 && !hc.first) ? x : s - t;
                         }
-                        publish(hc.p, FORWARD ? s : s / hc.dg);
+                        publish(hc, (FORWARD || !hc.last) ? s : s / hc.dg);
                         done = true; got = true;
                     } else if ((quiet & 15) == 15) {                       // now and then: has one of my ring slots been reused under me?
 #pragma unroll
@@ -907,22 +898,31 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
     }
 }
 
-// the operand streams of one narrow run (see TriFactor): one thread per row slot of its chunks
+// the operand streams of one narrow run (see TriFactor, tri_run_free_kernel): one thread per row of the run; `vstart` = first virtual row of
+// every row of the run (and the run's total behind the last).  The streams were zeroed before: 0 = no row / no such entry.
 __global__ __launch_bounds__(256) void trf_stream_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
-                                                         int32_t P0, int32_t P1, int32_t reach, int32_t cbase, int32_t* fdesc, double* fval) {
-    const int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= (((P1 - P0 + 63) >> 6) << 6)) return;
-    const int32_t p = P0 + slot;
-    const size_t base = (size_t)(cbase + (slot >> 6)) * 512 + (size_t)(slot & 63);
-    int32_t k0 = 0, k1 = 0;
-    if (p < P1) { k0 = ptr[p]; k1 = ptr[p + 1]; }
-    for (int u = 0; u < 8; ++u) {
-        int32_t d = 0; double v = 0.0;
-        if (k0 + u < k1) {
-            const int32_t c = col[k0 + u]; v = val[k0 + u];
-            d = (c >= P0 && p - c < reach) ? c - P0 + 1 : (int32_t)(0x80000000u | (uint32_t)c);
+                                                         int32_t P0, int32_t P1, int32_t reach, int32_t cbase, const int32_t* __restrict__ vstart,
+                                                         int32_t* vreal, int32_t* fdesc, double* fval, int32_t* fpos) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P1 - P0) return;
+    const int32_t p = P0 + i, k0 = ptr[p], L = ptr[p + 1] - k0, v0 = vstart[i], nv = vstart[i + 1] - v0;
+    for (int32_t j = 0; j < nv; ++j) {
+        const int32_t vp = v0 + j;
+        const size_t cl = (size_t)(cbase + (vp >> 6)) * 64 + (size_t)(vp & 63), base = (size_t)(cbase + (vp >> 6)) * 512 + (size_t)(vp & 63);
+        vreal[cl] = ((p + 1) & 0x1FFFFFFF) | (j == 0 ? 1 << 30 : 0) | (j == nv - 1 ? 1 << 29 : 0);
+        for (int u = 0; u < 8; ++u) {
+            int32_t d = 0, c = 0; double v = 0.0;
+            if (j > 0 && u == 0) { d = vp; v = 1.0; c = p; }             // the partial sum of the virtual row before (its tag: (vp - 1) + 1)
+            else {
+                const int32_t e = j == 0 ? u : 8 + (j - 1) * 7 + (u - 1);                // the row's entry in this slot
+                if (e < L) {
+                    c = col[k0 + e]; v = val[k0 + e];
+                    const int32_t vl = c >= P0 ? vstart[c - P0 + 1] - 1 : -1;             // the LAST virtual row of the operand's row holds its value
+                    d = (c >= P0 && vp - vl < reach) ? vl + 1 : (int32_t)(0x80000000u | (uint32_t)c);
+                }
+            }
+            fdesc[base + 64 * (size_t)u] = d; fval[base + 64 * (size_t)u] = v; fpos[base + 64 * (size_t)u] = c;
         }
-        fdesc[base + 64 * (size_t)u] = d; fval[base + 64 * (size_t)u] = v;
     }
 }
 
@@ -946,12 +946,12 @@ __global__ __launch_bounds__(256) void perm_kernel(const TriArgs* args, double* 
 }
 
 // KRYST_ILU_RUN_FREE (default 1): runs of narrow levels without barriers; needs 128 KiB of LDS, twice what a kernel gets without asking
-// `long_rows`: the share of the factor's rows with more than the eight entries the kernel's lean loop holds -- such a row sends its whole chunk
-// to the general loop (entries from memory, one at a time), and with many of them the barrier kernel is the faster one (1 M rows, 14 entries per
-// row of A, 21 % long rows: 49 ms against 32; 9 per row, 0.2 %: 11.4 against 14.6).  KRYST_ILU_RUN_FREE=2 takes the kernel regardless.
+// `long_rows`: the share of the factor's rows with more than eight entries.  Such a row is a chain of virtual rows in the kernel's streams (before
+// that it sent its whole chunk to a loop that took its entries from memory one at a time, and factors with more than 2 % of them were better off
+// with the barrier kernel: 12 entries per row of A 32.4 ms against 22.9; as chains 12.2).  KRYST_ILU_FREE_LONG_PCT (default 100) brings the limit back.
 static bool grant_free_runs(double long_rows) {
     if (env_int("KRYST_ILU_RUN_FREE", 1) == 0) return false;
-    if (long_rows > 0.01 * (double)env_int("KRYST_ILU_FREE_LONG_PCT", 2) && env_int("KRYST_ILU_RUN_FREE", 1) < 2) return false;
+    if (long_rows > 0.01 * (double)env_int("KRYST_ILU_FREE_LONG_PCT", 100) && env_int("KRYST_ILU_RUN_FREE", 1) < 2) return false;
     const bool ok = hipFuncSetAttribute((const void*)tri_run_free_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, TRF_LDS_BYTES) == hipSuccess &&
                     hipFuncSetAttribute((const void*)tri_run_free_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, TRF_LDS_BYTES) == hipSuccess;
     if (!ok) (void)hipGetLastError();
@@ -961,26 +961,41 @@ static bool grant_free_runs(double long_rows) {
 static const int NARROW = 2048;     // levels with at most this many rows are folded into one-workgroup runs (CSR fallback)
 
 // The operand streams of every narrow run of a factor that takes tri_run_free_kernel (F->free_runs), in the order enqueue_factor meets the runs.
-// 6 KiB per chunk of 64 rows.  Not enough memory, or offsets past 32 bits: the factor keeps the barrier kernel (free_runs = false).
-static int32_t build_free_streams(TriFactor* F, hipStream_t st) {
+// `hptr`: the factor's row pointers on the host.  8 KiB per chunk of 64 virtual rows.  Not enough memory, or offsets past 32 bits: the factor keeps
+// the barrier kernel (free_runs = false).
+static int32_t build_free_streams(TriFactor* F, hipStream_t st, const int32_t* hptr) {
     if (!F->free_runs) return KRYST_OK;
     const int nl = (int)F->lvl_off.size() - 1;
     std::vector<std::pair<int32_t, int32_t>> runs;
+    std::vector<size_t> voff;                              // where a run's vstart begins in `vs`
+    hvec<int32_t> vs;
     size_t chunks = 0;
     for (int lv = 0; lv < nl;) {
         if (F->lvl_off[lv + 1] - F->lvl_off[lv] <= NARROW) {
             int l1 = lv + 1;
             while (l1 < nl && F->lvl_off[l1 + 1] - F->lvl_off[l1] <= NARROW) ++l1;
-            runs.emplace_back(F->lvl_off[lv], F->lvl_off[l1]);
+            const int32_t P0 = F->lvl_off[lv], P1 = F->lvl_off[l1];
+            runs.emplace_back(P0, P1);
+            voff.push_back(vs.size());
+            int64_t v = 0;
+            vs.push_back(0);
+            for (int32_t p = P0; p < P1; ++p) { const int32_t L = hptr[p + 1] - hptr[p]; v += L <= 8 ? 1 : 1 + (L - 8 + 6) / 7; vs.push_back((int32_t)std::min<int64_t>(v, INT32_MAX)); }
+            if (v >= (1ll << 29)) { chunks = 0; runs.clear(); break; }
             F->run_cbase.push_back((int32_t)chunks);
-            chunks += (size_t)(F->lvl_off[l1] - F->lvl_off[lv] + 63) / 64;
+            F->run_nvirt.push_back((int32_t)v);
+            chunks += (size_t)(v + 63) / 64;
             lv = l1;
         } else ++lv;
     }
-    if (chunks == 0 || chunks * 512 * 8 >= ((size_t)1 << 32) ||
-        hipMalloc(&F->d_fdesc, chunks * 512 * sizeof(int32_t)) != hipSuccess || hipMalloc(&F->d_fval, chunks * 512 * sizeof(double)) != hipSuccess) {
+    int32_t* d_vs = nullptr;
+    const bool ok = chunks > 0 && chunks * 512 * 8 < ((size_t)1 << 32) &&
+                    hipMalloc(&F->d_fdesc, chunks * 512 * sizeof(int32_t)) == hipSuccess && hipMalloc(&F->d_fval, chunks * 512 * sizeof(double)) == hipSuccess &&
+                    hipMalloc(&F->d_fpos, chunks * 512 * sizeof(int32_t)) == hipSuccess && hipMalloc(&F->d_vreal, chunks * 64 * sizeof(int32_t)) == hipSuccess &&
+                    hipMalloc(&d_vs, vs.size() * sizeof(int32_t)) == hipSuccess;
+    if (!ok) {
         (void)hipGetLastError();
-        (void)hipFree(F->d_fdesc); (void)hipFree(F->d_fval); F->d_fdesc = nullptr; F->d_fval = nullptr; F->run_cbase.clear();
+        (void)hipFree(F->d_fdesc); (void)hipFree(F->d_fval); (void)hipFree(F->d_fpos); (void)hipFree(F->d_vreal); (void)hipFree(d_vs);
+        F->d_fdesc = nullptr; F->d_fval = nullptr; F->d_fpos = nullptr; F->d_vreal = nullptr; F->run_cbase.clear(); F->run_nvirt.clear();
         F->free_runs = false;
         if (F->ell) F->syncfree = true;                    // (an ELL factor's other form)
         return KRYST_OK;
@@ -988,16 +1003,22 @@ static int32_t build_free_streams(TriFactor* F, hipStream_t st) {
     // an operand counts as "in the ring" when no wave can have reused its slot yet in the ordinary course of things: the most advanced wave is
     // W <= 8 chunks ahead of the least advanced one (further only if its rows need none of the rows in between; the tags catch that)
     const int32_t reach = TRF_RING - 64 * (8 + 1);
-    for (size_t r = 0; r < runs.size(); ++r) {
-        const int32_t slots = (runs[r].second - runs[r].first + 63) / 64 * 64;
-        hipLaunchKernelGGL(trf_stream_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, F->d_ptr, F->d_col, F->d_val, runs[r].first, runs[r].second,
-                           reach, F->run_cbase[r], F->d_fdesc, F->d_fval);
+    hipError_t e = hipMemcpyAsync(d_vs, vs.data(), vs.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(F->d_fdesc, 0, chunks * 512 * sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(F->d_fval, 0, chunks * 512 * sizeof(double), st);
+    if (e == hipSuccess) e = hipMemsetAsync(F->d_fpos, 0, chunks * 512 * sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(F->d_vreal, 0, chunks * 64 * sizeof(int32_t), st);
+    for (size_t r = 0; e == hipSuccess && r < runs.size(); ++r) {
+        const int32_t rows = runs[r].second - runs[r].first;
+        hipLaunchKernelGGL(trf_stream_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, F->d_ptr, F->d_col, F->d_val, runs[r].first, runs[r].second,
+                           reach, F->run_cbase[r], d_vs + voff[r], F->d_vreal, F->d_fdesc, F->d_fval, F->d_fpos);
+        e = hipGetLastError();
     }
-    KR_HIP(hipGetLastError());
-    KR_HIP(hipStreamSynchronize(st));
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_vs);
+    if (e != hipSuccess) { set_error("operand streams of the run kernel: %s", hipGetErrorString(e)); return KRYST_ERR_HIP; }
     return KRYST_OK;
 }
-
 
 template <bool FORWARD>
 static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* d_args, const double* in, double* out) {
@@ -1035,9 +1056,9 @@ static int32_t enqueue_factor(hipStream_t s, const TriFactor& F, const TriArgs* 
                 // 22 rows per level 0.50 us per level against 0.53, 3 rows 0.42 against 0.44; 187 rows: 30.4 ms with 8, 42.6 with 4)
                 const int fw = env_int("KRYST_ILU_FREE_WAVES", mean_rows >= 64 ? 8 : 4);
                 const unsigned waves = fw >= 8 ? 8u : fw >= 4 ? 4u : fw >= 2 ? 2u : 1u;
-                hipLaunchKernelGGL((tri_run_free_kernel<FORWARD, 8>), dim3(1), dim3(64 * waves), (size_t)TRF_LDS_BYTES, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
-                                   F.d_diag, F.d_fdesc, F.d_fval, F.run_cbase[run_index++], F.lvl_off[lv], F.lvl_off[l1],
-                                   env_int("KRYST_ILU_FREE_TUNE", 1 | (1 << 9) | 16384));
+                hipLaunchKernelGGL((tri_run_free_kernel<FORWARD, 8>), dim3(1), dim3(64 * waves), (size_t)TRF_LDS_BYTES, s, d_args, in, out, F.d_diag, F.d_vreal,
+                                   F.d_fdesc, F.d_fval, F.d_fpos, F.run_cbase[run_index], F.run_nvirt[run_index], env_int("KRYST_ILU_FREE_TUNE", 1 | (1 << 9) | 16384));
+                ++run_index;
             } else if (env_int("KRYST_ILU_RUN_PIPE", 1) != 0)
                 hipLaunchKernelGGL((tri_run_pipe_kernel<FORWARD, 8>), dim3(1), dim3(run_threads), 0, s, d_args, in, out, F.d_ptr, F.d_col, F.d_val,
                                    F.d_diag, F.d_lvl_off, lv, l1);
@@ -1339,7 +1360,7 @@ static int32_t build_factor(int64_t n, const FlatRows& ent, const hvec<double>& 
     }
     KR_TRY(up(&F->d_ptr, ptr)); KR_TRY(up(&F->d_col, col)); KR_TRY(up(&F->d_val, val)); KR_TRY(up(&F->d_row, rowid));
     KR_TRY(up(&F->d_diag, dg)); KR_TRY(up(&F->d_lvl_off, F->lvl_off));
-    KR_TRY(build_free_streams(F, tl_setup_stream));
+    KR_TRY(build_free_streams(F, tl_setup_stream, ptr.data()));
     return KRYST_OK;
 }
 
@@ -2402,7 +2423,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
             else hipLaunchKernelGGL((gen_fill_kernel<false>), dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, n, F->d_row, d_pos, F->d_ptr, t.dg,
                                     F->d_col, F->d_val, F->d_diag, F->ell ? F->d_ecol : nullptr, F->d_eval, F->ell ? F->d_elen : nullptr);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("factor fill kernel failed"); rc = KRYST_ERR_HIP; }   // (pos lives in a host vector reused below)
-            if (rc == KRYST_OK) rc = build_free_streams(F, ctx->s_main);
+            if (rc == KRYST_OK) rc = build_free_streams(F, ctx->s_main, ptr.data());
         }
     }
     if (rc == KRYST_OK && hipMalloc(&D->d_mapLU, nb + 4) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
