@@ -659,7 +659,8 @@ __global__ __launch_bounds__(1024) void tri_run_pipe_kernel(const TriArgs* args,
 // loads.  A poll budget turns a logic error into NaNs instead of a hung GPU.
 #define TRF_RING 4096
 #define TRF_THREADS 512
-#define TRF_LDS_BYTES (TRF_RING * 16 + TRF_THREADS * 8 * 16 + 16)
+#define TRF_AHEAD 8
+#define TRF_LDS_BYTES (TRF_RING * 16 + TRF_THREADS * 8 * 16 + 16 + 64)
 template <bool FORWARD, int H>
 __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs* args, const double* __restrict__ in, double* out,
                                                                    const double* __restrict__ diag, const int32_t* __restrict__ vreal,
@@ -675,9 +676,15 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
     constexpr uint32_t TAG_PRIV = 0xFFFFFFFEu, TAG_CONST = 0xFFFFFFFFu;
     for (int x = threadIdx.x; x < (int)CONSTP; x += blockDim.x) trf_lds[x] = 0ull;         // tag 0: never written (LDS is not cleared between kernels)
     if (threadIdx.x == 0) { trf_lds[CONSTP] = (unsigned long long)TAG_CONST << 32; trf_lds[CONSTP + 1] = (unsigned long long)TAG_CONST << 32; }
-    __syncthreads();
     const int W = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t nchunk = (NV + 63) >> 6;
+    // Which chunk every wave is on (all its earlier ones are finished): a wave starts chunk c only when no wave is more than TRF_AHEAD chunks
+    // behind it.  An operand is taken from the ring up to `reach` = 55 chunks back (trf_stream_kernel), a slot is reused 64 chunks on: with
+    // 55 + TRF_AHEAD < 64 no pair is overwritten while a row that reads it is unsolved.  (Without it a wave whose rows need nothing of a slow
+    // wave's chunk ran 64 chunks ahead on a 27-point box and overwrote the partial sum a chain was waiting for.)
+    int* const wave_at = reinterpret_cast<int*>(&trf_lds[CONSTP + 2]);
+    if (lane == 0) __hip_atomic_store(&wave_at[w], w < nchunk ? w : INT32_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
     const int batch = tune & 255;
 
     struct Head { int32_t p, vp; bool first, last; double s, dg; };       // p: the row's position in the vector (-1: no row), vp: virtual position
@@ -724,6 +731,12 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
     // one chunk: its head hc and its operand streams bc are here; the next chunk's streams (into st) and the head after that are requested on the way
     auto chunk = [&](const Head& hc, const Stage& bc, const Stage& nx, Stage& st, Head& hnn, int32_t ch, double (&xg)[H]) {
         const int len = H, nh = H;                                         // (rows longer than H are chains of virtual rows: nothing is left over)
+        if (lane == 0) __hip_atomic_store(&wave_at[w], ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int spins = 0; spins < (1 << 24); ++spins) {
+            const int at = __hip_atomic_load(&wave_at[lane < W ? lane : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__all(ch - at <= TRF_AHEAD)) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
         // every operand as (word offset of its pair, expected tag); bit u of `vecm`: operand u comes from the vector, of `vpend`: ... and is not there yet
         uint32_t word[H], etag[H];
         unsigned vecm = 0, vpend = 0;
@@ -896,6 +909,7 @@ __global__ __launch_bounds__(TRF_THREADS) void tri_run_free_kernel(const TriArgs
         chunk(hc, sc, sa, sb, hnn, ch + 2 * W, xg);
         hc = hn; hn = hnn;
     }
+    if (lane == 0) __hip_atomic_store(&wave_at[w], INT32_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // the operand streams of one narrow run (see TriFactor, tri_run_free_kernel): one thread per row of the run; `vstart` = first virtual row of
