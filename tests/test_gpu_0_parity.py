@@ -625,6 +625,28 @@ def test_narrow_level_runs_of_a_deep_factor_bit_exact(ctx, pipe, monkeypatch):
             assert np.array_equal(pc.apply(r), ref.apply(r)), (pipe, seed)
 
 
+@pytest.mark.parametrize("tune", ["16897", "513", "8705"])
+def test_chains_of_virtual_rows_with_waves_that_could_run_ahead_bit_exact(ctx, tune, monkeypatch):
+    """tri_run_free_kernel on factors whose rows are all longer than its eight operands (a 27-point operator on a 41 x 30 x 19 box through the
+    level-ordered forms: 13 entries per row = chains of two virtual rows, the partial sum handed over through the LDS ring) and whose
+    dependency cones are narrow: a wave whose rows need nothing of a slow wave's chunk can get far ahead.  Before the waves were held within
+    eight chunks of each other one of them came round the ring and overwrote a partial sum that was still waited for (NaNs once the poll
+    budget ran out) -- with the gated loop (tune 513) every time, with the default now and then.  All three forms of the loop."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("KRYST_ILU_BOX", "0"); monkeypatch.setenv("KRYST_ILU_FREE_TUNE", tune)
+    t = lambda n: sp.diags([np.ones(n - 1), np.ones(n), np.ones(n - 1)], [-1, 0, 1])
+    rng = np.random.default_rng(3)
+    m = (sp.identity(41 * 30 * 19) * 28.0 - sp.kron(t(19), sp.kron(t(30), t(41)))).tocsr(); m.sort_indices()
+    m.data = m.data * rng.uniform(0.5, 1.5, len(m.data))
+    n = m.shape[0]
+    a = O.Csr(n, n, m.indptr, m.indices, m.data)
+    pc = K.TrueIlu0().setup(to_dev(ctx, a)); ref = O.Pc.ilu0_true(a)
+    assert pc.ilu_info()["form"].startswith("level"), pc.ilu_info()
+    for seed in (5, 6):
+        r = np.random.default_rng(seed).standard_normal(n)
+        assert np.array_equal(pc.apply(r), ref.apply(r)), (tune, seed)
+
+
 @pytest.mark.parametrize("grid_path", ["quad", "1", "wave0", "0"])
 def test_structured_grid_triangular_solve_bit_exact(ctx, grid_path, monkeypatch):
     """Factors of 7-point / 5-point operators on an Ni x Nj x Nk box are solved by the pipelined wavefront kernel
