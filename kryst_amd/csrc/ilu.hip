@@ -655,8 +655,10 @@ __global__ __launch_bounds__(1024) void tri_run_pipe_kernel(const TriArgs* args,
 // in tri_run_kernel's order.  Progress: the lowest unsolved position's row needs only solved rows, and the wave that owns its chunk has finished
 // all its earlier chunks (all positions below), so it is on that chunk now; every wave of the one workgroup is resident.  Positions that share
 // a ring slot belong to one wave (TRF_RING / 64 is a multiple of the wave count) and are solved in order.  The look-ahead: a chunk's operand
-// streams (descriptor and coefficient per operand and lane, laid out at set-up: trf_stream_kernel) are requested one chunk ahead with 16 coalesced
-// loads.  A poll budget turns a logic error into NaNs instead of a hung GPU.
+// streams (descriptor and coefficient per operand and lane, laid out at set-up: trf_stream_kernel) are requested two chunks ahead with 16 coalesced
+// loads, the gathers from the vector one chunk ahead.  Rows of more than eight entries are chains of virtual rows (below).  The waves are held
+// within TRF_AHEAD chunks of each other, so that no ring slot is reused under a reader.  A poll budget turns a logic error into NaNs instead of
+// a hung GPU.
 #define TRF_RING 4096
 #define TRF_THREADS 512
 #define TRF_AHEAD 8
