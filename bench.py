@@ -156,6 +156,7 @@ class ThreadedGroup:
 
 _T0 = time.time()
 _STAGE = {}
+_PROVISIONAL = {}                  # "line": a complete, measured JSON line the watchdog prints (rank 0) when a LATER stage hangs
 
 
 def stage(rank, name):
@@ -204,30 +205,71 @@ def host_mem_available_gb():
         return 0.0
 
 
+def cpu_info():
+    """CPU model, sockets and cores of this host (/proc/cpuinfo) and the CPUs this process may run on ("CPU model,
+    socket/core count"; the reference sizes its Rayon pool with num_cpus::get(), src/parallel/rayon_comm.rs:29-35)."""
+    model, phys, cores, logical = None, set(), set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                logical += 1
+            elif k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                pid = v; phys.add(v)
+            elif k == "core id":
+                cid = v; cores.add((pid, cid))
+    except Exception:
+        pass
+    return {"cpu_model": model, "sockets": len(phys) or None, "physical_cores": len(cores) or None, "logical_cpus": logical or None,
+            "cpus_allowed": len(os.sched_getaffinity(0))}
+
+
 def cpu_cg(grid, seconds, ctx=None):
     """The oracle's CG (the CPU restatement of the reference path, OpenMP over rows / tiles like the reference's Rayon loops,
-    device-order dot) on the grid^3 Poisson system: as many iterations as fit in ~`seconds`.  -> dict.
+    device-order dot) on the grid^3 Poisson system: as many iterations as fit in ~`seconds`, on ALL the CPUs this process may use
+    (num_cpus::get() threads, rayon_comm.rs:29-35) and -- when that is more than 16 -- on 16 threads (the GPU box's CPU share for one
+    GPU) as well; `value` is the faster of the two and `cores` its thread count.  -> dict.
     With a device context the oracle's residual history -- which this leg computes anyway -- CHECKS the GPU at full size: the same
     system solved by the library for the same number of iterations, histories compared entry by entry (`parity_at_size`; the oracle is
     the checker, outside every timed region)."""
     import numpy as np
     import kryst_amd as K
     from oracle import oracle as O
-    cores = min(len(os.sched_getaffinity(0)), 16)      # the GPU box's CPU share for one GPU
-    O.set_threads(cores)
+    info = cpu_info()
+    cores_all = info["cpus_allowed"]
     T, V, F = K.reduce_spec()
     rp, ci, va = K.host_stencil7(grid, "poisson")
     a = O.Csr(grid ** 3, grid ** 3, rp, ci, va, check=False)
     b = a.spmv(np.ones(a.nrows))
     rs = O.Reduce.tiled(T, V, F)
-    t0 = time.perf_counter(); O.solve("cg", a, b, tol=0.0, max_iters=2, rs=rs); t2 = time.perf_counter() - t0
-    iters = int(max(3, min(400, seconds / max(t2 / 3.0, 1e-4))))     # 2 iterations + the initial residual pass
-    t0 = time.perf_counter()
-    res = O.solve("cg", a, b, tol=0.0, max_iters=iters, rs=rs)
-    dt = time.perf_counter() - t0
-    out = {"value": res.iterations / dt, "unit": "cg_iterations/s", "cores": cores, "kind": "port", "grid": grid, "extrapolated": False,
-           "sample": f"{res.iterations} oracle CG iterations on the {grid}^3 Poisson system in {dt:.1f} s "
-                     f"(OpenMP rows/tiles over {cores} threads, device-order dot; usize = int64 indices like the reference)"}
+
+    def run(threads, budget):
+        O.set_threads(threads)
+        t0 = time.perf_counter(); O.solve("cg", a, b, tol=0.0, max_iters=2, rs=rs); t2 = time.perf_counter() - t0
+        iters = int(max(3, min(400, budget / max(t2 / 3.0, 1e-4))))     # 2 iterations + the initial residual pass
+        t0 = time.perf_counter()
+        res = O.solve("cg", a, b, tol=0.0, max_iters=iters, rs=rs)
+        return res, time.perf_counter() - t0
+
+    res, dt = run(cores_all, seconds)
+    value_all, cores = res.iterations / dt, cores_all
+    out = {"unit": "cg_iterations/s", "kind": "port", "grid": grid, "extrapolated": False, "cores_all": cores_all, "value_all_cores": value_all}
+    out.update(info)
+    sample = (f"{res.iterations} oracle CG iterations on the {grid}^3 Poisson system in {dt:.1f} s (OpenMP rows/tiles over all {cores_all} allowed CPUs, "
+              "device-order dot; usize = int64 indices like the reference)")
+    if cores_all > 16:
+        r16, dt16 = run(16, seconds / 2)
+        out["value_16_threads"] = r16.iterations / dt16
+        sample += f"; {r16.iterations} iterations in {dt16:.1f} s on 16 threads"
+    best16 = out.get("value_16_threads", 0.0) > value_all
+    out["value"], out["cores"] = (out["value_16_threads"], 16) if best16 else (value_all, cores_all)
+    out["sample"] = sample + f"; `value` = the faster figure ({out['cores']} threads)"
+    O.set_threads(cores_all)
+    iters = res.iterations
     if ctx is not None:
         try:
             del a, rp, ci, va
@@ -243,7 +285,7 @@ def cpu_cg(grid, seconds, ctx=None):
             out["parity_at_size"] = {"grid": grid, "solver": "cg (cg.rs:141-288), tol 0", "iterations_compared": int(m - 1), "history_entries": int(m),
                                      "rhs_bit_identical": same_b, "bit_identical": bool(len(gh) == len(oh) and np.array_equal(gh, oh)),
                                      "max_rel_dev": dev, "x_bit_identical": bool(np.array_equal(gx.to_host(), res.x)),
-                                     "checker": "oracle/kryst_oracle.c kro_cg in the library's dot order (KRO_REDUCE_TILED), " + str(cores) + " threads"}
+                                     "checker": "oracle/kryst_oracle.c kro_cg in the library's dot order (KRO_REDUCE_TILED), " + str(cores_all) + " threads"}
             del ga, gb, gx
         except Exception as e:
             out["parity_at_size"] = {"grid": grid, "error": f"{type(e).__name__}: {e}"}
@@ -252,7 +294,7 @@ def cpu_cg(grid, seconds, ctx=None):
         a = O.Csr(grid ** 3, grid ** 3, rp, ci, va, check=False)
         O.set_threads(1)
         t0 = time.perf_counter(); r1 = O.solve("cg", a, b, tol=0.0, max_iters=4, rs=rs); dt1 = time.perf_counter() - t0
-        O.set_threads(cores)
+        O.set_threads(cores_all)
         out["single_thread_value"] = r1.iterations / dt1
     return out
 
@@ -270,8 +312,10 @@ def cpu_baseline(grid, base256, ctx=None):
         scale = (256 / grid) ** 3
         out = dict(b, value=b["value"] * scale, grid=grid, extrapolated=True)
         out["sample"] = b["sample"] + f"; scaled by {scale:.4f} = (256/{grid})^3 rows (host memory below {need:.0f} GB)"
-        if "single_thread_value" in out:
-            out["single_thread_value"] = b["single_thread_value"] * scale
+        for k in ("single_thread_value", "value_all_cores", "value_16_threads"):
+            if k in out:
+                out[k] = b[k] * scale
+        out.pop("parity_at_size", None)
         return out
     except Exception as e:                              # the oracle is only the reported baseline, never the product
         return {"value": None, "unit": "cg_iterations/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
@@ -470,7 +514,35 @@ def stepped(K, ctx, group, method, a, pc, b, warmup, steps, batches=3):
     return sorted(dts)[len(dts) // 2], stats, dts
 
 
-def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3):
+GMRES_RESTART = 30
+
+
+def timed_gmres(K, ctx, group, a, pc, b, warmup, steps, batches=3):
+    """GmresSolver (gmres.rs:216-402; restart 30, the reference's default Left form with `pc`) has no stepping session -- its unit of
+    work is the restart cycle -- so a batch is one device-resident SOLVE of exactly K iterations from x0 = 0 with tol = 0 (the iteration cap
+    ends it: convergence.rs:25), after one warm-up solve of W iterations; every batch is bracketed by device synchronize + barrier on
+    both sides, the maximum over ranks per batch; -> (median batch seconds, stats, all batch seconds).  The solve's own set-up (the
+    initial residual, one small allocation) is inside the timed region, as SURVEY 8(d) words it: iterations / wall time of `solve`."""
+    def barrier():
+        ctx.synchronize()
+        group.barrier()
+    x = ctx.vec(a.nrows())
+    if warmup > 0:
+        K.GmresSolver(GMRES_RESTART, 0.0, warmup).solve(a, pc, b, x.fill(0.0))
+    dts, st = [], None
+    for _ in range(batches):
+        x.fill(0.0)
+        s = K.GmresSolver(GMRES_RESTART, 0.0, steps)
+        barrier()
+        t0 = time.perf_counter()
+        st = s.solve(a, pc, b, x)
+        barrier()
+        dts.append(group.allreduce_max(time.perf_counter() - t0))
+    assert st.iterations == steps, st
+    return sorted(dts)[len(dts) // 2], st, dts
+
+
+def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3, gmres_steps=0, provisional=None):
     """Everything measured on one grid size -> dict (the operator is built once; the plain-CSR figures re-run the same
     iterations with KRYST_SPMV_COMPRESS=0, which the library reads per session step)."""
     def barrier():
@@ -484,20 +556,33 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3):
     a = K.CsrMatrix.stencil7(grid, "poisson", ctx=ctx)
     nloc = a.nrows()
     b = a.spmv(ctx.vec(nloc).fill(1.0))                      # b = A*1 (tests/preconditioner_integration.rs:25-31 convention)
-    pc = K.Jacobi().setup(a) if solver == "pcg" else None
+    pc = K.Jacobi().setup(a) if solver in ("pcg", "gmres") else None
 
     def timed_iterations():
+        if solver == "gmres":
+            return timed_gmres(K, ctx, group, a, pc, b, warmup, steps, batches)
         return stepped(K, ctx, group, solver, a, pc, b, warmup, steps, batches)
 
-    stage(rank, "warm-up + timed iterations")
+    # N > 1: what the library chose by itself for this context and this operator (mailboxes / peer stores when their set-up and their checked
+    # test reduction / test exchange succeed on every rank), then the conservative pair FIRST -- RCCL all-gather + grouped ncclSend / ncclRecv --
+    # so that a measured line exists (`provisional`) before the forms that have never crossed xGMI are timed
+    defaults = None
+    if world > 1:
+        defaults = {"scalar_reduce": ctx.scalar_reduce("query"), "halo": a.halo_mode("query") if hasattr(a, "halo_mode") else "rccl"}
+        ctx.scalar_reduce("rccl")
+        a.halo_mode("rccl")
+    stage(rank, "warm-up + timed iterations" + (" (RCCL all-gather + RCCL halo)" if world > 1 else ""))
     dt, stats, dts = timed_iterations()
+    if provisional is not None:
+        provisional(dt, stats, a.encoding(), "RCCL all-gather + RCCL halo exchange only" if world > 1 else "headline iterations only")
     # N > 1: the same K iterations with the inner products crossing the ranks through the hipIpc mailboxes instead of two RCCL
     # all-gathers per iteration (kryst_ctx_scalar_reduce).  The faster path that reproduces the other's residual BIT FOR BIT is the
     # headline; both figures are reported.  (Every rank takes the same decision: times are max-reduced, scalars are identical.)
     reduce_info = None
     if world > 1:
         stage(rank, "mailbox setup + timed iterations (scalar all-reduce through hipIpc mailboxes)")
-        reduce_info = {"path": "rccl", "value_rccl": steps / dt, "value_ipc": None, "ipc": "unavailable on this node (hipIpc export / mapping failed)"}
+        reduce_info = {"path": "rccl", "value_rccl": steps / dt, "value_ipc": None, "ipc": "unavailable on this node (hipIpc export / mapping / test reduction failed)",
+                       "library_defaults": defaults}
         if ctx.scalar_reduce("ipc") == "ipc":
             try:
                 dt_ipc, stats_ipc, dts_ipc = timed_iterations()
@@ -552,7 +637,7 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3):
                     else:
                         a.halo_mode("rccl")
             else:
-                peer_note = "unavailable on this node (hipIpc export / mapping of the halo buffers failed)"
+                peer_note = "unavailable on this node (hipIpc export / mapping / test exchange of the halo buffers failed)"
         reduce_info.update(value_halo_early=forms["early"], value_halo_at_spmv=forms["at_spmv"], value_halo_peer_stores=forms.get("peer_stores"),
                            halo={"early": "early", "at_spmv": "at the SpMV", "peer_stores": "peer stores"}[best], peer_stores=peer_note)
         if best == "at_spmv":                                  # (the plain-CSR and phase runs below use the headline's setting)
@@ -587,13 +672,19 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3):
     if phase_iters > 0:
         stage(rank, "phase timing")
         x = ctx.vec(nloc)
-        with K.Session(solver, a, pc, b, x, tol=0.0, max_iters=phase_iters + 2) as sess:
-            sess.step(2)
+        if solver == "gmres":
             barrier()
             ctx.phase_timing_begin()
-            sess.step(phase_iters)
+            K.GmresSolver(GMRES_RESTART, 0.0, phase_iters).solve(a, pc, b, x)
             ph = ctx.phase_timing_end()
-            sess.end()
+        else:
+            with K.Session(solver, a, pc, b, x, tol=0.0, max_iters=phase_iters + 2) as sess:
+                sess.step(2)
+                barrier()
+                ctx.phase_timing_begin()
+                sess.step(phase_iters)
+                ph = ctx.phase_timing_end()
+                sess.end()
         mine = {k: v / phase_iters for k, v in ph.items() if v > 0.0}
         mine["total"] = sum(mine.values())
         phases = group.gather(mine)
@@ -609,6 +700,25 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3):
         for _ in range(100):
             ctx.all_reduce(1.0)
         collective_us = group.allreduce_max((time.perf_counter() - t0) / 100 * 1e6)
+    # north_star: "CG/GMRES iterations/sec ... at 1, 2, 4 and 8 GPUs" -- GMRES(30) + Jacobi on the same system, same partition, with the
+    # headline's scalar-reduce path and halo form (whole restart cycles: an iteration's cost grows with its position in the cycle)
+    gm = None
+    if gmres_steps > 0 and solver != "gmres":
+        stage(rank, "GMRES(30) + Jacobi timed solves")
+        try:
+            pcj = pc if solver == "pcg" else K.Jacobi().setup(a)
+            dt_g, st_g, dts_g = timed_gmres(K, ctx, group, a, pcj, b, min(warmup, GMRES_RESTART), gmres_steps, 2)
+            gm = {"workload": f"gmres30_left_jacobi_poisson7_{grid}^3", "value": gmres_steps / dt_g, "unit": "iterations/s", "steps": gmres_steps,
+                  "restart": GMRES_RESTART, "ms_per_step": dt_g / gmres_steps * 1e3, "batch_ms": [d * 1e3 for d in dts_g],
+                  "final_residual": st_g.final_residual, "preconditioning": "Left + Jacobi, the reference's default form (gmres.rs:279-307)",
+                  "rule": "one warm-up solve, then 2 solves of exactly `steps` iterations from x0 = 0 (tol 0), each bracketed by device synchronize + "
+                          "barrier, max over ranks; value = steps / the later-sorted batch",
+                  "algorithmic_bytes_per_iteration": spmv_bytes(nloc, a.nnz) + 1288 * nloc}
+            del pcj
+        except Exception as e:                              # the headline must survive a failing side measurement -- on every rank alike
+            gm = {"error": f"{type(e).__name__}: {e}"}
+        if world > 1 and group.allreduce_max(1.0 if "error" in gm else 0.0) > 0.0 and "error" not in gm:
+            gm = {"error": "failed on another rank"}
     nnz_loc = a.nnz
     roof_csr = roofline_csr_of(grid, nloc, nnz_loc, plain_ms, world)
     if skeleton_ms:
@@ -619,7 +729,7 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3):
             "frac": alg / (skeleton_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_over_skeleton": plain_ms / skeleton_ms}
     settings.close()
     return {"dt": dt, "dts": dts, "dt_plain": dt_plain, "dts_plain": dts_plain, "stats": stats, "enc": enc, "nloc": nloc, "nnz_loc": nnz_loc,
-            "collective_us": collective_us, "reduce_info": reduce_info,
+            "collective_us": collective_us, "reduce_info": reduce_info, "gmres": gm,
             "roofline": roofline_of(enc, grid, nloc, nnz_loc, spmv_ms, world, staged=a.pattern_info()["staged"]),
             "roofline_csr": roof_csr,
             "blas1": blas1_streams(K, ctx, nloc), "copy_gbs": copy_gbs, "phases": phases,
@@ -674,23 +784,25 @@ def tri_roofline(pc, r, z, n, nnz, reps=20):
     return out
 
 
-ILU_SETUP_NOTE = ("ilu_setup_ms = the SECOND setup of the same operator in this process (steady state: the device-side factorisation and the blocked "
-                  "layout); ilu_setup_first_call_ms = the first one, which also pays for first-use work that is not the factorisation's: the code "
-                  "objects of the setup kernels are loaded and ~22 GB (512^3) of device memory are allocated for the first time -- fresh VRAM costs whatever the "
-                  "driver's page clearing costs at that moment: 80 ms to 2.2 s measured for the same call (profiles/r04/ilu_setup_512.txt; round 3's "
-                  "72 / 255 / 519 ms at 512^3 were first calls at different points of a process's life)")
+ILU_SETUP_NOTE = ("ilu_setup_first_ms = the first set-up of this operator in the process (code objects of the set-up kernels loaded, device memory for the "
+                  "factors taken from the driver for the first time); ilu_setup_refactor_ms = set-ups of the SAME operator after the previous preconditioner "
+                  "was destroyed -- what a caller who re-factors pays (Ilup::setup is called per matrix, ilup.rs:77-134): the destroyed preconditioner's "
+                  "device blocks come back from the context's size-keyed pool (KRYST_DEV_POOL_MB, kryst_ctx_trim) instead of the driver, so the figure is "
+                  "the factorisation and the blocked layout, not allocation")
 
 
-def ilu_setup_times(K, ctx, a):
-    """(first-call seconds, steady-state seconds, preconditioner) of the true ILU(0) setup."""
+def ilu_setup_times(K, ctx, a, refactors=2):
+    """(first-call seconds, [re-factor seconds ...], preconditioner) of the true ILU(0) set-up: destroy, set up again, `refactors` times."""
     ctx.synchronize(); t0 = time.perf_counter()
     pc = K.TrueIlu0().setup(a)
     ctx.synchronize(); t_first = time.perf_counter() - t0
-    del pc
-    ctx.synchronize(); t0 = time.perf_counter()
-    pc = K.TrueIlu0().setup(a)
-    ctx.synchronize(); t_second = time.perf_counter() - t0
-    return t_first, t_second, pc
+    again = []
+    for _ in range(refactors):
+        del pc
+        ctx.synchronize(); t0 = time.perf_counter()
+        pc = K.TrueIlu0().setup(a)
+        ctx.synchronize(); again.append(time.perf_counter() - t0)
+    return t_first, again, pc
 
 
 def other_configs(K, ctx, steps, warmup):
@@ -712,12 +824,12 @@ def other_configs(K, ctx, steps, warmup):
     # ---- config 5: right-preconditioned BiCGStab + true ILU(0) on 256^3 anisotropic Poisson, absolute tol 1e-8 ||b|| (bicgstab.rs:69-293)
     a = K.CsrMatrix.stencil7(256, "aniso", ctx=ctx); n = a.nrows()
     b = a.spmv(ctx.vec(n).fill(1.0)); bn = K.norm(b)
-    t_first, t_setup, pc = ilu_setup_times(K, ctx, a)
+    t_first, t_again, pc = ilu_setup_times(K, ctx, a)
     dt, st = timed_solve(K, ctx, lambda: K.BiCgStabRightPcSolver(1e-8 * bn, 3000), a, pc, b)
     z = ctx.vec(n)
     out["config5_bicgstab_ilu0_256"] = {
         "workload": "bicgstab_right_true_ilu0_aniso7_256^3", "value": st.iterations / dt, "unit": "iterations/s", "iterations": st.iterations,
-        "converged": bool(st.converged), "final_residual": st.final_residual, "solve_seconds": dt, "ilu_setup_ms": t_setup * 1e3, "ilu_setup_first_call_ms": t_first * 1e3,
+        "converged": bool(st.converged), "final_residual": st.final_residual, "solve_seconds": dt, "ilu_setup_first_ms": t_first * 1e3, "ilu_setup_refactor_ms": min(t_again) * 1e3, "ilu_setup_refactor_all_ms": [t * 1e3 for t in t_again],
         "ilu_setup_note": ILU_SETUP_NOTE,
         "spmv_encoding": a.encoding()[0], "note": "the reference's BiCGStab ignores pc (bicgstab.rs:70); the preconditioned form is a labelled extension",
         "roofline": tri_roofline(pc, b, z, n, a.nnz)}
@@ -749,8 +861,8 @@ def other_configs(K, ctx, steps, warmup):
                 blk.update(value=kv / dt, unit="iterations/s", steps=kv, ms_per_step=dt / kv * 1e3, roofline=roofline_of(e, grid, n, nnz, ms, 1, "varcoef"))
             else:
                 blk.update(value_plain_csr=kv / dt, ms_per_step_plain_csr=dt / kv * 1e3, roofline_csr=roofline_csr_of(grid, n, nnz, ms, 2))
-        t_first, t_setup, pc = ilu_setup_times(K, ctx, a)
-        blk.update(ilu_setup_ms=t_setup * 1e3, ilu_setup_first_call_ms=t_first * 1e3)
+        t_first, t_again, pc = ilu_setup_times(K, ctx, a)
+        blk.update(ilu_setup_first_ms=t_first * 1e3, ilu_setup_refactor_ms=min(t_again) * 1e3, ilu_setup_refactor_all_ms=[t * 1e3 for t in t_again])
         blk["ilu_apply"] = tri_roofline(pc, b, y, n, nnz, reps=10)
         out[f"variable_coefficient_{grid}"] = blk
         del pc, a, b, y
@@ -832,6 +944,96 @@ def general_ilu(K, ctx):
     return out
 
 
+
+# ---------------------------------------------------------------------------------------------------------------- self-launch
+def _free_port_range(width=10):
+    """A local port with the next `width` ports free as well right now (the socket rendezvous listens on MASTER_PORT + 1 ...)."""
+    import socket
+    for _ in range(64):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        if port + width >= 65000:
+            continue
+        ok = True
+        for k in range(1, width):
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as t:
+                try:
+                    t.bind(("127.0.0.1", port + k))
+                except OSError:
+                    ok = False
+                    break
+        if ok:
+            return port
+    raise RuntimeError("bench.py: no free local port range for the rendezvous")
+
+
+def self_launch(argv, procs, limit_s):
+    """`python3 bench.py --gpus N` started PLAINLY (no WORLD_SIZE in the environment): this process becomes the launcher that
+    `mpirun` is for the reference (src/parallel/mpi_comm.rs:49-55).  It starts `procs` FRESH child processes of this very file with
+    RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT set (one rank per GPU; the children rendezvous over
+    kryst_amd/launch.py's sockets unless --launcher torch is given), relays rank 0's stdout -- the JSON line -- as its only stdout,
+    lets every rank's stage markers through on stderr, ends the others when one child exits non-zero and returns that code.
+    The launcher itself never touches the GPU: it imports neither kryst_amd nor torch and never execs (the children are started with
+    subprocess.Popen)."""
+    import signal
+    import subprocess
+    port = _free_port_range()
+    here = os.path.abspath(__file__)
+    kids = []
+    err_fd = sys.stderr.fileno()
+    for r in range(procs):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(procs), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(procs),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KRYST_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("KRYST_LAUNCHER", "socket")            # no torch import in N processes unless asked for (--launcher torch)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        kids.append(subprocess.Popen([sys.executable, here] + list(argv), env=env, stdin=subprocess.DEVNULL,
+                                     stdout=None if r == 0 else err_fd))     # rank 0's stdout IS this process's stdout
+    sys.stderr.write(f"[bench launcher +{time.time() - _T0:7.2f}s] started {procs} rank process(es), MASTER_PORT {port}: pids "
+                     + " ".join(str(k.pid) for k in kids) + "\n"); sys.stderr.flush()
+
+    def end_all(sig):
+        for k in kids:
+            if k.poll() is None:
+                try:
+                    k.send_signal(sig)                        # (exactly the processes started above, by pid)
+                except OSError:
+                    pass
+
+    rc, deadline = 0, time.time() + limit_s
+    try:
+        while True:
+            codes = [k.poll() for k in kids]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0] if bad[0] > 0 else 128 - bad[0]
+                sys.stderr.write(f"[bench launcher] rank process {codes.index(bad[0])} exited with {bad[0]}: ending the others\n"); sys.stderr.flush()
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                sys.stderr.write(f"[bench launcher] {limit_s:.0f} s without every rank finishing: ending the ranks\n"); sys.stderr.flush()
+                rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        end_all(signal.SIGTERM)
+        t_end = time.time() + 5.0
+        while any(k.poll() is None for k in kids) and time.time() < t_end:
+            time.sleep(0.05)
+        end_all(signal.SIGKILL)
+        for k in kids:
+            try:
+                k.wait(timeout=5)
+            except Exception:
+                pass
+    dump = os.environ.get("KRYST_BENCH_LAUNCHER_MAPS")        # tests: proof that the launcher mapped no HIP / kryst library
+    if dump:
+        with open(dump, "w") as f:
+            f.write(open("/proc/self/maps").read())
+    return rc
+
+
 def rank_main(args, group, rank, world, dev, grid):
     """One rank's whole run (the process's only one, or one of its rank threads)."""
     import kryst_amd as K
@@ -844,32 +1046,57 @@ def rank_main(args, group, rank, world, dev, grid):
 
     n = grid ** 3
     nnz = 7 * n - 6 * grid * grid
-    m = measure(K, ctx, group, grid, args.solver, args.warmup, args.steps, args.phase_iters, args.batches)
-    wl = "jacobi_pcg" if args.solver == "pcg" else "cg"
-    out = {
-        "metric": "cg_iterations_per_sec", "value": args.steps / m["dt"], "unit": "iterations/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["dt"] / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{wl}_poisson7_{grid}^3", "grid": grid, "rows": n, "nnz": nnz, "partition": f"{world} k-slab(s)",
-                   "rhs": "A*1", "x0": "0", "final_residual": m["stats"].final_residual, "spmv_encoding": m["enc"][0],
-                   "launcher": type(group).__name__ if not isinstance(group, ThreadedGroup) else f"{type(group.sh.inner).__name__} x {group.sh.per} rank threads per process"},
+    wl = {"pcg": "jacobi_pcg", "gmres": "gmres30_left_jacobi"}.get(args.solver, "cg")
+
+    def headline(dt, stats, enc):
+        return {
+            "metric": "gmres_iterations_per_sec" if args.solver == "gmres" else "cg_iterations_per_sec", "value": args.steps / dt, "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{wl}_poisson7_{grid}^3", "grid": grid, "rows": n, "nnz": nnz, "partition": f"{world} k-slab(s)",
+                       "rhs": "A*1", "x0": "0", "final_residual": stats.final_residual, "spmv_encoding": enc[0],
+                       "launcher": type(group).__name__ if not isinstance(group, ThreadedGroup) else f"{type(group.sh.inner).__name__} x {group.sh.per} rank threads per process"}}
+
+    def provisional(dt, stats, enc, what):
+        # every rank remembers that a measured line exists (the watchdog then ends the run with exit code 0); rank 0 holds the line itself
+        line = headline(dt, stats, enc)
+        line.update(roofline=None, provisional=what)
+        _PROVISIONAL["line"] = line
+
+    m = measure(K, ctx, group, grid, args.solver, args.warmup, args.steps, args.phase_iters, args.batches, args.gmres_steps, provisional)
+    out = headline(m["dt"], m["stats"], m["enc"])
+    roof = m["roofline"]
+    rc = m["roofline_csr"]
+    # SURVEY 8(d)'s own pair INSIDE the block the driver keeps: the plain-CSR kernel (the only one that moves 8(d)'s 12 nnz + 4 (n + 1) + 16 n
+    # bytes) priced at those bytes, and the iterations/s of the same K iterations with that kernel (`value_sec8d`)
+    roof["sec8d"] = {"kernel": rc["kernel"], "frac": rc["frac"], "achieved": rc["achieved"], "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                     "bytes_per_launch": rc["bytes_per_launch"], "bytes_model": rc["bytes_model"], "ms_per_launch": rc["ms_per_launch"],
+                     "traffic": rc.get("traffic"), "stream_skeleton": rc.get("stream_skeleton"),
+                     "value_sec8d": args.steps / m["dt_plain"], "value_unit": "iterations/s",
+                     "note": "north_star's '% of HBM roofline on CSR SpMV' and the iterations/s that go with it; `roofline.frac` above prices the "
+                             "default (lossless, more compact) storage form at ITS bytes"}
+    out.update({
         "timing": {"batches": len(m["dts"]), "batch_ms": [d * 1e3 for d in m["dts"]], "batch_ms_plain_csr": [d * 1e3 for d in m["dts_plain"]],
-                   "rule": "W warm-up iterations, then `batches` batches of exactly K iterations of ONE stepping session, each bracketed by device synchronize + "
-                           "barrier on both sides, max over ranks per batch; value = K / the MEDIAN batch"},
+                   "rule": "W warm-up iterations, then `batches` batches of exactly K iterations of ONE stepping session (GMRES: one solve of exactly K "
+                           "iterations per batch), each bracketed by device synchronize + barrier on both sides, max over ranks per batch; value = K / the MEDIAN batch"},
+        "value_sec8d": args.steps / m["dt_plain"],
         "value_plain_csr": args.steps / m["dt_plain"], "ms_per_step_plain_csr": m["dt_plain"] / args.steps * 1e3,
-        "roofline": m["roofline"], "roofline_csr": m["roofline_csr"], "roofline_blas1": m["blas1"],
+        "roofline": roof, "roofline_csr": m["roofline_csr"], "roofline_blas1": m["blas1"],
+        "gmres30_jacobi": m["gmres"],    # north_star: CG / GMRES iterations/s at 1, 2, 4, 8 GPUs -- GMRES(30) + Jacobi on the same system and partition
         "measured_copy_GBs": m["copy_gbs"],
         "phase_ms": m["phases"],         # per rank: device ms per iteration by phase (spmv / halo_wait / spmv_boundary / reduce / blas1)
         "scalar_all_reduce_us": m["collective_us"],   # N > 1: host round trip of one scalar all-reduce (all-gather + ordered fold + sync), max over ranks
         "scalar_reduce": m["reduce_info"],            # N > 1: which path carried the inner products in `value` (RCCL all-gather or hipIpc mailboxes) and both figures
-    }
+    })
+    _PROVISIONAL["line"] = dict(out, provisional="headline measurements complete; the side measurements (256^3, other configs, CPU baseline) were cut short")
     base256 = None
     if world == 1 and grid != 256 and not args.no_256:
-        m2 = measure(K, ctx, group, 256, args.solver, args.warmup, args.steps, args.phase_iters, args.batches)
+        m2 = measure(K, ctx, group, 256, args.solver, args.warmup, args.steps, args.phase_iters, args.batches, args.gmres_steps)
         out["config1_256"] = {"workload": f"{wl}_poisson7_256^3", "value": args.steps / m2["dt"], "unit": "iterations/s",
                               "ms_per_step": m2["dt"] / args.steps * 1e3, "batch_ms": [d * 1e3 for d in m2["dts"]], "value_plain_csr": args.steps / m2["dt_plain"],
+                              "value_sec8d": args.steps / m2["dt_plain"],
                               "roofline": m2["roofline"], "roofline_csr": m2["roofline_csr"], "roofline_blas1": m2["blas1"],
-                              "phase_ms": m2["phases"]}
+                              "gmres30_jacobi": m2["gmres"], "phase_ms": m2["phases"]}
         if not args.no_cpu_baseline:
             stage(rank, "cpu baseline + full-size parity 256^3")
             try:
@@ -891,6 +1118,7 @@ def rank_main(args, group, rank, world, dev, grid):
         if par:
             out["parity_at_size"] = par
     stage(rank, "gather / print")
+    _PROVISIONAL.clear()                       # (the real line follows: the watchdog must not print a second one)
     if rank == 0:
         print(json.dumps(out), flush=True)
     group.close()
@@ -903,7 +1131,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batches", type=int, default=3, help="timed batches of --steps iterations each; the median batch is the headline")
     ap.add_argument("--grid", type=int, default=0, help="grid edge (default 512 for every N)")
-    ap.add_argument("--solver", default="cg", choices=["cg", "pcg"])
+    ap.add_argument("--solver", default="cg", choices=["cg", "pcg", "gmres"],
+                    help="headline iteration: cg (cg.rs), pcg = Jacobi-PCG (pcg.rs), gmres = GMRES(30) Left + Jacobi (gmres.rs; a batch is one solve of K iterations)")
+    ap.add_argument("--gmres-steps", type=int, default=60,
+                    help="iterations of the GMRES(30) + Jacobi block measured beside a cg / pcg headline (whole restart cycles; 0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-256", action="store_true", help="skip the config1_256 block (N = 1 measures BASELINE configs[1]'s 256^3 grid too)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs and the variable-coefficient blocks (N = 1)")
@@ -916,6 +1147,13 @@ def main():
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between processes on this driver
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (the way the driver starts --gpus 1): become the launcher -- before anything of this process touches the GPU
+        per = max(1, args.ranks_per_process)
+        if args.gpus % per:
+            sys.exit(f"bench.py: --gpus {args.gpus} is not a multiple of --ranks-per-process {per}")
+        limit = float(os.environ.get("KRYST_BENCH_WATCHDOG_S", "280")) + 15.0
+        sys.exit(self_launch(sys.argv[1:], args.gpus // per, limit))
     procs = int(os.environ.get("WORLD_SIZE", "1"))
     prank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -927,12 +1165,19 @@ def main():
     limit = float(os.environ.get("KRYST_BENCH_WATCHDOG_S", "280" if world > 1 else "560"))
     def _watchdog():
         where = "; ".join(f"rank {r}: {nm}" for r, nm in sorted(_STAGE.items())) or "before the first stage"
-        sys.stderr.write(f"bench.py: watchdog timeout ({limit:.0f} s) -- last stage markers: {where}\n"); sys.stderr.flush(); os._exit(124)
+        sys.stderr.write(f"bench.py: watchdog timeout ({limit:.0f} s) -- last stage markers: {where}\n"); sys.stderr.flush()
+        line = _PROVISIONAL.get("line")
+        if line is None:
+            os._exit(124)
+        # a complete measurement exists and only a LATER stage hung: the measured line is printed (marked) instead of being lost with the run.
+        # Every rank reaches this branch alike (the provisional line is recorded right after a collective), so every rank exits with 0.
+        if prank == 0:
+            line = dict(line, truncated_by_watchdog=f"{limit:.0f} s; last stage markers: {where}")
+            sys.stdout.write(json.dumps(line) + "\n"); sys.stdout.flush()
+        os._exit(0)
     wd = threading.Timer(limit, _watchdog); wd.daemon = True; wd.start()
 
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
         args.gpus = world
     grid = args.grid or 512          # ONE fixed problem for every N (strong scaling, north_star): 512^3
 

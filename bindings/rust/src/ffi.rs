@@ -1,4 +1,4 @@
-//! Raw `extern "C"` declarations of include/kryst_hip.h (ABI version 4), one to one.  Everything returns an `i32` status:
+//! Raw `extern "C"` declarations of include/kryst_hip.h (ABI version 5), one to one.  Everything returns an `i32` status:
 //! 0 OK, 1..6 = `KError` (src/error.rs:6-19), >= 100 runtime / argument errors (`kryst_hip_last_error()` has the text).
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_void};
@@ -71,6 +71,7 @@ extern "C" {
     pub fn kryst_comm_all_reduce(ctx: Ctx, x: f64, out: *mut f64) -> i32;
     pub fn kryst_ctx_scalar_reduce(ctx: Ctx, mode: i32, active: *mut i32) -> i32;
     pub fn kryst_csr_halo_mode(a: Csr, mode: i32, active: *mut i32) -> i32;
+    pub fn kryst_ctx_trim(ctx: Ctx, bytes_released: *mut i64) -> i32;
     pub fn kryst_phase_timing_begin(ctx: Ctx) -> i32;
     pub fn kryst_phase_timing_end(ctx: Ctx, ms: *mut f64, count: i32) -> i32;
     pub fn kryst_phase_count() -> i32;

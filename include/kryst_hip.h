@@ -77,18 +77,30 @@ int32_t kryst_ctx_rank(kryst_ctx_t ctx, int32_t* rank, int32_t* nranks);   /* Co
 int32_t kryst_comm_barrier(kryst_ctx_t ctx);                       /* Comm::barrier, mpi_comm.rs:67 */
 int32_t kryst_comm_all_reduce(kryst_ctx_t ctx, double x, double* out);     /* Comm::all_reduce, mpi_comm.rs:116-121 */
 /* How the solvers' inner products cross the ranks (DistributedInnerProduct, core/wrappers.rs:134-156): mode 0 = RCCL all-gather +
- * rank-ordered fold (default), 1 = hipIpc-mapped mailboxes written and polled by the kernel that finishes the local fold (one
- * launch, no collective; the same bits).  COLLECTIVE over the context's ranks, no solve open.  Mode 1 returns KRYST_UNSUPPORTED --
- * on every rank, which all stay on RCCL -- when a mailbox cannot be exported or mapped.  *active (may be NULL): mode in use.
- * KRYST_SCALAR_REDUCE=ipc selects mode 1 at kryst_ctx_create_dist. */
+ * rank-ordered fold, 1 = hipIpc-mapped mailboxes written and polled by the kernel that finishes the local fold (one launch, no
+ * collective; the same bits), -1 = query (*active only; not collective).  Modes 0 / 1: COLLECTIVE over the context's ranks, no solve
+ * open.  Mode 1 returns KRYST_UNSUPPORTED -- on every rank, which all stay on RCCL -- when a mailbox cannot be exported or mapped or ONE
+ * CHECKED TEST REDUCTION over the fresh mailboxes does not arrive intact on some rank.  *active (may be NULL): mode in use.
+ * DEFAULT (ABI 5): kryst_ctx_create_dist with more than one rank tries mode 1 and keeps it when it works on every rank;
+ * KRYST_SCALAR_REDUCE=rccl keeps mode 0. */
 int32_t kryst_ctx_scalar_reduce(kryst_ctx_t ctx, int32_t mode, int32_t* active);
 /* How a row-partitioned operator's halo exchange travels (the neighbour exchange src/parallel/mpi_comm.rs:133-143 leaves as a TODO): mode 0 =
- * grouped ncclSend / ncclRecv on the second stream (default), 1 = direct peer stores -- a push kernel writes the rows each neighbour needs
+ * grouped ncclSend / ncclRecv on the second stream, 1 = direct peer stores -- a push kernel writes the rows each neighbour needs
  * straight into that neighbour's hipIpc-mapped landing buffer and stamps the exchange's epoch behind them, the receiver's compute stream
- * polls its stamps in front of the boundary tiles: no collective launch, no pack kernel, no event between receive and compute stream.
- * COLLECTIVE over the context's ranks, no solve open.  Mode 1 returns KRYST_UNSUPPORTED -- on every rank, which all stay on RCCL -- when a
- * landing buffer cannot be exported or mapped or a neighbour relation is one-way.  The same bits either way.  *active (may be NULL): mode in use. */
+ * polls its stamps in front of the boundary tiles: no collective launch, no pack kernel, no event between receive and compute stream --
+ * -1 = query (*active only; not collective).  Modes 0 / 1: COLLECTIVE over the context's ranks, no solve open.  Mode 1 returns
+ * KRYST_UNSUPPORTED -- on every rank, which all stay on RCCL -- when a landing buffer cannot be exported or mapped, a neighbour relation is
+ * one-way, or ONE CHECKED TEST EXCHANGE (every rank sends its global row numbers and compares what lands with its column list) does not
+ * arrive intact on some rank.  The same bits either way.  *active (may be NULL): mode in use.
+ * DEFAULT (ABI 5): kryst_csr_create_dist / kryst_csr_create_stencil7 on a context of several ranks try mode 1 and keep it when it works on
+ * every rank; KRYST_HALO_MODE=rccl keeps mode 0.  kryst_spmv on an operator in mode 1 returns KRYST_ERR_RCCL when a neighbour's stamp
+ * never arrived (the halo was NaNs). */
 int32_t kryst_csr_halo_mode(kryst_csr_t a, int32_t mode, int32_t* active);
+/* Returns to the driver what the context keeps between calls: the device blocks of destroyed ILU-family preconditioners -- kept, keyed by
+ * size, so that the next Preconditioner::setup of the same matrix (ilup.rs:77-134 is called per matrix, repeatedly) costs the factorisation
+ * and not 22 GB of allocation at 512^3; bounded by KRYST_DEV_POOL_MB (default 65536, 0 = no pool) -- and, when no solve is open, the solvers'
+ * work-vector arena.  *bytes_released may be NULL. */
+int32_t kryst_ctx_trim(kryst_ctx_t ctx, int64_t* bytes_released);
 /* measurement only: per-phase device time of the work enqueued between begin and end (hipEvents recorded on the compute stream
  * after each phase: time between two marks is charged to the later one).  ms[p] for p < kryst_phase_count(): "spmv" (tiles
  * without halo columns; single rank: the whole SpMV), "halo_wait" (compute stream waiting for the neighbour planes),

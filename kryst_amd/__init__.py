@@ -80,16 +80,24 @@ class Context:
         return out.value
 
     def scalar_reduce(self, mode):
-        """'rccl' | 'ipc': how the solvers' inner products cross the ranks (kryst_ctx_scalar_reduce; collective).  Returns the mode in
-        use afterwards ('ipc' falls back to 'rccl' on every rank when a mailbox cannot be mapped)."""
+        """'rccl' | 'ipc' | 'query': how the solvers' inner products cross the ranks (kryst_ctx_scalar_reduce; collective except 'query').
+        Returns the mode in use afterwards ('ipc' falls back to 'rccl' on every rank when a mailbox cannot be mapped or the test reduction
+        does not arrive intact).  A context of several ranks starts on 'ipc' when that works everywhere (KRYST_SCALAR_REDUCE=rccl: never)."""
         active = C.c_int32(0)
-        rc = lib().kryst_ctx_scalar_reduce(self.h, {"rccl": 0, "ipc": 1}[mode], C.byref(active))
+        rc = lib().kryst_ctx_scalar_reduce(self.h, {"rccl": 0, "ipc": 1, "query": -1}[mode], C.byref(active))
         if rc not in (0, 6):
             check(rc)
         return "ipc" if active.value else "rccl"
 
     def synchronize(self):
         check(lib().kryst_ctx_synchronize(self.h))
+
+    def trim(self):
+        """Give the device blocks kept for reuse (destroyed ILU preconditioners' storage, the solvers' work arena) back to the driver
+        (kryst_ctx_trim) -> bytes released."""
+        n = C.c_int64(0)
+        check(lib().kryst_ctx_trim(self.h, C.byref(n)))
+        return n.value
 
     def poison_lds(self):
         """Test hook: NaNs into every compute unit's LDS (a kernel must not depend on what LDS held before it started)."""
@@ -312,10 +320,12 @@ class CsrMatrix:
         return ms.value
 
     def halo_mode(self, mode):
-        """'rccl' | 'peer': how this row-partitioned operator's halo exchange travels (kryst_csr_halo_mode; collective).  Returns the mode in
-        use: 'peer' falls back to 'rccl' on every rank when a landing buffer cannot be exported / mapped (KRYST_UNSUPPORTED)."""
+        """'rccl' | 'peer' | 'query': how this row-partitioned operator's halo exchange travels (kryst_csr_halo_mode; collective except
+        'query').  Returns the mode in use: 'peer' falls back to 'rccl' on every rank when a landing buffer cannot be exported / mapped or
+        the test exchange does not arrive intact (KRYST_UNSUPPORTED).  A new operator starts on 'peer' when that works everywhere
+        (KRYST_HALO_MODE=rccl: never)."""
         active = C.c_int32(0)
-        rc = lib().kryst_csr_halo_mode(self.h, {"rccl": 0, "peer": 1}[mode], C.byref(active))
+        rc = lib().kryst_csr_halo_mode(self.h, {"rccl": 0, "peer": 1, "query": -1}[mode], C.byref(active))
         if rc not in (0, 6):                     # (6 = KRYST_UNSUPPORTED: the documented fallback)
             check(rc)
         return "peer" if active.value == 1 else "rccl"

@@ -50,6 +50,7 @@ SIGNATURES = {
     "kryst_comm_all_reduce": (C.c_int32, [Handle, C.c_double, c_dp]),
     "kryst_ctx_scalar_reduce": (C.c_int32, [Handle, C.c_int32, c_i32p]),
     "kryst_csr_halo_mode": (C.c_int32, [Handle, C.c_int32, c_i32p]),
+    "kryst_ctx_trim": (C.c_int32, [Handle, c_i64p]),
     "kryst_phase_timing_begin": (C.c_int32, [Handle]),
     "kryst_phase_timing_end": (C.c_int32, [Handle, c_dp, C.c_int32]),
     "kryst_phase_count": (C.c_int32, []),

@@ -135,7 +135,9 @@ struct kryst_ctx_s {
     std::vector<void*> ipc_opened;               // mappings to close
     unsigned long long* d_ipc_epoch = nullptr;   // reductions completed so far (device)
     bool ipc_on = false;                         // reduce_then uses the mailbox path
+    bool ipc_failed = false;                     // the test reduction over the mailboxes failed (agreed across ranks): never switched on again
     kr::PhaseTimer* phase = nullptr;     // non-null while kryst_phase_timing is on
+    std::vector<void*> deferred_free;    // device allocations that outlive their owner and go with the context (spmv.hip: halo_peer_destroy)
     int num_cu = 256;
 };
 
@@ -148,6 +150,17 @@ struct kryst_vec_s {
 namespace kr {
 
 int32_t ensure_partials(kryst_ctx_t ctx, int64_t ntiles);
+
+// Device blocks of a destroyed ILU-family preconditioner (factor streams, blocked layouts, work vectors, the set-up's scratch) are kept in a
+// size-keyed pool per DEVICE and handed to the next set-up that asks for the same size -- Ilup::setup is called per matrix, repeatedly
+// (ilup.rs:77-134), and at 512^3 giving 22 GB back to the driver and taking it again cost ten times the factorisation.
+// pool_malloc: an exact-size block from the pool, else hipMalloc (the pool is emptied and the call repeated once when the driver has no room).
+// pool_free: waits for the device like hipFree does, then keeps blocks of >= 1 MiB while the pool stays below KRYST_DEV_POOL_MB (default
+// 65536; 0: no pool), frees otherwise.  pool_trim gives everything back (kryst_ctx_trim).  Thread-safe.
+hipError_t pool_malloc_bytes(void** p, size_t bytes);
+hipError_t pool_free(void* p);
+size_t pool_trim(int device);                         // -> bytes returned to the driver
+template <class T> inline hipError_t pool_malloc(T** p, size_t bytes) { return pool_malloc_bytes(reinterpret_cast<void**>(p), bytes); }
 void phase_mark_slow(kryst_ctx_t ctx, int phase);                       // ctx.cpp
 inline void phase_mark(kryst_ctx_t ctx, int phase) { if (ctx->phase) phase_mark_slow(ctx, phase); }
 inline int64_t ntiles_of(int64_t n) { return (n + KR_TILE - 1) / KR_TILE; }

@@ -72,7 +72,9 @@ int32_t halo_begin(kryst_csr_t a, const double* x);
 // switch the operator's halo exchange to direct peer stores (collective; KRYST_UNSUPPORTED on every rank when a rank cannot map a peer's
 // landing buffer or a neighbour relation is one-way) / back to RCCL
 int32_t halo_peer_setup(kryst_csr_t a);
+int32_t halo_peer_selftest(kryst_csr_t a);   // one checked exchange over the fresh mappings; agreed verdict (KRYST_OK / KRYST_UNSUPPORTED on every rank)
 void halo_peer_destroy(kryst_csr_t a);
+int32_t halo_default_mode(kryst_csr_t a);    // at creation: peer stores when they work on every rank, else RCCL (KRYST_HALO_MODE=rccl: RCCL)
 // the tile ranges [lo, hi) whose rows are sent to neighbours, merged and ascending (send_contiguous operators)
 void halo_send_tiles(kryst_csr_t a, std::vector<std::pair<int64_t, int64_t>>& ranges);
 

@@ -618,6 +618,7 @@ int32_t kryst_csr_create_dist(kryst_ctx_t ctx, int64_t n_global, const int64_t* 
         for (int64_t v : all) every = every && v == 1;
         a->halo_early_ok = rc == KRYST_OK && every;
     }
+    if (rc == KRYST_OK) rc = halo_default_mode(a);       // (every rank is here with rc == KRYST_OK, or none is)
     if (rc != KRYST_OK) { if (a) kryst_csr_destroy(a); return rc; }
     *out = a;
     return KRYST_OK;
@@ -796,6 +797,9 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
                          pl.send_counts[me + 1] = N2; pl.send_off[me + 1] = nloc - N2; }
         pl.total_recv = (has_lower ? N2 : 0) + (has_upper ? N2 : 0);
         pl.total_send = pl.total_recv;
+        pl.recv_cols.clear();                           // global columns of the halo slots: the plane below, then the plane above
+        if (has_lower) for (int64_t c = lo - N2; c < lo; ++c) pl.recv_cols.push_back(c);
+        if (has_upper) for (int64_t c = hi; c < hi + N2; ++c) pl.recv_cols.push_back(c);
         a->send_contiguous = true;                      // send_off = first local row of each run
         a->halo_early_ok = true;                        // ... on every rank of a k-slab partition (analytic plan: nothing to agree on)
         std::vector<int32_t> ti, tb;
@@ -814,6 +818,11 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
         (void)hipMemsetAsync(pl.d_halo, 0, sizeof(double) * (size_t)(pl.total_recv + 2), ctx->s_main);
         if (hipStreamSynchronize(ctx->s_main) != hipSuccess) { set_error("halo setup failed"); rc = KRYST_ERR_HIP; }
     } while (0);
+    // several ranks: the default halo mode is chosen collectively, so a rank that failed above must say so before the others enter it
+    if (dist && P > 1 && ctx->comm) {
+        rc = agree_on_status(ctx, rc);
+        if (rc == KRYST_OK) rc = halo_default_mode(a);
+    }
     if (rc != KRYST_OK) { kryst_csr_destroy(a); return rc; }
     *out = a;
     return KRYST_OK;

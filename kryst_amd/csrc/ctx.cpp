@@ -1,6 +1,9 @@
 // Context management, error text, host-side problem generators.
 #include "dist.h"
 #include <cstdarg>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 
 namespace kr {
 std::atomic<uint32_t> g_env_epoch{1};
@@ -16,6 +19,75 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace kr
 namespace kr {
+// ---- device block pool (common.h)
+namespace {
+struct DevPool {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_blocks;         // size -> block, per device
+    std::unordered_map<void*, size_t> live;           // blocks handed out that may come back (>= POOL_MIN bytes)
+    size_t pooled = 0;
+};
+constexpr size_t POOL_MIN = (size_t)1 << 20;
+DevPool g_pools[64];
+size_t pool_cap_bytes() {
+    static const size_t cap = [] { const char* e = getenv("KRYST_DEV_POOL_MB"); const long long mb = e ? atoll(e) : 65536; return mb <= 0 ? (size_t)0 : (size_t)mb << 20; }();
+    return cap;
+}
+DevPool* pool_here(int* dev_out = nullptr) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    if (dev_out) *dev_out = dev;
+    return &g_pools[dev & 63];
+}
+}  // namespace
+hipError_t pool_malloc_bytes(void** p, size_t bytes) {
+    DevPool* P = pool_here();
+    if (bytes >= POOL_MIN && pool_cap_bytes() > 0) {
+        std::lock_guard<std::mutex> g(P->mu);
+        auto it = P->free_blocks.find(bytes);
+        if (it != P->free_blocks.end()) {
+            *p = it->second; P->pooled -= bytes; P->free_blocks.erase(it); P->live[*p] = bytes;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {                             // no room: what the pool holds goes back to the driver, then once more
+        (void)hipGetLastError();
+        int dev = 0; (void)pool_here(&dev);
+        if (pool_trim(dev) > 0) e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess && bytes >= POOL_MIN && pool_cap_bytes() > 0) { std::lock_guard<std::mutex> g(P->mu); P->live[*p] = bytes; }
+    return e;
+}
+hipError_t pool_free(void* p) {
+    if (!p) return hipSuccess;
+    DevPool* P = pool_here();
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> g(P->mu);
+        auto it = P->live.find(p);
+        if (it != P->live.end()) { bytes = it->second; P->live.erase(it); }
+    }
+    if (bytes == 0 || pool_cap_bytes() == 0) return hipFree(p);
+    // hipFree waits for the device before it releases a block; a block that goes to the pool instead must not be handed to a new owner
+    // under a kernel that still uses it either
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipGetLastError(); return hipFree(p); }
+    std::lock_guard<std::mutex> g(P->mu);
+    if (P->pooled + bytes > pool_cap_bytes()) return hipFree(p);
+    P->free_blocks.emplace(bytes, p); P->pooled += bytes;
+    return hipSuccess;
+}
+size_t pool_trim(int device) {
+    DevPool* P = &g_pools[device & 63];
+    std::multimap<size_t, void*> blocks;
+    size_t bytes = 0;
+    { std::lock_guard<std::mutex> g(P->mu); blocks.swap(P->free_blocks); bytes = P->pooled; P->pooled = 0; }
+    for (auto& b : blocks) (void)hipFree(b.second);
+    (void)hipGetLastError();
+    return bytes;
+}
+
 void phase_mark_slow(kryst_ctx_t ctx, int phase) {
     PhaseTimer* T = ctx->phase;
     hipEvent_t e = nullptr;
@@ -66,7 +138,7 @@ extern "C" {
 
 const char* kryst_hip_last_error(void) { return g_err; }
 int64_t kryst_hip_last_error_row(void) { return g_err_row; }
-int32_t kryst_hip_abi_version(void) { return 4; }
+int32_t kryst_hip_abi_version(void) { return 5; }
 void kryst_reduce_spec(int32_t* T, int32_t* V, int32_t* F) {
     if (T) *T = KR_T;
     if (V) *V = KR_V;
@@ -103,10 +175,11 @@ int32_t kryst_ctx_create_dist(int32_t device_id, int32_t rank, int32_t nranks, c
     int32_t rc = ctx_init(ctx);
     if (rc == KRYST_OK) rc = comm_init(ctx, uid);
     if (rc == KRYST_OK) {
-        // KRYST_SCALAR_REDUCE=ipc: the mailbox path from the start (all ranks read the same environment); failure to set it up is
-        // not an error -- the RCCL path stays
+        // The inner products cross the ranks through the hipIpc mailboxes whenever every rank can set them up AND one checked reduction
+        // arrives intact on every rank (dist.cpp: ipc_reduce_setup -> ipc_reduce_selftest; agreed outcome); otherwise -- not an error -- the
+        // RCCL all-gather stays.  KRYST_SCALAR_REDUCE=rccl: do not try (all ranks read the same environment).
         const char* e = getenv("KRYST_SCALAR_REDUCE");
-        if (e && strcmp(e, "ipc") == 0) { const int32_t r2 = ipc_reduce_setup(ctx); if (r2 != KRYST_OK && r2 != KRYST_UNSUPPORTED) rc = r2; }
+        if (nranks > 1 && !(e && strcmp(e, "rccl") == 0)) { const int32_t r2 = ipc_reduce_setup(ctx); if (r2 != KRYST_OK && r2 != KRYST_UNSUPPORTED) rc = r2; }
     }
     if (rc != KRYST_OK) { kryst_ctx_destroy(ctx); return rc; }      // frees whatever ctx_init / comm_init got as far as creating
     *out = ctx;
@@ -120,6 +193,8 @@ int32_t kryst_ctx_destroy(kryst_ctx_t ctx) {
     if (ctx->s_comm) (void)hipStreamSynchronize(ctx->s_comm);
     comm_destroy(ctx);
     if (ctx->phase) { for (auto& m : ctx->phase->marks) (void)hipEventDestroy(m.second); for (auto& e : ctx->phase->pool) (void)hipEventDestroy(e); delete ctx->phase; }
+    for (void* q : ctx->deferred_free) (void)hipFree(q);
+    (void)pool_trim(ctx->device);                     // (per device: a second context on this device simply refills it)
     (void)hipFree(ctx->d_partials); (void)hipFree(ctx->d_chunks); (void)hipFree(ctx->d_ticket); (void)hipFree(ctx->d_scal); (void)hipFree(ctx->d_gather); (void)hipFree(ctx->arena);
     (void)hipHostFree((void*)ctx->h_prog); (void)hipHostFree(ctx->h_pinned);
     for (hipEvent_t e : {ctx->ev_x_ready, ctx->ev_halo_done, ctx->tm0, ctx->tm1}) if (e) (void)hipEventDestroy(e);
@@ -136,6 +211,21 @@ int32_t kryst_ctx_synchronize(kryst_ctx_t ctx) {
     KR_HIP(hipSetDevice(ctx->device));
     KR_HIP(hipStreamSynchronize(ctx->s_comm));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
+    return KRYST_OK;
+}
+
+// Give back to the driver what the context keeps for reuse between calls: the device block pool of destroyed ILU-family preconditioners
+// (common.h: pool_*; per device) and -- when no solve or stepping session is open -- the work-vector arena of the solvers.
+int32_t kryst_ctx_trim(kryst_ctx_t ctx, int64_t* bytes_released) {
+    KR_ARG(ctx, "ctx_trim");
+    KR_HIP(hipSetDevice(ctx->device));
+    KR_TRY(kryst_ctx_synchronize(ctx));
+    size_t freed = pool_trim(ctx->device);
+    if (ctx->active_ws == nullptr && ctx->arena_owner == nullptr && ctx->arena) {
+        freed += ctx->arena_bytes;
+        (void)hipFree(ctx->arena); ctx->arena = nullptr; ctx->arena_bytes = 0; ctx->arena_used = 0;
+    }
+    if (bytes_released) *bytes_released = (int64_t)freed;
     return KRYST_OK;
 }
 
@@ -161,11 +251,13 @@ int32_t kryst_comm_all_reduce(kryst_ctx_t ctx, double x, double* out) {
     return KRYST_OK;
 }
 
-// How the solvers' inner products cross the ranks: mode 0 = RCCL all-gather + rank-ordered fold (default), 1 = IPC mailboxes
+// How the solvers' inner products cross the ranks: mode 0 = RCCL all-gather + rank-ordered fold, 1 = IPC mailboxes (the default when their
+// set-up and test reduction succeed on every rank), -1 = query
 // (dist.cpp: one launch per inner product, no collective).  COLLECTIVE: every rank of the context calls it with the same mode.
 // KRYST_UNSUPPORTED (mode 1) when some rank cannot export / map a mailbox: every rank then stays on RCCL.  *active: the mode in use.
 int32_t kryst_ctx_scalar_reduce(kryst_ctx_t ctx, int32_t mode, int32_t* active) {
-    KR_ARG(ctx && (mode == 0 || mode == 1), "ctx_scalar_reduce");
+    KR_ARG(ctx && (mode == 0 || mode == 1 || mode == -1), "ctx_scalar_reduce");
+    if (mode == -1) { if (active) *active = ctx->ipc_on ? 1 : 0; return KRYST_OK; }      // query only
     KR_ARG(ctx->active_ws == nullptr, "ctx_scalar_reduce: a solve or stepping session is open on this context");
     int32_t rc = KRYST_OK;
     if (ctx->nranks > 1 || ctx->comm) {

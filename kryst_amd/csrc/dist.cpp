@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <mutex>
 #include <unistd.h>
+#include <ctime>
+#include <cstdio>
 
 namespace kr {
 
@@ -163,10 +165,35 @@ void ipc_close_shared(void* ptr) {
 // one GPU): for them a kernel of one rank that waits for a kernel the sibling's host thread has yet to enqueue can wait for ever, because
 // host calls of that thread which synchronise the device or stage through the runtime (hipFree, a copy to pageable memory) wait for the
 // waiting kernel first -- measured: tools/peer_debug.py, DESIGN.md section 6.
-int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, std::vector<void*>& opened, bool same_device_siblings) {
+// Who a rank's process is, beyond its pid: pids repeat across nodes, PID namespaces and containers (pods start with small pids), and a
+// foreign rank that merely shares this process's pid must never be addressed by its raw device pointer.  A random 64-bit nonce drawn once
+// per process plus a hash of the host's boot id and name: only a rank that carries BOTH of this process's values lives in this address space.
+static uint64_t process_nonce() {
+    static const uint64_t nonce = [] {
+        uint64_t v = 0;
+        if (FILE* f = fopen("/dev/urandom", "rb")) { if (fread(&v, sizeof v, 1, f) != 1) v = 0; fclose(f); }
+        if (v == 0) v = ((uint64_t)getpid() * 0x9E3779B97F4A7C15ull) ^ (uint64_t)(uintptr_t)&v ^ (uint64_t)time(nullptr);
+        return v | 1ull;
+    }();
+    return nonce;
+}
+static uint64_t host_hash() {
+    static const uint64_t h = [] {
+        uint64_t x = 0xcbf29ce484222325ull;                              // FNV-1a over boot id + host name
+        auto eat = [&x](const char* s, size_t n) { for (size_t i = 0; i < n; ++i) { x ^= (unsigned char)s[i]; x *= 0x100000001b3ull; } };
+        char buf[256];
+        if (FILE* f = fopen("/proc/sys/kernel/random/boot_id", "rb")) { const size_t n = fread(buf, 1, sizeof buf, f); fclose(f); eat(buf, n); }
+        if (gethostname(buf, sizeof buf) == 0) { buf[sizeof buf - 1] = 0; eat(buf, strlen(buf)); }
+        return x;
+    }();
+    return h;
+}
+
+int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, std::vector<void*>& opened, bool same_device_siblings, bool* sibling) {
+    if (sibling) *sibling = false;
     KR_ARG(ctx->comm, "ipc_map_peers: context has no communicator");
     const int P = ctx->nranks, me = ctx->rank;
-    constexpr int W = 12;                      // words per rank: ok, pid, device, address, handle[8]
+    constexpr int W = 14;                      // words per rank: ok, pid, device, address, process nonce, host hash, handle[8]
     int64_t send[W] = {0};
     hipIpcMemHandle_t hmine;
     memset(&hmine, 0, sizeof hmine);
@@ -175,7 +202,8 @@ int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, st
     const char* why = "";
     if (!ok_mine) why = "no buffer to export";
     if (ok_mine) { const hipError_t e = hipIpcGetMemHandle(&hmine, mine); if (e != hipSuccess) { (void)hipGetLastError(); ok_mine = 0; why = hipGetErrorString(e); set_error("hipIpcGetMemHandle: %s", why); } }
-    send[0] = ok_mine; send[1] = (int64_t)getpid(); send[2] = ctx->device; send[3] = (int64_t)(uintptr_t)mine; memcpy(send + 4, &hmine, 64);
+    send[0] = ok_mine; send[1] = (int64_t)getpid(); send[2] = ctx->device; send[3] = (int64_t)(uintptr_t)mine;
+    send[4] = (int64_t)process_nonce(); send[5] = (int64_t)host_hash(); memcpy(send + 6, &hmine, 64);
     std::vector<int64_t> all((size_t)W * P, 0);
     int64_t *d_s = nullptr, *d_r = nullptr;
     int32_t rc = KRYST_OK;
@@ -193,7 +221,7 @@ int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, st
     for (int p = 0; p < P && ok_all; ++p) {
         const int64_t* w = &all[(size_t)W * p];
         if (p == me) { peers[p] = mine; continue; }
-        if (w[1] == (int64_t)getpid()) {                             // a rank of this process: same address space
+        if (w[1] == (int64_t)getpid() && w[4] == (int64_t)process_nonce() && w[5] == (int64_t)host_hash()) {      // a rank of THIS process: same address space
             const int pdev = (int)w[2];
             if (pdev == ctx->device && !same_device_siblings) { ok_all = 0; break; }      // (the caller's kernels must not wait on a sibling that shares the device)
             if (pdev != ctx->device) {
@@ -204,9 +232,10 @@ int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, st
                 (void)hipGetLastError();
             }
             peers[p] = reinterpret_cast<void*>((uintptr_t)w[3]);
+            if (sibling) *sibling = true;
             continue;
         }
-        hipIpcMemHandle_t h; memcpy(&h, w + 4, 64);
+        hipIpcMemHandle_t h; memcpy(&h, w + 6, 64);
         void* ptr = nullptr;
         { const hipError_t e = ipc_open_shared(&ptr, h); if (e != hipSuccess) { (void)hipGetLastError(); ok_all = 0; fprintf(stderr, "[kryst] rank %d: hipIpcOpenMemHandle of rank %d's buffer: %s\n", me, p, hipGetErrorString(e)); break; } }
         opened.push_back(ptr);
@@ -236,6 +265,7 @@ int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, st
 
 int32_t ipc_reduce_setup(kryst_ctx_t ctx) {
     if (ctx->ipc_on) return KRYST_OK;
+    if (ctx->ipc_mine && ctx->ipc_failed) { set_error("scalar all-reduce through mailboxes: the test reduction failed on this context before; the RCCL path stays in use"); return KRYST_UNSUPPORTED; }
     if (ctx->ipc_mine) { ctx->ipc_on = true; return KRYST_OK; }      // set up before and switched off: the mailboxes are still mapped on every rank,
                                                                      // and every rank has counted the same epochs
     KR_ARG(ctx->comm, "ipc_reduce_setup: context has no communicator");
@@ -260,7 +290,7 @@ int32_t ipc_reduce_setup(kryst_ctx_t ctx) {
                            hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;      // (cannot fail on one rank alone in practice: an 8 P byte copy)
     if (rc != KRYST_OK) { ipc_reduce_destroy(ctx); return rc; }
     ctx->ipc_on = true;
-    return KRYST_OK;
+    return ipc_reduce_selftest(ctx);                                 // (solvers.hip: one checked reduction; agreed verdict)
 }
 
 static int owner_of(const int64_t* row_offsets, int nranks, int64_t c) {

@@ -20,10 +20,12 @@ int32_t comm_exchange(kryst_ctx_t ctx, const void* send, const int64_t* send_cou
 // Mailbox path of the scalar all-reduce (see kryst_ctx_s): collective over the context's ranks (one all-gather of the IPC
 // handles).  On success ctx->ipc_on is set on EVERY rank, or on none (the outcome is agreed through an all-gather).
 int32_t ipc_reduce_setup(kryst_ctx_t ctx);
+int32_t ipc_reduce_selftest(kryst_ctx_t ctx);          // solvers.hip: one checked reduction over the fresh mailboxes (KRYST_OK / KRYST_UNSUPPORTED on every rank)
 // one allocation of every rank mapped into this process (hipIpc between processes, directly between ranks of one process); collective,
 // agreed outcome (KRYST_OK everywhere or KRYST_UNSUPPORTED everywhere); `opened` collects the mappings to close with hipIpcCloseMemHandle
 void ipc_close_shared(void* ptr);                       // closes a mapping ipc_map_peers opened (shared between the ranks of a process, counted)
-int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, std::vector<void*>& opened, bool same_device_siblings);
+// *sibling (optional): some peer is a rank of this very process and is addressed by its raw device pointer (no mapping keeps its memory alive)
+int32_t ipc_map_peers(kryst_ctx_t ctx, void* mine, std::vector<void*>& peers, std::vector<void*>& opened, bool same_device_siblings, bool* sibling = nullptr);
 void    ipc_reduce_destroy(kryst_ctx_t ctx);
 
 // Halo exchange by direct peer stores ("direct peer writes over xGMI / IPC-mapped buffers"; replaces the neighbour exchange
@@ -47,6 +49,8 @@ struct HaloPeer {
     HaloPullSeg* d_pull = nullptr; int npull = 0; int64_t pull_max = 0;
     unsigned int* d_ticket = nullptr;    // the push kernel's "last workgroup" counter
     unsigned long long epoch = 0;        // exchanges issued on this operator so far (the same number on every rank)
+    bool sibling = false;                // a rank thread of this process stores into `landing` by raw pointer: freed with the context, not the operator
+    bool failed = false;                 // the test exchange did not arrive intact (agreed across ranks): never switched on again
 };
 
 // Halo plan of a row-partitioned operator (host side; also exported as kryst_host_halo_recv_plan)

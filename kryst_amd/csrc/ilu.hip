@@ -139,9 +139,9 @@ struct TriFactor {                  // one triangular factor in level order
     int held = 16;                  // entries of a row the CSR sync-free kernel holds in registers (8: no row is longer than that)
     std::vector<int32_t> lvl_off;   // host: position offsets per level
     int32_t* d_lvl_off = nullptr;
-    void free_all() { (void)hipFree(d_ptr); (void)hipFree(d_col); (void)hipFree(d_val); (void)hipFree(d_row); (void)hipFree(d_diag); (void)hipFree(d_lvl_off);
-                      (void)hipFree(d_fdesc); (void)hipFree(d_fval); (void)hipFree(d_fpos); (void)hipFree(d_vreal);
-                      (void)hipFree(d_ecol); (void)hipFree(d_eval); (void)hipFree(d_elen); }
+    void free_all() { (void)pool_free(d_ptr); (void)pool_free(d_col); (void)pool_free(d_val); (void)pool_free(d_row); (void)pool_free(d_diag); (void)pool_free(d_lvl_off);
+                      (void)pool_free(d_fdesc); (void)pool_free(d_fval); (void)pool_free(d_fpos); (void)pool_free(d_vreal);
+                      (void)pool_free(d_ecol); (void)pool_free(d_eval); (void)pool_free(d_elen); }
     EllView view() const { return EllView{d_ecol, d_eval, d_elen, npos}; }
 };
 
@@ -160,8 +160,8 @@ struct GridFactor {
     double* d_edge_e = nullptr; double* d_edge_n = nullptr;                // edge rows handed to the next workgroup: [block][steps + 8][16]
     uint8_t* d_skip = nullptr;                                              // [block][quadrant][chunk]: coefficients repeat chunk - 3's (tri_quad_dedup_kernel)
     int64_t nskip = 0;                                                      // how many of them do (KRYST_ILU_VERBOSE)
-    void free_all() { (void)hipFree(d_c1); (void)hipFree(d_c2); (void)hipFree(d_c3); (void)hipFree(d_diag);
-                      (void)hipFree(d_blocked); (void)hipFree(d_edge_e); (void)hipFree(d_edge_n); (void)hipFree(d_skip); }
+    void free_all() { (void)pool_free(d_c1); (void)pool_free(d_c2); (void)pool_free(d_c3); (void)pool_free(d_diag);
+                      (void)pool_free(d_blocked); (void)pool_free(d_edge_e); (void)pool_free(d_edge_n); (void)pool_free(d_skip); }
 };
 struct GridView { int32_t Ni, Nj, Nk; const double* c1; const double* c2; const double* c3; const double* diag; };
 
@@ -179,7 +179,7 @@ struct BoxFactor {
     void* d_cb = nullptr;           // blocked copy for tri_box_kernel: [block][chunk][stream (, divisor)][step pair][lane] (tri_box_layout_kernel)
     uint32_t present = 0x1fff;      // streams with at least one entry
     bool regular = false;           // every present stream has an entry wherever the neighbour row exists in the box (tri_box.h: REGULAR)
-    void free_all() { (void)hipFree(d_c); (void)hipFree(d_diag); (void)hipFree(d_cb); d_c = nullptr; d_diag = nullptr; d_cb = nullptr; }
+    void free_all() { (void)pool_free(d_c); (void)pool_free(d_diag); (void)pool_free(d_cb); d_c = nullptr; d_diag = nullptr; d_cb = nullptr; }
 };
 struct BoxView { int32_t Ni, Nj, Nk; int64_t n; const double* c; const double* diag; int64_t cs; const void* cb; };   // cs: doubles from one stream to the next; cb: blocked copy (tri_box.h)
 // Streams are NOT n doubles apart: with n = 128^3 that is 16 MiB, and the 13 coefficients of a row would sit in the same HBM channel and bank
@@ -1005,12 +1005,12 @@ static int32_t build_free_streams(TriFactor* F, hipStream_t st, const int32_t* h
     }
     int32_t* d_vs = nullptr;
     const bool ok = chunks > 0 && chunks * 512 * 8 < ((size_t)1 << 32) &&
-                    hipMalloc(&F->d_fdesc, chunks * 512 * sizeof(int32_t)) == hipSuccess && hipMalloc(&F->d_fval, chunks * 512 * sizeof(double)) == hipSuccess &&
-                    hipMalloc(&F->d_fpos, chunks * 512 * sizeof(int32_t)) == hipSuccess && hipMalloc(&F->d_vreal, chunks * 64 * sizeof(int32_t)) == hipSuccess &&
-                    hipMalloc(&d_vs, vs.size() * sizeof(int32_t)) == hipSuccess;
+                    pool_malloc(&F->d_fdesc, chunks * 512 * sizeof(int32_t)) == hipSuccess && pool_malloc(&F->d_fval, chunks * 512 * sizeof(double)) == hipSuccess &&
+                    pool_malloc(&F->d_fpos, chunks * 512 * sizeof(int32_t)) == hipSuccess && pool_malloc(&F->d_vreal, chunks * 64 * sizeof(int32_t)) == hipSuccess &&
+                    pool_malloc(&d_vs, vs.size() * sizeof(int32_t)) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
-        (void)hipFree(F->d_fdesc); (void)hipFree(F->d_fval); (void)hipFree(F->d_fpos); (void)hipFree(F->d_vreal); (void)hipFree(d_vs);
+        (void)pool_free(F->d_fdesc); (void)pool_free(F->d_fval); (void)pool_free(F->d_fpos); (void)pool_free(F->d_vreal); (void)pool_free(d_vs);
         F->d_fdesc = nullptr; F->d_fval = nullptr; F->d_fpos = nullptr; F->d_vreal = nullptr; F->run_cbase.clear(); F->run_nvirt.clear();
         F->free_runs = false;
         if (F->ell) F->syncfree = true;                    // (an ELL factor's other form)
@@ -1031,7 +1031,7 @@ static int32_t build_free_streams(TriFactor* F, hipStream_t st, const int32_t* h
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d_vs);
+    (void)pool_free(d_vs);
     if (e != hipSuccess) { set_error("operand streams of the run kernel: %s", hipGetErrorString(e)); return KRYST_ERR_HIP; }
     return KRYST_OK;
 }
@@ -1281,7 +1281,7 @@ void ilu_free(kryst_pc_t pc) {
     if (D->h_gave_up) (void)hipHostFree(D->h_gave_up);
     if (D->exec) (void)hipGraphExecDestroy(D->exec);
     if (D->graph) (void)hipGraphDestroy(D->graph);
-    D->L.free_all(); D->U.free_all(); D->GL.free_all(); D->GU.free_all(); D->BL.free_all(); D->BU.free_all(); (void)hipFree(D->d_args); (void)hipFree(D->d_flags); (void)hipFree(D->d_y); (void)hipFree(D->d_rL); (void)hipFree(D->d_yU); (void)hipFree(D->d_zU); (void)hipFree(D->d_mapLU);
+    D->L.free_all(); D->U.free_all(); D->GL.free_all(); D->GU.free_all(); D->BL.free_all(); D->BU.free_all(); (void)pool_free(D->d_args); (void)pool_free(D->d_flags); (void)pool_free(D->d_y); (void)pool_free(D->d_rL); (void)pool_free(D->d_yU); (void)pool_free(D->d_zU); (void)pool_free(D->d_mapLU);
     delete D;
     pc->d_work = nullptr;
 }
@@ -1298,7 +1298,7 @@ static int32_t zero_dev(void* dst, size_t bytes, hipStream_t s) {
 }
 template <class T, class A>
 static int32_t up(T** dst, const std::vector<T, A>& v) {
-    KR_HIP(hipMalloc(dst, sizeof(T) * (v.size() + 1)));
+    KR_HIP(pool_malloc(dst, sizeof(T) * (v.size() + 1)));
     KR_HIP(hipMemsetAsync(*dst, 0, sizeof(T) * (v.size() + 1), tl_setup_stream));
     if (!v.empty()) KR_HIP(hipMemcpyAsync(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, tl_setup_stream));
     KR_HIP(hipStreamSynchronize(tl_setup_stream));
@@ -1535,8 +1535,8 @@ static int32_t build_box(int64_t n, const FlatRows& ent, const hvec<double>& dia
     int64_t* d_ptr = nullptr; int32_t* d_col = nullptr; double* d_val = nullptr; int32_t* d_bad = nullptr;
     const size_t cb = sizeof(double) * (size_t)13 * (size_t)box_stream_stride(n), ne = (size_t)ent.ptr[(size_t)n];
     int32_t bad = 1;
-    bool ok = hipMalloc(&d_ptr, sizeof(int64_t) * ((size_t)n + 1)) == hipSuccess && hipMalloc(&d_col, sizeof(int32_t) * (ne + 1)) == hipSuccess &&
-              hipMalloc(&d_val, sizeof(double) * (ne + 1)) == hipSuccess && hipMalloc(&d_bad, 128) == hipSuccess && hipMalloc(&B->d_c, cb) == hipSuccess;
+    bool ok = pool_malloc(&d_ptr, sizeof(int64_t) * ((size_t)n + 1)) == hipSuccess && pool_malloc(&d_col, sizeof(int32_t) * (ne + 1)) == hipSuccess &&
+              pool_malloc(&d_val, sizeof(double) * (ne + 1)) == hipSuccess && pool_malloc(&d_bad, 128) == hipSuccess && pool_malloc(&B->d_c, cb) == hipSuccess;
     unsigned long long hostw[16];                                           // [0]: "not a box factor", [1..13]: entries per stream
     ok = ok && hipMemsetAsync(B->d_c, 0, cb, st) == hipSuccess && hipMemsetAsync(d_bad, 0, 128, st) == hipSuccess &&
          hipMemcpyAsync(d_ptr, ent.ptr.data(), sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, st) == hipSuccess &&
@@ -1548,7 +1548,7 @@ static int32_t build_box(int64_t n, const FlatRows& ent, const hvec<double>& dia
         ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(hostw, d_bad, 128, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
         if (ok) bad = (int32_t)(hostw[0] & 0xffffffffull);
     }
-    (void)hipFree(d_ptr); (void)hipFree(d_col); (void)hipFree(d_val); (void)hipFree(d_bad);
+    (void)pool_free(d_ptr); (void)pool_free(d_col); (void)pool_free(d_val); (void)pool_free(d_bad);
     if (!ok) { (void)hipGetLastError(); B->free_all(); set_error("box-stencil factor: device allocation or copy failed"); return KRYST_ERR_HIP; }
     if (bad != 0) { B->free_all(); return KRYST_OK; }
     if (!forward) KR_TRY(up(&B->d_diag, diag));
@@ -1578,21 +1578,21 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
     kryst_ctx_t ctx = pc->ctx;
     const int64_t n = D->n;
     int32_t rc = KRYST_OK;
-    if (hipMalloc(&D->d_args, sizeof(TriArgs)) != hipSuccess || zero_dev(D->d_args, sizeof(TriArgs), ctx->s_main) != KRYST_OK) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+    if (pool_malloc(&D->d_args, sizeof(TriArgs)) != hipSuccess || zero_dev(D->d_args, sizeof(TriArgs), ctx->s_main) != KRYST_OK) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
     if (rc == KRYST_OK) {
         const size_t bytes = sizeof(double) * (size_t)((n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
         const bool grid = (D->GL.ok && D->GU.ok) || (D->BL.ok && D->BU.ok);   // the wavefront / box solves work in place: one intermediate vector
         for (double** pp : {&D->d_y, &D->d_rL, &D->d_yU, &D->d_zU}) {
             if (rc != KRYST_OK) break;
             if (grid && pp != &D->d_y) continue;
-            if (hipMalloc(pp, bytes) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+            if (pool_malloc(pp, bytes) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
             else if (hipMemsetAsync(*pp, 0, bytes, ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
         }
         if (rc == KRYST_OK && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;
     }
     if (rc == KRYST_OK && D->BL.ok && D->BU.ok && D->BL.Ni >= 2) {
         const size_t nb = (size_t)tb_nbj(D->BL.Nj) * (size_t)tb_nbk(D->BL.Nk);
-        if (hipMalloc(&D->d_flags, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess || zero_dev(D->d_flags, sizeof(int32_t) * (2 * nb + 1), ctx->s_main) != KRYST_OK) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (pool_malloc(&D->d_flags, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess || zero_dev(D->d_flags, sizeof(int32_t) * (2 * nb + 1), ctx->s_main) != KRYST_OK) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
         if (rc == KRYST_OK && (hipHostMalloc((void**)&D->h_gave_up, 64, hipHostMallocMapped) != hipSuccess ||
                                hipHostGetDevicePointer((void**)&D->d_gave_up, D->h_gave_up, 0) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = KRYST_ERR_HIP; }
         if (rc == KRYST_OK && env_int("KRYST_ILU_BOX", KR_ILU_BOX_DEFAULT) >= 2) {
@@ -1601,8 +1601,8 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
             const size_t el = (size_t)(TB_C / 2) * 64 * 16;
             const BoxView VA{D->BL.Ni, D->BL.Nj, D->BL.Nk, D->n, D->BL.d_c, nullptr, box_stream_stride(D->n), nullptr};
             const BoxView VB{D->BU.Ni, D->BU.Nj, D->BU.Nk, D->n, D->BU.d_c, D->BU.d_diag, box_stream_stride(D->n), nullptr};
-            if (hipMalloc(&D->BL.d_cb, nb * nch * 13 * el) != hipSuccess || hipMalloc(&D->BU.d_cb, nb * nch * 14 * el) != hipSuccess) {
-                (void)hipGetLastError(); (void)hipFree(D->BL.d_cb); (void)hipFree(D->BU.d_cb); D->BL.d_cb = D->BU.d_cb = nullptr;     // (no room: the hyperplane kernels)
+            if (pool_malloc(&D->BL.d_cb, nb * nch * 13 * el) != hipSuccess || pool_malloc(&D->BU.d_cb, nb * nch * 14 * el) != hipSuccess) {
+                (void)hipGetLastError(); (void)pool_free(D->BL.d_cb); (void)pool_free(D->BU.d_cb); D->BL.d_cb = D->BU.d_cb = nullptr;     // (no room: the hyperplane kernels)
             } else {
                 hipLaunchKernelGGL((tri_box_layout_kernel<true>), dim3((unsigned)(nb * nch)), dim3(256), 0, ctx->s_main, VA, (tw_v2*)D->BL.d_cb);
                 hipLaunchKernelGGL((tri_box_layout_kernel<false>), dim3((unsigned)(nb * nch)), dim3(256), 0, ctx->s_main, VB, (tw_v2*)D->BU.d_cb);
@@ -1624,7 +1624,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
     }
     if (rc == KRYST_OK && D->GL.ok && D->GU.ok) {
         const size_t nb = (size_t)((D->GL.Nj + 7) / 8) * (size_t)((D->GL.Nk + 7) / 8);
-        if (hipMalloc(&D->d_flags, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess || zero_dev(D->d_flags, sizeof(int32_t) * (2 * nb + 1), ctx->s_main) != KRYST_OK) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (pool_malloc(&D->d_flags, sizeof(int32_t) * (2 * nb + 1)) != hipSuccess || zero_dev(D->d_flags, sizeof(int32_t) * (2 * nb + 1), ctx->s_main) != KRYST_OK) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
         if (rc == KRYST_OK && (hipHostMalloc((void**)&D->h_gave_up, 64, hipHostMallocMapped) != hipSuccess ||
                                hipHostGetDevicePointer((void**)&D->d_gave_up, D->h_gave_up, 0) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = KRYST_ERR_HIP; }
         if (rc == KRYST_OK) *D->h_gave_up = 0;
@@ -1638,12 +1638,12 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
                 const int NA = fwd ? 3 : 4;
                 const size_t cbytes = nq * G->nch * NA * 4 * TQ_LINES * sizeof(tw_v2);
                 const size_t ebytes = nq * (size_t)(G->nch * TQ_C + 8) * 16 * sizeof(double);
-                if (hipMalloc(&G->d_blocked, cbytes) != hipSuccess || hipMalloc(&G->d_edge_e, ebytes) != hipSuccess ||
-                    hipMalloc(&G->d_edge_n, ebytes) != hipSuccess) {
+                if (pool_malloc(&G->d_blocked, cbytes) != hipSuccess || pool_malloc(&G->d_edge_e, ebytes) != hipSuccess ||
+                    pool_malloc(&G->d_edge_n, ebytes) != hipSuccess) {
                     // no room for the blocked copy (it doubles the factor's footprint): the 8 x 8 kernel works on the natural-order streams
                     (void)hipGetLastError();
                     for (GridFactor* H : {&D->GL, &D->GU}) {
-                        (void)hipFree(H->d_blocked); (void)hipFree(H->d_edge_e); (void)hipFree(H->d_edge_n); (void)hipFree(H->d_skip);
+                        (void)pool_free(H->d_blocked); (void)pool_free(H->d_edge_e); (void)pool_free(H->d_edge_n); (void)pool_free(H->d_skip);
                         H->d_blocked = nullptr; H->d_edge_e = H->d_edge_n = nullptr; H->d_skip = nullptr;
                     }
                     break;
@@ -1656,7 +1656,7 @@ static int32_t finish_ilu_device(kryst_pc_t pc, IluData* D) {
                 hipLaunchKernelGGL(tri_quad_fill_kernel, dim3(std::min<unsigned>(1024u, (unsigned)nq * 4u)), dim3(256), 0, ctx->s_main, G->d_edge_e, G->d_edge_n, (int)nq, G->nch, (int32_t*)nullptr, 0);
                 // which chunks repeat chunk - 3 bit for bit (their coefficients are in the solving wave's registers already)
                 if (env_int("KRYST_ILU_DEDUP", 1) && G->nch + 3 <= TQ_SKIPMAX) {
-                    if (hipMalloc(&G->d_skip, nq * 4 * (size_t)G->nch) != hipSuccess) { (void)hipGetLastError(); G->d_skip = nullptr; }      // (flags are optional)
+                    if (pool_malloc(&G->d_skip, nq * 4 * (size_t)G->nch) != hipSuccess) { (void)hipGetLastError(); G->d_skip = nullptr; }      // (flags are optional)
                     else if (fwd) hipLaunchKernelGGL((tri_quad_dedup_kernel<3>), dim3(lg), dim3(256), 0, ctx->s_main, (const tw_v2*)G->d_blocked, G->nch, G->d_skip);
                     else hipLaunchKernelGGL((tri_quad_dedup_kernel<4>), dim3(lg), dim3(256), 0, ctx->s_main, (const tw_v2*)G->d_blocked, G->nch, G->d_skip);
                 }
@@ -1840,13 +1840,13 @@ static int32_t grid_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out) {
     int32_t dict[256], used[256];
     {
         int32_t* d_used = nullptr;
-        KR_HIP(hipMalloc(&d_used, sizeof used));
+        KR_HIP(pool_malloc(&d_used, sizeof used));
         (void)hipMemsetAsync(d_used, 0, sizeof used, ctx->s_main);
         hipLaunchKernelGGL(code_usage_kernel, dim3((unsigned)std::min<int64_t>(4096, (a->nnz + 255) / 256 + 1)), dim3(256), 0, ctx->s_main, a->d_code, a->nnz, d_used);
         const hipError_t e1 = hipMemcpyAsync(used, d_used, sizeof used, hipMemcpyDeviceToHost, ctx->s_main);
         const hipError_t e2 = hipMemcpyAsync(dict, a->d_dict, sizeof dict, hipMemcpyDeviceToHost, ctx->s_main);
         const hipError_t e3 = hipStreamSynchronize(ctx->s_main);
-        (void)hipFree(d_used);
+        (void)pool_free(d_used);
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { set_error("code usage scan failed"); return KRYST_ERR_HIP; }
     }
     int64_t offs[3] = {0, 0, 0}; int no = 0;
@@ -1870,12 +1870,12 @@ static int32_t grid_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out) {
     // ---- seven coefficient streams + presence bits
     GridStreams G{};
     double* work[8] = {};
-    struct Guard { double** w; uint8_t** h; long long** f; int32_t** r; ~Guard() { for (int i = 0; i < 8; ++i) (void)hipFree(w[i]); (void)hipFree(*h); (void)hipFree(*f); (void)hipFree(*r); } };
+    struct Guard { double** w; uint8_t** h; long long** f; int32_t** r; ~Guard() { for (int i = 0; i < 8; ++i) (void)pool_free(w[i]); (void)pool_free(*h); (void)pool_free(*f); (void)pool_free(*r); } };
     uint8_t* d_have = nullptr; long long* d_flag = nullptr; int32_t* d_reject = nullptr;
     Guard guard{work, &d_have, &d_flag, &d_reject};
     const size_t vb = sizeof(double) * (size_t)(n + 8);
-    for (int q = 0; q < 8; ++q) KR_HIP(hipMalloc(&work[q], vb));
-    KR_HIP(hipMalloc(&d_have, (size_t)n + 8)); KR_HIP(hipMalloc(&d_flag, 16)); KR_HIP(hipMalloc(&d_reject, 4));
+    for (int q = 0; q < 8; ++q) KR_HIP(pool_malloc(&work[q], vb));
+    KR_HIP(pool_malloc(&d_have, (size_t)n + 8)); KR_HIP(pool_malloc(&d_flag, 16)); KR_HIP(pool_malloc(&d_reject, 4));
     KR_HIP(hipMemsetAsync(d_reject, 0, 4, ctx->s_main));
     KR_HIP(hipMemsetAsync(d_flag, 0xff, 16, ctx->s_main));
     G.km = work[0]; G.jm = work[1]; G.im = work[2]; G.dd = work[3]; G.ip = work[4]; G.jp = work[5]; G.kp = work[6]; G.have = d_have;
@@ -1895,7 +1895,7 @@ static int32_t grid_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out) {
     pc->d_work = reinterpret_cast<double*>(D);
     int32_t rc = KRYST_OK;
     for (double** pp : {&D->GL.d_c1, &D->GL.d_c2, &D->GL.d_c3, &D->GU.d_c1, &D->GU.d_c2, &D->GU.d_c3, &D->GU.d_diag})
-        if (rc == KRYST_OK && hipMalloc(pp, vb) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (rc == KRYST_OK && pool_malloc(pp, vb) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
     if (rc == KRYST_OK) {
         if (mode == KRYST_ILU_TRUE_ILU0) {
             double* wdd = work[7];
@@ -2049,10 +2049,10 @@ static int32_t ikj_on_device(kryst_csr_t a, const std::vector<int64_t>& rp, cons
     }
     lap("levels on the host");
     struct Tmp { double* w = nullptr; int32_t* dpos = nullptr; int32_t* done = nullptr; int32_t* order = nullptr; unsigned long long* bad = nullptr;
-                 ~Tmp() { (void)hipFree(w); (void)hipFree(dpos); (void)hipFree(done); (void)hipFree(order); (void)hipFree(bad); } } t;
-    if (hipMalloc(&t.w, sizeof(double) * (size_t)nnz) != hipSuccess || hipMalloc(&t.dpos, sizeof(int32_t) * (size_t)n) != hipSuccess ||
-        hipMalloc(&t.done, sizeof(int32_t) * (size_t)n) != hipSuccess || hipMalloc(&t.order, sizeof(int32_t) * (size_t)n) != hipSuccess ||
-        hipMalloc(&t.bad, 16) != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }
+                 ~Tmp() { (void)pool_free(w); (void)pool_free(dpos); (void)pool_free(done); (void)pool_free(order); (void)pool_free(bad); } } t;
+    if (pool_malloc(&t.w, sizeof(double) * (size_t)nnz) != hipSuccess || pool_malloc(&t.dpos, sizeof(int32_t) * (size_t)n) != hipSuccess ||
+        pool_malloc(&t.done, sizeof(int32_t) * (size_t)n) != hipSuccess || pool_malloc(&t.order, sizeof(int32_t) * (size_t)n) != hipSuccess ||
+        pool_malloc(&t.bad, 16) != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }
     KR_HIP(hipMemcpyAsync(t.order, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->s_main));
     KR_HIP(hipMemcpyAsync(t.w, a->d_val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, ctx->s_main));
     KR_HIP(hipMemsetAsync(t.bad, 0xff, 8, ctx->s_main));
@@ -2233,11 +2233,11 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
     if (a->d_code) {                         // a handful of offsets: a candidate grid operator (thin boxes, 2-D operators the device-side grid
                                              // setup passed on) -- the host path recognises those and takes the wavefront kernels
         int32_t used[256]; int32_t* d_used = nullptr;
-        KR_HIP(hipMalloc(&d_used, sizeof used));
+        KR_HIP(pool_malloc(&d_used, sizeof used));
         (void)hipMemsetAsync(d_used, 0, sizeof used, ctx->s_main);
         hipLaunchKernelGGL(code_usage_kernel, dim3((unsigned)std::min<int64_t>(4096, (nnz + 255) / 256 + 1)), dim3(256), 0, ctx->s_main, a->d_code, nnz, d_used);
         const hipError_t e1 = hipMemcpyAsync(used, d_used, sizeof used, hipMemcpyDeviceToHost, ctx->s_main), e2 = hipStreamSynchronize(ctx->s_main);
-        (void)hipFree(d_used);
+        (void)pool_free(d_used);
         if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }
         int cnt = 0;
         for (int q = 0; q < 256; ++q) cnt += used[q] ? 1 : 0;
@@ -2260,13 +2260,13 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
     struct Tmp {
         double *w = nullptr, *dg = nullptr; int32_t *dpos = nullptr, *done = nullptr, *order = nullptr, *nl = nullptr, *nu = nullptr;
         int32_t *posL = nullptr, *posU = nullptr; unsigned long long* flags = nullptr;
-        ~Tmp() { for (void* q : {(void*)w, (void*)dg, (void*)dpos, (void*)done, (void*)order, (void*)nl, (void*)nu, (void*)posL, (void*)posU, (void*)flags}) (void)hipFree(q); }
+        ~Tmp() { for (void* q : {(void*)w, (void*)dg, (void*)dpos, (void*)done, (void*)order, (void*)nl, (void*)nu, (void*)posL, (void*)posU, (void*)flags}) (void)pool_free(q); }
     } t;
     const size_t nb = sizeof(int32_t) * (size_t)n;
-    if (hipMalloc(&t.w, sizeof(double) * (size_t)nnz) != hipSuccess || hipMalloc(&t.dg, sizeof(double) * (size_t)n) != hipSuccess || hipMalloc(&t.dpos, nb) != hipSuccess ||
-        hipMalloc(&t.done, nb) != hipSuccess || hipMalloc(&t.order, nb) != hipSuccess ||
-        hipMalloc(&t.nl, nb) != hipSuccess || hipMalloc(&t.nu, nb) != hipSuccess || hipMalloc(&t.posL, nb) != hipSuccess || hipMalloc(&t.posU, nb) != hipSuccess ||
-        hipMalloc(&t.flags, 64) != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }
+    if (pool_malloc(&t.w, sizeof(double) * (size_t)nnz) != hipSuccess || pool_malloc(&t.dg, sizeof(double) * (size_t)n) != hipSuccess || pool_malloc(&t.dpos, nb) != hipSuccess ||
+        pool_malloc(&t.done, nb) != hipSuccess || pool_malloc(&t.order, nb) != hipSuccess ||
+        pool_malloc(&t.nl, nb) != hipSuccess || pool_malloc(&t.nu, nb) != hipSuccess || pool_malloc(&t.posL, nb) != hipSuccess || pool_malloc(&t.posU, nb) != hipSuccess ||
+        pool_malloc(&t.flags, 64) != hipSuccess) { (void)hipGetLastError(); return KRYST_OK; }
     const unsigned g = (unsigned)((n + 255) / 256);
     const int budget = std::max(1, env_int("KRYST_ILU_SETUP_POLL_BUDGET", 1 << 22));
     // flags: [0] first zero pivot (min), [1] stalled, [2] longest row
@@ -2288,7 +2288,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         int32_t* d_hist = nullptr; int32_t bad = 1;
         int32_t* d_bad = reinterpret_cast<int32_t*>(t.flags + 4);
         std::vector<int32_t> hist((size_t)H + 1, 0);
-        if (hipMalloc(&d_hist, sizeof(int32_t) * ((size_t)H + 1)) == hipSuccess && hipMemsetAsync(d_hist, 0, sizeof(int32_t) * ((size_t)H + 1), ctx->s_main) == hipSuccess) {
+        if (pool_malloc(&d_hist, sizeof(int32_t) * ((size_t)H + 1)) == hipSuccess && hipMemsetAsync(d_hist, 0, sizeof(int32_t) * ((size_t)H + 1), ctx->s_main) == hipSuccess) {
             hipLaunchKernelGGL(box_check_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, n, Ni, Nj, d_bad);
             hipLaunchKernelGGL(box_plane_hist_kernel, dim3(g), dim3(256), 0, ctx->s_main, n, Ni, Nj, d_hist);
             if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->s_main) == hipSuccess &&
@@ -2303,7 +2303,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
             }
         }
         (void)hipGetLastError();
-        (void)hipFree(d_hist);
+        (void)pool_free(d_hist);
         if (!plane_order) box_ni = 0;                                         // not (provably) a box operator: the general path below
         else lap("box operator checked, rows sorted by hyperplane");
     }
@@ -2373,9 +2373,9 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         int32_t* d_bad = reinterpret_cast<int32_t*>(t.flags + 3);
         unsigned long long* d_counts = nullptr; unsigned long long counts[26];
         int32_t bad = 1;
-        if (hipMalloc(&D->BL.d_c, cb) != hipSuccess || hipMalloc(&D->BU.d_c, cb) != hipSuccess || hipMalloc(&D->BU.d_diag, sizeof(double) * (size_t)n) != hipSuccess) {
+        if (pool_malloc(&D->BL.d_c, cb) != hipSuccess || pool_malloc(&D->BU.d_c, cb) != hipSuccess || pool_malloc(&D->BU.d_diag, sizeof(double) * (size_t)n) != hipSuccess) {
             (void)hipGetLastError();
-        } else if (hipMalloc(&d_counts, sizeof counts) == hipSuccess && hipMemsetAsync(d_counts, 0, sizeof counts, ctx->s_main) == hipSuccess &&
+        } else if (pool_malloc(&d_counts, sizeof counts) == hipSuccess && hipMemsetAsync(d_counts, 0, sizeof counts, ctx->s_main) == hipSuccess &&
                    hipMemsetAsync(D->BL.d_c, 0, cb, ctx->s_main) == hipSuccess && hipMemsetAsync(D->BU.d_c, 0, cb, ctx->s_main) == hipSuccess) {
             const int32_t Ni = (int32_t)box_ni, Nj = (int32_t)box_nj, Nk = (int32_t)(n64 / (box_ni * box_nj));
             hipLaunchKernelGGL(gen_box_fill_kernel, dim3(g), dim3(256), 0, ctx->s_main, a->d_row_ptr, a->d_col, t.w, t.dg, n, Ni, Nj, Nk, D->BL.d_c, D->BU.d_c, box_stream_stride(n), D->BU.d_diag, d_bad,
@@ -2387,7 +2387,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
                 box_classify(counts, true, Ni, Nj, Nk, &D->BL); box_classify(counts + 13, false, Ni, Nj, Nk, &D->BU);
             }
         }
-        (void)hipFree(d_counts);
+        (void)pool_free(d_counts);
         (void)hipGetLastError();
         if (D->BL.ok && D->BU.ok) {
             lap("box-stencil streams");
@@ -2423,12 +2423,12 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
         rc = up(&F->d_row, rowid);
         if (rc == KRYST_OK) rc = up(&F->d_ptr, ptr);
         if (rc == KRYST_OK) rc = up(&F->d_lvl_off, F->lvl_off);
-        if (rc == KRYST_OK && (hipMalloc(&F->d_col, sizeof(int32_t) * (fn + 1)) != hipSuccess || hipMalloc(&F->d_val, sizeof(double) * (fn + 1)) != hipSuccess ||
-                               hipMalloc(&F->d_diag, sizeof(double) * ((size_t)n + 1)) != hipSuccess)) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+        if (rc == KRYST_OK && (pool_malloc(&F->d_col, sizeof(int32_t) * (fn + 1)) != hipSuccess || pool_malloc(&F->d_val, sizeof(double) * (fn + 1)) != hipSuccess ||
+                               pool_malloc(&F->d_diag, sizeof(double) * ((size_t)n + 1)) != hipSuccess)) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
         if (rc == KRYST_OK && F->ell) {
             const size_t eb = (size_t)ELLW * n;
-            if (hipMalloc(&F->d_ecol, sizeof(int32_t) * (eb + 1)) != hipSuccess || hipMalloc(&F->d_eval, sizeof(double) * (eb + 1)) != hipSuccess ||
-                hipMalloc(&F->d_elen, (size_t)n + 1) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+            if (pool_malloc(&F->d_ecol, sizeof(int32_t) * (eb + 1)) != hipSuccess || pool_malloc(&F->d_eval, sizeof(double) * (eb + 1)) != hipSuccess ||
+                pool_malloc(&F->d_elen, (size_t)n + 1) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
             else if (hipMemsetAsync(F->d_ecol, 0, sizeof(int32_t) * (eb + 1), ctx->s_main) != hipSuccess ||
                      hipMemsetAsync(F->d_eval, 0, sizeof(double) * (eb + 1), ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;      // padding slots: column 0, value 0
         }
@@ -2442,7 +2442,7 @@ static int32_t general_setup_on_device(kryst_csr_t a, int mode, kryst_pc_t* out)
             if (rc == KRYST_OK) rc = build_free_streams(F, ctx->s_main, ptr.data());
         }
     }
-    if (rc == KRYST_OK && hipMalloc(&D->d_mapLU, nb + 4) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
+    if (rc == KRYST_OK && pool_malloc(&D->d_mapLU, nb + 4) != hipSuccess) { set_error("hipMalloc failed"); rc = KRYST_ERR_HIP; }
     if (rc == KRYST_OK) {
         hipLaunchKernelGGL(gen_maplu_kernel, dim3(g), dim3(256), 0, ctx->s_main, t.posL, t.posU, n, D->d_mapLU);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = KRYST_ERR_HIP;

@@ -665,6 +665,57 @@ SolverRun* make_cgs_run(kryst_vec_t b, kryst_vec_t x, const SolveIO& io);
 SolverRun* make_tfqmr_run(kryst_vec_t b, kryst_vec_t x, const SolveIO& io);
 int32_t fgmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io, int32_t orthog, double haptol, int32_t preallocate);   // fgmres.hip
 
+// ---- one checked reduction through freshly mapped mailboxes (dist.cpp: ipc_reduce_setup) before a solver relies on them: rank r sends
+// r + 1 through the very kernel the inner products use, every rank must read P (P + 1) / 2, and the verdict is agreed through RCCL -- the
+// mailbox path is on everywhere or nowhere.  What the set-up cannot see (a mapping that opens but does not carry system-scope stores
+// between these two devices) ends here, under a short poll budget, not in a user's solve.  KRYST_IPC_SELFTEST=0 skips it.
+struct IpcSelfTestLogic {
+    static constexpr bool RUN_WHEN_DONE = false;
+    LogicCtx c;
+    __device__ void run(const double* red) const { c.st->rsq = red[0]; }
+};
+int32_t ipc_reduce_selftest(kryst_ctx_t ctx) {
+    if (env_int("KRYST_IPC_SELFTEST", 1) == 0) return KRYST_OK;
+    const int P = ctx->nranks;
+    int64_t ok = 1;
+    int32_t rc = ensure_partials(ctx, 1);
+    if (rc != KRYST_OK) ok = 0;
+    DevState* st = reinterpret_cast<DevState*>(ctx->d_scal);
+    double* red = ctx->d_scal + 256;
+    const double mine = (double)(ctx->rank + 1);
+    if (ok && (hipMemsetAsync(ctx->d_scal, 0, sizeof(double) * 512, ctx->s_main) != hipSuccess ||
+               hipMemcpyAsync(ctx->d_partials, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess ||
+               hipStreamSynchronize(ctx->s_main) != hipSuccess)) { (void)hipGetLastError(); ok = 0; }
+    if (ok) {
+        const LogicCtx lc{st, nullptr, ctx->d_prog, red, 0.0, 1ll, 0, 0ll, 0};
+        const IpcView v{ctx->ipc_mine, ctx->d_ipc_peers, ctx->d_ipc_epoch, ctx->rank, P, 1 << 21};
+        hipLaunchKernelGGL((fold_ipc_logic_kernel<1, IpcSelfTestLogic>), dim3(1), dim3(KR_F), 0, ctx->s_main,
+                           ctx->d_partials, ctx->partials_cap, (int64_t)1, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), fold_err(ctx), red, IpcSelfTestLogic{lc}, v);
+        DevState h;
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess ||
+            hipStreamSynchronize(ctx->s_main) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
+        else ok = (h.status == KRYST_OK && h.done == 0 && h.rsq == 0.5 * (double)P * (double)(P + 1)) ? 1 : 0;
+    }
+    ctx->h_prog->done = 0; ctx->h_prog->status = 0;                     // (a failed test went through LogicCtx::finish)
+    (void)fold_gave_up(ctx);
+    int64_t *d_s = nullptr, *d_r = nullptr;
+    std::vector<int64_t> all((size_t)P, 0);
+    rc = KRYST_OK;
+    if (hipMalloc(&d_s, 8) != hipSuccess || hipMalloc(&d_r, sizeof(int64_t) * P) != hipSuccess) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK && (hipMemcpyAsync(d_s, &ok, 8, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK) rc = comm_all_gather_i64(ctx, d_s, d_r, 1, ctx->s_main);
+    if (rc == KRYST_OK && (hipMemcpyAsync(all.data(), d_r, sizeof(int64_t) * P, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
+    (void)hipFree(d_s); (void)hipFree(d_r);
+    if (rc != KRYST_OK) { (void)hipGetLastError(); ctx->ipc_on = false; return rc; }
+    for (int p = 0; p < P; ++p)
+        if (all[(size_t)p] != 1) {
+            ctx->ipc_on = false; ctx->ipc_failed = true;                // (the mailboxes stay mapped; the path is never switched on again)
+            set_error("scalar all-reduce through mailboxes: the test reduction did not arrive intact on rank %d; the RCCL path stays in use", p);
+            return KRYST_UNSUPPORTED;
+        }
+    return KRYST_OK;
+}
+
 }  // namespace kr
 
 using namespace kr;

@@ -1143,6 +1143,10 @@ void halo_peer_destroy(kryst_csr_t a) {
     HaloPeer& hp = a->plan.peer;
     for (void* q : hp.opened) ipc_close_shared(q);
     hp.opened.clear();
+    // A landing buffer that a rank THREAD of this process stores into by raw pointer (no hipIpc mapping keeps the memory alive for it) outlives
+    // the operator: a slower neighbour's last early push (solvers.hip: launch_direction) may still be queued when this rank destroys its
+    // operator.  It is freed with the context (ctx.cpp), after the streams of every rank of a rehearsal have drained.
+    if (hp.landing && hp.sibling) { a->ctx->deferred_free.push_back(hp.landing); hp.landing = nullptr; }
     (void)hipFree(hp.landing); (void)hipFree(hp.d_push); (void)hipFree(hp.d_pull); (void)hipFree(hp.d_ticket);
     hp.landing = nullptr; hp.d_push = nullptr; hp.d_pull = nullptr; hp.d_ticket = nullptr; hp.on = false;
     (void)hipGetLastError();
@@ -1153,6 +1157,7 @@ int32_t halo_peer_setup(kryst_csr_t a) {
     HaloPlan& pl = a->plan;
     HaloPeer& hp = pl.peer;
     if (hp.on) return KRYST_OK;
+    if (hp.landing && hp.failed) { set_error("halo by peer stores: the test exchange failed on this operator before; the RCCL exchange stays in use"); return KRYST_UNSUPPORTED; }
     if (hp.landing) { hp.on = true; return KRYST_OK; }               // set up before and switched off: still mapped everywhere, epochs counted alike
     KR_ARG(a->dist && ctx->comm, "halo_peer_setup: not a distributed operator");
     const int P = ctx->nranks, me = ctx->rank;
@@ -1179,7 +1184,7 @@ int32_t halo_peer_setup(kryst_csr_t a) {
     }
     std::vector<void*> peers;
     // (a pull kernel waits for a push its neighbour's host thread enqueues LATER -- at its next exchange: rank threads that share one device are refused)
-    int32_t rc = ipc_map_peers(ctx, hp.landing, peers, hp.opened, false);
+    int32_t rc = ipc_map_peers(ctx, hp.landing, peers, hp.opened, false, &hp.sibling);
     if (rc != KRYST_OK) { halo_peer_destroy(a); return rc; }
     // where my rows land in each neighbour's buffer: every rank's {stride, recv_off[0..P)} in one all-gather
     std::vector<int64_t> mine((size_t)P + 1), all((size_t)(P + 1) * P, 0);
@@ -1218,6 +1223,77 @@ int32_t halo_peer_setup(kryst_csr_t a) {
     if (!pull.empty()) KR_HIP(hipMemcpyAsync(hp.d_pull, pull.data(), sizeof(HaloPullSeg) * pull.size(), hipMemcpyHostToDevice, ctx->s_main));
     KR_HIP(hipStreamSynchronize(ctx->s_main));
     hp.on = true;
+    return halo_peer_selftest(a);
+}
+
+// One real exchange over the freshly mapped buffers before anybody relies on them: x[i] = this rank's global row number, pushed, pulled
+// and compared with the plan's column list on every rank; the verdict is agreed through an all-gather, so the peer stores are on everywhere
+// or nowhere (KRYST_UNSUPPORTED: the RCCL exchange stays).  A mapping that "succeeds" but does not carry the stores -- the one failure the
+// set-up itself cannot see -- ends here with a short poll budget instead of in a user's solve.  KRYST_HALO_SELFTEST=0 skips it.
+__global__ void halo_iota_kernel(double* x, int64_t n, int64_t base) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = (double)(base + i);
+}
+static int32_t halo_finish(kryst_csr_t a, int budget);
+int32_t halo_peer_selftest(kryst_csr_t a) {
+    kryst_ctx_t ctx = a->ctx;
+    HaloPlan& pl = a->plan;
+    if (env_int("KRYST_HALO_SELFTEST", 1) == 0) return KRYST_OK;
+    const int P = ctx->nranks;
+    int64_t ok = 1;
+    double* x = nullptr;
+    std::vector<double> got((size_t)pl.total_recv);
+    const bool have_cols = (int64_t)pl.recv_cols.size() == pl.total_recv;
+    const size_t xbytes = sizeof(double) * (size_t)((a->xlen + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
+    if (hipMalloc(&x, xbytes) != hipSuccess) { (void)hipGetLastError(); ok = 0; x = nullptr; }
+    // (a rank that could not allocate still takes part: its neighbours' pulls need its push -- of anything -- and everybody its vote)
+    double* src = x ? x : pl.d_halo;                                    // never dereferenced beyond the plan's rows when ok; garbage otherwise
+    if (x) {
+        hipLaunchKernelGGL(halo_iota_kernel, dim3((unsigned)((a->xlen + 255) / 256)), dim3(256), 0, ctx->s_main, x, a->xlen, pl.row_lo);
+        if (hipGetLastError() != hipSuccess) { (void)hipGetLastError(); ok = 0; }
+    }
+    int32_t rc = KRYST_OK;
+    if (x) {
+        rc = halo_begin(a, src);
+        if (rc == KRYST_OK) rc = halo_finish(a, 1 << 21);
+    } else {
+        ++pl.peer.epoch;                                                // keep the exchange count in step with the other ranks
+    }
+    a->halo_started_for = nullptr;
+    if (rc == KRYST_OK && (hipStreamSynchronize(ctx->s_comm) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess)) { (void)hipGetLastError(); ok = 0; }
+    if (rc != KRYST_OK) ok = 0;
+    if (fold_gave_up(ctx)) ok = 0;                                      // (reads and clears the error word of the pull)
+    if (ok && pl.total_recv > 0) {
+        if (hipMemcpyAsync(got.data(), pl.d_halo, sizeof(double) * got.size(), hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess ||
+            hipStreamSynchronize(ctx->s_main) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
+        for (int p = 0; p < P && ok; ++p) {
+            const int64_t lo = a->row_offsets.size() > (size_t)p + 1 ? a->row_offsets[(size_t)p] : 0, hi = a->row_offsets.size() > (size_t)p + 1 ? a->row_offsets[(size_t)p + 1] : (1ll << 62);
+            for (int64_t k = 0; k < pl.recv_counts[p] && ok; ++k) {
+                const double v = got[(size_t)(pl.recv_off[p] + k)];
+                if (have_cols) ok = v == (double)pl.recv_cols[(size_t)(pl.recv_off[p] + k)];
+                else ok = v >= (double)lo && v < (double)hi && (k == 0 || v > got[(size_t)(pl.recv_off[p] + k - 1)]);      // rows of rank p, ascending
+            }
+        }
+    }
+    (void)hipFree(x);
+    (void)hipMemsetAsync(pl.d_halo, 0, sizeof(double) * (size_t)(pl.total_recv + 2), ctx->s_main);
+    // the agreed verdict
+    int64_t *d_s = nullptr, *d_r = nullptr;
+    std::vector<int64_t> all((size_t)P, 0);
+    rc = KRYST_OK;
+    if (hipMalloc(&d_s, 8) != hipSuccess || hipMalloc(&d_r, sizeof(int64_t) * P) != hipSuccess) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK && (hipMemcpyAsync(d_s, &ok, 8, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
+    if (rc == KRYST_OK) rc = comm_all_gather_i64(ctx, d_s, d_r, 1, ctx->s_main);
+    if (rc == KRYST_OK && (hipMemcpyAsync(all.data(), d_r, sizeof(int64_t) * P, hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess || hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
+    (void)hipFree(d_s); (void)hipFree(d_r);
+    if (rc != KRYST_OK) { (void)hipGetLastError(); a->plan.peer.on = false; return rc; }
+    for (int p = 0; p < P; ++p)
+        if (all[(size_t)p] != 1) {
+            a->plan.peer.on = false;                                    // (the buffers stay mapped; a later kryst_csr_halo_mode(a, 1) tests again)
+            a->plan.peer.failed = true;
+            set_error("halo by peer stores: the test exchange did not arrive intact on rank %d; the RCCL exchange stays in use", p);
+            return KRYST_UNSUPPORTED;
+        }
     return KRYST_OK;
 }
 
@@ -1267,6 +1343,26 @@ int32_t halo_begin(kryst_csr_t a, const double* x) {
     return KRYST_OK;
 }
 
+// the receiving half of an exchange halo_begin started: afterwards the compute stream may read the plan's d_halo (budget <= 0: the default poll budget)
+static int32_t halo_finish(kryst_csr_t a, int budget) {
+    kryst_ctx_t ctx = a->ctx;
+    if (a->plan.peer.on) {
+        HaloPeer& hp = a->plan.peer;
+        // (my own push has read x: only needed before x is overwritten, and long since true -- the one local dependency that is left)
+        if (!a->halo_pushed_inline) KR_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_halo_done, 0));
+        if (hp.npull > 0) {
+            static const int dflt = [] { const char* e = getenv("KRYST_IPC_POLL_BUDGET"); return e ? std::max(1, atoi(e)) : (1 << 26); }();
+            const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(1, (hp.pull_max + 1023) / 1024), 256);
+            hipLaunchKernelGGL(halo_pull_kernel, dim3(gx, (unsigned)hp.npull), dim3(256), 0, ctx->s_main, hp.landing + (size_t)(hp.epoch & 1ull) * hp.stride,
+                               a->plan.d_halo, hp.d_pull, hp.epoch, budget > 0 ? std::min(budget, dflt) : dflt, fold_err(ctx) + 1);
+            KR_HIP(hipGetLastError());
+        }
+    } else {
+        KR_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_halo_done, 0));
+    }
+    return KRYST_OK;
+}
+
 int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const double* dvec, const int* done) {
     kryst_ctx_t ctx = a->ctx;
     if (nq > 0) KR_TRY(ensure_partials(ctx, a->ntiles));
@@ -1280,20 +1376,7 @@ int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const dou
     a->halo_started_for = nullptr;
     KR_TRY(launch_tiles<false>(a, x, y, nq, dvec, done, a->d_tiles_interior, a->n_interior));   // interior tiles have no halo columns
     phase_mark(ctx, KR_PH_SPMV);
-    if (a->plan.peer.on) {
-        HaloPeer& hp = a->plan.peer;
-        // (my own push has read x: only needed before x is overwritten, and long since true -- the one local dependency that is left)
-        if (!a->halo_pushed_inline) KR_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_halo_done, 0));
-        if (hp.npull > 0) {
-            static const int budget = [] { const char* e = getenv("KRYST_IPC_POLL_BUDGET"); return e ? std::max(1, atoi(e)) : (1 << 26); }();
-            const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(1, (hp.pull_max + 1023) / 1024), 256);
-            hipLaunchKernelGGL(halo_pull_kernel, dim3(gx, (unsigned)hp.npull), dim3(256), 0, ctx->s_main, hp.landing + (size_t)(hp.epoch & 1ull) * hp.stride,
-                               a->plan.d_halo, hp.d_pull, hp.epoch, budget, fold_err(ctx) + 1);
-            KR_HIP(hipGetLastError());
-        }
-    } else {
-        KR_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_halo_done, 0));
-    }
+    KR_TRY(halo_finish(a, 0));
     phase_mark(ctx, KR_PH_HALO_WAIT);
     KR_TRY(launch_tiles<true>(a, x, y, nq, dvec, done, a->d_tiles_boundary, a->n_boundary));
     phase_mark(ctx, KR_PH_SPMV_BOUNDARY);
@@ -1310,8 +1393,24 @@ extern "C" {
 // into hipIpc-mapped landing buffers (dist.h: HaloPeer).  COLLECTIVE: every rank calls it with the same mode.  KRYST_UNSUPPORTED (mode 1)
 // when some rank cannot export / map a landing buffer or a neighbour relation is one-way: every rank then stays on RCCL.  *active: the
 // mode in use.  The results are bit-identical either way (the same values land in the same halo slots).
+int32_t kryst_csr_halo_mode(kryst_csr_t a, int32_t mode, int32_t* active);
+}
+namespace kr {
+// A freshly created row-partitioned operator takes the peer-store exchange when every rank can map its neighbours' landing buffers and the
+// test exchange arrives intact everywhere (agreed outcome); otherwise -- not an error -- the grouped ncclSend / ncclRecv exchange stays.
+// KRYST_HALO_MODE=rccl: do not try.  COLLECTIVE like the creation itself.
+int32_t halo_default_mode(kryst_csr_t a) {
+    if (!a->dist || !a->ctx->comm || a->ctx->nranks < 2) return KRYST_OK;
+    const char* e = getenv("KRYST_HALO_MODE");
+    if (e && strcmp(e, "rccl") == 0) return KRYST_OK;
+    const int32_t rc = kryst_csr_halo_mode(a, 1, nullptr);
+    return rc == KRYST_UNSUPPORTED ? KRYST_OK : rc;
+}
+}
+extern "C" {
 int32_t kryst_csr_halo_mode(kryst_csr_t a, int32_t mode, int32_t* active) {
-    KR_ARG(a && (mode == 0 || mode == 1), "csr_halo_mode");
+    KR_ARG(a && (mode == 0 || mode == 1 || mode == -1), "csr_halo_mode");
+    if (mode == -1) { if (active) *active = a->plan.peer.on ? 1 : 0; return KRYST_OK; }       // query only
     KR_ARG(a->ctx->active_ws == nullptr, "csr_halo_mode: a solve or stepping session is open on this context");
     int32_t rc = KRYST_OK;
     if (a->dist && a->ctx->comm) {
@@ -1319,6 +1418,9 @@ int32_t kryst_csr_halo_mode(kryst_csr_t a, int32_t mode, int32_t* active) {
         KR_HIP(hipStreamSynchronize(a->ctx->s_comm));
         KR_HIP(hipStreamSynchronize(a->ctx->s_main));
         a->halo_started_for = nullptr;
+        // a pull that gave up earlier must not hand its exhausted patience to the mode chosen now (the word is sticky until the host reads it)
+        KR_HIP(hipMemsetAsync(fold_err(a->ctx) + 1, 0, sizeof(unsigned int), a->ctx->s_main));
+        KR_HIP(hipStreamSynchronize(a->ctx->s_main));
         if (mode == 1) rc = halo_peer_setup(a);
         else a->plan.peer.on = false;            // (the landing buffers stay mapped: switching back costs nothing)
     }
@@ -1333,7 +1435,10 @@ int32_t kryst_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y) {
     KR_ARG(y->n == a->nrows, "spmv: y.len() != nrows");     // sparse.rs:58 assert_eq!
     KR_ARG(x->d != y->d, "spmv: x and y alias");
     KR_HIP(hipSetDevice(a->ctx->device));
-    return launch_spmv(a, x->d, y->d, 0, nullptr, nullptr);
+    KR_TRY(launch_spmv(a, x->d, y->d, 0, nullptr, nullptr));
+    // outside a solver nobody else reads the pull's error word: a neighbour's stamp that never came (the halo is NaNs then) is this call's error
+    if (a->dist && a->plan.peer.on && use_collectives(a->ctx) && fold_gave_up(a->ctx)) return KRYST_ERR_RCCL;
+    return KRYST_OK;
 }
 
 // which encoding kryst_spmv streams for this operator under the current KRYST_SPMV_COMPRESS setting:

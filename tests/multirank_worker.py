@@ -95,6 +95,10 @@ def run_rank(rank, P, outdir, N, kind):
         uid = open(idfile, "rb").read()
     stage(rank, "ctx_create_dist")
     ctx = K.Context(0, rank, P, uid)
+    # what the library chose by itself (mailboxes when they work on every rank), then the RCCL all-gather path: the reference results below
+    # are made with RCCL + RCCL, the hipIpc forms are compared with them further down
+    default_scalar = ctx.scalar_reduce("query")
+    assert ctx.scalar_reduce("rccl") == "rccl"
     stage(rank, "operator")
     if kind in ("random", "mixed"):                   # general operator: halo entries from any rank / one non-contiguous send list
         m = random_system(N) if kind == "random" else mixed_system(N)
@@ -106,9 +110,12 @@ def run_rank(rank, P, outdir, N, kind):
     else:
         a = K.CsrMatrix.stencil7(N, kind, ctx=ctx)    # device generator or (KRYST_STENCIL_HOST=1) kryst_csr_create_dist
     nloc = a.nrows()
-    stage(rank, f"spmv nloc={nloc} encoding={a.encoding()[0]}")
+    default_halo = a.halo_mode("query")
+    assert a.halo_mode("rccl") == "rccl"
+    stage(rank, f"spmv nloc={nloc} encoding={a.encoding()[0]} defaults: scalar {default_scalar}, halo {default_halo}")
     b = a.spmv(ctx.vec(nloc).fill(1.0))
-    out = {"b": b.to_host(), "nloc": np.array([nloc])}
+    out = {"b": b.to_host(), "nloc": np.array([nloc]), "default_scalar_ipc": np.array([1 if default_scalar == "ipc" else 0]),
+           "default_halo_peer": np.array([1 if default_halo == "peer" else 0])}
     stage(rank, "norm")
     bn = K.norm(b)
     out["bnorm"] = np.array([bn])

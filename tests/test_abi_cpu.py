@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(L, nm), f"{nm} declared in kryst_hip.h but not exported"
         assert nm in _ffi.SIGNATURES, f"{nm} has no ctypes signature"
     assert set(_ffi.SIGNATURES) <= set(names)
-    assert K.lib().kryst_hip_abi_version() == 4
+    assert K.lib().kryst_hip_abi_version() == 5
 
 
 def test_reduce_spec():

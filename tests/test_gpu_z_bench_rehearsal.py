@@ -80,3 +80,46 @@ def test_bench_with_eight_ranks_as_four_processes_of_two_rank_threads():
     d = run_bench("torch", 4, 2, 64, solver="pcg")
     check_line(d, 8, 64)
     assert "rank threads" in d["config"]["launcher"]
+
+
+def run_bench_plain(world, per, grid, extra=(), solver="cg", timeout=900):
+    """`python3 bench.py --gpus N ...` started PLAINLY, the way the driver starts --gpus 1: bench.py launches its own rank processes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_z_multirank_shim import _build_shim
+    _build_shim()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(KRYST_RCCL_LIB=SHIM, KRYST_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "20", "--warmup", "3", "--grid", str(grid),
+           "--phase-iters", "5", "--solver", solver, "--ranks-per-process", str(per), "--gmres-steps", "30", *extra]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]                       # the JSON line is the ONLY thing on stdout
+    assert "[bench launcher" in r.stderr and "[bench rank 0 +" in r.stderr and f"[bench rank {world - per} +" in r.stderr
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_plain_bench_gpus_2_launches_itself():
+    d = run_bench_plain(2, 1, 64)
+    check_line(d, 2, 64)
+    assert d["config"]["launcher"] == "Rendezvous"                       # the socket rendezvous: no torch in the rank processes
+    g = d["gmres30_jacobi"]                                              # north_star: CG / GMRES iterations per second at every N
+    assert g["value"] > 0 and g["steps"] == 30 and g["restart"] == 30, g
+    s8 = d["roofline"]["sec8d"]                                          # SURVEY 8(d)'s pair inside the block the driver keeps
+    assert 0 < s8["frac"] <= 1.0 and s8["value_sec8d"] == d["value_sec8d"] == d["value_plain_csr"]
+    assert d["scalar_reduce"]["library_defaults"] == {"scalar_reduce": "ipc", "halo": "peer"}, d["scalar_reduce"]
+
+
+@pytest.mark.gpu
+def test_plain_bench_gpus_8_as_four_processes_of_two_rank_threads():
+    d = run_bench_plain(8, 2, 64, solver="pcg")
+    check_line(d, 8, 64)
+    assert "rank threads" in d["config"]["launcher"] and d["gmres30_jacobi"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_plain_bench_gmres_headline_two_ranks():
+    d = run_bench_plain(2, 1, 32, solver="gmres", extra=("--gmres-steps", "0"))
+    assert d["metric"] == "gmres_iterations_per_sec" and d["steps"] == 20 and d["value"] > 0 and d["n_gpus"] == 2
+    assert d["config"]["workload"] == "gmres30_left_jacobi_poisson7_32^3"

@@ -72,6 +72,10 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     # ... and with the halo exchange by direct peer stores (kryst_csr_halo_mode), alone and together with the mailboxes
     # (not between rank THREADS that share the device -- refused by design, see dist.cpp: ipc_map_peers -- the 5-process cases cover more ranks)
     assert all(int(r["peer_active"][0]) == (0 if per > 1 else 1) for r in R), "the peer-store halo exchange could not be set up between the ranks of this box"
+    # round 5: a context of several ranks and a new row-partitioned operator START on the hipIpc forms when their set-up and their checked
+    # test reduction / test exchange succeed on every rank (ctx.cpp: kryst_ctx_create_dist, spmv.hip: halo_default_mode)
+    assert all(int(r["default_scalar_ipc"][0]) == 1 for r in R), "the mailbox path was not the default"
+    assert all(int(r["default_halo_peer"][0]) == (0 if per > 1 else 1) for r in R), "the peer-store exchange was not the default"
     T, V, F = K.reduce_spec()
     if kind in ("random", "mixed"):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
