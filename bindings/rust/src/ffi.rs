@@ -8,6 +8,7 @@ pub type Csr = *mut c_void;
 pub type Vecd = *mut c_void;
 pub type Pc = *mut c_void;
 pub type Session = *mut c_void;
+pub type HostFactors = *mut c_void;
 
 pub const KRYST_OK: i32 = 0;
 pub const KRYST_FACTOR_ERROR: i32 = 1;
@@ -155,6 +156,12 @@ extern "C" {
     pub fn kryst_host_partition_rows(n: i64, nranks: i32, align: i64, row_offsets: *mut i64) -> i32;
     pub fn kryst_host_halo_recv_plan(rank: i32, nranks: i32, row_offsets: *const i64, row_ptr: *const i64, col_idx_global: *const i64,
                                      recv_counts: *mut i64, recv_cols: *mut i64) -> i64;
+    pub fn kryst_host_ilup(n: i64, row_ptr: *const i64, col: *const i32, val: *const f64, fill: i32, threads: i32, block: i64, out: *mut HostFactors) -> i32;
+    pub fn kryst_host_ilut(n: i64, row_ptr: *const i64, col: *const i32, val: *const f64, fill: i32, droptol: f64, threads: i32, out: *mut HostFactors) -> i32;
+    pub fn kryst_host_factors_sizes(f: HostFactors, n: *mut i64, nnz_l: *mut i64, nnz_u: *mut i64) -> i32;
+    pub fn kryst_host_factors_get(f: HostFactors, l_ptr: *mut i64, l_col: *mut i32, l_val: *mut f64, u_ptr: *mut i64, u_col: *mut i32, u_val: *mut f64, diag: *mut f64) -> i32;
+    pub fn kryst_host_factors_destroy(f: HostFactors) -> i32;
+    pub fn kryst_host_levels(n: i64, ptr: *const i64, col: *const i32, forward: i32, level: *mut i32, nlevels: *mut i32) -> i32;
     pub fn kryst_host_read_matrix_market(path: *const c_char, nrows: *mut i64, ncols: *mut i64, row_ptr: *mut i64, col_idx: *mut i64,
                                          vals: *mut f64) -> i64;
     pub fn kryst_host_read_petsc_binary(path: *const c_char, nrows: *mut i64, ncols: *mut i64, row_ptr: *mut i64, col_idx: *mut i64,

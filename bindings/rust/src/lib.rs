@@ -406,12 +406,17 @@ pub struct HipGmresSolver {
     pub restart: usize,
     pub conv: Convergence<f64>,
     pub preconditioning: Preconditioning,
+    /// LABELLED EXTENSION (not in the reference): with `Preconditioning::Left`, run the textbook left-preconditioned GMRES
+    /// (kryst_hip.h: precond_side 3 -- Arnoldi on M^-1 A from M^-1 r0, Gram-Schmidt against V) instead of the reference's Left arm
+    /// (gmres.rs:240-247,279-307), which orthogonalises against an un-normalised Z[0] and stagnates on BASELINE config 3.
+    pub textbook_left: bool,
 }
 impl HipGmresSolver {
     pub fn new(restart: usize, tol: f64, max_iters: usize) -> Self {
-        Self { restart, conv: Convergence { tol, max_iters }, preconditioning: Preconditioning::Left }
+        Self { restart, conv: Convergence { tol, max_iters }, preconditioning: Preconditioning::Left, textbook_left: false }
     }
     pub fn with_preconditioning(mut self, mode: Preconditioning) -> Self { self.preconditioning = mode; self }
+    pub fn with_textbook_left(mut self, flag: bool) -> Self { self.textbook_left = flag; self }
 }
 impl LinearSolver<HipCsrMatrix, Vec<f64>> for HipGmresSolver {
     type Error = KError;
@@ -420,7 +425,7 @@ impl LinearSolver<HipCsrMatrix, Vec<f64>> for HipGmresSolver {
         -> Result<SolveStats<f64>, KError> {
         let mut p = base_params(&self.conv);
         p.restart = self.restart as i32;
-        p.precond_side = match self.preconditioning { Preconditioning::None => 0, Preconditioning::Left => 1, Preconditioning::Right => 2 };
+        p.precond_side = match self.preconditioning { Preconditioning::None => 0, Preconditioning::Left => if self.textbook_left { 3 } else { 1 }, Preconditioning::Right => 2 };
         // the reference unwraps the preconditioner in the Left / Right branches (gmres.rs:245): None there is a panic, here too
         if pc.is_none() && p.precond_side != 0 { panic!("GMRES with Left/Right preconditioning needs a preconditioner (gmres.rs:245)"); }
         device_solve(ffi::kryst_gmres_solve, a, pc, true, b, x, Common { params: p, monitor: None, history: None })

@@ -104,7 +104,9 @@ int32_t kryst_ctx_trim(kryst_ctx_t ctx, int64_t* bytes_released);
 /* measurement only: per-phase device time of the work enqueued between begin and end (hipEvents recorded on the compute stream
  * after each phase: time between two marks is charged to the later one).  ms[p] for p < kryst_phase_count(): "spmv" (tiles
  * without halo columns; single rank: the whole SpMV), "halo_wait" (compute stream waiting for the neighbour planes),
- * "spmv_boundary", "reduce" (tile-partial fold + RCCL all-gather + rank-ordered fold + scalar step), "blas1", "pc". */
+ * "spmv_boundary", "reduce" (tile-partial fold + RCCL all-gather + rank-ordered fold + scalar step), "blas1" (vector updates other than
+ * the next two), "pc", "blas1_residual" (CG / PCG: r -= alpha Ap with its fused inner products), "blas1_direction" (CG / PCG: x += alpha p,
+ * p = z + beta p). */
 int32_t kryst_phase_timing_begin(kryst_ctx_t ctx);
 int32_t kryst_phase_timing_end(kryst_ctx_t ctx, double* ms, int32_t count);
 int32_t kryst_phase_count(void);
@@ -221,7 +223,7 @@ typedef struct {
     double  tol;                 /* Convergence::tol      src/utils/convergence.rs:4-7 */
     int64_t max_iters;           /* Convergence::max_iters */
     int32_t restart;             /* GmresSolver::restart  gmres.rs:40 */
-    int32_t precond_side;        /* gmres.rs:28-32 Preconditioning: 0 None, 1 Left (default), 2 Right */
+    int32_t precond_side;        /* gmres.rs:28-32 Preconditioning: 0 None, 1 Left (default), 2 Right; 3 = textbook Left, a labelled extension (kryst_gmres_solve) */
     int32_t norm_type;           /* CgNormType cg.rs:35: 0 Preconditioned, 1 Unpreconditioned (default), 2 Natural, 3 None */
     int32_t single_reduction;    /* with_single_reduction cg.rs:69 (same fold on the device; accepted, no effect) */
     int32_t has_radius;  double radius;        /* with_radius     cg.rs:74  (CG: trust-region exit cg.rs:177-202; PCG ignores it like the reference) */
@@ -301,6 +303,31 @@ int32_t kryst_host_partition_rows(int64_t n, int32_t nranks, int64_t align, int6
 int64_t kryst_host_halo_recv_plan(int32_t rank, int32_t nranks, const int64_t* row_offsets,
                                   const int64_t* row_ptr, const int64_t* col_idx_global,
                                   int64_t* recv_counts, int64_t* recv_cols);
+
+/* ---- host-side factorisations on plain host arrays: no device, no context (ABI 5).  Exactly the code kryst_pc_ilup / kryst_pc_ilut run between
+ * the download of the operator's rows and the upload of the factors (kryst_amd/csrc/host_factor.cpp), for CPU-only callers, for parity tests
+ * against the oracle without a GPU and for the sanitizer tier (make -C kryst_amd/csrc san SAN=thread | address,undefined).
+ * Rows (row_ptr[n+1], col[nnz] as int32, val[nnz]) of an n x n block; columns >= n (halo slots of a row-partitioned operator) are dropped.
+ * Results: L's strictly-lower kept entries with their multipliers, U's strictly-upper kept entries, the kept diagonal (1.0 where none is
+ * kept), each row in stored = ascending-column order (Ilut: in the order ilut.rs leaves them). */
+typedef struct kryst_host_factors_s* kryst_host_factors_t;
+/* Ilup::new(fill).setup (src/preconditioner/ilup.rs:77-134) as a row pipeline over `threads` host threads (<= 0: up to 16) in round-robin blocks
+ * of `block` rows (<= 0: 2048); any thread count and block size gives the bits of the one-thread loop.  KRYST_SOLVE_ERROR on a zero u_jj
+ * (ilup.rs:108-110), the column j of the LOWEST row that met one through kryst_hip_last_error_row(). */
+int32_t kryst_host_ilup(int64_t n, const int64_t* row_ptr, const int32_t* col, const double* val, int32_t fill, int32_t threads, int64_t block,
+                        kryst_host_factors_t* out);
+/* Ilut::new(fill, droptol).setup (src/preconditioner/ilut.rs:80-117): drop by magnitude, keep the `fill` largest of a row, split at the diagonal */
+int32_t kryst_host_ilut(int64_t n, const int64_t* row_ptr, const int32_t* col, const double* val, int32_t fill, double droptol, int32_t threads,
+                        kryst_host_factors_t* out);
+int32_t kryst_host_factors_sizes(kryst_host_factors_t f, int64_t* n, int64_t* nnz_l, int64_t* nnz_u);
+/* any pointer may be NULL; l_ptr / u_ptr hold n + 1 entries, diag n */
+int32_t kryst_host_factors_get(kryst_host_factors_t f, int64_t* l_ptr, int32_t* l_col, double* l_val, int64_t* u_ptr, int32_t* u_col, double* u_val,
+                               double* diag);
+int32_t kryst_host_factors_destroy(kryst_host_factors_t f);
+/* The level scheduler of the general triangular solve (ilup.rs:138-167 walks rows one after the other; rows of one level are independent):
+ * level[i] = 1 + the highest level among the rows that row i of a strictly-lower (forward != 0: rows ascending) or strictly-upper (rows
+ * descending) factor depends on, 0 when it depends on none.  *nlevels (may be NULL): the number of levels. */
+int32_t kryst_host_levels(int64_t n, const int64_t* ptr, const int32_t* col, int32_t forward, int32_t* level, int32_t* nlevels);
 
 /* Matrix Market coordinate file -> CSR (0-based, rows sorted, symmetric / skew-symmetric storage expanded, duplicates summed;
  * real, integer and pattern fields).  Returns nnz, or -1 (kryst_hip_last_error() says why).  Call with NULL arrays to size,

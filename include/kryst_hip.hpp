@@ -198,7 +198,7 @@ inline void apply_chebyshev(const HipCsrMatrix& a, const Vec& r, Vec& z, double 
 
 // ---- solvers -------------------------------------------------------------------------------------------------------
 enum class CgNormType { Preconditioned = 0, Unpreconditioned = 1, Natural = 2, None = 3 };      // cg.rs:35
-enum class Preconditioning { None = 0, Left = 1, Right = 2 };                                    // gmres.rs:28-32
+enum class Preconditioning { None = 0, Left = 1, Right = 2, LeftTextbook = 3 };                  // gmres.rs:28-32; LeftTextbook: labelled extension (kryst_hip.h: precond_side 3)
 
 class SolverBase : public LinearSolver<HipCsrMatrix, Vec> {
 public:

@@ -24,7 +24,7 @@ from ._ffi import KError, lib, check
 __all__ = ["Context", "DeviceVec", "CsrMatrix", "dot", "norm", "Jacobi", "Ilu0", "Ilup", "Ilut", "TrueIlu0", "Chebyshev",
            "ChebyshevPc", "IdentityPc", "ApproxInv", "apply_chebyshev", "Convergence", "SolveStats", "CgNormType",
            "Preconditioning", "CgSolver", "PcgSolver", "GmresSolver", "FgmresSolver", "Orthog", "CgsSolver", "TfqmrSolver", "BiCgStabSolver", "BiCgStabRightPcSolver", "Session", "KspContext", "SolverKind", "PC", "KError", "reduce_spec",
-           "host_stencil7", "partition_rows", "halo_recv_plan", "read_matrix_market", "read_petsc_binary"]
+           "host_stencil7", "partition_rows", "halo_recv_plan", "read_matrix_market", "read_petsc_binary", "host_ilup", "host_ilut", "host_levels"]
 
 
 def _dp(a):
@@ -199,6 +199,12 @@ def axpy(alpha, x, y):
 
 def aypx(beta, x, y):
     check(lib().kryst_aypx(float(beta), x.h, y.h))
+
+
+def sub(a, b, out):
+    """out[i] = a[i] - b[i] (cg.rs:123 `bi - ax`); `out` may be `a` or `b`."""
+    check(lib().kryst_sub(a.h, b.h, out.h))
+    return out
 
 
 STENCIL_KINDS = {"poisson": 0, "aniso": 1, "convdiff": 2, "varcoef": 3}   # kryst_csr_create_stencil7 / kryst_host_stencil7
@@ -584,6 +590,8 @@ class Preconditioning(enum.IntEnum):             # src/solver/gmres.rs:28-32
     NoPc = 0
     Left = 1
     Right = 2
+    LeftTextbook = 3                             # LABELLED EXTENSION (not in the reference): Arnoldi on M^-1 A from M^-1 r0, Gram-Schmidt against V --
+                                                 # the reference's Left orthogonalises against an un-normalised Z[0] (gmres.rs:240-247, 279-307)
 
 
 class _Solver:
@@ -918,6 +926,58 @@ def read_matrix_market(path):
 def read_petsc_binary(path):
     """PETSc binary AIJ matrix -> (nrows, ncols, row_ptr, col_idx, vals) (host only; kryst_host_read_petsc_binary)."""
     return _read_matrix_file(lib().kryst_host_read_petsc_binary, path)
+
+
+def _host_factors(h):
+    try:
+        n, nl, nu = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib().kryst_host_factors_sizes(h, C.byref(n), C.byref(nl), C.byref(nu)))
+        lp = np.zeros(n.value + 1, dtype=np.int64); up = np.zeros(n.value + 1, dtype=np.int64)
+        lc = np.zeros(max(nl.value, 1), dtype=np.int32); uc = np.zeros(max(nu.value, 1), dtype=np.int32)
+        lv = np.zeros(max(nl.value, 1)); uv = np.zeros(max(nu.value, 1)); dg = np.zeros(max(n.value, 1))
+        check(lib().kryst_host_factors_get(h, lp.ctypes.data_as(_ffi.c_i64p), lc.ctypes.data_as(_ffi.c_i32p), _dp(lv),
+                                           up.ctypes.data_as(_ffi.c_i64p), uc.ctypes.data_as(_ffi.c_i32p), _dp(uv), _dp(dg)))
+        return lp, lc[:nl.value], lv[:nl.value], up, uc[:nu.value], uv[:nu.value], dg[:n.value]
+    finally:
+        lib().kryst_host_factors_destroy(h)
+
+
+def _host_rows(row_ptr, col_idx, values):
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    ci = np.ascontiguousarray(col_idx, dtype=np.int32)
+    va = _f64(values)
+    if len(rp) < 1 or len(ci) != len(va) or int(rp[-1]) != len(va):
+        raise KError(102, "host factorisation: inconsistent array lengths")
+    return rp, ci, va
+
+
+def host_ilup(row_ptr, col_idx, values, fill, threads=0, block=0):
+    """Ilup::new(fill).setup (ilup.rs:77-134) on host arrays, no GPU (kryst_host_ilup): the row pipeline kryst_pc_ilup runs between download
+    and upload.  -> (l_ptr, l_col, l_val, u_ptr, u_col, u_val, diag): L's strictly-lower multipliers, U's strictly-upper kept entries, the kept
+    diagonal (1.0 where none is kept).  KError(SolveError) on a zero u_jj, `.row` = that j."""
+    rp, ci, va = _host_rows(row_ptr, col_idx, values)
+    h = _ffi.Handle()
+    check(lib().kryst_host_ilup(len(rp) - 1, rp.ctypes.data_as(_ffi.c_i64p), ci.ctypes.data_as(_ffi.c_i32p), _dp(va), fill, threads, block, C.byref(h)))
+    return _host_factors(h)
+
+
+def host_ilut(row_ptr, col_idx, values, fill, droptol, threads=0):
+    """Ilut::new(fill, droptol).setup (ilut.rs:80-117) on host arrays, no GPU (kryst_host_ilut); result as host_ilup."""
+    rp, ci, va = _host_rows(row_ptr, col_idx, values)
+    h = _ffi.Handle()
+    check(lib().kryst_host_ilut(len(rp) - 1, rp.ctypes.data_as(_ffi.c_i64p), ci.ctypes.data_as(_ffi.c_i32p), _dp(va), fill, float(droptol), threads, C.byref(h)))
+    return _host_factors(h)
+
+
+def host_levels(ptr, col, forward=True):
+    """Dependency levels of a strictly-lower (forward) / strictly-upper triangular factor's rows (kryst_host_levels) -> (level[n], nlevels)."""
+    p = np.ascontiguousarray(ptr, dtype=np.int64)
+    c = np.ascontiguousarray(col, dtype=np.int32)
+    lvl = np.zeros(max(len(p) - 1, 1), dtype=np.int32)
+    nl = C.c_int32(0)
+    check(lib().kryst_host_levels(len(p) - 1, p.ctypes.data_as(_ffi.c_i64p), c.ctypes.data_as(_ffi.c_i32p), 1 if forward else 0,
+                                  lvl.ctypes.data_as(_ffi.c_i32p), C.byref(nl)))
+    return lvl[:len(p) - 1], nl.value
 
 
 def host_stencil7(N, kind="poisson", k_lo=0, k_hi=None):

@@ -122,6 +122,12 @@ SIGNATURES = {
     "kryst_host_read_petsc_binary": (C.c_int64, [C.c_char_p, c_i64p, c_i64p, c_i64p, c_i64p, c_dp]),
     "kryst_host_read_matrix_market": (C.c_int64, [C.c_char_p, c_i64p, c_i64p, c_i64p, c_i64p, c_dp]),
     "kryst_host_halo_recv_plan": (C.c_int64, [C.c_int32, C.c_int32, c_i64p, c_i64p, c_i64p, c_i64p, c_i64p]),
+    "kryst_host_ilup": (C.c_int32, [C.c_int64, c_i64p, c_i32p, c_dp, C.c_int32, C.c_int32, C.c_int64, C.POINTER(Handle)]),
+    "kryst_host_ilut": (C.c_int32, [C.c_int64, c_i64p, c_i32p, c_dp, C.c_int32, C.c_double, C.c_int32, C.POINTER(Handle)]),
+    "kryst_host_factors_sizes": (C.c_int32, [Handle, c_i64p, c_i64p, c_i64p]),
+    "kryst_host_factors_get": (C.c_int32, [Handle, c_i64p, c_i32p, c_dp, c_i64p, c_i32p, c_dp, c_dp]),
+    "kryst_host_factors_destroy": (C.c_int32, [Handle]),
+    "kryst_host_levels": (C.c_int32, [C.c_int64, c_i64p, c_i32p, C.c_int32, c_i32p, c_i32p]),
 }
 
 _lib = None

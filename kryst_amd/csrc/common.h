@@ -92,8 +92,10 @@ enum { KR_PH_SPMV = 0,          // SpMV tiles that need no halo (single rank: th
        KR_PH_HALO_WAIT,         // compute stream waiting for the halo exchange after the interior tiles
        KR_PH_SPMV_BOUNDARY,     // tiles with halo columns
        KR_PH_REDUCE,            // tile-partial fold, RCCL all-gather, rank-ordered fold + the solver's scalar step
-       KR_PH_BLAS1,             // fused vector updates (incl. their tile partials)
+       KR_PH_BLAS1,             // fused vector updates (incl. their tile partials) that are neither of the two below
        KR_PH_PC,                // preconditioner apply
+       KR_PH_BLAS1_RESIDUAL,    // CG / PCG: r -= alpha Ap with the fused (r,r) [, z = D^-1 r, (r,z)]   (CgResidualOp / PcgResidualOp / the eager forms)
+       KR_PH_BLAS1_DIRECTION,   // CG / PCG: x += alpha p, p = z + beta p                                (CgDirectionOp / AypxDevOp)
        KR_PH_COUNT };
 struct PhaseTimer {
     std::vector<std::pair<int, hipEvent_t>> marks;      // (phase, event recorded after it); phase -1: the start mark

@@ -1,5 +1,6 @@
 // RCCL binding + halo planning.  Compiled with hipcc (host code only).
 #include "dist.h"
+#include "ipc_table.h"
 #include <map>
 #include <array>
 #include <mutex>
@@ -130,31 +131,23 @@ void ipc_reduce_destroy(kryst_ctx_t ctx) {
 // hipIpcOpenMemHandle / hipIpcCloseMemHandle, once per handle and PROCESS: two ranks of one process (rank threads) both want their common
 // peers' buffers, and a second open of a handle the process already holds -- or two opens of it at the same moment -- is not something the
 // runtime promises to survive (seen on one box in four: the mailbox set-up of the 4 x 2 rehearsal fell back to RCCL now and then).  The
-// mappings are shared and counted; the last close unmaps.
+// mappings are shared and counted; the last close unmaps (ipc_table.h: the counting itself, free of HIP so that the sanitizer tier runs it).
 namespace {
-struct IpcShared { void* ptr; int refs; };
-std::mutex g_ipc_mu;
-std::map<std::array<char, 68>, IpcShared> g_ipc_open;               // key: the handle and the device it was opened on
+struct HipIpcOps {
+    static int open(void** ptr, const SharedMappingKey& key) {
+        hipIpcMemHandle_t h; memcpy(&h, key.data(), 64);
+        return (int)hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess);
+    }
+    static void close(void* ptr) { (void)hipIpcCloseMemHandle(ptr); }
+};
+SharedMappings<HipIpcOps> g_ipc_open;
 }  // namespace
 hipError_t ipc_open_shared(void** ptr, const hipIpcMemHandle_t& h) {
-    std::array<char, 68> key; memcpy(key.data(), &h, 64);
-    int dev = -1; (void)hipGetDevice(&dev); memcpy(key.data() + 64, &dev, 4);
-    std::lock_guard<std::mutex> g(g_ipc_mu);
-    auto it = g_ipc_open.find(key);
-    if (it != g_ipc_open.end()) { ++it->second.refs; *ptr = it->second.ptr; return hipSuccess; }
-    const hipError_t e = hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess);
-    if (e == hipSuccess) g_ipc_open.emplace(key, IpcShared{*ptr, 1});
-    return e;
+    SharedMappingKey key; memcpy(key.data(), &h, 64);
+    int dev = -1; (void)hipGetDevice(&dev); memcpy(key.data() + 64, &dev, 4);      // key: the handle and the device it is opened on
+    return (hipError_t)g_ipc_open.open(ptr, key);
 }
-void ipc_close_shared(void* ptr) {
-    std::lock_guard<std::mutex> g(g_ipc_mu);
-    for (auto it = g_ipc_open.begin(); it != g_ipc_open.end(); ++it)
-        if (it->second.ptr == ptr) {
-            if (--it->second.refs == 0) { (void)hipIpcCloseMemHandle(ptr); g_ipc_open.erase(it); }
-            return;
-        }
-    (void)hipIpcCloseMemHandle(ptr);                                  // (not one of ours)
-}
+void ipc_close_shared(void* ptr) { g_ipc_open.close(ptr); }
 
 // Map one allocation of every rank into this process: `mine` (device memory of this rank, fine-grained when peers write it with
 // system-scope stores) is exported, the handles travel in one all-gather, and peers[p] receives rank p's allocation as THIS process

@@ -95,6 +95,10 @@ template <class Op> struct ew_bpc<Op, std::void_t<decltype(Op::BPC)>> { static c
 template <class Op, class = void> struct ew_tag { static const char* get() { return nullptr; } };
 template <class Op> struct ew_tag<Op, std::void_t<decltype(Op::TAG)>> { static const char* get() { return Op::TAG; } };
 
+// phase an op's launches are charged to while kryst_phase_timing is on: KR_PH_BLAS1 unless the op declares `static constexpr int PHASE`
+template <class Op, class = void> struct ew_phase { static constexpr int value = KR_PH_BLAS1; };
+template <class Op> struct ew_phase<Op, std::void_t<decltype(Op::PHASE)>> { static constexpr int value = Op::PHASE; };
+
 // bpc <= 0: the kernel shape's default (KRYST_EW_BLOCKS_PER_CU overrides it)
 template <class Op, class Gate>
 inline int32_t launch_ew_gated(kryst_ctx_t ctx, const Op& op, int64_t n, const Gate& gate, int bpc = 0, int64_t tile_lo = 0, int64_t tile_hi = -1) {
@@ -118,7 +122,7 @@ inline int32_t launch_ew_gated(kryst_ctx_t ctx, const Op& op, int64_t n, const G
     hipLaunchKernelGGL((ew_kernel<Op, Gate>), dim3((unsigned)grid), dim3(KR_T), 0, ctx->s_main, op, gate, n, tile_lo, tile_hi,
                        ctx->d_partials, ctx->partials_cap);
     KR_HIP(hipGetLastError());
-    phase_mark(ctx, KR_PH_BLAS1);
+    phase_mark(ctx, ew_phase<Op>::value);
     return KRYST_OK;
 }
 

@@ -15,9 +15,10 @@ struct GmState {                     // device
     int cyc_stop;                    // leave the Arnoldi loop of this cycle
     int happy;
     int m;
-    int side;                        // 0 none, 1 left, 2 right
+    int side;                        // 0 none, 1 left, 2 right, 3 textbook left (labelled extension)
     long long iteration;
     double r0_norm, beta, hcur, hj1;
+    double res0_in;                  // the norm the in-cycle convergence test divides by: res0, or (side 3) ||M^-1 r0|| of the first cycle
 };
 
 struct GmPtrs { GmState* gs; double* h; double* g; double* cs; double* sn; double* y; int restart; };
@@ -90,7 +91,7 @@ struct GmInitLogic {                 // gmres.rs:227-233 ; red0 = (r0,r0)
     __device__ void run(const double* red) const {
         DevState* st = c.st;
         const double beta = dsqrt(red[0]);
-        P.gs->beta = beta; st->res0 = beta;
+        P.gs->beta = beta; st->res0 = beta; P.gs->res0_in = beta;
         st->iterations = 0; st->final_residual = beta; st->converged = 0;
         P.gs->iteration = 0; P.gs->side = side;
         if (c.max_iters <= 0 || P.restart <= 0) c.finish(KRYST_OK);     // n_outer == 0 (:231,:234)
@@ -103,6 +104,7 @@ struct GmCycleLogic {                // gmres.rs:238, :268-275 ; for Right: red0
         GmState* gs = P.gs;
         double r0_norm = gs->beta;                                      // :238
         if (right) { r0_norm = dsqrt(red[0]); gs->beta = r0_norm; }     // :252, :259
+        if (right == 2 && gs->iteration == 0) gs->res0_in = r0_norm;    // side 3: the first cycle's ||M^-1 r0||
         gs->r0_norm = r0_norm;
         for (int k = 0; k < (P.restart + 1) * P.restart; ++k) P.h[k] = 0.0;
         for (int k = 0; k <= P.restart; ++k) P.g[k] = 0.0;
@@ -130,14 +132,14 @@ struct GmNormLogic {                 // gmres.rs:97-101 / :299-303 / :331-335 th
     static constexpr bool RUN_WHEN_DONE = false;
     LogicCtx c; GmPtrs P; int j;
     __device__ void run(const double* red) const {
-        GmState* gs = P.gs; DevState* st = c.st;
+        GmState* gs = P.gs;
         if (gs->cyc_stop) return;
         const double eps = 1e-14;                                       // :233
         const double hj1 = dsqrt(red[0]);
         HH(j + 1, j) = hj1; gs->hj1 = hj1;
         if (fabs(hj1) < eps) {
             gs->happy = 1;
-            if (gs->side != 0) { gs->cyc_stop = 1; return; }            // :300-303 / :332-335: break BEFORE givens, m unchanged
+            if (gs->side == 1 || gs->side == 2) { gs->cyc_stop = 1; return; }   // :300-303 / :332-335: break BEFORE givens, m unchanged (side 3: as arnoldi)
         }
         // apply_givens_and_update_g (:154-176)
         for (int i = 0; i < j; ++i) {
@@ -155,7 +157,7 @@ struct GmNormLogic {                 // gmres.rs:97-101 / :299-303 / :331-335 th
         P.g[j + 1] = -P.sn[j] * P.g[j] + P.cs[j] * P.g[j + 1];
         P.g[j] = temp;
         const double res_norm = fabs(P.g[j + 1]);                       // :348
-        const bool conv = c.check(res_norm, st->res0, gs->iteration);   // :349-350
+        const bool conv = c.check(res_norm, gs->res0_in, gs->iteration);   // :349-350 (res0_in == res0 unless side 3)
         c.push(res_norm);                                               // addition: the reference keeps no GMRES history
         gs->m = j + 1;                                                  // :351
         if (conv || gs->happy) gs->cyc_stop = 1;                        // :352-354
@@ -211,7 +213,10 @@ int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
     kryst_pc_s pcl; kryst_pc_t pc = nullptr;
     if (io.pc) { KR_ARG(io.pc->ctx == ctx, "solve: preconditioner context"); pcl = *io.pc; if (pcl.n < 0) pcl.n = n; pc = &pcl; }
     const int side = pc ? p->precond_side : 0;        // `match (self.preconditioning, pc)`: anything else takes the `_` arm
-    KR_ARG(side >= 0 && side <= 2, "gmres: precond_side");
+    // side 3 -- a LABELLED EXTENSION, not in the reference: textbook left preconditioning (Arnoldi on M^-1 A from M^-1 r0 / ||M^-1 r0||,
+    // Gram-Schmidt against V, in-cycle test on the preconditioned residual, cycle-end test on the true one; oracle: kro_gmres side 3).
+    // The reference's own Left arm (side 1) orthogonalises against an un-normalised Z[0] and stagnates on BASELINE config 3.
+    KR_ARG(side >= 0 && side <= 3, "gmres: precond_side");
     const int R = p->restart;
     Workspace ws(ctx, n);
     const int64_t n_outer = (p->max_iters + R - 1) / R;                                            // :231
@@ -251,7 +256,12 @@ int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
 
     for (int64_t outer = 0; outer < n_outer; ++outer) {                                           // :234
         // ---- cycle start
-        if (side == 2) {                                                                          // :248-260
+        if (side == 3) {                                                                          // extension: v0 = M^-1 r0 / ||M^-1 r0||
+            rc = pc_apply_dev(pc, r0, z, done); if (rc) return rc;
+            KR_TRY(launch_ew(ctx, DotOneOp{z, z}, n, done));
+            KR_TRY((reduce_then<1>(ctx, nt, ws.red, GmCycleLogic{lc, P, 2})));
+            KR_TRY(launch_ew(ctx, DivOp{&P.gs->r0_norm, z, V[0]}, n, done));
+        } else if (side == 2) {                                                                   // :248-260
             rc = pc_apply_dev(pc, r0, z, done); if (rc) return rc;
             KR_TRY(launch_ew(ctx, DotOneOp{z, z}, n, done));
             KR_TRY((reduce_then<1>(ctx, nt, ws.red, GmCycleLogic{lc, P, 1})));
@@ -269,6 +279,11 @@ int32_t gmres_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
             KR_HIP(hipGetLastError());
             double* zz; const std::vector<double*>& B = (side == 1) ? Z : V;
             if (side == 1) {                                                                      // :281-284
+                KR_TRY(launch_spmv(a, V[j], w, 0, nullptr, d_gate));
+                rc = pc_apply_dev(pc, w, z, d_gate); if (rc) return rc;
+                zz = z;
+                KR_TRY(launch_iter(ctx, DotOneOp{zz, B[0]}, n, st, gs));
+            } else if (side == 3) {                                                               // extension: z = M^-1 A v_j against V
                 KR_TRY(launch_spmv(a, V[j], w, 0, nullptr, d_gate));
                 rc = pc_apply_dev(pc, w, z, d_gate); if (rc) return rc;
                 zz = z;

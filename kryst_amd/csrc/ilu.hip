@@ -18,6 +18,7 @@
 // workgroup barriers replace kernel boundaries) was built and measured: bit-identical but no faster, removed again.
 // In a distributed context the factors are block-local (block-Jacobi ILU): halo columns are dropped.
 #include "pc.h"
+#include "host_factor.h"
 #include <chrono>
 #include <thread>
 #include <sched.h>
@@ -26,6 +27,7 @@
 #include <new>
 #include <pthread.h>
 #include <memory>
+#include <string>
 #include <mutex>
 #include <atomic>
 #include "ew.h"
@@ -35,75 +37,8 @@
 
 namespace kr {
 
-// host-side loops over independent rows, split over the box's cores (setup only)
-template <class F>
-static void par_rows(int64_t n, F body) {
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    if (n < (1 << 16) || hw == 1) { body((int64_t)0, n); return; }
-    std::vector<std::thread> th;
-    const int64_t per = (n + hw - 1) / hw;
-    for (unsigned t = 0; t < hw; ++t) {
-        const int64_t lo = std::min<int64_t>(n, per * t), hi = std::min<int64_t>(n, lo + per);
-        if (lo < hi) th.emplace_back([=] { body(lo, hi); });
-    }
-    for (auto& t : th) t.join();
-}
-// Host arrays of the setup paths (hundreds of MB on a 128^3 operator): elements are NOT value-initialised (a std::vector zeroes what the
-// next loop overwrites, on one thread), and blocks of 4 MiB and more are 2 MiB-aligned with a huge-page hint -- first-touch page faults
-// and the unmapping at the end were a quarter of the Ilup(1) setup (round 4).
-// Big blocks are not given back to the OS but kept (KRYST_HOST_POOL_MB, default 2048; 0: off) for the next set-up: mapping and unmapping ~1 GB per
-// Ilup set-up at 128^3 was a third of its time, and the unmapping of one set-up got in the way of the page faults of the next.
-struct HostPool {
-    std::mutex mu; std::vector<std::pair<void*, size_t>> blocks; size_t held = 0;
-    ~HostPool() { for (auto& b : blocks) std::free(b.first); }
-    void* take(size_t bytes) {
-        std::lock_guard<std::mutex> g(mu);
-        size_t best = blocks.size();
-        for (size_t i = 0; i < blocks.size(); ++i)
-            if (blocks[i].second >= bytes && blocks[i].second <= 2 * bytes && (best == blocks.size() || blocks[i].second < blocks[best].second)) best = i;
-        if (best == blocks.size()) return nullptr;
-        void* q = blocks[best].first; held -= blocks[best].second;
-        blocks[best] = blocks.back(); blocks.pop_back();
-        return q;
-    }
-    bool give(void* q, size_t bytes) {
-        const size_t limit = (size_t)std::max(0ll, env_ll("KRYST_HOST_POOL_MB", 2048)) << 20;
-        std::lock_guard<std::mutex> g(mu);
-        if (held + bytes > limit) return false;
-        blocks.emplace_back(q, bytes); held += bytes;
-        return true;
-    }
-};
-static HostPool g_host_pool;
-template <class T>
-struct HostAlloc {
-    using value_type = T;
-    HostAlloc() = default;
-    template <class U> HostAlloc(const HostAlloc<U>&) {}
-    static size_t rounded(size_t bytes) { const size_t big = (size_t)1 << 21; return (bytes + big - 1) / big * big; }
-    T* allocate(size_t cnt) {
-        const size_t bytes = cnt * sizeof(T);
-        void* q = nullptr;
-        if (bytes >= ((size_t)1 << 22)) {
-            if ((q = g_host_pool.take(rounded(bytes)))) return static_cast<T*>(q);
-            if (posix_memalign(&q, (size_t)1 << 21, rounded(bytes)) != 0) throw std::bad_alloc();
-            (void)madvise(q, rounded(bytes), MADV_HUGEPAGE);
-        } else if (!(q = std::malloc(std::max<size_t>(bytes, 1)))) throw std::bad_alloc();
-        return static_cast<T*>(q);
-    }
-    void deallocate(T* q, size_t cnt) {
-        const size_t bytes = cnt * sizeof(T);
-        if (bytes >= ((size_t)1 << 22) && g_host_pool.give(q, rounded(bytes))) return;
-        std::free(q);
-    }
-    template <class U, class... A> void construct(U* q, A&&... a) {
-        if constexpr (sizeof...(A) == 0) ::new ((void*)q) U; else ::new ((void*)q) U(std::forward<A>(a)...);
-    }
-    template <class U> bool operator==(const HostAlloc<U>&) const { return true; }
-    template <class U> bool operator!=(const HostAlloc<U>&) const { return false; }
-};
-template <class T> using hvec = std::vector<T, HostAlloc<T>>;
-void janitor_wait();        // (defined with the janitor thread below) what the previous set-up released is in the pool after this
+// (par_rows, the host block pool / hvec, the janitor thread, FlatRows and the host-side factorisations themselves: host_factor.h -- no device call
+// in there, so that the same code builds for the CPU alone under the sanitizers)
 
 // wavefront kernel by number of 8 x 8 line blocks in the (j, k) plane: the 16 x 16 kernel from 32^3 up (table at its use)
 static int default_wave_form(unsigned nb8) { return nb8 >= 16 ? 2 : 1; }
@@ -980,6 +915,9 @@ static const int NARROW = 2048;     // levels with at most this many rows are fo
 // `hptr`: the factor's row pointers on the host.  8 KiB per chunk of 64 virtual rows.  Not enough memory, or offsets past 32 bits: the factor keeps
 // the barrier kernel (free_runs = false).
 static int32_t build_free_streams(TriFactor* F, hipStream_t st, const int32_t* hptr) {
+    // tri_run_free_kernel packs a row's absolute position into 29 bits of `vreal` (flags at bits 29, 30) and forms byte offsets in 32 bits:
+    // a factor of 2^29 rows or more -- it would fit a 288 GB card -- takes the pipe / sync-free kernels instead
+    if (F->free_runs && F->npos >= (1ll << 29)) F->free_runs = false;
     if (!F->free_runs) return KRYST_OK;
     const int nl = (int)F->lvl_off.size() - 1;
     std::vector<std::pair<int32_t, int32_t>> runs;
@@ -1306,24 +1244,11 @@ static int32_t up(T** dst, const std::vector<T, A>& v) {
 }
 
 
-// kept entries of a triangular factor, row by row in STORED order (flat CSR: a vector per row costs 2n heap blocks)
-struct FlatRows {
-    hvec<int64_t> ptr; hvec<int32_t> col; hvec<double> val;
-    int64_t len(int64_t i) const { return ptr[(size_t)i + 1] - ptr[(size_t)i]; }
-};
-
 // level order of one factor
 static int32_t build_factor(int64_t n, const FlatRows& ent, const hvec<double>& diag, bool forward, TriFactor* F,
                             std::vector<int32_t>* pos_out) {
     std::vector<int32_t> lvl((size_t)n, 0);
-    int32_t nl = 0;
-    auto level_of = [&](int64_t i) {
-        int32_t l = 0;
-        for (int64_t k = ent.ptr[i]; k < ent.ptr[i + 1]; ++k) l = std::max(l, lvl[ent.col[k]] + 1);
-        lvl[i] = l; nl = std::max(nl, l + 1);
-    };
-    if (forward) for (int64_t i = 0; i < n; ++i) level_of(i);
-    else for (int64_t i = n - 1; i >= 0; --i) level_of(i);
+    const int32_t nl = host_levels(n, ent.ptr.data(), ent.col.data(), forward, lvl.data());      // (host_factor.cpp)
     F->lvl_off.assign((size_t)nl + 1, 0);
     for (int64_t i = 0; i < n; ++i) F->lvl_off[lvl[i] + 1]++;
     for (int l = 0; l < nl; ++l) F->lvl_off[l + 1] += F->lvl_off[l];
@@ -1704,15 +1629,22 @@ static int32_t finish_ilu_pc(kryst_csr_t a, int mode, bool divide, const FlatRow
     if (rc == KRYST_OK && !(D->GL.ok && D->GU.ok) && !(D->BL.ok && D->BU.ok)) {
         std::vector<int32_t> posL, posU;
         // the two factors' level orders are independent: side by side (each has its own host arrays; the uploads share the context's stream)
+        // (the error text is thread-local and an exception must not leave a thread function: the worker hands both back -- ADVICE r04)
         int32_t rc_u = KRYST_OK;
+        std::string err_u;
         std::thread upper([&] {
-            (void)hipSetDevice(ctx->device);
-            tl_setup_stream = ctx->s_main;
-            rc_u = build_factor(n, ue, dg, false, &D->U, &posU);
+            try {
+                (void)hipSetDevice(ctx->device);
+                tl_setup_stream = ctx->s_main;
+                rc_u = build_factor(n, ue, dg, false, &D->U, &posU);
+                if (rc_u != KRYST_OK) err_u = kryst_hip_last_error();
+            } catch (const std::bad_alloc&) { rc_u = KRYST_ERR_ARG; err_u = "ILU set-up: out of host memory while level-ordering U";
+            } catch (...) { rc_u = KRYST_ERR_ARG; err_u = "ILU set-up: unexpected exception while level-ordering U"; }
         });
-        rc = build_factor(n, le, ones, true, &D->L, &posL);
+        try { rc = build_factor(n, le, ones, true, &D->L, &posL); }
+        catch (const std::bad_alloc&) { rc = KRYST_ERR_ARG; set_error("ILU set-up: out of host memory while level-ordering L"); }
         upper.join();
-        if (rc == KRYST_OK) rc = rc_u;
+        if (rc == KRYST_OK && rc_u != KRYST_OK) { rc = rc_u; set_error("%s", err_u.c_str()); }
         if (rc == KRYST_OK) {
             std::vector<int32_t> mapLU((size_t)n);
             for (int64_t i = 0; i < n; ++i) mapLU[posU[i]] = posL[i];
@@ -2585,40 +2517,6 @@ extern "C" int32_t kryst_pc_ilu0(kryst_csr_t a, int32_t mode, kryst_pc_t* out) {
 // one thread did all of it before: 300 ms of the 620 ms Ilup(1) setup at 128^3).  The lowest unfinished row never waits for an
 // unfinished one, so somebody always makes progress.  The same operations on the same operands in the same order as the one-thread
 // loop: same bits.
-namespace kr {
-// releases big host arrays off the caller's thread; at most one release in flight, joined before the next and when the library goes
-struct Janitor {
-    std::thread th; std::mutex mu;
-    ~Janitor() { if (th.joinable()) th.join(); }
-    template <class F> void run(F&& f) { std::lock_guard<std::mutex> g(mu); if (th.joinable()) th.join(); th = std::thread(std::forward<F>(f)); }
-    // a set-up about to take big host arrays: what the previous one released should be in the pool by then (a back-to-back second set-up
-    // that overtook the janitor took fresh pages instead -- download 43-74 ms instead of 4-6)
-    void wait() { std::lock_guard<std::mutex> g(mu); if (th.joinable()) th.join(); }
-};
-static Janitor g_janitor;
-void janitor_wait() { g_janitor.wait(); }
-struct IlupU { int32_t c; double v; uint64_t lev; };                       // a nonzero a_work[j][k], k > j, of a finished row
-struct IlupE { int32_t c; double v; };                                     // a kept entry of L or U
-template <class T>
-struct Arena {                                                             // append-only; what has been handed out never moves (other threads read it)
-    std::vector<hvec<T>> chunks; size_t used = 0, cap = 0;                 // (8 MiB chunks: huge pages, HostAlloc)
-    // room for `cnt` elements with its pages already mapped: a thread that takes page faults (or maps a new chunk) in the middle of the row
-    // pipeline holds up every thread behind it
-    void reserve_mapped(size_t cnt) {
-        cap = std::max<size_t>(cnt, ((size_t)8 << 20) / sizeof(T)); chunks.emplace_back(); chunks.back().resize(cap); used = 0;
-        char* q = reinterpret_cast<char*>(chunks.back().data()); const size_t bytes = cap * sizeof(T);
-#ifdef MADV_POPULATE_WRITE
-        if (madvise(reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(q) + 4095) & ~(uintptr_t)4095), bytes > 8192 ? (bytes - 4096) & ~(size_t)4095 : 0, MADV_POPULATE_WRITE) == 0) return;
-#endif
-        for (size_t x = 0; x < bytes; x += 4096) q[x] = 0;
-    }
-    T* take(size_t cnt) {
-        if (used + cnt > cap) { cap = std::max<size_t>(cnt, ((size_t)8 << 20) / sizeof(T)); chunks.emplace_back(); chunks.back().resize(cap); used = 0; }
-        T* p = chunks.back().data() + used; used += cnt; return p;
-    }
-};
-}  // namespace kr
-
 static int32_t ilup_setup(kryst_csr_t a, int32_t fill, kryst_pc_t* out);
 extern "C" int32_t kryst_pc_ilup(kryst_csr_t a, int32_t fill, kryst_pc_t* out) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -2639,169 +2537,27 @@ static int32_t ilup_setup(kryst_csr_t a, int32_t fill, kryst_pc_t* out) {
     hvec<int64_t> rp; hvec<int32_t> col; hvec<double> val;
     KR_TRY(download_rows(a, rp, col, val));
     lap("download");
-    const uint64_t UMAX = ~0ull;
-    struct WEnt { int32_t c; double v; uint64_t lev; };
-    struct RowOut { const IlupU* u = nullptr; const IlupE* l = nullptr; const IlupE* k = nullptr; int32_t nu = 0, nl = 0, nk = 0; };
-    hvec<RowOut> rows((size_t)n);                                          // finished rows: upper part (for later rows), kept L and U entries
-    hvec<double> udiag((size_t)n), dg((size_t)n);                          // a_work[j][j] of a finished row; the kept diagonal
-    par_rows(n, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) { rows[(size_t)i] = RowOut(); udiag[(size_t)i] = 0.0; dg[(size_t)i] = 1.0; } });
-    std::atomic<long long> bad_row{-1};                                    // lowest row i whose elimination met a zero u_jj ...
-    std::vector<long long> bad_col;                                        // ... and that j, per thread
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    const unsigned T = (unsigned)std::max(1, std::min<int>((int)hw, env_int("KRYST_ILUP_THREADS", n < 4096 ? 1 : (int)hw)));
-    // Blocks of 2 048 rows (measured at 128^3, 16 threads: 512 rows 197 ms, 1 024 110, 2 048 89, 4 096 90): on a grid with lines of 128 rows that is 16 lines, and row i's pivot rows i - 1, i - Ni (+ 1), i - Ni Nj (+ 1, + Ni)
-    // are the thread's own except along the block's first line -- a pivot row finished by another core costs a few cache-line
-    // transfers (0.2 - 1 us each on the two-socket hosts of the GPU boxes; blocks of 8 rows, tried first, were 3 x SLOWER than one thread).
-    // A thread publishes its finished rows 16 at a time (and before it waits itself): one flag byte per row, so a consumer walking a
-    // line behind its producer takes the flags' cache line once per batch, not once per row.
-    const int64_t B = std::max(1, env_int("KRYST_ILUP_BLOCK", 2048)), nblocks = (n + B - 1) / B;
-    std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[(size_t)n + 64]);
-    par_rows(n, [&](int64_t lo, int64_t hi) { for (int64_t r = lo; r < hi; ++r) done[(size_t)r].store(0, std::memory_order_relaxed); });
-    bad_col.assign(T, -1);
-    std::vector<double> waited(T, 0.0), busy(T, 0.0); std::vector<long long> waits(T, 0);   // (KRYST_ILU_VERBOSE: where a thread's time went)
-    std::vector<long long> bad_at(T, -1);
-    std::vector<Arena<IlupU>> arena_u(T); std::vector<Arena<IlupE>> arena_l(T), arena_k(T);   // (alive until the gather below)
-    std::atomic<unsigned> warm{0};
-    auto worker = [&](unsigned tid) {
-        const auto tw0 = std::chrono::steady_clock::now();
-        struct Stop { const std::chrono::steady_clock::time_point t0; double* out; ~Stop() { *out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } stop{tw0, &busy[tid]};
-        Arena<IlupU>& au = arena_u[tid]; Arena<IlupE>& al = arena_l[tid]; Arena<IlupE>& ak = arena_k[tid];
-        std::vector<WEnt> W; std::vector<IlupE> L, Kp; std::vector<IlupU> U;
-        W.reserve(256); L.reserve(256); Kp.reserve(256); U.reserve(256);
-        // every thread's first block waits for the one before it, so a slow start (a core waking up, the first pages of its arenas) would be paid
-        // T times in a row: touch the first chunk of each arena, then start together
-        if (T > 1) {
-            // (an estimate of this thread's share: (fill + 1) times the operator's entries above / below the diagonal, and a tenth on top;
-            // a thread that runs out continues in 8 MiB chunks)
-            const size_t share = (size_t)((double)(rp[(size_t)n] - n) * 0.5 * (double)(fill + 1) * 1.1 / (double)T) + 4096;
-            au.reserve_mapped(share); al.reserve_mapped(share); ak.reserve_mapped(share);
-            warm.fetch_add(1);
-            for (unsigned spin = 0; warm.load(std::memory_order_acquire) < T; ++spin) if ((spin & 1023) == 1023) std::this_thread::yield();
-        }
-        for (int64_t b = tid; b < nblocks; b += T) {
-            const bool trace = verbose && getenv("KRYST_ILUP_TRACE") && b < 6 * (int64_t)T && (tid < 3 || tid == T - 1);
-            const double tb0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count(), wb0 = waited[tid];
-            int64_t published = b * B;                                      // rows [b B, published) of this block carry their flag
-            auto publish = [&](int64_t upto) { for (; published < upto; ++published) done[(size_t)published].store(1, std::memory_order_release); };
-            for (int64_t i = b * B; i < std::min(n, (b + 1) * B); ++i) {
-                { const long long br = bad_row.load(std::memory_order_relaxed); if (br >= 0 && br < i) return; }   // the reference stopped before this row
-                W.clear(); L.clear(); Kp.clear(); U.clear();
-                for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
-                    if (col[k] < n) W.push_back(WEnt{col[k], val[k], val[k] != 0.0 ? 0ull : UMAX});   // ilup.rs:88-101 (halo columns dropped)
-                std::sort(W.begin(), W.end(), [](const WEnt& x, const WEnt& y) { return x.c < y.c; });   // (a block's local numbering is ascending already)
-                // The working row is a small SORTED array; iterating it by index while inserting fill entries BEHIND the cursor visits
-                // exactly the columns `for j in 0..i` would (an inserted column is > j).
-                for (size_t p = 0; p < W.size() && W[p].c < i; ++p) {                              // :104 `for j in 0..i`
-                    const int32_t j = W[p].c;
-                    const double ejv = W[p].v; const uint64_t ejl = W[p].lev;
-                    if (!(ejv != 0.0 && ejl <= (uint64_t)fill)) continue;                          // :106
-                    if (j < b * B && done[(size_t)j].load(std::memory_order_acquire) == 0) {      // row j is somebody else's and still under way
-                        publish(i);                                                                // (nobody waits for what this thread has finished)
-                        const auto w0 = std::chrono::steady_clock::now();
-                        ++waits[tid];
-                        for (unsigned spin = 0; done[(size_t)j].load(std::memory_order_acquire) == 0; ++spin) {
-                            const long long br = bad_row.load(std::memory_order_relaxed);
-                            if (br >= 0 && br < i) return;
-                            if ((spin & 1023) == 1023) std::this_thread::yield();
-                        }
-                        waited[tid] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
-                    }
-                    const double u_jj = udiag[(size_t)j];
-                    if (u_jj == 0.0) {                                                             // :108-110
-                        long long cur = bad_row.load();
-                        while ((cur < 0 || i < cur) && !bad_row.compare_exchange_weak(cur, (long long)i)) {}
-                        if (bad_at[tid] < 0 || i < bad_at[tid]) { bad_at[tid] = i; bad_col[tid] = j; }
-                        return;
-                    }
-                    const double lij = ejv / u_jj;                                                 // :112
-                    L.push_back(IlupE{j, lij});
-                    size_t q = p + 1;                                                              // both lists ascend: one merge pass per pivot row
-                    const IlupU* uj = rows[(size_t)j].u;
-                    for (int32_t t = 0; t < rows[(size_t)j].nu; ++t) {                             // :116 `for k in (j+1)..n`
-                        uint64_t nl = ejl;                                                         // saturating adds (:118)
-                        nl = (nl > UMAX - uj[t].lev) ? UMAX : nl + uj[t].lev;
-                        nl = (nl == UMAX) ? UMAX : nl + 1;
-                        if (nl <= (uint64_t)fill) {
-                            const int32_t k = uj[t].c;
-                            while (q < W.size() && W[q].c < k) ++q;
-                            if (q == W.size() || W[q].c != k) W.insert(W.begin() + (std::ptrdiff_t)q, WEnt{k, 0.0, UMAX});
-                            W[q].v = W[q].v - lij * uj[t].v;                                       // :121
-                            if (nl < W[q].lev) W[q].lev = nl;                                      // :122
-                        }
-                    }
-                }
-                for (const WEnt& e : W) {
-                    if (e.c < i) continue;
-                    if (e.c == i) udiag[(size_t)i] = e.v;
-                    if (e.v != 0.0 && e.lev <= (uint64_t)fill) {                                   // :129-134
-                        if (e.c == i) dg[(size_t)i] = e.v;
-                        else Kp.push_back(IlupE{e.c, e.v});
-                    }
-                    if (e.c > i && e.v != 0.0) U.push_back(IlupU{e.c, e.v, e.lev});
-                }
-                RowOut& r = rows[(size_t)i];
-                r.nu = (int32_t)U.size(); r.nl = (int32_t)L.size(); r.nk = (int32_t)Kp.size();
-                if (r.nu) { IlupU* d = au.take(U.size()); std::copy(U.begin(), U.end(), d); r.u = d; }
-                if (r.nl) { auto* d = al.take(L.size()); std::copy(L.begin(), L.end(), d); r.l = d; }
-                if (r.nk) { auto* d = ak.take(Kp.size()); std::copy(Kp.begin(), Kp.end(), d); r.k = d; }
-                if (((i + 1) & 15) == 0) publish(i + 1);
-            }
-            publish(std::min(n, (b + 1) * B));
-            if (trace) fprintf(stderr, "[kryst ilup]     thread %u block %lld: %.3f .. %.3f ms, waited %.3f\n", tid, (long long)b, tb0,
-                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count(), waited[tid] - wb0);
-        }
-    };
-    FlatRows le, ue;
-    {
-        // the workers exchange finished rows through the caches: keep them on neighbouring cores (one group of 16 consecutive CPU numbers
-        // around the caller's: one socket, two L3 domains on the GPU boxes' hosts) -- KRYST_ILUP_CPU_GROUP=0 leaves the placement to the OS
-        const int group = env_int("KRYST_ILUP_CPU_GROUP", 16);
-        const int cpu0 = sched_getcpu();
-        auto placed = [&](unsigned t) {
-            if (group > 0 && cpu0 >= 0 && T > 1) {
-                cpu_set_t set; CPU_ZERO(&set);
-                const int base = cpu0 / group * group;
-                for (int c = base; c < base + group && c < CPU_SETSIZE; ++c) CPU_SET(c, &set);
-                (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);     // (refused: the OS places the thread)
-            }
-            worker(t);
-        };
-        if (T == 1) worker(0);
-        else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < T; ++t) th.emplace_back(placed, t);
-            for (auto& t : th) t.join();
-        }
-    }
-    if (bad_row.load() >= 0) {
-        const long long i = bad_row.load();
-        long long j = -1;
-        for (unsigned t = 0; t < T; ++t) if (bad_at[t] == i) j = bad_col[t];
-        set_error("ILUP: zero diagonal in U at row %lld", j);
-        return KRYST_SOLVE_ERROR;
-    }
-    lap("elimination");
-    if (verbose) for (unsigned t = 0; t < T; ++t) fprintf(stderr, "[kryst ilup]   thread %u: %.0f ms, of which %.0f ms in %lld waits for another thread's rows\n", t, busy[t], waited[t], waits[t]);
-    le.ptr.assign((size_t)n + 1, 0); ue.ptr.assign((size_t)n + 1, 0);
-    for (int64_t i = 0; i < n; ++i) { le.ptr[(size_t)i + 1] = le.ptr[(size_t)i] + rows[(size_t)i].nl; ue.ptr[(size_t)i + 1] = ue.ptr[(size_t)i] + rows[(size_t)i].nk; }
-    le.col.resize((size_t)le.ptr[(size_t)n]); le.val.resize(le.col.size()); ue.col.resize((size_t)ue.ptr[(size_t)n]); ue.val.resize(ue.col.size());
-    par_rows(n, [&](int64_t lo, int64_t hi) {
-        for (int64_t i = lo; i < hi; ++i) {
-            const RowOut& r = rows[(size_t)i];
-            for (int32_t t = 0; t < r.nl; ++t) { le.col[(size_t)le.ptr[(size_t)i] + t] = r.l[t].c; le.val[(size_t)le.ptr[(size_t)i] + t] = r.l[t].v; }
-            for (int32_t t = 0; t < r.nk; ++t) { ue.col[(size_t)ue.ptr[(size_t)i] + t] = r.k[t].c; ue.val[(size_t)ue.ptr[(size_t)i] + t] = r.k[t].v; }
-        }
-    });
-    lap("kept entries gathered");
+    // the elimination itself: the row pipeline over the host's cores (host_factor.cpp: host_ilup_rows -- ilup.rs:77-134 on sparse rows)
+    IlupOptions opt;
+    opt.threads = env_int("KRYST_ILUP_THREADS", 0); opt.block = std::max(1, env_int("KRYST_ILUP_BLOCK", 2048));
+    opt.cpu_group = env_int("KRYST_ILUP_CPU_GROUP", 16); opt.verbose = verbose; opt.trace = verbose && getenv("KRYST_ILUP_TRACE") != nullptr;
+    FlatRows le, ue; hvec<double> dg;
+    long long zero_col = -1;
+    std::shared_ptr<void> scratch;
+    int hrc = 2;
+    try { hrc = host_ilup_rows(n, rp.data(), col.data(), val.data(), fill, opt, le, ue, dg, &zero_col, &scratch); }
+    catch (const std::bad_alloc&) { hrc = 2; }
+    if (hrc == 1) { set_error("ILUP: zero diagonal in U at row %lld", zero_col); return KRYST_SOLVE_ERROR; }
+    if (hrc != 0) { set_error("ILUP: out of host memory during the elimination"); return KRYST_ERR_ARG; }
     const int32_t rc = finish_ilu_pc(a, 10 + fill, true, le, ue, dg, out);
     lap("device structures");
     // ~1 GB of host arrays at 128^3: unmapping them takes 60-70 ms, which the caller need not wait for
-    struct Bundle { std::vector<Arena<IlupU>> u; std::vector<Arena<IlupE>> l, k; hvec<RowOut> rows; FlatRows le, ue; hvec<int64_t> rp; hvec<int32_t> col; hvec<double> val; };
+    struct Bundle { std::shared_ptr<void> scratch; FlatRows le, ue; hvec<int64_t> rp; hvec<int32_t> col; hvec<double> val; hvec<double> dg; };
     auto bundle = std::make_shared<Bundle>();
-    bundle->u.swap(arena_u); bundle->l.swap(arena_l); bundle->k.swap(arena_k); bundle->rows.swap(rows);
+    bundle->scratch.swap(scratch);
     bundle->le.ptr.swap(le.ptr); bundle->le.col.swap(le.col); bundle->le.val.swap(le.val); bundle->ue.ptr.swap(ue.ptr); bundle->ue.col.swap(ue.col); bundle->ue.val.swap(ue.val);
-    bundle->rp.swap(rp); bundle->col.swap(col); bundle->val.swap(val);
-    g_janitor.run([bundle]() mutable { bundle.reset(); });
+    bundle->rp.swap(rp); bundle->col.swap(col); bundle->val.swap(val); bundle->dg.swap(dg);
+    janitor_run(bundle);
     lap("host arrays handed to the janitor thread");
     return rc;
 }
@@ -2813,46 +2569,74 @@ extern "C" int32_t kryst_pc_ilut(kryst_csr_t a, int32_t fill, double droptol, kr
     const int64_t n = a->nrows;
     hvec<int64_t> rp; hvec<int32_t> col; hvec<double> val;
     KR_TRY(download_rows(a, rp, col, val));
-    // rows are independent (ilut.rs:80-150 eliminates nothing): counted and written by the host's cores, straight into flat arrays
-    hvec<double> dg((size_t)n);
-    par_rows(n, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) dg[(size_t)i] = 1.0; });
-    FlatRows le, ue;
-    le.ptr.assign((size_t)n + 1, 0); ue.ptr.assign((size_t)n + 1, 0);
-    auto kept_row = [&](int64_t i, std::vector<std::pair<int32_t, double>>& row) {
-        row.clear();
-        for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
-            if (col[k] < n && val[k] != 0.0 && std::fabs(val[k]) >= droptol) row.push_back({col[k], val[k]});     // :88-95
-        if ((int64_t)row.size() > fill) {                                                                        // :97-100
-            std::stable_sort(row.begin(), row.end(), [](const std::pair<int32_t, double>& x, const std::pair<int32_t, double>& y) {
-                return std::fabs(x.second) > std::fabs(y.second); });
-            row.resize((size_t)fill);
-        }
-    };
-    par_rows(n, [&](int64_t lo, int64_t hi) {
-        std::vector<std::pair<int32_t, double>> row;
-        for (int64_t i = lo; i < hi; ++i) {
-            kept_row(i, row);
-            int64_t nl = 0, nu = 0;
-            for (auto& e : row) { if (e.first < i) ++nl; else if (e.first > i) ++nu; }
-            le.ptr[(size_t)i + 1] = nl; ue.ptr[(size_t)i + 1] = nu;
-        }
-    });
-    for (int64_t i = 0; i < n; ++i) { le.ptr[(size_t)i + 1] += le.ptr[(size_t)i]; ue.ptr[(size_t)i + 1] += ue.ptr[(size_t)i]; }
-    le.col.resize((size_t)le.ptr[(size_t)n]); le.val.resize(le.col.size()); ue.col.resize((size_t)ue.ptr[(size_t)n]); ue.val.resize(ue.col.size());
-    par_rows(n, [&](int64_t lo, int64_t hi) {
-        std::vector<std::pair<int32_t, double>> row;
-        for (int64_t i = lo; i < hi; ++i) {
-            kept_row(i, row);
-            int64_t pl = le.ptr[(size_t)i], pu = ue.ptr[(size_t)i];
-            bool have_d = false;
-            for (auto& e : row) {                                                                                // :104-112
-                if (e.first < i) { le.col[(size_t)pl] = e.first; le.val[(size_t)pl] = e.second; ++pl; }
-                else if (e.first > i) { ue.col[(size_t)pu] = e.first; ue.val[(size_t)pu] = e.second; ++pu; }
-                else if (!have_d) { dg[(size_t)i] = e.second; have_d = true; }                                   // :143-144
-            }
-        }
-    });
+    FlatRows le, ue; hvec<double> dg;
+    try { host_ilut_rows(n, rp.data(), col.data(), val.data(), fill, droptol, le, ue, dg); }     // (host_factor.cpp; ilut.rs:80-150)
+    catch (const std::bad_alloc&) { set_error("ILUT: out of host memory"); return KRYST_ERR_ARG; }
     return finish_ilu_pc(a, 100, true, le, ue, dg, out);
+}
+
+// ---- the host-side factorisations on plain host arrays (kryst_hip.h: no device, no context): what kryst_pc_ilup / kryst_pc_ilut run between the
+// download of the operator's rows and the upload of the factors, for CPU-only callers, for tests against the oracle and for the sanitizer tier
+struct kryst_host_factors_s { kr::FlatRows le, ue; kr::hvec<double> dg; int64_t n = 0; };
+static int32_t host_rows_check(int64_t n, const int64_t* row_ptr, const int32_t* col, const double* val, const char* who) {
+    if (n < 0 || !row_ptr || (row_ptr[n] > 0 && (!col || !val)) || row_ptr[0] != 0) { set_error("bad argument: %s", who); return KRYST_ERR_ARG; }
+    for (int64_t i = 0; i < n; ++i) if (row_ptr[i + 1] < row_ptr[i]) { set_error("bad argument: %s: row_ptr must not decrease", who); return KRYST_ERR_ARG; }
+    for (int64_t k = 0; k < row_ptr[n]; ++k) if (col[k] < 0) { set_error("bad argument: %s: negative column", who); return KRYST_ERR_ARG; }
+    return KRYST_OK;
+}
+extern "C" int32_t kryst_host_ilup(int64_t n, const int64_t* row_ptr, const int32_t* col, const double* val, int32_t fill, int32_t threads, int64_t block,
+                                   kryst_host_factors_t* out) {
+    KR_ARG(out && fill >= 0, "host_ilup");
+    KR_TRY(host_rows_check(n, row_ptr, col, val, "host_ilup"));
+    std::unique_ptr<kryst_host_factors_s> F(new kryst_host_factors_s());
+    F->n = n;
+    IlupOptions opt; opt.threads = threads; opt.block = block > 0 ? block : 2048; opt.cpu_group = 0;
+    long long zero_col = -1;
+    int hrc = 2;
+    try { hrc = host_ilup_rows(n, row_ptr, col, val, fill, opt, F->le, F->ue, F->dg, &zero_col, nullptr); } catch (const std::bad_alloc&) { hrc = 2; }
+    if (hrc == 1) { set_error("ILUP: zero diagonal in U at row %lld", zero_col); set_error_row(zero_col); return KRYST_SOLVE_ERROR; }
+    if (hrc != 0) { set_error("host_ilup: out of host memory"); return KRYST_ERR_ARG; }
+    *out = F.release();
+    return KRYST_OK;
+}
+extern "C" int32_t kryst_host_ilut(int64_t n, const int64_t* row_ptr, const int32_t* col, const double* val, int32_t fill, double droptol, int32_t threads,
+                                   kryst_host_factors_t* out) {
+    KR_ARG(out && fill >= 0, "host_ilut");
+    KR_TRY(host_rows_check(n, row_ptr, col, val, "host_ilut"));
+    std::unique_ptr<kryst_host_factors_s> F(new kryst_host_factors_s());
+    F->n = n;
+    try { host_ilut_rows(n, row_ptr, col, val, fill, droptol, F->le, F->ue, F->dg, threads); } catch (const std::bad_alloc&) { set_error("host_ilut: out of host memory"); return KRYST_ERR_ARG; }
+    *out = F.release();
+    return KRYST_OK;
+}
+extern "C" int32_t kryst_host_factors_sizes(kryst_host_factors_t f, int64_t* n, int64_t* nnz_l, int64_t* nnz_u) {
+    KR_ARG(f, "host_factors_sizes");
+    if (n) *n = f->n;
+    if (nnz_l) *nnz_l = f->le.ptr.empty() ? 0 : f->le.ptr[(size_t)f->n];
+    if (nnz_u) *nnz_u = f->ue.ptr.empty() ? 0 : f->ue.ptr[(size_t)f->n];
+    return KRYST_OK;
+}
+extern "C" int32_t kryst_host_factors_get(kryst_host_factors_t f, int64_t* l_ptr, int32_t* l_col, double* l_val, int64_t* u_ptr, int32_t* u_col, double* u_val, double* diag) {
+    KR_ARG(f, "host_factors_get");
+    const size_t n = (size_t)f->n;
+    if (l_ptr) std::copy(f->le.ptr.begin(), f->le.ptr.begin() + (std::ptrdiff_t)n + 1, l_ptr);
+    if (u_ptr) std::copy(f->ue.ptr.begin(), f->ue.ptr.begin() + (std::ptrdiff_t)n + 1, u_ptr);
+    if (l_col) std::copy(f->le.col.begin(), f->le.col.end(), l_col);
+    if (l_val) std::copy(f->le.val.begin(), f->le.val.end(), l_val);
+    if (u_col) std::copy(f->ue.col.begin(), f->ue.col.end(), u_col);
+    if (u_val) std::copy(f->ue.val.begin(), f->ue.val.end(), u_val);
+    if (diag) std::copy(f->dg.begin(), f->dg.begin() + (std::ptrdiff_t)n, diag);
+    return KRYST_OK;
+}
+extern "C" int32_t kryst_host_factors_destroy(kryst_host_factors_t f) { delete f; return KRYST_OK; }
+extern "C" int32_t kryst_host_levels(int64_t n, const int64_t* ptr, const int32_t* col, int32_t forward, int32_t* level, int32_t* nlevels) {
+    KR_ARG(n >= 0 && ptr && level && (ptr[n] == 0 || col), "host_levels");
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t k = ptr[i]; k < ptr[i + 1]; ++k)
+            if (col[k] < 0 || col[k] >= n || (forward ? col[k] >= i : col[k] <= i)) { set_error("bad argument: host_levels: row %lld is not strictly %s", (long long)i, forward ? "lower" : "upper"); return KRYST_ERR_ARG; }
+    const int32_t nl = host_levels(n, ptr, col, forward != 0, level);
+    if (nlevels) *nlevels = nl;
+    return KRYST_OK;
 }
 
 // What an ILU-family preconditioner's apply runs and streams (bench.py prices the triangular solve with it):

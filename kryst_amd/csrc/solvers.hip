@@ -17,7 +17,7 @@ struct DotPairOp {
 };
 template <bool KEEP = false>
 struct AypxDevOp {                   // y = x + beta*y  (cg.rs:274-276, pcg.rs:215-217), beta on the device
-    static constexpr int NQ = 0; static constexpr const char* TAG = "AypxDev";
+    static constexpr int NQ = 0; static constexpr const char* TAG = "AypxDev"; static constexpr int PHASE = KR_PH_BLAS1_DIRECTION;
     const double* beta; const double* x; double* y;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double be = *beta;
@@ -30,7 +30,7 @@ struct AypxDevOp {                   // y = x + beta*y  (cg.rs:274-276, pcg.rs:2
 // x += alpha p ; r -= alpha Ap (cg.rs:207-212) ; partial r.r (cg.rs:223) [; partial r.p for the Natural norm, :227]
 template <bool KEEP = false>
 struct CgUpdate1 {
-    static constexpr int NQ = 1; static constexpr const char* TAG = "CgUpdate1";
+    static constexpr int NQ = 1; static constexpr const char* TAG = "CgUpdate1"; static constexpr int PHASE = KR_PH_BLAS1_RESIDUAL;
     const double* alpha; const double* p; const double* ap; double* x; double* r;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         const double al = *alpha;
@@ -76,7 +76,7 @@ struct CgUpdate0 {                   // no fused dot (PCG with a non-pointwise p
 // inside the iteration).
 template <bool KEEP = false>
 struct CgResidualOp {                // r -= alpha Ap (cg.rs:210-212) ; partial r.r (:223)
-    static constexpr int NQ = 1; static constexpr const char* TAG = "CgResidual"; static constexpr int BPC = 3;       // 2 reads + 1 write + a fold per tile: 3 workgroups per CU (tools/stream_ab.py: 512^3 0.609 -> 0.533 ms, 256^3 0.077 -> 0.065)
+    static constexpr int NQ = 1; static constexpr const char* TAG = "CgResidual"; static constexpr int PHASE = KR_PH_BLAS1_RESIDUAL; static constexpr int BPC = 3;       // 2 reads + 1 write + a fold per tile: 3 workgroups per CU (tools/stream_ab.py: 512^3 0.609 -> 0.533 ms, 256^3 0.077 -> 0.065)
     const double* alpha; const double* ap; double* r;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         const double al = *alpha;
@@ -98,7 +98,7 @@ struct CgResidual0Op {               // r -= alpha Ap, no fused dot (PCG with a 
 };
 template <bool KEEP = false>
 struct CgDirectionOp {               // x += alpha p (cg.rs:207-209, deferred) ; p = z + beta p (cg.rs:274-276, pcg.rs:215-217; z = r for CG)
-    static constexpr int NQ = 0; static constexpr const char* TAG = "CgDirection"; static constexpr int BPC = 3;   // inside CG: 2 -> 3 +4.4 % (256^3), +1.1 % (512^3); PCG +3.0 % / -0.7 %
+    static constexpr int NQ = 0; static constexpr const char* TAG = "CgDirection"; static constexpr int PHASE = KR_PH_BLAS1_DIRECTION; static constexpr int BPC = 3;   // inside CG: 2 -> 3 +4.4 % (256^3), +1.1 % (512^3); PCG +3.0 % / -0.7 %
     const DevState* st; const double* z; double* p; double* x;
     __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
         const double al = st->alpha, be = st->beta;
@@ -333,7 +333,7 @@ int32_t cg_solve(kryst_vec_t bv, kryst_vec_t xv, const SolveIO& io) {
 //   x += alpha p ; r -= alpha Ap ; z = M^-1 r ; partial 0 = r.z ; partial 1 = norm quantity (z.z | r.r)
 template <bool JACOBI, bool KEEP = false>
 struct PcgUpdateOp {
-    static constexpr int NQ = 2; static constexpr const char* TAG = "PcgUpdate"; static constexpr int BPC = 3;       // 5 reads + 3 writes: 3 workgroups per CU measured best (+3 %)
+    static constexpr int NQ = 2; static constexpr const char* TAG = "PcgUpdate"; static constexpr int PHASE = KR_PH_BLAS1_RESIDUAL; static constexpr int BPC = 3;       // 5 reads + 3 writes: 3 workgroups per CU measured best (+3 %)
     const double* alpha; const double* p; const double* ap; double* x; double* r; double* z; const double* inv;
     int norm_type;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {
@@ -356,7 +356,7 @@ struct PcgUpdateOp {
 
 template <bool JACOBI, bool KEEP = false>
 struct PcgResidualOp {               // PcgUpdateOp without its x half (deferred to CgDirectionOp): 2-3 reads + 1-2 writes
-    static constexpr int NQ = 2; static constexpr const char* TAG = "PcgResidual"; static constexpr int BPC = 3;
+    static constexpr int NQ = 2; static constexpr const char* TAG = "PcgResidual"; static constexpr int PHASE = KR_PH_BLAS1_RESIDUAL; static constexpr int BPC = 3;
     const double* alpha; const double* ap; double* r; double* z; const double* inv;
     int norm_type;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[2]) const {

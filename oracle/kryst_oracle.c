@@ -659,10 +659,23 @@ int32_t kro_gmres(const kro_csr_t* a, const kro_pc_t* pc, const double* b, doubl
     int64_t n_outer = restart > 0 ? (p->max_iters + restart - 1) / restart : 0;   /* :231 div_ceil */
     int64_t iteration = 0;
     const double eps = 1e-14;                                       /* :233 */
+    double res0_in = res0;                                          /* the norm the in-cycle test divides by (side 3: ||M^-1 r0|| of the first cycle) */
     for (int64_t outer = 0; outer < n_outer; ++outer) {             /* :234 */
         int64_t nv = 0, nz = 0;
         double r0_norm = beta;                                      /* :238 */
-        if (side == 1) {                                            /* :240-247 */
+        if (side == 3) {
+            /* LABELLED EXTENSION, not in the reference: textbook left preconditioning (Saad, Alg. 9.4) in the reference's frame.
+             * The reference's Left arm (:240-247, :279-307) orthogonalises against Z with the UN-normalised Z[0] = M^-1 v0 and starts g
+             * from the unpreconditioned ||r0||, so its least-squares problem is not the one of M^-1 A x = M^-1 b.  Here: Arnoldi on
+             * M^-1 A started from M^-1 r0 / ||M^-1 r0||, modified Gram-Schmidt twice against V as in arnoldi (:83-96), x updated with V
+             * (:362-386), the in-cycle test on the preconditioned residual |g[j+1]| relative to the first cycle's ||M^-1 r0||, the
+             * cycle-end test on the true residual exactly as :388-398.  Happy breakdown as in arnoldi (:97-101): Givens still applied. */
+            rc = kro_pc_apply(pc, r0, z, n); if (rc) goto out_noupdate;
+            r0_norm = kro_norm(rs, z, n);
+            PFOR(k, n) V[0][k] = z[k] / r0_norm;
+            nv = 1;
+            if (outer == 0) res0_in = r0_norm;
+        } else if (side == 1) {                                     /* :240-247 */
             PFOR(k, n) V[0][k] = r0[k] / r0_norm;
             nv = 1;
             rc = kro_pc_apply(pc, V[0], Z[0], n); if (rc) goto out_noupdate;   /* `.expect` panics in the reference */
@@ -707,6 +720,13 @@ int32_t kro_gmres(const kro_csr_t* a, const kro_pc_t* pc, const double* b, doubl
                 PFOR(k, n) V[nv][k] = z[k] / hj;
                 rc = kro_pc_apply(pc, V[nv], Z[nz], n); if (rc) goto out_noupdate;
                 nv++; nz++;
+            } else if (side == 3) {                                 /* extension: z = M^-1 A v_j, orthogonalised against V */
+                kro_spmv(a, V[j], w);
+                rc = kro_pc_apply(pc, w, z, n); if (rc) goto out_noupdate;
+                mgs2(rs, z, V, j, h, ld, n);
+                H(j + 1, j) = kro_norm(rs, z, n);
+                if (fabs(H(j + 1, j)) < eps) happy = 1;
+                else { double hj = H(j + 1, j); PFOR(k, n) V[nv][k] = z[k] / hj; nv++; }
             } else {                                                /* :343-345 -> arnoldi :65-105 */
                 kro_spmv(a, V[j], w);
                 mgs2(rs, w, V, j, h, ld, n);
@@ -716,7 +736,7 @@ int32_t kro_gmres(const kro_csr_t* a, const kro_pc_t* pc, const double* b, doubl
             }
             givens_update(h, ld, g, cs, sn, j, eps);                /* :347 */
             double res_norm = fabs(g[j + 1]);                       /* :348 */
-            int stop = conv_check(p->tol, p->max_iters, res_norm, res0, iteration, st);   /* :349-350 */
+            int stop = conv_check(p->tol, p->max_iters, res_norm, res0_in, iteration, st);   /* :349-350 (res0_in == res0 unless side 3) */
             trace_push(tr, iteration, res_norm);                    /* addition: the reference keeps no GMRES history */
             m = j + 1;                                              /* :351 */
             if ((stop && st->converged) || happy) break;            /* :352-354 */

@@ -99,7 +99,7 @@ typedef struct {
     double  tol;
     int64_t max_iters;
     int32_t restart;          /* GMRES */
-    int32_t precond_side;     /* GMRES: 0 None, 1 Left (default, gmres.rs:53), 2 Right */
+    int32_t precond_side;     /* GMRES: 0 None, 1 Left (default, gmres.rs:53), 2 Right; 3 = textbook Left (labelled extension, not in the reference) */
     int32_t norm_type;        /* CG/PCG CgNormType: 0 Preconditioned, 1 Unpreconditioned (default), 2 Natural, 3 None */
     int32_t single_reduction; /* cg.rs:146-165, pcg.rs:151-160 */
     int32_t has_radius;   double radius;      /* cg.rs:177-202 */

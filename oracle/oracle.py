@@ -18,6 +18,7 @@ OK, FACTOR_ERROR, SOLVE_ERROR, INDEFINITE_MATRIX, INDEFINITE_PC, ZERO_PIVOT, UNS
 REDUCE_SERIAL, REDUCE_TILED = 0, 1
 PC_NONE, PC_IDENTITY, PC_JACOBI, PC_ILU0_COMPAT, PC_ILUP0, PC_ILU0_TRUE, PC_CHEB_STUB, PC_CHEB, PC_TRIROWS = range(9)
 SIDE_NONE, SIDE_LEFT, SIDE_RIGHT = 0, 1, 2
+SIDE_LEFT_TEXTBOOK = 3          # labelled extension (kro_gmres side 3): Arnoldi on M^-1 A from M^-1 r0, Gram-Schmidt against V
 NORM_PRECONDITIONED, NORM_UNPRECONDITIONED, NORM_NATURAL, NORM_NONE = 0, 1, 2, 3
 
 _dp = C.POINTER(C.c_double)

@@ -143,6 +143,7 @@ def run_rank(rank, P, outdir, N, kind):
     cheb = K.ChebyshevPc(3, 1.0, 11.5).setup(a)
     extra = [("gmres_cheb", K.GmresSolver(8, 1e-9, 32).with_preconditioning(K.Preconditioning.Left), cheb),
              ("gmres_right", K.GmresSolver(8, 1e-9, 40).with_preconditioning(K.Preconditioning.Right), pcj),
+             ("gmres_ltb", K.GmresSolver(8, 1e-9, 40).with_preconditioning(K.Preconditioning.LeftTextbook), pcj),      # the labelled extension (side 3)
              ("bicg_rpc", K.BiCgStabRightPcSolver(1e-9 * bn, 120), pcj)]
     if light:
         extra = []

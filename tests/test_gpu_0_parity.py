@@ -1360,7 +1360,7 @@ def test_bicgstab_edge_exits(ctx, rs):
     _check_solver(res, st, s, x)
 
 
-@pytest.mark.parametrize("side", [K.Preconditioning.NoPc, K.Preconditioning.Left, K.Preconditioning.Right])
+@pytest.mark.parametrize("side", [K.Preconditioning.NoPc, K.Preconditioning.Left, K.Preconditioning.Right, K.Preconditioning.LeftTextbook])
 @pytest.mark.parametrize("restart", [5, 30])
 def test_gmres_bit_exact(ctx, rs, side, restart):
     a = O.stencil7(8, "convdiff")
@@ -1396,6 +1396,11 @@ def test_solvers_with_ilu_bit_exact(ctx, rs, mode):
     kpc, opc = kcls().setup(dn), ofn(an)
     res = O.solve("gmres", an, bn, pc=opc, tol=1e-9, max_iters=60, restart=20, side=O.SIDE_LEFT, rs=rs)
     s = K.GmresSolver(20, 1e-9, 60); x = np.zeros(an.nrows)
+    st = s.solve(dn, kpc, bn, x)
+    _check_solver(res, st, s, x)
+    # ... and the textbook Left extension (precond_side 3) with the same factors
+    res = O.solve("gmres", an, bn, pc=opc, tol=1e-9, max_iters=60, restart=20, side=O.SIDE_LEFT_TEXTBOOK, rs=rs)
+    s = K.GmresSolver(20, 1e-9, 60).with_preconditioning(K.Preconditioning.LeftTextbook); x = np.zeros(an.nrows)
     st = s.solve(dn, kpc, bn, x)
     _check_solver(res, st, s, x)
     tol = 1e-9 * np.linalg.norm(bn)
@@ -1438,7 +1443,7 @@ def test_gmres_happy_breakdown_paths(ctx, rs):
     ao = O.Csr.from_dense(np.eye(6))
     a = to_dev(ctx, ao)
     b = np.arange(1.0, 7.0)
-    for side in (0, 1, 2):
+    for side in (0, 1, 2, 3):
         opc = None if side == 0 else O.Pc.jacobi(ao)
         kpc = None if side == 0 else K.Jacobi().setup(a)
         res = O.solve("gmres", ao, b, pc=opc, tol=1e-10, max_iters=12, restart=4, side=side, rs=rs)

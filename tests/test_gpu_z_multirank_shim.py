@@ -100,6 +100,7 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
              ("cgs", "cgs", None, dict(tol=1e-9, max_iters=60)), ("tfqmr", "tfqmr", None, dict(tol=1e-9, max_iters=30)),
              ("gmres_cheb", "gmres", O.Pc.chebyshev(a, 1.0, 11.5, 3), dict(tol=1e-9, max_iters=32, restart=8, side=O.SIDE_LEFT)),
              ("gmres_right", "gmres", O.Pc.jacobi(a), dict(tol=1e-9, max_iters=40, restart=8, side=O.SIDE_RIGHT)),
+             ("gmres_ltb", "gmres", O.Pc.jacobi(a), dict(tol=1e-9, max_iters=40, restart=8, side=O.SIDE_LEFT_TEXTBOOK)),
              ("bicg_rpc", "bicgstab_rpc", O.Pc.jacobi(a), dict(tol=1e-9 * bn, max_iters=120))]
     if light:
         cases = cases[:3]

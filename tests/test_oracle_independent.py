@@ -148,10 +148,17 @@ def gmres(a, pc, side, b, x0, restart, tol, max_iters):     # gmres.rs:216-402
     iterations, final_residual, converged = 0, beta, False
     n_outer = -(-max_iters // restart)                       # div_ceil :231
     iteration = 0
-    for _ in range(n_outer):
+    res0_in = res0                                           # what the in-cycle test divides by (the extension below changes it)
+    for outer in range(n_outer):
         v, zb = [], []
         r0_norm = beta
-        if side == "left" and pc is not None:                # :239-246
+        if side == "left_textbook" and pc is not None:       # LABELLED EXTENSION, not in the reference (written from Saad's Alg. 9.4 in the
+            z0 = pc.apply(r0)                                # reference's frame, without looking at the C oracle): v0 = M^-1 r0 / ||M^-1 r0||
+            r0_norm = norm(z0)
+            v.append([zi / r0_norm for zi in z0])
+            if outer == 0:
+                res0_in = r0_norm
+        elif side == "left" and pc is not None:              # :239-246
             v0 = [ri / r0_norm for ri in r0]
             v.append(v0)
             zb.append(pc.apply(v0))
@@ -192,6 +199,13 @@ def gmres(a, pc, side, b, x0, restart, tol, max_iters):     # gmres.rs:216-402
                 vj1 = [wi / h[j + 1][j] for wi in w2]
                 v.append(vj1)
                 zb.append(pc.apply(vj1))
+            elif side == "left_textbook" and pc is not None:     # extension: z = M^-1 A v_j against V; breakdown handled as arnoldi does
+                z = mgs2(pc.apply(matvec(a, v[j])), v, h, j)
+                h[j + 1][j] = norm(z)
+                if abs(h[j + 1][j]) < EPS:
+                    happy = True
+                else:
+                    v.append([zi / h[j + 1][j] for zi in z])
             else:                                            # arnoldi :65-105: the rotation still runs after a happy breakdown
                 w = mgs2(matvec(a, v[j]), v, h, j)
                 h[j + 1][j] = norm(w)
@@ -201,7 +215,7 @@ def gmres(a, pc, side, b, x0, restart, tol, max_iters):     # gmres.rs:216-402
                     v.append([wi / h[j + 1][j] for wi in w])
             givens(h, g, cs, sn, j)                          # :347
             res_norm = abs(g[j + 1])
-            rel = res_norm / res0                            # Convergence::check, convergence.rs:18-34
+            rel = res_norm / res0_in                         # Convergence::check, convergence.rs:18-34 (res0_in is res0 in the reference's arms)
             stop = rel <= tol or iteration >= max_iters
             iterations, final_residual, converged = iteration, res_norm, stop
             m = j + 1
@@ -383,7 +397,7 @@ def tridiag(n, lo, di, up):
 
 
 A4 = [[4.0, 1.0, 0.0, 0.0], [1.0, 3.0, 1.0, 0.0], [0.0, 1.0, 2.0, 1.0], [0.0, 0.0, 1.0, 3.0]]        # gmres.rs:441-450
-SIDES = {"none": O.SIDE_NONE, "left": O.SIDE_LEFT, "right": O.SIDE_RIGHT}
+SIDES = {"none": O.SIDE_NONE, "left": O.SIDE_LEFT, "right": O.SIDE_RIGHT, "left_textbook": O.SIDE_LEFT_TEXTBOOK}
 
 
 def _cases():
@@ -400,7 +414,8 @@ def _cases():
 
 
 @pytest.mark.parametrize("name,a,x_true,restart,tol,max_iters", _cases(), ids=[c[0] for c in _cases()])
-@pytest.mark.parametrize("side,pcname", [("none", None), ("left", "jacobi"), ("right", "jacobi"), ("left", "ilu0"), ("right", "ilu0")])
+@pytest.mark.parametrize("side,pcname", [("none", None), ("left", "jacobi"), ("right", "jacobi"), ("left", "ilu0"), ("right", "ilu0"),
+                                         ("left_textbook", "jacobi"), ("left_textbook", "ilu0")])
 def test_c_oracle_equals_the_independent_transcription_bitwise(name, a, x_true, restart, tol, max_iters, side, pcname):
     b = matvec(a, x_true)
     pc_py = {None: None, "jacobi": Jacobi, "ilu0": Ilu0}[pcname]
@@ -413,6 +428,30 @@ def test_c_oracle_equals_the_independent_transcription_bitwise(name, a, x_true, 
     assert (ref.iterations, ref.converged) == (its, conv), (name, side, pcname)
     assert ref.final_residual == fin, (name, side, pcname, ref.final_residual, fin)
     assert np.array_equal(ref.x, np.array(x_py)), (name, side, pcname, np.max(np.abs(ref.x - np.array(x_py))))
+
+
+def test_textbook_left_gmres_extension_properties():
+    """The labelled extension (kro_gmres side 3; Preconditioning.LeftTextbook on the device) pinned by what it must be, since the reference
+    has no such arm: (a) with the identity as preconditioner it IS the unpreconditioned solver, bit for bit (z = w, ||M^-1 r0|| = ||r0||);
+    (b) on the reference's own Left + Ilu0 integration case (tests/preconditioner_integration.rs:169-179), where the reference's Left arm
+    needs two restart cycles = 20 iterations, it converges inside the first cycle; (c) it solves every case to the tolerance."""
+    class Identity:
+        def apply(self, r):
+            return list(r)
+    for name, a, x_true, restart, tol, max_iters in _cases():
+        b = matvec(a, x_true)
+        x0 = [0.0] * len(b)
+        plain = gmres(a, None, "none", b, x0, restart, tol, max_iters)
+        ident = gmres(a, Identity(), "left_textbook", b, x0, restart, tol, max_iters)
+        assert plain == ident, name
+        for pc in (Jacobi(a), Ilu0(a)):
+            x, its, fin, conv = gmres(a, pc, "left_textbook", b, x0, restart, tol, max_iters)
+            assert conv and norm([bi - axi for axi, bi in zip(matvec(a, x), b)]) <= 10 * tol * norm(b), (name, type(pc).__name__, its, fin)
+    a = tridiag(10, -1.0, 2.0, 0.5)
+    b = matvec(a, [1.0] * 10)
+    _, its_ref, _, conv_ref = gmres(a, Ilu0(a), "left", b, [0.0] * 10, 10, 1e-12, 100)
+    _, its_txt, _, conv_txt = gmres(a, Ilu0(a), "left_textbook", b, [0.0] * 10, 10, 1e-12, 100)
+    assert conv_ref and its_ref == 20 and conv_txt and its_txt <= 10, (its_ref, its_txt)
 
 
 def test_ilu0_factors_and_apply_bitwise():
