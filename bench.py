@@ -480,8 +480,9 @@ def blas1_in_solver(K, ctx, n, solver, phase):
     shapes timed in isolation on fresh vectors (kryst_bench_streams) are kept beside them as `isolated_ms_per_launch` -- round 4 quoted only
     those, and they ran 13 % slower than the kernels inside the solve."""
     iso = blas1_streams(K, ctx, n) if solver in ("cg", "pcg") else []
-    if not phase or solver not in ("cg", "pcg") or "blas1_residual" not in phase or "blas1_direction" not in phase:
+    if not phase or solver not in ("cg", "pcg") or "blas1_residual" not in phase:
         return iso
+    # (no "blas1_direction" phase: the direction pass is inside the SpMV -- spmv_pattern_fuse_kernel -- and only the residual pass is a BLAS-1 launch)
     defer = os.environ.get("KRYST_CG_DEFER_X", "1") != "0"
     if solver == "cg":
         shapes = (("blas1_residual", "ew_kernel<CgResidualOp> (r -= alpha Ap, fused (r,r))", 3), ("blas1_direction", "ew_kernel<CgDirectionOp> (x += alpha p, p = r + beta p)", 5)) if defer else \
@@ -491,6 +492,10 @@ def blas1_in_solver(K, ctx, n, solver, phase):
                  (("blas1_residual", "ew_kernel<PcgUpdateOp> (x += alpha p, r -= alpha Ap, z = D^-1 r, fused (r,z), (r,r))", 8), ("blas1_direction", "ew_kernel<AypxDevOp> (p = z + beta p)", 3))
     out = []
     for k, (key, name, words) in enumerate(shapes):
+        if key not in phase:
+            out.append({"kernel": name, "fused_into": "spmv_pattern_fuse_kernel (x += alpha p_old and p = z + beta p_old ride on the SpMV's window fill: no launch of its own)",
+                        "isolated_ms_per_launch": iso[k]["ms_per_launch"] if solver == "cg" and k < len(iso) else None})
+            continue
         ms = phase[key]
         ach = words * 8 * n / (ms * 1e-3) / 1e9
         blk = {"kernel": name, "bound": "hbm", "bytes_per_launch": words * 8 * n, "ms_per_launch": ms, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -755,16 +760,33 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3, 
             gm = {"error": "failed on another rank"}
     nnz_loc = a.nnz
     roof_csr = roofline_csr_of(grid, nloc, nnz_loc, plain_ms, world)
+    fused_block = None
+    mine_ph = phases[rank] if phases else None
+    if solver in ("cg", "pcg") and mine_ph and "blas1_direction" not in mine_ph and "spmv" in mine_ph and enc[0] == "csr-p16":
+        # the timed loop's SpMV launch IS the fused kernel: z, p_old, x read; p_new, x, y written; one 16-bit pattern id per row
+        moved = 50 * nloc
+        ms_f = mine_ph["spmv"]
+        ach = moved / (ms_f * 1e-3) / 1e9
+        fused_block = {"bound": "hbm", "kernel": "spmv_pattern_fuse_kernel<1> (CSR-P16 staged window; the window fill forms p = z + beta p_old, stores p for its own rows and "
+                                                 "carries the deferred x += alpha p_old: direction pass + SpMV + (p,Ap) partials in one launch)",
+                       "bytes_per_launch": moved, "bytes_model": "per row: z, p_old, x read (24 B), p_new, x, y written (24 B), pattern id (2 B)",
+                       "ms_per_launch": ms_f, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                       "timed": "inside the solver's iterations (kryst_phase_timing: the `spmv` phase of the phase run)"}
     if skeleton_ms:
         alg = spmv_bytes(nloc, nnz_loc)
         roof_csr["stream_skeleton"] = {
             "kernel": "csr_skeleton_kernel (the CSR arrays streamed, x read once, y written once: SURVEY 8(d)'s bytes, no gathers / products / row sums / fold; "
                       "same arrays, same process)", "ms_per_launch": skeleton_ms, "achieved": alg / (skeleton_ms * 1e-3) / 1e9, "unit": "GB/s",
             "frac": alg / (skeleton_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_over_skeleton": plain_ms / skeleton_ms}
+    try:
+        roof_csr["placement"] = dict(a.placement_info(), note="homes tried for (row_ptr, col, val) at creation (KRYST_CSR_PLACEMENT_TRIES; default 3 beyond 4 GB of CSR "
+                                     "arrays), the traffic skeleton's ms per launch on each, the one kept")
+    except Exception:
+        pass
     settings.close()
     return {"dt": dt, "dts": dts, "dt_plain": dt_plain, "dts_plain": dts_plain, "stats": stats, "enc": enc, "nloc": nloc, "nnz_loc": nnz_loc,
             "collective_us": collective_us, "reduce_info": reduce_info, "gmres": gm,
-            "roofline": roofline_of(enc, grid, nloc, nnz_loc, spmv_ms, world, staged=a.pattern_info()["staged"]),
+            "roofline": dict(roofline_of(enc, grid, nloc, nnz_loc, spmv_ms, world, staged=a.pattern_info()["staged"]), fused_direction_spmv=fused_block),
             "roofline_csr": roof_csr,
             "blas1": blas1_in_solver(K, ctx, nloc, solver, phases[rank] if phases else None), "copy_gbs": copy_gbs, "phases": phases,
             "final_residual_plain": stats_plain.final_residual}
@@ -1131,7 +1153,7 @@ def rank_main(args, group, rank, world, dev, grid):
     # bytes) priced at those bytes, and the iterations/s of the same K iterations with that kernel (`value_sec8d`)
     roof["sec8d"] = {"kernel": rc["kernel"], "frac": rc["frac"], "achieved": rc["achieved"], "unit": "GB/s", "peak": HBM_PEAK_GBS,
                      "bytes_per_launch": rc["bytes_per_launch"], "bytes_model": rc["bytes_model"], "ms_per_launch": rc["ms_per_launch"],
-                     "traffic": rc.get("traffic"), "stream_skeleton": rc.get("stream_skeleton"),
+                     "traffic": rc.get("traffic"), "stream_skeleton": rc.get("stream_skeleton"), "placement": rc.get("placement"),
                      "value_sec8d": args.steps / m["dt_plain"], "value_unit": "iterations/s",
                      "note": "north_star's '% of HBM roofline on CSR SpMV' and the iterations/s that go with it; `roofline.frac` above prices the "
                              "default (lossless, more compact) storage form at ITS bytes"}

@@ -100,6 +100,7 @@ extern "C" {
     pub fn kryst_csr_tile_order(a: Csr, info: *mut i64) -> i32;
     pub fn kryst_csr_pattern_info(a: Csr, info: *mut i64) -> i32;
     pub fn kryst_csr_download(a: Csr, row_ptr: *mut i64, col_idx_local: *mut i32, vals: *mut f64) -> i32;
+    pub fn kryst_csr_placement_info(a: Csr, tries: *mut i32, chosen: *mut i32, skeleton_ms8: *mut f64) -> i32;
 
     pub fn kryst_spmv(a: Csr, x: Vecd, y: Vecd) -> i32;
     pub fn kryst_spmv_host(a: Csr, x: *const f64, nx: i64, y: *mut f64, ny: i64) -> i32;

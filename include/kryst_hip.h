@@ -161,6 +161,11 @@ int32_t kryst_csr_tile_order(kryst_csr_t a, int64_t* info);
  * takes that kernel now */
 int32_t kryst_csr_pattern_info(kryst_csr_t a, int64_t* info);
 int32_t kryst_csr_download(kryst_csr_t a, int64_t* row_ptr, int32_t* col_idx_local, double* vals);
+/* Measurement hook (ABI 5): where the CSR arrays live.  The same plain-CSR stream mix runs at 0.70 .. 0.76 of the HBM peak depending on where
+ * the driver put the three arrays (round 4, 512^3), so a single-rank creation may try several homes for (row_ptr, col, val) -- K =
+ * KRYST_CSR_PLACEMENT_TRIES, default 3 once the arrays exceed 4 GB, else 1 -- time the kernel's traffic skeleton on each and keep the fastest.
+ * *tries homes tried, *chosen the one kept, skeleton_ms8[8] the skeleton's milliseconds per launch on each home tried. */
+int32_t kryst_csr_placement_info(kryst_csr_t a, int32_t* tries, int32_t* chosen, double* skeleton_ms8);
 
 /* MatVec::matvec (src/core/traits.rs:4-7) == SparseMatrix::spmv (sparse.rs:56-67): y <- A x, y overwritten */
 int32_t kryst_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y);

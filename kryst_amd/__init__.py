@@ -319,6 +319,13 @@ class CsrMatrix:
         check(lib().kryst_csr_pattern_info(self.h, info))
         return {"line": info[0], "uniform_far": bool(info[1]), "interior_first": info[2], "staged": bool(info[3])}
 
+    def placement_info(self):
+        """Where the CSR arrays live (kryst_csr_placement_info): {"tries", "chosen", "skeleton_ms": [...]} of the homes tried at creation."""
+        t, c = C.c_int32(0), C.c_int32(0)
+        ms = (C.c_double * 8)()
+        check(lib().kryst_csr_placement_info(self.h, C.byref(t), C.byref(c), ms))
+        return {"tries": t.value, "chosen": c.value, "skeleton_ms": [ms[k] for k in range(t.value)]}
+
     def bench_spmv(self, x, y, fused_dots=1, reps=50):
         """Average milliseconds per launch of the SpMV kernel (HIP events on the compute stream)."""
         ms = C.c_double()

@@ -72,6 +72,7 @@ SIGNATURES = {
     "kryst_csr_destroy": (C.c_int32, [Handle]),
     "kryst_csr_shape": (C.c_int32, [Handle, c_i64p, c_i64p, c_i64p]),
     "kryst_csr_download": (C.c_int32, [Handle, c_i64p, c_i32p, c_dp]),
+    "kryst_csr_placement_info": (C.c_int32, [Handle, c_i32p, c_i32p, c_dp]),
     "kryst_spmv": (C.c_int32, [Handle, Handle, Handle]),
     "kryst_spmv_host": (C.c_int32, [Handle, c_dp, C.c_int64, c_dp, C.c_int64]),
     "kryst_csr_encoding": (C.c_int32, [Handle, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -55,6 +55,8 @@ struct kryst_csr_s {
                                     // behind the pass that writes it -- a per-iteration exchange that all ranks issue or none does
     bool halo_pushed_inline = false;            // (peer stores) the push in flight was enqueued on the compute stream itself
     const double* halo_started_for = nullptr;   // the halo exchange of this input vector is already in flight (halo_begin: a solver started it early)
+    // where the CSR arrays live (bench_streams.hip: csr_place): homes tried, the one kept, the traffic skeleton's ms on each
+    int32_t placement_tries = 1, placement_chosen = 0; double placement_ms[8] = {0};
 };
 
 namespace kr {
@@ -65,6 +67,10 @@ constexpr int KR_TMAX = 2048;
 // y <- A x on ctx->s_main.  nq = 0: plain.  nq = 1: also tile partials of sum d[i]*y[i] into partial array 0.
 // nq = 2: additionally sum y[i]*y[i] into partial array 1.  `done` (device flag) makes the launch a no-op when set.
 int32_t launch_spmv(kryst_csr_t a, const double* x, double* y, int nq, const double* dvec, const int* done);
+// CG / PCG with the direction pass inside the SpMV (spmv.hip: spmv_pattern_fuse_kernel): whether the operator can take it, and the launch
+bool spmv_can_fuse_direction(kryst_csr_t a);
+int32_t launch_spmv_fused(kryst_csr_t a, const double* z, const double* p_old, double* p_new, double* xvec, double* y, int nq,
+                          const double* alpha, const double* beta, const long long* xpend, long long it, const int* done);
 // Distributed operators: start the halo exchange of x NOW (everything enqueued on the compute stream so far is waited for, nothing
 // later) and remember it, so that the next launch_spmv(a, x, ...) does not start it again.  A solver calls it after the launch that
 // wrote the rows the neighbours need and before the launches that write the rest (send_contiguous operators only).
@@ -74,6 +80,7 @@ int32_t halo_begin(kryst_csr_t a, const double* x);
 int32_t halo_peer_setup(kryst_csr_t a);
 int32_t halo_peer_selftest(kryst_csr_t a);   // one checked exchange over the fresh mappings; agreed verdict (KRYST_OK / KRYST_UNSUPPORTED on every rank)
 void halo_peer_destroy(kryst_csr_t a);
+int32_t csr_place(kryst_csr_t a);            // KRYST_CSR_PLACEMENT_TRIES: the fastest of up to K homes for (row_ptr, col, val), by the traffic skeleton (bench_streams.hip)
 int32_t halo_default_mode(kryst_csr_t a);    // at creation: peer stores when they work on every rank, else RCCL (KRYST_HALO_MODE=rccl: RCCL)
 // the tile ranges [lo, hi) whose rows are sent to neighbours, merged and ascending (send_contiguous operators)
 void halo_send_tiles(kryst_csr_t a, std::vector<std::pair<int64_t, int64_t>>& ranges);

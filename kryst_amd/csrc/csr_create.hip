@@ -444,6 +444,7 @@ static int32_t create_local(kryst_ctx_t ctx, int64_t nrows, int64_t ncols, const
     for (int64_t i = 0; i <= nrows; ++i) rp32[i] = (int32_t)rp[i];
     for (int64_t k = 0; k < nnz; ++k) c32[k] = (int32_t)col[k];
     int32_t rc = upload_csr(a, rp32, c32, val);
+    if (rc == KRYST_OK) rc = csr_place(a);
     if (rc != KRYST_OK) { kryst_csr_destroy(a); return rc; }
     *out = a;
     return KRYST_OK;
@@ -823,6 +824,7 @@ static int32_t create_stencil7_device(kryst_ctx_t ctx, int32_t N, int32_t kind, 
         rc = agree_on_status(ctx, rc);
         if (rc == KRYST_OK) rc = halo_default_mode(a);
     }
+    if (rc == KRYST_OK && !dist) rc = csr_place(a);
     if (rc != KRYST_OK) { kryst_csr_destroy(a); return rc; }
     *out = a;
     return KRYST_OK;

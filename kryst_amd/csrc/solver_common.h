@@ -37,6 +37,8 @@ struct DevState {
     int early;               // BiCGStab: s-norm exit pending its x update
     long long xlast;         // CG / PCG with the deferred x update: the iteration that ended the solve AFTER the reference's x += alpha p
                              // (its direction pass still has to add alpha p to x; iterations count from 1, 0 = none)
+    long long xpend;         // CG / PCG with the direction pass inside the SpMV: the iteration whose x += alpha p is still owed (the fused
+                             // SpMV of iteration xpend + 1 pays it, or the flush at the end of the solve / session)
 };
 
 struct LogicCtx {

@@ -54,6 +54,7 @@ struct SolverRun {
     virtual ~SolverRun() { if (a) a->halo_started_for = nullptr; }
     virtual int32_t begin() = 0;
     virtual int32_t iterate(int64_t i) = 0;
+    virtual int32_t flush() { return KRYST_OK; }     // work a solver still owes once its last iteration has been enqueued (CG / PCG: the deferred x update)
     int32_t common_begin(int64_t hist_entries, int work_vectors) {
         KR_HIP(hipSetDevice(ctx->device));
         a->halo_started_for = nullptr;        // (an early halo start belongs to ONE solve: work vectors of later solves reuse the addresses)
@@ -73,6 +74,7 @@ struct SolverRun {
         return KRYST_OK;
     }
     int32_t end() {
+        KR_TRY(flush());
         KR_HIP(hipStreamSynchronize(ctx->s_comm));
         KR_HIP(hipStreamSynchronize(ctx->s_main));
         a->halo_started_for = nullptr;

@@ -181,6 +181,7 @@ struct CgBetaLogic {                 // cg.rs:223-284
     __device__ void run(const double* red) const {
         DevState* st = c.st;
         const long long i = st->iter + 1;
+        st->xpend = i;                                                 // (x += alpha p of this iteration, :207-209, is behind us in the reference)
         const double rsq_new = red[0];
         double res_norm;
         switch (c.norm_type) {                                         // :224-229
@@ -271,19 +272,57 @@ struct AxpyIfOp {                    // x += alpha*p, only while st->early is ra
         st2(x, i, xx.a + al * pp.a, xx.b + al * pp.b);
     }
 };
+// the x update the fused form still owes when no further fused SpMV follows (the end of a solve or session)
+struct GateXOwed {
+    const DevState* st; long long it;
+    __device__ __forceinline__ bool skip() const { return st->xpend != it; }
+};
+struct CgFlushOp {                   // x += alpha p (cg.rs:207-209 / pcg.rs:175-177) of the last enqueued iteration
+    static constexpr int NQ = 0; static constexpr const char* TAG = "CgFlush"; static constexpr int PHASE = KR_PH_BLAS1_DIRECTION;
+    const DevState* st; const double* p; double* x;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const double al = st->alpha;
+        const d2 pp = ld2(p, i), xx = ld2(x, i);
+        st2(x, i, xx.a + al * pp.a, xx.b + al * pp.b);
+    }
+};
 struct CgRun : SolverRun {
     using SolverRun::SolverRun;
     double *r = nullptr, *pp = nullptr, *ap = nullptr, *ax = nullptr;
+    double* p2 = nullptr;            // the fused form's second direction vector (p_old / p_new alternate)
+    bool fuse = false; long long fused_upto = 0;     // fused_upto: the last iteration enqueued in the fused form (its x update rides on the next one)
     int32_t begin() override {
         KR_TRY(solve_args_check(io, bv, xv));
-        KR_TRY(common_begin(prm.max_iters + 2, 4));                                               // cg.rs:117
+        // the direction pass inside the SpMV (spmv.hip: spmv_pattern_fuse_kernel) where the operator's form allows it
+        fuse = cg_defer_x() && !prm.has_radius && !prm.has_obj_target && prm.norm_type != 2 && spmv_can_fuse_direction(a);
+        KR_TRY(common_begin(prm.max_iters + 2, fuse ? 5 : 4));                                    // cg.rs:117
         KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&ap));
+        if (fuse) KR_TRY(ws.vec(&p2));
         if (prm.has_obj_target) KR_TRY(ws.vec(&ax));
         KR_TRY(residual_dot(a, bv->d, xw, r, ap, nullptr));                                       // :120-125, :127
         KR_HIP(hipMemcpyAsync(pp, r, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));      // :126
         return reduce_then<1>(ctx, nt, ws.red, CgInitLogic{lc});
     }
+    int32_t flush() override {
+        if (!fuse || fused_upto == 0) return KRYST_OK;
+        return launch_ew_gated(ctx, CgFlushOp{ws.st, pp, xw}, n, GateXOwed{ws.st, fused_upto});
+    }
     int32_t iterate(int64_t it) override {
+        if (fuse) {
+            // iteration it: [x += alpha p_old owed by iteration it - 1; p = r + beta p_old; Ap; (p, Ap)] in ONE pass, alpha, the residual pass, beta
+            if (fused_upto == it - 1 && it > 1) {
+                KR_TRY(launch_spmv_fused(a, r, pp, p2, xw, ap, 1, &ws.st->alpha, &ws.st->beta, &ws.st->xpend, (long long)it, done));
+                std::swap(pp, p2);
+            } else {
+                KR_TRY(launch_spmv(a, pp, ap, 1, pp, done));                                      // the first iteration: p = r already
+            }
+            KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgAlphaLogic{lc})));
+            if (keep_in_cache(n)) KR_TRY(launch_ew(ctx, CgResidualOp<true>{&ws.st->alpha, ap, r}, n, done));
+            else KR_TRY(launch_ew(ctx, CgResidualOp<false>{&ws.st->alpha, ap, r}, n, done));
+            KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgBetaLogic{lc})));
+            fused_upto = it;
+            return KRYST_OK;
+        }
         KR_TRY(launch_spmv(a, pp, ap, 1, pp, done));                                              // :143-144 + (p,Ap) :164
         KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgAlphaLogic{lc})));
         if (cg_defer_x() && !prm.has_radius && !prm.has_obj_target && prm.norm_type != 2) {       // x += alpha p rides on the direction pass
@@ -415,6 +454,7 @@ struct PcgBetaLogic {                // pcg.rs:188-218
     __device__ void run(const double* red) const {
         DevState* st = c.st;
         const long long i1 = st->iter + 1;                             // the reference's i + 1
+        st->xpend = i1;                                                // (x += alpha p of this iteration, :175-177, is behind us in the reference)
         const double rz_new = red[0];
         double res_norm;
         switch (c.norm_type) {                                         // :190-195
@@ -440,14 +480,18 @@ struct PcgBetaLogic {                // pcg.rs:188-218
 struct PcgRun : SolverRun {
     using SolverRun::SolverRun;
     double *r = nullptr, *z = nullptr, *pp = nullptr, *ap = nullptr;
+    double* p2 = nullptr;            // the fused form's second direction vector
     bool alias = false, jac = false;
+    bool fuse = false; long long fused_upto = 0;
     int32_t begin() override {
         KR_TRY(solve_args_check(io, bv, xv));
         // radius / obj_target are fields of PcgSolver (pcg.rs:39-41) but PcgSolver::solve never reads them: accepted, ignored
-        KR_TRY(common_begin(prm.max_iters + 2, 4));                                               // pcg.rs:117
+        fuse = cg_defer_x() && spmv_can_fuse_direction(a);                                        // (spmv.hip: spmv_pattern_fuse_kernel)
+        KR_TRY(common_begin(prm.max_iters + 2, fuse ? 5 : 4));                                    // pcg.rs:117
         alias = !pc || pc->kind == KR_PC_IDENTITY;      // z == r  (pcg.rs:130,186 clone_from / IdentityPC)
         jac = pc && pc->kind == KR_PC_JACOBI;
         KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&ap));
+        if (fuse) KR_TRY(ws.vec(&p2));
         if (alias) z = r; else KR_TRY(ws.vec(&z));
         KR_TRY(launch_spmv(a, xw, ap, 0, nullptr, nullptr));                                      // :119-124
         KR_TRY(launch_ew(ctx, SubDotOp{bv->d, ap, r}, n, nullptr));
@@ -457,9 +501,19 @@ struct PcgRun : SolverRun {
         KR_TRY(launch_ew(ctx, DotPairOp{r, z, nq_a, nq_a}, n, nullptr));
         return reduce_then<2>(ctx, nt, ws.red, PcgInitLogic{lc});
     }
+    int32_t flush() override {
+        if (!fuse || fused_upto == 0) return KRYST_OK;
+        return launch_ew_gated(ctx, CgFlushOp{ws.st, pp, xw}, n, GateXOwed{ws.st, fused_upto});
+    }
     int32_t iterate(int64_t it) override {
         const int nt_ = prm.norm_type;
-        KR_TRY(launch_spmv(a, pp, ap, 1, pp, done));                                              // :149-160
+        const bool fused_now = fuse && fused_upto == it - 1 && it > 1;
+        if (fused_now) {       // [x += alpha p_old owed by iteration it - 1; p = z + beta p_old; Ap; (p, Ap)] in one pass
+            KR_TRY(launch_spmv_fused(a, z, pp, p2, xw, ap, 1, &ws.st->alpha, &ws.st->beta, &ws.st->xpend, (long long)it, done));
+            std::swap(pp, p2);
+        } else {
+            KR_TRY(launch_spmv(a, pp, ap, 1, pp, done));                                          // :149-160
+        }
         KR_TRY((reduce_then<1>(ctx, nt, ws.red, PcgAlphaLogic{lc})));
         if (cg_defer_x()) {                                                                       // x += alpha p (:175-177) rides on the direction pass
             const bool keep = keep_in_cache(n);
@@ -476,6 +530,7 @@ struct PcgRun : SolverRun {
                 KR_TRY(launch_ew(ctx, DotPairOp{r, z, nq_a, nq_a}, n, done));                     // :188-195
             }
             KR_TRY((reduce_then<2>(ctx, nt, ws.red, PcgBetaLogic{lc})));
+            if (fuse) { fused_upto = it; return KRYST_OK; }                                       // (the direction pass is the next iteration's SpMV)
             if ((alias || jac) && keep) return launch_direction(ctx, a, CgDirectionOp<true>{ws.st, z, pp, xw}, n, ws.st, (long long)it, pp);
             return launch_direction(ctx, a, CgDirectionOp<false>{ws.st, z, pp, xw}, n, ws.st, (long long)it, pp);   // :175-177, :215-217
         }

@@ -767,6 +767,153 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_stage_kernel(const SpmvArgs
     }
 }
 
+// CG / PCG with the direction pass INSIDE the SpMV (spmv_pattern_fuse_kernel; round 5).  An iteration used to end with the
+// direction pass  x += alpha p, p = z + beta p  (5 vector words per row) and the next one began with the SpMV reading that p again.  Here the
+// staged-window kernel forms p itself: its window fill reads z and p_old instead of p and stores  z + beta p_old  -- cg.rs:274-276 /
+// pcg.rs:215-217, the same un-fused multiply and add per element, so the same bits -- into LDS; the rows the run OWNS also go to p_new in
+// memory, and the deferred  x += alpha p_old  (cg.rs:207-209) rides on the p_old values the fill holds anyway.  The far operands (rows +-
+// far_lo / far_hi away) are formed the same way from z and p_old there: a row's p_new is computed by up to three workgroups, from the same
+// operands in the same order.  p_old and p_new are DIFFERENT arrays (the solver ping-pongs): nobody reads what another workgroup writes.
+// Per row: z, p_old, x read, p_new, x, y written + the pattern id -- 50 bytes instead of 40 (direction) + 18 (SpMV), and one launch fewer.
+//   xpend == it - 1: the x update of the previous iteration is owed (always, unless the solve ended earlier and it has been paid);
+//   done: the solve has ended -- only the owed x update happens, nothing else is touched.
+struct FuseArgs { const double* z; const double* p_old; double* p_new; double* xvec; const double* alpha; const double* beta; const long long* xpend; long long it; };
+template <int NQ, int T>
+__global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs a, const FuseArgs f, const int32_t n, const int32_t far_lo, const int32_t far_hi) {
+    const bool ended = a.done && *a.done;
+    const bool owed = *f.xpend == f.it - 1;
+    if (ended && !owed) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int XS = T * KR_TILE + 2 * n + 4;                                  // staged elements (even)
+    double* xs = reinterpret_cast<double*>(smem);
+    uint2* meta = reinterpret_cast<uint2*>(xs + XS);
+    double* pval = reinterpret_cast<double*>(meta + a.npat);
+    double* red = reinterpret_cast<double*>(smem + a.pat_red_off);
+    const int t = threadIdx.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int G = a.group;
+    const int qr = (((slot / G) * 8 + xcd) * G + slot % G) * T;
+    if (qr >= a.ntiles) return;
+    const int nt = min(T, a.ntiles - qr);
+    const int q0 = qr;
+    const int32_t r0 = q0 * KR_TILE;
+    const double al = *f.alpha, be = *f.beta;
+    if (ended) {                                                             // (uniform) only x += alpha p_old is still owed, on the run's own rows
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            if (k >= nt) break;
+            const int32_t row = r0 + k * KR_TILE + 2 * t;
+            const d2 pp = ld2(f.p_old, row), xx = ld2(f.xvec, row);
+            st2(f.xvec, row, xx.a + al * pp.a, xx.b + al * pp.b);
+        }
+        return;
+    }
+    unsigned ids[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) ids[k] = k < nt ? *reinterpret_cast<const unsigned*>(a.pid + (size_t)(q0 + k) * KR_TILE + 2 * t) : 0u;
+    constexpr int NP = (T * KR_TILE + 2 * 1024 + 4 + 2 * KR_T - 1) / (2 * KR_T);
+    const int npairs = XS / 2;
+    const int32_t e0 = r0 - n - 2;                                           // element staged at xs[0] (even)
+    const int32_t xsafe = (int32_t)a.xsafe;
+    const bool inside = e0 >= 0 && e0 + XS <= xsafe && (int64_t)r0 + far_lo >= 0 && (int64_t)r0 + T * KR_TILE + far_hi <= (int64_t)xsafe;
+    const int own_lo = (n + 2) / 2, own_hi = own_lo + nt * (KR_TILE / 2);   // window pairs that are rows of this run
+    // ---- the window: p_new = z + beta p_old, formed in registers, stored to LDS; own rows also to memory, with their x update
+    v2d zz[NP], po[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int pi = t + i * KR_T;
+        zz[i].x = 0.0; zz[i].y = 0.0; po[i] = zz[i];
+        if (pi < npairs) {
+            const int32_t e = inside ? e0 + 2 * pi : min(max(e0 + 2 * pi, 0), xsafe);     // outside x: any valid pair (those operands are absent entries)
+            zz[i] = *reinterpret_cast<const v2d*>(f.z + e);
+            po[i] = *reinterpret_cast<const v2d*>(f.p_old + e);
+        }
+    }
+    v2d lo[T], hi[T];
+    {
+        v2d zl[T], pl[T], zh[T], ph[T];
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            const int64_t row = (int64_t)r0 + k * KR_TILE + 2 * t;
+            const int64_t cl = inside ? row + far_lo : min(max(row + far_lo, (int64_t)0), (int64_t)xsafe);
+            const int64_t ch = inside ? row + far_hi : min(max(row + far_hi, (int64_t)0), (int64_t)xsafe);
+            zl[k] = *reinterpret_cast<const v2d*>(f.z + cl); pl[k] = *reinterpret_cast<const v2d*>(f.p_old + cl);
+            zh[k] = *reinterpret_cast<const v2d*>(f.z + ch); ph[k] = *reinterpret_cast<const v2d*>(f.p_old + ch);
+        }
+        for (int i = t; i < a.npat; i += KR_T) meta[i] = reinterpret_cast<const uint2*>(a.pmeta)[i];
+        for (int i = t; i < a.ntab; i += KR_T) pval[i] = a.pval[i];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int pi = t + i * KR_T;
+            if (pi < npairs) {
+                v2d pn; pn.x = zz[i].x + be * po[i].x; pn.y = zz[i].y + be * po[i].y;
+                *reinterpret_cast<v2d*>(xs + 2 * pi) = pn;
+                if (pi >= own_lo && pi < own_hi) {                           // a pair of rows this run owns (never clamped: inside [0, padded n))
+                    const int32_t row = e0 + 2 * pi;
+                    st2(f.p_new, row, pn.x, pn.y);
+                    if (owed) { const d2 xx = ld2(f.xvec, row); st2(f.xvec, row, xx.a + al * po[i].x, xx.b + al * po[i].y); }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            lo[k].x = zl[k].x + be * pl[k].x; lo[k].y = zl[k].y + be * pl[k].y;
+            hi[k].x = zh[k].x + be * ph[k].x; hi[k].y = zh[k].y + be * ph[k].y;
+        }
+    }
+    __syncthreads();
+    // ---- tile after tile out of LDS (spmv_pattern_stage_kernel's arithmetic)
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        if (k >= nt) break;                                                  // (uniform)
+        const int32_t row = r0 + k * KR_TILE + 2 * t;
+        const bool va = row < a.nrows, vb = row + 1 < a.nrows;
+        const uint2 ma = va ? meta[ids[k] & 0xffffu] : make_uint2(0u, 0u), mb = vb ? meta[ids[k] >> 16] : make_uint2(0u, 0u);
+        const int j = k * KR_TILE + 2 * t + n + 2;                           // xs[j] = p_new[row]
+        const v2d A = *reinterpret_cast<const v2d*>(xs + j - 2), B = *reinterpret_cast<const v2d*>(xs + j), C = *reinterpret_cast<const v2d*>(xs + j + 2);
+        const v2d M = *reinterpret_cast<const v2d*>(xs + j - n), P = *reinterpret_cast<const v2d*>(xs + j + n);
+        v2d e[7];
+        e[0] = lo[k]; e[1] = M; e[2].x = A.y; e[2].y = B.x; e[3] = B; e[4].x = B.y; e[4].y = C.x; e[5] = P; e[6] = hi[k];
+        const double* tva = pval + (ma.x & 0xffffu); const double* tvb = pval + (mb.x & 0xffffu);
+        const unsigned ka = ma.y, kb = mb.y;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const double ta = s0 + tva[u] * e[u].x, tb = s1 + tvb[u] * e[u].y;
+            s0 = ((ka >> u) & 1u) ? ta : s0;
+            s1 = ((kb >> u) & 1u) ? tb : s1;
+        }
+        if (vb) st2(a.y, row, s0, s1);
+        else if (va) a.y[row] = s0;
+        if constexpr (NQ > 0) {
+            double acc[NQ];
+            acc[0] = 0.0;
+            if (va) acc[0] = acc[0] + B.x * s0;
+            if (vb) acc[0] = acc[0] + B.y * s1;
+            if constexpr (NQ > 1) {
+                acc[1] = 0.0;
+                if (va) acc[1] = acc[1] + s0 * s0;
+                if (vb) acc[1] = acc[1] + s1 * s1;
+            }
+#pragma unroll
+            for (int kk = 0; kk < NQ; ++kk) {
+                const double wsum = wave_butterfly(acc[kk]);
+                if ((t & 63) == 0) red[(k * NQ + kk) * (KR_T / 64) + (t >> 6)] = wsum;
+            }
+        }
+    }
+    if constexpr (NQ > 0) {
+        __syncthreads();
+        if (t < nt * NQ) {
+            const int k = t / NQ, kk = t % NQ;
+            double sum = red[t * (KR_T / 64)];
+#pragma unroll
+            for (int w2 = 1; w2 < KR_T / 64; ++w2) sum = sum + red[t * (KR_T / 64) + w2];
+            a.partials[kk * a.pstride + q0 + k] = sum;
+        }
+    }
+}
+
 // CSR-DIA (spmv_dia_kernel): operators with a handful of well-filled diagonals -- every stencil on a structured grid, variable
 // coefficients included.  The values are stored as one stream per diagonal in natural row order (csr_create.hip: build_dia), an
 // absent entry carries a NaN payload no stored value may have, so there are NO row pointers, NO per-entry codes and no
@@ -1340,6 +1487,46 @@ int32_t halo_begin(kryst_csr_t a, const double* x) {
                          pl.recv_off.data(), true, ctx->s_comm));
     KR_HIP(hipEventRecord(ctx->ev_halo_done, ctx->s_comm));
     a->halo_started_for = x;
+    return KRYST_OK;
+}
+
+// Can the operator take the fused form (spmv_pattern_fuse_kernel)?  A single-rank stencil operator in its CSR-P16 form whose bases are all
+// (far, -n, -1, 0, +1, +n, far) with the same far offsets everywhere -- what launch_tiles would hand to spmv_pattern_stage_kernel<.., UFAR>.
+bool spmv_can_fuse_direction(kryst_csr_t a) {
+    return !a->dist && a->d_pid && a->pat_stage_n > 0 && a->pat_far_uniform && a->npat <= 512 && a->ntab <= 512 && a->nrows == a->xlen &&
+           takes_pattern_path(a, false) && env_int("KRYST_SPMV_STAGE", 1) != 0 && env_int("KRYST_SPMV_STAGE_UFAR", 1) != 0 &&
+           a->xlen + 2 * KR_TILE < (1ll << 31) && env_int("KRYST_CG_FUSE_P", 1) != 0;
+}
+// y = A p_new with p_new = z + beta p_old formed on the way (stored to p_new), the owed x += alpha p_old on the same pass, partial (p_new, y)
+// [and (y, y)] -- see spmv_pattern_fuse_kernel.  `done`, alpha, beta, xpend: device scalars of the solve; it: the iteration being enqueued.
+int32_t launch_spmv_fused(kryst_csr_t a, const double* z, const double* p_old, double* p_new, double* xvec, double* y, int nq,
+                          const double* alpha, const double* beta, const long long* xpend, long long it, const int* done) {
+    kryst_ctx_t ctx = a->ctx;
+    KR_ARG(spmv_can_fuse_direction(a) && nq >= 1 && nq <= 2, "launch_spmv_fused: operator cannot take the fused form");
+    KR_TRY(ensure_partials(ctx, a->ntiles));
+    SpmvArgs args;
+    memset(&args, 0, sizeof args);
+    args.x = p_new; args.y = y; args.ntiles = (int32_t)a->ntiles; args.nrows = (int32_t)a->nrows; args.nloc = (int32_t)a->nrows;
+    args.dvec = p_new; args.partials = ctx->d_partials; args.pstride = ctx->partials_cap; args.done = done;
+    args.pid = a->d_pid; args.pmeta = a->d_pmeta; args.poff = a->d_poff; args.pval = a->d_pval; args.npat = a->npat; args.ntab = a->ntab;
+    const int T = env_int("KRYST_SPMV_FUSE_T", 2) <= 2 ? 2 : 4;
+    const int32_t n_ = a->pat_stage_n;
+    const size_t xs_bytes = sizeof(double) * (size_t)(T * KR_TILE + 2 * n_ + 4);
+    const size_t tab = xs_bytes + (size_t)a->npat * 8 + (size_t)a->ntab * 8;
+    args.pat_red_off = (int32_t)((tab + 15) & ~(size_t)15);
+    const size_t lds_s = (size_t)args.pat_red_off + sizeof(double) * (size_t)T * (size_t)nq * (KR_T / 64);
+    args.xsafe = (a->xlen + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE - 2;
+    const int64_t nruns = (a->ntiles + T - 1) / T;
+    args.group = std::max(1, env_int("KRYST_SPMV_STAGE_GROUP", nruns >= 2048 ? 4 : 1));
+    const int64_t per_xcd = ((nruns + 7) / 8 + args.group - 1) / args.group * args.group;
+    const dim3 sgrid((unsigned)(per_xcd * 8)), block(KR_T);
+    const FuseArgs f{z, p_old, p_new, xvec, alpha, beta, xpend, it};
+#define KR_FUSE(NQ_) do { if (T == 2) hipLaunchKernelGGL((spmv_pattern_fuse_kernel<NQ_, 2>), sgrid, block, lds_s, ctx->s_main, args, f, n_, a->pat_far_lo, a->pat_far_hi); \
+                          else hipLaunchKernelGGL((spmv_pattern_fuse_kernel<NQ_, 4>), sgrid, block, lds_s, ctx->s_main, args, f, n_, a->pat_far_lo, a->pat_far_hi); } while (0)
+    if (nq == 1) KR_FUSE(1); else KR_FUSE(2);
+#undef KR_FUSE
+    KR_HIP(hipGetLastError());
+    phase_mark(ctx, KR_PH_SPMV);
     return KRYST_OK;
 }
 

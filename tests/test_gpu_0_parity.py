@@ -308,6 +308,35 @@ def test_spmv_pattern_kernel_with_staged_window_bit_exact(ctx, rs, monkeypatch):
 
 
 @pytest.mark.parametrize("slots", ["2", "4", "7"])
+
+def test_csr_placement_tries_keep_the_operator_bit_exact(ctx, monkeypatch):
+    """KRYST_CSR_PLACEMENT_TRIES (bench_streams.hip: csr_place): the creation copies (row_ptr, col, val) to further homes, times the traffic
+    skeleton on each and keeps the fastest -- whichever home wins, the operator is the same: plain-CSR SpMV, download and a CG solve bit for bit,
+    through kryst_csr_create and through the device generator."""
+    monkeypatch.setenv("KRYST_CSR_PLACEMENT_TRIES", "4")
+    monkeypatch.setenv("KRYST_SPMV_COMPRESS", "0")
+    rng = np.random.default_rng(77)
+    T, V, F = K.reduce_spec()
+    rs = O.Reduce.tiled(T, V, F)
+    for ao, make in ((O.stencil7(24, "convdiff"), lambda: K.CsrMatrix.stencil7(24, "convdiff", ctx=ctx)),
+                     (random_csr_fast(rng, 20000, 20000, 8), None)):
+        a = make() if make else to_dev(ctx, ao)
+        info = a.placement_info()
+        assert info["tries"] == 4 and 0 <= info["chosen"] < 4 and len(info["skeleton_ms"]) == 4 and all(m > 0 for m in info["skeleton_ms"]), info
+        x = rng.standard_normal(ao.ncols)
+        assert np.array_equal(a.spmv(x), ao.spmv(x))
+        rp, ci, va = a.download()
+        assert np.array_equal(rp, ao.row_ptr) and np.array_equal(ci, ao.col_idx) and np.array_equal(va, ao.vals)
+    ao = O.stencil7(24, "poisson"); a = K.CsrMatrix.stencil7(24, "poisson", ctx=ctx)
+    b = ao.spmv(np.ones(ao.nrows))
+    res = O.solve("cg", ao, b, tol=1e-9, max_iters=300, rs=rs)
+    s = K.CgSolver(1e-9, 300); xx = np.zeros(ao.nrows)
+    st = s.solve(a, None, b, xx)
+    assert st.iterations == res.iterations and np.array_equal(xx, res.x) and np.array_equal(np.array(s.residual_history), res.history)
+    monkeypatch.setenv("KRYST_CSR_PLACEMENT_TRIES", "1")
+    assert K.CsrMatrix.stencil7(12, "poisson", ctx=ctx).placement_info()["tries"] == 1
+
+
 @pytest.mark.parametrize("nt,align", [("0", "0"), ("1", "0"), ("1", "1")])
 def test_spmv_plain_kernel_settings_bit_exact(ctx, slots, nt, align, monkeypatch):
     """spmv_wave_kernel with every window size (the launcher picks 7 or 4 pair slots by vector size), nontemporal stream loads
