@@ -307,8 +307,6 @@ def test_spmv_pattern_kernel_with_staged_window_bit_exact(ctx, rs, monkeypatch):
         assert np.array_equal(ag.spmv(x), ao.spmv(x)), (N, kind)
 
 
-@pytest.mark.parametrize("slots", ["2", "4", "7"])
-
 def test_csr_placement_tries_keep_the_operator_bit_exact(ctx, monkeypatch):
     """KRYST_CSR_PLACEMENT_TRIES (bench_streams.hip: csr_place): the creation copies (row_ptr, col, val) to further homes, times the traffic
     skeleton on each and keeps the fastest -- whichever home wins, the operator is the same: plain-CSR SpMV, download and a CG solve bit for bit,
@@ -337,6 +335,7 @@ def test_csr_placement_tries_keep_the_operator_bit_exact(ctx, monkeypatch):
     assert K.CsrMatrix.stencil7(12, "poisson", ctx=ctx).placement_info()["tries"] == 1
 
 
+@pytest.mark.parametrize("slots", ["2", "4", "7"])
 @pytest.mark.parametrize("nt,align", [("0", "0"), ("1", "0"), ("1", "1")])
 def test_spmv_plain_kernel_settings_bit_exact(ctx, slots, nt, align, monkeypatch):
     """spmv_wave_kernel with every window size (the launcher picks 7 or 4 pair slots by vector size), nontemporal stream loads
