@@ -778,14 +778,15 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_stage_kernel(const SpmvArgs
 //   xpend == it - 1: the x update of the previous iteration is owed (always, unless the solve ended earlier and it has been paid);
 //   done: the solve has ended -- only the owed x update happens, nothing else is touched.
 struct FuseArgs { const double* z; const double* p_old; double* p_new; double* xvec; const double* alpha; const double* beta; const long long* xpend; long long it; };
-template <int NQ, int T>
+// NMAX: the line length the instance is built for (the window's pairs per lane are a compile-time count): 512 or 1024
+template <int NQ, int T, int NMAX>
 __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs a, const FuseArgs f, const int32_t n, const int32_t far_lo, const int32_t far_hi) {
     const bool ended = a.done && *a.done;
     const bool owed = *f.xpend == f.it - 1;
     if (ended && !owed) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int XS = T * KR_TILE + 2 * n + 4;                                  // staged elements (even)
-    double* xs = reinterpret_cast<double*>(smem);
+    double* xs = reinterpret_cast<double*>(smem);                            // p_old's window, overwritten in place by p_new's
     uint2* meta = reinterpret_cast<uint2*>(xs + XS);
     double* pval = reinterpret_cast<double*>(meta + a.npat);
     double* red = reinterpret_cast<double*>(smem + a.pat_red_off);
@@ -811,24 +812,46 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs 
     unsigned ids[T];
 #pragma unroll
     for (int k = 0; k < T; ++k) ids[k] = k < nt ? *reinterpret_cast<const unsigned*>(a.pid + (size_t)(q0 + k) * KR_TILE + 2 * t) : 0u;
-    constexpr int NP = (T * KR_TILE + 2 * 1024 + 4 + 2 * KR_T - 1) / (2 * KR_T);
+    constexpr int NP = (T * KR_TILE + 2 * NMAX + 4 + 2 * KR_T - 1) / (2 * KR_T);   // pairs per lane at most (n <= NMAX)
     const int npairs = XS / 2;
     const int32_t e0 = r0 - n - 2;                                           // element staged at xs[0] (even)
     const int32_t xsafe = (int32_t)a.xsafe;
     const bool inside = e0 >= 0 && e0 + XS <= xsafe && (int64_t)r0 + far_lo >= 0 && (int64_t)r0 + T * KR_TILE + far_hi <= (int64_t)xsafe;
     const int own_lo = (n + 2) / 2, own_hi = own_lo + nt * (KR_TILE / 2);   // window pairs that are rows of this run
-    // ---- the window: p_new = z + beta p_old, formed in registers, stored to LDS; own rows also to memory, with their x update
-    v2d zz[NP], po[NP];
+    // ---- the window: p_old straight into LDS (LDS-DMA, lane t's pairs t + 256 i land where lane t reads them back), z into registers
+    const int wbase = __builtin_amdgcn_readfirstlane(t & ~63);
+    v2d zz[NP], xo[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int pi = t + i * KR_T;
-        zz[i].x = 0.0; zz[i].y = 0.0; po[i] = zz[i];
+        zz[i].x = 0.0; zz[i].y = 0.0; xo[i] = zz[i];
         if (pi < npairs) {
             const int32_t e = inside ? e0 + 2 * pi : min(max(e0 + 2 * pi, 0), xsafe);     // outside x: any valid pair (those operands are absent entries)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(f.p_old + e),
+                                             (__attribute__((address_space(3))) void*)(xs + 2 * (i * KR_T + wbase)), 16, 0, 0);
             zz[i] = *reinterpret_cast<const v2d*>(f.z + e);
-            po[i] = *reinterpret_cast<const v2d*>(f.p_old + e);
+            if (owed && pi >= own_lo && pi < own_hi) xo[i] = *reinterpret_cast<const v2d*>(f.xvec + e);      // (own rows are never clamped)
         }
     }
+    for (int i = t; i < a.npat; i += KR_T) meta[i] = reinterpret_cast<const uint2*>(a.pmeta)[i];
+    for (int i = t; i < a.ntab; i += KR_T) pval[i] = a.pval[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's share of the window has landed (the compiler does not count LDS-DMA requests)
+    // p_new = z + beta p_old (cg.rs:274-276 / pcg.rs:215-217, un-fused multiply and add), in place; own rows also to memory, with their x update
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int pi = t + i * KR_T;
+        if (pi < npairs) {
+            const v2d po = *reinterpret_cast<const v2d*>(xs + 2 * pi);
+            v2d pn; pn.x = zz[i].x + be * po.x; pn.y = zz[i].y + be * po.y;
+            *reinterpret_cast<v2d*>(xs + 2 * pi) = pn;
+            if (pi >= own_lo && pi < own_hi) {
+                const int32_t row = e0 + 2 * pi;
+                st2(f.p_new, row, pn.x, pn.y);
+                if (owed) st2(f.xvec, row, xo[i].x + al * po.x, xo[i].y + al * po.y);
+            }
+        }
+    }
+    // the far operands of every tile of the run, formed the same way from z and p_old there (requested now: in flight across the barrier)
     v2d lo[T], hi[T];
     {
         v2d zl[T], pl[T], zh[T], ph[T];
@@ -840,28 +863,13 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs 
             zl[k] = *reinterpret_cast<const v2d*>(f.z + cl); pl[k] = *reinterpret_cast<const v2d*>(f.p_old + cl);
             zh[k] = *reinterpret_cast<const v2d*>(f.z + ch); ph[k] = *reinterpret_cast<const v2d*>(f.p_old + ch);
         }
-        for (int i = t; i < a.npat; i += KR_T) meta[i] = reinterpret_cast<const uint2*>(a.pmeta)[i];
-        for (int i = t; i < a.ntab; i += KR_T) pval[i] = a.pval[i];
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int pi = t + i * KR_T;
-            if (pi < npairs) {
-                v2d pn; pn.x = zz[i].x + be * po[i].x; pn.y = zz[i].y + be * po[i].y;
-                *reinterpret_cast<v2d*>(xs + 2 * pi) = pn;
-                if (pi >= own_lo && pi < own_hi) {                           // a pair of rows this run owns (never clamped: inside [0, padded n))
-                    const int32_t row = e0 + 2 * pi;
-                    st2(f.p_new, row, pn.x, pn.y);
-                    if (owed) { const d2 xx = ld2(f.xvec, row); st2(f.xvec, row, xx.a + al * po[i].x, xx.b + al * po[i].y); }
-                }
-            }
-        }
+        __syncthreads();                                                     // every wave's p_new pairs are in LDS
 #pragma unroll
         for (int k = 0; k < T; ++k) {
             lo[k].x = zl[k].x + be * pl[k].x; lo[k].y = zl[k].y + be * pl[k].y;
             hi[k].x = zh[k].x + be * ph[k].x; hi[k].y = zh[k].y + be * ph[k].y;
         }
     }
-    __syncthreads();
     // ---- tile after tile out of LDS (spmv_pattern_stage_kernel's arithmetic)
 #pragma unroll
     for (int k = 0; k < T; ++k) {
@@ -1495,7 +1503,10 @@ int32_t halo_begin(kryst_csr_t a, const double* x) {
 bool spmv_can_fuse_direction(kryst_csr_t a) {
     return !a->dist && a->d_pid && a->pat_stage_n > 0 && a->pat_far_uniform && a->npat <= 512 && a->ntab <= 512 && a->nrows == a->xlen &&
            takes_pattern_path(a, false) && env_int("KRYST_SPMV_STAGE", 1) != 0 && env_int("KRYST_SPMV_STAGE_UFAR", 1) != 0 &&
-           a->xlen + 2 * KR_TILE < (1ll << 31) && env_int("KRYST_CG_FUSE_P", 1) != 0;
+           a->xlen + 2 * KR_TILE < (1ll << 31) &&
+           // measured (profiles/r05/cg_fuse_ab.jsonl, cg_fuse_sweep.jsonl): fewer bytes only pay where the vectors do not live in the 256 MiB Infinity
+           // Cache anyway -- 512^3 CG +3.5 % (PCG +3.3 %), 256^3 -5 %, 128^3 -4 %.  KRYST_CG_FUSE_P = 1 / 0 forces the fused / unfused form.
+           env_int("KRYST_CG_FUSE_P", a->nrows * 8 > env_ll("KRYST_CG_FUSE_MIN_BYTES", 256ll << 20) ? 1 : 0) != 0;
 }
 // y = A p_new with p_new = z + beta p_old formed on the way (stored to p_new), the owed x += alpha p_old on the same pass, partial (p_new, y)
 // [and (y, y)] -- see spmv_pattern_fuse_kernel.  `done`, alpha, beta, xpend: device scalars of the solve; it: the iteration being enqueued.
@@ -1509,22 +1520,38 @@ int32_t launch_spmv_fused(kryst_csr_t a, const double* z, const double* p_old, d
     args.x = p_new; args.y = y; args.ntiles = (int32_t)a->ntiles; args.nrows = (int32_t)a->nrows; args.nloc = (int32_t)a->nrows;
     args.dvec = p_new; args.partials = ctx->d_partials; args.pstride = ctx->partials_cap; args.done = done;
     args.pid = a->d_pid; args.pmeta = a->d_pmeta; args.poff = a->d_poff; args.pval = a->d_pval; args.npat = a->npat; args.ntab = a->ntab;
-    const int T = env_int("KRYST_SPMV_FUSE_T", 2) <= 2 ? 2 : 4;
+    const int T = env_int("KRYST_SPMV_FUSE_T", 4) <= 2 ? 2 : 4;     // runs of 4 tiles: the window's halo (2 n + 4 elements) is read for 2 048 rows instead of 1 024
     const int32_t n_ = a->pat_stage_n;
     const size_t xs_bytes = sizeof(double) * (size_t)(T * KR_TILE + 2 * n_ + 4);
     const size_t tab = xs_bytes + (size_t)a->npat * 8 + (size_t)a->ntab * 8;
     args.pat_red_off = (int32_t)((tab + 15) & ~(size_t)15);
-    const size_t lds_s = (size_t)args.pat_red_off + sizeof(double) * (size_t)T * (size_t)nq * (KR_T / 64);
+    size_t lds_s = (size_t)args.pat_red_off + sizeof(double) * (size_t)T * (size_t)nq * (KR_T / 64);
+    // resident workgroups per CU: like the BLAS-1 streams (ew.h: 2-3 workgroups per CU keep DRAM pages open, 8 lose a sixth of the bandwidth) this
+    // kernel is a mix of read and write streams; the dynamic LDS request is padded so that only `wgcu` workgroups fit a CU's 160 KiB
+    const int wgcu = env_int("KRYST_SPMV_FUSE_WG_PER_CU", 0);
+    if (wgcu > 0) lds_s = std::max(lds_s, std::min<size_t>((size_t)(160 << 10) / (size_t)wgcu - 512, (size_t)64 << 10));
     args.xsafe = (a->xlen + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE - 2;
     const int64_t nruns = (a->ntiles + T - 1) / T;
     args.group = std::max(1, env_int("KRYST_SPMV_STAGE_GROUP", nruns >= 2048 ? 4 : 1));
     const int64_t per_xcd = ((nruns + 7) / 8 + args.group - 1) / args.group * args.group;
     const dim3 sgrid((unsigned)(per_xcd * 8)), block(KR_T);
     const FuseArgs f{z, p_old, p_new, xvec, alpha, beta, xpend, it};
-#define KR_FUSE(NQ_) do { if (T == 2) hipLaunchKernelGGL((spmv_pattern_fuse_kernel<NQ_, 2>), sgrid, block, lds_s, ctx->s_main, args, f, n_, a->pat_far_lo, a->pat_far_hi); \
-                          else hipLaunchKernelGGL((spmv_pattern_fuse_kernel<NQ_, 4>), sgrid, block, lds_s, ctx->s_main, args, f, n_, a->pat_far_lo, a->pat_far_hi); } while (0)
+    if (lds_s > ((size_t)48 << 10)) {       // (more than the default dynamic LDS limit: once per instance)
+        static bool raised = false;
+        if (!raised) {
+            for (const void* fn : {(const void*)spmv_pattern_fuse_kernel<1, 2, 512>, (const void*)spmv_pattern_fuse_kernel<1, 2, 1024>, (const void*)spmv_pattern_fuse_kernel<1, 4, 512>,
+                                   (const void*)spmv_pattern_fuse_kernel<1, 4, 1024>, (const void*)spmv_pattern_fuse_kernel<2, 2, 512>, (const void*)spmv_pattern_fuse_kernel<2, 2, 1024>,
+                                   (const void*)spmv_pattern_fuse_kernel<2, 4, 512>, (const void*)spmv_pattern_fuse_kernel<2, 4, 1024>})
+                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
+            raised = true;
+        }
+    }
+#define KR_FUSE_N(NQ_, T_) do { if (n_ <= 512) hipLaunchKernelGGL((spmv_pattern_fuse_kernel<NQ_, T_, 512>), sgrid, block, lds_s, ctx->s_main, args, f, n_, a->pat_far_lo, a->pat_far_hi); \
+                                else hipLaunchKernelGGL((spmv_pattern_fuse_kernel<NQ_, T_, 1024>), sgrid, block, lds_s, ctx->s_main, args, f, n_, a->pat_far_lo, a->pat_far_hi); } while (0)
+#define KR_FUSE(NQ_) do { if (T == 2) KR_FUSE_N(NQ_, 2); else KR_FUSE_N(NQ_, 4); } while (0)
     if (nq == 1) KR_FUSE(1); else KR_FUSE(2);
 #undef KR_FUSE
+#undef KR_FUSE_N
     KR_HIP(hipGetLastError());
     phase_mark(ctx, KR_PH_SPMV);
     return KRYST_OK;

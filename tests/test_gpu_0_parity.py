@@ -1202,6 +1202,57 @@ def test_deferred_x_update_on_every_exit_path(ctx, rs, defer_x, monkeypatch):
             assert np.array_equal(xs.to_host(), res.x), (method, k)
 
 
+@pytest.mark.parametrize("fuse", ["1", "0"])
+@pytest.mark.parametrize("N,kind,T", [(10, "aniso", "2"), (16, "poisson", "2"), (16, "poisson", "4"), (32, "convdiff", "2"), (40, "poisson", "4")])
+def test_direction_pass_inside_the_spmv_on_every_exit_path(ctx, rs, fuse, N, kind, T, monkeypatch):
+    """Round 5: on stencil operators in their staged CSR-P16 form CG / PCG form p = z + beta p_old INSIDE the next iteration's SpMV
+    (spmv.hip: spmv_pattern_fuse_kernel) and the deferred x += alpha p rides on the same pass -- two direction vectors alternate, the x
+    update of iteration k is paid by the fused SpMV of iteration k + 1 or, when none follows, by a flush at the end.  KRYST_CG_FUSE_P=0 is
+    the unfused form.  Both must leave iteration counts, histories and x as the oracle does on every way out: convergence (the device runs
+    ahead of the host: fused SpMVs enqueued behind the final iteration must pay the owed update exactly once), the iteration cap (1, 2, 3,
+    8 -- the flush), an initial guess, Jacobi / identity / ILU preconditioners, stepping sessions in several steps, runs of 2 and of 4 tiles,
+    grids whose last run is partial."""
+    monkeypatch.setenv("KRYST_CG_FUSE_P", fuse); monkeypatch.setenv("KRYST_SPMV_FUSE_T", T)
+    a = O.stencil7(N, kind)
+    d = K.CsrMatrix.stencil7(N, kind, ctx=ctx) if N % 4 == 0 else to_dev(ctx, a)
+    assert d.encoding()[0] == "csr-p16" and d.pattern_info()["staged"]
+    b = O.splitmix64_uniform(0xD0E + N, a.nrows)
+    x0 = O.splitmix64_uniform(0xABC, a.nrows)
+    sym = kind != "convdiff"
+    pcs = [("cg", K.CgSolver, None, None), ("pcg", K.PcgSolver, O.Pc.jacobi(a), K.Jacobi().setup(d)), ("pcg", K.PcgSolver, None, None),
+           ("pcg", K.PcgSolver, O.Pc.identity(), K.IdentityPc().setup(d))]
+    if N <= 16:
+        pcs.append(("pcg", K.PcgSolver, O.Pc.ilu0_true(a), K.TrueIlu0().setup(d)))
+    for cap in (1, 2, 3, 8, 400):
+        for name, cls, opc, kpc in pcs:
+            res = O.solve(name, a, b, pc=opc, x0=x0, tol=1e-9, max_iters=cap, rs=rs, raise_on_error=False)
+            s = cls(1e-9, cap); x = x0.copy()
+            try:
+                st, code = s.solve(d, kpc, b, x), 0
+            except K.KError as e:                           # (the unsymmetric operator: IndefiniteMatrix / IndefinitePreconditioner must match too)
+                st, code = e.stats, e.code
+            assert code == res.code, (name, cap, code, res.code)
+            _check_solver(res, st, s, x, exact=(code == 0))
+    if sym:
+        for method, opc, kpc in (("cg", None, None), ("pcg", O.Pc.jacobi(a), K.Jacobi().setup(d))):
+            for steps in ((1,), (2, 1), (3, 4), (1, 1, 1, 5)):
+                k = sum(steps)
+                res = O.solve(method, a, b, pc=opc, tol=1e-30, max_iters=k, rs=rs)
+                xs, bs = K.DeviceVec(ctx, np.zeros(a.nrows)), K.DeviceVec(ctx, b)
+                with K.Session(method, d, kpc, bs, xs, tol=1e-30, max_iters=1000) as sess:
+                    for q in steps:
+                        sess.step(q)
+                    st = sess.end()
+                assert st.iterations == k and np.array_equal(xs.to_host(), res.x) and np.array_equal(np.array(sess.residual_history), res.history), (method, steps)
+        # a session that converges in the middle of a step: the iterations enqueued behind the last one must not touch x again
+        res = O.solve("cg", a, b, tol=1e-6, max_iters=1000, rs=rs)
+        xs, bs = K.DeviceVec(ctx, np.zeros(a.nrows)), K.DeviceVec(ctx, b)
+        with K.Session("cg", d, None, bs, xs, tol=1e-6, max_iters=1000) as sess:
+            sess.step(res.iterations + 7)
+            st = sess.end()
+        assert st.iterations == res.iterations and st.converged and np.array_equal(xs.to_host(), res.x)
+
+
 def test_pcg_with_chebyshev_extension_bit_exact(ctx, rs):
     a = O.stencil7(10)
     b = a.spmv(np.ones(a.nrows))
