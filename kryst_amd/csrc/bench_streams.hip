@@ -176,6 +176,75 @@ __global__ __launch_bounds__(KR_T) void csr_skeleton_kernel(const int32_t* __res
 }
 }  // namespace kr
 
+// ---- EXPERIMENT (round 5): the same bytes as ONE stream.  The plain kernel's skeleton reads two matrix streams that advance at different rates
+// (8 B and 4 B per entry) plus row pointers, x and y; a read-only stream of the same size runs 10-20 % faster on this HBM.  Here the entries are
+// addressed in CHUNKS of 256: chunk c = 256 column indices (1 KiB) followed by 256 values (2 KiB), 3 KiB apart -- one sequential stream of
+// 12 bytes per entry.  Traffic only (the buffer's contents are not looked at); `packed` must hold 3072 * ceil((nnz + 8) / 256) bytes.
+namespace kr {
+template <bool NT>
+__global__ __launch_bounds__(KR_T) void csr_skeleton_packed_kernel(const int32_t* __restrict__ rp, const char* __restrict__ packed,
+                                                                   const double* __restrict__ x, double* __restrict__ y, int64_t n, int64_t ntiles) {
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    const int64_t q = blockIdx.x;
+    if (q >= ntiles) return;
+    const int64_t r0 = q * KR_TILE, r1 = r0 + KR_TILE < n ? r0 + KR_TILE : n;
+    const int64_t ri = r0 + 2 * t < n ? r0 + 2 * t : ((n - 1) & ~(int64_t)1);
+    const sk_u2 mine = *reinterpret_cast<const sk_u2*>(rp + ri);
+    unsigned acc = mine.x ^ mine.y;
+    const int64_t k0 = (int64_t)rp[r0] & ~(int64_t)1, k1 = rp[r1];
+    const int64_t wq = (((k1 - k0 + 3) / 4) + 1) & ~(int64_t)1;
+    const int64_t e0 = k0 + w * wq, e1 = e0 + wq < k1 ? e0 + wq : k1;
+    for (int64_t off = e0; off < e1; off += 4 * 128) {
+        sk_u4 v[4]; sk_u2 c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t k = off + u * 128 + 2 * l;
+            v[u] = sk_u4{0u, 0u, 0u, 0u}; c[u] = sk_u2{0u, 0u};
+            if (k < e1) {
+                const char* chunk = packed + (k >> 8) * 3072;
+                const sk_u2* pc = reinterpret_cast<const sk_u2*>(chunk + (k & 255) * 4);
+                const sk_u4* pv = reinterpret_cast<const sk_u4*>(chunk + 1024 + (k & 255) * 8);
+                v[u] = NT ? __builtin_nontemporal_load(pv) : *pv;
+                c[u] = NT ? __builtin_nontemporal_load(pc) : *pc;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w ^ c[u].x ^ c[u].y;
+    }
+    const sk_u4 xv = *reinterpret_cast<const sk_u4*>(x + r0 + 2 * t);
+    acc ^= xv.x ^ xv.w;
+    sk_u4 yv; yv.x = acc; yv.y = (unsigned)t; yv.z = 0u; yv.w = 1u;
+    __builtin_nontemporal_store(yv, reinterpret_cast<sk_u4*>(y + r0 + 2 * t));
+}
+}  // namespace kr
+extern "C" int32_t kryst_debug_csr_skeleton_packed(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t reps, double* avg_ms) {
+    KR_ARG(a && x && y && avg_ms && reps >= 1 && !a->dist && a->nrows == a->xlen && a->d_row_ptr, "debug_csr_skeleton_packed");
+    kryst_ctx_t ctx = a->ctx;
+    KR_HIP(hipSetDevice(ctx->device));
+    const int64_t nt = ntiles_of(a->nrows);
+    char* packed = nullptr;
+    const size_t bytes = (size_t)3072 * (size_t)((a->nnz + 8 + 255) / 256 + 1);
+    KR_HIP(hipMalloc(&packed, bytes));
+    KR_HIP(hipMemsetAsync(packed, 0, bytes, ctx->s_main));
+    const bool nontemporal = a->nrows * 8 > (256ll << 20);
+    auto once = [&] {
+        if (nontemporal) hipLaunchKernelGGL((csr_skeleton_packed_kernel<true>), dim3((unsigned)nt), dim3(KR_T), 0, ctx->s_main, a->d_row_ptr, packed, x->d, y->d, a->nrows, nt);
+        else hipLaunchKernelGGL((csr_skeleton_packed_kernel<false>), dim3((unsigned)nt), dim3(KR_T), 0, ctx->s_main, a->d_row_ptr, packed, x->d, y->d, a->nrows, nt);
+    };
+    once();
+    (void)hipEventRecord(ctx->tm0, ctx->s_main);
+    for (int r = 0; r < reps; ++r) once();
+    (void)hipEventRecord(ctx->tm1, ctx->s_main);
+    (void)hipEventSynchronize(ctx->tm1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ctx->tm0, ctx->tm1);
+    *avg_ms = (double)ms / reps;
+    (void)hipStreamSynchronize(ctx->s_main);
+    (void)hipFree(packed);
+    KR_HIP(hipGetLastError());
+    return KRYST_OK;
+}
+
 // ---- where the CSR arrays live (KRYST_CSR_PLACEMENT_TRIES, csr.h: csr_place).  Round 4 measured that the SAME plain-CSR stream mix runs at 0.70 to
 // 0.76 of peak depending on where the driver put the operator's three arrays (profiles/r04/plain_csr_placement_with_skeleton_512.txt: six
 // instances in one process, the skeleton itself 2.28 .. 2.50 ms at 512^3) -- a property of the allocation, not of the kernel.  With K > 1 the
