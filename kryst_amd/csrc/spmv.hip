@@ -811,7 +811,7 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs 
     }
     unsigned ids[T];
 #pragma unroll
-    for (int k = 0; k < T; ++k) ids[k] = k < nt ? *reinterpret_cast<const unsigned*>(a.pid + (size_t)(q0 + k) * KR_TILE + 2 * t) : 0u;
+    for (int k = 0; k < T; ++k) ids[k] = k < nt ? __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(a.pid + (size_t)(q0 + k) * KR_TILE + 2 * t)) : 0u;   // (read once: not in the way of z / p_old in L2)
     constexpr int NP = (T * KR_TILE + 2 * NMAX + 4 + 2 * KR_T - 1) / (2 * KR_T);   // pairs per lane at most (n <= NMAX)
     const int npairs = XS / 2;
     const int32_t e0 = r0 - n - 2;                                           // element staged at xs[0] (even)
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(f.p_old + e),
                                              (__attribute__((address_space(3))) void*)(xs + 2 * (i * KR_T + wbase)), 16, 0, 0);
             zz[i] = *reinterpret_cast<const v2d*>(f.z + e);
-            if (owed && pi >= own_lo && pi < own_hi) xo[i] = *reinterpret_cast<const v2d*>(f.xvec + e);      // (own rows are never clamped)
+            if (owed && pi >= own_lo && pi < own_hi) xo[i] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(f.xvec + e));      // (own rows are never clamped; read once)
         }
     }
     for (int i = t; i < a.npat; i += KR_T) meta[i] = reinterpret_cast<const uint2*>(a.pmeta)[i];
