@@ -1,39 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- CG iterations/sec + SpMV GB/s against the HBM roofline on synthetic 3-D 7-point Poisson CSR.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1 started PLAINLY (no WORLD_SIZE in the environment): this process launches N rank processes of itself, one per GPU (self_launch below);
+        under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* set) it is one rank.
 
-A "step" is ONE iteration of the reference's unpreconditioned CG (src/solver/cg.rs:141-285: SpMV + 2 inner products + 3
-vector updates) on a matrix, right-hand side and iterate that are already resident in HBM.  W warm-up iterations and exactly
-K timed iterations run inside one stepping session (tol = 0, so the device never stops early); the timed region is bracketed
-by barrier + device synchronize on both sides and the maximum over ranks is reported.  One JSON line on rank 0.
+A "step" is ONE iteration of the reference's unpreconditioned CG (src/solver/cg.rs:141-285: SpMV + 2 inner products + 3 vector updates) on a matrix,
+right-hand side and iterate that are already resident in HBM.  W warm-up iterations and three batches of exactly K timed iterations run inside one
+stepping session (tol = 0, so the device never stops early); every batch is bracketed by device synchronize + barrier on both sides, the maximum over
+ranks is taken per batch and the MEDIAN batch is the headline.  One JSON line on rank 0.  (--solver pcg / gmres: Jacobi-PCG / GMRES(30) + Jacobi.)
 
-Workload: ONE fixed 512^3 system for every N (BASELINE.json's metric is quoted on 256^3 / 512^3; north_star asks for strong
-scaling of CG iterations/sec on 512^3, which fits a single 288 GB GPU).  N > 1: row-partitioned in k-slabs over the ranks, halo
-planes over xGMI, inner products by RCCL all-gather.
+Workload: ONE fixed 512^3 system for every N (BASELINE.json's metric is quoted on 256^3 / 512^3; north_star asks for strong scaling of CG iterations/sec
+on 512^3, which fits a single 288 GB GPU).  N > 1: row-partitioned in k-slabs over the ranks, halo planes and inner products over xGMI (hipIpc peer
+stores / mailboxes where a checked test transfer succeeds on every rank, else RCCL; the line says which).
 
 What the line holds (every `frac` is bytes the named kernel really moves / its HIP-event time / 8 TB/s, so it is <= 1):
   value             CG iterations/s with the operator in its default (most compact lossless) storage form
-  value_plain_csr   the same K iterations with KRYST_SPMV_COMPRESS=0: the 12-bytes-per-entry CSR arrays are streamed, which is
-                    what every matrix that is not a constant-coefficient stencil gets
-  roofline          the SpMV kernel of the timed loop (fused (p,Ap) partials): bytes it moves (model; PMC `traffic` beside it --
-                    at N = 1 measured by this very command for the 512^3 forms, two rocprofv3 --pmc passes per form in child
-                    processes; otherwise from profiles/spmv_traffic.json when that was measured on this very source tree;
-                    `traffic_source` says which), `algorithmic_*` = SURVEY 8(d)'s CSR bytes for comparison (a re-encoded
-                    operator moves fewer)
-  roofline_csr      the plain-CSR kernel on SURVEY 8(d)'s bytes: north_star's "% of HBM roofline on CSR SpMV"
-  roofline_blas1    the two vector kernels of a CG iteration
+  value_sec8d       the same K iterations with KRYST_SPMV_COMPRESS=0 (= value_plain_csr): the 12-bytes-per-entry CSR arrays of SURVEY 8(d) are streamed,
+                    which is what every matrix that is not a constant-coefficient stencil gets -- the figure comparable to north_star
+  roofline          the SpMV kernel of the default form, priced at the bytes IT streams (PMC `traffic` beside it -- at N = 1 measured by this very command,
+                    two rocprofv3 --pmc passes per form in child processes).  Inside it:
+                      roofline.sec8d                 the plain-CSR kernel on SURVEY 8(d)'s bytes (north_star's "% of HBM roofline on CSR SpMV"), its traffic
+                                                     skeleton on the same arrays, the homes tried for the arrays, value_sec8d
+                      roofline.fused_direction_spmv  the kernel the timed loop really launches when CG's direction pass rides inside the SpMV
+  roofline_blas1    the vector kernels of a CG iteration, timed INSIDE the solver's iterations (phase run)
+  gmres30_jacobi    GMRES(30) Left + Jacobi on the same operator and partition: iterations/s of solves of exactly 60 iterations (north_star: CG / GMRES at 1-8 GPUs)
   phase_ms          device time per iteration by phase (hipEvents between the phases, a separate short run), per rank
+  scalar_reduce     (N > 1) which transport carried the inner products and the halo in `value`, every form's figure, the library's defaults
   config1_256       (N = 1) the same measurements on BASELINE configs[1]'s 256^3 grid, with the CPU port timed on that grid
-  config3_gmres30_jacobi_256, config5_bicgstab_ilu0_256, config4_jacobi_pcg_512
-                    (N = 1) the other BASELINE configs on one GPU: iterations/s of the solve to the config's tolerance (configs 3, 5)
-                    or of a fixed number of stepped iterations (config 4), each with the roofline block of ITS dominant kernel
-                    (Gram-Schmidt link; triangular solve -- priced at the bytes it moves, SURVEY 8(d)'s bytes labelled beside it)
-  variable_coefficient_256 / _512
-                    (N = 1) a 7-point operator with per-edge random coefficients (kind "varcoef"): neither CSR-P16 / D16 nor the
-                    triangular solve's chunk dedup apply -- SpMV form / ms / fraction, CG iterations/s, ILU(0) apply ms
-  cpu_baseline      the oracle's CG timed on the host cores AT the workload's size (512^3 when host memory allows, else the
-                    256^3 sample scaled and marked "extrapolated": true)
+  config3_gmres30_jacobi_256 (three GMRES forms with their true residuals), config5_bicgstab_ilu0_256, config4_jacobi_pcg_512, variable_coefficient_256 / _512,
+  general_ilu       (N = 1) the other BASELINE configs and operators the encodings do not apply to, each with the roofline block of ITS dominant kernel
+  cpu_baseline      the oracle's CG timed on the host cores AT the workload's size (16 threads and all allowed CPUs, the CPU named); parity_at_size: its
+                    iterations compared with the GPU bit for bit
 """
 import argparse
 import json
