@@ -743,7 +743,7 @@ int32_t ipc_reduce_selftest(kryst_ctx_t ctx) {
                hipStreamSynchronize(ctx->s_main) != hipSuccess)) { (void)hipGetLastError(); ok = 0; }
     if (ok) {
         const LogicCtx lc{st, nullptr, ctx->d_prog, red, 0.0, 1ll, 0, 0ll, 0};
-        const IpcView v{ctx->ipc_mine, ctx->d_ipc_peers, ctx->d_ipc_epoch, ctx->rank, P, 1 << 21};
+        const IpcView v{ctx->ipc_mine, ctx->d_ipc_peers, ctx->d_ipc_epoch, ctx->rank, P, 1 << 24};     // (short by the solvers' standards -- 2^26 -- yet long enough for peers that time-slice one GPU in the tests)
         hipLaunchKernelGGL((fold_ipc_logic_kernel<1, IpcSelfTestLogic>), dim3(1), dim3(KR_F), 0, ctx->s_main,
                            ctx->d_partials, ctx->partials_cap, (int64_t)1, ctx->d_chunks, ctx->chunks_cap, fold_ticket(ctx), fold_err(ctx), red, IpcSelfTestLogic{lc}, v);
         DevState h;
