@@ -73,6 +73,10 @@ hipError_t pool_free(void* p) {
     // under a kernel that still uses it either
     const hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) { (void)hipGetLastError(); return hipFree(p); }
+    // test hook (KRYST_DEV_POOL_POISON=1): a pooled block is handed out again UNCLEARED, so whatever a set-up reads it must have written itself --
+    // the tests fill every block that enters the pool with 0xFF bytes (NaNs as doubles, -1 as indices)
+    static const bool poison = [] { const char* e = getenv("KRYST_DEV_POOL_POISON"); return e && atoi(e) != 0; }();
+    if (poison && (hipMemset(p, 0xFF, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) (void)hipGetLastError();
     std::lock_guard<std::mutex> g(P->mu);
     if (P->pooled + bytes > pool_cap_bytes()) return hipFree(p);
     P->free_blocks.emplace(bytes, p); P->pooled += bytes;

@@ -28,6 +28,10 @@ def pytest_collection_modifyitems(session, config, items):
 # Every -m gpu test therefore starts with NaNs in every compute unit's LDS (kryst_bench_poison_lds) and in 4 GB of just-freed device memory.
 import pytest
 
+# ... and every device block that enters the library's pool of destroyed ILU preconditioners' storage is filled with 0xFF bytes (NaNs / -1) before the
+# next set-up is handed it uncleared (ctx.cpp: pool_free; read once per process, so it is set before the library loads -- child processes inherit it)
+os.environ.setdefault("KRYST_DEV_POOL_POISON", "1")
+
 _poison_ctx = None
 
 

@@ -1107,6 +1107,38 @@ def test_ilu_apply_twice_reuses_graph(ctx):
         assert np.array_equal(pc.apply(r), ref.apply(r))
 
 
+def test_refactoring_reuses_pooled_device_blocks_and_trim_returns_them(ctx):
+    """Preconditioner::setup is called per matrix, repeatedly (ilup.rs:77-134): the device blocks of a destroyed ILU-family preconditioner go to
+    the context's size-keyed pool and the next set-up of the same operator takes them back -- blocks that are NOT cleared in between, so every
+    byte a set-up relies on must be written by it (tests/conftest.py sets KRYST_DEV_POOL_POISON: every block that enters the pool is filled with
+    0xFF bytes); kryst_ctx_trim gives the pool back."""
+    import os
+    assert os.environ.get("KRYST_DEV_POOL_POISON") == "1"
+    rng = np.random.default_rng(21)
+    ctx.trim()
+    cases = [(O.stencil7(40, "aniso"), lambda: K.CsrMatrix.stencil7(40, "aniso", ctx=ctx)),      # 7-point grid: device set-up, blocked layouts (> 1 MiB blocks)
+             (random_csr_fast(rng, 60000, 60000, 9), None)]                                      # general operator: level-ordered factors, operand streams
+    for ao, make in cases:
+        if make is None:                                                                        # (a diagonally dominant copy: the factorisation must not break down)
+            import scipy.sparse as sp
+            m = sp.csr_matrix((ao.vals, ao.col_idx, ao.row_ptr), shape=(ao.nrows, ao.ncols))
+            m = (m - sp.diags(m.diagonal()) + sp.diags(np.asarray(abs(m).sum(axis=1)).ravel() + 1.0)).tocsr(); m.sort_indices()
+            ao = O.Csr(m.shape[0], m.shape[1], m.indptr, m.indices, m.data)
+        a = make() if make else to_dev(ctx, ao)
+        r = rng.standard_normal(ao.nrows)
+        ref = O.Pc.ilu0_true(ao).apply(r)
+        for round_ in range(3):
+            pc = K.TrueIlu0().setup(a)
+            assert np.array_equal(pc.apply(r), ref), round_
+            del pc                                                                              # (its blocks go to the pool, poisoned)
+        freed = ctx.trim()
+        assert freed > 0, "nothing was pooled"
+        pc = K.TrueIlu0().setup(a)                                                              # and after the trim: fresh blocks, same bits
+        assert np.array_equal(pc.apply(r), ref)
+        del pc
+    assert ctx.trim() >= 0
+
+
 # ------------------------------------------------------------------------------------------------ solvers
 def _check_solver(res, stats, solver, x, exact=True):
     assert stats.iterations == res.iterations and stats.converged == res.converged
