@@ -107,6 +107,7 @@ extern "C" {
     pub fn kryst_bench_spmv(a: Csr, x: Vecd, y: Vecd, fused_dots: i32, reps: i32, avg_ms: *mut f64) -> i32;
     pub fn kryst_bench_streams(ctx: Ctx, n: i64, stride_bytes: i64, kind: i32, reps: i32, avg_ms: *mut f64) -> i32;
     pub fn kryst_bench_csr_skeleton(a: Csr, x: Vecd, y: Vecd, reps: i32, avg_ms: *mut f64) -> i32;
+    pub fn kryst_bench_spmv_fused(a: Csr, x: Vecd, y: Vecd, reps: i32, avg_ms: *mut f64) -> i32;
     pub fn kryst_bench_poison_lds(ctx: Ctx) -> i32;
 
     pub fn kryst_dot(x: Vecd, y: Vecd, out: *mut f64) -> i32;

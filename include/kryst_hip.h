@@ -184,6 +184,9 @@ int32_t kryst_bench_streams(kryst_ctx_t ctx, int64_t n, int64_t stride_bytes, in
  * column indices streamed, x read once, y written once (SURVEY 8(d)'s bytes; y receives garbage): what this mix of five read streams and
  * one written reaches on this HBM, for `roofline_csr`'s "fraction of what the mix can reach" (bench.py: stream_skeleton) */
 int32_t kryst_bench_csr_skeleton(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t reps, double* avg_ms);
+/* measurement only (ABI 5): average ms per launch of the kernel CG / PCG launch when the direction pass rides inside the SpMV (cg.rs:207-209,274-276 +
+ * sparse.rs:107-113 in one pass: z = x, p_old, x-update vectors of its own); KRYST_UNSUPPORTED when the operator has no staged CSR-P16 form */
+int32_t kryst_bench_spmv_fused(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t reps, double* avg_ms);
 /* test hook: fills the LDS of every compute unit with NaNs.  LDS is not cleared between kernels, so whatever a kernel reads from LDS
  * before writing it is what an earlier kernel -- of any process -- left there; a round-4 kernel did, and was wrong on one GPU box in five */
 int32_t kryst_bench_poison_lds(kryst_ctx_t ctx);

@@ -332,6 +332,16 @@ class CsrMatrix:
         check(lib().kryst_bench_spmv(self.h, x.h, y.h, fused_dots, reps, C.byref(ms)))
         return ms.value
 
+    def bench_spmv_fused(self, x, y, reps=20):
+        """Average milliseconds per launch of the fused direction + SpMV kernel of CG / PCG (kryst_bench_spmv_fused); None when the operator
+        cannot take that form."""
+        ms = C.c_double()
+        rc = lib().kryst_bench_spmv_fused(self.h, x.h, y.h, reps, C.byref(ms))
+        if rc == 6:
+            return None
+        check(rc)
+        return ms.value
+
     def halo_mode(self, mode):
         """'rccl' | 'peer' | 'query': how this row-partitioned operator's halo exchange travels (kryst_csr_halo_mode; collective except
         'query').  Returns the mode in use: 'peer' falls back to 'rccl' on every rank when a landing buffer cannot be exported / mapped or

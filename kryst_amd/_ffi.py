@@ -81,6 +81,7 @@ SIGNATURES = {
     "kryst_bench_spmv": (C.c_int32, [Handle, Handle, Handle, C.c_int32, C.c_int32, c_dp]),
     "kryst_bench_streams": (C.c_int32, [Handle, C.c_int64, C.c_int64, C.c_int32, C.c_int32, c_dp]),
     "kryst_bench_csr_skeleton": (C.c_int32, [Handle, Handle, Handle, C.c_int32, c_dp]),
+    "kryst_bench_spmv_fused": (C.c_int32, [Handle, Handle, Handle, C.c_int32, c_dp]),
     "kryst_bench_poison_lds": (C.c_int32, [Handle]),
     "kryst_dot": (C.c_int32, [Handle, Handle, c_dp]),
     "kryst_norm": (C.c_int32, [Handle, c_dp]),

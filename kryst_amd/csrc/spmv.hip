@@ -827,7 +827,11 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs 
     for (int i = 0; i < NP; ++i) {
         const int pi = t + i * KR_T;
         zz[i].x = 0.0; zz[i].y = 0.0; xo[i] = zz[i];
+#ifdef KR_TUNING
+        if (pi < npairs && (!(a.abl & 2) || (pi >= own_lo && pi < own_hi))) {   // abl 2 (timing only): the window's halo is not loaded
+#else
         if (pi < npairs) {
+#endif
             const int32_t e = inside ? e0 + 2 * pi : min(max(e0 + 2 * pi, 0), xsafe);     // outside x: any valid pair (those operands are absent entries)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(f.p_old + e),
                                              (__attribute__((address_space(3))) void*)(xs + 2 * (i * KR_T + wbase)), 16, 0, 0);
@@ -848,8 +852,11 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs 
             *reinterpret_cast<v2d*>(xs + 2 * pi) = pn;
             if (pi >= own_lo && pi < own_hi) {
                 const int32_t row = e0 + 2 * pi;
-                st2(f.p_new, row, pn.x, pn.y);
-                if (owed) st2(f.xvec, row, xo[i].x + al * po.x, xo[i].y + al * po.y);
+#ifdef KR_TUNING
+                if (a.abl & 8) { if (pn.x == 1.23456789e-300) st2(f.p_new, row, pn.x, pn.y); } else      // abl 8 (timing only): no p_new / x stores
+#endif
+                { st2(f.p_new, row, pn.x, pn.y);
+                if (owed) st2(f.xvec, row, xo[i].x + al * po.x, xo[i].y + al * po.y); }
             }
         }
     }
@@ -862,6 +869,9 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs 
             const int64_t row = (int64_t)r0 + k * KR_TILE + 2 * t;
             const int64_t cl = inside ? row + far_lo : min(max(row + far_lo, (int64_t)0), (int64_t)xsafe);
             const int64_t ch = inside ? row + far_hi : min(max(row + far_hi, (int64_t)0), (int64_t)xsafe);
+#ifdef KR_TUNING
+            if (a.abl & 1) { zl[k].x = (double)cl; zl[k].y = 1.0; pl[k] = zl[k]; zh[k].x = (double)ch; zh[k].y = 2.0; ph[k] = zh[k]; continue; }   // abl 1 (timing only): no far operands
+#endif
             zl[k] = *reinterpret_cast<const v2d*>(f.z + cl); pl[k] = *reinterpret_cast<const v2d*>(f.p_old + cl);
             zh[k] = *reinterpret_cast<const v2d*>(f.z + ch); ph[k] = *reinterpret_cast<const v2d*>(f.p_old + ch);
         }
@@ -893,8 +903,11 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs 
             s0 = ((ka >> u) & 1u) ? ta : s0;
             s1 = ((kb >> u) & 1u) ? tb : s1;
         }
-        if (vb) st2(a.y, row, s0, s1);
-        else if (va) a.y[row] = s0;
+#ifdef KR_TUNING
+        if (a.abl & 4) { if (s0 == 1.23456789e-300) a.y[row] = s0; } else      // abl 4 (timing only): no y traffic
+#endif
+        { if (vb) st2(a.y, row, s0, s1);
+        else if (va) a.y[row] = s0; }
         if constexpr (NQ > 0) {
             double acc[NQ];
             acc[0] = 0.0;
@@ -1512,10 +1525,16 @@ bool spmv_can_fuse_direction(kryst_csr_t a) {
 }
 // y = A p_new with p_new = z + beta p_old formed on the way (stored to p_new), the owed x += alpha p_old on the same pass, partial (p_new, y)
 // [and (y, y)] -- see spmv_pattern_fuse_kernel.  `done`, alpha, beta, xpend: device scalars of the solve; it: the iteration being enqueued.
+static int32_t launch_spmv_fused_impl(kryst_csr_t a, const double* z, const double* p_old, double* p_new, double* xvec, double* y, int nq,
+                                      const double* alpha, const double* beta, const long long* xpend, long long it, const int* done, bool force);
 int32_t launch_spmv_fused(kryst_csr_t a, const double* z, const double* p_old, double* p_new, double* xvec, double* y, int nq,
                           const double* alpha, const double* beta, const long long* xpend, long long it, const int* done) {
+    return launch_spmv_fused_impl(a, z, p_old, p_new, xvec, y, nq, alpha, beta, xpend, it, done, false);
+}
+static int32_t launch_spmv_fused_impl(kryst_csr_t a, const double* z, const double* p_old, double* p_new, double* xvec, double* y, int nq,
+                                      const double* alpha, const double* beta, const long long* xpend, long long it, const int* done, bool force) {
     kryst_ctx_t ctx = a->ctx;
-    KR_ARG(spmv_can_fuse_direction(a) && nq >= 1 && nq <= 2, "launch_spmv_fused: operator cannot take the fused form");
+    KR_ARG((force || spmv_can_fuse_direction(a)) && nq >= 1 && nq <= 2, "launch_spmv_fused: operator cannot take the fused form");
     KR_TRY(ensure_partials(ctx, a->ntiles));
     SpmvArgs args;
     memset(&args, 0, sizeof args);
@@ -1538,6 +1557,9 @@ int32_t launch_spmv_fused(kryst_csr_t a, const double* z, const double* p_old, d
     const int64_t per_xcd = ((nruns + 7) / 8 + args.group - 1) / args.group * args.group;
     const dim3 sgrid((unsigned)(per_xcd * 8)), block(KR_T);
     const FuseArgs f{z, p_old, p_new, xvec, alpha, beta, xpend, it};
+#ifdef KR_TUNING
+    args.abl = env_int("KRYST_FUSE_ABL", 0);          // timing-only ablations (tuning builds; wrong results)
+#endif
     if (lds_s > ((size_t)48 << 10)) {       // (more than the default dynamic LDS limit: once per instance)
         static bool raised = false;
         if (!raised) {
@@ -1719,6 +1741,44 @@ int32_t kryst_bench_spmv(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t fu
     (void)hipStreamSynchronize(ctx->s_main);
     if (use_collectives(ctx)) (void)hipStreamSynchronize(ctx->s_comm);
     for (int k = 1; k < 3; ++k) if (xs[k] != x->d) (void)hipFree(xs[k]);
+    return rc;
+}
+
+// Measurement hook: average milliseconds per launch of the fused direction + SpMV kernel of CG / PCG (spmv_pattern_fuse_kernel) on work vectors of its
+// own: z = x, p_old = a copy of x, alpha = 1e-3, beta = 0.5, the x update owed at every launch; p_old / p_new alternate like in the solver.
+// KRYST_UNSUPPORTED when the operator cannot take the fused form.
+int32_t kryst_bench_spmv_fused(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t reps, double* avg_ms) {
+    KR_ARG(a && x && y && avg_ms && reps >= 1, "bench_spmv_fused");
+    KR_ARG(x->n == a->xlen && y->n == a->nrows && x->ctx == a->ctx && y->ctx == a->ctx, "bench_spmv_fused: size / context mismatch");
+    kryst_ctx_t ctx = a->ctx;
+    KR_HIP(hipSetDevice(ctx->device));
+    if (!(!a->dist && a->d_pid && a->pat_stage_n > 0 && a->pat_far_uniform && a->npat <= 512 && a->ntab <= 512 && a->nrows == a->xlen && takes_pattern_path(a, false))) {
+        set_error("bench_spmv_fused: the operator has no staged CSR-P16 form with uniform far offsets");
+        return KRYST_UNSUPPORTED;
+    }
+    const size_t bytes = sizeof(double) * (size_t)((x->n + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE);
+    double *p[2] = {nullptr, nullptr}, *xv = nullptr, *sc = nullptr;
+    int32_t rc = KRYST_OK;
+    if (hipMalloc(&p[0], bytes) != hipSuccess || hipMalloc(&p[1], bytes) != hipSuccess || hipMalloc(&xv, bytes) != hipSuccess || hipMalloc(&sc, 64) != hipSuccess) rc = KRYST_ERR_HIP;
+    const double host_sc[4] = {1e-3, 0.5, 0.0, 0.0};                 // alpha, beta, xpend (as a long long 0), pad
+    if (rc == KRYST_OK && (hipMemcpyAsync(p[0], x->d, bytes, hipMemcpyDeviceToDevice, ctx->s_main) != hipSuccess || hipMemsetAsync(p[1], 0, bytes, ctx->s_main) != hipSuccess ||
+                           hipMemsetAsync(xv, 0, bytes, ctx->s_main) != hipSuccess || hipMemcpyAsync(sc, host_sc, sizeof host_sc, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess ||
+                           hipStreamSynchronize(ctx->s_main) != hipSuccess)) rc = KRYST_ERR_HIP;
+    const long long* xpend = reinterpret_cast<const long long*>(sc + 2);
+    auto once = [&](int r) { return launch_spmv_fused_impl(a, x->d, p[r & 1], p[(r + 1) & 1], xv, y->d, 1, sc, sc + 1, xpend, 1ll, nullptr, true); };
+    if (rc == KRYST_OK) rc = once(0);
+    if (rc == KRYST_OK) {
+        (void)hipEventRecord(ctx->tm0, ctx->s_main);
+        for (int r = 1; r <= reps && rc == KRYST_OK; ++r) rc = once(r);
+        (void)hipEventRecord(ctx->tm1, ctx->s_main);
+        (void)hipEventSynchronize(ctx->tm1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ctx->tm0, ctx->tm1);
+        *avg_ms = (double)ms / reps;
+    }
+    (void)hipStreamSynchronize(ctx->s_main);
+    (void)hipFree(p[0]); (void)hipFree(p[1]); (void)hipFree(xv); (void)hipFree(sc);
+    if (rc == KRYST_ERR_HIP) set_error("bench_spmv_fused: allocation or copy failed");
     return rc;
 }
 
