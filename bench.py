@@ -723,7 +723,7 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3, 
         mine = {k: v / phase_iters for k, v in ph.items() if v > 0.0}
         mine["total"] = sum(mine.values())
         # "blas1" = every vector update of the iteration (its residual and direction passes are listed on their own as well)
-        mine["blas1"] = mine.get("blas1", 0.0) + mine.get("blas1_residual", 0.0) + mine.get("blas1_direction", 0.0)
+        mine["blas1"] = mine.get("blas1", 0.0) + mine.get("blas1_residual", 0.0) + mine.get("blas1_direction", 0.0) + mine.get("blas1_xbatch", 0.0)
         phases = group.gather(mine)
     # N > 1: what one scalar collective costs end to end (local value -> RCCL all-gather -> rank-ordered fold -> host), so that the
     # first real multi-GPU run says how much of an iteration the two inner-product exchanges can be at most
@@ -761,15 +761,26 @@ def measure(K, ctx, group, grid, solver, warmup, steps, phase_iters, batches=3, 
     fused_block = None
     mine_ph = phases[rank] if phases else None
     if solver in ("cg", "pcg") and mine_ph and "blas1_direction" not in mine_ph and "spmv" in mine_ph and enc[0] == "csr-p16":
-        # the timed loop's SpMV launch IS the fused kernel: z, p_old, x read; p_new, x, y written; one 16-bit pattern id per row
-        moved = 50 * nloc
+        # the timed loop's SpMV launch IS the fused kernel: z, p_old [, x] read; p_new [, x], y written; one 16-bit pattern id per row.  With x updated
+        # in batches (phase "blas1_xbatch" present) x is not touched here: XBatchOp applies x += alpha_i p_i for m iterations in one pass.
+        xbatched = "blas1_xbatch" in mine_ph
+        moved = (34 if xbatched else 50) * nloc
         ms_f = mine_ph["spmv"]
         ach = moved / (ms_f * 1e-3) / 1e9
-        fused_block = {"bound": "hbm", "kernel": "spmv_pattern_fuse_kernel<1> (CSR-P16 staged window; the window fill forms p = z + beta p_old, stores p for its own rows and "
-                                                 "carries the deferred x += alpha p_old: direction pass + SpMV + (p,Ap) partials in one launch)",
-                       "bytes_per_launch": moved, "bytes_model": "per row: z, p_old, x read (24 B), p_new, x, y written (24 B), pattern id (2 B)",
+        fused_block = {"bound": "hbm", "kernel": "spmv_pattern_fuse_kernel<1> (CSR-P16 staged window; the window fill forms p = z + beta p_old and stores p for its own rows"
+                                                 + ("" if xbatched else ", carries the deferred x += alpha p_old") + ": direction pass + SpMV + (p,Ap) partials in one launch)",
+                       "bytes_per_launch": moved, "bytes_model": "per row: z, p_old read (16 B), p_new, y written (16 B), pattern id (2 B)" if xbatched else
+                                                                 "per row: z, p_old, x read (24 B), p_new, x, y written (24 B), pattern id (2 B)",
                        "ms_per_launch": ms_f, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                        "timed": "inside the solver's iterations (kryst_phase_timing: the `spmv` phase of the phase run)"}
+        if xbatched:
+            m = int(os.environ.get("KRYST_CG_X_BATCH", "8" if solver == "cg" else "7"))
+            launches = max(1, len([i for i in range(3, phase_iters + 3) if i % m == 0]))      # the phase run covers iterations 3 .. phase_iters + 2
+            ms_x = mine_ph["blas1_xbatch"] * phase_iters / launches
+            fused_block["x_batch"] = {"kernel": f"ew_kernel<XBatchOp> (x += alpha_i p_i for {m} iterations in one pass: x read and written once, {m} direction vectors read)",
+                                      "iterations_per_launch": m, "bytes_per_launch": (m + 2) * 8 * nloc, "ms_per_launch": ms_x,
+                                      "achieved": (m + 2) * 8 * nloc / (ms_x * 1e-3) / 1e9, "unit": "GB/s", "frac": (m + 2) * 8 * nloc / (ms_x * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "ms_per_iteration": ms_x / m}
     if skeleton_ms:
         alg = spmv_bytes(nloc, nnz_loc)
         roof_csr["stream_skeleton"] = {
@@ -1218,7 +1229,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-256", action="store_true", help="skip the config1_256 block (N = 1 measures BASELINE configs[1]'s 256^3 grid too)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs and the variable-coefficient blocks (N = 1)")
-    ap.add_argument("--phase-iters", type=int, default=20, help="iterations of the per-phase timing run (0: skip)")
+    ap.add_argument("--phase-iters", type=int, default=56, help="iterations of the per-phase timing run (0: skip)")
     ap.add_argument("--launcher", default="auto", choices=["auto", "torch", "socket"],
                     help="N > 1 plumbing for the RCCL id / barrier: torch.distributed gloo (default) or kryst_amd/launch.py (no torch)")
     ap.add_argument("--ranks-per-process", type=int, default=1,

@@ -106,7 +106,7 @@ int32_t kryst_ctx_trim(kryst_ctx_t ctx, int64_t* bytes_released);
  * without halo columns; single rank: the whole SpMV), "halo_wait" (compute stream waiting for the neighbour planes),
  * "spmv_boundary", "reduce" (tile-partial fold + RCCL all-gather + rank-ordered fold + scalar step), "blas1" (vector updates other than
  * the next two), "pc", "blas1_residual" (CG / PCG: r -= alpha Ap with its fused inner products), "blas1_direction" (CG / PCG: x += alpha p,
- * p = z + beta p). */
+ * p = z + beta p), "blas1_xbatch" (CG / PCG with the direction pass inside the SpMV: x += alpha_i p_i for a batch of iterations in one pass). */
 int32_t kryst_phase_timing_begin(kryst_ctx_t ctx);
 int32_t kryst_phase_timing_end(kryst_ctx_t ctx, double* ms, int32_t count);
 int32_t kryst_phase_count(void);

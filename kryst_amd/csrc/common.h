@@ -96,6 +96,7 @@ enum { KR_PH_SPMV = 0,          // SpMV tiles that need no halo (single rank: th
        KR_PH_PC,                // preconditioner apply
        KR_PH_BLAS1_RESIDUAL,    // CG / PCG: r -= alpha Ap with the fused (r,r) [, z = D^-1 r, (r,z)]   (CgResidualOp / PcgResidualOp / the eager forms)
        KR_PH_BLAS1_DIRECTION,   // CG / PCG: x += alpha p, p = z + beta p                                (CgDirectionOp / AypxDevOp)
+       KR_PH_BLAS1_XBATCH,      // CG / PCG with x updated in batches: x += alpha_i p_i for the last m iterations in one pass    (XBatchOp)
        KR_PH_COUNT };
 struct PhaseTimer {
     std::vector<std::pair<int, hipEvent_t>> marks;      // (phase, event recorded after it); phase -1: the start mark

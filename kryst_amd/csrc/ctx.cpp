@@ -315,7 +315,7 @@ int32_t kryst_phase_timing_end(kryst_ctx_t ctx, double* ms, int32_t count) {
 int32_t kryst_phase_count(void) { return KR_PH_COUNT; }
 
 const char* kryst_phase_name(int32_t phase) {
-    static const char* names[KR_PH_COUNT] = {"spmv", "halo_wait", "spmv_boundary", "reduce", "blas1", "pc", "blas1_residual", "blas1_direction"};
+    static const char* names[KR_PH_COUNT] = {"spmv", "halo_wait", "spmv_boundary", "reduce", "blas1", "pc", "blas1_residual", "blas1_direction", "blas1_xbatch"};
     return (phase >= 0 && phase < KR_PH_COUNT) ? names[phase] : "";
 }
 

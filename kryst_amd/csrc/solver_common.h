@@ -39,6 +39,7 @@ struct DevState {
                              // (its direction pass still has to add alpha p to x; iterations count from 1, 0 = none)
     long long xpend;         // CG / PCG with the direction pass inside the SpMV: the iteration whose x += alpha p is still owed (the fused
                              // SpMV of iteration xpend + 1 pays it, or the flush at the end of the solve / session)
+    double alpha_hist[16];   // ... with x updated in BATCHES (solvers.hip: XBatchOp): alpha of iteration i at [i % ring]
 };
 
 struct LogicCtx {

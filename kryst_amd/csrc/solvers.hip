@@ -173,6 +173,7 @@ struct CgAlphaLogic {                // cg.rs:164-175
             return;
         }
         st->alpha = st->rsq / p_dot_ap;                                // :175
+        st->alpha_hist[(st->iter + 1) & 15] = st->alpha;               // (x updated in batches: XBatchOp reads it; the ring of direction vectors has <= 16 slots)
     }
 };
 struct CgBetaLogic {                 // cg.rs:223-284
@@ -286,18 +287,89 @@ struct CgFlushOp {                   // x += alpha p (cg.rs:207-209 / pcg.rs:175
         st2(x, i, xx.a + al * pp.a, xx.b + al * pp.b);
     }
 };
+// ---- x updated in BATCHES (round 5).  A written byte costs this HBM what 2-2.5 read bytes cost (profiles/r05/fuse_kernel_ablations.txt: the fused
+// kernel's three written vectors are 0.54 of its 1.34 ms), and x += alpha_i p_i (cg.rs:207-209) writes x every iteration although nothing reads x
+// before the solve returns.  With the direction vectors kept in a ring of m + 1 buffers (p_new is written every iteration anyway) the m updates of
+// iterations k - m + 1 .. k are applied in ONE pass -- x = x + alpha_i p_i for i ascending, each the reference's un-fused multiply and add on the
+// reference's operands, so the same bits -- which reads x once and writes it once per m iterations.  Updates beyond `xpend` (the solve ended before
+// them) are not applied; the flush at the end of a solve / session applies what the last partial batch owes.
+template <int M>                   // M: the batch's length when every one of its updates happened (the common case), 0: any length, tested per update
+struct XBatchOp {
+    static constexpr int NQ = 0; static constexpr const char* TAG = "XBatch"; static constexpr int PHASE = KR_PH_BLAS1_XBATCH; static constexpr int BPC = 2;
+    const DevState* st; const double* p[8]; long long lo; int cnt; double* x;       // p[u]: the direction vector of iteration lo + u
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        const long long last = st->xpend;                                     // (uniform) updates of later iterations never happened in the reference
+        d2 xx = ld2(x, i);
+        if (M > 0 && lo + M - 1 <= last) {                                    // all M loads in flight together, then the M updates in iteration order
+            d2 pp[M > 0 ? M : 1]; double al[M > 0 ? M : 1];
+#pragma unroll
+            for (int u = 0; u < M; ++u) { pp[u] = ld2(p[u], i); al[u] = st->alpha_hist[(lo + u) & 15]; }
+#pragma unroll
+            for (int u = 0; u < M; ++u) { xx.a = xx.a + al[u] * pp[u].a; xx.b = xx.b + al[u] * pp[u].b; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u < cnt && lo + u <= last) {
+                    const double al = st->alpha_hist[(lo + u) & 15];
+                    const d2 pp = ld2(p[u], i);
+                    xx.a = xx.a + al * pp.a; xx.b = xx.b + al * pp.b;
+                }
+            }
+        }
+        st2(x, i, xx.a, xx.b);
+    }
+};
+struct GateXBatch {                  // nothing to apply: the solve ended before this batch's first iteration
+    const DevState* st; long long lo;
+    __device__ __forceinline__ bool skip() const { return st->xpend < lo; }
+};
+template <int M>
+inline int32_t launch_x_batch_m(kryst_ctx_t ctx, DevState* st, const std::vector<double*>& ring, int xb, long long lo, long long hi, double* x, int64_t n) {
+    XBatchOp<M> op; op.st = st; op.lo = lo; op.cnt = (int)(hi - lo + 1); op.x = x;
+    for (int u = 0; u < 8; ++u) op.p[u] = ring[(size_t)((lo + std::min<long long>(u, hi - lo)) % (xb + 1))];
+    return launch_ew_gated(ctx, op, n, GateXBatch{st, lo});
+}
+// x += alpha_i p_i for iterations lo .. hi (those that happened), p_i in ring[i % (xb + 1)]
+inline int32_t launch_x_batch(kryst_ctx_t ctx, DevState* st, const std::vector<double*>& ring, int xb, long long lo, long long hi, double* x, int64_t n) {
+    switch ((int)(hi - lo + 1)) {
+        case 2: return launch_x_batch_m<2>(ctx, st, ring, xb, lo, hi, x, n);
+        case 3: return launch_x_batch_m<3>(ctx, st, ring, xb, lo, hi, x, n);
+        case 4: return launch_x_batch_m<4>(ctx, st, ring, xb, lo, hi, x, n);
+        case 5: return launch_x_batch_m<5>(ctx, st, ring, xb, lo, hi, x, n);
+        case 6: return launch_x_batch_m<6>(ctx, st, ring, xb, lo, hi, x, n);
+        case 7: return launch_x_batch_m<7>(ctx, st, ring, xb, lo, hi, x, n);
+        case 8: return launch_x_batch_m<8>(ctx, st, ring, xb, lo, hi, x, n);
+        default: return launch_x_batch_m<0>(ctx, st, ring, xb, lo, hi, x, n);
+    }
+}
+// x-batch length: 1 = every iteration (x rides on the fused pass that reads p_old); KRYST_CG_X_BATCH forces (<= 8).  Measured at 512^3
+// (profiles/r05/cg_xbatch_ab.jsonl): CG 545 / 560 / 575 / 579 / 584 / 582 / 588 it/s at m = 1 / 2 / 4 / 5 / 6 / 7 / 8 (unfused 530); PCG 447 / 459 / 487 /
+// 489 / 490 / 490.5 / 472 (unfused 443) -- PCG's thirteen 1 GB work vectors lose at m = 8 what the ninth ring slot costs, so 7 there.
+inline int cg_x_batch(bool pcg) {
+    return std::max(1, std::min(8, env_int("KRYST_CG_X_BATCH", pcg ? 7 : 8)));
+}
 struct CgRun : SolverRun {
     using SolverRun::SolverRun;
     double *r = nullptr, *pp = nullptr, *ap = nullptr, *ax = nullptr;
     double* p2 = nullptr;            // the fused form's second direction vector (p_old / p_new alternate)
     bool fuse = false; long long fused_upto = 0;     // fused_upto: the last iteration enqueued in the fused form (its x update rides on the next one)
+    int xb = 1; std::vector<double*> ring;           // xb > 1: x in batches of xb iterations, direction vector of iteration k in ring[k % (xb + 1)]
+    int32_t x_batch(long long lo, long long hi) {    // apply the x updates of iterations lo .. hi (those that happened)
+        if (hi < lo) return KRYST_OK;
+        return launch_x_batch(ctx, ws.st, ring, xb, lo, hi, xw, n);
+    }
     int32_t begin() override {
         KR_TRY(solve_args_check(io, bv, xv));
         // the direction pass inside the SpMV (spmv.hip: spmv_pattern_fuse_kernel) where the operator's form allows it
         fuse = cg_defer_x() && !prm.has_radius && !prm.has_obj_target && prm.norm_type != 2 && spmv_can_fuse_direction(a);
-        KR_TRY(common_begin(prm.max_iters + 2, fuse ? 5 : 4));                                    // cg.rs:117
+        xb = fuse ? cg_x_batch(false) : 1;
+        KR_TRY(common_begin(prm.max_iters + 2, fuse ? (xb > 1 ? 3 + xb + 1 : 5) : 4));            // cg.rs:117
         KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&ap));
-        if (fuse) KR_TRY(ws.vec(&p2));
+        if (fuse && xb > 1) {                          // the ring: slot 1 is p_1 (= pp below), the others follow
+            ring.assign((size_t)xb + 1, nullptr);
+            ring[1 % (xb + 1)] = pp;
+            for (int k = 0; k <= xb; ++k) if (!ring[(size_t)k]) KR_TRY(ws.vec(&ring[(size_t)k]));
+        } else if (fuse) KR_TRY(ws.vec(&p2));
         if (prm.has_obj_target) KR_TRY(ws.vec(&ax));
         KR_TRY(residual_dot(a, bv->d, xw, r, ap, nullptr));                                       // :120-125, :127
         KR_HIP(hipMemcpyAsync(pp, r, padded_bytes(n), hipMemcpyDeviceToDevice, ctx->s_main));      // :126
@@ -305,14 +377,21 @@ struct CgRun : SolverRun {
     }
     int32_t flush() override {
         if (!fuse || fused_upto == 0) return KRYST_OK;
+        if (xb > 1) return x_batch(fused_upto / xb * xb + 1, fused_upto);                         // what the last partial batch owes
         return launch_ew_gated(ctx, CgFlushOp{ws.st, pp, xw}, n, GateXOwed{ws.st, fused_upto});
     }
     int32_t iterate(int64_t it) override {
         if (fuse) {
-            // iteration it: [x += alpha p_old owed by iteration it - 1; p = r + beta p_old; Ap; (p, Ap)] in ONE pass, alpha, the residual pass, beta
+            // iteration it: [x += alpha p_old owed by iteration it - 1 (xb == 1); p = r + beta p_old; Ap; (p, Ap)] in ONE pass, alpha, the residual pass, beta
             if (fused_upto == it - 1 && it > 1) {
-                KR_TRY(launch_spmv_fused(a, r, pp, p2, xw, ap, 1, &ws.st->alpha, &ws.st->beta, &ws.st->xpend, (long long)it, done));
-                std::swap(pp, p2);
+                if (xb > 1) {
+                    double* p_old = ring[(size_t)((it - 1) % (xb + 1))]; double* p_new = ring[(size_t)(it % (xb + 1))];
+                    KR_TRY(launch_spmv_fused(a, r, p_old, p_new, nullptr, ap, 1, &ws.st->alpha, &ws.st->beta, &ws.st->xpend, (long long)it, done));
+                    pp = p_new;
+                } else {
+                    KR_TRY(launch_spmv_fused(a, r, pp, p2, xw, ap, 1, &ws.st->alpha, &ws.st->beta, &ws.st->xpend, (long long)it, done));
+                    std::swap(pp, p2);
+                }
             } else {
                 KR_TRY(launch_spmv(a, pp, ap, 1, pp, done));                                      // the first iteration: p = r already
             }
@@ -321,6 +400,7 @@ struct CgRun : SolverRun {
             else KR_TRY(launch_ew(ctx, CgResidualOp<false>{&ws.st->alpha, ap, r}, n, done));
             KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgBetaLogic{lc})));
             fused_upto = it;
+            if (xb > 1 && it % xb == 0) KR_TRY(x_batch(it - xb + 1, it));                          // the x updates of the last xb iterations, one pass
             return KRYST_OK;
         }
         KR_TRY(launch_spmv(a, pp, ap, 1, pp, done));                                              // :143-144 + (p,Ap) :164
@@ -446,6 +526,7 @@ struct PcgAlphaLogic {               // pcg.rs:151-173
             return;
         }
         st->alpha = st->rz / p_dot_ap;                                 // :173
+        st->alpha_hist[(st->iter + 1) & 15] = st->alpha;
     }
 };
 struct PcgBetaLogic {                // pcg.rs:188-218
@@ -483,15 +564,25 @@ struct PcgRun : SolverRun {
     double* p2 = nullptr;            // the fused form's second direction vector
     bool alias = false, jac = false;
     bool fuse = false; long long fused_upto = 0;
+    int xb = 1; std::vector<double*> ring;           // x in batches (see CgRun)
+    int32_t x_batch(long long lo, long long hi) {
+        if (hi < lo) return KRYST_OK;
+        return launch_x_batch(ctx, ws.st, ring, xb, lo, hi, xw, n);
+    }
     int32_t begin() override {
         KR_TRY(solve_args_check(io, bv, xv));
         // radius / obj_target are fields of PcgSolver (pcg.rs:39-41) but PcgSolver::solve never reads them: accepted, ignored
         fuse = cg_defer_x() && spmv_can_fuse_direction(a);                                        // (spmv.hip: spmv_pattern_fuse_kernel)
-        KR_TRY(common_begin(prm.max_iters + 2, fuse ? 5 : 4));                                    // pcg.rs:117
+        xb = fuse ? cg_x_batch(true) : 1;
+        KR_TRY(common_begin(prm.max_iters + 2, fuse ? (xb > 1 ? 4 + xb + 1 : 5) : 4));            // pcg.rs:117
         alias = !pc || pc->kind == KR_PC_IDENTITY;      // z == r  (pcg.rs:130,186 clone_from / IdentityPC)
         jac = pc && pc->kind == KR_PC_JACOBI;
         KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&ap));
-        if (fuse) KR_TRY(ws.vec(&p2));
+        if (fuse && xb > 1) {
+            ring.assign((size_t)xb + 1, nullptr);
+            ring[1 % (xb + 1)] = pp;
+            for (int k = 0; k <= xb; ++k) if (!ring[(size_t)k]) KR_TRY(ws.vec(&ring[(size_t)k]));
+        } else if (fuse) KR_TRY(ws.vec(&p2));
         if (alias) z = r; else KR_TRY(ws.vec(&z));
         KR_TRY(launch_spmv(a, xw, ap, 0, nullptr, nullptr));                                      // :119-124
         KR_TRY(launch_ew(ctx, SubDotOp{bv->d, ap, r}, n, nullptr));
@@ -503,12 +594,17 @@ struct PcgRun : SolverRun {
     }
     int32_t flush() override {
         if (!fuse || fused_upto == 0) return KRYST_OK;
+        if (xb > 1) return x_batch(fused_upto / xb * xb + 1, fused_upto);
         return launch_ew_gated(ctx, CgFlushOp{ws.st, pp, xw}, n, GateXOwed{ws.st, fused_upto});
     }
     int32_t iterate(int64_t it) override {
         const int nt_ = prm.norm_type;
         const bool fused_now = fuse && fused_upto == it - 1 && it > 1;
-        if (fused_now) {       // [x += alpha p_old owed by iteration it - 1; p = z + beta p_old; Ap; (p, Ap)] in one pass
+        if (fused_now && xb > 1) {
+            double* p_old = ring[(size_t)((it - 1) % (xb + 1))]; double* p_new = ring[(size_t)(it % (xb + 1))];
+            KR_TRY(launch_spmv_fused(a, z, p_old, p_new, nullptr, ap, 1, &ws.st->alpha, &ws.st->beta, &ws.st->xpend, (long long)it, done));
+            pp = p_new;
+        } else if (fused_now) {       // [x += alpha p_old owed by iteration it - 1; p = z + beta p_old; Ap; (p, Ap)] in one pass
             KR_TRY(launch_spmv_fused(a, z, pp, p2, xw, ap, 1, &ws.st->alpha, &ws.st->beta, &ws.st->xpend, (long long)it, done));
             std::swap(pp, p2);
         } else {
@@ -530,7 +626,11 @@ struct PcgRun : SolverRun {
                 KR_TRY(launch_ew(ctx, DotPairOp{r, z, nq_a, nq_a}, n, done));                     // :188-195
             }
             KR_TRY((reduce_then<2>(ctx, nt, ws.red, PcgBetaLogic{lc})));
-            if (fuse) { fused_upto = it; return KRYST_OK; }                                       // (the direction pass is the next iteration's SpMV)
+            if (fuse) {                                                                           // (the direction pass is the next iteration's SpMV)
+                fused_upto = it;
+                if (xb > 1 && it % xb == 0) KR_TRY(x_batch(it - xb + 1, it));
+                return KRYST_OK;
+            }
             if ((alias || jac) && keep) return launch_direction(ctx, a, CgDirectionOp<true>{ws.st, z, pp, xw}, n, ws.st, (long long)it, pp);
             return launch_direction(ctx, a, CgDirectionOp<false>{ws.st, z, pp, xw}, n, ws.st, (long long)it, pp);   // :175-177, :215-217
         }

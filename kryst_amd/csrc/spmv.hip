@@ -782,7 +782,7 @@ struct FuseArgs { const double* z; const double* p_old; double* p_new; double* x
 template <int NQ, int T, int NMAX>
 __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs a, const FuseArgs f, const int32_t n, const int32_t far_lo, const int32_t far_hi) {
     const bool ended = a.done && *a.done;
-    const bool owed = *f.xpend == f.it - 1;
+    const bool owed = f.xvec != nullptr && *f.xpend == f.it - 1;            // (xvec == nullptr: the solver updates x in batches, solvers.hip: XBatchOp)
     if (ended && !owed) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int XS = T * KR_TILE + 2 * n + 4;                                  // staged elements (even)
@@ -1519,9 +1519,10 @@ bool spmv_can_fuse_direction(kryst_csr_t a) {
     return !a->dist && a->d_pid && a->pat_stage_n > 0 && a->pat_far_uniform && a->npat <= 512 && a->ntab <= 512 && a->nrows == a->xlen &&
            takes_pattern_path(a, false) && env_int("KRYST_SPMV_STAGE", 1) != 0 && env_int("KRYST_SPMV_STAGE_UFAR", 1) != 0 &&
            a->xlen + 2 * KR_TILE < (1ll << 31) &&
-           // measured (profiles/r05/cg_fuse_ab.jsonl, cg_fuse_sweep.jsonl): fewer bytes only pay where the vectors do not live in the 256 MiB Infinity
-           // Cache anyway -- 512^3 CG +3.5 % (PCG +3.3 %), 256^3 -5 %, 128^3 -4 %.  KRYST_CG_FUSE_P = 1 / 0 forces the fused / unfused form.
-           env_int("KRYST_CG_FUSE_P", a->nrows * 8 > env_ll("KRYST_CG_FUSE_MIN_BYTES", 256ll << 20) ? 1 : 0) != 0;
+           // measured (profiles/r05/cg_fuse_ab.jsonl, cg_fuse_sweep.jsonl, cg_xbatch_ab.jsonl): fewer bytes only pay where the vectors are far beyond
+           // the 256 MiB Infinity Cache -- with x in batches 512^3 CG +11 % (PCG +10 %), 480^3 +6 %, 448^3 +-1 %, 416^3 -1 %, 384^3 -6 %, 256^3 0 .. -5 %.
+           // KRYST_CG_FUSE_P = 1 / 0 forces the fused / unfused form.
+           env_int("KRYST_CG_FUSE_P", a->nrows * 8 > env_ll("KRYST_CG_FUSE_MIN_BYTES", 768ll << 20) ? 1 : 0) != 0;
 }
 // y = A p_new with p_new = z + beta p_old formed on the way (stored to p_new), the owed x += alpha p_old on the same pass, partial (p_new, y)
 // [and (y, y)] -- see spmv_pattern_fuse_kernel.  `done`, alpha, beta, xpend: device scalars of the solve; it: the iteration being enqueued.

@@ -1234,17 +1234,19 @@ def test_deferred_x_update_on_every_exit_path(ctx, rs, defer_x, monkeypatch):
             assert np.array_equal(xs.to_host(), res.x), (method, k)
 
 
-@pytest.mark.parametrize("fuse", ["1", "0"])
+@pytest.mark.parametrize("fuse,xbatch", [("1", "1"), ("1", "4"), ("1", "3"), ("1", "8"), ("0", "1")])
 @pytest.mark.parametrize("N,kind,T", [(10, "aniso", "2"), (16, "poisson", "2"), (16, "poisson", "4"), (32, "convdiff", "2"), (40, "poisson", "4")])
-def test_direction_pass_inside_the_spmv_on_every_exit_path(ctx, rs, fuse, N, kind, T, monkeypatch):
+def test_direction_pass_inside_the_spmv_on_every_exit_path(ctx, rs, fuse, xbatch, N, kind, T, monkeypatch):
     """Round 5: on stencil operators in their staged CSR-P16 form CG / PCG form p = z + beta p_old INSIDE the next iteration's SpMV
     (spmv.hip: spmv_pattern_fuse_kernel) and the deferred x += alpha p rides on the same pass -- two direction vectors alternate, the x
     update of iteration k is paid by the fused SpMV of iteration k + 1 or, when none follows, by a flush at the end.  KRYST_CG_FUSE_P=0 is
     the unfused form.  Both must leave iteration counts, histories and x as the oracle does on every way out: convergence (the device runs
     ahead of the host: fused SpMVs enqueued behind the final iteration must pay the owed update exactly once), the iteration cap (1, 2, 3,
     8 -- the flush), an initial guess, Jacobi / identity / ILU preconditioners, stepping sessions in several steps, runs of 2 and of 4 tiles,
-    grids whose last run is partial."""
-    monkeypatch.setenv("KRYST_CG_FUSE_P", fuse); monkeypatch.setenv("KRYST_SPMV_FUSE_T", T)
+    grids whose last run is partial.  xbatch > 1: x is updated in BATCHES -- the direction vectors of the last m iterations stay in a ring and
+    x += alpha_i p_i for i = k - m + 1 .. k happens in one pass every m iterations (XBatchOp), a partial batch at the end (caps and session
+    lengths that are not multiples of m, solves that end inside a batch)."""
+    monkeypatch.setenv("KRYST_CG_FUSE_P", fuse); monkeypatch.setenv("KRYST_SPMV_FUSE_T", T); monkeypatch.setenv("KRYST_CG_X_BATCH", xbatch)
     a = O.stencil7(N, kind)
     d = K.CsrMatrix.stencil7(N, kind, ctx=ctx) if N % 4 == 0 else to_dev(ctx, a)
     assert d.encoding()[0] == "csr-p16" and d.pattern_info()["staged"]
@@ -1255,7 +1257,7 @@ def test_direction_pass_inside_the_spmv_on_every_exit_path(ctx, rs, fuse, N, kin
            ("pcg", K.PcgSolver, O.Pc.identity(), K.IdentityPc().setup(d))]
     if N <= 16:
         pcs.append(("pcg", K.PcgSolver, O.Pc.ilu0_true(a), K.TrueIlu0().setup(d)))
-    for cap in (1, 2, 3, 8, 400):
+    for cap in (1, 2, 3, 4, 5, 8, 9, 400):
         for name, cls, opc, kpc in pcs:
             res = O.solve(name, a, b, pc=opc, x0=x0, tol=1e-9, max_iters=cap, rs=rs, raise_on_error=False)
             s = cls(1e-9, cap); x = x0.copy()
@@ -1267,7 +1269,7 @@ def test_direction_pass_inside_the_spmv_on_every_exit_path(ctx, rs, fuse, N, kin
             _check_solver(res, st, s, x, exact=(code == 0))
     if sym:
         for method, opc, kpc in (("cg", None, None), ("pcg", O.Pc.jacobi(a), K.Jacobi().setup(d))):
-            for steps in ((1,), (2, 1), (3, 4), (1, 1, 1, 5)):
+            for steps in ((1,), (2, 1), (3, 4), (1, 1, 1, 5), (4, 4), (5, 6, 2)):
                 k = sum(steps)
                 res = O.solve(method, a, b, pc=opc, tol=1e-30, max_iters=k, rs=rs)
                 xs, bs = K.DeviceVec(ctx, np.zeros(a.nrows)), K.DeviceVec(ctx, b)
