@@ -111,6 +111,18 @@ struct CgDirectionOp {               // x += alpha p (cg.rs:207-209, deferred) ;
         }
     }
 };
+// the same pass with the direction vectors in a RING and x updated in batches (XBatchOp below): p_new = z + beta p_old, out of place; x is not touched
+template <bool KEEP = false>
+struct CgDirectionRingOp {
+    static constexpr int NQ = 0; static constexpr const char* TAG = "CgDirectionRing"; static constexpr int PHASE = KR_PH_BLAS1_DIRECTION; static constexpr int BPC = 3;
+    const DevState* st; const double* z; const double* p_old; double* p_new;
+    __device__ __forceinline__ void pair(int64_t i, bool, bool, double (&)[1]) const {
+        if (st->done != 0) return;                                        // (uniform) the solve ended in this iteration: no further direction
+        const double be = st->beta;
+        const d2 pp = ld2(p_old, i), zz = ld2_sel<KEEP>(z, i);
+        st2(p_new, i, zz.a + be * pp.a, zz.b + be * pp.b);
+    }
+};
 struct GateXPending {                // runs while the solve is under way, and once more in the iteration that ended it after the x update
     const DevState* st; long long it;
     __device__ __forceinline__ bool skip() const { return st->done && st->xlast != it; }
@@ -348,12 +360,21 @@ inline int32_t launch_x_batch(kryst_ctx_t ctx, DevState* st, const std::vector<d
 inline int cg_x_batch(bool pcg) {
     return std::max(1, std::min(8, env_int("KRYST_CG_X_BATCH", pcg ? 7 : 8)));
 }
+// ... and in the UNFUSED deferred form (every operator form, every rank of a partition) the same ring is available: the direction pass writes
+// p_new = z + beta p_old out of place (CgDirectionRingOp: 2 reads + 1 write instead of 3 + 2) and XBatchOp pays x -- 34 instead of 40 bytes per row
+// and iteration.  MEASURED AND OFF BY DEFAULT (profiles/r05/cg_ring_unfused_ab.jsonl): 192^3 .. 384^3 run 2-7 % SLOWER (the in-place direction vector
+// is what the 256 MiB Infinity Cache hands from the direction pass to the SpMV; nine ring slots defeat that), 512^3 on plain CSR +-1 %, 64^3 / 128^3
+// +3 %.  KRYST_CG_X_BATCH = m > 1 turns it on (tests do).
+inline int cg_x_batch_unfused() {
+    return std::max(1, std::min(8, env_int("KRYST_CG_X_BATCH", 1)));
+}
 struct CgRun : SolverRun {
     using SolverRun::SolverRun;
     double *r = nullptr, *pp = nullptr, *ap = nullptr, *ax = nullptr;
     double* p2 = nullptr;            // the fused form's second direction vector (p_old / p_new alternate)
     bool fuse = false; long long fused_upto = 0;     // fused_upto: the last iteration enqueued in the fused form (its x update rides on the next one)
     int xb = 1; std::vector<double*> ring;           // xb > 1: x in batches of xb iterations, direction vector of iteration k in ring[k % (xb + 1)]
+    bool ringdir = false;                            // the unfused deferred form with the ring (CgDirectionRingOp)
     int32_t x_batch(long long lo, long long hi) {    // apply the x updates of iterations lo .. hi (those that happened)
         if (hi < lo) return KRYST_OK;
         return launch_x_batch(ctx, ws.st, ring, xb, lo, hi, xw, n);
@@ -361,11 +382,13 @@ struct CgRun : SolverRun {
     int32_t begin() override {
         KR_TRY(solve_args_check(io, bv, xv));
         // the direction pass inside the SpMV (spmv.hip: spmv_pattern_fuse_kernel) where the operator's form allows it
-        fuse = cg_defer_x() && !prm.has_radius && !prm.has_obj_target && prm.norm_type != 2 && spmv_can_fuse_direction(a);
-        xb = fuse ? cg_x_batch(false) : 1;
-        KR_TRY(common_begin(prm.max_iters + 2, fuse ? (xb > 1 ? 3 + xb + 1 : 5) : 4));            // cg.rs:117
+        const bool deferred = cg_defer_x() && !prm.has_radius && !prm.has_obj_target && prm.norm_type != 2;
+        fuse = deferred && spmv_can_fuse_direction(a);
+        xb = fuse ? cg_x_batch(false) : deferred ? cg_x_batch_unfused() : 1;
+        ringdir = !fuse && xb > 1;
+        KR_TRY(common_begin(prm.max_iters + 2, xb > 1 ? 3 + xb + 1 : fuse ? 5 : 4));              // cg.rs:117
         KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&ap));
-        if (fuse && xb > 1) {                          // the ring: slot 1 is p_1 (= pp below), the others follow
+        if (xb > 1) {                                  // the ring: slot 1 is p_1 (= pp below), the others follow
             ring.assign((size_t)xb + 1, nullptr);
             ring[1 % (xb + 1)] = pp;
             for (int k = 0; k <= xb; ++k) if (!ring[(size_t)k]) KR_TRY(ws.vec(&ring[(size_t)k]));
@@ -376,7 +399,7 @@ struct CgRun : SolverRun {
         return reduce_then<1>(ctx, nt, ws.red, CgInitLogic{lc});
     }
     int32_t flush() override {
-        if (!fuse || fused_upto == 0) return KRYST_OK;
+        if ((!fuse && !ringdir) || fused_upto == 0) return KRYST_OK;
         if (xb > 1) return x_batch(fused_upto / xb * xb + 1, fused_upto);                         // what the last partial batch owes
         return launch_ew_gated(ctx, CgFlushOp{ws.st, pp, xw}, n, GateXOwed{ws.st, fused_upto});
     }
@@ -409,6 +432,14 @@ struct CgRun : SolverRun {
             if (keep_in_cache(n)) KR_TRY(launch_ew(ctx, CgResidualOp<true>{&ws.st->alpha, ap, r}, n, done));
             else KR_TRY(launch_ew(ctx, CgResidualOp<false>{&ws.st->alpha, ap, r}, n, done));      // :210-212 + (r,r) :223
             KR_TRY((reduce_then<1>(ctx, nt, ws.red, CgBetaLogic{lc})));
+            if (ringdir) {                             // p_{it+1} = r + beta p_it into the next ring slot; x in batches
+                double* p_new = ring[(size_t)((it + 1) % (xb + 1))];
+                if (keep_in_cache(n)) KR_TRY(launch_direction(ctx, a, CgDirectionRingOp<true>{ws.st, r, pp, p_new}, n, ws.st, (long long)it, p_new));
+                else KR_TRY(launch_direction(ctx, a, CgDirectionRingOp<false>{ws.st, r, pp, p_new}, n, ws.st, (long long)it, p_new));
+                pp = p_new; fused_upto = it;
+                if (it % xb == 0) KR_TRY(x_batch(it - xb + 1, it));
+                return KRYST_OK;
+            }
             if (keep_in_cache(n)) return launch_direction(ctx, a, CgDirectionOp<true>{ws.st, r, pp, xw}, n, ws.st, (long long)it, pp);
             return launch_direction(ctx, a, CgDirectionOp<false>{ws.st, r, pp, xw}, n, ws.st, (long long)it, pp);   // :207-209, :274-276
         }
@@ -565,6 +596,7 @@ struct PcgRun : SolverRun {
     bool alias = false, jac = false;
     bool fuse = false; long long fused_upto = 0;
     int xb = 1; std::vector<double*> ring;           // x in batches (see CgRun)
+    bool ringdir = false;
     int32_t x_batch(long long lo, long long hi) {
         if (hi < lo) return KRYST_OK;
         return launch_x_batch(ctx, ws.st, ring, xb, lo, hi, xw, n);
@@ -573,12 +605,13 @@ struct PcgRun : SolverRun {
         KR_TRY(solve_args_check(io, bv, xv));
         // radius / obj_target are fields of PcgSolver (pcg.rs:39-41) but PcgSolver::solve never reads them: accepted, ignored
         fuse = cg_defer_x() && spmv_can_fuse_direction(a);                                        // (spmv.hip: spmv_pattern_fuse_kernel)
-        xb = fuse ? cg_x_batch(true) : 1;
-        KR_TRY(common_begin(prm.max_iters + 2, fuse ? (xb > 1 ? 4 + xb + 1 : 5) : 4));            // pcg.rs:117
+        xb = fuse ? cg_x_batch(true) : cg_defer_x() ? cg_x_batch_unfused() : 1;
+        ringdir = !fuse && xb > 1;
+        KR_TRY(common_begin(prm.max_iters + 2, xb > 1 ? 4 + xb + 1 : fuse ? 5 : 4));              // pcg.rs:117
         alias = !pc || pc->kind == KR_PC_IDENTITY;      // z == r  (pcg.rs:130,186 clone_from / IdentityPC)
         jac = pc && pc->kind == KR_PC_JACOBI;
         KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&ap));
-        if (fuse && xb > 1) {
+        if (xb > 1) {
             ring.assign((size_t)xb + 1, nullptr);
             ring[1 % (xb + 1)] = pp;
             for (int k = 0; k <= xb; ++k) if (!ring[(size_t)k]) KR_TRY(ws.vec(&ring[(size_t)k]));
@@ -593,7 +626,7 @@ struct PcgRun : SolverRun {
         return reduce_then<2>(ctx, nt, ws.red, PcgInitLogic{lc});
     }
     int32_t flush() override {
-        if (!fuse || fused_upto == 0) return KRYST_OK;
+        if ((!fuse && !ringdir) || fused_upto == 0) return KRYST_OK;
         if (xb > 1) return x_batch(fused_upto / xb * xb + 1, fused_upto);
         return launch_ew_gated(ctx, CgFlushOp{ws.st, pp, xw}, n, GateXOwed{ws.st, fused_upto});
     }
@@ -629,6 +662,14 @@ struct PcgRun : SolverRun {
             if (fuse) {                                                                           // (the direction pass is the next iteration's SpMV)
                 fused_upto = it;
                 if (xb > 1 && it % xb == 0) KR_TRY(x_batch(it - xb + 1, it));
+                return KRYST_OK;
+            }
+            if (ringdir) {
+                double* p_new = ring[(size_t)((it + 1) % (xb + 1))];
+                if ((alias || jac) && keep) KR_TRY(launch_direction(ctx, a, CgDirectionRingOp<true>{ws.st, z, pp, p_new}, n, ws.st, (long long)it, p_new));
+                else KR_TRY(launch_direction(ctx, a, CgDirectionRingOp<false>{ws.st, z, pp, p_new}, n, ws.st, (long long)it, p_new));
+                pp = p_new; fused_upto = it;
+                if (it % xb == 0) KR_TRY(x_batch(it - xb + 1, it));
                 return KRYST_OK;
             }
             if ((alias || jac) && keep) return launch_direction(ctx, a, CgDirectionOp<true>{ws.st, z, pp, xw}, n, ws.st, (long long)it, pp);

@@ -1199,13 +1199,13 @@ def test_pcg_bit_exact(ctx, rs, pcname, norm, defer_x, monkeypatch):
     _check_solver(res, st, s, x)
 
 
-@pytest.mark.parametrize("defer_x", ["1", "0"])
-def test_deferred_x_update_on_every_exit_path(ctx, rs, defer_x, monkeypatch):
+@pytest.mark.parametrize("defer_x,xbatch", [("1", "1"), ("1", "2"), ("1", "8"), ("0", "1")])
+def test_deferred_x_update_on_every_exit_path(ctx, rs, defer_x, xbatch, monkeypatch):
     """x += alpha p travels with the direction pass (p is read once per iteration).  Every way out of CG / PCG must leave x as the
     reference does: convergence, the iteration cap (1, 2, 7 iterations -- `converged` true, x includes the last alpha p), p.Ap <= 0
     (x untouched by that iteration), a non-pointwise preconditioner (ILU: the unfused PCG path), a stepping session ended after k
-    iterations, and an initial guess."""
-    monkeypatch.setenv("KRYST_CG_DEFER_X", defer_x)
+    iterations, and an initial guess.  xbatch > 1: the direction vectors in a ring, x paid in batches of that many iterations (XBatchOp)."""
+    monkeypatch.setenv("KRYST_CG_DEFER_X", defer_x); monkeypatch.setenv("KRYST_CG_X_BATCH", xbatch)
     a = O.stencil7(9, "aniso"); d = to_dev(ctx, a)
     b = O.splitmix64_uniform(0xD0E, a.nrows)
     x0 = O.splitmix64_uniform(0xABC, a.nrows)
@@ -1234,7 +1234,7 @@ def test_deferred_x_update_on_every_exit_path(ctx, rs, defer_x, monkeypatch):
             assert np.array_equal(xs.to_host(), res.x), (method, k)
 
 
-@pytest.mark.parametrize("fuse,xbatch", [("1", "1"), ("1", "4"), ("1", "3"), ("1", "8"), ("0", "1")])
+@pytest.mark.parametrize("fuse,xbatch", [("1", "1"), ("1", "4"), ("1", "3"), ("1", "8"), ("0", "1"), ("0", "2"), ("0", "3"), ("0", "8")])
 @pytest.mark.parametrize("N,kind,T", [(10, "aniso", "2"), (16, "poisson", "2"), (16, "poisson", "4"), (32, "convdiff", "2"), (40, "poisson", "4")])
 def test_direction_pass_inside_the_spmv_on_every_exit_path(ctx, rs, fuse, xbatch, N, kind, T, monkeypatch):
     """Round 5: on stencil operators in their staged CSR-P16 form CG / PCG form p = z + beta p_old INSIDE the next iteration's SpMV
@@ -1245,7 +1245,8 @@ def test_direction_pass_inside_the_spmv_on_every_exit_path(ctx, rs, fuse, xbatch
     8 -- the flush), an initial guess, Jacobi / identity / ILU preconditioners, stepping sessions in several steps, runs of 2 and of 4 tiles,
     grids whose last run is partial.  xbatch > 1: x is updated in BATCHES -- the direction vectors of the last m iterations stay in a ring and
     x += alpha_i p_i for i = k - m + 1 .. k happens in one pass every m iterations (XBatchOp), a partial batch at the end (caps and session
-    lengths that are not multiples of m, solves that end inside a batch)."""
+    lengths that are not multiples of m, solves that end inside a batch).  fuse = 0 with xbatch > 1: the UNFUSED form with the ring -- the direction
+    pass writes p_new = z + beta p_old out of place (CgDirectionRingOp) and never touches x."""
     monkeypatch.setenv("KRYST_CG_FUSE_P", fuse); monkeypatch.setenv("KRYST_SPMV_FUSE_T", T); monkeypatch.setenv("KRYST_CG_X_BATCH", xbatch)
     a = O.stencil7(N, kind)
     d = K.CsrMatrix.stencil7(N, kind, ctx=ctx) if N % 4 == 0 else to_dev(ctx, a)

@@ -34,7 +34,12 @@ def _build_shim():
                                                  (8, 32, "poisson", "0+light+t2"), (8, 4000, "random", "0+light+t2"),
                                                  # five PROCESSES (with the test runner itself six have the GPU open: the most a GPU box admits): the
                                                  # peer-store halo exchange and the mailboxes between five ranks
-                                                 (5, 20, "poisson", "0+light"), (5, 3000, "random", "0+light")])
+                                                 (5, 20, "poisson", "0+light"), (5, 3000, "random", "0+light"),
+                                                 # "+ring": CG / PCG keep their direction vectors in a ring and pay x in batches of 3 iterations
+                                                 # (solvers.hip: CgDirectionRingOp + XBatchOp; by default only for vectors beyond 32 MiB) -- with the
+                                                 # early halo start of the NEW direction vector, on P16 / DIA / general operators
+                                                 (2, 12, "poisson", "0+ring"), (4, 48, "poisson", "0+light+ring"), (3, 40, "varcoef", "0+light+ring"),
+                                                 (5, 3000, "random", "0+light+ring")])
 def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     from oracle import oracle as O
     import kryst_amd as K
@@ -46,6 +51,8 @@ def test_multirank_on_one_gpu(tmp_path, P, N, kind, hostgen):
     light = "light" in flags
     if light:
         env["KRYST_MR_LIGHT"] = "1"
+    if "ring" in flags:
+        env["KRYST_CG_X_BATCH"] = "3"
     per = 2 if "t2" in flags else 1                     # ranks per process (host threads)
     if per > 1:
         env["GPU_MAX_HW_QUEUES"] = "8"                  # every rank's two streams on hardware queues of their own: a kernel that polls for a peer
