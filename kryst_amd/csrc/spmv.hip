@@ -779,10 +779,13 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_stage_kernel(const SpmvArgs
 //   done: the solve has ended -- only the owed x update happens, nothing else is touched.
 struct FuseArgs { const double* z; const double* p_old; double* p_new; double* xvec; const double* alpha; const double* beta; const long long* xpend; long long it; };
 // NMAX: the line length the instance is built for (the window's pairs per lane are a compile-time count): 512 or 1024
-template <int NQ, int T, int NMAX>
+// XU: the deferred x update rides on this kernel (false: the solver updates x in batches, solvers.hip: XBatchOp -- no registers held for x)
+// (measured and not kept, round 5: runs of 8 tiles -- 166 registers, 3 waves per SIMD: 582-590 against 596 it/s; amdgpu_waves_per_eu(5): four
+// spilled registers, 565 against 596)
+template <int NQ, int T, int NMAX, bool XU>
 __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs a, const FuseArgs f, const int32_t n, const int32_t far_lo, const int32_t far_hi) {
     const bool ended = a.done && *a.done;
-    const bool owed = f.xvec != nullptr && *f.xpend == f.it - 1;            // (xvec == nullptr: the solver updates x in batches, solvers.hip: XBatchOp)
+    const bool owed = XU && *f.xpend == f.it - 1;
     if (ended && !owed) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int XS = T * KR_TILE + 2 * n + 4;                                  // staged elements (even)
@@ -822,11 +825,11 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs 
     const int own_lo = (n + 2) / 2, own_hi = own_lo + nt * (KR_TILE / 2);   // window pairs that are rows of this run
     // ---- the window: p_old straight into LDS (LDS-DMA, lane t's pairs t + 256 i land where lane t reads them back), z into registers
     const int wbase = __builtin_amdgcn_readfirstlane(t & ~63);
-    v2d zz[NP], xo[NP];
+    v2d zz[NP], xo[XU ? NP : 1];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int pi = t + i * KR_T;
-        zz[i].x = 0.0; zz[i].y = 0.0; xo[i] = zz[i];
+        zz[i].x = 0.0; zz[i].y = 0.0; if constexpr (XU) xo[i] = zz[i];
 #ifdef KR_TUNING
         if (pi < npairs && (!(a.abl & 2) || (pi >= own_lo && pi < own_hi))) {   // abl 2 (timing only): the window's halo is not loaded
 #else
@@ -836,7 +839,7 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(f.p_old + e),
                                              (__attribute__((address_space(3))) void*)(xs + 2 * (i * KR_T + wbase)), 16, 0, 0);
             zz[i] = *reinterpret_cast<const v2d*>(f.z + e);
-            if (owed && pi >= own_lo && pi < own_hi) xo[i] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(f.xvec + e));      // (own rows are never clamped; read once)
+            if constexpr (XU) { if (owed && pi >= own_lo && pi < own_hi) xo[i] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(f.xvec + e)); }     // (own rows are never clamped; read once)
         }
     }
     for (int i = t; i < a.npat; i += KR_T) meta[i] = reinterpret_cast<const uint2*>(a.pmeta)[i];
@@ -856,7 +859,7 @@ __global__ __launch_bounds__(KR_T) void spmv_pattern_fuse_kernel(const SpmvArgs 
                 if (a.abl & 8) { if (pn.x == 1.23456789e-300) st2(f.p_new, row, pn.x, pn.y); } else      // abl 8 (timing only): no p_new / x stores
 #endif
                 { st2(f.p_new, row, pn.x, pn.y);
-                if (owed) st2(f.xvec, row, xo[i].x + al * po.x, xo[i].y + al * po.y); }
+                if constexpr (XU) { if (owed) st2(f.xvec, row, xo[i].x + al * po.x, xo[i].y + al * po.y); } }
             }
         }
     }
@@ -1028,6 +1031,19 @@ __global__ void pack_kernel(const double* x, const int32_t* idx, double* out, in
 static int spmv_blocks_per_cu() { return env_int("KRYST_SPMV_BLOCKS_PER_CU", 0); }
 
 // Which kernel a launch takes is decided from the forms the operator has and the KRYST_SPMV_* settings (read per launch).
+// Runs per XCD group of the staged-window kernels (spmv_pattern_stage_kernel / _fuse_kernel: groups of G consecutive runs round-robin over the 8
+// XCDs): groups of 4 once the launch is well beyond one wave of workgroups (in-process A/B inside CG: 512^3 +1.2 %, 256^3 +-0, 192^3 +4 %, but
+// 128^3 -19 %; 8: +1.3 / -4.5 % at 512^3 / 256^3; 32: -2 / -21 %).  The FUSED kernel reads its far operands (rows +- one plane) from TWO vectors:
+// when a grid plane (far_hi rows) is a whole number of groups per XCD -- G = plane / (8 T tiles) -- the same (i, j) strip of every plane lands on
+// the same XCD, whose L2 then streams those rows itself: 512^3 fused CG, G = 16 against 4: 613 against 596 it/s (three interleaved rounds,
+// tools/cg_fuse_knobs.py).  The plain staged kernel does not care at 512^3 (0.500-0.508 ms for G = 1 .. 16, tools/stage_group_ab.py) and loses
+// with large groups at 384^3 (0.26 against 0.21 ms), so it keeps 4.
+static int stage_group_default(kryst_csr_t a, int64_t nruns, int T, bool fused) {
+    if (nruns < 2048) return 1;
+    const int64_t plane = a->pat_far_uniform ? (int64_t)a->pat_far_hi : 0, per = (int64_t)KR_TILE * 8 * T;
+    if (fused && plane > 0 && plane % per == 0 && plane / per >= 2 && plane / per <= 64) return (int)(plane / per);
+    return 4;
+}
 static bool takes_pattern_path(kryst_csr_t a, bool halo) {
     return a->d_pid && env_int("KRYST_SPMV_COMPRESS", 3) >= 3 && a->xlen + (halo ? a->plan.total_recv : 0) < (1ll << 28) && a->nrows < (1ll << 28);
 }
@@ -1110,9 +1126,7 @@ static int32_t launch_tiles(kryst_csr_t a, const double* x, double* y, int nq, c
             const size_t lds_s = (size_t)args.pat_red_off + sizeof(double) * (size_t)T * (size_t)(nq > 0 ? nq : 1) * (KR_T / 64);
             args.xsafe = (a->xlen + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE - 2;
             const int64_t nruns = (ntiles + T - 1) / T;
-            // groups of 4 runs per XCD once the launch is well beyond one wave of workgroups (in-process A/B: 512^3 +1.2 %, 256^3 +-0,
-            // 192^3 +4 %, but 128^3 -19 %; 8: +1.3 / -4.5 % at 512^3 / 256^3; 32: -2 / -21 %)
-            args.group = std::max(1, env_int("KRYST_SPMV_STAGE_GROUP", nruns >= 2048 ? 4 : 1));
+            args.group = std::max(1, env_int("KRYST_SPMV_STAGE_GROUP", stage_group_default(a, nruns, T, false)));
             const int64_t per_xcd = ((nruns + 7) / 8 + args.group - 1) / args.group * args.group;      // slots per XCD: whole groups
             const dim3 sgrid((unsigned)(per_xcd * 8));
             const bool center = nq > 0 && dvec == x;
@@ -1554,7 +1568,7 @@ static int32_t launch_spmv_fused_impl(kryst_csr_t a, const double* z, const doub
     if (wgcu > 0) lds_s = std::max(lds_s, std::min<size_t>((size_t)(160 << 10) / (size_t)wgcu - 512, (size_t)64 << 10));
     args.xsafe = (a->xlen + KR_TILE - 1) / KR_TILE * KR_TILE + KR_TILE - 2;
     const int64_t nruns = (a->ntiles + T - 1) / T;
-    args.group = std::max(1, env_int("KRYST_SPMV_STAGE_GROUP", nruns >= 2048 ? 4 : 1));
+    args.group = std::max(1, env_int("KRYST_SPMV_STAGE_GROUP", stage_group_default(a, nruns, T, true)));
     const int64_t per_xcd = ((nruns + 7) / 8 + args.group - 1) / args.group * args.group;
     const dim3 sgrid((unsigned)(per_xcd * 8)), block(KR_T);
     const FuseArgs f{z, p_old, p_new, xvec, alpha, beta, xpend, it};
@@ -1564,16 +1578,18 @@ static int32_t launch_spmv_fused_impl(kryst_csr_t a, const double* z, const doub
     if (lds_s > ((size_t)48 << 10)) {       // (more than the default dynamic LDS limit: once per instance)
         static bool raised = false;
         if (!raised) {
-            for (const void* fn : {(const void*)spmv_pattern_fuse_kernel<1, 2, 512>, (const void*)spmv_pattern_fuse_kernel<1, 2, 1024>, (const void*)spmv_pattern_fuse_kernel<1, 4, 512>,
-                                   (const void*)spmv_pattern_fuse_kernel<1, 4, 1024>, (const void*)spmv_pattern_fuse_kernel<2, 2, 512>, (const void*)spmv_pattern_fuse_kernel<2, 2, 1024>,
-                                   (const void*)spmv_pattern_fuse_kernel<2, 4, 512>, (const void*)spmv_pattern_fuse_kernel<2, 4, 1024>})
+#define KR_FUSE_FNS(NQ_, T_, X_) (const void*)spmv_pattern_fuse_kernel<NQ_, T_, 512, X_>, (const void*)spmv_pattern_fuse_kernel<NQ_, T_, 1024, X_>
+            for (const void* fn : {KR_FUSE_FNS(1, 2, true), KR_FUSE_FNS(1, 4, true), KR_FUSE_FNS(2, 2, true), KR_FUSE_FNS(2, 4, true),
+                                   KR_FUSE_FNS(1, 2, false), KR_FUSE_FNS(1, 4, false), KR_FUSE_FNS(2, 2, false), KR_FUSE_FNS(2, 4, false)})
                 (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
+#undef KR_FUSE_FNS
             raised = true;
         }
     }
-#define KR_FUSE_N(NQ_, T_) do { if (n_ <= 512) hipLaunchKernelGGL((spmv_pattern_fuse_kernel<NQ_, T_, 512>), sgrid, block, lds_s, ctx->s_main, args, f, n_, a->pat_far_lo, a->pat_far_hi); \
-                                else hipLaunchKernelGGL((spmv_pattern_fuse_kernel<NQ_, T_, 1024>), sgrid, block, lds_s, ctx->s_main, args, f, n_, a->pat_far_lo, a->pat_far_hi); } while (0)
-#define KR_FUSE(NQ_) do { if (T == 2) KR_FUSE_N(NQ_, 2); else KR_FUSE_N(NQ_, 4); } while (0)
+#define KR_FUSE_N(NQ_, T_, X_) do { if (n_ <= 512) hipLaunchKernelGGL((spmv_pattern_fuse_kernel<NQ_, T_, 512, X_>), sgrid, block, lds_s, ctx->s_main, args, f, n_, a->pat_far_lo, a->pat_far_hi); \
+                                    else hipLaunchKernelGGL((spmv_pattern_fuse_kernel<NQ_, T_, 1024, X_>), sgrid, block, lds_s, ctx->s_main, args, f, n_, a->pat_far_lo, a->pat_far_hi); } while (0)
+#define KR_FUSE(NQ_) do { if (xvec) { if (T == 2) KR_FUSE_N(NQ_, 2, true); else KR_FUSE_N(NQ_, 4, true); } \
+                          else { if (T == 2) KR_FUSE_N(NQ_, 2, false); else KR_FUSE_N(NQ_, 4, false); } } while (0)
     if (nq == 1) KR_FUSE(1); else KR_FUSE(2);
 #undef KR_FUSE
 #undef KR_FUSE_N
