@@ -373,3 +373,141 @@ extern "C" int32_t kryst_bench_csr_skeleton(kryst_csr_t a, kryst_vec_t x, kryst_
     KR_HIP(hipStreamSynchronize(ctx->s_main));
     return KRYST_OK;
 }
+
+// ---- EXPERIMENT (round 5): the plain-CSR traffic as a PERSISTENT, SOFTWARE-PIPELINED stream.  The BLAS-1 kernels reach 0.77 of peak with a capped
+// grid whose workgroups stride over the vector (a narrow moving window keeps DRAM pages open; ew.h), the one-tile-per-workgroup skeleton 0.70-0.72,
+// and a persistent SpMV grid WITHOUT prefetch 0.51-0.57 (each tile is a chain of three dependent round trips).  Here ONE workgroup per CU strides
+// over the tiles and keeps the matrix streams of the next TWO tiles in flight by LDS-DMA (global_load_lds: no registers, 12 requests of 1 KiB /
+// 256 B per wave and tile into a ring of three tile buffers), row pointers three tiles ahead (scalar loads), x one tile ahead; every wait is a
+// counted s_waitcnt.  Traffic only -- the buffers are xor-ed into y.  Sized for tiles of at most 4 x 896 entries (7 per row).
+namespace kr {
+constexpr int SKP_VAL = 7, SKP_C4 = 3, SKP_C1 = 2;                          // requests per wave and tile: 7 x 1 KiB of values, 3 x 1 KiB + 2 x 256 B of columns
+constexpr int SKP_WAVE_BYTES = SKP_VAL * 1024 + SKP_C4 * 1024 + SKP_C1 * 256;   // 10 752
+constexpr int SKP_REQ = SKP_VAL + SKP_C4 + SKP_C1;                           // 12
+template <int AUX>
+__global__ __launch_bounds__(KR_T) void csr_skeleton_persist_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                                    const double* __restrict__ x, double* __restrict__ y, int64_t n, int64_t ntiles, int64_t nnz) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char skp_lds[];
+    const int t = threadIdx.x, l = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t G = gridDim.x;
+    const int64_t trips = (ntiles + G - 1) / G;
+    const int64_t kmax = (nnz + 6) & ~(int64_t)3;                              // last entry a 16-byte request may start at (the arrays carry 8 entries of padding)
+    auto tile_of = [&](int64_t j) -> int64_t { const int64_t q = blockIdx.x + j * G; return q < ntiles ? q : ntiles - 1; };
+    // the row pointers of a tile are LOADED in one trip (two scalar loads, issued together) and USED in the next: no trip waits for them
+    auto rows_of = [&](int64_t q, int32_t& ka, int32_t& kb) {
+        const int64_t r0 = q * KR_TILE, r1 = r0 + KR_TILE < n ? r0 + KR_TILE : n;
+        ka = rp[r0]; kb = rp[r1];
+    };
+    auto quarter = [&](int32_t ka, int32_t kb) -> int64_t {                    // first entry of this wave's quarter of the tile
+        const int64_t k0 = (int64_t)ka & ~(int64_t)3, k1 = kb;
+        const int64_t wq = (((k1 - k0 + 3) / 4) + 3) & ~(int64_t)3;
+        return k0 + w * wq;
+    };
+    auto request = [&](int64_t e0, int slot) {                                 // the 12 requests of one tile into ring slot `slot`
+        unsigned char* base = skp_lds + ((size_t)slot * 4 + w) * SKP_WAVE_BYTES;
+#pragma unroll
+        for (int u = 0; u < SKP_VAL; ++u) {
+            int64_t k = e0 + u * 128 + 2 * l; k = k < kmax ? k : kmax;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(val + k), (__attribute__((address_space(3))) void*)(base + u * 1024), 16, 0, AUX & 3);
+        }
+#pragma unroll
+        for (int u = 0; u < SKP_C4; ++u) {
+            int64_t k = e0 + u * 256 + 4 * l; k = k < kmax ? k : kmax;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(col + k), (__attribute__((address_space(3))) void*)(base + SKP_VAL * 1024 + u * 1024), 16, 0, AUX & 3);
+        }
+#pragma unroll
+        for (int u = 0; u < SKP_C1; ++u) {
+            int64_t k = e0 + SKP_C4 * 256 + u * 64 + l; k = k < kmax ? k : kmax;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(col + k), (__attribute__((address_space(3))) void*)(base + (SKP_VAL + SKP_C4) * 1024 + u * 256), 4, 0, AUX & 3);
+        }
+    };
+    // row pointers by VECTOR loads issued by hand (every lane the same address; a scalar load's wait is the compiler's, and it puts it right behind the
+    // load): those of tile j + 4 are requested in trip j, and trip j + 2 -- two counted waits later -- turns them into the tile's requests
+    auto rows_req = [&](int64_t q, int32_t& va, int32_t& vb) {
+        const int64_t r0 = q * KR_TILE, r1 = r0 + KR_TILE < n ? r0 + KR_TILE : n;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(va) : "v"(rp + r0) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(vb) : "v"(rp + r1) : "memory");
+    };
+    int32_t ka, kb;
+    rows_of(tile_of(0), ka, kb); request(quarter(ka, kb), 0);
+    rows_of(tile_of(1), ka, kb); request(quarter(ka, kb), 1);
+    rows_of(tile_of(2), ka, kb);                                              // (tile 2: used by the first trip)
+    int32_t a3, b3, a4, b4;
+    rows_req(tile_of(3), a3, b3);
+    sk_u4 xv, xn; sk_u2 pv, pn;                                               // x and the lane's own two row pointers of a tile (4 (n + 1) bytes of SURVEY 8(d)'s count)
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xv) : "v"(x + tile_of(0) * KR_TILE + 2 * t) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pv) : "v"(rp + tile_of(0) * KR_TILE + 2 * t) : "memory");
+    {   // a store in front of the loop, so that every trip sees the same number of younger requests (the first tile's rows: written again below)
+        const sk_u4 z4 = {0u, 0u, 0u, 0u};
+        asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(y + tile_of(0) * KR_TILE + 2 * t), "v"(z4) : "memory");
+    }
+    // STATIC register roles (the loop body is two trips long): a register whose load is in flight must not be copied -- the hardware does not
+    // interlock a VGPR read with an outstanding load, only s_waitcnt does
+    auto trip = [&](int64_t j, sk_u4& xcur, sk_u4& xnext, sk_u2& pcur, sk_u2& pnext, int32_t& rnew_a, int32_t& rnew_b, int32_t& rold_a, int32_t& rold_b) __attribute__((always_inline)) {
+        rows_req(tile_of(j + 4), rnew_a, rnew_b);
+        if constexpr ((AUX & 4) != 0) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pnext) : "v"(rp + tile_of(j + 1) * KR_TILE + 2 * t) : "memory");
+        request(quarter(ka, kb), (int)((j + 2) % 3));                          // tile j + 2
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xnext) : "v"(x + tile_of(j + 1) * KR_TILE + 2 * t) : "memory");
+        if constexpr ((AUX & 4) == 0) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pnext) : "v"((AUX & 8) ? rp + 2 * t : rp + tile_of(j + 1) * KR_TILE + 2 * t) : "memory");
+        // tile j's streams, x and row pointers have landed: younger are the previous trip's store, this trip's 2 + 12 requests, x(j + 1) and its row pointers
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(SKP_REQ + 5) : "memory");
+        asm volatile("" : "+v"(xcur), "+v"(pcur), "+v"(rold_a), "+v"(rold_b)); // (x(j) and the row pointers of tile j + 3 are older still)
+        const unsigned char* base = skp_lds + ((size_t)(j % 3) * 4 + w) * SKP_WAVE_BYTES;
+        unsigned acc = xcur.x ^ xcur.w ^ pcur.x ^ pcur.y;
+#pragma unroll
+        for (int u = 0; u < SKP_VAL + SKP_C4; ++u) {
+            const sk_u4 v = *reinterpret_cast<const sk_u4*>(base + u * 1024 + 16 * l);
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+#pragma unroll
+        for (int u = 0; u < SKP_C1; ++u) acc ^= *reinterpret_cast<const unsigned*>(base + (SKP_VAL + SKP_C4) * 1024 + u * 256 + 4 * l);
+        sk_u4 yv; yv.x = acc; yv.y = (unsigned)t; yv.z = 0u; yv.w = 1u;
+        const int64_t q = blockIdx.x + j * G;
+        // (a tile past the end repeats the last one: the same store again)
+        asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(y + (q < ntiles ? q : ntiles - 1) * KR_TILE + 2 * t), "v"(yv) : "memory");
+        ka = __builtin_amdgcn_readfirstlane(rold_a); kb = __builtin_amdgcn_readfirstlane(rold_b);
+    };
+#pragma unroll 1
+    for (int64_t j = 0; j < trips; j += 2) {                                  // (an odd trip count runs one trip past the end: the last tile again)
+        trip(j, xv, xn, pv, pn, a4, b4, a3, b3);
+        trip(j + 1, xn, xv, pn, pv, a3, b3, a4, b4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // (requests past the end: nothing of this wave's is in flight when its LDS goes away)
+}
+}  // namespace kr
+extern "C" int32_t kryst_debug_csr_skeleton_persist(kryst_csr_t a, kryst_vec_t x, kryst_vec_t y, int32_t reps, int32_t grid, int32_t aux, double* avg_ms) {
+    KR_ARG(a && x && y && avg_ms && reps >= 1 && !a->dist && a->nrows == a->xlen && a->d_row_ptr && a->nrows >= 4 * KR_TILE, "debug_csr_skeleton_persist");
+    kryst_ctx_t ctx = a->ctx;
+    KR_HIP(hipSetDevice(ctx->device));
+    const int64_t nt = ntiles_of(a->nrows);
+    KR_ARG(a->nnz <= 7 * a->nrows, "debug_csr_skeleton_persist: sized for at most 7 entries per row");
+    const size_t lds = (size_t)3 * 4 * SKP_WAVE_BYTES;
+    const unsigned g = (unsigned)std::min<int64_t>(nt, grid > 0 ? grid : ctx->num_cu);
+    static bool raised = false;
+    if (!raised) {
+        KR_HIP(hipFuncSetAttribute((const void*)csr_skeleton_persist_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KR_HIP(hipFuncSetAttribute((const void*)csr_skeleton_persist_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KR_HIP(hipFuncSetAttribute((const void*)csr_skeleton_persist_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KR_HIP(hipFuncSetAttribute((const void*)csr_skeleton_persist_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+    }
+    auto once = [&] {
+        if (aux == 2) hipLaunchKernelGGL((csr_skeleton_persist_kernel<2>), dim3(g), dim3(KR_T), lds, ctx->s_main, a->d_row_ptr, a->d_col, a->d_val, x->d, y->d, a->nrows, nt, a->nnz);
+        else if (aux == 4) hipLaunchKernelGGL((csr_skeleton_persist_kernel<4>), dim3(g), dim3(KR_T), lds, ctx->s_main, a->d_row_ptr, a->d_col, a->d_val, x->d, y->d, a->nrows, nt, a->nnz);
+        else if (aux == 8) hipLaunchKernelGGL((csr_skeleton_persist_kernel<8>), dim3(g), dim3(KR_T), lds, ctx->s_main, a->d_row_ptr, a->d_col, a->d_val, x->d, y->d, a->nrows, nt, a->nnz);
+        else hipLaunchKernelGGL((csr_skeleton_persist_kernel<0>), dim3(g), dim3(KR_T), lds, ctx->s_main, a->d_row_ptr, a->d_col, a->d_val, x->d, y->d, a->nrows, nt, a->nnz);
+    };
+    once();
+    KR_HIP(hipGetLastError());
+    (void)hipEventRecord(ctx->tm0, ctx->s_main);
+    for (int r = 0; r < reps; ++r) once();
+    (void)hipEventRecord(ctx->tm1, ctx->s_main);
+    (void)hipEventSynchronize(ctx->tm1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ctx->tm0, ctx->tm1);
+    *avg_ms = (double)ms / reps;
+    KR_HIP(hipGetLastError());
+    KR_HIP(hipStreamSynchronize(ctx->s_main));
+    return KRYST_OK;
+}
