@@ -3,8 +3,8 @@
 G=${1:-512}
 cd /tmp && export TMPDIR=/tmp
 O=/root/repo/gpurun_out/cg_pmc; rm -rf $O; mkdir -p $O
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -o f -- python3 /root/repo/tools/cg_only.py $G 12 > $O/f.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- python3 /root/repo/tools/cg_only.py $G 12 > $O/w.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -o f -- python3 /root/repo/tools/cg_only.py $G 26 > $O/f.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- python3 /root/repo/tools/cg_only.py $G 26 > $O/w.log 2>&1 || exit 1
 python3 - $O $G <<'PY'
 import csv, glob, sys, collections
 o, g = sys.argv[1], int(sys.argv[2]); n = g ** 3
