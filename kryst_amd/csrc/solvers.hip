@@ -365,6 +365,15 @@ inline int cg_x_batch(bool pcg) {
 // and iteration.  MEASURED AND OFF BY DEFAULT (profiles/r05/cg_ring_unfused_ab.jsonl): 192^3 .. 384^3 run 2-7 % SLOWER (the in-place direction vector
 // is what the 256 MiB Infinity Cache hands from the direction pass to the SpMV; nine ring slots defeat that), 512^3 on plain CSR +-1 %, 64^3 / 128^3
 // +3 %.  KRYST_CG_X_BATCH = m > 1 turns it on (tests do).
+// the ring costs xb - 1 work vectors more than the two alternating direction vectors: only where the device has the room (what the context's
+// arena already holds counts as room)
+inline int ring_if_it_fits(kryst_ctx_t ctx, int64_t n, int xb, int work_vectors) {
+    if (xb <= 1) return 1;
+    size_t free_b = 0, total_b = 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    const size_t need = padded_bytes(n) * (size_t)(work_vectors + 2);
+    return need <= ctx->arena_bytes || need <= free_b + ctx->arena_bytes ? xb : 1;
+}
 inline int cg_x_batch_unfused() {
     return std::max(1, std::min(8, env_int("KRYST_CG_X_BATCH", 1)));
 }
@@ -385,6 +394,7 @@ struct CgRun : SolverRun {
         const bool deferred = cg_defer_x() && !prm.has_radius && !prm.has_obj_target && prm.norm_type != 2;
         fuse = deferred && spmv_can_fuse_direction(a);
         xb = fuse ? cg_x_batch(false) : deferred ? cg_x_batch_unfused() : 1;
+        xb = ring_if_it_fits(ctx, n, xb, 3 + xb + 1);
         ringdir = !fuse && xb > 1;
         KR_TRY(common_begin(prm.max_iters + 2, xb > 1 ? 3 + xb + 1 : fuse ? 5 : 4));              // cg.rs:117
         KR_TRY(ws.vec(&r)); KR_TRY(ws.vec(&pp)); KR_TRY(ws.vec(&ap));
@@ -606,6 +616,7 @@ struct PcgRun : SolverRun {
         // radius / obj_target are fields of PcgSolver (pcg.rs:39-41) but PcgSolver::solve never reads them: accepted, ignored
         fuse = cg_defer_x() && spmv_can_fuse_direction(a);                                        // (spmv.hip: spmv_pattern_fuse_kernel)
         xb = fuse ? cg_x_batch(true) : cg_defer_x() ? cg_x_batch_unfused() : 1;
+        xb = ring_if_it_fits(ctx, n, xb, 4 + xb + 1);
         ringdir = !fuse && xb > 1;
         KR_TRY(common_begin(prm.max_iters + 2, xb > 1 ? 4 + xb + 1 : fuse ? 5 : 4));              // pcg.rs:117
         alias = !pc || pc->kind == KR_PC_IDENTITY;      // z == r  (pcg.rs:130,186 clone_from / IdentityPC)
