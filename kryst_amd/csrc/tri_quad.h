@@ -634,31 +634,41 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
 #pragma unroll
         for (int u = 0; u < C; ++u) {
             const int t = t0 + u;
+#if defined(TQ_ABL) && (TQ_ABL & 16)
+            double yj = y, yk = y;
+#else
+            // the j-neighbour's row sits one lane down in the same row of 16 lanes: a DPP shift (no LDS); lanes with jl == 0 (every
+            // eighth) take the west row instead.  The k-neighbour is 8 lanes down, across rows of 16: a wave permute -- requested FIRST (round 5):
+            // the LDS executes a wave's operations in order and this one is on the step's dependent chain, the reads below are not
+            double yj = tq_shr1(y), yk = tw_bperm(idx8, y);
+#endif
+#if defined(TQ_ABL) && (TQ_ABL & 8)
+            const double wv = 0.5, sv = 0.25;
+#else
+            const double* const wp = u == 0 ? w_first : w_next;
+            const double* const spn = u == 0 ? s_first : s_next;
+            if (u != 0) { w_next += w_stride; s_next += s_stride; }
+            asm volatile("" ::: "memory");
+            double wv = *wp, sv = *spn;
+            asm volatile("" ::: "memory");
             if (__builtin_expect(t >= seen, 0)) {                          // rows of the west / south neighbours for this step not yet known to be there
 #ifdef KR_TW_TRACE
                 const long long tw0 = wall_clock64();
 #endif
+                // A wave at the front of the pipeline runs in lockstep with its producers -- and its first chunks are what the next block waits
+                // for.  The counters AND the rows in ONE LDS round trip (round 5): the counters are read first, so rows read behind a counter that
+                // covers them are the producer's (it writes the row, then the count); read behind a counter that does not, they are read again.
 #pragma unroll 1
                 for (int budget = 1 << 26; budget > 0; --budget) {
-                    seen = __builtin_amdgcn_readfirstlane(min(tq_peek(w_cnt) - w_off, tq_peek(s_cnt) - s_off));
+                    const int cw = tq_peek(w_cnt), cs = tq_peek(s_cnt);
+                    wv = *wp; sv = *spn;
+                    asm volatile("" ::: "memory");
+                    seen = __builtin_amdgcn_readfirstlane(min(cw - w_off, cs - s_off));
                     if (t < seen) break;
                     TQ_NAP(1);
                 }
                 TQ_ACC(11, tw0);
             }
-#if defined(TQ_ABL) && (TQ_ABL & 8)
-            const double wv = 0.5, sv = 0.25;
-#else
-            double wv, sv;
-            if (u == 0) { wv = *w_first; sv = *s_first; }
-            else { wv = *w_next; sv = *s_next; w_next += w_stride; s_next += s_stride; }
-#endif
-#if defined(TQ_ABL) && (TQ_ABL & 16)
-            double yj = y, yk = y;
-#else
-            // the j-neighbour's row sits one lane down in the same row of 16 lanes: a DPP shift (no LDS); lanes with jl == 0 (every
-            // eighth) take the west row instead.  The k-neighbour is 8 lanes down, across rows of 16: a wave permute.
-            double yj = tq_shr1(y), yk = tw_bperm(idx8, y);
 #endif
             if (jl == 0) yj = wv;
             if (kl == 0) yk = sv;
