@@ -31,7 +31,8 @@ namespace kr {
 
 // -DTQ_ABL=bits: TIMING-ONLY ablations (wrong results; never in the shipped library): 1 no result stores, 2 coefficients from four
 // cached chunks, 4 spins sleep 4x longer, 8 no west/south ring reads, 16 no lane exchange, 32 no ring write, 64 no stage read,
-// 128 a poller stream counts as fully delivered once its first rows have arrived.
+// 128 a poller stream counts as fully delivered once its first rows have arrived, 256 the solving waves never wait for the result stores,
+// 512 every result store goes into the vector's first 32 KiB.
 #if defined(TQ_ABL) && (TQ_ABL & 4)
 #define TQ_NAP(n) __builtin_amdgcn_s_sleep(4 * (n))
 #else
@@ -347,7 +348,11 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
                     const int ia = FORWARD ? 8 * m + 2 * sc : 8 * m + 7 - 2 * sc, ib = FORWARD ? ia + 1 : ia - 1;   // line rows of the piece, in memory order
                     tw_v2 v;
                     v.x = ring_q[((ia + gs) & (YR - 1)) * 64 + L]; v.y = ring_q[((ib + gs) & (YR - 1)) * 64 + L];
+#if defined(TQ_ABL) && (TQ_ABL & 512)
+                    const int64_t lo = (l00 + r * w_dr + (FORWARD ? 8 * m : Q.Ni - 8 - 8 * m)) & 4095;              // timing only: every result store into the vector's first 32 KiB (cache hits)
+#else
                     const int64_t lo = l00 + r * w_dr + (FORWARD ? 8 * m : Q.Ni - 8 - 8 * m);                       // lowest memory row of the group
+#endif
                     *(__attribute__((address_space(1))) tw_v2*)(out + lo + 2 * sc) = v;
                 }
             } else {
@@ -609,6 +614,9 @@ __global__ __launch_bounds__(512, 2) void tri_quad_kernel(const TriArgs* args, c
                 const int vw = __hip_atomic_load(&written[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 asm volatile("" ::: "memory");
                 int m = 8 * vw - 14;                                               // the stores of chunk w read steps >= 8 w - 7: like an exporter at that step
+#if defined(TQ_ABL) && (TQ_ABL & 256)
+                m = 1 << 29;                                                       // timing only: the solving wave never waits for the result stores
+#endif
                 if (cons_a >= 0) m = min(m, va * C);                               // (published when the chunk's steps are done)
                 if (cons_b >= 0) m = min(m, vb * C);
                 if (exp_a >= 0) m = min(m, ve - 7);
