@@ -222,8 +222,17 @@ def cpu_info():
                 cid = v; cores.add((pid, cid))
     except Exception:
         pass
+    # the cgroup's CPU bandwidth (cpu.max = "quota period"): a container may be ALLOWED on every CPU of the host and still be granted only a
+    # few CPUs' worth of time -- threads beyond that are throttled, not run (the GPU boxes: 256 CPUs allowed, 16 granted)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
     return {"cpu_model": model, "sockets": len(phys) or None, "physical_cores": len(cores) or None, "logical_cpus": logical or None,
-            "cpus_allowed": len(os.sched_getaffinity(0))}
+            "cpus_allowed": len(os.sched_getaffinity(0)), "cpu_quota_cores": quota}
 
 
 def cpu_cg(grid, seconds, ctx=None):
@@ -238,7 +247,11 @@ def cpu_cg(grid, seconds, ctx=None):
     import kryst_amd as K
     from oracle import oracle as O
     info = cpu_info()
+    # "all the CPUs this process may use": the affinity mask, cut to the cgroup's CPU bandwidth when that is smaller (256 threads on a quota of 16
+    # CPUs are throttled to 16 CPUs' worth of time and thrash: round 5 measured 0.49 it/s that way against 4.4 on 16 threads)
     cores_all = info["cpus_allowed"]
+    if info.get("cpu_quota_cores"):
+        cores_all = max(1, min(cores_all, int(info["cpu_quota_cores"] + 0.999)))
     T, V, F = K.reduce_spec()
     rp, ci, va = K.host_stencil7(grid, "poisson")
     a = O.Csr(grid ** 3, grid ** 3, rp, ci, va, check=False)
@@ -265,9 +278,12 @@ def cpu_cg(grid, seconds, ctx=None):
     if cores_all > t16:
         r_all, dt_all = run(cores_all, seconds / 2)
         out["value_all_cores"] = r_all.iterations / dt_all
-        sample += f"; {r_all.iterations} iterations in {dt_all:.1f} s on all {cores_all} allowed CPUs"
+        sample += f"; {r_all.iterations} iterations in {dt_all:.1f} s on all {cores_all} usable CPUs"
     else:
         out["value_all_cores"] = out["value_16_threads"]
+        if info.get("cpu_quota_cores") and info["cpus_allowed"] > cores_all:
+            sample += (f"; the process is allowed on {info['cpus_allowed']} CPUs but its cgroup grants {info['cpu_quota_cores']:g} CPUs of time (cpu.max): "
+                       f"{cores_all} threads ARE all the cores it can use")
     best_all = out["value_all_cores"] > out["value_16_threads"]
     out["value"], out["cores"] = (out["value_all_cores"], cores_all) if best_all else (out["value_16_threads"], t16)
     out["sample"] = sample + f"; `value` = the faster figure ({out['cores']} threads)"
