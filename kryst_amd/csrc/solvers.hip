@@ -360,11 +360,6 @@ inline int32_t launch_x_batch(kryst_ctx_t ctx, DevState* st, const std::vector<d
 inline int cg_x_batch(bool pcg) {
     return std::max(1, std::min(8, env_int("KRYST_CG_X_BATCH", pcg ? 7 : 8)));
 }
-// ... and in the UNFUSED deferred form (every operator form, every rank of a partition) the same ring is available: the direction pass writes
-// p_new = z + beta p_old out of place (CgDirectionRingOp: 2 reads + 1 write instead of 3 + 2) and XBatchOp pays x -- 34 instead of 40 bytes per row
-// and iteration.  MEASURED AND OFF BY DEFAULT (profiles/r05/cg_ring_unfused_ab.jsonl): 192^3 .. 384^3 run 2-7 % SLOWER (the in-place direction vector
-// is what the 256 MiB Infinity Cache hands from the direction pass to the SpMV; nine ring slots defeat that), 512^3 on plain CSR +-1 %, 64^3 / 128^3
-// +3 %.  KRYST_CG_X_BATCH = m > 1 turns it on (tests do).
 // the ring costs xb - 1 work vectors more than the two alternating direction vectors: only where the device has the room (what the context's
 // arena already holds counts as room)
 inline int ring_if_it_fits(kryst_ctx_t ctx, int64_t n, int xb, int work_vectors) {
@@ -374,6 +369,11 @@ inline int ring_if_it_fits(kryst_ctx_t ctx, int64_t n, int xb, int work_vectors)
     const size_t need = padded_bytes(n) * (size_t)(work_vectors + 2);
     return need <= ctx->arena_bytes || need <= free_b + ctx->arena_bytes ? xb : 1;
 }
+// ... and in the UNFUSED deferred form (every operator form, every rank of a partition) the same ring is available: the direction pass writes
+// p_new = z + beta p_old out of place (CgDirectionRingOp: 2 reads + 1 write instead of 3 + 2) and XBatchOp pays x -- 34 instead of 40 bytes per row
+// and iteration.  MEASURED AND OFF BY DEFAULT (profiles/r05/cg_ring_unfused_ab.jsonl): 192^3 .. 384^3 run 2-7 % SLOWER (the in-place direction vector
+// is what the 256 MiB Infinity Cache hands from the direction pass to the SpMV; nine ring slots defeat that), 512^3 on plain CSR +-1 %, 64^3 / 128^3
+// +3 %.  KRYST_CG_X_BATCH = m > 1 turns it on (tests do).
 inline int cg_x_batch_unfused() {
     return std::max(1, std::min(8, env_int("KRYST_CG_X_BATCH", 1)));
 }
