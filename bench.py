@@ -18,11 +18,15 @@ What the line holds (every `frac` is bytes the named kernel really moves / its H
   value             CG iterations/s with the operator in its default (most compact lossless) storage form
   value_sec8d       the same K iterations with KRYST_SPMV_COMPRESS=0 (= value_plain_csr): the 12-bytes-per-entry CSR arrays of SURVEY 8(d) are streamed,
                     which is what every matrix that is not a constant-coefficient stencil gets -- the figure comparable to north_star
-  roofline          the SpMV kernel of the default form, priced at the bytes IT streams (PMC `traffic` beside it -- at N = 1 measured by this very command,
-                    two rocprofv3 --pmc passes per form in child processes).  Inside it:
+  roofline          the DOMINANT kernel of the timed loop, priced at the bytes IT streams, timed inside the solver's iterations, PMC `traffic` of exactly that
+                    kernel beside it (at N = 1 measured by this very command: two rocprofv3 --pmc passes in child processes).  At 512^3 on one GPU that is
+                    spmv_pattern_fuse_kernel (direction pass + SpMV + (p,Ap) partials in one launch, x updated in batches: 34 bytes per row); otherwise the
+                    SpMV kernel of the default storage form.  Inside it:
                       roofline.sec8d                 the plain-CSR kernel on SURVEY 8(d)'s bytes (north_star's "% of HBM roofline on CSR SpMV"), its traffic
                                                      skeleton on the same arrays, the homes tried for the arrays, value_sec8d
-                      roofline.fused_direction_spmv  the kernel the timed loop really launches when CG's direction pass rides inside the SpMV
+                      roofline.x_batch               the pass that pays x += alpha_i p_i for a batch of iterations
+                      roofline.spmv_alone            (fused loop only) the staged-window SpMV kernel of the default form on its own, as earlier rounds reported it
+                      roofline.fused_direction_spmv  (fused loop only) the top-level figures again under the key this round introduced first
   roofline_blas1    the vector kernels of a CG iteration, timed INSIDE the solver's iterations (phase run)
   gmres30_jacobi    GMRES(30) Left + Jacobi on the same operator and partition: iterations/s of solves of exactly 60 iterations (north_star: CG / GMRES at 1-8 GPUs)
   phase_ms          device time per iteration by phase (hipEvents between the phases, a separate short run), per rank
@@ -342,7 +346,7 @@ def cpu_baseline(grid, base256, ctx=None):
 
 # ---------------------------------------------------------------------------------------------------------------- GPU side
 _LIVE_TRAFFIC = {}
-LIVE_FORMS = {(512, "default"), (512, "plain")}          # measured in THIS run (about 7 s per pass); the other sizes / forms come from profiles/
+LIVE_FORMS = {(512, "default"), (512, "plain"), (512, "fused")}     # measured in THIS run (about 7 s per pass); the other sizes / forms come from profiles/
 
 
 def live_traffic(grid, form):
@@ -368,10 +372,13 @@ def live_traffic(grid, form):
             if form == "plain":
                 env["KRYST_SPMV_COMPRESS"] = "0"
             means = {}
+            # form "fused": the kernel the timed CG loop launches when the direction pass rides inside the SpMV -- a CG session of 26 iterations
+            # (tools/cg_only.py; it ends with the DotOp launches the read side is calibrated on, like spmv_only.py)
+            prog = ([os.path.join(ROOT, "tools", "cg_only.py"), str(grid), "26"] if form == "fused" else
+                    [os.path.join(ROOT, "tools", "spmv_only.py"), str(grid), "5", "1", "varcoef" if form == "varcoef" else "poisson"])
             for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 d = os.path.join(tmp, counter)
-                r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
-                                    os.path.join(ROOT, "tools", "spmv_only.py"), str(grid), "5", "1", "varcoef" if form == "varcoef" else "poisson"],
+                r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable] + prog,
                                    cwd="/tmp", env=env, capture_output=True, timeout=90)
                 if r.returncode != 0:
                     raise RuntimeError(f"rocprofv3 --pmc {counter} failed")
@@ -380,7 +387,7 @@ def live_traffic(grid, form):
                     if row["Counter_Name"] == counter:
                         acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
                 means[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
-            spmv = [k for k in means["FETCH_SIZE"] if "spmv" in k and "<1," in k][0]
+            spmv = [k for k in means["FETCH_SIZE"] if ("spmv_pattern_fuse_kernel" in k if form == "fused" else "spmv" in k and "<1," in k)][0]
             dotk = [k for k in means["FETCH_SIZE"] if "DotOp" in k][0]
             cal = (2 * grid ** 3 * 8) / (means["FETCH_SIZE"][dotk] * 1024.0)
             res = means["FETCH_SIZE"][spmv] * 1024.0 * cal + means["WRITE_SIZE"][spmv] * 1024.0
@@ -1174,6 +1181,24 @@ def rank_main(args, group, rank, world, dev, grid):
     out = headline(m["dt"], m["stats"], m["enc"])
     roof = m["roofline"]
     rc = m["roofline_csr"]
+    fb = roof.get("fused_direction_spmv")
+    if fb:
+        # The timed loop's dominant kernel is the FUSED kernel (direction pass + SpMV + (p,Ap) partials; the staged-window SpMV alone is not
+        # launched by the loop at all): it is the top-level block, timed INSIDE the solver's iterations, with the HBM traffic of exactly that
+        # kernel from two rocprofv3 --pmc passes over a CG session of this command (world == 1).  The SpMV-alone block moves to `spmv_alone`.
+        alone = {k: v for k, v in roof.items() if k != "fused_direction_spmv"}
+        top = dict(fb)
+        if world == 1:
+            tr = live_traffic(grid, "fused")
+            if tr:
+                top["traffic"] = tr
+                top["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over a CG session (tools/cg_only.py) run by this command, read side calibrated on DotOp"
+                top["frac_traffic"] = tr / (top["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        top.setdefault("traffic", None)
+        top["share_of_iteration"] = top["ms_per_launch"] / (m["dt"] / args.steps * 1e3)
+        top["spmv_alone"] = alone
+        top["fused_direction_spmv"] = {k: v for k, v in fb.items()}          # (the same figures under the round's earlier key)
+        roof = top
     # SURVEY 8(d)'s own pair INSIDE the block the driver keeps: the plain-CSR kernel (the only one that moves 8(d)'s 12 nnz + 4 (n + 1) + 16 n
     # bytes) priced at those bytes, and the iterations/s of the same K iterations with that kernel (`value_sec8d`)
     roof["sec8d"] = {"kernel": rc["kernel"], "frac": rc["frac"], "achieved": rc["achieved"], "unit": "GB/s", "peak": HBM_PEAK_GBS,
