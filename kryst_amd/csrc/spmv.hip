@@ -1036,7 +1036,8 @@ static int spmv_blocks_per_cu() { return env_int("KRYST_SPMV_BLOCKS_PER_CU", 0);
 // 128^3 -19 %; 8: +1.3 / -4.5 % at 512^3 / 256^3; 32: -2 / -21 %).  The FUSED kernel reads its far operands (rows +- one plane) from TWO vectors:
 // when a grid plane (far_hi rows) is a whole number of groups per XCD -- G = plane / (8 T tiles) -- the same (i, j) strip of every plane lands on
 // the same XCD, whose L2 then streams those rows itself: 512^3 fused CG, G = 16 against 4: 613 against 596 it/s (three interleaved rounds,
-// tools/cg_fuse_knobs.py).  The plain staged kernel does not care at 512^3 (0.500-0.508 ms for G = 1 .. 16, tools/stage_group_ab.py) and loses
+// tools/cg_fuse_knobs.py).  (Walking SUB-strips of R runs plane by plane -- resident runs then neighbours in k -- was measured and loses: R = 1 / 2 / 4 /
+// 8 / 16: 563 / 578 / 590 / 603 / 616 it/s; a run that jumps a plane every few runs costs DRAM page locality more than the far operands' L2 hits give.)  The plain staged kernel does not care at 512^3 (0.500-0.508 ms for G = 1 .. 16, tools/stage_group_ab.py) and loses
 // with large groups at 384^3 (0.26 against 0.21 ms), so it keeps 4.
 static int stage_group_default(kryst_csr_t a, int64_t nruns, int T, bool fused) {
     if (nruns < 2048) return 1;
