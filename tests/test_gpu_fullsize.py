@@ -271,6 +271,33 @@ def test_config4_jacobi_pcg_512_cubed_on_one_gpu(ctx):
 
 
 @pytest.mark.gpu
+def test_cg_forms_bit_identical_at_512_cubed(ctx, monkeypatch):
+    """Round 5: at 512^3 CG / PCG take, by default, the direction pass inside the staged-window SpMV (spmv_pattern_fuse_kernel) with x updated in
+    batches of 8 / 7 iterations from a ring of direction vectors (XBatchOp) -- a form the small parity cases only reach through environment knobs.
+    Here the DEFAULT path at the size that selects it, for an iteration count that ends inside a batch: residual history and x must be bit for bit
+    those of the unfused form (KRYST_CG_FUSE_P=0), which the oracle pins at 256^3 and in bench.py's parity_at_size, and of a second default run."""
+    grid, iters = 512, 43
+    a = K.CsrMatrix.stencil7(grid, "poisson", ctx=ctx)
+    n = a.nrows()
+    b = a.spmv(ctx.vec(n).fill(1.0))
+    pcj = K.Jacobi().setup(a)
+    for cls, pc in ((K.CgSolver, None), (K.PcgSolver, pcj)):
+        runs = []
+        for fuse in ("0", None, None):
+            if fuse is None:
+                monkeypatch.delenv("KRYST_CG_FUSE_P", raising=False)
+            else:
+                monkeypatch.setenv("KRYST_CG_FUSE_P", fuse)
+            x = ctx.vec(n)
+            s = cls(0.0, iters)
+            st = s.solve(a, pc, b, x)
+            runs.append((st.iterations, np.array(s.residual_history), x.to_host()))
+        assert runs[0][0] == iters
+        for r in runs[1:]:
+            assert r[0] == runs[0][0] and np.array_equal(r[1], runs[0][1]) and np.array_equal(r[2], runs[0][2]), cls.__name__
+
+
+@pytest.mark.gpu
 def test_sizes_at_the_index_limits(ctx, monkeypatch):
     """648^3 = 272 M rows is beyond the CSR-P16 kernel's 32-bit byte offsets (2^28 rows): the operator must fall back to CSR-D16 and say
     so, and every form must still give the exact row sums of the Poisson operator (A 1 = number of missing neighbours) and agree bit for
