@@ -50,8 +50,11 @@ def _compare(name, gpu_hist, gpu_stats, gpu_x, ref_tiled, ref_serial, serial_tol
     return dev
 
 
-def test_config2_cg_256_cubed_full_history_equals_the_oracle(ctx):
-    """BASELINE config 2 as written: unpreconditioned CG on 256^3 Poisson, tol 1e-8, max 2000 (cg.rs:114-288) -- all ~580 iterations."""
+def test_config2_cg_256_cubed_full_history_equals_the_oracle(ctx, monkeypatch):
+    """BASELINE config 2 as written: unpreconditioned CG on 256^3 Poisson, tol 1e-8, max 2000 (cg.rs:114-288) -- all ~580 iterations.
+    Then the SAME solve through the form bench.py's 512^3 headline takes (round 5: the direction pass inside the staged-window SpMV, x updated
+    in batches of 8 iterations from a ring of direction vectors), forced here at 256^3: the same iterations, history and x -- the convergence
+    falls inside a batch (581 = 72 x 8 + 5)."""
     O, a, b = _oracle_system("poisson")
     T, V, F = K.reduce_spec()
     ga = K.CsrMatrix.stencil7(N, "poisson", ctx=ctx)
@@ -64,6 +67,11 @@ def test_config2_cg_256_cubed_full_history_equals_the_oracle(ctx):
     ref_t = O.solve("cg", a, b, tol=1e-8, max_iters=2000, rs=O.Reduce.tiled(T, V, F))
     ref_s = O.solve("cg", a, b, tol=1e-8, max_iters=2000, rs=O.Reduce.serial())
     _compare("config 2: CG 256^3 to 1e-8", s.residual_history, st, x.to_host(), ref_t, ref_s, SERIAL_TOL)
+    monkeypatch.setenv("KRYST_CG_FUSE_P", "1")
+    s2 = K.CgSolver(1e-8, 2000)
+    x2 = ctx.vec(N ** 3)
+    st2 = s2.solve(ga, None, gb, x2)
+    _compare("config 2 through the fused SpMV with x in batches", s2.residual_history, st2, x2.to_host(), ref_t, ref_s, SERIAL_TOL)
 
 
 def test_config4_jacobi_pcg_256_cubed_hundred_iterations_equal_the_oracle(ctx):
