@@ -123,3 +123,28 @@ def test_plain_bench_gmres_headline_two_ranks():
     d = run_bench_plain(2, 1, 32, solver="gmres", extra=("--gmres-steps", "0"))
     assert d["metric"] == "gmres_iterations_per_sec" and d["steps"] == 20 and d["value"] > 0 and d["n_gpus"] == 2
     assert d["config"]["workload"] == "gmres30_left_jacobi_poisson7_32^3"
+
+
+@pytest.mark.gpu
+def test_bench_one_gpu_line_with_the_fused_loop():
+    """The shape of the N = 1 line when the timed loop takes the fused form (at 512^3 by default; forced here on a 64^3 grid through
+    KRYST_CG_FUSE_MIN_BYTES): the top-level `roofline` is the fused kernel -- the dominant kernel of the timed loop, timed inside the solver --
+    with the batch pass, the SpMV-alone block and SURVEY 8(d)'s pair inside it; one JSON line on stdout; the driver's own arguments."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(KRYST_CG_FUSE_MIN_BYTES="1", KRYST_BENCH_LIVE_TRAFFIC="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--grid", "64", "--no-256", "--no-configs",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    roof = d["roofline"]
+    assert "spmv_pattern_fuse_kernel" in roof["kernel"] and roof["bound"] == "hbm" and 0 < roof["frac"] <= 1.0 and roof["peak"] == 8000.0
+    assert roof["bytes_per_launch"] == 34 * 64 ** 3 and roof["traffic"] is None and 0 < roof["share_of_iteration"] < 1
+    xb = roof["x_batch"]
+    assert xb["iterations_per_launch"] == 8 and xb["bytes_per_launch"] == 10 * 8 * 64 ** 3 and xb["ms_per_launch"] > 0
+    assert "spmv_pattern_stage_kernel" in roof["spmv_alone"]["kernel"] and 0 < roof["sec8d"]["frac"] <= 1.0
+    assert "blas1_xbatch" in d["phase_ms"][0] and "blas1_direction" not in d["phase_ms"][0]
+    assert len(d["timing"]["batch_ms"]) == 3
