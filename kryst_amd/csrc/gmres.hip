@@ -73,11 +73,15 @@ struct GateCycle {
     const DevState* st; const GmState* gs;
     __device__ __forceinline__ bool skip() const { return st->done || gs->cyc_stop; }
 };
-// the Gram-Schmidt links (3 reads + 1 write + a reduction per tile) want 6 workgroups per CU: GMRES(30) 256^3 244 -> 309 it/s with 4
-// (round 1), 347.7 -> 356.5 with 6 (round 3, tools/solver_ab.py: 2 / 3 / 4 / 5 / 6 / 8 per CU = 250 / 319 / 348 / 356 / 357 / 339 it/s)
+// the Gram-Schmidt links (3 reads + 1 write + a reduction per tile) want 6 workgroups per CU WHILE z lives in the memory-side cache: GMRES(30)
+// 256^3 244 -> 309 it/s with 4 (round 1), 347.7 -> 356.5 with 6 (round 3, tools/solver_ab.py: 2 / 3 / 4 / 5 / 6 / 8 per CU = 250 / 319 / 348 / 356 /
+// 357 / 339 it/s).  Beyond the cache every word comes from HBM and the streams' rule holds (ew.h: a narrow moving window keeps DRAM pages open) --
+// round 5, tools/fgmres_only.py: 512^3 38.0 / 40.1 / 41.0 / 33.2 it/s with 6 / 4 / 3 / 2 per CU, 384^3 94.9 / 97.6 / 97.8 with 6 / 4 / 3,
+// 320^3 165.3 / 169.6 / 166.3: 6 in the cache regime, 3 for vectors beyond 768 MiB, 4 in between.
 template <class Op>
 static int32_t launch_iter(kryst_ctx_t ctx, const Op& op, int64_t n, const DevState* st, const GmState* gs) {
-    static const int bpc = [] { const char* e = getenv("KRYST_GMRES_BLOCKS_PER_CU"); return e ? atoi(e) : 6; }();
+    static const int forced = [] { const char* e = getenv("KRYST_GMRES_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
+    const int bpc = forced > 0 ? forced : keep_in_cache(n) ? 6 : n * 8 > (768ll << 20) ? 3 : 4;
     return launch_ew_gated(ctx, op, n, GateCycle{st, gs}, bpc);
 }
 // "gate" kernel: copies done||cyc_stop into one int so that launch_spmv / pc_apply_dev can use their `done` hook
