@@ -61,6 +61,7 @@ struct MultiAxpyOp {                 // w = w - h_k v_k, k ascending (:223-228 /
 template <bool KEEP>
 struct RefineLinkOp {                // if |corr| > 1e-10: w = w - corr v_i (:242-246); partial (w, next) or (w, w)
     static constexpr int NQ = 1; static constexpr const char* TAG = "RefineLink";
+    static constexpr int BPC = 6;    // round 5 (tools/fgmres_only.py, FGMRES(30) with Orthog::Modified): 2 / 3 / 4 / 5 / 6 / 8 workgroups per CU = 48 / 55 / 60 / 64 / 66 / 66 it/s at 512^3, 400 / 460 / 489 / - / 526 at 256^3
     const FgState* fs; const double* vi; const double* next; double* w;
     __device__ __forceinline__ void pair(int64_t i, bool in0, bool in1, double (&acc)[1]) const {
         d2 ww = ld2_sel<KEEP>(w, i);
